@@ -1,0 +1,142 @@
+"""Seeded synthetic inputs for tests, bench and the golden-vector generator.
+
+Everything here is generated on the CPU from `torch.Generator().manual_seed(...)`
+so that the container (where the reference can be imported to produce golden
+outputs) and the GPU box (where only this repo exists) build bit-identical
+inputs.  Conventions follow SURVEY.md §8(d):
+
+* tri-planes  clamp(0.3*randn, -1, 1), shape (1, 3, 9, H, W)
+  (reference init/clamp: recon_NeRF/lib/renderer.py:27, run_nerf_batch.py:271-272)
+* render MLP  nn.Linear-style U(-1/sqrt(fan_in), 1/sqrt(fan_in)) per tensor
+  (state_dict names of human_diffusion/NeRF/renderer.py:29-39)
+* cameras     pinhole orbit, un-normalised ray directions
+  (human_diffusion/SynBodyView_datasets.py:316-329), near/far from a slab test
+  against the bounds padded by 0.01, rays that miss get near=0, far=1
+  (SynBodyView_datasets.py:370-403, 428-433)
+"""
+import math
+
+import numpy as np
+import torch
+
+RENDER_MLP_SHAPES = [
+    ("pts_linears.0.weight", (128, 27)),
+    ("pts_linears.0.bias", (128,)),
+    ("pts_linears.1.weight", (128, 128)),
+    ("pts_linears.1.bias", (128,)),
+    ("pts_linears.2.weight", (128, 155)),
+    ("pts_linears.2.bias", (128,)),
+    ("feature_linear.weight", (128, 128)),
+    ("feature_linear.bias", (128,)),
+    ("alpha_linear.weight", (1, 128)),
+    ("alpha_linear.bias", (1,)),
+    ("views_linear.weight", (64, 155)),
+    ("views_linear.bias", (64,)),
+    ("rgb_linear.weight", (3, 64)),
+    ("rgb_linear.bias", (3,)),
+]
+
+WORLD_BOUNDS = [[-1.0, -1.1, -1.0], [1.0, 1.1, 1.0]]
+
+
+def _gen(seed):
+    g = torch.Generator()
+    g.manual_seed(int(seed))
+    return g
+
+
+def render_mlp_state(seed=3, gain=1.0):
+    """Deterministic render-MLP parameters keyed like the reference state_dict."""
+    out = {}
+    fan_in = {}
+    for name, shape in RENDER_MLP_SHAPES:
+        stem = name.rsplit(".", 1)[0]
+        if name.endswith("weight"):
+            fan_in[stem] = shape[1]
+    for i, (name, shape) in enumerate(RENDER_MLP_SHAPES):
+        stem = name.rsplit(".", 1)[0]
+        bound = gain / math.sqrt(fan_in[stem])
+        t = (torch.rand(shape, generator=_gen(seed * 1000 + i)) * 2 - 1) * bound
+        out[name] = t.float()
+    return out
+
+
+def triplane(seed=11, H=256, W=256, sigma=0.3, batch=1):
+    x = torch.randn((batch, 3, 9, H, W), generator=_gen(seed)) * sigma
+    return x.clamp_(-1, 1).float()
+
+
+def importance_u(n_rays, n_importance, seed=5):
+    return torch.rand((n_rays, n_importance), generator=_gen(seed)).float()
+
+
+def state_from_shapes(keys_shapes, seed, std=0.05, norm_jitter=0.1):
+    """Deterministic tensors for an arbitrary (name, shape) list.
+
+    Used for UNet parity: the weights never travel as fixtures, only the key
+    list does; both sides rebuild them from the seed.  Biases and weights are
+    N(0, std^2) scaled by 1/sqrt(fan_in) for matrices/convs so activations stay
+    O(1); GroupNorm affine gets 1 + jitter / jitter.
+    """
+    out = {}
+    for i, (name, shape) in enumerate(keys_shapes):
+        g = _gen(seed * 100003 + i)
+        shape = tuple(shape)
+        t = torch.randn(shape, generator=g)
+        if len(shape) >= 2:
+            fan = 1
+            for d in shape[1:]:
+                fan *= d
+            t = t * (1.0 / math.sqrt(fan))
+        elif "norm" in name or name.endswith("in_layers.0.weight") or name.endswith("out_layers.0.weight") \
+                or name.endswith("in_layers.0.bias") or name.endswith("out_layers.0.bias") \
+                or name.startswith("out.0."):
+            t = t * norm_jitter + (1.0 if name.endswith("weight") else 0.0)
+        else:
+            t = t * std
+        out[name] = t.float()
+    return out
+
+
+def orbit_camera(view, n_views, H, W, radius=3.0, focal_mult=1.1):
+    """Pinhole camera looking at the origin from azimuth 2*pi*view/n_views."""
+    az = 2.0 * math.pi * view / n_views
+    cam = np.array([radius * math.sin(az), 0.0, radius * math.cos(az)], dtype=np.float64)
+    fwd = -cam / np.linalg.norm(cam)
+    up = np.array([0.0, -1.0, 0.0])  # image y grows downwards
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    # camera-to-world rotation with columns (x=right, y=down, z=fwd)
+    c2w = np.stack([right, down, fwd], axis=1)
+    f = focal_mult * W
+    K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1.0]])
+    return K, c2w, cam
+
+
+def orbit_rays(view, n_views, H, W, bounds=None):
+    """rays_o, rays_d (H*W,3), near, far (H*W,) as float32 torch tensors."""
+    bounds = np.asarray(WORLD_BOUNDS if bounds is None else bounds, dtype=np.float64)
+    K, c2w, cam = orbit_camera(view, n_views, H, W)
+    i, j = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64), indexing="xy")
+    pix = np.stack([i, j, np.ones_like(i)], axis=-1).reshape(-1, 3)
+    d_cam = pix @ np.linalg.inv(K).T
+    rays_d = d_cam @ c2w.T  # not normalised, like the reference
+    rays_o = np.broadcast_to(cam, rays_d.shape).copy()
+    near, far = near_far_from_bounds(bounds, rays_o, rays_d)
+    return (torch.from_numpy(rays_o).float(), torch.from_numpy(rays_d).float(),
+            torch.from_numpy(near).float(), torch.from_numpy(far).float())
+
+
+def near_far_from_bounds(bounds, rays_o, rays_d, pad=0.01):
+    lo = bounds[0] - pad
+    hi = bounds[1] + pad
+    d = np.where(rays_d == 0.0, 1e-8, rays_d)
+    t0 = (lo[None] - rays_o) / d
+    t1 = (hi[None] - rays_o) / d
+    tmin = np.minimum(t0, t1).max(axis=1)
+    tmax = np.maximum(t0, t1).min(axis=1)
+    hit = (tmax > tmin) & (tmax > 0)
+    near = np.where(hit, np.maximum(tmin, 0.0), 0.0)
+    far = np.where(hit, tmax, 1.0)
+    return near, far
