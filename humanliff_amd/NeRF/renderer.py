@@ -1,0 +1,190 @@
+"""Drop-in `Renderer` / `render` for the tri-plane NeRF decode path, backed by the HIP kernels.
+
+Mirrors (same names, argument order and return structure):
+    Renderer.__init__   human_diffusion/NeRF/renderer.py:14-50
+    Renderer.render     human_diffusion/NeRF/renderer.py:234-281   (recon twin: recon_NeRF/lib/renderer.py:244)
+    render              human_diffusion/scripts/triplane_sample_layered.py:250-288
+                        (recon twin: recon_NeRF/run_nerf_batch.py:29-67; "render_rays" in BASELINE.json)
+
+Scope: use_canonical_space=False, test (inference) mode, triplane_ch=27 - the shipped SynBody
+sampling configuration.  Everything numerical happens in libhumanliff_hip.so; there is no
+PyTorch fallback (a missing library or a CPU tensor raises).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .fields import PositionalEncoding
+
+_MLP_ORDER = ("pts_linears.0", "pts_linears.1", "pts_linears.2", "feature_linear", "alpha_linear",
+              "views_linear", "rgb_linear")
+
+
+class Renderer(nn.Module):
+    def __init__(self, use_canonical_space=True, num_instances=1, triplane_dim=256, triplane_ch=18,
+                 smpl_type='smpl', test=False):
+        super().__init__()
+        self.use_canonical_space = use_canonical_space
+        self.num_instances = num_instances
+        self.triplane_dim = triplane_dim
+        self.triplane_ch = triplane_ch
+        self.test = test
+        self.smpl_type = smpl_type
+        self.view_enc = PositionalEncoding(num_freqs=4)
+        d_in, d_hidden, n_layers = triplane_ch, 128, 2
+        self.skips = [n_layers / 2]
+        widths = [d_in] + [d_hidden + d_in if i in self.skips else d_hidden for i in range(n_layers)]
+        self.pts_linears = nn.ModuleList([nn.Linear(w, d_hidden) for w in widths])
+        self.feature_linear = nn.Linear(d_hidden, d_hidden)
+        self.alpha_linear = nn.Linear(d_hidden, 1)
+        self.views_linear = nn.Linear(d_hidden + 27, d_hidden // 2)
+        self.rgb_linear = nn.Linear(d_hidden // 2, 3)
+        # The reference also loads SMPL(-X) assets here (renderer.py:41-50); they are only used by the
+        # canonical-space deformation, which is outside this build's scope.
+        self._packed = None
+        self._packed_key = None
+        self._planes_cache = {}
+        self._ws = None
+
+    # ---- packing caches ------------------------------------------------------------------------
+    def _mlp_tensors(self):
+        sd = dict(self.named_parameters())
+        out = []
+        for stem in _MLP_ORDER:
+            out += [sd[stem + ".weight"], sd[stem + ".bias"]]
+        return out
+
+    def _packed_mlp(self, device):
+        ts = self._mlp_tensors()
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (str(device),)
+        if self._packed is None or self._packed_key != key:
+            for t in ts:
+                if not t.is_cuda:
+                    raise RuntimeError("Renderer parameters must live on the GPU (call .to('cuda')); "
+                                       "humanliff_amd has no CPU path")
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise RuntimeError("Renderer parameters must be contiguous fp32")
+            L = _lib.lib()
+            params = _lib.RenderMlpParams(*[C.c_void_p(t.data_ptr()) for t in ts])
+            buf = torch.empty(L.hl_render_mlp_packed_bytes() // 4, dtype=torch.float32, device=device)
+            _lib.check(L.hl_render_mlp_pack(C.byref(params), _lib.ptr(buf), _lib.stream_ptr()), "hl_render_mlp_pack")
+            self._packed, self._packed_key = buf, key
+        return self._packed
+
+    def _packed_planes(self, planes):
+        """planes (3,9,H,W) fp32 device view of one subject -> packed texel-major copy (cached)."""
+        key = (planes.data_ptr(), planes._version, tuple(planes.shape))
+        hit = self._planes_cache.get(key)
+        if hit is None:
+            L = _lib.lib()
+            H, W = planes.shape[-2:]
+            src = planes.contiguous()
+            buf = torch.empty(L.hl_planes_packed_bytes(H, W) // 4, dtype=torch.float32, device=planes.device)
+            _lib.check(L.hl_planes_pack(_lib.ptr(src), H, W, _lib.ptr(buf), _lib.stream_ptr()), "hl_planes_pack")
+            if len(self._planes_cache) > 8:
+                self._planes_cache.clear()
+            self._planes_cache[key] = hit = buf
+        return hit
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() * 4 < nbytes or self._ws.device != device:
+            self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        return self._ws
+
+    # ---- reference API ---------------------------------------------------------------------------
+    def render(self, tp_input, world_pts, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance=128,
+               white_bkgd=False, *, n_samples=None, u=None):
+        """Same contract as the reference's Renderer.render; returns the dict
+        {'rgb_map','acc_map','normal_map','depth_map'} of detached tensors.
+
+        world_pts is accepted for signature compatibility and not read: the kernel forms
+        rays_o + rays_d * z_vals itself, which is how every reference caller builds world_pts
+        (triplane_sample_layered.py:277).  Extensions (keyword-only): z_vals=None with n_samples
+        lets the kernel generate the linspace depths; u (bs*R, n_importance) supplies sample_pdf's
+        uniforms, otherwise they are drawn exactly like the reference does - torch.rand on the
+        CPU generator, then copied to the device (renderer.py:545).
+        """
+        if self.use_canonical_space:
+            raise NotImplementedError("use_canonical_space=True (SMPL inverse-LBS) is not built; "
+                                      "see DESIGN.md 'out of scope'")
+        if self.triplane_ch != 27:
+            raise NotImplementedError("the HIP ray-march kernel is specialised for triplane_ch=27")
+        assert tri_planes.dim() == 5 and tri_planes.shape[1] == 3 and tri_planes.shape[2] == 9, \
+            "tri_planes must be (bs, 3, 9, H, W)"
+        bs, _, _, H, W = tri_planes.shape
+        dev = tri_planes.device
+        rays_o = rays_o.reshape(bs, -1, 3)
+        rays_d = rays_d.reshape(bs, -1, 3)
+        R = rays_o.shape[1]
+        near = near.reshape(bs, R)
+        far = far.reshape(bs, R)
+        if z_vals is not None:
+            assert z_vals.shape[:2] == (bs, R)
+            n_samples = z_vals.shape[2]
+        assert n_samples is not None and n_samples >= 2
+        bounds = tp_input['world_bounds'].reshape(bs, 2, 3)
+        if n_importance > 0:
+            assert n_importance == n_samples, \
+                "the reference reshapes coarse densities to n_importance (renderer.py:250): counts must match"
+            if u is None:
+                u = torch.rand([bs * R, n_importance]).to(dev)
+            u = u.reshape(bs, R, n_importance)
+        L = _lib.lib()
+        packed = self._packed_mlp(dev)
+        ws = self._workspace(L.hl_render_workspace_bytes(R, n_samples, n_importance), dev)
+        rgb = torch.empty((bs, R, 3), dtype=torch.float32, device=dev)
+        acc = torch.empty((bs, R), dtype=torch.float32, device=dev)
+        depth = torch.empty((bs, R), dtype=torch.float32, device=dev)
+        flags = _lib.HL_RENDER_NORMALIZE_DEPTH | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0)
+        f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+        for b in range(bs):
+            pp = self._packed_planes(tri_planes[b])
+            zb = f32(z_vals[b]) if z_vals is not None else None
+            ub = f32(u[b]) if n_importance > 0 else None
+            ro, rd, nr, fr, bd = f32(rays_o[b]), f32(rays_d[b]), f32(near[b]), f32(far[b]), f32(bounds[b])
+            _lib.check(L.hl_render_rays(
+                _lib.ptr(packed), _lib.ptr(pp), H, W, _lib.ptr(bd), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(nr),
+                _lib.ptr(fr), _lib.ptr(zb), _lib.ptr(ub), R, n_samples, n_importance, flags,
+                _lib.ptr(rgb[b]), _lib.ptr(acc[b]), _lib.ptr(depth[b]), _lib.ptr(ws), _lib.stream_ptr()),
+                "hl_render_rays")
+        # normal_map aliases rgb_map in the reference (renderer.py:228)
+        return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
+
+
+def render(chunk=1024 * 32, rays_o=None, rays_d=None, near=0., far=1., tri_planes=None, tp_input=None, renderer=None,
+           n_samples=128, perturb=0., n_importance=0, white_bkgd=False):
+    """Render rays in chunks; returns [rgb_map, acc_map, normal_map, depth_map] like the reference.
+
+    For perturb == 0 the depths are generated inside the kernel (no (R, n_samples, 3) point tensor
+    is materialised); for perturb > 0 the stratified jitter is drawn with torch.rand on the device
+    exactly where the reference draws it and the depths are handed to the kernel.
+    """
+    batch_size, n_rays, _ = rays_d.shape
+    rays_o = rays_o.reshape(batch_size, -1, 3)
+    rays_d = rays_d.reshape(batch_size, -1, 3)
+    near = near.reshape(batch_size, -1, 1)
+    far = far.reshape(batch_size, -1, 1)
+    # the recon twin passes a DDP/DataParallel-wrapped renderer (run_nerf_batch.py:58)
+    core = renderer.module if hasattr(renderer, "module") else renderer
+    outs = {}
+    for i in range(0, rays_o.shape[1], chunk):
+        ro, rd = rays_o[:, i:i + chunk], rays_d[:, i:i + chunk]
+        nr, fr = near[:, i:i + chunk], far[:, i:i + chunk]
+        z = None
+        if perturb > 0.:
+            t_vals = torch.linspace(0., 1., steps=n_samples, device=rays_o.device)
+            z = nr * (1. - t_vals) + fr * t_vals
+            mids = .5 * (z[..., 1:] + z[..., :-1])
+            upper = torch.cat([mids, z[..., -1:]], -1)
+            lower = torch.cat([z[..., :1], mids], -1)
+            z = lower + (upper - lower) * torch.rand(z.shape, device=rays_o.device)
+        ret = core.render(tp_input, None, z, ro, rd, nr, fr, tri_planes, n_importance, white_bkgd,
+                          n_samples=n_samples)
+        for k, v in ret.items():
+            outs.setdefault(k, []).append(v)
+    return [torch.cat(v, 1) for v in outs.values()]
+
+
+render_rays = render

@@ -1,0 +1,84 @@
+"""ctypes binding of libhumanliff_hip.so (the C ABI declared in include/humanliff_hip.h).
+
+There is no fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhumanliff_hip.so")
+
+HL_RENDER_WHITE_BKGD = 1
+HL_RENDER_NORMALIZE_DEPTH = 2
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipCallError(RuntimeError):
+    pass
+
+
+class RenderMlpParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "pts0_w", "pts0_b", "pts1_w", "pts1_b", "pts2_w", "pts2_b", "feat_w", "feat_b",
+        "alpha_w", "alpha_b", "views_w", "views_b", "rgb_w", "rgb_b")]
+
+
+_lib = None
+
+_p, _i, _i64, _u, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/humanliff_hip.h declares
+SIGNATURES = {
+    "hl_version": (_i, []),
+    "hl_last_error": (C.c_char_p, []),
+    "hl_render_mlp_packed_bytes": (_sz, []),
+    "hl_render_mlp_pack": (_i, [C.POINTER(RenderMlpParams), _p, _p]),
+    "hl_planes_packed_bytes": (_sz, [_i, _i]),
+    "hl_planes_pack": (_i, [_p, _i, _i, _p, _p]),
+    "hl_render_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "hl_render_rays": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _u, _p, _p, _p, _p, _p]),
+    "hl_render_coarse": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p]),
+    "hl_render_importance": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _p, _p]),
+    "hl_render_fine": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _u, _p, _p, _p, _p]),
+}
+
+
+def lib():
+    """Load (once) and return the ctypes handle. Raises HipLibraryMissing if it was never built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -m humanliff_amd.build` "
+                "(there is no CPU or PyTorch fallback for the hot paths)")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().hl_last_error()
+        raise HipCallError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int64 CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_cuda, "humanliff_amd kernels need device tensors (no CPU path)"
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

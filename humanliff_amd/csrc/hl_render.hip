@@ -1,0 +1,669 @@
+// Tri-plane NeRF volume renderer for MI355X (gfx950): hand-written HIP, fp32 MFMA.
+//
+// Replaces, for use_canonical_space=False / test mode, the reference's
+//   Renderer.render / render_core / up_sample / NeRF_network   human_diffusion/NeRF/renderer.py:134-281
+//   sample_from_planes / project_onto_planes / sample_pdf       human_diffusion/NeRF/renderer.py:486-563
+//   PositionalEncoding.forward                                  human_diffusion/NeRF/fields.py:45-85
+// (the reference launches ~60 stock PyTorch kernels per chunk and materialises every intermediate).
+//
+// Three launches per ray batch, everything else stays on chip:
+//   k_march<false>  coarse pass: tri-plane gather -> density MLP            -> sigma (R,N)
+//   k_importance    per ray: weights -> inverse CDF with the caller's u -> sort -> z_all (R,2N)
+//   k_march<true>   fine pass:   tri-plane gather -> full MLP -> alpha compositing -> rgb/acc/depth
+//
+// MLP on the matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32, an fmaf chain):
+//   The layer is evaluated TRANSPOSED: D[unit][ray] += W[unit][k] * H[k][ray].  With the 32x32x2
+//   fragment layout the accumulator of lane l holds, for ray (l & 31), the units
+//   (r&3) + 8*(r>>2) + 4*(l>>5) — which is exactly the shape of a B operand (lane l supplies
+//   B[k = l>>5][ray = l&31]) if step r pairs unit u_lo(r) on lanes 0-31 with u_lo(r)+4 on lanes
+//   32-63.  The weights (A operand) are pre-packed in that k order, so activations never leave
+//   the register file between layers: no LDS round trip, no transposes, softplus in place.
+//   One wave owns 32 rays (two lanes per ray: the halves split the 27 features / 27 view
+//   encodings and the hidden units); a workgroup is 8 waves = 256 rays and streams the packed
+//   weights (17 x 16 KB per sample) from L2 through a two-slot LDS ring, one barrier per chunk.
+#include "hl_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// packed layout
+// ---------------------------------------------------------------------------------------------
+constexpr int CHUNK_FLOATS = 4096;  // 16 KB: [tile t][step/4][lane 64][4 steps]
+constexpr int NCH_FULL = 17;
+constexpr int NCH_COARSE = 10;
+constexpr int SMALL_FLOATS = 1024;
+constexpr int PACKED_FLOATS = NCH_FULL * CHUNK_FLOATS + SMALL_FLOATS;
+// offsets inside the small-parameter block (floats); [t][half][16] lane-order tables
+constexpr int SM_B0 = 0, SM_B1 = 128, SM_B2 = 256, SM_BF = 384, SM_BV = 512, SM_AW = 576, SM_RW = 704,
+              SM_AB = 896, SM_RB = 897;
+
+struct ChunkDesc {
+    int w;      // 0 pts0, 1 pts1, 2 pts2, 3 feat, 4 views
+    int ld;     // row length of that weight
+    int col0;   // first input column of this part
+    int kind;   // 0 feature part, 1 hidden part, 2 view-encoding part
+    int base;   // hidden part: first step (k-pair) covered
+    int nt;     // 32-unit output tiles
+    int nsteps; // padded steps in the chunk image
+};
+__constant__ ChunkDesc c_chunks[NCH_FULL] = {
+    {0, 27, 0, 0, 0, 4, 16},                                                                      // L0
+    {1, 128, 0, 1, 0, 4, 16},  {1, 128, 0, 1, 16, 4, 16}, {1, 128, 0, 1, 32, 4, 16}, {1, 128, 0, 1, 48, 4, 16},  // L1
+    {2, 155, 0, 0, 0, 4, 16},                                                                     // L2 (features)
+    {2, 155, 27, 1, 0, 4, 16}, {2, 155, 27, 1, 16, 4, 16}, {2, 155, 27, 1, 32, 4, 16}, {2, 155, 27, 1, 48, 4, 16},
+    {3, 128, 0, 1, 0, 4, 16},  {3, 128, 0, 1, 16, 4, 16}, {3, 128, 0, 1, 32, 4, 16}, {3, 128, 0, 1, 48, 4, 16},  // feature
+    {4, 155, 0, 1, 0, 2, 32},  {4, 155, 0, 1, 32, 2, 32},                                         // views (feature)
+    {4, 155, 128, 2, 0, 2, 16},                                                                   // views (dir enc)
+};
+
+// unit index carried by accumulator register r (0..15) of tile t on lane-half h
+__host__ __device__ inline int unit_of(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct PackArgs {
+    const float *w[5];
+    const float *b[5];  // pts0,pts1,pts2,feat,views
+    const float *alpha_w, *alpha_b, *rgb_w, *rgb_b;
+    float *out;
+};
+
+__global__ void k_pack_mlp(PackArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= PACKED_FLOATS) return;
+    float v = 0.f;
+    if (idx < NCH_FULL * CHUNK_FLOATS) {
+        const int c = idx / CHUNK_FLOATS, e = idx % CHUNK_FLOATS;
+        const ChunkDesc d = c_chunks[c];
+        const int ns4 = d.nsteps / 4;
+        const int k4 = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+        const int s4 = rest % ns4, t = rest / ns4;
+        if (t < d.nt) {
+            const int step = s4 * 4 + k4, half = lane >> 5, out = 32 * t + (lane & 31);
+            int in = -1;
+            if (d.kind == 0) {
+                const int k = step + 15 * half;
+                if (step < 15 && k < 27) in = k;
+            } else if (d.kind == 1) {
+                const int sp = d.base + step;
+                in = unit_of(sp >> 4, sp & 15, half);
+            } else {
+                const int k = step + 14 * half;
+                if (step < 14 && k < 27) in = k;
+            }
+            if (in >= 0) v = a.w[d.w][out * d.ld + d.col0 + in];
+        }
+    } else {
+        const int s = idx - NCH_FULL * CHUNK_FLOATS;
+        if (s < SM_AW) {  // biases
+            const int layer = s < SM_BV ? s / 128 : 4;
+            const int o = s - (layer < 4 ? layer * 128 : SM_BV);
+            const int r = o & 15, h = (o >> 4) & 1, t = o >> 5;
+            v = a.b[layer][unit_of(t, r, h)];
+        } else if (s < SM_RW) {
+            const int o = s - SM_AW, r = o & 15, h = (o >> 4) & 1, t = o >> 5;
+            v = a.alpha_w[unit_of(t, r, h)];
+        } else if (s < SM_AB) {
+            const int o = s - SM_RW, r = o & 15, h = (o >> 4) & 1, t = (o >> 5) & 1, c = o >> 6;
+            v = a.rgb_w[c * 64 + unit_of(t, r, h)];
+        } else if (s == SM_AB) {
+            v = a.alpha_b[0];
+        } else if (s < SM_RB + 3) {
+            v = a.rgb_b[s - SM_RB];
+        }
+    }
+    a.out[idx] = v;
+}
+
+// planes (3,9,H,W) -> [q = plane*3 + group][y][x][4] (3 channels + 0)
+__global__ void k_pack_planes(const float *__restrict__ src, float4 *__restrict__ dst, int H, int W) {
+    const int64_t n = (int64_t)9 * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = i / ((int64_t)H * W), yx = i % ((int64_t)H * W);
+        const float *s = src + (q * 3) * (int64_t)H * W + yx;
+        dst[i] = make_float4(s[0], s[(int64_t)H * W], s[2 * (int64_t)H * W], 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// math helpers (file is compiled with -ffp-contract=off: mul/add sequences stay as the
+// reference's eager PyTorch ops evaluate them)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_hidden(float x) {
+    // F.softplus(beta=1, threshold=20): max(x,0) + log1p(exp(-|x|)) ; abs error ~1e-7 (hardware exp2/log2)
+    const float e = __expf(-fabsf(x));
+    return fmaxf(x, 0.f) + __logf(1.f + e);
+}
+__device__ __forceinline__ float softplus_exact(float x) {
+    // density softplus feeds 1-exp(-sp*1e10) on the last sample: keep full relative accuracy for x << 0
+    return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ f32x16 softplus16(f32x16 v) {
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = softplus_hidden(v[i]);
+    return o;
+}
+
+// 16 k-steps (4 groups of 4) of NT output tiles.  A fragments: one ds_read_b128 = 4 steps of one tile.
+template <int NT, int NS4, int NREAL>
+__device__ __forceinline__ void mma16(f32x16 (&acc)[NT], const f32x16 b, const f32x4 *__restrict__ ldsA, int s4base,
+                                      int lane) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        if (s4 * 4 >= NREAL) break;
+        f32x4 a[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = ldsA[(t * NS4 + s4base + s4) * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (s4 * 4 + k < NREAL) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][k], b[s4 * 4 + k], acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// accumulator init = bias in lane order ([t][half][16] table in LDS)
+template <int NT>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[NT], const float *__restrict__ tbl, int half) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 *p = reinterpret_cast<const f32x4 *>(tbl + (t * 2 + half) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = p[q];
+            acc[t][4 * q + 0] = v[0];
+            acc[t][4 * q + 1] = v[1];
+            acc[t][4 * q + 2] = v[2];
+            acc[t][4 * q + 3] = v[3];
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ float dot_lane(const f32x16 (&h)[NT], const float *__restrict__ tbl, int half) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 *p = reinterpret_cast<const f32x4 *>(tbl + (t * 2 + half) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = p[q];
+            s = fmaf(h[t][4 * q + 0], v[0], s);
+            s = fmaf(h[t][4 * q + 1], v[1], s);
+            s = fmaf(h[t][4 * q + 2], v[2], s);
+            s = fmaf(h[t][4 * q + 3], v[3], s);
+        }
+    }
+    return s + __shfl_xor(s, 32);  // the two halves of a ray hold disjoint units
+}
+
+struct MarchArgs {
+    const float *packed;   // hl_render_mlp_pack output
+    const float4 *planes;  // hl_planes_pack output
+    int H, W;
+    const float *bounds;  // (2,3) device
+    const float *rays_o, *rays_d, *near, *far;
+    const float *z;  // coarse: (R,N) or null (linspace); fine: (R,S) or null
+    long long R;
+    int S;  // samples marched per ray
+    unsigned flags;
+    float *sigma_out;            // coarse
+    float *rgb, *acc, *depth;    // fine
+};
+
+// torch.linspace(0,1,N)[s] (CPU/CUDA kernels are symmetric about the midpoint)
+__device__ __forceinline__ float linspace01(int s, int N) {
+    const float step = 1.0f / (float)(N - 1);
+    return s < N / 2 ? step * (float)s : 1.0f - step * (float)(N - 1 - s);
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(512, 2) void k_march(const MarchArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * CHUNK_FLOATS + SMALL_FLOATS];
+    constexpr int NCH = FULL ? NCH_FULL : NCH_COARSE;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const long long ray = ((long long)blockIdx.x * 8 + (tid >> 6)) * 32 + (lane & 31);
+    const bool valid = ray < a.R;
+    const long long rc = valid ? ray : a.R - 1;
+
+    f32x4 *ldsv = reinterpret_cast<f32x4 *>(lds);
+    const float *small = lds + 2 * CHUNK_FLOATS;
+    const f32x4 *gw = reinterpret_cast<const f32x4 *>(a.packed);
+    for (int i = tid; i < SMALL_FLOATS / 4; i += 512) ldsv[2 * CHUNK_FLOATS / 4 + i] = gw[NCH_FULL * CHUNK_FLOATS / 4 + i];
+    // weight ring: chunk 0 -> slot 0, chunk 1 -> slot 1, chunk 2 staged in registers
+    ldsv[tid] = gw[tid];
+    ldsv[512 + tid] = gw[512 + tid];
+    ldsv[1024 + tid] = gw[1024 + tid];
+    ldsv[1024 + 512 + tid] = gw[1024 + 512 + tid];
+    f32x4 st0 = gw[2048 + tid], st1 = gw[2048 + 512 + tid];
+    int cur = 0;  // float4 offset of the slot holding the chunk being consumed
+
+    const float ox = a.rays_o[rc * 3 + 0], oy = a.rays_o[rc * 3 + 1], oz = a.rays_o[rc * 3 + 2];
+    const float dx = a.rays_d[rc * 3 + 0], dy = a.rays_d[rc * 3 + 1], dz = a.rays_d[rc * 3 + 2];
+    const float nr = a.near[rc], fr = a.far[rc];
+    const int S = a.S;
+    const float offH = (float)(1.0 / (double)a.H);
+    const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
+    const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
+
+    // view-direction encoding, this half's 14 of the 27 (+1 pad) entries   [fields.py:54-85]
+    f32x16 ev;
+    if constexpr (FULL) {
+        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float vd[3] = {dx / nrm, dy / nrm, dz / nrm};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float lo = 0.f, hi = 0.f;
+            // entry k: k<3 raw component; else j=(k-3)/3, comp=(k-3)%3, sin(vd*2^(j/2) + (j&1)*pi/2)
+            auto enc = [&](int k) -> float {
+                if (k >= 27) return 0.f;
+                if (k < 3) return vd[k];
+                const int jj = (k - 3) / 3, comp = (k - 3) % 3;
+                const float f = (float)(1 << (jj >> 1));
+                const float ph = (jj & 1) ? 1.57079632679489661923f : 0.f;
+                return sinf(ph + vd[comp] * f);
+            };
+            if (s < 14) {
+                lo = enc(s);
+                hi = enc(s + 14);
+            }
+            ev[s] = half ? hi : lo;
+        }
+    }
+
+    float T = 1.f, acc_w = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f;
+    float zc;  // depth of the current sample
+    if (a.z) zc = a.z[rc * S];
+    else zc = nr * (1.f - linspace01(0, S)) + fr * linspace01(0, S);
+
+    __syncthreads();
+
+#define HL_CHUNK_ADVANCE(cnext2)                                              \
+    __syncthreads();                                                          \
+    cur ^= 1024;                                                              \
+    ldsv[(cur ^ 1024) + tid] = st0;                                           \
+    ldsv[(cur ^ 1024) + 512 + tid] = st1;                                     \
+    st0 = gw[(cnext2) * 1024 + tid];                                          \
+    st1 = gw[(cnext2) * 1024 + 512 + tid];
+
+    // Ring invariant while chunk g is consumed: slot `cur` holds g, the other slot holds (or is
+    // being filled with) g+1, the staging registers hold (or are receiving) g+2.
+    // HL_CHUNK_ADVANCE(g+2), executed when moving on to chunk g: (1) barrier - every wave is done
+    // with g-1 and the writes of g are visible, (2) flip `cur`, (3) write the staged chunk g+1 into
+    // the slot g-1 just released, (4) start loading g+2 from L2 (lands during g's MFMAs).
+    for (int s = 0; s < S; ++s) {
+        // ---- next depth (needed for the section length) ----
+        float zn = 0.f;
+        if (s + 1 < S) {
+            if (a.z) zn = a.z[rc * S + s + 1];
+            else { const float t = linspace01(s + 1, S); zn = nr * (1.f - t) + fr * t; }
+        }
+        // ---- tri-plane features of this half  [renderer.py:502-531] ----
+        const float px = ox + dx * zc, py = oy + dy * zc, pz = oz + dz * zc;
+        const float nx = 2.f * (px - bmin0) / bext0 - 1.f;
+        const float ny = 2.f * (py - bmin1) / bext1 - 1.f;
+        const float nz = 2.f * (pz - bmin2) / bext2 - 1.f;
+        f32x16 f;
+        f[15] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int qlo = i, qhi = (i + 5 > 8) ? 8 : i + 5;
+            const int q = half ? qhi : qlo;
+            const int p = half ? qhi / 3 : qlo / 3, g = half ? qhi % 3 : qlo % 3;
+            float gu = (p == 2) ? nz : nx;
+            float gv = (p == 1) ? nz : ny;
+            gu = (g == 1) ? gu + offH : gu;
+            gv = (g == 2) ? gv + offH : gv;
+            const float ix = ((gu + 1.f) * (float)a.W - 1.f) / 2.f;
+            const float iy = ((gv + 1.f) * (float)a.H - 1.f) / 2.f;
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+            float w_nw = (x1f - ix) * (y1f - iy), w_ne = (ix - x0f) * (y1f - iy);
+            float w_sw = (x1f - ix) * (iy - y0f), w_se = (ix - x0f) * (iy - y0f);
+            const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+            const bool vx0 = (x0 >= 0) & (x0 < a.W), vx1 = (x1 >= 0) & (x1 < a.W);
+            const bool vy0 = (y0 >= 0) & (y0 < a.H), vy1 = (y1 >= 0) & (y1 < a.H);
+            w_nw = (vx0 & vy0) ? w_nw : 0.f;
+            w_ne = (vx1 & vy0) ? w_ne : 0.f;
+            w_sw = (vx0 & vy1) ? w_sw : 0.f;
+            w_se = (vx1 & vy1) ? w_se : 0.f;
+            const int cx0 = min(max(x0, 0), a.W - 1), cx1 = min(max(x1, 0), a.W - 1);
+            const int cy0 = min(max(y0, 0), a.H - 1), cy1 = min(max(y1, 0), a.H - 1);
+            const float4 *pl = a.planes + (long long)q * a.H * a.W;
+            const float4 t_nw = pl[cy0 * a.W + cx0], t_ne = pl[cy0 * a.W + cx1];
+            const float4 t_sw = pl[cy1 * a.W + cx0], t_se = pl[cy1 * a.W + cx1];
+            const bool live = half ? (i + 5 <= 8) : true;
+            const float r0 = t_nw.x * w_nw + t_ne.x * w_ne + t_sw.x * w_sw + t_se.x * w_se;
+            const float r1 = t_nw.y * w_nw + t_ne.y * w_ne + t_sw.y * w_sw + t_se.y * w_se;
+            const float r2 = t_nw.z * w_nw + t_ne.z * w_ne + t_sw.z * w_sw + t_se.z * w_se;
+            f[3 * i + 0] = live ? r0 : 0.f;
+            f[3 * i + 1] = live ? r1 : 0.f;
+            f[3 * i + 2] = live ? r2 : 0.f;
+        }
+
+        // ---- MLP  [renderer.py:134-156] ----
+        f32x16 X[4], Y[4];
+        // L0: features -> X (chunk 0)
+        load_bias<4>(X, small + SM_B0, half);
+        mma16<4, 4, 15>(X, f, ldsv + cur, 0, lane);
+        // L1: softplus(X) -> Y (chunks 1-4)
+        load_bias<4>(Y, small + SM_B1, half);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            HL_CHUNK_ADVANCE((k + 3) % NCH)
+            X[k] = softplus16(X[k]);
+            mma16<4, 4, 16>(Y, X[k], ldsv + cur, 0, lane);
+        }
+        // L2: [features, softplus(Y)] -> X (chunks 5, 6-9)
+        HL_CHUNK_ADVANCE(7 % NCH)
+        load_bias<4>(X, small + SM_B2, half);
+        mma16<4, 4, 15>(X, f, ldsv + cur, 0, lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            HL_CHUNK_ADVANCE((k + 8) % NCH)
+            Y[k] = softplus16(Y[k]);
+            mma16<4, 4, 16>(X, Y[k], ldsv + cur, 0, lane);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = softplus16(X[k]);
+        const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];
+
+        if constexpr (!FULL) {
+            if (valid && half == 0) a.sigma_out[ray * S + s] = sigma_raw;
+            HL_CHUNK_ADVANCE(2)  // back to chunk 0 for the next sample (chunk 1 staged, stage chunk 2)
+        } else {
+            // feature_linear (no activation): X -> Y (chunks 10-13)
+            load_bias<4>(Y, small + SM_BF, half);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                HL_CHUNK_ADVANCE((k + 12) % NCH)
+                mma16<4, 4, 16>(Y, X[k], ldsv + cur, 0, lane);
+            }
+            // views_linear: [feature, enc(dir)] -> V (chunks 14,15,16), 64 units = 2 tiles
+            f32x16 V[2];
+            load_bias<2>(V, small + SM_BV, half);
+            HL_CHUNK_ADVANCE(16 % NCH)
+            mma16<2, 8, 16>(V, Y[0], ldsv + cur, 0, lane);
+            mma16<2, 8, 16>(V, Y[1], ldsv + cur, 4, lane);
+            HL_CHUNK_ADVANCE(17 % NCH)
+            mma16<2, 8, 16>(V, Y[2], ldsv + cur, 0, lane);
+            mma16<2, 8, 16>(V, Y[3], ldsv + cur, 4, lane);
+            HL_CHUNK_ADVANCE(18 % NCH)
+            mma16<2, 4, 14>(V, ev, ldsv + cur, 0, lane);
+            V[0] = softplus16(V[0]);
+            V[1] = softplus16(V[1]);
+            const float cr = dot_lane<2>(V, small + SM_RW, half) + small[SM_RB + 0];
+            const float cg = dot_lane<2>(V, small + SM_RW + 64, half) + small[SM_RB + 1];
+            const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
+            HL_CHUNK_ADVANCE(19 % NCH)  // chunk 0 of the next sample
+
+            // ---- alpha compositing  [renderer.py:185-186, 213, 221-229] ----
+            const float dist = (s + 1 < S) ? zn - zc : 1e10f;
+            const float alpha = 1.f - expf(-softplus_exact(sigma_raw) * dist);
+            const float w = alpha * T;
+            acc_w += w;
+            acc_r += (1.f / (1.f + expf(-cr))) * w;
+            acc_g += (1.f / (1.f + expf(-cg))) * w;
+            acc_b += (1.f / (1.f + expf(-cb))) * w;
+            acc_d += w * zc;
+            T *= (1.f - alpha + 1e-7f);
+        }
+        zc = zn;
+    }
+#undef HL_CHUNK_ADVANCE
+
+    if constexpr (FULL) {
+        if (valid && half == 0) {
+            if (a.flags & HL_RENDER_WHITE_BKGD) {
+                const float bg = 1.f - acc_w;
+                acc_r += bg; acc_g += bg; acc_b += bg;
+            }
+            if (a.flags & HL_RENDER_NORMALIZE_DEPTH) {
+                acc_d = (acc_d - nr) / (fr - nr + 1e-5f);
+                acc_d = acc_d > 1.f ? 1.f : acc_d;
+                acc_d = acc_d < 0.f ? 0.f : acc_d;
+            }
+            a.rgb[ray * 3 + 0] = acc_r;
+            a.rgb[ray * 3 + 1] = acc_g;
+            a.rgb[ray * 3 + 2] = acc_b;
+            a.acc[ray] = acc_w;
+            a.depth[ray] = acc_d;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// importance sampling + merge: one wave per ray   [renderer.py:158-170, 533-563, 252-253]
+// ---------------------------------------------------------------------------------------------
+constexpr int IMP_MAX_N = 512;
+
+__device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(v, d);
+        if (lane >= d) v *= o;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_scan_add(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+struct ImpArgs {
+    const float *sigma, *rays_d, *near, *far, *z, *u;
+    long long R;
+    int N, Ni;
+    float *z_all;
+};
+
+__global__ __launch_bounds__(64) void k_importance(const ImpArgs a) {
+    __shared__ float s_w[IMP_MAX_N];       // weights, then cdf
+    __shared__ float s_z[2 * IMP_MAX_N];   // merged depths (padded to a power of two)
+    const int lane = threadIdx.x;
+    const long long ray = blockIdx.x;
+    const int N = a.N, Ni = a.Ni;
+    const float nr = a.near[ray], fr = a.far[ray];
+    const float dxx = a.rays_d[ray * 3], dyy = a.rays_d[ray * 3 + 1], dzz = a.rays_d[ray * 3 + 2];
+    const float dn = sqrtf(dxx * dxx + dyy * dyy + dzz * dzz);
+
+    auto zval = [&](int i) -> float {
+        if (a.z) return a.z[ray * N + i];
+        const float t = linspace01(i, N);
+        return nr * (1.f - t) + fr * t;
+    };
+    // weights w_i = alpha_i * prod_{j<i}(1 - alpha_j + 1e-10)
+    float carry = 1.f;
+    for (int base = 0; base < N; base += 64) {
+        const int i = base + lane;
+        float alpha = 0.f, zi = 0.f;
+        if (i < N) {
+            zi = zval(i);
+            float dist = (i + 1 < N) ? zval(i + 1) - zi : 1e10f;
+            dist = dist * dn;
+            alpha = 1.f - expf(-softplus_exact(a.sigma[ray * N + i]) * dist);
+            s_z[i] = zi;
+        }
+        const float fct = (i < N) ? (1.f - alpha + 1e-10f) : 1.f;
+        const float incl = wave_incl_scan_mul(fct, lane);
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.f;
+        if (i < N) s_w[i] = alpha * (carry * excl);
+        carry *= __shfl(incl, 63);
+    }
+    __syncthreads();
+    // pdf over w[1..N-2] (+1e-5), cdf[0]=0, cdf[m]=sum_{i<=m} pdf_i   (N-1 entries)
+    const int M = N - 2;  // number of pdf bins
+    float tot = 0.f;
+    for (int i = 1 + lane; i <= M; i += 64) tot += s_w[i] + 1e-5f;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+    __syncthreads();
+    float run = 0.f;
+    for (int base = 1; base <= M; base += 64) {
+        const int i = base + lane;
+        const float p = (i <= M) ? (s_w[i] + 1e-5f) / tot : 0.f;
+        const float incl = wave_incl_scan_add(p, lane) + run;
+        __syncthreads();
+        if (i <= M) s_w[i] = incl;
+        run = __shfl(incl, 63);
+    }
+    if (lane == 0) s_w[0] = 0.f;
+    __syncthreads();
+    // inverse CDF: idx = #(cdf <= u) (searchsorted right=True) over cdf[0..M]
+    const int nc = M + 1;  // cdf entries == bins entries == N-1
+    for (int q = lane; q < Ni; q += 64) {
+        const float uq = a.u[ray * Ni + q];
+        int lo = 0, hi = nc;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_w[mid] <= uq) lo = mid + 1; else hi = mid;
+        }
+        const int below = max(lo - 1, 0), above = min(lo, nc - 1);
+        const float c0 = s_w[below], c1 = s_w[above];
+        const float b0 = 0.5f * (s_z[below + 1] + s_z[below]);
+        const float b1 = 0.5f * (s_z[above + 1] + s_z[above]);
+        float den = c1 - c0;
+        den = den < 1e-5f ? 1.f : den;
+        const float t = (uq - c0) / den;
+        s_z[N + q] = b0 + t * (b1 - b0);  // slots >= N: never read by the midpoint lookups above
+    }
+    const int tot_n = N + Ni;
+    int P = 1;
+    while (P < tot_n) P <<= 1;
+    for (int q = Ni + lane; q < P - N; q += 64) s_z[N + q] = __builtin_inff();
+    __syncthreads();
+    // bitonic sort of P values
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int e = lane; e < P / 2; e += 64) {
+                const int pos = 2 * j * (e / j) + (e % j), par = pos + j;
+                const bool up = (pos & k) == 0;
+                const float x = s_z[pos], y = s_z[par];
+                if ((x > y) == up) { s_z[pos] = y; s_z[par] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = lane; i < tot_n; i += 64) a.z_all[ray * tot_n + i] = s_z[i];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+size_t hl_render_mlp_packed_bytes(void) { return (size_t)PACKED_FLOATS * sizeof(float); }
+
+int hl_render_mlp_pack(const hl_render_mlp_params *p, void *packed, void *stream) {
+    HL_REQUIRE(p && packed, "hl_render_mlp_pack: null argument");
+    PackArgs a;
+    a.w[0] = p->pts0_w; a.w[1] = p->pts1_w; a.w[2] = p->pts2_w; a.w[3] = p->feat_w; a.w[4] = p->views_w;
+    a.b[0] = p->pts0_b; a.b[1] = p->pts1_b; a.b[2] = p->pts2_b; a.b[3] = p->feat_b; a.b[4] = p->views_b;
+    a.alpha_w = p->alpha_w; a.alpha_b = p->alpha_b; a.rgb_w = p->rgb_w; a.rgb_b = p->rgb_b;
+    for (int i = 0; i < 5; ++i) HL_REQUIRE(a.w[i] && a.b[i], "hl_render_mlp_pack: null weight %d", i);
+    HL_REQUIRE(a.alpha_w && a.alpha_b && a.rgb_w && a.rgb_b, "hl_render_mlp_pack: null head weight");
+    a.out = (float *)packed;
+    hipLaunchKernelGGL(k_pack_mlp, dim3((PACKED_FLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_pack_mlp");
+}
+
+size_t hl_planes_packed_bytes(int H, int W) { return (size_t)9 * H * W * sizeof(float4); }
+
+int hl_planes_pack(const float *planes, int H, int W, void *packed, void *stream) {
+    HL_REQUIRE(planes && packed && H > 0 && W > 0, "hl_planes_pack: bad argument");
+    const int64_t n = (int64_t)9 * H * W;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_pack_planes, dim3(grid), dim3(256), 0, (hipStream_t)stream, planes, (float4 *)packed, H, W);
+    return hl::check_launch("k_pack_planes");
+}
+
+size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance) {
+    if (n_rays <= 0 || n_importance <= 0) return 256;
+    return (size_t)n_rays * (size_t)(n_samples + n_samples + n_importance) * sizeof(float) + 256;
+}
+
+static int fill_march(MarchArgs &a, const void *mlp, const void *planes, int H, int W, const float *bounds,
+                      const float *ro, const float *rd, const float *nr, const float *fr) {
+    HL_REQUIRE(mlp && planes && bounds && ro && rd && nr && fr, "render: null argument");
+    HL_REQUIRE(H > 0 && W > 0, "render: bad plane size %dx%d", H, W);
+    a.packed = (const float *)mlp;
+    a.planes = (const float4 *)planes;
+    a.H = H; a.W = W;
+    a.bounds = bounds;
+    a.rays_o = ro; a.rays_d = rd; a.near = nr; a.far = fr;
+    return HL_OK;
+}
+
+int hl_render_coarse(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
+                     const float *rays_o, const float *rays_d, const float *near, const float *far,
+                     const float *z_vals, int64_t n_rays, int n_samples, float *sigma_out, void *stream) {
+    HL_REQUIRE(n_rays > 0 && n_samples >= 2 && sigma_out, "hl_render_coarse: bad argument");
+    MarchArgs a{};
+    int rcode = fill_march(a, mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far);
+    if (rcode) return rcode;
+    a.z = z_vals; a.R = n_rays; a.S = n_samples; a.flags = 0; a.sigma_out = sigma_out;
+    const unsigned grid = (unsigned)((n_rays + 255) / 256);
+    hipLaunchKernelGGL(k_march<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_march<coarse>");
+}
+
+int hl_render_importance(const float *sigma, const float *rays_d, const float *near, const float *far,
+                         const float *z_vals, const float *u, int64_t n_rays, int n_samples, int n_importance,
+                         float *z_all_out, void *stream) {
+    HL_REQUIRE(sigma && rays_d && near && far && u && z_all_out, "hl_render_importance: null argument");
+    HL_REQUIRE(n_rays > 0 && n_samples >= 3 && n_importance >= 1, "hl_render_importance: bad sizes");
+    if (n_samples > IMP_MAX_N || n_importance > IMP_MAX_N)
+        return hl::fail(HL_ERR_UNSUPPORTED, "hl_render_importance: n_samples/n_importance > %d", IMP_MAX_N);
+    ImpArgs a{sigma, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_all_out};
+    hipLaunchKernelGGL(k_importance, dim3((unsigned)n_rays), dim3(64), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_importance");
+}
+
+int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
+                   const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z_all,
+                   int64_t n_rays, int n_total_samples, unsigned flags, float *rgb, float *acc, float *depth,
+                   void *stream) {
+    HL_REQUIRE(n_rays > 0 && n_total_samples >= 2 && rgb && acc && depth, "hl_render_fine: bad argument");
+    MarchArgs a{};
+    int rcode = fill_march(a, mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far);
+    if (rcode) return rcode;
+    a.z = z_all; a.R = n_rays; a.S = n_total_samples; a.flags = flags;
+    a.rgb = rgb; a.acc = acc; a.depth = depth;
+    const unsigned grid = (unsigned)((n_rays + 255) / 256);
+    hipLaunchKernelGGL(k_march<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_march<fine>");
+}
+
+int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
+                   const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z_vals,
+                   const float *u, int64_t n_rays, int n_samples, int n_importance, unsigned flags, float *rgb,
+                   float *acc, float *depth, void *workspace, void *stream) {
+    if (n_importance > 0) {
+        // renderer.py:250 reshapes the coarse densities to (.., n_importance): only equal counts are valid
+        HL_REQUIRE(n_importance == n_samples, "render: n_importance (%d) must equal n_samples (%d)", n_importance,
+                   n_samples);
+        HL_REQUIRE(u && workspace, "render: u and workspace are required when n_importance > 0");
+        float *sigma = (float *)workspace;
+        float *z_all = sigma + (size_t)n_rays * n_samples;
+        int rcode = hl_render_coarse(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, n_rays,
+                                     n_samples, sigma, stream);
+        if (rcode) return rcode;
+        rcode = hl_render_importance(sigma, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_all, stream);
+        if (rcode) return rcode;
+        return hl_render_fine(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_all, n_rays,
+                              n_samples + n_importance, flags, rgb, acc, depth, stream);
+    }
+    return hl_render_fine(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, n_rays, n_samples,
+                          flags, rgb, acc, depth, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+"""GPU parity: HIP ray-march path (through the C ABI) vs golden vectors from the reference and
+vs the CPU oracle on the same seeded inputs.  Tolerances are fp32-roundoff class and written
+next to each check."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import load_render_case, psnr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def make_renderer(mlp, dev):
+    from humanliff_amd.NeRF import Renderer
+    r = Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, smpl_type='smpl', test=True)
+    missing = r.load_state_dict(mlp, strict=False)
+    assert set(missing.missing_keys) <= {"view_enc._freqs", "view_enc._phases"}
+    return r.to(dev)
+
+
+def hip_render(i, dev, z_vals=None):
+    r = make_renderer(i["mlp"], dev)
+    tp = {"world_bounds": i["bounds"][None].to(dev)}
+    out = r.render(tp, None, z_vals, i["rays_o"][None].to(dev), i["rays_d"][None].to(dev), i["near"][None, :, None].to(dev),
+                   i["far"][None, :, None].to(dev), i["planes"].to(dev), i["n_importance"], i["white_bkgd"],
+                   n_samples=i["n_samples"], u=i["u"].to(dev))
+    torch.cuda.synchronize()
+    return r, {k: v[0].cpu() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_render_matches_reference_golden(name, dev):
+    i, e = load_render_case(name)
+    r, out = hip_render(i, dev)
+    # intermediates kept in the workspace: sigma (R,N) then z_all (R,2N)
+    R, N = i["rays_o"].shape[0], i["n_samples"]
+    ws = r._ws.cpu()
+    sigma = ws[:R * N].reshape(R, N)
+    assert (sigma - e["sigma_coarse"]).abs().max() < 2e-5          # raw densities, |sigma| ~ 1
+    assert (out["rgb_map"] - e["rgb"]).abs().max() < 2e-5          # colours in [0,1]
+    assert (out["acc_map"] - e["acc"]).abs().max() < 2e-5
+    assert (out["depth_map"] - e["depth"]).abs().max() < 5e-5
+    assert psnr(out["rgb_map"], e["rgb"]) > 90.0                   # north-star bar is 45 dB
+    assert out["normal_map"].data_ptr() == out["rgb_map"].data_ptr() or torch.equal(out["normal_map"], out["rgb_map"])
+
+
+def test_importance_stage_matches_oracle(dev):
+    """k_importance alone, fed the oracle's coarse densities: merged depths must agree to 1e-5 of the
+    ray span and be sorted."""
+    from oracle import render_oracle as ro
+    from humanliff_amd import _lib
+    i, e = load_render_case("c")
+    R, N = i["rays_o"].shape[0], i["n_samples"]
+    t = torch.linspace(0, 1, N)
+    z = i["near"][:, None] * (1 - t) + i["far"][:, None] * t
+    want = ro.importance_z(e["sigma_coarse"], z, i["rays_d"], i["u"])
+    L = _lib.lib()
+    z_all = torch.empty((R, 2 * N), device=dev)
+    d = lambda x: x.contiguous().to(dev)  # noqa: E731
+    sig, rd, nr, fr, u = d(e["sigma_coarse"]), d(i["rays_d"]), d(i["near"]), d(i["far"]), d(i["u"])
+    _lib.check(L.hl_render_importance(_lib.ptr(sig), _lib.ptr(rd), _lib.ptr(nr), _lib.ptr(fr), None, _lib.ptr(u),
+                                      R, N, N, _lib.ptr(z_all), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    got = z_all.cpu()
+    assert (got[:, 1:] >= got[:, :-1]).all()
+    span = (i["far"] - i["near"])[:, None]
+    assert ((got - want).abs() / span).max() < 1e-4
+    # explicit z_vals input == generated linspace
+    zd = d(z)
+    z_all2 = torch.empty_like(z_all)
+    _lib.check(L.hl_render_importance(_lib.ptr(sig), _lib.ptr(rd), _lib.ptr(nr), _lib.ptr(fr), _lib.ptr(zd), _lib.ptr(u),
+                                      R, N, N, _lib.ptr(z_all2), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert (z_all2.cpu() - got).abs().max() < 1e-6
+
+
+def test_no_importance_and_explicit_z(dev):
+    """n_importance=0 path and caller-supplied (perturbed) z_vals vs the oracle."""
+    from oracle import render_oracle as ro
+    i, _ = load_render_case("a")
+    i = dict(i)
+    i["n_importance"] = 0
+    R, N = i["rays_o"].shape[0], i["n_samples"]
+    g = torch.Generator().manual_seed(77)
+    t = torch.linspace(0, 1, N)
+    z = i["near"][:, None] * (1 - t) + i["far"][:, None] * t
+    z = z + (torch.rand((R, N), generator=g) - 0.5) * (i["far"] - i["near"])[:, None] / (2 * N)
+    _, out = hip_render(i, dev, z_vals=z[None].to(dev))
+    rgb, acc, depth = ro.render_rays(i["mlp"], i["planes"][0], i["bounds"], i["rays_o"], i["rays_d"], i["near"], i["far"],
+                                     N, 0, z_vals=z)
+    assert (out["rgb_map"] - rgb).abs().max() < 2e-5
+    assert (out["acc_map"] - acc).abs().max() < 2e-5
+    assert (out["depth_map"] - depth).abs().max() < 5e-5
+
+
+def test_render_function_chunks_like_reference(dev):
+    """render() (the 'render_rays' of BASELINE.json): list output order, ragged last chunk."""
+    from humanliff_amd.NeRF import render
+    i, e = load_render_case("a")
+    r = make_renderer(i["mlp"], dev)
+    tp = {"world_bounds": i["bounds"][None].to(dev)}
+    torch.manual_seed(5)  # the reference draws u per chunk from the CPU generator
+    ret = render(chunk=100, rays_o=i["rays_o"][None].to(dev), rays_d=i["rays_d"][None].to(dev),
+                 near=i["near"][None].to(dev), far=i["far"][None].to(dev), tri_planes=i["planes"].to(dev), tp_input=tp,
+                 renderer=r, n_samples=i["n_samples"], perturb=0., n_importance=i["n_importance"])
+    assert len(ret) == 4
+    rgb, acc, normal, depth = [x.cpu() for x in ret]
+    assert rgb.shape == (1, 256, 3) and acc.shape == (1, 256) and depth.shape == (1, 256)
+    assert torch.equal(rgb, normal)
+    # chunked u draws differ from the single-draw fixture, so compare against the oracle run chunk-wise
+    from oracle import render_oracle as ro
+    torch.manual_seed(5)
+    want = []
+    for s in range(0, 256, 100):
+        sl = slice(s, min(s + 100, 256))
+        u = torch.rand([sl.stop - sl.start, i["n_importance"]])
+        want.append(ro.render_rays(i["mlp"], i["planes"][0], i["bounds"], i["rays_o"][sl], i["rays_d"][sl], i["near"][sl],
+                                   i["far"][sl], i["n_samples"], i["n_importance"], u=u)[0])
+    assert (rgb[0] - torch.cat(want)).abs().max() < 2e-5
+
+
+def test_production_shape_vs_oracle(dev):
+    """256x256 planes, 128+128 samples, 1500 rays of a 512x512 view (ragged vs the 256-ray workgroup)."""
+    from oracle import render_oracle as ro
+    from humanliff_amd import synthetic as syn
+    planes = syn.triplane(seed=11, H=256, W=256)
+    mlp = syn.render_mlp_state(3, gain=2.0)
+    ro_, rd_, nr_, fr_ = syn.orbit_rays(7, 36, 512, 512)
+    sl = slice(512 * 250 + 11, 512 * 250 + 11 + 1500)
+    i = dict(planes=planes, bounds=torch.tensor(syn.WORLD_BOUNDS), rays_o=ro_[sl], rays_d=rd_[sl], near=nr_[sl], far=fr_[sl],
+             u=syn.importance_u(1500, 128, seed=5), mlp=mlp, n_samples=128, n_importance=128, white_bkgd=False)
+    _, out = hip_render(i, dev)
+    rgb, acc, depth = ro.render_rays(mlp, planes[0], i["bounds"], i["rays_o"], i["rays_d"], i["near"], i["far"], 128, 128,
+                                     u=i["u"])
+    assert (out["rgb_map"] - rgb).abs().max() < 5e-5
+    assert (out["acc_map"] - acc).abs().max() < 5e-5
+    assert (out["depth_map"] - depth).abs().max() < 2e-4
+    assert psnr(out["rgb_map"], rgb) > 80.0
+
+
+def test_bad_arguments_raise(dev):
+    from humanliff_amd.NeRF import Renderer
+    i, _ = load_render_case("a")
+    r = make_renderer(i["mlp"], dev)
+    tp = {"world_bounds": i["bounds"][None].to(dev)}
+    with pytest.raises(AssertionError):   # n_samples != n_importance (renderer.py:250)
+        r.render(tp, None, None, i["rays_o"][None].to(dev), i["rays_d"][None].to(dev), i["near"][None].to(dev),
+                 i["far"][None].to(dev), i["planes"].to(dev), 16, False, n_samples=32)
+    with pytest.raises(NotImplementedError):
+        Renderer(use_canonical_space=True, triplane_ch=27).render(tp, None, None, None, None, None, None, i["planes"])
