@@ -28,6 +28,13 @@ class RenderMlpParams(C.Structure):
         "alpha_w", "alpha_b", "views_w", "views_b", "rgb_w", "rgb_b")]
 
 
+class UNetCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("model_channels", C.c_int), ("out_channels", C.c_int),
+                ("num_res_blocks", C.c_int), ("n_levels", C.c_int), ("channel_mult", C.c_int * 8),
+                ("n_attention_ds", C.c_int), ("attention_ds", C.c_int * 8), ("num_heads", C.c_int),
+                ("num_heads_upsample", C.c_int), ("num_classes", C.c_int), ("controlnet", C.c_int)]
+
+
 _lib = None
 
 _p, _i, _i64, _u, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint, C.c_size_t
@@ -45,6 +52,17 @@ SIGNATURES = {
     "hl_render_coarse": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p]),
     "hl_render_importance": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _p, _p]),
     "hl_render_fine": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _u, _p, _p, _p, _p]),
+    "hl_unet_packed_bytes": (_sz, [C.POINTER(UNetCfg)]),
+    "hl_unet_create": (_i, [C.POINTER(UNetCfg), _i, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                            _p, _p, C.POINTER(C.c_void_p)]),
+    "hl_unet_destroy": (None, [_p]),
+    "hl_unet_workspace_bytes": (_sz, [_p, _i, _i, _i]),
+    "hl_unet_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "hl_diffusion_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _p]),
+    "hl_conv2d_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
+    "hl_groupnorm_coef": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "hl_attention_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "hl_timestep_embedding": (_i, [_p, _p, _i, _i, _p, _p]),
 }
 
 

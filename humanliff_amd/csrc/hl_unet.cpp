@@ -1,0 +1,538 @@
+// Host runtime of the tri-plane UNet denoiser: binds a reference state_dict, packs the weights
+// and walks the network issuing the kernels of hl_unet_kernels.hip on the caller's stream.
+//
+// Mirrors the structure UNetModel.__init__ builds (human_diffusion/improved_diffusion/unet.py:323-525)
+// and the dataflow of UNetModel.forward (unet.py:550-615) for cond_type in {"controlnet", ""},
+// use_scale_shift_norm=True, dims=2.  Activations are NHWC fp32; every skip "concat" of the decoder is a
+// buffer whose two channel ranges are written in place by their producers (the previous decoder block and
+// the control-branch zero-conv, whose epilogue also adds the encoder skip: hs.pop() + hs_cond.pop()).
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "hl_unet_kernels.h"
+
+namespace {
+
+using hl::ConvArgs;
+using hl::View;
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Conv {
+    const float *w = nullptr;  // packed
+    const float *bias = nullptr;
+    int Cin = 0, Cin_pad = 0, Cout = 0, ks = 1;
+};
+struct Norm {
+    const float *gamma = nullptr, *beta = nullptr;
+    int C = 0;
+};
+struct Res {
+    Norm n1, n2;
+    Conv c1, c2, skip;
+    bool has_skip = false;
+    long emb_off = 0;
+    int Cin = 0, Cout = 0;
+};
+struct Attn {
+    Norm norm;
+    Conv qkv, proj;
+    int C = 0, heads = 1;
+};
+enum Kind { K_CONV, K_RES, K_ATTN, K_DOWN, K_UP };
+struct Layer {
+    Kind kind;
+    int idx;
+};
+struct Block {
+    std::vector<Layer> layers;
+    int Cout = 0;
+    int ds_out = 1;  // spatial downsample factor of the block output
+};
+
+struct Net {
+    hl_unet_cfg cfg{};
+    std::unordered_map<std::string, std::pair<const float *, int64_t>> sd;
+    std::vector<Conv> convs;  // bare convs, down/up convs, proj convs
+    std::vector<Res> res;
+    std::vector<Attn> attn;
+    std::vector<Block> in_blocks, out_blocks, cond_blocks;
+    Block middle;
+    std::vector<int> proj_cond;  // conv index per control block
+    Conv out_conv;
+    Norm out_norm;
+    const float *te0_w = nullptr, *te0_b = nullptr, *te2_w = nullptr, *te2_b = nullptr, *label = nullptr;
+    const float *emb_w = nullptr, *emb_b = nullptr;  // stacked emb_layers
+    long emb_total = 0;
+    int E = 0;         // time_embed_dim
+    int Cpad0 = 0;     // padded input channels
+    // packing cursor
+    float *packed = nullptr;
+    size_t packed_off = 0;  // floats
+    bool dry = true;        // only size the packed buffer
+    hipStream_t st = nullptr;
+    std::string err;
+};
+
+const float *lookup(Net &n, const std::string &name, int64_t expect) {
+    if (n.dry) return reinterpret_cast<const float *>(16);
+    auto it = n.sd.find(name);
+    if (it == n.sd.end()) { if (n.err.empty()) n.err = "missing state_dict key: " + name; return nullptr; }
+    if (expect >= 0 && it->second.second != expect) {
+        if (n.err.empty()) n.err = "shape mismatch for " + name + ": got " + std::to_string(it->second.second) + " elements, expected " + std::to_string(expect);
+        return nullptr;
+    }
+    return it->second.first;
+}
+
+Conv make_conv(Net &n, const std::string &p, int Cin, int Cout, int ks) {
+    Conv c;
+    c.Cin = Cin; c.Cin_pad = round_up(Cin, 16); c.Cout = Cout; c.ks = ks;
+    const size_t fl = hl::conv_packed_floats(Cout, c.Cin_pad, ks);
+    const float *w = lookup(n, p + ".weight", (int64_t)Cout * Cin * ks * ks);
+    c.bias = lookup(n, p + ".bias", Cout);
+    if (!n.dry && w) {
+        float *dst = n.packed + n.packed_off;
+        if (hl::conv_pack_weights(w, Cout, Cin, c.Cin_pad, ks, dst, n.st) != 0 && n.err.empty()) n.err = hl_last_error();
+        c.w = dst;
+    }
+    n.packed_off += (fl + 63) / 64 * 64;
+    return c;
+}
+Norm make_norm(Net &n, const std::string &p, int C) {
+    Norm g;
+    g.C = C;
+    g.gamma = lookup(n, p + ".weight", C);
+    g.beta = lookup(n, p + ".bias", C);
+    return g;
+}
+
+struct EmbPiece { std::string name; int O; long off; };
+
+int add_res(Net &n, std::vector<EmbPiece> &emb, const std::string &p, int Cin, int Cout) {
+    Res r;
+    r.Cin = Cin; r.Cout = Cout;
+    r.n1 = make_norm(n, p + ".in_layers.0", Cin);
+    r.c1 = make_conv(n, p + ".in_layers.2", Cin, Cout, 3);
+    r.emb_off = n.emb_total;
+    emb.push_back({p + ".emb_layers.1", 2 * Cout, n.emb_total});
+    n.emb_total += 2 * Cout;
+    r.n2 = make_norm(n, p + ".out_layers.0", Cout);
+    r.c2 = make_conv(n, p + ".out_layers.3", Cout, Cout, 3);
+    r.has_skip = Cin != Cout;
+    if (r.has_skip) {
+        // the shipped config uses a 1x1 skip (use_conv=False, unet.py:177-184); a 3x3 one is told apart by size
+        int ks = 1;
+        if (!n.dry) {
+            auto it = n.sd.find(p + ".skip_connection.weight");
+            if (it != n.sd.end() && it->second.second == (int64_t)Cout * Cin * 9) ks = 3;
+        }
+        r.skip = make_conv(n, p + ".skip_connection", Cin, Cout, ks);
+        if (n.dry) n.packed_off += hl::conv_packed_floats(Cout, round_up(Cin, 16), 3);  // size for the worst case
+    }
+    n.res.push_back(r);
+    return (int)n.res.size() - 1;
+}
+int add_attn(Net &n, const std::string &p, int C, int heads) {
+    Attn a;
+    a.C = C; a.heads = heads;
+    a.norm = make_norm(n, p + ".norm", C);
+    a.qkv = make_conv(n, p + ".qkv", C, 3 * C, 1);
+    a.proj = make_conv(n, p + ".proj_out", C, C, 1);
+    n.attn.push_back(a);
+    return (int)n.attn.size() - 1;
+}
+int add_conv(Net &n, const std::string &p, int Cin, int Cout, int ks) {
+    n.convs.push_back(make_conv(n, p, Cin, Cout, ks));
+    return (int)n.convs.size() - 1;
+}
+bool has_ds(const hl_unet_cfg &c, int ds) {
+    for (int i = 0; i < c.n_attention_ds; ++i)
+        if (c.attention_ds[i] == ds) return true;
+    return false;
+}
+
+// builds one encoder (main or control) following unet.py:375-415 / 477-518
+void build_encoder(Net &n, std::vector<EmbPiece> &emb, const std::string &root, std::vector<Block> &blocks,
+                   std::vector<int> &chans) {
+    const hl_unet_cfg &c = n.cfg;
+    Block b0;
+    b0.layers.push_back({K_CONV, add_conv(n, root + ".0.0", c.in_channels, c.model_channels, 3)});
+    b0.Cout = c.model_channels;
+    b0.ds_out = 1;
+    blocks.push_back(b0);
+    chans.push_back(c.model_channels);
+    int ch = c.model_channels, ds = 1, bi = 1;
+    for (int level = 0; level < c.n_levels; ++level) {
+        for (int r = 0; r < c.num_res_blocks; ++r) {
+            Block b;
+            const std::string p = root + "." + std::to_string(bi);
+            const int co = c.channel_mult[level] * c.model_channels;
+            b.layers.push_back({K_RES, add_res(n, emb, p + ".0", ch, co)});
+            ch = co;
+            if (has_ds(c, ds)) b.layers.push_back({K_ATTN, add_attn(n, p + ".1", ch, c.num_heads)});
+            b.Cout = ch; b.ds_out = ds;
+            blocks.push_back(b);
+            chans.push_back(ch);
+            ++bi;
+        }
+        if (level != c.n_levels - 1) {
+            Block b;
+            const std::string p = root + "." + std::to_string(bi);
+            b.layers.push_back({K_DOWN, add_conv(n, p + ".0.op", ch, ch, 3)});
+            ds *= 2;
+            b.Cout = ch; b.ds_out = ds;
+            blocks.push_back(b);
+            chans.push_back(ch);
+            ++bi;
+        }
+    }
+}
+
+void build(Net &n) {
+    const hl_unet_cfg &c = n.cfg;
+    n.E = 4 * c.model_channels;
+    n.Cpad0 = round_up(c.in_channels, 16);
+    n.emb_total = 0;
+    n.packed_off = 0;
+    n.convs.clear(); n.res.clear(); n.attn.clear();
+    n.in_blocks.clear(); n.out_blocks.clear(); n.cond_blocks.clear(); n.proj_cond.clear();
+    std::vector<EmbPiece> emb;
+    n.te0_w = lookup(n, "time_embed.0.weight", (int64_t)n.E * c.model_channels);
+    n.te0_b = lookup(n, "time_embed.0.bias", n.E);
+    n.te2_w = lookup(n, "time_embed.2.weight", (int64_t)n.E * n.E);
+    n.te2_b = lookup(n, "time_embed.2.bias", n.E);
+    n.label = c.num_classes > 0 ? lookup(n, "label_emb.weight", (int64_t)c.num_classes * n.E) : nullptr;
+
+    std::vector<int> chans;
+    build_encoder(n, emb, "input_blocks", n.in_blocks, chans);
+    int ch = chans.back();
+    int ds = n.in_blocks.back().ds_out;
+    {
+        Block m;
+        m.layers.push_back({K_RES, add_res(n, emb, "middle_block.0", ch, ch)});
+        m.layers.push_back({K_ATTN, add_attn(n, "middle_block.1", ch, c.num_heads)});
+        m.layers.push_back({K_RES, add_res(n, emb, "middle_block.2", ch, ch)});
+        m.Cout = ch; m.ds_out = ds;
+        n.middle = m;
+    }
+    std::vector<int> stack = chans;
+    int bi = 0;
+    for (int level = c.n_levels - 1; level >= 0; --level) {
+        for (int i = 0; i <= c.num_res_blocks; ++i) {
+            Block b;
+            const std::string p = "output_blocks." + std::to_string(bi);
+            const int skip = stack.back();
+            stack.pop_back();
+            const int co = c.model_channels * c.channel_mult[level];
+            int li = 0;
+            b.layers.push_back({K_RES, add_res(n, emb, p + "." + std::to_string(li++), ch + skip, co)});
+            ch = co;
+            if (has_ds(c, ds)) b.layers.push_back({K_ATTN, add_attn(n, p + "." + std::to_string(li++), ch, c.num_heads_upsample)});
+            if (level && i == c.num_res_blocks) {
+                b.layers.push_back({K_UP, add_conv(n, p + "." + std::to_string(li++) + ".conv", ch, ch, 3)});
+                ds /= 2;
+            }
+            b.Cout = ch; b.ds_out = ds;
+            n.out_blocks.push_back(b);
+            ++bi;
+        }
+    }
+    n.out_norm = make_norm(n, "out.0", ch);
+    n.out_conv = make_conv(n, "out.2", c.model_channels, c.out_channels, 3);
+    if (c.controlnet) {
+        std::vector<int> cch;
+        build_encoder(n, emb, "input_blocks_cond", n.cond_blocks, cch);
+        for (size_t i = 0; i < n.cond_blocks.size(); ++i)
+            n.proj_cond.push_back(add_conv(n, "input_blocks_proj_cond." + std::to_string(i), cch[i], cch[i], 1));
+    }
+    // stacked emb_layers: rows [emb_total][E] then bias [emb_total]
+    const size_t wfl = (size_t)n.emb_total * n.E;
+    if (!n.dry) {
+        float *wdst = n.packed + n.packed_off, *bdst = wdst + wfl;
+        for (auto &e : emb) {
+            const float *w = lookup(n, e.name + ".weight", (int64_t)e.O * n.E);
+            const float *b = lookup(n, e.name + ".bias", e.O);
+            if (!w || !b) continue;
+            hipMemcpyAsync(wdst + (size_t)e.off * n.E, w, (size_t)e.O * n.E * sizeof(float), hipMemcpyDeviceToDevice, n.st);
+            hipMemcpyAsync(bdst + e.off, b, (size_t)e.O * sizeof(float), hipMemcpyDeviceToDevice, n.st);
+        }
+        n.emb_w = wdst; n.emb_b = bdst;
+    }
+    n.packed_off += (wfl + n.emb_total + 63) / 64 * 64;
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+struct Exec {
+    Net &n;
+    bool run;          // false: only size the workspace
+    char *ws;
+    size_t off = 0;
+    hipStream_t st;
+    int B, H, W;
+    float *emb_all = nullptr;
+    float *gn_scratch = nullptr;
+    int rc = 0;
+
+    float *alloc(size_t floats) {
+        float *p = run ? reinterpret_cast<float *>(ws + off) : nullptr;
+        off += (floats * sizeof(float) + 255) / 256 * 256;
+        return p;
+    }
+    View plain(int ds, int C) {
+        View v;
+        v.N = B; v.H = H / ds; v.W = W / ds; v.C = C; v.pitch = C;
+        v.p = alloc((size_t)v.pixels() * C);
+        return v;
+    }
+    void ok(int r) { if (r && !rc) rc = r; }
+
+    void conv(const Conv &c, const View &in, const View &out, int stride, int ups, const float *cA, const float *cB, int act,
+              const float *res, long res_pitch, float *out2 = nullptr, long out2_pitch = 0, const float *res2 = nullptr,
+              long res2_pitch = 0, int nchw = 0) {
+        if (!run) return;
+        ConvArgs a{};
+        a.in = in; a.in.C = c.Cin_pad;
+        a.w = c.w; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
+        a.coefA = cA; a.coefB = cB; a.act = act;
+        a.out = out; a.res = res; a.res_pitch = res_pitch;
+        a.out2 = out2; a.out2_pitch = out2_pitch; a.res2 = res2; a.res2_pitch = res2_pitch; a.out_nchw = nchw;
+        ok(hl::conv2d(a, st));
+    }
+    void coef(const View &x, const Norm &g, const float *emb, float *&cA, float *&cB) {
+        cA = alloc((size_t)B * x.C);
+        cB = alloc((size_t)B * x.C);
+        if (run) ok(hl::groupnorm_coef(x, g.gamma, g.beta, emb, n.emb_total, cA, cB, gn_scratch, st));
+    }
+    void res_block(const Res &r, const View &x, const View &dst) {
+        float *a1, *b1, *a2, *b2;
+        coef(x, r.n1, nullptr, a1, b1);
+        View h = plain(H / dst.H, r.Cout);
+        conv(r.c1, x, h, 1, 0, a1, b1, 1, nullptr, 0);
+        coef(h, r.n2, run ? emb_all + r.emb_off : nullptr, a2, b2);
+        if (r.has_skip) {
+            conv(r.skip, x, dst, 1, 0, nullptr, nullptr, 0, nullptr, 0);
+            conv(r.c2, h, dst, 1, 0, a2, b2, 1, dst.p, dst.pitch);
+        } else {
+            conv(r.c2, h, dst, 1, 0, a2, b2, 1, x.p, x.pitch);
+        }
+    }
+    void attn_block(const Attn &a, const View &x, const View &dst) {
+        float *ca, *cb;
+        coef(x, a.norm, nullptr, ca, cb);
+        View qkv = plain(H / x.H, 3 * a.C);
+        conv(a.qkv, x, qkv, 1, 0, ca, cb, 0, nullptr, 0);
+        View o = plain(H / x.H, a.C);
+        if (run) ok(hl::attention(qkv.p, B, x.H * x.W, a.C, a.heads, o.p, st));
+        conv(a.proj, o, dst, 1, 0, nullptr, nullptr, 0, x.p, x.pitch);
+    }
+    // run one TimestepEmbedSequential; the last layer writes into dst
+    void block(const Block &b, View x, const View &dst) {
+        for (size_t i = 0; i < b.layers.size(); ++i) {
+            const Layer &L = b.layers[i];
+            const bool last = i + 1 == b.layers.size();
+            int Cout, ds_out;
+            const int ds_in = H / x.H;
+            switch (L.kind) {
+                case K_CONV: Cout = n.convs[L.idx].Cout; ds_out = ds_in; break;
+                case K_RES: Cout = n.res[L.idx].Cout; ds_out = ds_in; break;
+                case K_ATTN: Cout = n.attn[L.idx].C; ds_out = ds_in; break;
+                case K_DOWN: Cout = n.convs[L.idx].Cout; ds_out = ds_in * 2; break;
+                default: Cout = n.convs[L.idx].Cout; ds_out = ds_in / 2; break;
+            }
+            View y = last ? dst : plain(ds_out, Cout);
+            switch (L.kind) {
+                case K_CONV: conv(n.convs[L.idx], x, y, 1, 0, nullptr, nullptr, 0, nullptr, 0); break;
+                case K_RES: res_block(n.res[L.idx], x, y); break;
+                case K_ATTN: attn_block(n.attn[L.idx], x, y); break;
+                case K_DOWN: conv(n.convs[L.idx], x, y, 2, 0, nullptr, nullptr, 0, nullptr, 0); break;
+                case K_UP: conv(n.convs[L.idx], x, y, 1, 1, nullptr, nullptr, 0, nullptr, 0); break;
+            }
+            x = y;
+        }
+    }
+
+    void forward(const float *x, const int64_t *t, const float *tf, const float *x_cond, const int64_t *y, float *out) {
+        const hl_unet_cfg &c = n.cfg;
+        gn_scratch = alloc(hl::gn_scratch_floats(B));
+        // embeddings (unet.py:564, 584-586) and all ResBlock emb_layers in one stacked product
+        float *temb = alloc((size_t)B * c.model_channels), *e1 = alloc((size_t)B * n.E), *emb = alloc((size_t)B * n.E);
+        emb_all = alloc((size_t)B * n.emb_total);
+        View xin; xin.N = B; xin.H = H; xin.W = W; xin.C = n.Cpad0; xin.pitch = n.Cpad0;
+        xin.p = alloc((size_t)xin.pixels() * n.Cpad0);
+        View xsum = xin;
+        if (c.controlnet) xsum.p = alloc((size_t)xin.pixels() * n.Cpad0);
+        if (run) {
+            ok(hl::timestep_embedding(t, tf, B, c.model_channels, temb, st));
+            ok(hl::linear_small(temb, c.model_channels, B, c.model_channels, n.te0_w, n.te0_b, n.E, 0, nullptr, nullptr, e1, n.E, st));
+            ok(hl::linear_small(e1, n.E, B, n.E, n.te2_w, n.te2_b, n.E, 1, c.num_classes > 0 ? n.label : nullptr, y, emb, n.E, st));
+            ok(hl::linear_small(emb, n.E, B, n.E, n.emb_w, n.emb_b, (int)n.emb_total, 1, nullptr, nullptr, emb_all, n.emb_total, st));
+            ok(hl::prep_inputs(x, c.controlnet ? x_cond : nullptr, B, c.in_channels, H, W, n.Cpad0, xin.p,
+                               c.controlnet ? xsum.p : nullptr, st));
+        }
+        // decoder "concat" buffers: [h | skip]; sized from the block structure
+        const size_t nb = n.in_blocks.size();
+        std::vector<View> cat(nb);
+        {
+            int ch = n.middle.Cout;
+            for (size_t j = 0; j < nb; ++j) {
+                const Block &src = n.in_blocks[nb - 1 - j];
+                cat[j] = plain(src.ds_out, ch + src.Cout);
+                ch = n.out_blocks[j].Cout;
+            }
+        }
+        auto first_part = [&](size_t j, int C) { View v = cat[j]; v.C = C; return v; };
+        // main encoder
+        std::vector<View> hs(nb);
+        View h = xin;
+        for (size_t i = 0; i < nb; ++i) {
+            hs[i] = plain(n.in_blocks[i].ds_out, n.in_blocks[i].Cout);
+            if (!c.controlnet && run) {
+                // no control branch: the skip goes straight into its concat slot (second channel range)
+            }
+            block(n.in_blocks[i], h, hs[i]);
+            h = hs[i];
+        }
+        block(n.middle, h, first_part(0, n.middle.Cout));
+        // control branch (unet.py:594-602): zero-conv output feeds the next block AND (+ encoder skip) the decoder
+        if (c.controlnet) {
+            View hc = xsum;
+            for (size_t i = 0; i < nb; ++i) {
+                View tmp = plain(n.cond_blocks[i].ds_out, n.cond_blocks[i].Cout);
+                block(n.cond_blocks[i], hc, tmp);
+                View pj = plain(n.cond_blocks[i].ds_out, n.cond_blocks[i].Cout);
+                const size_t j = nb - 1 - i;
+                const int Ch = cat[j].C - hs[i].C;
+                conv(n.convs[n.proj_cond[i]], tmp, pj, 1, 0, nullptr, nullptr, 0, nullptr, 0,
+                     run ? cat[j].p + Ch : nullptr, cat[j].pitch, hs[i].p, hs[i].pitch);
+                hc = pj;
+            }
+        } else if (run) {
+            for (size_t i = 0; i < nb; ++i) {
+                const size_t j = nb - 1 - i;
+                const int Ch = cat[j].C - hs[i].C;
+                hipMemcpy2DAsync(cat[j].p + Ch, cat[j].pitch * sizeof(float), hs[i].p, hs[i].pitch * sizeof(float),
+                                 (size_t)hs[i].C * sizeof(float), (size_t)hs[i].pixels(), hipMemcpyDeviceToDevice, st);
+            }
+        }
+        // decoder
+        View last;
+        for (size_t j = 0; j < nb; ++j) {
+            View dst = (j + 1 < nb) ? first_part(j + 1, n.out_blocks[j].Cout) : plain(n.out_blocks[j].ds_out, n.out_blocks[j].Cout);
+            block(n.out_blocks[j], cat[j], dst);
+            last = dst;
+        }
+        float *ca, *cb;
+        coef(last, n.out_norm, nullptr, ca, cb);
+        View o; o.N = B; o.H = H; o.W = W; o.C = c.out_channels; o.pitch = c.out_channels; o.p = out;
+        conv(n.out_conv, last, o, 1, 0, ca, cb, 1, nullptr, 0, nullptr, 0, nullptr, 0, 1);
+    }
+};
+
+int validate(const hl_unet_cfg *c) {
+    HL_REQUIRE(c, "unet: null cfg");
+    HL_REQUIRE(c->n_levels >= 1 && c->n_levels <= 8 && c->n_attention_ds >= 0 && c->n_attention_ds <= 8, "unet: bad cfg sizes");
+    HL_REQUIRE(c->model_channels % 32 == 0, "unet: model_channels must be a multiple of 32 (GroupNorm32)");
+    HL_REQUIRE(c->in_channels > 0 && c->out_channels > 0 && c->num_res_blocks > 0 && c->num_heads > 0, "unet: bad cfg");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hl_unet_packed_bytes(const hl_unet_cfg *cfg) {
+    if (validate(cfg)) return 0;
+    Net n;
+    n.cfg = *cfg;
+    if (n.cfg.num_heads_upsample <= 0) n.cfg.num_heads_upsample = n.cfg.num_heads;
+    n.dry = true;
+    build(n);
+    return n.packed_off * sizeof(float) + 256;
+}
+
+int hl_unet_create(const hl_unet_cfg *cfg, int n_tensors, const char *const *names, const void *const *ptrs,
+                   const int64_t *numels, void *packed, void *stream, void **handle) {
+    int rc = validate(cfg);
+    if (rc) return rc;
+    HL_REQUIRE(names && ptrs && numels && packed && handle, "hl_unet_create: null argument");
+    Net *n = new Net();
+    n->cfg = *cfg;
+    if (n->cfg.num_heads_upsample <= 0) n->cfg.num_heads_upsample = n->cfg.num_heads;
+    for (int i = 0; i < n_tensors; ++i) n->sd[names[i]] = {static_cast<const float *>(ptrs[i]), numels[i]};
+    n->dry = false;
+    n->packed = static_cast<float *>(packed);
+    n->st = (hipStream_t)stream;
+    build(*n);
+    if (!n->err.empty()) {
+        rc = hl::fail(HL_ERR_INVALID, "hl_unet_create: %s", n->err.c_str());
+        delete n;
+        return rc;
+    }
+    *handle = n;
+    return HL_OK;
+}
+
+void hl_unet_destroy(void *handle) { delete static_cast<Net *>(handle); }
+
+size_t hl_unet_workspace_bytes(void *handle, int B, int H, int W) {
+    if (!handle || B <= 0) return 0;
+    Net &n = *static_cast<Net *>(handle);
+    Exec e{n, false, nullptr, 0, nullptr, B, H, W};
+    e.forward(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    return e.off + 256;
+}
+
+int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float *t_float, const float *x_cond,
+                    const int64_t *y, float *out, int B, int H, int W, void *workspace, void *stream) {
+    HL_REQUIRE(handle && x && (t || t_float) && out && workspace, "hl_unet_forward: null argument");
+    Net &n = *static_cast<Net *>(handle);
+    const int total_ds = 1 << (n.cfg.n_levels - 1);
+    HL_REQUIRE(B >= 1 && B <= 16, "hl_unet_forward: batch %d outside [1,16]", B);
+    HL_REQUIRE(H % total_ds == 0 && W % total_ds == 0, "hl_unet_forward: H,W must be divisible by %d", total_ds);
+    HL_REQUIRE(!n.cfg.controlnet || x_cond, "hl_unet_forward: x_cond is required with cond_type='controlnet'");
+    HL_REQUIRE(n.cfg.num_classes == 0 || y, "hl_unet_forward: y is required for a class-conditional model");
+    Exec e{n, true, static_cast<char *>(workspace), 0, (hipStream_t)stream, B, H, W};
+    e.forward(x, t, t_float, x_cond, y, out);
+    return e.rc;
+}
+
+// ---- single ops for tests ------------------------------------------------------------------------
+int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout, int ks,
+                   int stride, int upsample, const float *coefA, const float *coefB, int silu, const float *residual,
+                   float *out, void *scratch, size_t scratch_bytes, void *stream) {
+    HL_REQUIRE(Cin % 16 == 0, "hl_conv2d_nhwc: Cin must be a multiple of 16");
+    const size_t need = hl::conv_packed_floats(Cout, Cin, ks) * sizeof(float);
+    HL_REQUIRE(scratch && scratch_bytes >= need, "hl_conv2d_nhwc: scratch too small (%zu < %zu)", scratch_bytes, need);
+    int rc = hl::conv_pack_weights(w_oihw, Cout, Cin, Cin, ks, static_cast<float *>(scratch), (hipStream_t)stream);
+    if (rc) return rc;
+    ConvArgs a{};
+    a.in.p = const_cast<float *>(in); a.in.N = N; a.in.H = H; a.in.W = W; a.in.C = Cin; a.in.pitch = Cin;
+    a.w = static_cast<float *>(scratch); a.bias = bias; a.Cout = Cout; a.ks = ks; a.stride = stride; a.ups = upsample;
+    a.coefA = coefA; a.coefB = coefB; a.act = silu;
+    const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
+    a.out.p = out; a.out.N = N; a.out.H = (Hv + 2 * pad - ks) / stride + 1; a.out.W = (Wv + 2 * pad - ks) / stride + 1;
+    a.out.C = Cout; a.out.pitch = Cout;
+    a.res = residual; a.res_pitch = Cout;
+    return hl::conv2d(a, (hipStream_t)stream);
+}
+
+int hl_groupnorm_coef(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta, const float *emb,
+                      float *coefA, float *coefB, void *scratch, size_t scratch_bytes, void *stream) {
+    HL_REQUIRE(scratch && scratch_bytes >= hl::gn_scratch_floats(N) * sizeof(float), "hl_groupnorm_coef: scratch too small");
+    View v; v.p = const_cast<float *>(x); v.N = N; v.H = H; v.W = W; v.C = C; v.pitch = C;
+    return hl::groupnorm_coef(v, gamma, beta, emb, 2L * C, coefA, coefB, static_cast<float *>(scratch), (hipStream_t)stream);
+}
+
+int hl_timestep_embedding(const int64_t *t, const float *t_float, int B, int dim, float *out, void *stream) {
+    HL_REQUIRE(dim % 2 == 0, "hl_timestep_embedding: odd dim %d", dim);
+    return hl::timestep_embedding(t, t_float, B, dim, out, (hipStream_t)stream);
+}
+
+int hl_attention_nhwc(const float *qkv, int N, int T, int C, int heads, float *out, void *stream) {
+    return hl::attention(qkv, N, T, C, heads, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// Launchers of the UNet / sampler device kernels (hl_unet_kernels.hip). Internal header.
+#pragma once
+#include "hl_common.h"
+
+namespace hl {
+
+// NHWC fp32 tensor view with a channel pitch (so two producers can write into one "concat" buffer).
+struct View {
+    float *p = nullptr;
+    int N = 0, H = 0, W = 0, C = 0;
+    long pitch = 0;  // floats between consecutive pixels
+    long pixels() const { return (long)N * H * W; }
+};
+
+struct ConvArgs {
+    View in;             // C must be a multiple of 16 (pad channels are zero and have zero weights)
+    const float *w;      // packed [Cout_pad][Ktot], K index = (cin/16 * taps + tap) * 16 + cin%16
+    const float *bias;   // [Cout] or null
+    int Cout;            // real output channels
+    int ks;              // 1 or 3 (pad = ks/2)
+    int stride;          // 1 or 2
+    int ups;             // 1: input is read through a nearest x2 upsample (unet.py:77)
+    const float *coefA;  // per-(n, cin) affine applied before the conv (GroupNorm [+scale/shift]) or null
+    const float *coefB;
+    int act;             // 1: SiLU after the affine
+    View out;            // NHWC (pitch honoured) unless out_nchw
+    const float *res;    // residual added to out (may alias out.p), pitch res_pitch; or null
+    long res_pitch;
+    float *out2;         // optional second output out2 = out + res2
+    long out2_pitch;
+    const float *res2;
+    long res2_pitch;
+    int out_nchw;        // write (N, Cout, H, W) instead of NHWC
+};
+int conv2d(const ConvArgs &a, hipStream_t st);
+size_t conv_packed_floats(int Cout, int Cin_pad, int ks);
+int conv_pack_weights(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, float *packed, hipStream_t st);
+
+// GroupNorm(32 groups, eps 1e-5) statistics -> per-(n,c) affine  y = x*A + B   (nn.py:17-19,100)
+// optional scale/shift (ResBlock use_scale_shift_norm, unet.py:203-206): y = GN(x)*(1+scale)+shift,
+// where emb (N, emb_pitch) holds [scale(C) | shift(C)] starting at emb + n*emb_pitch.
+size_t gn_scratch_floats(int N);
+int groupnorm_coef(const View &x, const float *gamma, const float *beta, const float *emb, long emb_pitch, float *coefA,
+                   float *coefB, float *scratch, hipStream_t st);
+
+// out[b][o] = bias[o] + sum_k act(in[b][k]) * W[o][k] (+ addrow[idx[b]][o]);  B <= 8
+int linear_small(const float *in, long in_pitch, int B, int K, const float *W, const float *bias, int O, int silu_in,
+                 const float *addrow, const int64_t *idx, float *out, long out_pitch, hipStream_t st);
+// sinusoidal timestep embedding (nn.py:103-121); t is int64 (B,)
+int timestep_embedding(const int64_t *t, const float *t_float, int B, int dim, float *out, hipStream_t st);
+
+// QKV attention (unet.py:255-274): qkv (N, T, 3C) with channel = head*3ch + {q|k|v}*ch + c ; out (N, T, C)
+int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipStream_t st);
+
+// (B,C,H,W) x, x_cond -> NHWC padded to Cpad: x_nhwc and (x + x_cond)_nhwc   (unet.py:588,596)
+int prep_inputs(const float *x, const float *x_cond, int B, int C, int H, int W, int Cpad, float *x_nhwc, float *xsum_nhwc,
+                hipStream_t st);
+
+}  // namespace hl

@@ -1,0 +1,589 @@
+// Device kernels of the tri-plane UNet denoiser and the sampler update, MI355X (gfx950), fp32.
+//
+// What each kernel replaces in the reference (human_diffusion/improved_diffusion/):
+//   k_conv            nn.Conv2d 3x3 / 3x3 stride 2 / nearest-x2 + 3x3 / 1x1 / Conv1d k=1 (unet.py:68,100,149,
+//                     164-184,237-239,378,486-518) as ONE implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32),
+//                     with GroupNorm-apply(+scale/shift)+SiLU fused into the tile load and bias / residual /
+//                     skip-sum fused into the store.  NHWC activations, channel pitch so concats are free.
+//   k_gn_partial/coef GroupNorm32(32, C) statistics (nn.py:17-19,100) folded to a per-(n,c) affine.
+//   k_linear_small    time_embed / emb_layers nn.Linear at batch <= 8 (unet.py:151-157,366-370).
+//   k_attention       QKVAttention (unet.py:255-274): fp32 flash-style, softmax in fp32.
+//   k_prep_inputs     x.type(dtype), x + x_cond (unet.py:588,596) and NCHW -> NHWC.
+#include "hl_unet_kernels.h"
+
+namespace hl {
+namespace {
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM convolution
+// ---------------------------------------------------------------------------------------------
+struct ConvK {
+    const float *in; long in_pitch; int N, Hin, Win, Cin;
+    int Hout, Wout, ks, stride, ups, taps;
+    const float *w; long Ktot; const float *bias; int Cout;
+    const float *cA; const float *cB; int act;
+    float *out; long out_pitch; const float *res; long res_pitch;
+    float *out2; long out2_pitch; const float *res2; long res2_pitch;
+    int out_nchw; long M; int wrows;
+};
+
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(WM *WN * 64) void k_conv(const ConvK p) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHR = WM * WN * 64, LDA = 20;
+    constexpr int A_F4 = BM * 4, B_F4 = BN * 4;
+    constexpr int A_PER = (A_F4 + NTHR - 1) / NTHR, B_PER = (B_F4 + NTHR - 1) / NTHR;
+    constexpr int STAGE = (BM + BN) * LDA;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int q = tid & 3;
+    const int pad = p.ks >> 1;
+
+    // per-thread A rows (output pixels)
+    int a_n[A_PER], a_y[A_PER], a_x[A_PER];
+    bool a_ok[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int e = tid + i * NTHR;
+        const long P = m0 + (e >> 2);
+        a_ok[i] = (e < A_F4) && (P < p.M);
+        const long Pc = a_ok[i] ? P : 0;
+        const int hw = p.Hout * p.Wout;
+        a_n[i] = (int)(Pc / hw);
+        const int rem = (int)(Pc - (long)a_n[i] * hw);
+        a_y[i] = rem / p.Wout;
+        a_x[i] = rem - a_y[i] * p.Wout;
+    }
+
+    f32x4 ra[A_PER], rcA[A_PER], rcB[A_PER], rb[B_PER];
+    bool rv[A_PER];
+
+    auto load_tile = [&](int kt) {
+        const int cc = kt / p.taps, tap = kt - cc * p.taps;
+        const int ky = (p.ks == 3) ? tap / 3 : 0, kx = (p.ks == 3) ? tap - ky * 3 : 0;
+        const int c = cc * 16 + q * 4;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int iy, ix;
+            bool ok = a_ok[i];
+            if (p.ups) {
+                const int vy = a_y[i] + ky - pad, vx = a_x[i] + kx - pad;
+                ok = ok && vy >= 0 && vy < 2 * p.Hin && vx >= 0 && vx < 2 * p.Win;
+                iy = vy >> 1; ix = vx >> 1;
+            } else {
+                iy = a_y[i] * p.stride + ky - pad; ix = a_x[i] * p.stride + kx - pad;
+                ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+            }
+            rv[i] = ok;
+            if (ok) {
+                ra[i] = *reinterpret_cast<const f32x4 *>(p.in + (((long)a_n[i] * p.Hin + iy) * p.Win + ix) * p.in_pitch + c);
+                if (p.cA) {
+                    rcA[i] = *reinterpret_cast<const f32x4 *>(p.cA + (long)a_n[i] * p.Cin + c);
+                    rcB[i] = *reinterpret_cast<const f32x4 *>(p.cB + (long)a_n[i] * p.Cin + c);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int e = tid + i * NTHR;
+            const int gn = n0 + (e >> 2);
+            if (e < B_F4 && gn < p.wrows) rb[i] = *reinterpret_cast<const f32x4 *>(p.w + (long)gn * p.Ktot + (long)kt * 16 + q * 4);
+            else rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float *base = lds + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int e = tid + i * NTHR;
+            if (e < A_F4) {
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (rv[i]) {
+                    v = ra[i];
+                    if (p.cA) v = v * rcA[i] + rcB[i];
+                    if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                }
+                *reinterpret_cast<f32x4 *>(base + (e >> 2) * LDA + q * 4) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int e = tid + i * NTHR;
+            if (e < B_F4) *reinterpret_cast<f32x4 *>(base + (BM + (e >> 2)) * LDA + q * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.Cin / 16) * p.taps;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float *base = lds + buf * STAGE;
+        f32x4 a[MT][2], b[NT][2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const float *r = base + (wm * MT * 32 + i * 32 + (lane & 31)) * LDA + half * 8;
+            a[i][0] = *reinterpret_cast<const f32x4 *>(r);
+            a[i][1] = *reinterpret_cast<const f32x4 *>(r + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float *r = base + (BM + wn * NT * 32 + j * 32 + (lane & 31)) * LDA + half * 8;
+            b[j][0] = *reinterpret_cast<const f32x4 *>(r);
+            b[j][1] = *reinterpret_cast<const f32x4 *>(r + 4);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s >> 2][s & 3], b[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds channel (lane&31) of pixels (r&3)+8*(r>>2)+4*half
+    const int hw = p.Hout * p.Wout;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * NT * 32 + j * 32 + (lane & 31);
+            if (n >= p.Cout) continue;
+            const float bs = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bs;
+                if (p.res) v += p.res[m * p.res_pitch + n];
+                if (p.out_nchw) {
+                    const long img = m / hw, rem = m - img * hw;
+                    p.out[(img * p.Cout + n) * hw + rem] = v;
+                } else {
+                    p.out[m * p.out_pitch + n] = v;
+                }
+                if (p.out2) p.out2[m * p.out2_pitch + n] = v + p.res2[m * p.res2_pitch + n];
+            }
+        }
+}
+
+__global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, int ks, int rows, float *__restrict__ dst) {
+    const int taps = ks * ks;
+    const long Ktot = (long)Cin_pad * taps;
+    const long n = (long)rows * Ktot;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i / Ktot);
+        const long k = i - (long)o * Ktot;
+        const int c16 = (int)(k & 15);
+        const long t = k >> 4;
+        const int tap = (int)(t % taps), cc = (int)(t / taps);
+        const int cin = cc * 16 + c16;
+        float v = 0.f;
+        if (o < Cout && cin < Cin) v = w[((long)o * Cin + cin) * taps + tap];
+        dst[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics
+// ---------------------------------------------------------------------------------------------
+// grid (nchunks, N); blockDim = (C/4) * k threads; thread owns one float4 channel column.
+__global__ void k_gn_partial(const float *__restrict__ x, long pitch, int HW, int C, int nchunks, float *__restrict__ partial) {
+    extern __shared__ float sh[];  // [k][C] sums then [k][C] sumsq
+    const int cq = C >> 2;
+    const int k = blockDim.x / cq;
+    const int c4 = threadIdx.x % cq, prow = threadIdx.x / cq;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int per = (HW + nchunks - 1) / nchunks;
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, ss = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (prow < k) {
+        const float *base = x + (long)n * HW * pitch + c4 * 4;
+        for (int pp = p0 + prow; pp < p1; pp += k) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (long)pp * pitch);
+            s += v;
+            ss += v * v;
+        }
+        float *d = sh + (long)prow * C + c4 * 4;
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+        float *d2 = sh + (long)(k + prow) * C + c4 * 4;
+        d2[0] = ss[0]; d2[1] = ss[1]; d2[2] = ss[2]; d2[3] = ss[3];
+    }
+    __syncthreads();
+    const int cg = C / 32;
+    if (threadIdx.x < 64) {
+        const int g = threadIdx.x & 31, which = threadIdx.x >> 5;
+        float t = 0.f;
+        for (int r = 0; r < k; ++r)
+            for (int c = 0; c < cg; ++c) t += sh[(long)(which * k + r) * C + g * cg + c];
+        partial[(((long)n * nchunks + chunk) * 32 + g) * 2 + which] = t;
+    }
+}
+
+// grid N, block C threads (looped): A = rstd*gamma [*(1+scale)], B = (beta - mean*rstd*gamma)[*(1+scale) + shift]
+__global__ void k_gn_coef(const float *__restrict__ partial, int nchunks, int HW, int C, const float *__restrict__ gamma,
+                          const float *__restrict__ beta, const float *__restrict__ emb, long emb_pitch,
+                          float *__restrict__ cA, float *__restrict__ cB) {
+    const int n = blockIdx.x;
+    const int cg = C / 32;
+    const double cnt = (double)HW * cg;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cg;
+        double s = 0.0, ss = 0.0;
+        for (int k = 0; k < nchunks; ++k) {
+            s += (double)partial[(((long)n * nchunks + k) * 32 + g) * 2 + 0];
+            ss += (double)partial[(((long)n * nchunks + k) * 32 + g) * 2 + 1];
+        }
+        const double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        float a = rstd * gamma[c];
+        float b = beta[c] - (float)mean * a;
+        if (emb) {
+            const float sc = 1.f + emb[(long)n * emb_pitch + c];
+            const float sh = emb[(long)n * emb_pitch + C + c];
+            a = a * sc;
+            b = b * sc + sh;
+        }
+        cA[(long)n * C + c] = a;
+        cB[(long)n * C + c] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small-batch linear: one wave per output row
+// ---------------------------------------------------------------------------------------------
+template <int MAXB>
+__global__ __launch_bounds__(256) void k_linear_small(const float *__restrict__ in, long in_pitch, int B, int K,
+                                                      const float *__restrict__ W, const float *__restrict__ bias, int O,
+                                                      int silu_in, const float *__restrict__ addrow,
+                                                      const int64_t *__restrict__ idx, float *__restrict__ out, long out_pitch) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= O) return;
+    float acc[MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = W[(long)o * K + k];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b)
+            if (b < B) {
+                float v = in[(long)b * in_pitch + k];
+                if (silu_in) v = silu_f(v);
+                acc[b] = fmaf(v, w, acc[b]);
+            }
+    }
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        float v = acc[b];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+        if (lane == 0 && b < B) {
+            v += bias ? bias[o] : 0.f;
+            if (addrow) v += addrow[(long)idx[b] * O + o];
+            out[(long)b * out_pitch + o] = v;
+        }
+    }
+}
+
+__global__ void k_timestep_embedding(const int64_t *__restrict__ t, const float *__restrict__ tf, int B, int dim, float *__restrict__ out) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, j = i - b * dim;
+    float v = 0.f;
+    if (j < 2 * half) {
+        const int k = j < half ? j : j - half;
+        // freqs = exp(-ln(10000) * k / half) in fp32 (nn.py:113-116)
+        const float f = expf(-9.210340371976184f * (float)k / (float)half);
+        const float a = (tf ? tf[b] : (float)t[b]) * f;
+        v = j < half ? cosf(a) : sinf(a);
+    }
+    out[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention: one wave = 32 queries of one (n, head); 4 waves per block share K/V tiles in LDS.
+// S^T[key][q] = K[key][:] . Q^T[:, q]  (A = K tile from LDS, B = Q^T from registers)
+// O^T[c][q]  += V^T[c][key] . P^T[key][q]  (A = V tile from LDS read "down the keys", B = P^T = the
+// S^T accumulator itself after softmax - same register-resident trick as the render MLP)
+// ---------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(256, 1) void k_attention(const float *__restrict__ qkv, int T, int C, int heads, float *__restrict__ out) {
+    constexpr int CT = CH / 32;   // channel tiles of the output
+    constexpr int KS = CH / 2;    // k-steps of the QK^T product
+    constexpr int LDK = CH + 1;   // odd row stride: rows differ per lane in the A reads
+    __shared__ float sK[32 * LDK];
+    __shared__ float sV[32 * CH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int nh = blockIdx.y;  // n*heads + head
+    const int n = nh / heads, head = nh % heads;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const float scale = 1.f / sqrtf(sqrtf((float)CH));
+    const long pitch = 3L * C;
+    const float *base = qkv + (long)n * T * pitch + (long)head * 3 * CH;
+
+    // Q^T operand: lane (query j, half) holds q[c = 2s + half] * scale
+    const int qj = min(q0 + (lane & 31), T - 1);
+    float qreg[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qreg[s] = base[(long)qj * pitch + 2 * s + half] * scale;
+
+    f32x16 o[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float mrun = -3.0e38f, lrun = 0.f;
+
+    for (int k0 = 0; k0 < T; k0 += 32) {
+        __syncthreads();
+        for (int e = tid; e < 32 * CH; e += 256) {
+            const int key = e / CH, c = e - key * CH;
+            const int kk = min(k0 + key, T - 1);
+            sK[key * LDK + c] = base[(long)kk * pitch + CH + c] * scale;
+            sV[key * CH + c] = base[(long)kk * pitch + 2 * CH + c];
+        }
+        __syncthreads();
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(lane & 31) * LDK + 2 * s + half], qreg[s], st, 0, 0, 0);
+        // st[r] = score(key = (r&3)+8*(r>>2)+4*half, query = lane&31); mask keys beyond T
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= T) st[r] = -3.0e38f;
+            mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __expf(mrun - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = __expf(st[r] - mnew);
+            psum += st[r];
+        }
+        psum += __shfl_xor(psum, 32);
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int key = (s & 3) + 8 * (s >> 2) + 4 * half;  // the key this lane's st[s] belongs to
+                o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[key * CH + c * 32 + (lane & 31)], st[s], o[c], 0, 0, 0);
+            }
+        }
+    }
+    // o[c][r] = O^T[channel = c*32 + (r&3)+8*(r>>2)+4*half][query = lane&31]
+    const int qi = q0 + (lane & 31);
+    if (qi < T) {
+        const float inv = 1.f / lrun;
+        float *dst = out + ((long)n * T + qi) * C + head * CH;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = o[c][r] * inv;
+    }
+}
+
+// generic (slow) attention for head widths that are not a multiple of 32: one thread per (query, channel-chunk)
+__global__ void k_attention_generic(const float *__restrict__ qkv, int T, int C, int heads, int ch, float *__restrict__ out) {
+    extern __shared__ float sh[];  // scores of one query row per wave: [waves][T]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nh = blockIdx.y, n = nh / heads, head = nh % heads;
+    const int qi = blockIdx.x * 4 + wave;
+    if (qi >= T) return;
+    const float scale = 1.f / sqrtf(sqrtf((float)ch));
+    const long pitch = 3L * C;
+    const float *base = qkv + (long)n * T * pitch + (long)head * 3 * ch;
+    float *sc = sh + (long)wave * T;
+    float mx = -3.0e38f;
+    for (int k = lane; k < T; k += 64) {
+        float s = 0.f;
+        for (int c = 0; c < ch; ++c) s = fmaf(base[(long)qi * pitch + c] * scale, base[(long)k * pitch + ch + c] * scale, s);
+        sc[k] = s;
+        mx = fmaxf(mx, s);
+    }
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    float sum = 0.f;
+    for (int k = lane; k < T; k += 64) {
+        const float e = __expf(sc[k] - mx);
+        sc[k] = e;
+        sum += e;
+    }
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int c = lane; c < ch; c += 64) {
+        float a = 0.f;
+        for (int k = 0; k < T; ++k) a = fmaf(sc[k], base[(long)k * pitch + 2 * ch + c], a);
+        out[((long)n * T + qi) * C + head * ch + c] = a / sum;
+    }
+}
+
+__global__ void k_prep_inputs(const float *__restrict__ x, const float *__restrict__ xc, int B, int C, int HW, int Cpad,
+                              float *__restrict__ xo, float *__restrict__ xs) {
+    const long n = (long)B * HW * Cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const long pix = i / Cpad;
+        const long b = pix / HW, r = pix - b * HW;
+        float v = 0.f, s = 0.f;
+        if (c < C) {
+            v = x[(b * C + c) * HW + r];
+            s = xc ? v + xc[(b * C + c) * HW + r] : v;
+        }
+        xo[i] = v;
+        if (xs) xs[i] = s;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+size_t conv_packed_floats(int Cout, int Cin_pad, int ks) { return (size_t)round_up(Cout, 64) * Cin_pad * ks * ks; }
+
+int conv_pack_weights(const float *w, int Cout, int Cin, int Cin_pad, int ks, float *packed, hipStream_t st) {
+    HL_REQUIRE(w && packed && Cin_pad % 16 == 0 && Cin <= Cin_pad && (ks == 1 || ks == 3), "conv_pack_weights: bad argument");
+    const int rows = round_up(Cout, 64);
+    hipLaunchKernelGGL(k_pack_conv, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, ks, rows, packed);
+    return check_launch("k_pack_conv");
+}
+
+int conv2d(const ConvArgs &a, hipStream_t st) {
+    HL_REQUIRE(a.in.p && a.w && a.out.p, "conv2d: null tensor");
+    HL_REQUIRE(a.in.C % 16 == 0, "conv2d: Cin (%d) must be padded to a multiple of 16", a.in.C);
+    HL_REQUIRE(a.ks == 1 || a.ks == 3, "conv2d: kernel size %d", a.ks);
+    HL_REQUIRE(a.stride == 1 || (a.stride == 2 && !a.ups), "conv2d: stride/upsample combination");
+    HL_REQUIRE((a.in.pitch % 4) == 0 && ((uintptr_t)a.in.p % 16) == 0, "conv2d: input must be 16-byte aligned per pixel");
+    ConvK p{};
+    p.in = a.in.p; p.in_pitch = a.in.pitch; p.N = a.in.N; p.Hin = a.in.H; p.Win = a.in.W; p.Cin = a.in.C;
+    p.Hout = a.out.H; p.Wout = a.out.W; p.ks = a.ks; p.stride = a.stride; p.ups = a.ups; p.taps = a.ks * a.ks;
+    const int pad = a.ks / 2;
+    const int Hv = a.ups ? 2 * a.in.H : a.in.H, Wv = a.ups ? 2 * a.in.W : a.in.W;
+    HL_REQUIRE(a.out.H == (Hv + 2 * pad - a.ks) / a.stride + 1 && a.out.W == (Wv + 2 * pad - a.ks) / a.stride + 1 &&
+                   a.out.N == a.in.N, "conv2d: output shape mismatch");
+    p.w = a.w; p.Ktot = (long)a.in.C * p.taps; p.bias = a.bias; p.Cout = a.Cout; p.wrows = round_up(a.Cout, 64);
+    p.cA = a.coefA; p.cB = a.coefB; p.act = a.act;
+    p.out = a.out.p; p.out_pitch = a.out.pitch; p.res = a.res; p.res_pitch = a.res_pitch;
+    p.out2 = a.out2; p.out2_pitch = a.out2_pitch; p.res2 = a.res2; p.res2_pitch = a.res2_pitch;
+    p.out_nchw = a.out_nchw;
+    p.M = (long)a.out.N * a.out.H * a.out.W;
+    const long M = p.M;
+    const int cpad = p.wrows;
+    const long big_blocks = ((M + 127) / 128) * (cpad / 192);
+    if (cpad % 192 == 0 && big_blocks >= 192) {
+        dim3 grid((unsigned)((M + 127) / 128), cpad / 192);
+        hipLaunchKernelGGL((k_conv<2, 2, 2, 3>), grid, dim3(256), 0, st, p);
+    } else if (a.Cout <= 32) {
+        dim3 grid((unsigned)((M + 127) / 128), 1);
+        hipLaunchKernelGGL((k_conv<4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+    } else {
+        dim3 grid((unsigned)((M + 63) / 64), cpad / 64);
+        hipLaunchKernelGGL((k_conv<2, 2, 1, 1>), grid, dim3(256), 0, st, p);
+    }
+    return check_launch("k_conv");
+}
+
+static int gn_chunks(int HW) {
+    int c = HW / 256;
+    if (c < 1) c = 1;
+    if (c > 128) c = 128;
+    return c;
+}
+size_t gn_scratch_floats(int N) { return (size_t)N * 128 * 32 * 2; }
+
+int groupnorm_coef(const View &x, const float *gamma, const float *beta, const float *emb, long emb_pitch, float *cA, float *cB,
+                   float *scratch, hipStream_t st) {
+    HL_REQUIRE(x.p && gamma && beta && cA && cB && scratch, "groupnorm_coef: null argument");
+    HL_REQUIRE(x.C % 32 == 0, "GroupNorm32 needs C %% 32 == 0 (C=%d)", x.C);
+    const int HW = x.H * x.W, cq = x.C / 4;
+    const int nch = gn_chunks(HW);
+    int k = 512 / cq;
+    if (k < 1) k = 1;
+    HL_REQUIRE(cq <= 1024, "groupnorm_coef: C too large");
+    const int threads = cq * k > 64 ? cq * k : 64;
+    const size_t shm = (size_t)2 * k * x.C * sizeof(float);
+    hipLaunchKernelGGL(k_gn_partial, dim3(nch, x.N), dim3(threads), shm, st, x.p, x.pitch, HW, x.C, nch, scratch);
+    int rc = check_launch("k_gn_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gn_coef, dim3(x.N), dim3(256), 0, st, scratch, nch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
+    return check_launch("k_gn_coef");
+}
+
+int linear_small(const float *in, long in_pitch, int B, int K, const float *W, const float *bias, int O, int silu_in,
+                 const float *addrow, const int64_t *idx, float *out, long out_pitch, hipStream_t st) {
+    HL_REQUIRE(in && W && out && B >= 1, "linear_small: bad argument");
+    HL_REQUIRE(B <= 16, "linear_small: batch %d > 16 (split the batch)", B);
+    dim3 grid((O + 3) / 4);
+    if (B <= 4)
+        hipLaunchKernelGGL(k_linear_small<4>, grid, dim3(256), 0, st, in, in_pitch, B, K, W, bias, O, silu_in, addrow, idx, out, out_pitch);
+    else if (B <= 8)
+        hipLaunchKernelGGL(k_linear_small<8>, grid, dim3(256), 0, st, in, in_pitch, B, K, W, bias, O, silu_in, addrow, idx, out, out_pitch);
+    else
+        hipLaunchKernelGGL(k_linear_small<16>, grid, dim3(256), 0, st, in, in_pitch, B, K, W, bias, O, silu_in, addrow, idx, out, out_pitch);
+    return check_launch("k_linear_small");
+}
+
+int timestep_embedding(const int64_t *t, const float *tf, int B, int dim, float *out, hipStream_t st) {
+    HL_REQUIRE((t || tf) && out && B > 0 && dim > 0, "timestep_embedding: bad argument");
+    hipLaunchKernelGGL(k_timestep_embedding, dim3((B * dim + 255) / 256), dim3(256), 0, st, t, tf, B, dim, out);
+    return check_launch("k_timestep_embedding");
+}
+
+int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipStream_t st) {
+    HL_REQUIRE(qkv && out && heads > 0 && C % heads == 0, "attention: bad argument");
+    const int ch = C / heads;
+    dim3 grid((T + 127) / 128, N * heads);
+    switch (ch) {
+        case 32: hipLaunchKernelGGL(k_attention<32>, grid, dim3(256), 0, st, qkv, T, C, heads, out); break;
+        case 64: hipLaunchKernelGGL(k_attention<64>, grid, dim3(256), 0, st, qkv, T, C, heads, out); break;
+        case 96: hipLaunchKernelGGL(k_attention<96>, grid, dim3(256), 0, st, qkv, T, C, heads, out); break;
+        case 128: hipLaunchKernelGGL(k_attention<128>, grid, dim3(256), 0, st, qkv, T, C, heads, out); break;
+        case 192: hipLaunchKernelGGL(k_attention<192>, grid, dim3(256), 0, st, qkv, T, C, heads, out); break;
+        default: {
+            HL_REQUIRE((size_t)T * 4 * sizeof(float) <= 60000, "attention: T=%d too long for the generic kernel", T);
+            hipLaunchKernelGGL(k_attention_generic, dim3((T + 3) / 4, N * heads), dim3(256), (size_t)T * 4 * sizeof(float), st,
+                               qkv, T, C, heads, ch, out);
+        }
+    }
+    return check_launch("k_attention");
+}
+
+int prep_inputs(const float *x, const float *xc, int B, int C, int H, int W, int Cpad, float *xo, float *xs, hipStream_t st) {
+    HL_REQUIRE(x && xo && Cpad >= C, "prep_inputs: bad argument");
+    hipLaunchKernelGGL(k_prep_inputs, dim3(2048), dim3(256), 0, st, x, xc, B, C, H * W, Cpad, xo, xs);
+    return check_launch("k_prep_inputs");
+}
+
+}  // namespace hl

@@ -1,0 +1,95 @@
+"""Timestep respacing with the reference's API (human_diffusion/improved_diffusion/respace.py).
+
+space_timesteps (:7-60) -> kept original-schedule steps; SpacedDiffusion (:63-110) re-derives betas for
+the kept steps; _WrappedModel (:113-122) maps loop indices back to ORIGINAL timesteps before the UNet
+sees them.  Here the map lives on the device once (the reference rebuilds the tensor every call).
+"""
+import numpy as np
+import torch as th
+
+from .gaussian_diffusion import GaussianDiffusion
+
+
+def space_timesteps(num_timesteps, section_counts):
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            want = int(section_counts[len("ddim"):])
+            for stride in range(1, num_timesteps):
+                steps = range(0, num_timesteps, stride)
+                if len(steps) == want:
+                    return set(steps)
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(x) for x in section_counts.split(",")]
+    base, extra = divmod(num_timesteps, len(section_counts))
+    kept, start = [], 0
+    for i, count in enumerate(section_counts):
+        size = base + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        stride = 1 if count <= 1 else (size - 1) / (count - 1)
+        pos = 0.0
+        for _ in range(count):
+            kept.append(start + round(pos))
+            pos += stride
+        start += size
+    return set(kept)
+
+
+class SpacedDiffusion(GaussianDiffusion):
+    def __init__(self, use_timesteps, **kwargs):
+        self.use_timesteps = set(use_timesteps)
+        self.original_num_steps = len(kwargs["betas"])
+        base_acp = np.cumprod(1.0 - np.array(kwargs["betas"], dtype=np.float64), axis=0)
+        self.timestep_map, new_betas, last = [], [], 1.0
+        for i, acp in enumerate(base_acp):
+            if i in self.use_timesteps:
+                new_betas.append(1 - acp / last)
+                last = acp
+                self.timestep_map.append(i)
+        kwargs["betas"] = np.array(new_betas)
+        super().__init__(**kwargs)
+
+    def p_mean_variance(self, model, *args, **kwargs):
+        return super().p_mean_variance(self._wrap_model(model), *args, **kwargs)
+
+    def p_sample(self, model, *args, **kwargs):
+        return super().p_sample(self._wrap_model(model), *args, **kwargs)
+
+    def ddim_sample(self, model, *args, **kwargs):
+        return super().ddim_sample(self._wrap_model(model), *args, **kwargs)
+
+    def training_losses(self, model, *args, **kwargs):
+        return super().training_losses(self._wrap_model(model), *args, **kwargs)
+
+    def _loop(self, step, model, *args, **kwargs):
+        return super()._loop(step, model, *args, **kwargs)
+
+    def _wrap_model(self, model):
+        if isinstance(model, _WrappedModel):
+            return model
+        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+
+    def _scale_timesteps(self, t):
+        return t  # scaling is done by the wrapped model
+
+
+class _WrappedModel:
+    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps):
+        self.model = model
+        self.timestep_map = timestep_map
+        self.rescale_timesteps = rescale_timesteps
+        self.original_num_steps = original_num_steps
+        self._maps = {}
+
+    def parameters(self):
+        return self.model.parameters()
+
+    def __call__(self, x, ts, x_cond, **kwargs):
+        key = (str(ts.device), ts.dtype)
+        m = self._maps.get(key)
+        if m is None:
+            m = self._maps[key] = th.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
+        new_ts = m[ts]
+        if self.rescale_timesteps:
+            new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
+        return self.model(x, new_ts, x_cond, **kwargs)

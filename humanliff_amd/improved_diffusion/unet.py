@@ -1,0 +1,250 @@
+"""UNetModel with the reference's constructor, forward signature and state_dict layout
+(human_diffusion/improved_diffusion/unet.py:323-615), executed by libhumanliff_hip.so.
+
+The torch modules declared here only own the parameters (so reference checkpoints load with
+load_state_dict and .to(device) works).  forward() hands the parameter pointers to the C ABI
+(hl_unet_create / hl_unet_forward); there is no PyTorch implementation of the math and no CPU path.
+Supported configuration: dims=2, use_scale_shift_norm=True, cond_type in {"controlnet", ""},
+use_3d_aware=False, inference (no autograd through the HIP kernels).
+"""
+import ctypes as C
+
+import torch as th
+import torch.nn as nn
+
+from .. import _lib
+from .nn import SiLU, conv_nd, linear, normalization, zero_module
+
+
+class TimestepBlock(nn.Module):
+    pass
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    pass
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2):
+        super().__init__()
+        assert use_conv, "conv_resample=False is not built"
+        self.channels, self.use_conv, self.dims = channels, use_conv, dims
+        self.conv = conv_nd(dims, channels, channels, 3, padding=1)
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2):
+        super().__init__()
+        assert use_conv, "conv_resample=False is not built"
+        self.channels, self.use_conv, self.dims = channels, use_conv, dims
+        self.op = conv_nd(dims, channels, channels, 3, stride=2, padding=1)
+
+
+class ResBlock(TimestepBlock):
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
+                 use_3d_aware=False, dims=2, use_checkpoint=False):
+        super().__init__()
+        if not use_scale_shift_norm or use_3d_aware:
+            raise NotImplementedError("only use_scale_shift_norm=True, use_3d_aware=False is built")
+        oc = out_channels or channels
+        self.channels, self.emb_channels, self.dropout, self.out_channels = channels, emb_channels, dropout, oc
+        self.in_layers = nn.Sequential(normalization(channels), SiLU(), conv_nd(dims, channels, oc, 3, padding=1))
+        self.emb_layers = nn.Sequential(SiLU(), linear(emb_channels, 2 * oc))
+        self.out_layers = nn.Sequential(normalization(oc), SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(conv_nd(dims, oc, oc, 3, padding=1)))
+        if oc == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = conv_nd(dims, channels, oc, 3 if use_conv else 1, padding=1 if use_conv else 0)
+
+
+class QKVAttention(nn.Module):
+    pass
+
+
+class AttentionBlock(nn.Module):
+    def __init__(self, channels, num_heads=1, use_checkpoint=False):
+        super().__init__()
+        self.channels, self.num_heads = channels, num_heads
+        self.norm = normalization(channels)
+        self.qkv = conv_nd(1, channels, channels * 3, 1)
+        self.attention = QKVAttention()
+        self.proj_out = zero_module(conv_nd(1, channels, channels, 1))
+
+
+def _encoder(in_channels, mc, channel_mult, num_res_blocks, attention_resolutions, emb_dim, dropout, dims, heads):
+    """Block list of one encoder tower + its per-block channel counts (unet.py:375-415 / 477-518)."""
+    blocks = [TimestepEmbedSequential(conv_nd(dims, in_channels, mc, 3, padding=1))]
+    chans, ch, ds = [mc], mc, 1
+    for level, mult in enumerate(channel_mult):
+        for _ in range(num_res_blocks):
+            layers = [ResBlock(ch, emb_dim, dropout, out_channels=mult * mc, dims=dims, use_scale_shift_norm=True)]
+            ch = mult * mc
+            if ds in attention_resolutions:
+                layers.append(AttentionBlock(ch, num_heads=heads))
+            blocks.append(TimestepEmbedSequential(*layers))
+            chans.append(ch)
+        if level != len(channel_mult) - 1:
+            blocks.append(TimestepEmbedSequential(Downsample(ch, True, dims=dims)))
+            chans.append(ch)
+            ds *= 2
+    return blocks, chans, ch, ds
+
+
+class UNetModel(nn.Module):
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
+                 num_heads=1, num_heads_upsample=-1, use_scale_shift_norm=False, cond_type="", use_3d_aware=False,
+                 transformer_depth=1, context_dim=None):
+        super().__init__()
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        if dims != 2 or not conv_resample or use_3d_aware or not use_scale_shift_norm or cond_type not in ("controlnet", ""):
+            raise NotImplementedError(
+                "the MI355X build covers dims=2, conv_resample=True, use_scale_shift_norm=True, "
+                "cond_type in {'controlnet',''}, use_3d_aware=False (the shipped HumanLiff configuration)")
+        if dropout != 0:
+            raise NotImplementedError("dropout > 0 is a training feature; inference build only")
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = tuple(attention_resolutions)
+        self.dropout, self.channel_mult, self.conv_resample = dropout, tuple(channel_mult), conv_resample
+        self.num_classes, self.use_checkpoint = num_classes, use_checkpoint
+        self.num_heads, self.num_heads_upsample = num_heads, num_heads_upsample
+        self.cond_type, self.use_3d_aware = cond_type, use_3d_aware
+
+        emb_dim = model_channels * 4
+        self.time_embed = nn.Sequential(linear(model_channels, emb_dim), SiLU(), linear(emb_dim, emb_dim))
+        if num_classes is not None:
+            self.label_emb = nn.Embedding(num_classes, emb_dim)
+        enc, chans, ch, ds = _encoder(in_channels, model_channels, self.channel_mult, num_res_blocks,
+                                      self.attention_resolutions, emb_dim, dropout, dims, num_heads)
+        self.input_blocks = nn.ModuleList(enc)
+        self.middle_block = TimestepEmbedSequential(
+            ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=True),
+            AttentionBlock(ch, num_heads=num_heads),
+            ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=True))
+        self.output_blocks = nn.ModuleList([])
+        stack = list(chans)
+        for level, mult in list(enumerate(self.channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                layers = [ResBlock(ch + stack.pop(), emb_dim, dropout, out_channels=model_channels * mult, dims=dims,
+                                   use_scale_shift_norm=True)]
+                ch = model_channels * mult
+                if ds in self.attention_resolutions:
+                    layers.append(AttentionBlock(ch, num_heads=num_heads_upsample))
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, True, dims=dims))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(normalization(ch), SiLU(),
+                                 zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
+        if cond_type == "controlnet":
+            cenc, cchans, _, _ = _encoder(in_channels, model_channels, self.channel_mult, num_res_blocks,
+                                          self.attention_resolutions, emb_dim, dropout, dims, num_heads)
+            self.input_blocks_cond = nn.ModuleList(cenc)
+            self.input_blocks_proj_cond = nn.ModuleList(
+                [zero_module(conv_nd(dims, c, c, 1, padding=0)) for c in cchans])
+        self._hip = None       # (handle, packed buffer, key)
+        self._ws = {}          # (B,H,W,device) -> workspace tensor
+
+    # ---- reference API kept for callers ----------------------------------------------------------
+    @property
+    def inner_dtype(self):
+        return next(self.input_blocks.parameters()).dtype
+
+    def convert_to_fp16(self):
+        raise NotImplementedError("fp16 torso is a training feature of the reference; this build computes in fp32")
+
+    def convert_to_fp32(self):
+        return None
+
+    # ---- HIP binding -------------------------------------------------------------------------------
+    def _cfg(self):
+        c = _lib.UNetCfg()
+        c.in_channels, c.model_channels, c.out_channels = self.in_channels, self.model_channels, self.out_channels
+        c.num_res_blocks = self.num_res_blocks
+        c.n_levels = len(self.channel_mult)
+        for i, m in enumerate(self.channel_mult):
+            c.channel_mult[i] = m
+        c.n_attention_ds = len(self.attention_resolutions)
+        for i, d in enumerate(self.attention_resolutions):
+            c.attention_ds[i] = d
+        c.num_heads, c.num_heads_upsample = self.num_heads, self.num_heads_upsample
+        c.num_classes = self.num_classes or 0
+        c.controlnet = 1 if self.cond_type == "controlnet" else 0
+        return c
+
+    def _bind(self):
+        sd = self.state_dict(keep_vars=True)
+        key = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        if self._hip is not None and self._hip[2] == key:
+            return self._hip[0]
+        L = _lib.lib()
+        if self._hip is not None:
+            L.hl_unet_destroy(self._hip[0])
+            self._hip = None
+        dev = None
+        for k, v in sd.items():
+            if not v.is_cuda:
+                raise RuntimeError("UNetModel parameters must be on the GPU (model.to('cuda')); there is no CPU path")
+            if v.dtype != th.float32 or not v.is_contiguous():
+                raise RuntimeError(f"parameter {k} must be contiguous fp32")
+            dev = v.device
+        cfg = self._cfg()
+        nbytes = L.hl_unet_packed_bytes(C.byref(cfg))
+        if nbytes == 0:
+            _lib.check(-1, "hl_unet_packed_bytes")
+        packed = th.empty(nbytes // 4 + 64, dtype=th.float32, device=dev)
+        n = len(sd)
+        names = (C.c_char_p * n)(*[k.encode() for k in sd])
+        ptrs = (C.c_void_p * n)(*[v.data_ptr() for v in sd.values()])
+        numels = (C.c_int64 * n)(*[v.numel() for v in sd.values()])
+        handle = C.c_void_p()
+        with th.cuda.device(dev):
+            _lib.check(L.hl_unet_create(C.byref(cfg), n, names, ptrs, numels, _lib.ptr(packed), _lib.stream_ptr(),
+                                        C.byref(handle)), "hl_unet_create")
+        self._hip = (handle, packed, key)
+        self._ws = {}
+        return handle
+
+    def __del__(self):
+        try:
+            if self._hip is not None:
+                _lib.lib().hl_unet_destroy(self._hip[0])
+        except Exception:
+            pass
+
+    def forward(self, x, timesteps, x_cond=None, y=None):
+        """Same contract as the reference: x (N,C,H,W), timesteps (N,), x_cond (N,C,H,W), y (N,) -> (N,C_out,H,W)."""
+        if th.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("autograd through the HIP UNet is not built (inference only)")
+        if self.num_classes is not None:
+            assert y is not None and y.shape == (x.shape[0],)
+        if self.cond_type == "controlnet":
+            assert x_cond is not None, "cond_type='controlnet' needs x_cond (zeros for the first layer)"
+        if not x.is_cuda:
+            raise RuntimeError("UNetModel.forward needs CUDA(HIP) tensors; there is no CPU path")
+        handle = self._bind()
+        L = _lib.lib()
+        B, Cc, H, W = x.shape
+        assert Cc == self.in_channels
+        xin = x.detach().to(th.float32).contiguous()
+        xc = x_cond.detach().to(th.float32).contiguous() if x_cond is not None else None
+        ti = tf = None
+        if timesteps.is_floating_point():
+            tf = timesteps.to(th.float32).contiguous()
+        else:
+            ti = timesteps.to(th.int64).contiguous()
+        yi = y.to(th.int64).contiguous() if y is not None else None
+        out = th.empty((B, self.out_channels, H, W), dtype=th.float32, device=x.device)
+        wkey = (B, H, W, str(x.device))
+        ws = self._ws.get(wkey)
+        if ws is None:
+            nbytes = L.hl_unet_workspace_bytes(handle, B, H, W)
+            self._ws.clear()
+            ws = self._ws[wkey] = th.empty(nbytes // 4 + 64, dtype=th.float32, device=x.device)
+        with th.cuda.device(x.device):
+            _lib.check(L.hl_unet_forward(handle, _lib.ptr(xin), _lib.ptr(ti), _lib.ptr(tf), _lib.ptr(xc), _lib.ptr(yi),
+                                         _lib.ptr(out), B, H, W, _lib.ptr(ws), _lib.stream_ptr()), "hl_unet_forward")
+        return out.to(x.dtype)

@@ -80,8 +80,8 @@ size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance
  *   u        (R,n_importance) uniform draws of sample_pdf (renderer.py:545); required
  *            when n_importance > 0 (n_importance must then equal n_samples, renderer.py:250)
  *   rgb (R,3)  acc (R)  depth (R)   outputs; normal_map == rgb_map in the reference
- *   sigma_coarse_out (R,n_samples) / z_all_out (R,n_samples+n_importance): optional
- *            copies of the intermediates (NULL to skip), for parity tests.
+ *   workspace  hl_render_workspace_bytes(); afterwards holds sigma_coarse (R,n_samples)
+ *            followed by the merged depths z_all (R,n_samples+n_importance)
  */
 int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
                    const float *rays_o, const float *rays_d, const float *near, const float *far,
@@ -99,6 +99,72 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
                    const float *rays_o, const float *rays_d, const float *near, const float *far,
                    const float *z_all /* (R,S) or NULL -> linspace */, int64_t n_rays, int n_total_samples,
                    unsigned flags, float *rgb, float *acc, float *depth, void *stream);
+
+
+/* ------------------------------------------------------------------------
+ * Path 1 — tri-plane UNet denoiser + Gaussian-diffusion sampler update
+ * ------------------------------------------------------------------------ */
+
+/* Architecture hyper-parameters, as UNetModel.__init__ receives them
+ * (human_diffusion/improved_diffusion/unet.py:323-343, built by script_util.py:98-150).
+ * Supported: dims=2, use_scale_shift_norm=True, cond_type="controlnet" or "" , dropout=0,
+ * conv_resample=True, use_3d_aware=False (the shipped configuration). */
+typedef struct hl_unet_cfg {
+    int in_channels, model_channels, out_channels, num_res_blocks;
+    int n_levels;
+    int channel_mult[8];
+    int n_attention_ds;
+    int attention_ds[8];        /* downsample rates at which attention is inserted */
+    int num_heads, num_heads_upsample;
+    int num_classes;            /* 0: not class conditional */
+    int controlnet;             /* 1: cond_type == "controlnet" */
+} hl_unet_cfg;
+
+/* Bytes of the re-laid weights (conv OIHW -> GEMM-ready rows, emb_layers stacked). */
+size_t hl_unet_packed_bytes(const hl_unet_cfg *cfg);
+
+/* Bind a state_dict (the reference's key names) and pack it.
+ * names/ptrs/numels: n_tensors parallel arrays; ptrs are device fp32 tensors in the
+ * reference layouts (Conv2d OIHW, Conv1d (O,I,1), Linear (O,I)).  GroupNorm affine, biases
+ * and label_emb are used in place (the caller keeps them alive); everything else is copied
+ * into `packed`.  Replaces UNetModel.__init__ + load_state_dict for inference. */
+int hl_unet_create(const hl_unet_cfg *cfg, int n_tensors, const char *const *names, const void *const *ptrs,
+                   const int64_t *numels, void *packed, void *stream, void **handle);
+void hl_unet_destroy(void *handle);
+
+size_t hl_unet_workspace_bytes(void *handle, int B, int H, int W);
+
+/* Replaces UNetModel.forward(x, timesteps, x_cond, y) (unet.py:550-615).
+ * x, x_cond, out: (B, C, H, W) fp32 NCHW; t, y: (B) int64 (y NULL if not class conditional,
+ * x_cond NULL only without controlnet).  t holds ORIGINAL-schedule integer timesteps
+ * (respace.py:117-122 with rescale_timesteps=False); t_float, if non-NULL, overrides it with
+ * fractional timesteps (rescale_timesteps=True). */
+int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float *t_float, const float *x_cond,
+                    const int64_t *y, float *out, int B, int H, int W, void *workspace, void *stream);
+
+/* Fused sampler update (everything after the model call in p_sample / ddim_sample,
+ * gaussian_diffusion.py:293-333, 356-388, 484-529) for EPSILON prediction with a fixed
+ * variance.  coef: (T, 8) fp32 per-kept-timestep table built by the host mirror from the
+ * float64 schedule: [sqrt_recip_acp, sqrt_recipm1_acp, c0, c1, c2, 0, 0, 0] where
+ *   mode 0 (p_sample):  x0 = clip(r*x - rm1*eps); sample = (c0*x0 + c1*x) + (t!=0) * c2 * noise
+ *   mode 1 (ddim):      x0 = clip(r*x - rm1*eps); e = (r*x - x0)/rm1;
+ *                       sample = (x0*c0 + c1*e) + (t!=0) * c2 * noise
+ * t: (B) int64 indices into the table; n_per_sample = C*H*W; noise may be NULL (no noise term:
+ * `sample` is then the model mean of p_mean_variance); pred_xstart may be NULL. */
+int hl_diffusion_step(int mode, const float *x, const float *eps, const float *noise, const float *coef,
+                      const int64_t *t, float *sample, float *pred_xstart, int64_t n_per_sample, int B, int clip,
+                      void *stream);
+
+/* Single ops of the UNet path, exposed for parity tests and profiling (NHWC fp32). */
+int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,
+                   int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
+                   const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream);
+int hl_groupnorm_coef(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta,
+                      const float *emb /* (N,2C) or NULL */, float *coefA, float *coefB, void *scratch,
+                      size_t scratch_bytes, void *stream);
+int hl_attention_nhwc(const float *qkv, int N, int T, int C, int heads, float *out, void *stream);
+/* timestep_embedding (nn.py:103-121): t int64 (B) or t_float fp32 (B) -> out (B, dim), dim even */
+int hl_timestep_embedding(const int64_t *t, const float *t_float, int B, int dim, float *out, void *stream);
 
 #ifdef __cplusplus
 }

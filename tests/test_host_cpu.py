@@ -1,0 +1,121 @@
+"""Host-side (no GPU) checks of the product package: state_dict layout, schedules, factories,
+the C-ABI library (loads, exports every declared symbol), loud failure without a GPU."""
+import ast
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(over):
+    from humanliff_amd.improved_diffusion.script_util import model_and_diffusion_defaults
+    a = model_and_diffusion_defaults()
+    a.update(dict(in_channels=27, out_channels=27, class_cond=True, learn_sigma=False, num_heads=4, rescale_timesteps=False))
+    a.update(over)
+    return a
+
+
+@pytest.mark.parametrize("name", ["tiny32", "mid64", "deep256"])
+def test_unet_state_dict_layout_equals_reference(name):
+    """Keys, order and shapes of UNetModel.state_dict() == the reference's (stored in the fixture)."""
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion
+    g = np.load(os.path.join(GOLDEN, f"unet_{name}.npz"))
+    over = dict(image_size=int(g["arg_image_size"]), num_channels=int(g["arg_num_channels"]),
+                num_res_blocks=int(g["arg_num_res_blocks"]), attention_resolutions=str(g["arg_attention_resolutions"]))
+    model, diffusion = create_model_and_diffusion(**_args(over))
+    mine = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+    ref = [(str(k), ast.literal_eval(str(s))) for k, s in zip(g["keys"], g["shapes"])]
+    assert mine == ref
+    assert sum(p.numel() for p in model.parameters()) == int(g["n_params"])
+    # zero_module'd tensors start at zero like the reference (unet.py:170, 240, 470, 486)
+    sd = model.state_dict()
+    for k in sd:
+        if re.search(r"out_layers\.3\.|proj_out\.|^out\.2\.|input_blocks_proj_cond", k):
+            assert float(sd[k].abs().max()) == 0.0, k
+
+
+def test_production_config_counts():
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion
+    m, d = create_model_and_diffusion(**_args(dict(image_size=256, num_channels=192, num_res_blocks=3,
+                                                    attention_resolutions="32,16,8", timestep_respacing="250")))
+    assert sum(p.numel() for p in m.parameters()) == 497173083
+    assert len(m.state_dict()) == 953
+    assert d.num_timesteps == 250 and d.timestep_map[:5] == [0, 4, 8, 12, 16] and d.timestep_map[-1] == 999
+
+
+@pytest.mark.parametrize("tag,spec", [("full", ""), ("r250", "250"), ("ddim50", "ddim50"), ("ddim10", "ddim10"),
+                                      ("mix", "10,15,20")])
+def test_spaced_diffusion_tables_equal_reference(tag, spec):
+    from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
+    g = np.load(os.path.join(GOLDEN, "diffusion_steps.npz"))
+    d = create_gaussian_diffusion(steps=1000, timestep_respacing=spec)
+    assert d.timestep_map == list(g[f"{tag}_map"])
+    assert np.array_equal(d.betas, g[f"{tag}_betas"])
+    assert np.array_equal(d.posterior_log_variance_clipped, g[f"{tag}_post_logvar"])
+    assert np.array_equal(d.posterior_mean_coef1, g[f"{tag}_coef1"])
+    assert np.array_equal(d.posterior_mean_coef2, g[f"{tag}_coef2"])
+    assert np.array_equal(d.sqrt_recip_alphas_cumprod, g[f"{tag}_sqrt_recip"])
+    assert np.array_equal(d.sqrt_recipm1_alphas_cumprod, g[f"{tag}_sqrt_recipm1"])
+
+
+def test_schedule_errors_match_reference_types():
+    from humanliff_amd.improved_diffusion import gaussian_diffusion as gd
+    from humanliff_amd.improved_diffusion.respace import space_timesteps
+    from humanliff_amd.improved_diffusion.script_util import create_model
+    g = np.load(os.path.join(GOLDEN, "diffusion_steps.npz"))
+    assert np.array_equal(gd.get_named_beta_schedule("cosine", 50), g["cosine50_betas"])
+    with pytest.raises(NotImplementedError):
+        gd.get_named_beta_schedule("quadratic", 10)
+    with pytest.raises(ValueError):
+        space_timesteps(1000, "ddim999")
+    with pytest.raises(ValueError):
+        space_timesteps(10, "20")
+    with pytest.raises(ValueError):       # script_util.py:124
+        create_model(100, 27, 32, 27, 1, False, True, False, "16,8", 4, -1, True, "controlnet", False, 0.0)
+
+
+def test_library_exports_every_declared_symbol():
+    from humanliff_amd import _lib
+    from humanliff_amd.build import build
+    build()
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "humanliff_hip.h")).read()
+    declared = set(re.findall(r"\b(hl_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"hl_status"}
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/humanliff_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert L.hl_version() >= 100
+    assert L.hl_render_mlp_packed_bytes() == (17 * 4096 + 1024) * 4
+    assert L.hl_planes_packed_bytes(256, 256) == 9 * 256 * 256 * 16
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must fail loudly, never silently route to PyTorch."""
+    from humanliff_amd.NeRF import Renderer
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion
+    m, d = create_model_and_diffusion(**_args(dict(image_size=32, num_channels=32, num_res_blocks=1)))
+    x = torch.zeros(1, 27, 32, 32)
+    with pytest.raises(RuntimeError):
+        m(x, torch.tensor([3]), x, y=torch.tensor([0]))
+    with pytest.raises(RuntimeError):
+        d.p_sample(lambda *a, **k: x, x, x, torch.tensor([3]))
+    r = Renderer(use_canonical_space=False, triplane_ch=27, test=True)
+    with pytest.raises((RuntimeError, AssertionError)):
+        r.render({"world_bounds": torch.zeros(1, 2, 3)}, None, None, torch.zeros(1, 4, 3), torch.ones(1, 4, 3),
+                 torch.zeros(1, 4), torch.ones(1, 4), torch.zeros(1, 3, 9, 8, 8), 0, False, n_samples=4)
+
+
+def test_product_never_imports_oracle():
+    for base, _, files in os.walk(os.path.join(ROOT, "humanliff_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(base, f)).read()
+                assert "oracle" not in src, f"{f} mentions the oracle"
