@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""bench.py - headline benchmark of the two hot paths on MI355X.
+
+    python bench.py --gpus 1 --steps 8 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Primary metric (BASELINE.json configs[1]): denoise-steps/sec of the production 256x256x27 tri-plane UNet
+(497M params) inside the 1000-step DDPM p_sample loop at batch 4 per GPU.  A "step" is one p_sample call:
+UNet forward + fused posterior update + noise draw for the whole batch; value = ranks * 4 * K / seconds.
+Secondary metric (configs[2]) in the "render" object: Mrays/sec of the tri-plane renderer, 512x512 views,
+128 coarse + 128 importance samples per ray.  Weak scaling: every rank runs its own subjects / views; the
+only collective is the final all-gather of samples and images (north star), inside the timed region.
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events (per-kernel-category events
+inside hl_unet_forward for the conv kernels; torch events around the stage launches for the ray-march
+kernel) on one extra pass after the timed region; `cpu_baseline` times the oracle (a PyTorch-CPU
+restatement of the reference's algorithm, kind "port") on this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+UNET_GFLOP_PER_SAMPLE_STEP = 2015.4
+RENDER_FLOP_PER_RAY = 128 * 79616 + 256 * 132608   # 44 138 496 at 128+128
+FINE_FLOP_PER_RAY = 256 * 132608
+COARSE_FLOP_PER_RAY = 128 * 79616
+
+F4 = dict(image_size=256, in_channels=27, out_channels=27, num_channels=192, num_res_blocks=3, num_heads=4,
+          num_heads_upsample=-1, attention_resolutions="32,16,8", dropout=0.0, learn_sigma=False, sigma_small=False,
+          class_cond=True, diffusion_steps=1000, noise_schedule="linear", timestep_respacing="", use_kl=False,
+          predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=True, use_checkpoint=False,
+          use_scale_shift_norm=True, cond_type="controlnet", use_3d_aware=False)
+
+
+def dist_setup(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+    return rank, local, world
+
+
+def barrier(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds, world, dev):
+    if world == 1:
+        return seconds
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def build_unet(dev, seed=1):
+    from humanliff_amd import synthetic as syn
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion
+    model, diffusion = create_model_and_diffusion(**F4)
+    keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    sd = syn.state_from_shapes(keys, seed=seed)   # every zero_module'd tensor re-randomised (SURVEY 8(c) rule 1)
+    model.load_state_dict(sd)
+    return model.to(dev).eval(), diffusion, sd
+
+
+def bench_unet(args, rank, world, dev):
+    from humanliff_amd import _lib
+    B = args.batch
+    model, diffusion, sd = build_unet(dev)
+    g = torch.Generator().manual_seed(7 + rank)
+    x_T = torch.randn((B, 27, 256, 256), generator=g).to(dev)
+    x_cond = torch.zeros((B, 27, 256, 256), device=dev)          # layer 0: zeros (triplane_sample_layered.py:124-129)
+    y = torch.zeros((B,), dtype=torch.int64, device=dev)
+    it = diffusion.p_sample_loop_progressive(model, (B, 27, 256, 256), x_cond=x_cond, noise=x_T, clip_denoised=True,
+                                             model_kwargs={"y": y}, device=dev)
+    for _ in range(args.warmup):
+        out = next(it)
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = next(it)
+    if world > 1:   # final gather of the samples (triplane_sample_layered.py:211-212)
+        import torch.distributed as dist
+        gathered = [torch.empty_like(out["sample"]) for _ in range(world)]
+        dist.all_gather(gathered, out["sample"])
+    barrier(world)
+    secs = max_over_ranks(time.perf_counter() - t0, world, dev)
+    assert torch.isfinite(out["sample"]).all()
+    # ---- roofline leg: one more step with per-launch HIP events inside hl_unet_forward ----
+    L = _lib.lib()
+    handle = model._hip[0]
+    _lib.check(L.hl_unet_profile(handle, 1))
+    next(it)
+    ms, fl, nl = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int64 * 4)()
+    _lib.check(L.hl_unet_profile_read(handle, ms, fl, nl))
+    _lib.check(L.hl_unet_profile(handle, 0))
+    conv_ms, conv_fl, conv_n = ms[0], fl[0], nl[0]
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    roof = {"bound": "mfma", "kernel": "k_conv (implicit-GEMM conv/1x1, v_mfma_f32_32x32x2_f32), all launches of one denoise step",
+            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_per_step": int(conv_n), "gflop_per_step": round(conv_fl / 1e9, 1), "ms_per_step": round(conv_ms, 3),
+            "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4),
+            "other_ms": {"groupnorm": round(ms[1], 3), "attention": round(ms[2], 3), "emb_prep": round(ms[3], 3)}}
+    del it
+    return secs, roof, sd, model
+
+
+def bench_render(args, rank, world, dev):
+    from humanliff_amd import _lib, synthetic as syn
+    from humanliff_amd.NeRF import Renderer
+    H = W = 512
+    N = 128
+    planes = syn.triplane(seed=11 + rank).to(dev)
+    mlp = syn.render_mlp_state(3)
+    r = Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, smpl_type='smpl', test=True)
+    r.load_state_dict(mlp, strict=False)
+    r = r.to(dev)
+    tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].to(dev)}
+    views = args.views
+    rays = [[t.to(dev) for t in syn.orbit_rays((rank * views + v) % 36, 36, H, W)] for v in range(views + 1)]
+    gu = torch.Generator(device=dev).manual_seed(5 + rank)
+    u = torch.rand((H * W, N), generator=gu, device=dev)
+
+    def one(v):
+        ro, rd, nr, fr = rays[v]
+        return r.render(tp, None, None, ro[None], rd[None], nr[None], fr[None], planes, N, False, n_samples=N, u=u)
+
+    one(views)   # warm-up view (also packs MLP + planes)
+    barrier(world)
+    t0 = time.perf_counter()
+    imgs = [one(v)["rgb_map"] for v in range(views)]
+    if world > 1:   # north star: RCCL all-gather of the final images
+        import torch.distributed as dist
+        mine = torch.stack(imgs)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+    barrier(world)
+    secs = max_over_ranks(time.perf_counter() - t0, world, dev)
+    assert torch.isfinite(imgs[0]).all()
+    # ---- roofline leg: the three stages of one view timed with events on the launch stream ----
+    L = _lib.lib()
+    R = H * W
+    ro, rd, nr, fr = [t.contiguous() for t in rays[0]]
+    packed, pp = r._packed_mlp(dev), r._packed_planes(planes[0])
+    sig = torch.empty((R, N), device=dev)
+    z_all = torch.empty((R, 2 * N), device=dev)
+    rgb, acc, dep = torch.empty((R, 3), device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
+    bd = tp["world_bounds"][0].contiguous()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    p, s = _lib.ptr, _lib.stream_ptr
+    ev[0].record()
+    _lib.check(L.hl_render_coarse(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), None, R, N, p(sig), s()))
+    ev[1].record()
+    _lib.check(L.hl_render_importance(p(sig), p(rd), p(nr), p(fr), None, p(u), R, N, N, p(z_all), s()))
+    ev[2].record()
+    _lib.check(L.hl_render_fine(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), p(z_all), R, 2 * N, 2,
+                                p(rgb), p(acc), p(dep), s()))
+    ev[3].record()
+    torch.cuda.synchronize()
+    t_c, t_i, t_f = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
+    achieved = R * FINE_FLOP_PER_RAY / (t_f * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": "k_march<true> (fine pass: tri-plane gather + full MLP + compositing), one 512x512 view",
+            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "launch_ms": round(t_f, 3),
+            "coarse": {"launch_ms": round(t_c, 3), "achieved": round(R * COARSE_FLOP_PER_RAY / (t_c * 1e-3) / 1e12, 2)},
+            "importance_ms": round(t_i, 3)}
+    return secs, roof, views * R
+
+
+def cpu_baseline_unet(sd, threads):
+    """Oracle UNet forward + DDPM update on the host, B=1: 1 warm-up + 1 timed step (a B=4 1000-step run
+    would take hours)."""
+    from oracle import diffusion_oracle as do
+    from oracle import unet_oracle as uo
+    torch.set_num_threads(threads)
+    s = do.Schedule(do.linear_betas(1000), list(range(1000)))
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((1, 27, 256, 256), generator=g)
+    xc = torch.zeros_like(x)
+    y = torch.zeros((1,), dtype=torch.int64)
+    n_timed = 1
+    with torch.no_grad():
+        for i in range(1 + n_timed):
+            if i == 1:
+                t0 = time.perf_counter()
+            t = torch.tensor([999 - i])
+            eps = uo.unet_forward(sd, x, t, xc, y)
+            x, _ = do.p_sample_step(s, x, t, eps, torch.randn(x.shape, generator=g))
+    dt = time.perf_counter() - t0
+    return {"value": round(n_timed / dt, 4), "unit": "denoise-steps/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32 restatement) p_sample, production UNet, batch 1, {n_timed} timed step after 1 warm-up"}
+
+
+def cpu_baseline_render(threads, n_rays=2048):
+    from humanliff_amd import synthetic as syn
+    from oracle import render_oracle as ro
+    torch.set_num_threads(threads)
+    planes = syn.triplane(seed=11)[0]
+    mlp = syn.render_mlp_state(3)
+    o, d, nr, fr = syn.orbit_rays(0, 36, 512, 512)
+    sl = slice(512 * 256, 512 * 256 + n_rays)
+    u = syn.importance_u(n_rays, 128, seed=5)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ro.render_rays(mlp, planes, torch.tensor(syn.WORLD_BOUNDS), o[sl], d[sl], nr[sl], fr[sl], 128, 128, u=u)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_rays / dt / 1e6, 6), "unit": "Mrays/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32 restatement) render of {n_rays} rays of one 512x512 view at 128+128 samples"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="subjects per GPU in the denoise loop (configs[1]: 4)")
+    ap.add_argument("--views", type=int, default=2, help="512x512 views per GPU in the render leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-render", action="store_true")
+    args = ap.parse_args()
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    from humanliff_amd import _lib
+    _lib.lib()   # fail loudly if the HIP library was not built
+    rank, local, world = dist_setup(args.gpus)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local)
+
+    secs, roof, sd, model = bench_unet(args, rank, world, dev)
+    value = world * args.batch * args.steps / secs
+    del model
+    torch.cuda.empty_cache()
+    render = None
+    if not args.no_render:
+        rsecs, rroof, rays_per_rank = bench_render(args, rank, world, dev)
+        render = {"metric": "Mrays/sec@256spp", "value": round(world * rays_per_rank / rsecs / 1e6, 4), "unit": "Mrays/s",
+                  "views_per_gpu": args.views, "ms_per_view": round(rsecs * 1e3 / args.views, 3), "roofline": rroof,
+                  "config": {"workload": "configs[2]: tri-plane NeRF render 512x512, n_samples=128 + n_importance=128, "
+                                         "views of a 36-view orbit, random 256x256x27 tri-plane", "rays_per_view": 512 * 512}}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = os.cpu_count() or 1
+        cpu = cpu_baseline_unet(sd, threads)
+        if render is not None:
+            render["cpu_baseline"] = cpu_baseline_render(threads)
+    if rank == 0:
+        line = {
+            "metric": "denoise-steps/sec", "value": round(value, 3), "unit": "denoise-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(secs * 1e3 / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 256x256x27 tri-plane UNet (controlnet, 497M params), 1000-step DDPM "
+                                   "p_sample_loop, batch=4 per GPU", "global_batch": world * args.batch,
+                       "parallelism": f"replicas x{world} (subjects sharded, final all-gather only)",
+                       "gflop_per_sample_step": UNET_GFLOP_PER_SAMPLE_STEP},
+            "step_tflops": round(world * args.batch * args.steps * UNET_GFLOP_PER_SAMPLE_STEP / secs / 1e3, 2),
+            "roofline": roof, "cpu_baseline": cpu, "render": render,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -155,11 +155,14 @@ class Renderer(nn.Module):
 
 def render(chunk=1024 * 32, rays_o=None, rays_d=None, near=0., far=1., tri_planes=None, tp_input=None, renderer=None,
            n_samples=128, perturb=0., n_importance=0, white_bkgd=False):
-    """Render rays in chunks; returns [rgb_map, acc_map, normal_map, depth_map] like the reference.
+    """Render rays; returns [rgb_map, acc_map, normal_map, depth_map] like the reference.
 
-    For perturb == 0 the depths are generated inside the kernel (no (R, n_samples, 3) point tensor
-    is materialised); for perturb > 0 the stratified jitter is drawn with torch.rand on the device
-    exactly where the reference draws it and the depths are handed to the kernel.
+    The reference walks the rays in `chunk`-sized pieces to bound its intermediates (~2.4 KB per sample
+    point); the fused kernel keeps them on chip, so all rays go down in ONE launch set (16 384-ray chunks
+    would fill only a quarter of the MI355X).  Rays are independent, so the result per ray is unchanged;
+    the random draws keep the reference's per-chunk call pattern (same shapes, same order): sample_pdf's
+    uniforms from the CPU generator (renderer.py:545) and, for perturb > 0, the stratified jitter from the
+    device generator (triplane_sample_layered.py:275).
     """
     batch_size, n_rays, _ = rays_d.shape
     rays_o = rays_o.reshape(batch_size, -1, 3)
@@ -168,23 +171,28 @@ def render(chunk=1024 * 32, rays_o=None, rays_d=None, near=0., far=1., tri_plane
     far = far.reshape(batch_size, -1, 1)
     # the recon twin passes a DDP/DataParallel-wrapped renderer (run_nerf_batch.py:58)
     core = renderer.module if hasattr(renderer, "module") else renderer
-    outs = {}
-    for i in range(0, rays_o.shape[1], chunk):
-        ro, rd = rays_o[:, i:i + chunk], rays_d[:, i:i + chunk]
-        nr, fr = near[:, i:i + chunk], far[:, i:i + chunk]
-        z = None
-        if perturb > 0.:
-            t_vals = torch.linspace(0., 1., steps=n_samples, device=rays_o.device)
-            z = nr * (1. - t_vals) + fr * t_vals
-            mids = .5 * (z[..., 1:] + z[..., :-1])
-            upper = torch.cat([mids, z[..., -1:]], -1)
-            lower = torch.cat([z[..., :1], mids], -1)
-            z = lower + (upper - lower) * torch.rand(z.shape, device=rays_o.device)
-        ret = core.render(tp_input, None, z, ro, rd, nr, fr, tri_planes, n_importance, white_bkgd,
-                          n_samples=n_samples)
-        for k, v in ret.items():
-            outs.setdefault(k, []).append(v)
-    return [torch.cat(v, 1) for v in outs.values()]
+    R = rays_o.shape[1]
+    z, us = None, []
+    if perturb > 0.:
+        zs = []
+        t_vals = torch.linspace(0., 1., steps=n_samples, device=rays_o.device)
+        for i in range(0, R, chunk):
+            zc = near[:, i:i + chunk] * (1. - t_vals) + far[:, i:i + chunk] * t_vals
+            mids = .5 * (zc[..., 1:] + zc[..., :-1])
+            upper = torch.cat([mids, zc[..., -1:]], -1)
+            lower = torch.cat([zc[..., :1], mids], -1)
+            zs.append(lower + (upper - lower) * torch.rand(zc.shape, device=rays_o.device))
+        z = torch.cat(zs, 1)
+    if n_importance > 0:
+        for i in range(0, R, chunk):
+            cr = min(chunk, R - i)
+            us.append(torch.rand([batch_size * cr, n_importance]).reshape(batch_size, cr, n_importance))
+        u = torch.cat(us, 1).to(rays_o.device)
+    else:
+        u = None
+    ret = core.render(tp_input, None, z, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd,
+                      n_samples=n_samples, u=u)
+    return [ret[k] for k in ret]
 
 
 render_rays = render

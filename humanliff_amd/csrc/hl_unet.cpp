@@ -74,7 +74,19 @@ struct Net {
     bool dry = true;        // only size the packed buffer
     hipStream_t st = nullptr;
     std::string err;
+    // optional per-category HIP-event timing of one forward (bench.py roofline leg)
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct Span { int cat; size_t a, b; double flops; };
+    std::vector<Span> spans;
+    size_t ev_used = 0;
+    ~Net() { for (auto e : ev_pool) hipEventDestroy(e); }
+    size_t next_event() {
+        if (ev_used == ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); ev_pool.push_back(e); }
+        return ev_used++;
+    }
 };
+enum { CAT_CONV = 0, CAT_GN = 1, CAT_ATTN = 2, CAT_OTHER = 3, CAT_N = 4 };
 
 const float *lookup(Net &n, const std::string &name, int64_t expect) {
     if (n.dry) return reinterpret_cast<const float *>(16);
@@ -288,6 +300,18 @@ struct Exec {
         return v;
     }
     void ok(int r) { if (r && !rc) rc = r; }
+    size_t span_begin() {
+        if (!n.prof) return 0;
+        const size_t a = n.next_event();
+        hipEventRecord(n.ev_pool[a], st);
+        return a;
+    }
+    void span_end(int cat, size_t a, double flops) {
+        if (!n.prof) return;
+        const size_t b = n.next_event();
+        hipEventRecord(n.ev_pool[b], st);
+        n.spans.push_back({cat, a, b, flops});
+    }
 
     void conv(const Conv &c, const View &in, const View &out, int stride, int ups, const float *cA, const float *cB, int act,
               const float *res, long res_pitch, float *out2 = nullptr, long out2_pitch = 0, const float *res2 = nullptr,
@@ -299,12 +323,18 @@ struct Exec {
         a.coefA = cA; a.coefB = cB; a.act = act;
         a.out = out; a.res = res; a.res_pitch = res_pitch;
         a.out2 = out2; a.out2_pitch = out2_pitch; a.res2 = res2; a.res2_pitch = res2_pitch; a.out_nchw = nchw;
+        const size_t e0 = span_begin();
         ok(hl::conv2d(a, st));
+        span_end(CAT_CONV, e0, 2.0 * (double)out.pixels() * c.Cout * c.Cin * c.ks * c.ks);
     }
     void coef(const View &x, const Norm &g, const float *emb, float *&cA, float *&cB) {
         cA = alloc((size_t)B * x.C);
         cB = alloc((size_t)B * x.C);
-        if (run) ok(hl::groupnorm_coef(x, g.gamma, g.beta, emb, n.emb_total, cA, cB, gn_scratch, st));
+        if (run) {
+            const size_t e0 = span_begin();
+            ok(hl::groupnorm_coef(x, g.gamma, g.beta, emb, n.emb_total, cA, cB, gn_scratch, st));
+            span_end(CAT_GN, e0, 0.0);
+        }
     }
     void res_block(const Res &r, const View &x, const View &dst) {
         float *a1, *b1, *a2, *b2;
@@ -325,7 +355,12 @@ struct Exec {
         View qkv = plain(H / x.H, 3 * a.C);
         conv(a.qkv, x, qkv, 1, 0, ca, cb, 0, nullptr, 0);
         View o = plain(H / x.H, a.C);
-        if (run) ok(hl::attention(qkv.p, B, x.H * x.W, a.C, a.heads, o.p, st));
+        if (run) {
+            const size_t e0 = span_begin();
+            ok(hl::attention(qkv.p, B, x.H * x.W, a.C, a.heads, o.p, st));
+            const double T = (double)x.H * x.W;
+            span_end(CAT_ATTN, e0, 4.0 * B * T * T * a.C);
+        }
         conv(a.proj, o, dst, 1, 0, nullptr, nullptr, 0, x.p, x.pitch);
     }
     // run one TimestepEmbedSequential; the last layer writes into dst
@@ -365,12 +400,14 @@ struct Exec {
         View xsum = xin;
         if (c.controlnet) xsum.p = alloc((size_t)xin.pixels() * n.Cpad0);
         if (run) {
+            const size_t e0 = span_begin();
             ok(hl::timestep_embedding(t, tf, B, c.model_channels, temb, st));
             ok(hl::linear_small(temb, c.model_channels, B, c.model_channels, n.te0_w, n.te0_b, n.E, 0, nullptr, nullptr, e1, n.E, st));
             ok(hl::linear_small(e1, n.E, B, n.E, n.te2_w, n.te2_b, n.E, 1, c.num_classes > 0 ? n.label : nullptr, y, emb, n.E, st));
             ok(hl::linear_small(emb, n.E, B, n.E, n.emb_w, n.emb_b, (int)n.emb_total, 1, nullptr, nullptr, emb_all, n.emb_total, st));
             ok(hl::prep_inputs(x, c.controlnet ? x_cond : nullptr, B, c.in_channels, H, W, n.Cpad0, xin.p,
                                c.controlnet ? xsum.p : nullptr, st));
+            span_end(CAT_OTHER, e0, 2.0 * B * ((double)n.E * c.model_channels + (double)n.E * n.E + (double)n.emb_total * n.E));
         }
         // decoder "concat" buffers: [h | skip]; sized from the block structure
         const size_t nb = n.in_blocks.size();
@@ -389,9 +426,6 @@ struct Exec {
         View h = xin;
         for (size_t i = 0; i < nb; ++i) {
             hs[i] = plain(n.in_blocks[i].ds_out, n.in_blocks[i].Cout);
-            if (!c.controlnet && run) {
-                // no control branch: the skip goes straight into its concat slot (second channel range)
-            }
             block(n.in_blocks[i], h, hs[i]);
             h = hs[i];
         }
@@ -497,6 +531,31 @@ int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float 
     Exec e{n, true, static_cast<char *>(workspace), 0, (hipStream_t)stream, B, H, W};
     e.forward(x, t, t_float, x_cond, y, out);
     return e.rc;
+}
+
+int hl_unet_profile(void *handle, int enable) {
+    HL_REQUIRE(handle, "hl_unet_profile: null handle");
+    Net &n = *static_cast<Net *>(handle);
+    n.prof = enable != 0;
+    n.spans.clear();
+    n.ev_used = 0;
+    return HL_OK;
+}
+
+int hl_unet_profile_read(void *handle, double *h_ms, double *h_flops, int64_t *h_launches) {
+    HL_REQUIRE(handle && h_ms && h_flops && h_launches, "hl_unet_profile_read: null argument");
+    Net &n = *static_cast<Net *>(handle);
+    for (int i = 0; i < CAT_N; ++i) { h_ms[i] = 0; h_flops[i] = 0; h_launches[i] = 0; }
+    if (n.spans.empty()) return HL_OK;
+    HL_HIP(hipEventSynchronize(n.ev_pool[n.spans.back().b]));
+    for (auto &sp : n.spans) {
+        float ms = 0.f;
+        HL_HIP(hipEventElapsedTime(&ms, n.ev_pool[sp.a], n.ev_pool[sp.b]));
+        h_ms[sp.cat] += ms; h_flops[sp.cat] += sp.flops; h_launches[sp.cat] += 1;
+    }
+    n.spans.clear();
+    n.ev_used = 0;
+    return HL_OK;
 }
 
 // ---- single ops for tests ------------------------------------------------------------------------

@@ -142,6 +142,14 @@ size_t hl_unet_workspace_bytes(void *handle, int B, int H, int W);
 int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float *t_float, const float *x_cond,
                     const int64_t *y, float *out, int B, int H, int W, void *workspace, void *stream);
 
+/* Instrumentation for the roofline measurement (bench.py): with profiling enabled every kernel launch
+ * of hl_unet_forward is bracketed by HIP events on the caller's stream.  hl_unet_profile_read waits for
+ * them and returns, per category {0 conv/GEMM, 1 GroupNorm, 2 attention, 3 embeddings+prep}, the summed
+ * kernel time (ms), the algorithmic FLOPs (2*MAC) and the launch count since the last read (host arrays
+ * of 4).  Not meant for the timed production path. */
+int hl_unet_profile(void *handle, int enable);
+int hl_unet_profile_read(void *handle, double *h_ms, double *h_flops, int64_t *h_launches);
+
 /* Fused sampler update (everything after the model call in p_sample / ddim_sample,
  * gaussian_diffusion.py:293-333, 356-388, 484-529) for EPSILON prediction with a fixed
  * variance.  coef: (T, 8) fp32 per-kept-timestep table built by the host mirror from the
