@@ -257,7 +257,9 @@ def main():
                                          "views of a 36-view orbit, random 256x256x27 tri-plane", "rays_per_view": 512 * 512}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = os.cpu_count() or 1
+        # PyTorch-CPU stops scaling (and then collapses) beyond ~32 threads on this path: measured on the
+        # MI355X host (256 logical CPUs) 3x3 conv 192->192@256^2: 49/47/40/90/208 ms at 8/16/32/64/128 threads
+        threads = min(len(os.sched_getaffinity(0)), 32)
         cpu = cpu_baseline_unet(sd, threads)
         if render is not None:
             render["cpu_baseline"] = cpu_baseline_render(threads)

@@ -1,4 +1,4 @@
-import sys, os
+import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests.test_oracle_diffusion import _stub
@@ -13,12 +13,31 @@ d = create_gaussian_diffusion(steps=1000, timestep_respacing="")
 t = torch.from_numpy(g["step_full_1_t"]).long()
 model = lambda xx, tt, xcond, y=None: _stub(xx.cpu(), tt.cpu(), xcond.cpu(), y.cpu()).to(dev)
 torch.randn_like = lambda ref: noise.to(ref.device)
-ps = d.p_sample(model, x.to(dev), xc.to(dev), t.to(dev), clip_denoised=True, model_kwargs={"y": y.to(dev)})
-want = torch.from_numpy(g["step_full_1_p_sample"])
-diff = (ps["sample"].cpu() - want).abs()
-print("p_sample maxdiff", diff.max().item(), "per batch", diff.amax(dim=(1,2,3)))
-print("x0 maxdiff", (ps["pred_xstart"].cpu() - torch.from_numpy(g["step_full_1_p_x0"])).abs().amax(dim=(1,2,3)))
-tab = d._table("ddpm", dev).cpu()
+dd = d.ddim_sample(model, x.to(dev), t.to(dev), x_cond=xc.to(dev), clip_denoised=True, model_kwargs={"y": y.to(dev)})
+want = torch.from_numpy(g["step_full_1_ddim_sample"])
+got = dd["sample"].cpu()
+diff = (got - want).abs()
+print("ddim maxdiff per batch", diff.amax(dim=(1,2,3)), "n mismatching", (diff > 0).sum(dim=(1,2,3)))
+# CPU oracle on THIS host vs golden
 s = do.Schedule(do.linear_betas(1000), list(range(1000)))
-print("tab rows", tab[t], )
-print("oracle", torch.from_numpy(s.sqrt_recip)[t].float(), torch.from_numpy(s.sqrt_recipm1)[t].float(), torch.from_numpy(s.coef1)[t].float(), torch.from_numpy(s.coef2)[t].float(), torch.exp(0.5*torch.from_numpy(np.log(s.fixed_large_var))[t].float()))
+eps = _stub(x, t, xc, y)
+o, _ = do.ddim_step(s, x, t, eps, noise, True, 0.0)
+print("host oracle vs golden", (o - want).abs().amax(dim=(1,2,3)))
+idx = (diff > 0).nonzero()[:3]
+tab = d._table("ddim", dev, 0.0).cpu()
+for i in idx:
+    b = i[0].item(); xv = x[tuple(i)].item(); ev = eps[tuple(i)].item()
+    r, rm1, c0, c1 = [np.float32(v) for v in tab[t[b], :4]]
+    xv = np.float32(xv); ev = np.float32(ev)
+    x0 = np.float32(np.float32(r * xv) - np.float32(rm1 * ev)); x0 = np.float32(min(max(x0, -1), 1))
+    num = np.float32(np.float32(r * xv) - x0); e2 = np.float32(num / rm1)
+    m = np.float32(np.float32(x0 * c0) + np.float32(c1 * e2))
+    print("b", b, "t", t[b].item(), "got", got[tuple(i)].item(), "want", want[tuple(i)].item(), "np emu", m, "e2", e2, "num", num, "rm1", rm1)
+# thread scaling of the dominant CPU op
+import torch.nn.functional as F
+xx = torch.randn(1, 192, 256, 256); w = torch.randn(192, 192, 3, 3)
+for th in (8, 16, 32, 64, 128):
+    torch.set_num_threads(th)
+    F.conv2d(xx, w, padding=1); t0 = time.time(); F.conv2d(xx, w, padding=1); F.conv2d(xx, w, padding=1); print("threads", th, "conv s", (time.time() - t0) / 2, flush=True)
+    h = torch.randn(262144, 128); t0 = time.time(); F.softplus(h); print("  softplus s", time.time() - t0, flush=True)
+print("affinity", len(os.sched_getaffinity(0)), "cpu_count", os.cpu_count())

@@ -79,12 +79,16 @@ def test_single_steps(tag, spec, clip):
     t = torch.from_numpy(g[f"step_{tag}_{c}_t"]).long()
     eps = _stub(x, torch.tensor(s.timestep_map)[t], xc, y)
     ps, x0 = do.p_sample_step(s, x, t, eps, noise, clip)
-    assert torch.equal(ps, torch.from_numpy(g[f"step_{tag}_{c}_p_sample"]))          # same fp32 op order: bit-exact
-    assert torch.equal(x0, torch.from_numpy(g[f"step_{tag}_{c}_p_x0"]))
+    # same fp32 op order as the reference; bit-equal on the build host, within 2 ulp on hosts whose
+    # CPU kernels round the per-timestep scalars differently (observed between x86 ISAs)
+    def near(a, b):
+        return ((a - b).abs() <= 3e-7 * b.abs() + 2e-7).all()
+    assert near(ps, torch.from_numpy(g[f"step_{tag}_{c}_p_sample"]))
+    assert near(x0, torch.from_numpy(g[f"step_{tag}_{c}_p_x0"]))
     dd, _ = do.ddim_step(s, x, t, eps, noise, clip, 0.0)
-    assert torch.equal(dd, torch.from_numpy(g[f"step_{tag}_{c}_ddim_sample"]))
+    assert near(dd, torch.from_numpy(g[f"step_{tag}_{c}_ddim_sample"]))
     de, _ = do.ddim_step(s, x, t, eps, noise, clip, 0.7)
-    assert torch.equal(de, torch.from_numpy(g[f"step_{tag}_{c}_ddim_eta_sample"]))
+    assert near(de, torch.from_numpy(g[f"step_{tag}_{c}_ddim_eta_sample"]))
 
 
 @pytest.mark.parametrize("tag,spec,ddim", [("ddim10", "ddim10", True), ("p8", "8", False)])
