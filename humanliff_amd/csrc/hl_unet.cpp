@@ -286,6 +286,7 @@ struct Exec {
     int B, H, W;
     float *emb_all = nullptr;
     float *gn_scratch = nullptr;
+    float *splitk_ws = nullptr;
     int rc = 0;
 
     float *alloc(size_t floats) {
@@ -323,6 +324,7 @@ struct Exec {
         a.coefA = cA; a.coefB = cB; a.act = act;
         a.out = out; a.res = res; a.res_pitch = res_pitch;
         a.out2 = out2; a.out2_pitch = out2_pitch; a.res2 = res2; a.res2_pitch = res2_pitch; a.out_nchw = nchw;
+        a.splitk_ws = splitk_ws; a.splitk_ws_bytes = hl::conv_splitk_ws_bytes();
         const size_t e0 = span_begin();
         ok(hl::conv2d(a, st));
         span_end(CAT_CONV, e0, 2.0 * (double)out.pixels() * c.Cout * c.Cin * c.ks * c.ks);
@@ -392,6 +394,7 @@ struct Exec {
     void forward(const float *x, const int64_t *t, const float *tf, const float *x_cond, const int64_t *y, float *out) {
         const hl_unet_cfg &c = n.cfg;
         gn_scratch = alloc(hl::gn_scratch_floats(B));
+        splitk_ws = alloc(hl::conv_splitk_ws_bytes() / sizeof(float));
         // embeddings (unet.py:564, 584-586) and all ResBlock emb_layers in one stacked product
         float *temb = alloc((size_t)B * c.model_channels), *e1 = alloc((size_t)B * n.E), *emb = alloc((size_t)B * n.E);
         emb_all = alloc((size_t)B * n.emb_total);
@@ -575,6 +578,12 @@ int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w
     a.out.p = out; a.out.N = N; a.out.H = (Hv + 2 * pad - ks) / stride + 1; a.out.W = (Wv + 2 * pad - ks) / stride + 1;
     a.out.C = Cout; a.out.pitch = Cout;
     a.res = residual; a.res_pitch = Cout;
+    // whatever scratch is left after the packed weights serves split-K (small-M shapes)
+    const size_t used = (need + 255) / 256 * 256;
+    if (scratch_bytes > used + (1u << 20)) {
+        a.splitk_ws = reinterpret_cast<float *>(static_cast<char *>(scratch) + used);
+        a.splitk_ws_bytes = scratch_bytes - used;
+    }
     return hl::conv2d(a, (hipStream_t)stream);
 }
 

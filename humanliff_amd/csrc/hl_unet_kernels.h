@@ -14,7 +14,7 @@ struct View {
 
 struct ConvArgs {
     View in;             // C must be a multiple of 16 (pad channels are zero and have zero weights)
-    const float *w;      // packed [Cout_pad][Ktot], K index = (cin/16 * taps + tap) * 16 + cin%16
+    const float *w;      // packed [Cout_pad][Ktot], K index = (tap * Cin/16 + cin/16) * 16 + cin%16
     const float *bias;   // [Cout] or null
     int Cout;            // real output channels
     int ks;              // 1 or 3 (pad = ks/2)
@@ -31,7 +31,10 @@ struct ConvArgs {
     const float *res2;
     long res2_pitch;
     int out_nchw;        // write (N, Cout, H, W) instead of NHWC
+    float *splitk_ws;    // optional scratch for split-K partial sums (small-M layers); null disables split-K
+    size_t splitk_ws_bytes;
 };
+size_t conv_splitk_ws_bytes();
 int conv2d(const ConvArgs &a, hipStream_t st);
 size_t conv_packed_floats(int Cout, int Cin_pad, int ks);
 int conv_pack_weights(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, float *packed, hipStream_t st);

@@ -14,7 +14,8 @@
 namespace hl {
 namespace {
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+// x*sigmoid(x); v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division sequence
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM convolution
@@ -27,50 +28,93 @@ struct ConvK {
     float *out; long out_pitch; const float *res; long res_pitch;
     float *out2; long out2_pitch; const float *res2; long res2_pitch;
     int out_nchw; long M; int wrows;
+    int kt_per;        // k-tiles per split (blockIdx.z); gridDim.z == 1 -> whole K
+    int n_mtiles, n_nblocks;
+    float *partial;    // split-K: raw accumulators [z][M][Cout]
 };
 
-template <int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(WM *WN * 64) void k_conv(const ConvK p) {
+// MODE 0: raw input, 1: per-(n,c) affine (GroupNorm), 2: affine + SiLU.
+// K is walked tap-major: for tap { for 16-channel chunk }, so inside a tap every pointer just advances by 16
+// floats; the tap change (9 times per launch) recomputes the per-row pointers and padding predicates.
+template <int WM, int WN, int MT, int NT, int MODE>
+__global__ __launch_bounds__(WM *WN * 64, (MT * NT <= 3) ? 4 : 2) void k_conv(const ConvK p) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHR = WM * WN * 64, LDA = 20;
     constexpr int A_F4 = BM * 4, B_F4 = BN * 4;
     constexpr int A_PER = (A_F4 + NTHR - 1) / NTHR, B_PER = (B_F4 + NTHR - 1) / NTHR;
     constexpr int STAGE = (BM + BN) * LDA;
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][STAGE] tiles, then [nimg][2][Cin] GroupNorm affine
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const long m0 = (long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int q = tid & 3;
+    // Workgroup -> (pixel tile, N block).  The dispatcher places workgroup b on XCD b % 8 (observed, speed only):
+    // give every XCD a contiguous run of work items, N block fastest, so the N blocks of a pixel tile and the
+    // vertically adjacent tiles (which re-read the same input rows for the 3x3 taps) share one XCD's L2.
+    const int total = p.n_mtiles * p.n_nblocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int mt_idx = wi / p.n_nblocks;
+    const long m0 = (long)mt_idx * BM;
+    const int n0 = (wi - mt_idx * p.n_nblocks) * BN;
     const int pad = p.ks >> 1;
+    const int ncc = p.Cin >> 4;
+    const int hw_out = p.Hout * p.Wout;
+    const int img0 = (int)(m0 / hw_out);          // first image this pixel tile touches
+    float *coef = lds + 2 * STAGE;
+    if (MODE != 0) {
+        const long mlast = (m0 + BM - 1 < p.M ? m0 + BM - 1 : p.M - 1);
+        const int nimg = (int)(mlast / hw_out) - img0 + 1;
+        for (int e = tid; e < nimg * p.Cin; e += NTHR) {
+            const int im = e / p.Cin, c = e - im * p.Cin;
+            coef[(im * 2) * p.Cin + c] = p.cA[(long)(img0 + im) * p.Cin + c];
+            coef[(im * 2 + 1) * p.Cin + c] = p.cB[(long)(img0 + im) * p.Cin + c];
+        }
+    }
 
-    // per-thread A rows (output pixels)
-    int a_n[A_PER], a_y[A_PER], a_x[A_PER];
-    bool a_ok[A_PER];
+    // float4 element e of a tile -> (row, quarter): 8 consecutive lanes take 8 consecutive rows of one
+    // quarter, which makes the ds_write_b128 groups bank-conflict free at a 20-dword row stride.
+    int a_n[A_PER], a_y[A_PER], a_x[A_PER], a_q[A_PER], a_row[A_PER];
+    bool a_in[A_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
         const int e = tid + i * NTHR;
-        const long P = m0 + (e >> 2);
-        a_ok[i] = (e < A_F4) && (P < p.M);
-        const long Pc = a_ok[i] ? P : 0;
-        const int hw = p.Hout * p.Wout;
-        a_n[i] = (int)(Pc / hw);
-        const int rem = (int)(Pc - (long)a_n[i] * hw);
+        a_row[i] = (e & 7) | ((e >> 5) << 3);
+        a_q[i] = (e >> 3) & 3;
+        const long P = m0 + a_row[i];
+        a_in[i] = (e < A_F4) && (P < p.M);
+        const long Pc = a_in[i] ? P : 0;
+        a_n[i] = (int)(Pc / hw_out);
+        const int rem = (int)(Pc - (long)a_n[i] * hw_out);
         a_y[i] = rem / p.Wout;
         a_x[i] = rem - a_y[i] * p.Wout;
     }
+    const float *pA[A_PER];   // current tap, channel 0 of this thread's quarter
+    int cofs[A_PER];          // LDS offset of this row's coefA quarter (coefB is Cin further)
+    bool okA[A_PER];
+    const float *pB[B_PER];
+    int b_row[B_PER];
+    bool b_in[B_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) cofs[i] = ((a_n[i] - img0) * 2) * p.Cin + a_q[i] * 4;
 
-    f32x4 ra[A_PER], rcA[A_PER], rcB[A_PER], rb[B_PER];
-    bool rv[A_PER];
+    const int nk_all = ncc * p.taps;
+    const int kt0 = blockIdx.z * p.kt_per;
+    const int nk = min(nk_all, kt0 + p.kt_per);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int e = tid + i * NTHR;
+        b_row[i] = (e & 7) | ((e >> 5) << 3);
+        const int gn = n0 + b_row[i];
+        b_in[i] = (e < B_F4) && gn < p.wrows;
+        pB[i] = p.w + (long)(b_in[i] ? gn : 0) * p.Ktot + (long)kt0 * 16 + ((e >> 3) & 3) * 4;
+    }
 
-    auto load_tile = [&](int kt) {
-        const int cc = kt / p.taps, tap = kt - cc * p.taps;
+    auto set_tap = [&](int tap) {
         const int ky = (p.ks == 3) ? tap / 3 : 0, kx = (p.ks == 3) ? tap - ky * 3 : 0;
-        const int c = cc * 16 + q * 4;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int iy, ix;
-            bool ok = a_ok[i];
+            bool ok = a_in[i];
             if (p.ups) {
                 const int vy = a_y[i] + ky - pad, vx = a_x[i] + kx - pad;
                 ok = ok && vy >= 0 && vy < 2 * p.Hin && vx >= 0 && vx < 2 * p.Win;
@@ -79,42 +123,56 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv(const ConvK p) {
                 iy = a_y[i] * p.stride + ky - pad; ix = a_x[i] * p.stride + kx - pad;
                 ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
             }
-            rv[i] = ok;
-            if (ok) {
-                ra[i] = *reinterpret_cast<const f32x4 *>(p.in + (((long)a_n[i] * p.Hin + iy) * p.Win + ix) * p.in_pitch + c);
-                if (p.cA) {
-                    rcA[i] = *reinterpret_cast<const f32x4 *>(p.cA + (long)a_n[i] * p.Cin + c);
-                    rcB[i] = *reinterpret_cast<const f32x4 *>(p.cB + (long)a_n[i] * p.Cin + c);
-                }
-            }
+            okA[i] = ok;
+            const long off = ok ? (((long)a_n[i] * p.Hin + iy) * p.Win + ix) * p.in_pitch : 0;   // padding: read pixel 0, zeroed later
+            pA[i] = p.in + off + a_q[i] * 4;
+        }
+    };
+    int tap_l = kt0 / ncc, cc_l = kt0 - tap_l * ncc;   // load cursor
+    set_tap(tap_l);
+
+    f32x4 ra[A_PER], rb[B_PER];
+    bool rv[A_PER];
+    int rc = 0;   // channel offset of the staged tile
+
+    auto load_tile = [&]() {
+        const int c = cc_l * 16;
+        rc = c;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            ra[i] = *reinterpret_cast<const f32x4 *>(pA[i] + c);
+            rv[i] = okA[i];
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
-            const int e = tid + i * NTHR;
-            const int gn = n0 + (e >> 2);
-            if (e < B_F4 && gn < p.wrows) rb[i] = *reinterpret_cast<const f32x4 *>(p.w + (long)gn * p.Ktot + (long)kt * 16 + q * 4);
-            else rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[i] = *reinterpret_cast<const f32x4 *>(pB[i]);
+            pB[i] += 16;
+        }
+        if (++cc_l == ncc) {
+            cc_l = 0;
+            if (++tap_l < p.taps) set_tap(tap_l);
         }
     };
     auto store_tile = [&](int buf) {
         float *base = lds + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            const int e = tid + i * NTHR;
-            if (e < A_F4) {
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (rv[i]) {
-                    v = ra[i];
-                    if (p.cA) v = v * rcA[i] + rcB[i];
-                    if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
-                }
-                *reinterpret_cast<f32x4 *>(base + (e >> 2) * LDA + q * 4) = v;
+            f32x4 v = ra[i];
+            if (MODE != 0) {
+                const f32x4 ca = *reinterpret_cast<const f32x4 *>(coef + cofs[i] + rc);
+                const f32x4 cb = *reinterpret_cast<const f32x4 *>(coef + cofs[i] + p.Cin + rc);
+                v = v * ca + cb;
             }
+            if (MODE == 2) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+            if (!rv[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (A_F4 % NTHR == 0 || tid + i * NTHR < A_F4)
+                *reinterpret_cast<f32x4 *>(base + a_row[i] * LDA + a_q[i] * 4) = v;
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int e = tid + i * NTHR;
-            if (e < B_F4) *reinterpret_cast<f32x4 *>(base + (BM + (e >> 2)) * LDA + q * 4) = rb[i];
+            if (B_F4 % NTHR == 0 || e < B_F4)
+                *reinterpret_cast<f32x4 *>(base + (BM + b_row[i]) * LDA + ((e >> 3) & 3) * 4) = b_in[i] ? rb[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -126,13 +184,13 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv(const ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (p.Cin / 16) * p.taps;
-    load_tile(0);
+    load_tile();
+    if (MODE != 0) __syncthreads();   // the coefficient table above is read by store_tile
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < nk) load_tile();
         const float *base = lds + buf * STAGE;
         f32x4 a[MT][2], b[NT][2];
 #pragma unroll
@@ -159,7 +217,23 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv(const ConvK p) {
     }
 
     // epilogue: lane holds channel (lane&31) of pixels (r&3)+8*(r>>2)+4*half
-    const int hw = p.Hout * p.Wout;
+    if (p.partial) {  // split-K: raw partial sums, finished by k_splitk_finish
+        float *dst = p.partial + (long)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * NT * 32 + j * 32 + (lane & 31);
+                if (n >= p.Cout) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long m = m0 + wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < p.M) dst[m * p.Cout + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    const int hw = hw_out;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -184,6 +258,27 @@ __global__ __launch_bounds__(WM *WN * 64) void k_conv(const ConvK p) {
         }
 }
 
+// split-K epilogue: sum the slabs in a fixed order (deterministic), then bias / residual / second output
+__global__ void k_splitk_finish(const ConvK p, int splits) {
+    const long total = p.M * p.Cout;
+    const int hw = p.Hout * p.Wout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / p.Cout;
+        const int n = (int)(i - m * p.Cout);
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += p.partial[(long)z * total + i];
+        v += p.bias ? p.bias[n] : 0.f;
+        if (p.res) v += p.res[m * p.res_pitch + n];
+        if (p.out_nchw) {
+            const long img = m / hw, rem = m - img * hw;
+            p.out[(img * p.Cout + n) * hw + rem] = v;
+        } else {
+            p.out[m * p.out_pitch + n] = v;
+        }
+        if (p.out2) p.out2[m * p.out2_pitch + n] = v + p.res2[m * p.res2_pitch + n];
+    }
+}
+
 __global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, int ks, int rows, float *__restrict__ dst) {
     const int taps = ks * ks;
     const long Ktot = (long)Cin_pad * taps;
@@ -193,7 +288,8 @@ __global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int 
         const long k = i - (long)o * Ktot;
         const int c16 = (int)(k & 15);
         const long t = k >> 4;
-        const int tap = (int)(t % taps), cc = (int)(t / taps);
+        const int ncc = Cin_pad >> 4;
+        const int cc = (int)(t % ncc), tap = (int)(t / ncc);   // tap-major, like k_conv walks K
         const int cin = cc * 16 + c16;
         float v = 0.f;
         if (o < Cout && cin < Cin) v = w[((long)o * Cin + cin) * taps + tap];
@@ -471,6 +567,8 @@ __global__ void k_prep_inputs(const float *__restrict__ x, const float *__restri
 // ---------------------------------------------------------------------------------------------
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+size_t conv_splitk_ws_bytes() { return (size_t)64 << 20; }
+
 size_t conv_packed_floats(int Cout, int Cin_pad, int ks) { return (size_t)round_up(Cout, 64) * Cin_pad * ks * ks; }
 
 int conv_pack_weights(const float *w, int Cout, int Cin, int Cin_pad, int ks, float *packed, hipStream_t st) {
@@ -501,16 +599,59 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     p.M = (long)a.out.N * a.out.H * a.out.W;
     const long M = p.M;
     const int cpad = p.wrows;
-    const long big_blocks = ((M + 127) / 128) * (cpad / 192);
-    if (cpad % 192 == 0 && big_blocks >= 192) {
-        dim3 grid((unsigned)((M + 127) / 128), cpad / 192);
-        hipLaunchKernelGGL((k_conv<2, 2, 2, 3>), grid, dim3(256), 0, st, p);
-    } else if (a.Cout <= 32) {
-        dim3 grid((unsigned)((M + 127) / 128), 1);
-        hipLaunchKernelGGL((k_conv<4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+    const int nk = (a.in.C / 16) * p.taps;
+    // tile configs: 0 = 128x96 (4 waves of 32x96: 48 accumulators -> 4 waves/SIMD), 1 = 128x32, 2 = 64x64
+    const long big_blocks = ((M + 127) / 128) * (cpad / 96);
+    int cfg;
+    long blocks;
+    if (cpad % 96 == 0 && big_blocks >= 384) { cfg = 0; blocks = big_blocks; }
+    else if (a.Cout <= 32) { cfg = 1; blocks = (M + 127) / 128; }
+    else { cfg = 2; blocks = ((M + 63) / 64) * (cpad / 64); }
+    int splits = 1;
+    if (a.splitk_ws && blocks < 384 && nk >= 16) {
+        splits = (int)((640 + blocks - 1) / blocks);
+        if (splits > nk / 8) splits = nk / 8;
+        if (splits > 16) splits = 16;
+        while (splits > 1 && (size_t)splits * M * a.Cout * sizeof(float) > a.splitk_ws_bytes) --splits;
+        if (splits < 1) splits = 1;
+    }
+    p.kt_per = (nk + splits - 1) / splits;
+    splits = (nk + p.kt_per - 1) / p.kt_per;
+    p.partial = splits > 1 ? a.splitk_ws : nullptr;
+    const int mode = a.coefA ? (a.act ? 2 : 1) : 0;
+    HL_REQUIRE(a.coefA || !a.act, "conv2d: SiLU without the GroupNorm affine is not used by the UNet");
+    const long hw_o = (long)a.out.H * a.out.W;
+#define HL_CONV_GO(WM_, WN_, MT_, NT_, GRID)                                                         \
+    do {                                                                                             \
+        constexpr int BM_ = WM_ * MT_ * 32, BN_ = WN_ * NT_ * 32;                                    \
+        const int nimg = (int)((BM_ + hw_o - 1) / hw_o) + 1;                                         \
+        const size_t shm = ((size_t)2 * (BM_ + BN_) * 20 + (mode ? (size_t)nimg * 2 * a.in.C : 0)) * sizeof(float); \
+        HL_REQUIRE(shm <= 160 * 1024, "conv2d: LDS request %zu too large", shm);                     \
+        if (mode == 0) hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 0>), GRID, dim3(256), shm, st, p);      \
+        else if (mode == 1) hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 1>), GRID, dim3(256), shm, st, p); \
+        else hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 2>), GRID, dim3(256), shm, st, p);                \
+    } while (0)
+    if (cfg == 0) {
+        p.n_mtiles = (int)((M + 127) / 128); p.n_nblocks = cpad / 96;
+        dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
+        HL_CONV_GO(4, 1, 1, 3, grid);
+    } else if (cfg == 1) {
+        p.n_mtiles = (int)((M + 127) / 128); p.n_nblocks = 1;
+        dim3 grid((unsigned)p.n_mtiles, 1, splits);
+        HL_CONV_GO(4, 1, 1, 1, grid);
     } else {
-        dim3 grid((unsigned)((M + 63) / 64), cpad / 64);
-        hipLaunchKernelGGL((k_conv<2, 2, 1, 1>), grid, dim3(256), 0, st, p);
+        p.n_mtiles = (int)((M + 63) / 64); p.n_nblocks = cpad / 64;
+        dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
+        HL_CONV_GO(2, 2, 1, 1, grid);
+    }
+#undef HL_CONV_GO
+    if (splits > 1) {
+        int rc = check_launch("k_conv");
+        if (rc) return rc;
+        long g = (M * a.Cout + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)g), dim3(256), 0, st, p, splits);
+        return check_launch("k_splitk_finish");
     }
     return check_launch("k_conv");
 }

@@ -31,7 +31,8 @@ def hip_conv(x, w, b, ks, stride=1, ups=0, cA=None, cB=None, silu=0, res=None):
     Hv, Wv = (2 * H, 2 * W) if ups else (H, W)
     Ho, Wo = (Hv + 2 * (ks // 2) - ks) // stride + 1, (Wv + 2 * (ks // 2) - ks) // stride + 1
     out = torch.empty((N, Ho, Wo, Cout), device=dev)
-    scratch = torch.empty(((Cout + 63) // 64 * 64) * C * ks * ks + 64, device=dev)
+    # packed weights + room for split-K partial sums (taken for shapes that would under-fill the chip)
+    scratch = torch.empty(((Cout + 63) // 64 * 64) * C * ks * ks + 64 + (8 << 20), device=dev)
     d = lambda t: None if t is None else t.contiguous().to(dev)  # noqa: E731
     wd, bd, cAd, cBd = d(w), d(b), d(cA), d(cB)
     rd = d(nhwc(res)) if res is not None else None
@@ -45,12 +46,15 @@ def hip_conv(x, w, b, ks, stride=1, ups=0, cA=None, cB=None, silu=0, res=None):
 @pytest.mark.parametrize("N,C,H,W,Cout,ks,stride,ups", [
     (2, 32, 16, 16, 64, 3, 1, 0),      # small-tile config
     (1, 192, 32, 32, 192, 3, 1, 0),    # production channel count
-    (4, 192, 64, 64, 192, 3, 1, 0),    # big-tile config (128x192), M=16384
+    (4, 192, 64, 64, 192, 3, 1, 0),    # M=16384
+    (2, 192, 128, 128, 192, 3, 1, 0),  # main tile config (128x96, 4 waves/SIMD), 512 workgroups, XCD remap
+    (1, 96, 160, 96, 96, 3, 1, 0),     # main tile config with a ragged last pixel tile (M=15360) and Cout=96
     (2, 64, 16, 16, 64, 3, 2, 0),      # Downsample (unet.py:100)
     (2, 64, 8, 8, 64, 3, 1, 1),        # Upsample: nearest x2 then conv (unet.py:77-79)
     (2, 96, 12, 20, 128, 1, 1, 0),     # 1x1 skip / zero-conv, ragged M
     (1, 64, 16, 16, 27, 3, 1, 0),      # 27 output channels (N tile 32)
-    (2, 384, 8, 8, 1152, 1, 1, 0),     # qkv projection
+    (2, 384, 8, 8, 1152, 1, 1, 0),     # qkv projection (split-K x3)
+    (4, 768, 8, 8, 768, 3, 1, 0),      # 8x8 level of the production UNet: K=6912, split-K
 ])
 def test_conv_matches_torch(N, C, H, W, Cout, ks, stride, ups):
     g = torch.Generator().manual_seed(N * 1000 + C + H + Cout)
