@@ -301,7 +301,9 @@ __global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int 
 // GroupNorm statistics
 // ---------------------------------------------------------------------------------------------
 // grid (nchunks, N); blockDim = (C/4) * k threads; thread owns one float4 channel column.
-__global__ void k_gn_partial(const float *__restrict__ x, long pitch, int HW, int C, int nchunks, float *__restrict__ partial) {
+__global__ void k_gn_partial(const float *__restrict__ x, long pitch, int HW, int C, int nchunks, float *__restrict__ partial,
+                             const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ emb,
+                             long emb_pitch, float *__restrict__ cA, float *__restrict__ cB) {
     extern __shared__ float sh[];  // [k][C] sums then [k][C] sumsq
     const int cq = C >> 2;
     const int k = blockDim.x / cq;
@@ -324,12 +326,35 @@ __global__ void k_gn_partial(const float *__restrict__ x, long pitch, int HW, in
     }
     __syncthreads();
     const int cg = C / 32;
+    __shared__ float gs[64];
     if (threadIdx.x < 64) {
         const int g = threadIdx.x & 31, which = threadIdx.x >> 5;
         float t = 0.f;
         for (int r = 0; r < k; ++r)
             for (int c = 0; c < cg; ++c) t += sh[(long)(which * k + r) * C + g * cg + c];
         partial[(((long)n * nchunks + chunk) * 32 + g) * 2 + which] = t;
+        gs[which * 32 + g] = t;
+    }
+    if (nchunks != 1 || cA == nullptr) return;
+    // one workgroup saw the whole image: finish the affine here (saves the k_gn_coef launch)
+    __syncthreads();
+    const double cnt = (double)HW * cg;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cg;
+        const double mean = (double)gs[g] / cnt;
+        double var = (double)gs[32 + g] / cnt - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        float a = rstd * gamma[c];
+        float b = beta[c] - (float)mean * a;
+        if (emb) {
+            const float sc = 1.f + emb[(long)n * emb_pitch + c];
+            const float sf = emb[(long)n * emb_pitch + C + c];
+            a = a * sc;
+            b = b * sc + sf;
+        }
+        cA[(long)n * C + c] = a;
+        cB[(long)n * C + c] = b;
     }
 }
 
@@ -600,16 +625,20 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     const long M = p.M;
     const int cpad = p.wrows;
     const int nk = (a.in.C / 16) * p.taps;
-    // tile configs: 0 = 128x96 (4 waves of 32x96: 48 accumulators -> 4 waves/SIMD), 1 = 128x32, 2 = 64x64
-    const long big_blocks = ((M + 127) / 128) * (cpad / 96);
+    // tile configs: 0 = 128x96 (4 waves of 32x96: 48 accumulators -> 4 waves/SIMD, 4 workgroups/CU = 1024 slots),
+    // 1 = 128x32 (Cout <= 32), 2 = 64x64.  Small-M layers keep the efficient main tile and split K instead
+    // (deterministic slabs + k_splitk_finish) until the grid covers the chip.
+    const long main_blocks = ((M + 127) / 128) * (cpad / 96);
+    const int max_splits = a.splitk_ws ? (nk / 8 < 16 ? nk / 8 : 16) : 1;
     int cfg;
     long blocks;
-    if (cpad % 96 == 0 && big_blocks >= 384) { cfg = 0; blocks = big_blocks; }
+    if (cpad % 96 == 0 && main_blocks * (max_splits > 0 ? max_splits : 1) >= 192) { cfg = 0; blocks = main_blocks; }
     else if (a.Cout <= 32) { cfg = 1; blocks = (M + 127) / 128; }
     else { cfg = 2; blocks = ((M + 63) / 64) * (cpad / 64); }
     int splits = 1;
-    if (a.splitk_ws && blocks < 384 && nk >= 16) {
-        splits = (int)((640 + blocks - 1) / blocks);
+    const long target = cfg == 2 ? 1280 : 1024;
+    if (a.splitk_ws && blocks <= target / 2 && nk >= 16) {
+        splits = (int)(target / blocks);
         if (splits > nk / 8) splits = nk / 8;
         if (splits > 16) splits = 16;
         while (splits > 1 && (size_t)splits * M * a.Cout * sizeof(float) > a.splitk_ws_bytes) --splits;
@@ -656,7 +685,8 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     return check_launch("k_conv");
 }
 
-static int gn_chunks(int HW) {
+static int gn_chunks(int HW, int C) {
+    if ((long)HW * C <= 524288) return 1;   // one 1024-thread workgroup per image: statistics + affine in one launch
     int c = HW / 256;
     if (c < 1) c = 1;
     if (c > 128) c = 128;
@@ -669,15 +699,16 @@ int groupnorm_coef(const View &x, const float *gamma, const float *beta, const f
     HL_REQUIRE(x.p && gamma && beta && cA && cB && scratch, "groupnorm_coef: null argument");
     HL_REQUIRE(x.C % 32 == 0, "GroupNorm32 needs C %% 32 == 0 (C=%d)", x.C);
     const int HW = x.H * x.W, cq = x.C / 4;
-    const int nch = gn_chunks(HW);
-    int k = 512 / cq;
+    const int nch = gn_chunks(HW, x.C);
+    int k = (nch == 1 ? 1024 : 512) / cq;
     if (k < 1) k = 1;
     HL_REQUIRE(cq <= 1024, "groupnorm_coef: C too large");
     const int threads = cq * k > 64 ? cq * k : 64;
     const size_t shm = (size_t)2 * k * x.C * sizeof(float);
-    hipLaunchKernelGGL(k_gn_partial, dim3(nch, x.N), dim3(threads), shm, st, x.p, x.pitch, HW, x.C, nch, scratch);
+    hipLaunchKernelGGL(k_gn_partial, dim3(nch, x.N), dim3(threads), shm, st, x.p, x.pitch, HW, x.C, nch, scratch, gamma, beta, emb,
+                       emb_pitch, cA, cB);
     int rc = check_launch("k_gn_partial");
-    if (rc) return rc;
+    if (rc || nch == 1) return rc;
     hipLaunchKernelGGL(k_gn_coef, dim3(x.N), dim3(256), 0, st, scratch, nch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
     return check_launch("k_gn_coef");
 }
