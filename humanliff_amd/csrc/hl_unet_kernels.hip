@@ -314,7 +314,18 @@ __global__ void k_gn_partial(const float *__restrict__ x, long pitch, int HW, in
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, ss = f32x4{0.f, 0.f, 0.f, 0.f};
     if (prow < k) {
         const float *base = x + (long)n * HW * pitch + c4 * 4;
-        for (int pp = p0 + prow; pp < p1; pp += k) {
+        int pp = p0 + prow;
+        for (; pp + 3 * k < p1; pp += 4 * k) {   // four independent loads in flight
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(base + (long)pp * pitch);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(base + (long)(pp + k) * pitch);
+            const f32x4 v2 = *reinterpret_cast<const f32x4 *>(base + (long)(pp + 2 * k) * pitch);
+            const f32x4 v3 = *reinterpret_cast<const f32x4 *>(base + (long)(pp + 3 * k) * pitch);
+            s += v0; ss += v0 * v0;
+            s += v1; ss += v1 * v1;
+            s += v2; ss += v2 * v2;
+            s += v3; ss += v3 * v3;
+        }
+        for (; pp < p1; pp += k) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (long)pp * pitch);
             s += v;
             ss += v * v;
@@ -448,17 +459,17 @@ __global__ void k_timestep_embedding(const int64_t *__restrict__ t, const float 
 // O^T[c][q]  += V^T[c][key] . P^T[key][q]  (A = V tile from LDS read "down the keys", B = P^T = the
 // S^T accumulator itself after softmax - same register-resident trick as the render MLP)
 // ---------------------------------------------------------------------------------------------
-template <int CH>
-__global__ __launch_bounds__(256, 1) void k_attention(const float *__restrict__ qkv, int T, int C, int heads, float *__restrict__ out) {
+template <int CH, int WPB>
+__global__ __launch_bounds__(WPB * 64, 1) void k_attention(const float *__restrict__ qkv, int T, int C, int heads, float *__restrict__ out) {
     constexpr int CT = CH / 32;   // channel tiles of the output
     constexpr int KS = CH / 2;    // k-steps of the QK^T product
     constexpr int LDK = CH + 1;   // odd row stride: rows differ per lane in the A reads
     __shared__ float sK[32 * LDK];
-    __shared__ float sV[32 * CH];
+    __shared__ __attribute__((aligned(16))) float sV[32 * CH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int nh = blockIdx.y;  // n*heads + head
     const int n = nh / heads, head = nh % heads;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int q0 = (blockIdx.x * WPB + wave) * 32;
     const float scale = 1.f / sqrtf(sqrtf((float)CH));
     const long pitch = 3L * C;
     const float *base = qkv + (long)n * T * pitch + (long)head * 3 * CH;
@@ -478,11 +489,14 @@ __global__ __launch_bounds__(256, 1) void k_attention(const float *__restrict__ 
 
     for (int k0 = 0; k0 < T; k0 += 32) {
         __syncthreads();
-        for (int e = tid; e < 32 * CH; e += 256) {
-            const int key = e / CH, c = e - key * CH;
+        for (int e = tid; e < 32 * (CH / 4); e += WPB * 64) {   // 16-byte global loads; K rows keep an odd LDS stride
+            const int key = e / (CH / 4), c = (e - key * (CH / 4)) * 4;
             const int kk = min(k0 + key, T - 1);
-            sK[key * LDK + c] = base[(long)kk * pitch + CH + c] * scale;
-            sV[key * CH + c] = base[(long)kk * pitch + 2 * CH + c];
+            const f32x4 kv = *reinterpret_cast<const f32x4 *>(base + (long)kk * pitch + CH + c);
+            const f32x4 vv = *reinterpret_cast<const f32x4 *>(base + (long)kk * pitch + 2 * CH + c);
+            float *dk = sK + key * LDK + c;
+            dk[0] = kv[0] * scale; dk[1] = kv[1] * scale; dk[2] = kv[2] * scale; dk[3] = kv[3] * scale;
+            *reinterpret_cast<f32x4 *>(sV + key * CH + c) = vv;
         }
         __syncthreads();
         f32x16 st;
@@ -736,19 +750,31 @@ int timestep_embedding(const int64_t *t, const float *tf, int B, int dim, float 
 int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipStream_t st) {
     HL_REQUIRE(qkv && out && heads > 0 && C % heads == 0, "attention: bad argument");
     const int ch = C / heads;
-    dim3 grid((T + 127) / 128, N * heads);
+    // 32 queries per wave; pick waves per workgroup so the grid has at least ~256 workgroups (K/V tiles are
+    // shared through LDS inside a workgroup, and are L2-resident across workgroups)
+    const int qtiles = (T + 31) / 32;
+    int wpb = 4;
+    while (wpb > 1 && (long)((qtiles + wpb - 1) / wpb) * N * heads < 256) wpb >>= 1;
+    dim3 grid((qtiles + wpb - 1) / wpb, N * heads);
+#define HL_ATT(CH_)                                                                                         \
+    do {                                                                                                    \
+        if (wpb == 4) hipLaunchKernelGGL((k_attention<CH_, 4>), grid, dim3(256), 0, st, qkv, T, C, heads, out);      \
+        else if (wpb == 2) hipLaunchKernelGGL((k_attention<CH_, 2>), grid, dim3(128), 0, st, qkv, T, C, heads, out); \
+        else hipLaunchKernelGGL((k_attention<CH_, 1>), grid, dim3(64), 0, st, qkv, T, C, heads, out);                \
+    } while (0)
     switch (ch) {
-        case 32: hipLaunchKernelGGL(k_attention<32>, grid, dim3(256), 0, st, qkv, T, C, heads, out); break;
-        case 64: hipLaunchKernelGGL(k_attention<64>, grid, dim3(256), 0, st, qkv, T, C, heads, out); break;
-        case 96: hipLaunchKernelGGL(k_attention<96>, grid, dim3(256), 0, st, qkv, T, C, heads, out); break;
-        case 128: hipLaunchKernelGGL(k_attention<128>, grid, dim3(256), 0, st, qkv, T, C, heads, out); break;
-        case 192: hipLaunchKernelGGL(k_attention<192>, grid, dim3(256), 0, st, qkv, T, C, heads, out); break;
+        case 32: HL_ATT(32); break;
+        case 64: HL_ATT(64); break;
+        case 96: HL_ATT(96); break;
+        case 128: HL_ATT(128); break;
+        case 192: HL_ATT(192); break;
         default: {
             HL_REQUIRE((size_t)T * 4 * sizeof(float) <= 60000, "attention: T=%d too long for the generic kernel", T);
             hipLaunchKernelGGL(k_attention_generic, dim3((T + 3) / 4, N * heads), dim3(256), (size_t)T * 4 * sizeof(float), st,
                                qkv, T, C, heads, ch, out);
         }
     }
+#undef HL_ATT
     return check_launch("k_attention");
 }
 
