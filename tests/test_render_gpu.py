@@ -156,3 +156,24 @@ def test_bad_arguments_raise(dev):
                  i["far"][None].to(dev), i["planes"].to(dev), 16, False, n_samples=32)
     with pytest.raises(NotImplementedError):
         Renderer(use_canonical_space=True, triplane_ch=27).render(tp, None, None, None, None, None, None, i["planes"])
+
+
+def test_density_grid_matches_oracle(dev):
+    """extract_geometry's density lattice on the coarse kernel vs the oracle MLP at the
+    reference's meshgrid points (renderer.py:297-318); ragged resolution."""
+    from oracle import render_oracle as ro
+    from humanliff_amd import synthetic as syn
+    planes = syn.triplane(seed=11, H=64, W=64)
+    mlp = syn.render_mlp_state(3, gain=2.0)
+    r = make_renderer(mlp, dev)
+    bounds = torch.tensor(syn.WORLD_BOUNDS)
+    N = 21
+    u = r.density_grid({"world_bounds": bounds[None].to(dev)}, planes.to(dev), resolution=N, rays_per_launch=200).cpu()
+    X, Y, Z = [torch.linspace(float(bounds[0, k]), float(bounds[1, k]), N) for k in range(3)]
+    xx, yy, zz = torch.meshgrid(X, Y, Z, indexing="ij")
+    pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=1)
+    want = -ro.mlp(mlp, ro.plane_features(planes[0], pts, bounds)).reshape(N, N, N)
+    assert u.shape == (N, N, N)
+    assert (u - want).abs().max() < 2e-5
+    with pytest.raises(ImportError):
+        r.extract_geometry({"world_bounds": bounds[None].to(dev)}, planes.to(dev), resolution=8)
