@@ -58,6 +58,7 @@ SIGNATURES = {
     "hl_unet_destroy": (None, [_p]),
     "hl_unet_workspace_bytes": (_sz, [_p, _i, _i, _i]),
     "hl_unet_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "hl_unet_set_overlap": (_i, [_p, _i]),
     "hl_unet_profile": (_i, [_p, _i]),
     "hl_unet_profile_read": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "hl_diffusion_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _p]),

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <string>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "hl_unet_kernels.h"
@@ -74,13 +75,24 @@ struct Net {
     bool dry = true;        // only size the packed buffer
     hipStream_t st = nullptr;
     std::string err;
+    // the control encoder runs on its own stream next to the main encoder (they only meet at the skip sums)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_block;   // main encoder block i finished (its output feeds the skip sum)
+    bool overlap = true;
     // optional per-category HIP-event timing of one forward (bench.py roofline leg)
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;
     struct Span { int cat; size_t a, b; double flops; };
     std::vector<Span> spans;
     size_t ev_used = 0;
-    ~Net() { for (auto e : ev_pool) hipEventDestroy(e); }
+    ~Net() {
+        for (auto e : ev_pool) hipEventDestroy(e);
+        for (auto e : ev_block) hipEventDestroy(e);
+        if (ev_fork) hipEventDestroy(ev_fork);
+        if (ev_join) hipEventDestroy(ev_join);
+        if (side) hipStreamDestroy(side);
+    }
     size_t next_event() {
         if (ev_used == ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); ev_pool.push_back(e); }
         return ev_used++;
@@ -287,6 +299,7 @@ struct Exec {
     float *emb_all = nullptr;
     float *gn_scratch = nullptr;
     float *splitk_ws = nullptr;
+    float *gn_scratch2 = nullptr, *splitk_ws2 = nullptr;   // second set for the side stream
     int rc = 0;
 
     float *alloc(size_t floats) {
@@ -395,6 +408,8 @@ struct Exec {
         const hl_unet_cfg &c = n.cfg;
         gn_scratch = alloc(hl::gn_scratch_floats(B));
         splitk_ws = alloc(hl::conv_splitk_ws_bytes() / sizeof(float));
+        gn_scratch2 = alloc(hl::gn_scratch_floats(B));
+        splitk_ws2 = alloc(hl::conv_splitk_ws_bytes() / sizeof(float));
         // embeddings (unet.py:564, 584-586) and all ResBlock emb_layers in one stacked product
         float *temb = alloc((size_t)B * c.model_channels), *e1 = alloc((size_t)B * n.E), *emb = alloc((size_t)B * n.E);
         emb_all = alloc((size_t)B * n.emb_total);
@@ -424,17 +439,26 @@ struct Exec {
             }
         }
         auto first_part = [&](size_t j, int C) { View v = cat[j]; v.C = C; return v; };
-        // main encoder
+        // main encoder + middle on the caller's stream; control encoder on the side stream (unet.py:588-602).
+        // They are independent except that control block i's zero-conv adds the main encoder's hs[i].
+        const bool fork = run && c.controlnet && n.overlap && !n.prof && n.side;
+        hipStream_t main_st = st;
+        if (fork) {
+            hipEventRecord(n.ev_fork, main_st);
+            hipStreamWaitEvent(n.side, n.ev_fork, 0);
+        }
         std::vector<View> hs(nb);
         View h = xin;
         for (size_t i = 0; i < nb; ++i) {
             hs[i] = plain(n.in_blocks[i].ds_out, n.in_blocks[i].Cout);
             block(n.in_blocks[i], h, hs[i]);
+            if (fork) hipEventRecord(n.ev_block[i], main_st);
             h = hs[i];
         }
         block(n.middle, h, first_part(0, n.middle.Cout));
-        // control branch (unet.py:594-602): zero-conv output feeds the next block AND (+ encoder skip) the decoder
+        // control branch: zero-conv output feeds the next block AND (+ encoder skip) the decoder
         if (c.controlnet) {
+            if (fork) { st = n.side; std::swap(gn_scratch, gn_scratch2); std::swap(splitk_ws, splitk_ws2); }
             View hc = xsum;
             for (size_t i = 0; i < nb; ++i) {
                 View tmp = plain(n.cond_blocks[i].ds_out, n.cond_blocks[i].Cout);
@@ -442,9 +466,15 @@ struct Exec {
                 View pj = plain(n.cond_blocks[i].ds_out, n.cond_blocks[i].Cout);
                 const size_t j = nb - 1 - i;
                 const int Ch = cat[j].C - hs[i].C;
+                if (fork) hipStreamWaitEvent(n.side, n.ev_block[i], 0);
                 conv(n.convs[n.proj_cond[i]], tmp, pj, 1, 0, nullptr, nullptr, 0, nullptr, 0,
                      run ? cat[j].p + Ch : nullptr, cat[j].pitch, hs[i].p, hs[i].pitch);
                 hc = pj;
+            }
+            if (fork) {
+                hipEventRecord(n.ev_join, n.side);
+                st = main_st; std::swap(gn_scratch, gn_scratch2); std::swap(splitk_ws, splitk_ws2);
+                hipStreamWaitEvent(main_st, n.ev_join, 0);
             }
         } else if (run) {
             for (size_t i = 0; i < nb; ++i) {
@@ -508,7 +538,20 @@ int hl_unet_create(const hl_unet_cfg *cfg, int n_tensors, const char *const *nam
         delete n;
         return rc;
     }
+    if (n->cfg.controlnet) {
+        hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
+        hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming);
+        hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming);
+        n->ev_block.resize(n->in_blocks.size());
+        for (auto &e : n->ev_block) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    }
     *handle = n;
+    return HL_OK;
+}
+
+int hl_unet_set_overlap(void *handle, int enable) {
+    HL_REQUIRE(handle, "hl_unet_set_overlap: null handle");
+    static_cast<Net *>(handle)->overlap = enable != 0;
     return HL_OK;
 }
 

@@ -369,24 +369,32 @@ __global__ void k_gn_partial(const float *__restrict__ x, long pitch, int HW, in
     }
 }
 
-// grid N, block C threads (looped): A = rstd*gamma [*(1+scale)], B = (beta - mean*rstd*gamma)[*(1+scale) + shift]
-__global__ void k_gn_coef(const float *__restrict__ partial, int nchunks, int HW, int C, const float *__restrict__ gamma,
-                          const float *__restrict__ beta, const float *__restrict__ emb, long emb_pitch,
-                          float *__restrict__ cA, float *__restrict__ cB) {
-    const int n = blockIdx.x;
+// grid (32 groups, N), one wave each: lanes sum the chunk partials (double), then lanes < C/32 write
+// A = rstd*gamma [*(1+scale)], B = (beta - mean*rstd*gamma) [*(1+scale) + shift] for the group's channels
+__global__ __launch_bounds__(64) void k_gn_coef(const float *__restrict__ partial, int nchunks, int HW, int C,
+                                                const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                const float *__restrict__ emb, long emb_pitch, float *__restrict__ cA,
+                                                float *__restrict__ cB) {
+    const int g = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
     const int cg = C / 32;
+    double s = 0.0, ss = 0.0;
+    for (int k = lane; k < nchunks; k += 64) {
+        const float *pp = partial + (((long)n * nchunks + k) * 32 + g) * 2;
+        s += (double)pp[0];
+        ss += (double)pp[1];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        s += __shfl_xor(s, d);
+        ss += __shfl_xor(ss, d);
+    }
     const double cnt = (double)HW * cg;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / cg;
-        double s = 0.0, ss = 0.0;
-        for (int k = 0; k < nchunks; ++k) {
-            s += (double)partial[(((long)n * nchunks + k) * 32 + g) * 2 + 0];
-            ss += (double)partial[(((long)n * nchunks + k) * 32 + g) * 2 + 1];
-        }
-        const double mean = s / cnt;
-        double var = ss / cnt - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    for (int j = lane; j < cg; j += 64) {
+        const int c = g * cg + j;
         float a = rstd * gamma[c];
         float b = beta[c] - (float)mean * a;
         if (emb) {
@@ -723,7 +731,7 @@ int groupnorm_coef(const View &x, const float *gamma, const float *beta, const f
                        emb_pitch, cA, cB);
     int rc = check_launch("k_gn_partial");
     if (rc || nch == 1) return rc;
-    hipLaunchKernelGGL(k_gn_coef, dim3(x.N), dim3(256), 0, st, scratch, nch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
+    hipLaunchKernelGGL(k_gn_coef, dim3(32, x.N), dim3(64), 0, st, scratch, nch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
     return check_launch("k_gn_coef");
 }
 

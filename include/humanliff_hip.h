@@ -142,6 +142,12 @@ size_t hl_unet_workspace_bytes(void *handle, int B, int H, int W);
 int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float *t_float, const float *x_cond,
                     const int64_t *y, float *out, int B, int H, int W, void *workspace, void *stream);
 
+/* The control encoder (input_blocks_cond) is independent of the main encoder up to the skip sums; by default
+ * hl_unet_forward runs it on an internal second HIP stream, forked from and joined back into the caller's
+ * stream with events (the low-resolution layers of the two branches then fill the chip together).
+ * enable = 0 issues everything on the caller's stream. */
+int hl_unet_set_overlap(void *handle, int enable);
+
 /* Instrumentation for the roofline measurement (bench.py): with profiling enabled every kernel launch
  * of hl_unet_forward is bracketed by HIP events on the caller's stream.  hl_unet_profile_read waits for
  * them and returns, per category {0 conv/GEMM, 1 GroupNorm, 2 attention, 3 embeddings+prep}, the summed
