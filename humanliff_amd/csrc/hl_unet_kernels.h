@@ -14,7 +14,7 @@ struct View {
 
 struct ConvArgs {
     View in;             // C must be a multiple of 16 (pad channels are zero and have zero weights)
-    const float *w;      // packed [Cout_pad][Ktot], K index = (tap * Cin/16 + cin/16) * 16 + cin%16
+    const float *w;      // packed [Cout_pad][Ktot], K order = kt_decode() in hl_unet_kernels.hip (groups of two 16-channel chunks, taps inside)
     const float *bias;   // [Cout] or null
     int Cout;            // real output channels
     int ks;              // 1 or 3 (pad = ks/2)

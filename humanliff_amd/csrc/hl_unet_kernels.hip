@@ -20,6 +20,21 @@ __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_r
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM convolution
 // ---------------------------------------------------------------------------------------------
+// Order in which K is walked (and packed): groups of KG 16-channel chunks; inside a group all taps; inside a
+// tap the group's chunks.  With KG = 2 a pixel's full 128-byte line (32 channels) is consumed by two consecutive
+// k-tiles and the nine taps of a group (which re-read shifted copies of the same lines) are only 2*9 k-tiles
+// apart, so they hit in the XCD's L2 - while the tap (and with it every padding predicate and the uniform
+// address delta) changes only every KG k-tiles.
+constexpr int KG = 4;
+__host__ __device__ inline void kt_decode(int kt, int ncc, int taps, int &cc, int &tap) {
+    const int per = KG * taps;
+    const int cg = kt / per, r = kt - cg * per;
+    const int g = (ncc - cg * KG) < KG ? (ncc - cg * KG) : KG;   // chunks in this group (last one may be short)
+    // full groups come first, so r indexes inside this group only if cg is the short one at the end
+    tap = r / g;
+    cc = cg * KG + (r - tap * g);
+}
+
 struct ConvK {
     const float *in; long in_pitch; int N, Hin, Win, Cin;
     int Hout, Wout, ks, stride, ups, taps;
@@ -34,9 +49,9 @@ struct ConvK {
 };
 
 // MODE 0: raw input, 1: per-(n,c) affine (GroupNorm), 2: affine + SiLU.
-// K is walked tap-major: for tap { for 16-channel chunk }, so inside a tap every pointer just advances by 16
-// floats; the tap change (9 times per launch) recomputes the per-row pointers and padding predicates.
-template <int WM, int WN, int MT, int NT, int MODE>
+// K order: see kt_decode.  Inside a tap every pointer just advances by 16 floats; a tap change recomputes the
+// per-row pointers and padding predicates (set_tap).
+template <int WM, int WN, int MT, int NT, int MODE, bool UPS>
 __global__ __launch_bounds__(WM *WN * 64, (MT * NT <= 3) ? 4 : 2) void k_conv(const ConvK p) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHR = WM * WN * 64, LDA = 20;
     constexpr int A_F4 = BM * 4, B_F4 = BN * 4;
@@ -109,26 +124,50 @@ __global__ __launch_bounds__(WM *WN * 64, (MT * NT <= 3) ? 4 : 2) void k_conv(co
         pB[i] = p.w + (long)(b_in[i] ? gn : 0) * p.Ktot + (long)kt0 * 16 + ((e >> 3) & 3) * 4;
     }
 
-    auto set_tap = [&](int tap) {
-        const int ky = (p.ks == 3) ? tap / 3 : 0, kx = (p.ks == 3) ? tap - ky * 3 : 0;
+    // Without upsampling the input pixel of tap (ky,kx) is base + (ky*Win + kx) pixels for every row: the delta
+    // is a wave-uniform scalar, the per-row state is one base offset and a 9-bit validity mask.
+    long a_base[A_PER];
+    unsigned a_mask[A_PER];
+    if (!UPS) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            int iy, ix;
-            bool ok = a_in[i];
-            if (p.ups) {
-                const int vy = a_y[i] + ky - pad, vx = a_x[i] + kx - pad;
-                ok = ok && vy >= 0 && vy < 2 * p.Hin && vx >= 0 && vx < 2 * p.Win;
-                iy = vy >> 1; ix = vx >> 1;
-            } else {
-                iy = a_y[i] * p.stride + ky - pad; ix = a_x[i] * p.stride + kx - pad;
-                ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+            const int by = a_y[i] * p.stride - pad, bx = a_x[i] * p.stride - pad;
+            a_base[i] = (((long)a_n[i] * p.Hin + by) * p.Win + bx) * p.in_pitch + a_q[i] * 4;
+            unsigned m = 0;
+            for (int t = 0; t < p.taps; ++t) {
+                const int ky = (p.ks == 3) ? t / 3 : 0, kx = (p.ks == 3) ? t - ky * 3 : 0;
+                const bool ok = a_in[i] && by + ky >= 0 && by + ky < p.Hin && bx + kx >= 0 && bx + kx < p.Win;
+                m |= (ok ? 1u : 0u) << t;
             }
+            a_mask[i] = m;
+        }
+    }
+    auto set_tap = [&](int tap) {
+        const int ky = (p.ks == 3) ? tap / 3 : 0, kx = (p.ks == 3) ? tap - ky * 3 : 0;
+        if (!UPS) {
+            const long delta = ((long)ky * p.Win + kx) * p.in_pitch;   // scalar
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const bool ok = (a_mask[i] >> tap) & 1u;
+                okA[i] = ok;
+                pA[i] = p.in + (ok ? a_base[i] + delta : (long)(a_q[i] * 4));   // padding: read pixel 0, zeroed later
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int vy = a_y[i] + ky - pad, vx = a_x[i] + kx - pad;
+            const bool ok = a_in[i] && vy >= 0 && vy < 2 * p.Hin && vx >= 0 && vx < 2 * p.Win;
+            const int iy = vy >> 1, ix = vx >> 1;
             okA[i] = ok;
-            const long off = ok ? (((long)a_n[i] * p.Hin + iy) * p.Win + ix) * p.in_pitch : 0;   // padding: read pixel 0, zeroed later
+            const long off = ok ? (((long)a_n[i] * p.Hin + iy) * p.Win + ix) * p.in_pitch : 0;
             pA[i] = p.in + off + a_q[i] * 4;
         }
     };
-    int tap_l = kt0 / ncc, cc_l = kt0 - tap_l * ncc;   // load cursor
+    int tap_l, cc_l;   // load cursor
+    kt_decode(kt0, ncc, p.taps, cc_l, tap_l);
+    int cg_l = cc_l / KG;                                        // current chunk group
+    int gend_l = min(ncc, (cg_l + 1) * KG);                      // one past its last chunk
     set_tap(tap_l);
 
     f32x4 ra[A_PER], rb[B_PER];
@@ -148,9 +187,14 @@ __global__ __launch_bounds__(WM *WN * 64, (MT * NT <= 3) ? 4 : 2) void k_conv(co
             rb[i] = *reinterpret_cast<const f32x4 *>(pB[i]);
             pB[i] += 16;
         }
-        if (++cc_l == ncc) {
-            cc_l = 0;
-            if (++tap_l < p.taps) set_tap(tap_l);
+        if (++cc_l == gend_l) {          // group's chunks done for this tap -> next tap, or next group
+            if (++tap_l == p.taps) {
+                tap_l = 0;
+                ++cg_l;
+                gend_l = min(ncc, (cg_l + 1) * KG);
+            }
+            cc_l = cg_l * KG;
+            if (cc_l < ncc) set_tap(tap_l);
         }
     };
     auto store_tile = [&](int buf) {
@@ -288,8 +332,8 @@ __global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int 
         const long k = i - (long)o * Ktot;
         const int c16 = (int)(k & 15);
         const long t = k >> 4;
-        const int ncc = Cin_pad >> 4;
-        const int cc = (int)(t % ncc), tap = (int)(t / ncc);   // tap-major, like k_conv walks K
+        int cc, tap;
+        kt_decode((int)t, Cin_pad >> 4, taps, cc, tap);         // the order k_conv walks K
         const int cin = cc * 16 + c16;
         float v = 0.f;
         if (o < Cout && cin < Cin) v = w[((long)o * Cin + cin) * taps + tap];
@@ -678,9 +722,12 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         const int nimg = (int)((BM_ + hw_o - 1) / hw_o) + 1;                                         \
         const size_t shm = ((size_t)2 * (BM_ + BN_) * 20 + (mode ? (size_t)nimg * 2 * a.in.C : 0)) * sizeof(float); \
         HL_REQUIRE(shm <= 160 * 1024, "conv2d: LDS request %zu too large", shm);                     \
-        if (mode == 0) hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 0>), GRID, dim3(256), shm, st, p);      \
-        else if (mode == 1) hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 1>), GRID, dim3(256), shm, st, p); \
-        else hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 2>), GRID, dim3(256), shm, st, p);                \
+        if (a.ups) {   /* nearest x2 + conv: only ever follows a raw tensor (unet.py:77-79) */                \
+            HL_REQUIRE(mode == 0, "conv2d: upsample with a GroupNorm prologue is not used by the UNet");    \
+            hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 0, true>), GRID, dim3(256), shm, st, p);          \
+        } else if (mode == 0) hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 0, false>), GRID, dim3(256), shm, st, p); \
+        else if (mode == 1) hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 1, false>), GRID, dim3(256), shm, st, p);   \
+        else hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 2, false>), GRID, dim3(256), shm, st, p);                  \
     } while (0)
     if (cfg == 0) {
         p.n_mtiles = (int)((M + 127) / 128); p.n_nblocks = cpad / 96;
