@@ -172,7 +172,7 @@ def bench_render(args, rank, world, dev):
     ev[1].record()
     _lib.check(L.hl_render_importance(p(sig), p(rd), p(nr), p(fr), None, p(u), R, N, N, p(z_all), s()))
     ev[2].record()
-    _lib.check(L.hl_render_fine(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), p(z_all), R, 2 * N, 2,
+    _lib.check(L.hl_render_fine(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), p(z_all), 1, R, 2 * N, 2,
                                 p(rgb), p(acc), p(dep), s()))
     ev[3].record()
     torch.cuda.synchronize()

@@ -18,6 +18,22 @@ import torch.nn as nn
 from .. import _lib
 from .fields import PositionalEncoding
 
+def untile_rows(buf, n_rays, n_cols):
+    """Tile-major workspace array [ceil(R/32)][n_cols][32] (include/humanliff_hip.h) -> rows (R, n_cols)."""
+    tiles = (n_rays + 31) // 32
+    return buf[:tiles * n_cols * 32].view(tiles, n_cols, 32).permute(0, 2, 1).reshape(tiles * 32, n_cols)[:n_rays]
+
+
+def tile_rows(rows):
+    """rows (R, n_cols) -> tile-major flat buffer, rays padded to a multiple of 32 with copies of the last row."""
+    R, n_cols = rows.shape
+    tiles = (R + 31) // 32
+    pad = tiles * 32 - R
+    if pad:
+        rows = torch.cat([rows, rows[-1:].expand(pad, n_cols)], 0)
+    return rows.view(tiles, 32, n_cols).permute(0, 2, 1).contiguous().view(-1)
+
+
 _MLP_ORDER = ("pts_linears.0", "pts_linears.1", "pts_linears.2", "feature_linear", "alpha_linear",
               "views_linear", "rgb_linear")
 
@@ -180,13 +196,16 @@ class Renderer(nn.Module):
         L = _lib.lib()
         packed, pp = self._packed_mlp(dev), self._packed_planes(tri_planes[0])
         out = torch.empty((N * N, N), dtype=torch.float32, device=dev)
+        rays_per_launch = max(32, rays_per_launch // 32 * 32)
+        tmp = torch.empty(((rays_per_launch + 31) // 32) * 32 * N, dtype=torch.float32, device=dev)
         for i in range(0, N * N, rays_per_launch):
             j = min(N * N, i + rays_per_launch)
             z = Z.to(dev)[None].expand(j - i, N).contiguous()
             ro, rd = rays_o[i:j].contiguous(), rays_d[i:j].contiguous()
             _lib.check(L.hl_render_coarse(_lib.ptr(packed), _lib.ptr(pp), H, W, _lib.ptr(bounds), _lib.ptr(ro), _lib.ptr(rd),
-                                          _lib.ptr(zero[i:j]), _lib.ptr(zero[i:j]), _lib.ptr(z), j - i, N, _lib.ptr(out[i:j]),
+                                          _lib.ptr(zero[i:j]), _lib.ptr(zero[i:j]), _lib.ptr(z), j - i, N, _lib.ptr(tmp),
                                           _lib.stream_ptr()), "hl_render_coarse")
+            out[i:j] = untile_rows(tmp, j - i, N)
         return (-out).reshape(N, N, N)
 
     def extract_geometry(self, tp_input, tri_planes=None, resolution=512, threshold=0.0):

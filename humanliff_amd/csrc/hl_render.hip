@@ -205,7 +205,8 @@ struct MarchArgs {
     int H, W;
     const float *bounds;  // (2,3) device
     const float *rays_o, *rays_d, *near, *far;
-    const float *z;  // coarse: (R,N) or null (linspace); fine: (R,S) or null
+    const float *z;  // depths: null (linspace), caller rows (R,S), or the tile-major workspace [R/32][S][32]
+    int z_tiled;
     long long R;
     int S;  // samples marched per ray
     unsigned flags;
@@ -224,9 +225,18 @@ __global__ __launch_bounds__(512, 2) void k_march(const MarchArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * CHUNK_FLOATS + SMALL_FLOATS];
     constexpr int NCH = FULL ? NCH_FULL : NCH_COARSE;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
-    const long long ray = ((long long)blockIdx.x * 8 + (tid >> 6)) * 32 + (lane & 31);
+    // Workgroup b runs on XCD b % 8 (observed; speed only): hand every XCD a contiguous run of 256-ray groups so
+    // its L2 sees one band of the image (and of the tri-planes) instead of rows from everywhere.
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const long long wg = (long long)xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
+    const long long tile = wg * 8 + (tid >> 6);             // 32-ray tile of this wave
+    const long long ray = tile * 32 + (lane & 31);
     const bool valid = ray < a.R;
     const long long rc = valid ? ray : a.R - 1;
+    // workspace arrays are tile-major [tile][sample][32 rays]: one 128-byte line per wave and sample
+    // (waves past the last tile of a ragged batch clamp to it for reads and never store)
+    const long long tiles_n = (a.R + 31) / 32;
+    const long long zt_base = (tile < tiles_n ? tile : tiles_n - 1) * 32 * (long long)a.S + (lane & 31);
 
     f32x4 *ldsv = reinterpret_cast<f32x4 *>(lds);
     const float *small = lds + 2 * CHUNK_FLOATS;
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void k_march(const MarchArgs a) {
 
     float T = 1.f, acc_w = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f;
     float zc;  // depth of the current sample
-    if (a.z) zc = a.z[rc * S];
+    if (a.z) zc = a.z_tiled ? a.z[zt_base] : a.z[rc * S];
     else zc = nr * (1.f - linspace01(0, S)) + fr * linspace01(0, S);
 
     __syncthreads();
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void k_march(const MarchArgs a) {
         // ---- next depth (needed for the section length) ----
         float zn = 0.f;
         if (s + 1 < S) {
-            if (a.z) zn = a.z[rc * S + s + 1];
+            if (a.z) zn = a.z_tiled ? a.z[zt_base + 32LL * (s + 1)] : a.z[rc * S + s + 1];
             else { const float t = linspace01(s + 1, S); zn = nr * (1.f - t) + fr * t; }
         }
         // ---- tri-plane features of this half  [renderer.py:502-531] ----
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void k_march(const MarchArgs a) {
         const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];
 
         if constexpr (!FULL) {
-            if (valid && half == 0) a.sigma_out[ray * S + s] = sigma_raw;
+            if (half == 0 && tile * 32 < a.R) a.sigma_out[zt_base + 32LL * s] = sigma_raw;   // tiles are padded to 32 rays
             HL_CHUNK_ADVANCE(2)  // back to chunk 0 for the next sample (chunk 1 staged, stage chunk 2)
         } else {
             // feature_linear (no activation): X -> Y (chunks 10-13)
@@ -463,95 +473,106 @@ struct ImpArgs {
     float *z_all;
 };
 
-__global__ __launch_bounds__(64) void k_importance(const ImpArgs a) {
-    __shared__ float s_w[IMP_MAX_N];       // weights, then cdf
-    __shared__ float s_z[2 * IMP_MAX_N];   // merged depths (padded to a power of two)
-    const int lane = threadIdx.x;
-    const long long ray = blockIdx.x;
+__global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
+    // one workgroup = one 32-ray tile (the unit the march kernels read/write as 128-byte lines); each of the 4 waves
+    // runs 8 rays one after the other with wave-wide scans / searches / sort in its own LDS arrays
+    __shared__ float s_wA[4][IMP_MAX_N];       // weights, then cdf
+    __shared__ float s_zA[4][2 * IMP_MAX_N];   // merged depths (padded to a power of two)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *s_w = s_wA[wv], *s_z = s_zA[wv];
+    const long long tile = blockIdx.x;
     const int N = a.N, Ni = a.Ni;
-    const float nr = a.near[ray], fr = a.far[ray];
-    const float dxx = a.rays_d[ray * 3], dyy = a.rays_d[ray * 3 + 1], dzz = a.rays_d[ray * 3 + 2];
-    const float dn = sqrtf(dxx * dxx + dyy * dyy + dzz * dzz);
-
-    auto zval = [&](int i) -> float {
-        if (a.z) return a.z[ray * N + i];
-        const float t = linspace01(i, N);
-        return nr * (1.f - t) + fr * t;
-    };
-    // weights w_i = alpha_i * prod_{j<i}(1 - alpha_j + 1e-10)
-    float carry = 1.f;
-    for (int base = 0; base < N; base += 64) {
-        const int i = base + lane;
-        float alpha = 0.f, zi = 0.f;
-        if (i < N) {
-            zi = zval(i);
-            float dist = (i + 1 < N) ? zval(i + 1) - zi : 1e10f;
-            dist = dist * dn;
-            alpha = 1.f - expf(-softplus_exact(a.sigma[ray * N + i]) * dist);
-            s_z[i] = zi;
-        }
-        const float fct = (i < N) ? (1.f - alpha + 1e-10f) : 1.f;
-        const float incl = wave_incl_scan_mul(fct, lane);
-        float excl = __shfl_up(incl, 1);
-        if (lane == 0) excl = 1.f;
-        if (i < N) s_w[i] = alpha * (carry * excl);
-        carry *= __shfl(incl, 63);
-    }
-    __syncthreads();
-    // pdf over w[1..N-2] (+1e-5), cdf[0]=0, cdf[m]=sum_{i<=m} pdf_i   (N-1 entries)
-    const int M = N - 2;  // number of pdf bins
-    float tot = 0.f;
-    for (int i = 1 + lane; i <= M; i += 64) tot += s_w[i] + 1e-5f;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
-    __syncthreads();
-    float run = 0.f;
-    for (int base = 1; base <= M; base += 64) {
-        const int i = base + lane;
-        const float p = (i <= M) ? (s_w[i] + 1e-5f) / tot : 0.f;
-        const float incl = wave_incl_scan_add(p, lane) + run;
-        __syncthreads();
-        if (i <= M) s_w[i] = incl;
-        run = __shfl(incl, 63);
-    }
-    if (lane == 0) s_w[0] = 0.f;
-    __syncthreads();
-    // inverse CDF: idx = #(cdf <= u) (searchsorted right=True) over cdf[0..M]
-    const int nc = M + 1;  // cdf entries == bins entries == N-1
-    for (int q = lane; q < Ni; q += 64) {
-        const float uq = a.u[ray * Ni + q];
-        int lo = 0, hi = nc;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_w[mid] <= uq) lo = mid + 1; else hi = mid;
-        }
-        const int below = max(lo - 1, 0), above = min(lo, nc - 1);
-        const float c0 = s_w[below], c1 = s_w[above];
-        const float b0 = 0.5f * (s_z[below + 1] + s_z[below]);
-        const float b1 = 0.5f * (s_z[above + 1] + s_z[above]);
-        float den = c1 - c0;
-        den = den < 1e-5f ? 1.f : den;
-        const float t = (uq - c0) / den;
-        s_z[N + q] = b0 + t * (b1 - b0);  // slots >= N: never read by the midpoint lookups above
-    }
     const int tot_n = N + Ni;
     int P = 1;
     while (P < tot_n) P <<= 1;
-    for (int q = Ni + lane; q < P - N; q += 64) s_z[N + q] = __builtin_inff();
-    __syncthreads();
-    // bitonic sort of P values
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int e = lane; e < P / 2; e += 64) {
-                const int pos = 2 * j * (e / j) + (e % j), par = pos + j;
-                const bool up = (pos & k) == 0;
-                const float x = s_z[pos], y = s_z[par];
-                if ((x > y) == up) { s_z[pos] = y; s_z[par] = x; }
+    for (int rr = 0; rr < 8; ++rr) {
+        const int j = wv * 8 + rr;
+        const long long ray_raw = tile * 32 + j;
+        const long long ray = ray_raw < a.R ? ray_raw : a.R - 1;   // padded rays recompute the last one (never read back)
+        const float nr = a.near[ray], fr = a.far[ray];
+        const float dxx = a.rays_d[ray * 3], dyy = a.rays_d[ray * 3 + 1], dzz = a.rays_d[ray * 3 + 2];
+        const float dn = sqrtf(dxx * dxx + dyy * dyy + dzz * dzz);
+        const float *sig = a.sigma + tile * 32 * (long long)N + j;          // [s][32]
+        float *zout = a.z_all + tile * 32 * (long long)tot_n + j;           // [s][32]
+
+        auto zval = [&](int i) -> float {
+            if (a.z) return a.z[ray * N + i];
+            const float t = linspace01(i, N);
+            return nr * (1.f - t) + fr * t;
+        };
+        // weights w_i = alpha_i * prod_{k<i}(1 - alpha_k + 1e-10)
+        float carry = 1.f;
+        for (int base = 0; base < N; base += 64) {
+            const int i = base + lane;
+            float alpha = 0.f, zi = 0.f;
+            if (i < N) {
+                zi = zval(i);
+                float dist = (i + 1 < N) ? zval(i + 1) - zi : 1e10f;
+                dist = dist * dn;
+                alpha = 1.f - expf(-softplus_exact(sig[32LL * i]) * dist);
+                s_z[i] = zi;
             }
-            __syncthreads();
+            const float fct = (i < N) ? (1.f - alpha + 1e-10f) : 1.f;
+            const float incl = wave_incl_scan_mul(fct, lane);
+            float excl = __shfl_up(incl, 1);
+            if (lane == 0) excl = 1.f;
+            if (i < N) s_w[i] = alpha * (carry * excl);
+            carry *= __shfl(incl, 63);
         }
+        __syncthreads();
+        // pdf over w[1..N-2] (+1e-5), cdf[0]=0, cdf[m]=sum_{i<=m} pdf_i   (N-1 entries)
+        const int M = N - 2;
+        float tot = 0.f;
+        for (int i = 1 + lane; i <= M; i += 64) tot += s_w[i] + 1e-5f;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+        __syncthreads();
+        float run = 0.f;
+        for (int base = 1; base <= M; base += 64) {
+            const int i = base + lane;
+            const float pr = (i <= M) ? (s_w[i] + 1e-5f) / tot : 0.f;
+            const float incl = wave_incl_scan_add(pr, lane) + run;
+            __syncthreads();
+            if (i <= M) s_w[i] = incl;
+            run = __shfl(incl, 63);
+        }
+        if (lane == 0) s_w[0] = 0.f;
+        __syncthreads();
+        // inverse CDF: idx = #(cdf <= u) (searchsorted right=True) over cdf[0..M]
+        const int nc = M + 1;
+        for (int q = lane; q < Ni; q += 64) {
+            const float uq = a.u[ray * Ni + q];
+            int lo = 0, hi = nc;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_w[mid] <= uq) lo = mid + 1; else hi = mid;
+            }
+            const int below = max(lo - 1, 0), above = min(lo, nc - 1);
+            const float c0 = s_w[below], c1 = s_w[above];
+            const float b0 = 0.5f * (s_z[below + 1] + s_z[below]);
+            const float b1 = 0.5f * (s_z[above + 1] + s_z[above]);
+            float den = c1 - c0;
+            den = den < 1e-5f ? 1.f : den;
+            const float t = (uq - c0) / den;
+            s_z[N + q] = b0 + t * (b1 - b0);   // slots >= N: never read by the midpoint lookups above
+        }
+        for (int q = Ni + lane; q < P - N; q += 64) s_z[N + q] = __builtin_inff();
+        __syncthreads();
+        // bitonic sort of P values
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                for (int e = lane; e < P / 2; e += 64) {
+                    const int pos = 2 * jj * (e / jj) + (e % jj), par = pos + jj;
+                    const bool up = (pos & k) == 0;
+                    const float x = s_z[pos], y = s_z[par];
+                    if ((x > y) == up) { s_z[pos] = y; s_z[par] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = lane; i < tot_n; i += 64) zout[32LL * i] = s_z[i];
+        __syncthreads();
     }
-    for (int i = lane; i < tot_n; i += 64) a.z_all[ray * tot_n + i] = s_z[i];
 }
 
 }  // namespace
@@ -586,9 +607,12 @@ int hl_planes_pack(const float *planes, int H, int W, void *packed, void *stream
     return hl::check_launch("k_pack_planes");
 }
 
+static inline int64_t tiles32(int64_t n_rays) { return (n_rays + 31) / 32; }
+
 size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance) {
     if (n_rays <= 0 || n_importance <= 0) return 256;
-    return (size_t)n_rays * (size_t)(n_samples + n_samples + n_importance) * sizeof(float) + 256;
+    // tile-major [ceil(R/32)][samples][32]: sigma (n_samples) then z_all (n_samples + n_importance)
+    return (size_t)tiles32(n_rays) * 32 * (size_t)(n_samples + n_samples + n_importance) * sizeof(float) + 256;
 }
 
 static int fill_march(MarchArgs &a, const void *mlp, const void *planes, int H, int W, const float *bounds,
@@ -610,7 +634,7 @@ int hl_render_coarse(const void *mlp_packed, const void *planes_packed, int H, i
     MarchArgs a{};
     int rcode = fill_march(a, mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far);
     if (rcode) return rcode;
-    a.z = z_vals; a.R = n_rays; a.S = n_samples; a.flags = 0; a.sigma_out = sigma_out;
+    a.z = z_vals; a.z_tiled = 0; a.R = n_rays; a.S = n_samples; a.flags = 0; a.sigma_out = sigma_out;
     const unsigned grid = (unsigned)((n_rays + 255) / 256);
     hipLaunchKernelGGL(k_march<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_march<coarse>");
@@ -624,23 +648,31 @@ int hl_render_importance(const float *sigma, const float *rays_d, const float *n
     if (n_samples > IMP_MAX_N || n_importance > IMP_MAX_N)
         return hl::fail(HL_ERR_UNSUPPORTED, "hl_render_importance: n_samples/n_importance > %d", IMP_MAX_N);
     ImpArgs a{sigma, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_all_out};
-    hipLaunchKernelGGL(k_importance, dim3((unsigned)n_rays), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_importance, dim3((unsigned)tiles32(n_rays)), dim3(256), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_importance");
 }
 
-int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
-                   const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z_all,
-                   int64_t n_rays, int n_total_samples, unsigned flags, float *rgb, float *acc, float *depth,
-                   void *stream) {
+static int render_fine_impl(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
+                            const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z_all,
+                            int z_tiled, int64_t n_rays, int n_total_samples, unsigned flags, float *rgb, float *acc,
+                            float *depth, void *stream) {
     HL_REQUIRE(n_rays > 0 && n_total_samples >= 2 && rgb && acc && depth, "hl_render_fine: bad argument");
     MarchArgs a{};
     int rcode = fill_march(a, mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far);
     if (rcode) return rcode;
-    a.z = z_all; a.R = n_rays; a.S = n_total_samples; a.flags = flags;
+    a.z = z_all; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_total_samples; a.flags = flags;
     a.rgb = rgb; a.acc = acc; a.depth = depth;
     const unsigned grid = (unsigned)((n_rays + 255) / 256);
     hipLaunchKernelGGL(k_march<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_march<fine>");
+}
+
+int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
+                   const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z_all,
+                   int z_tiled, int64_t n_rays, int n_total_samples, unsigned flags, float *rgb, float *acc, float *depth,
+                   void *stream) {
+    return render_fine_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_all, z_tiled, n_rays,
+                            n_total_samples, flags, rgb, acc, depth, stream);
 }
 
 int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
@@ -653,17 +685,17 @@ int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int
                    n_samples);
         HL_REQUIRE(u && workspace, "render: u and workspace are required when n_importance > 0");
         float *sigma = (float *)workspace;
-        float *z_all = sigma + (size_t)n_rays * n_samples;
+        float *z_all = sigma + (size_t)tiles32(n_rays) * 32 * n_samples;
         int rcode = hl_render_coarse(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, n_rays,
                                      n_samples, sigma, stream);
         if (rcode) return rcode;
         rcode = hl_render_importance(sigma, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_all, stream);
         if (rcode) return rcode;
-        return hl_render_fine(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_all, n_rays,
-                              n_samples + n_importance, flags, rgb, acc, depth, stream);
+        return render_fine_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_all, 1, n_rays,
+                                n_samples + n_importance, flags, rgb, acc, depth, stream);
     }
-    return hl_render_fine(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, n_rays, n_samples,
-                          flags, rgb, acc, depth, stream);
+    return render_fine_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, 0, n_rays, n_samples,
+                            flags, rgb, acc, depth, stream);
 }
 
 }  // extern "C"

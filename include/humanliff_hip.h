@@ -80,15 +80,19 @@ size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance
  *   u        (R,n_importance) uniform draws of sample_pdf (renderer.py:545); required
  *            when n_importance > 0 (n_importance must then equal n_samples, renderer.py:250)
  *   rgb (R,3)  acc (R)  depth (R)   outputs; normal_map == rgb_map in the reference
- *   workspace  hl_render_workspace_bytes(); afterwards holds sigma_coarse (R,n_samples)
- *            followed by the merged depths z_all (R,n_samples+n_importance)
+ *   workspace  hl_render_workspace_bytes(); afterwards holds, tile-major, sigma_coarse
+ *            [ceil(R/32)][n_samples][32] followed by the merged depths z_all
+ *            [ceil(R/32)][n_samples+n_importance][32] (ray r = tile r/32, lane r%32): one 128-byte
+ *            line per wave and sample instead of 4-byte accesses at a row stride
  */
 int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
                    const float *rays_o, const float *rays_d, const float *near, const float *far,
                    const float *z_vals, const float *u, int64_t n_rays, int n_samples, int n_importance,
                    unsigned flags, float *rgb, float *acc, float *depth, void *workspace, void *stream);
 
-/* The three stages of hl_render_rays, exposed for tests and profiling. */
+/* The three stages of hl_render_rays, exposed for tests and profiling.  sigma_out / sigma and z_all_out /
+ * z_all use the tile-major workspace layout described above (buffers sized for ceil(R/32)*32 rays);
+ * hl_render_fine takes z_all either tile-major (z_tiled = 1) or as caller rows (R,S) (z_tiled = 0). */
 int hl_render_coarse(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
                      const float *rays_o, const float *rays_d, const float *near, const float *far,
                      const float *z_vals, int64_t n_rays, int n_samples, float *sigma_out, void *stream);
@@ -97,7 +101,7 @@ int hl_render_importance(const float *sigma, const float *rays_d, const float *n
                          float *z_all_out, void *stream);
 int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
                    const float *rays_o, const float *rays_d, const float *near, const float *far,
-                   const float *z_all /* (R,S) or NULL -> linspace */, int64_t n_rays, int n_total_samples,
+                   const float *z_all /* or NULL -> linspace */, int z_tiled, int64_t n_rays, int n_total_samples,
                    unsigned flags, float *rgb, float *acc, float *depth, void *stream);
 
 

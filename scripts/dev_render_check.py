@@ -11,8 +11,8 @@ for name in ["a", "b", "c"]:
     i, e = load_render_case(name)
     r, out = hip_render(i, dev)
     R, N = i["rays_o"].shape[0], i["n_samples"]
-    ws = r._ws.cpu()
-    sigma = ws[:R * N].reshape(R, N)
+    from humanliff_amd.NeRF.renderer import untile_rows
+    sigma = untile_rows(r._ws.cpu(), R, N)
     print(name, "sigma", float((sigma - e["sigma_coarse"]).abs().max()),
           "rgb", float((out["rgb_map"] - e["rgb"]).abs().max()),
           "acc", float((out["acc_map"] - e["acc"]).abs().max()),
