@@ -14,8 +14,9 @@
 namespace hl {
 namespace {
 
-// x*sigmoid(x); v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division sequence
-__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+// x*sigmoid(x) on raw v_exp_f32 (2^x) + v_rcp_f32, ~1 ulp each: 5 VALU ops.  exp2 overflowing to inf (v << 0)
+// gives rcp(inf) = 0 -> -0, underflow (v >> 0) gives v; no fix-ups needed.
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v)); }
 
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM convolution
