@@ -34,6 +34,11 @@ UNET_GFLOP_PER_SAMPLE_STEP = 2015.4
 RENDER_FLOP_PER_RAY = 128 * 79616 + 256 * 132608   # 44 138 496 at 128+128
 FINE_FLOP_PER_RAY = 256 * 132608
 COARSE_FLOP_PER_RAY = 128 * 79616
+# Fabric-side bytes per launch of the two dominant kernels from the separate rocprofv3 PMC passes (FETCH_SIZE
+# doubled per the gfx950 calibration, WRITE_SIZE as is): profiles/r01_pmc_hbm_traffic.md.  Not measured by this
+# script - PMC collection needs its own runs.
+PMC_TRAFFIC = {"k_conv_avg_launch_b4": 207e6, "k_march_fine_512x512": 3.8e9,
+               "source": "profiles/r01_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
 
 F4 = dict(image_size=256, in_channels=27, out_channels=27, num_channels=192, num_res_blocks=3, num_heads=4,
           num_heads_upsample=-1, attention_resolutions="32,16,8", dropout=0.0, learn_sigma=False, sigma_small=False,
@@ -119,7 +124,8 @@ def bench_unet(args, rank, world, dev):
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     roof = {"bound": "mfma", "kernel": "k_conv (implicit-GEMM conv/1x1, v_mfma_f32_32x32x2_f32), all launches of one denoise step",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": PMC_TRAFFIC["k_conv_avg_launch_b4"] if B == 4 else None, "traffic_source": PMC_TRAFFIC["source"],
             "launches_per_step": int(conv_n), "gflop_per_step": round(conv_fl / 1e9, 1), "ms_per_step": round(conv_ms, 3),
             "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4),
             "other_ms": {"groupnorm": round(ms[1], 3), "attention": round(ms[2], 3), "emb_prep": round(ms[3], 3)}}
@@ -183,7 +189,8 @@ def bench_render(args, rank, world, dev):
     achieved = R * FINE_FLOP_PER_RAY / (t_f * 1e-3) / 1e12
     roof = {"bound": "mfma", "kernel": "k_march<true> (fine pass: tri-plane gather + full MLP + compositing), one 512x512 view",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "launch_ms": round(t_f, 3),
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": PMC_TRAFFIC["k_march_fine_512x512"],
+            "traffic_source": PMC_TRAFFIC["source"], "launch_ms": round(t_f, 3),
             "coarse": {"launch_ms": round(t_c, 3), "achieved": round(R * COARSE_FLOP_PER_RAY / (t_c * 1e-3) / 1e12, 2)},
             "importance_ms": round(t_i, 3)}
     return secs, roof, views * R
