@@ -237,3 +237,47 @@ def test_full_sampling_loops_match_reference(tag, spec, ddim):
     assert n["i"] == int(gl[f"{tag}_ndraws"])               # same RNG call pattern as the reference
     err = (out.cpu() - torch.from_numpy(gl[f"{tag}_sample"])).abs().max()
     assert err < 5e-4, float(err)                           # 8-10 recurrent UNet evaluations
+
+
+def test_c_abi_error_convention():
+    """Bad arguments come back as negative status + message (never an exception across the ABI, never a crash);
+    the Python mirrors re-raise with the reference's exception types."""
+    import ctypes as C
+    from humanliff_amd import _lib
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+    L = _lib.lib()
+    x = torch.zeros((1, 8, 8, 24), device=dev)          # Cin not a multiple of 16
+    w = torch.zeros((32, 24, 3, 3), device=dev)
+    out = torch.zeros((1, 8, 8, 32), device=dev)
+    scratch = torch.zeros(1 << 20, device=dev)
+    rc = L.hl_conv2d_nhwc(_lib.ptr(x), 1, 8, 8, 24, _lib.ptr(w), None, 32, 3, 1, 0, None, None, 0, None, _lib.ptr(out),
+                          _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr())
+    assert rc == -1 and b"multiple of 16" in L.hl_last_error()
+    rc = L.hl_diffusion_step(7, _lib.ptr(out), _lib.ptr(out), None, _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), None, 16, 1, 1,
+                             _lib.stream_ptr())
+    assert rc == -1 and b"mode" in L.hl_last_error()
+    rc = L.hl_render_importance(_lib.ptr(out), _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), None, _lib.ptr(out), 4, 1024, 1024,
+                                _lib.ptr(out), _lib.stream_ptr())
+    assert rc == -2                                       # unsupported size, HL_ERR_UNSUPPORTED
+    # state_dict with a missing / mis-shaped tensor is reported by name
+    a = model_and_diffusion_defaults()
+    a.update(dict(in_channels=27, out_channels=27, class_cond=True, image_size=32, num_channels=32, num_res_blocks=1))
+    m, _ = create_model_and_diffusion(**a)
+    m = m.to(dev)
+    cfg = m._cfg()
+    sd = {k: v for k, v in m.state_dict().items() if k != "middle_block.1.qkv.weight"}
+    n = len(sd)
+    names = (C.c_char_p * n)(*[k.encode() for k in sd])
+    ptrs = (C.c_void_p * n)(*[v.data_ptr() for v in sd.values()])
+    numels = (C.c_int64 * n)(*[v.numel() for v in sd.values()])
+    packed = torch.empty(L.hl_unet_packed_bytes(C.byref(cfg)) // 4 + 64, device=dev)
+    h = C.c_void_p()
+    rc = L.hl_unet_create(C.byref(cfg), n, names, ptrs, numels, _lib.ptr(packed), _lib.stream_ptr(), C.byref(h))
+    assert rc == -1 and b"middle_block.1.qkv.weight" in L.hl_last_error()
+    # Python mirror: shape assertions like the reference (unet.py:585)
+    with pytest.raises(AssertionError):
+        m(torch.zeros(2, 27, 32, 32, device=dev), torch.tensor([1, 2], device=dev), torch.zeros(2, 27, 32, 32, device=dev),
+          y=torch.tensor([0], device=dev))
+    with pytest.raises(_lib.HipCallError):                # H, W not divisible by the total downsampling
+        m(torch.zeros(1, 27, 36, 36, device=dev), torch.tensor([1], device=dev), torch.zeros(1, 27, 36, 36, device=dev),
+          y=torch.tensor([0], device=dev))
