@@ -300,6 +300,8 @@ struct Exec {
     float *gn_scratch = nullptr;
     float *splitk_ws = nullptr;
     float *gn_scratch2 = nullptr, *splitk_ws2 = nullptr;   // second set for the side stream
+    float *act_ws = nullptr, *act_ws2 = nullptr;           // materialised GroupNorm(+SiLU) inputs (k_conv_dma path)
+    size_t act_need = 0;                                   // floats, largest normalised conv input seen
     int rc = 0;
 
     float *alloc(size_t floats) {
@@ -330,6 +332,10 @@ struct Exec {
     void conv(const Conv &c, const View &in, const View &out, int stride, int ups, const float *cA, const float *cB, int act,
               const float *res, long res_pitch, float *out2 = nullptr, long out2_pitch = 0, const float *res2 = nullptr,
               long res2_pitch = 0, int nchw = 0) {
+        if (!run) {   // sizing pass (pointers are null here): the largest conv input is also the largest normalised one
+            const size_t need = (size_t)in.pixels() * c.Cin_pad;
+            if (need > act_need) act_need = need;
+        }
         if (!run) return;
         ConvArgs a{};
         a.in = in; a.in.C = c.Cin_pad;
@@ -338,6 +344,7 @@ struct Exec {
         a.out = out; a.res = res; a.res_pitch = res_pitch;
         a.out2 = out2; a.out2_pitch = out2_pitch; a.res2 = res2; a.res2_pitch = res2_pitch; a.out_nchw = nchw;
         a.splitk_ws = splitk_ws; a.splitk_ws_bytes = hl::conv_splitk_ws_bytes();
+        a.act_ws = act_ws; a.act_ws_bytes = act_need * sizeof(float);
         const size_t e0 = span_begin();
         ok(hl::conv2d(a, st));
         span_end(CAT_CONV, e0, 2.0 * (double)out.pixels() * c.Cout * c.Cin * c.ks * c.ks);
@@ -458,7 +465,7 @@ struct Exec {
         block(n.middle, h, first_part(0, n.middle.Cout));
         // control branch: zero-conv output feeds the next block AND (+ encoder skip) the decoder
         if (c.controlnet) {
-            if (fork) { st = n.side; std::swap(gn_scratch, gn_scratch2); std::swap(splitk_ws, splitk_ws2); }
+            if (fork) { st = n.side; std::swap(gn_scratch, gn_scratch2); std::swap(splitk_ws, splitk_ws2); std::swap(act_ws, act_ws2); }
             View hc = xsum;
             for (size_t i = 0; i < nb; ++i) {
                 View tmp = plain(n.cond_blocks[i].ds_out, n.cond_blocks[i].Cout);
@@ -473,7 +480,7 @@ struct Exec {
             }
             if (fork) {
                 hipEventRecord(n.ev_join, n.side);
-                st = main_st; std::swap(gn_scratch, gn_scratch2); std::swap(splitk_ws, splitk_ws2);
+                st = main_st; std::swap(gn_scratch, gn_scratch2); std::swap(splitk_ws, splitk_ws2); std::swap(act_ws, act_ws2);
                 hipStreamWaitEvent(main_st, n.ev_join, 0);
             }
         } else if (run) {
@@ -562,7 +569,7 @@ size_t hl_unet_workspace_bytes(void *handle, int B, int H, int W) {
     Net &n = *static_cast<Net *>(handle);
     Exec e{n, false, nullptr, 0, nullptr, B, H, W};
     e.forward(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    return e.off + 256;
+    return e.off + 2 * e.act_need * sizeof(float) + 1024;
 }
 
 int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float *t_float, const float *x_cond,
@@ -574,7 +581,12 @@ int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float 
     HL_REQUIRE(H % total_ds == 0 && W % total_ds == 0, "hl_unet_forward: H,W must be divisible by %d", total_ds);
     HL_REQUIRE(!n.cfg.controlnet || x_cond, "hl_unet_forward: x_cond is required with cond_type='controlnet'");
     HL_REQUIRE(n.cfg.num_classes == 0 || y, "hl_unet_forward: y is required for a class-conditional model");
+    Exec dry{n, false, nullptr, 0, nullptr, B, H, W};   // sizes only (host work, no launches)
+    dry.forward(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     Exec e{n, true, static_cast<char *>(workspace), 0, (hipStream_t)stream, B, H, W};
+    e.act_need = dry.act_need;
+    e.act_ws = reinterpret_cast<float *>(static_cast<char *>(workspace) + (dry.off + 255) / 256 * 256);
+    e.act_ws2 = e.act_ws + dry.act_need;
     e.forward(x, t, t_float, x_cond, y, out);
     return e.rc;
 }
@@ -622,7 +634,13 @@ int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w
     a.out.C = Cout; a.out.pitch = Cout;
     a.res = residual; a.res_pitch = Cout;
     // whatever scratch is left after the packed weights serves split-K (small-M shapes)
-    const size_t used = (need + 255) / 256 * 256;
+    size_t used = (need + 255) / 256 * 256;
+    const size_t act_bytes = coefA ? (size_t)N * H * W * Cin * sizeof(float) : 0;
+    if (act_bytes && scratch_bytes >= used + act_bytes) {      // room for the materialised GroupNorm input (DMA path)
+        a.act_ws = reinterpret_cast<float *>(static_cast<char *>(scratch) + used);
+        a.act_ws_bytes = act_bytes;
+        used += (act_bytes + 255) / 256 * 256;
+    }
     if (scratch_bytes > used + (1u << 20)) {
         a.splitk_ws = reinterpret_cast<float *>(static_cast<char *>(scratch) + used);
         a.splitk_ws_bytes = scratch_bytes - used;

@@ -31,6 +31,8 @@ struct ConvArgs {
     const float *res2;
     long res2_pitch;
     int out_nchw;        // write (N, Cout, H, W) instead of NHWC
+    float *act_ws;       // optional scratch (pixels*Cin floats) for the materialised GroupNorm(+SiLU) input of k_conv_dma
+    size_t act_ws_bytes;
     float *splitk_ws;    // optional scratch for split-K partial sums (small-M layers); null disables split-K
     size_t splitk_ws_bytes;
 };

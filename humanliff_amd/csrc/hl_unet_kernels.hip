@@ -11,6 +11,8 @@
 //   k_prep_inputs     x.type(dtype), x + x_cond (unet.py:588,596) and NCHW -> NHWC.
 #include "hl_unet_kernels.h"
 
+#include <cstdlib>
+
 namespace hl {
 namespace {
 
@@ -301,6 +303,245 @@ __global__ __launch_bounds__(WM *WN * 64, (MT * NT <= 3) ? 4 : 2) void k_conv(co
                 if (p.out2) p.out2[m * p.out2_pitch + n] = v + p.res2[m * p.res2_pitch + n];
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_dma: the same implicit GEMM (128x96 tile, 4 waves of 32x96, K order of kt_decode, raw input) with both
+// operand tiles staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, no VALU, no ds_write) into a
+// ring of NS stages, D = NS-1 tiles in flight, ONE raw s_barrier per k-tile and counted vmcnt waits.
+// LDS rows are unpadded 64-byte lines (a DMA instruction fills 1 KiB linearly: 16 rows); bank conflicts of the
+// ds_read_b128 fragment reads are avoided by XOR-swizzling the 16-byte quarter with (row>>2)&3, applied on the
+// per-lane SOURCE address of the DMA and on the read address.  Zero padding comes from a page of zeros.
+// The GroupNorm(+SiLU) prologue cannot ride a DMA, so normalised inputs are materialised once by k_gn_apply.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) float g_zero_page[64];
+
+template <int WM, int NS>
+__global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : (NS == 2 ? 4 : 3)) void k_conv_dma(const ConvK p) {
+    constexpr int BM = WM * 32, BN = 96, ROWS = BM + BN, STAGE_F = ROWS * 16, D = NS - 1;
+    constexpr int NB2 = (WM == 4) ? 2 : 1;   // B instructions per wave (6 in total, instruction b = wave + WM*j)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = p.n_mtiles * p.n_nblocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int mt_idx = wi / p.n_nblocks;
+    const long m0 = (long)mt_idx * BM;
+    const int n0 = (wi - mt_idx * p.n_nblocks) * BN;
+    const int pad = p.ks >> 1;
+    const int ncc = p.Cin >> 4;
+    const int hw_out = p.Hout * p.Wout;
+
+    // DMA instruction i of a tile fills rows 16i..16i+15: A rows by instructions wave + WM*j (j = 0,1), the 96 B rows
+    // by instructions BM/16 + b with b = wave + WM*j < 6.
+    // Lane L of an instruction writes physical quarter L&3 of row 16i + (L>>2).
+    const int lrow = lane >> 2, pq = lane & 3;
+    long a_base[2];        // j = 0,1: A rows (pixels)
+    unsigned a_mask[2];
+    const float *pB[2];    // j = 2,3: B rows (output channels)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave + WM * j) * 16 + lrow;
+        const int ql = pq ^ ((row >> 2) & 3);
+        const long P = m0 + row;
+        const bool in = P < p.M;
+        const long Pc = in ? P : 0;
+        const int n = (int)(Pc / hw_out);
+        const int rem = (int)(Pc - (long)n * hw_out);
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        const int by = oy * p.stride - pad, bx = ox * p.stride - pad;
+        a_base[j] = (((long)n * p.Hin + by) * p.Win + bx) * p.in_pitch + ql * 4;
+        unsigned m = 0;
+        for (int t = 0; t < p.taps; ++t) {
+            const int ky = (p.ks == 3) ? t / 3 : 0, kx = (p.ks == 3) ? t - ky * 3 : 0;
+            const bool ok = in && by + ky >= 0 && by + ky < p.Hin && bx + kx >= 0 && bx + kx < p.Win;
+            m |= (ok ? 1u : 0u) << t;
+        }
+        a_mask[j] = m;
+    }
+    const int nk_all = ncc * p.taps;
+    const int kt0 = blockIdx.z * p.kt_per;
+    const int nk = min(nk_all, kt0 + p.kt_per);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int brow = (wave + WM * j) * 16 + lrow;         // valid < 96
+        const int row = BM + brow;
+        const int ql = pq ^ ((row >> 2) & 3);
+        const int gn = n0 + brow;
+        const bool ok = brow < BN && gn < p.wrows;
+        pB[j] = ok ? p.w + (long)gn * p.Ktot + (long)kt0 * 16 + ql * 4 : g_zero_page + ql * 4;   // zero page never advances
+    }
+    const bool b_ok0 = (wave * 16 + lrow) < BN && (n0 + wave * 16 + lrow) < p.wrows;
+    const bool b_ok1 = ((wave + WM) * 16 + lrow) < BN && (n0 + (wave + WM) * 16 + lrow) < p.wrows;
+    const bool has_b0 = wave < 6;                              // B instruction wave
+    const bool has_b1 = (NB2 == 2) && wave + WM < 6;           // B instruction wave + WM
+
+    int tap_i, cc_i;                                           // issue cursor
+    kt_decode(kt0, ncc, p.taps, cc_i, tap_i);
+    int cg_i = cc_i / KG, gend_i = min(ncc, (cg_i + 1) * KG);
+    auto issue = [&](int stage) {
+        const int ky = (p.ks == 3) ? tap_i / 3 : 0, kx = (p.ks == 3) ? tap_i - ky * 3 : 0;
+        const long delta = ((long)ky * p.Win + kx) * p.in_pitch + cc_i * 16;
+        float *dst = lds + stage * STAGE_F + wave * 256;       // + WM*256 floats per j (WM instructions further)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = (a_mask[j] >> tap_i) & 1u;
+            const float *src = ok ? p.in + (a_base[j] + delta) : g_zero_page + pq * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + j * (WM * 256)), 16, 0, 0);
+        }
+        if (has_b0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pB[0],
+                                             (__attribute__((address_space(3))) void *)(dst + BM * 16), 16, 0, 0);
+        if (has_b1)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pB[1],
+                                             (__attribute__((address_space(3))) void *)(dst + BM * 16 + WM * 256), 16, 0, 0);
+        if (b_ok0) pB[0] += 16;
+        if (b_ok1) pB[1] += 16;
+        if (++cc_i == gend_i) {
+            if (++tap_i == p.taps) { tap_i = 0; ++cg_i; gend_i = min(ncc, (cg_i + 1) * KG); }
+            cc_i = cg_i * KG;
+        }
+    };
+
+    // fragment read offsets (floats) inside a stage; the three B fragments sit 32 rows (512 floats) apart with the
+    // same swizzle phase, so they share one address register and differ by immediate offsets
+    const int ra = wave * 32 + (lane & 31);
+    const int sa = (ra >> 2) & 3;
+    const int a_off0 = ra * 16 + (((2 * half) ^ sa) << 2), a_off1 = ra * 16 + (((2 * half + 1) ^ sa) << 2);
+    const int rb = BM + (lane & 31);
+    const int sb = (rb >> 2) & 3;
+    const int b_off0 = rb * 16 + (((2 * half) ^ sb) << 2), b_off1 = rb * 16 + (((2 * half + 1) ^ sb) << 2);
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // Software pipeline over HALF k-tiles (8 of the 16 channels = 12 MFMAs): the LDS reads of the next half are in
+    // flight while the MFMAs of the current half run, and the per-tile barrier is followed directly by MFMAs whose
+    // operands are already in registers.  Per tile t:
+    //     3 mfma h0(t) | read h1(t) | 9 mfma h0(t) | wait DMA(t+1), barrier | 3 mfma h1(t) | issue DMA(t+NS), read h0(t+1) | 9 mfma h1(t)
+    int issued = 0;                                            // tiles issued so far (relative)
+    const int ntiles = nk - kt0;
+    auto wait_tile = [&](int t) {   // my DMAs of tile t have landed once only the younger tiles' instructions are outstanding
+        const int younger = issued - t - 1;
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NS == 3) {   // one younger tile in flight: 2 A + (has_b0) + (has_b1) instructions of this wave
+            const int n_w = 2 + (has_b0 ? 1 : 0) + (has_b1 ? 1 : 0);
+            if (n_w == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (n_w == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+        if (t < ntiles) { issue(t % NS); ++issued; }
+    f32x4 a0, a1, b0[3], b1[3];
+    if (ntiles > 0) {
+        wait_tile(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issued < ntiles) { issue(issued % NS); ++issued; }
+        a0 = *reinterpret_cast<const f32x4 *>(lds + a_off0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) b0[j] = *reinterpret_cast<const f32x4 *>(lds + b_off0 + j * 512);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        const float *base = lds + (t % NS) * STAGE_F;
+        // (the reads go AFTER the first MFMAs in program order: the compiler's wait for h0 is a full lgkmcnt(0))
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[j][0], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a1 = *reinterpret_cast<const f32x4 *>(base + a_off1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) b1[j] = *reinterpret_cast<const f32x4 *>(base + b_off1 + j * 512);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 1; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[j][s], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = t + 1 < ntiles;
+        if (more) {
+            wait_tile(t + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done reading tile t before its stage refills
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], b1[j][0], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            if (issued < ntiles) { issue(issued % NS); ++issued; }
+            const float *nbase = lds + ((t + 1) % NS) * STAGE_F;
+            a0 = *reinterpret_cast<const f32x4 *>(nbase + a_off0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) b0[j] = *reinterpret_cast<const f32x4 *>(nbase + b_off0 + j * 512);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 1; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[j][s], acc[j], 0, 0, 0);
+    }
+
+    // epilogue (same contract as k_conv)
+    if (p.partial) {
+        float *dst = p.partial + (long)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = n0 + j * 32 + (lane & 31);
+            if (n >= p.Cout) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.M) dst[m * p.Cout + n] = acc[j][r];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int n = n0 + j * 32 + (lane & 31);
+        if (n >= p.Cout) continue;
+        const float bs = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= p.M) continue;
+            float v = acc[j][r] + bs;
+            if (p.res) v += p.res[m * p.res_pitch + n];
+            if (p.out_nchw) {
+                const long img = m / hw_out, rem = m - img * hw_out;
+                p.out[(img * p.Cout + n) * hw_out + rem] = v;
+            } else {
+                p.out[m * p.out_pitch + n] = v;
+            }
+            if (p.out2) p.out2[m * p.out2_pitch + n] = v + p.res2[m * p.res2_pitch + n];
+        }
+    }
+}
+
+// y = x*A[n,c] + B[n,c] (and SiLU): the GroupNorm-apply pre-pass for k_conv_dma.  x has a channel pitch, y is dense.
+__global__ void k_gn_apply(const float *__restrict__ x, long pitch, long pixels_per_img, long npix, int C,
+                           const float *__restrict__ cA, const float *__restrict__ cB, int act, float *__restrict__ y) {
+    const int cq = C >> 2;
+    const long n4 = npix * cq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cq;
+        const int c = (int)(i - pix * cq) * 4;
+        const long n = pix / pixels_per_img;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + pix * pitch + c);
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(cA + n * C + c);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(cB + n * C + c);
+        f32x4 o = v * a + b;
+        if (act) { o[0] = silu_f(o[0]); o[1] = silu_f(o[1]); o[2] = silu_f(o[2]); o[3] = silu_f(o[3]); }
+        *reinterpret_cast<f32x4 *>(y + pix * C + c) = o;
+    }
 }
 
 // split-K epilogue: sum the slabs in a fixed order (deterministic), then bias / residual / second output
@@ -702,8 +943,16 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     if (cpad % 96 == 0 && main_blocks * (max_splits > 0 ? max_splits : 1) >= 192) { cfg = 0; blocks = main_blocks; }
     else if (a.Cout <= 32) { cfg = 1; blocks = (M + 127) / 128; }
     else { cfg = 2; blocks = ((M + 63) / 64) * (cpad / 64); }
+    // main-tile layers that need no upsampling go through k_conv_dma (GroupNorm materialised by k_gn_apply first);
+    // the 8-wave 256x96 tile when that covers at least half the chip (2 workgroups/CU = 512 slots), else 4 waves x 128x96
+    static const int dma_thr = getenv("HL_CONV_T8") ? atoi(getenv("HL_CONV_T8")) : 256;
+    static const int dma_off = getenv("HL_CONV_NODMA") ? 1 : 0;
+    const bool dma = !dma_off && cfg == 0 && !a.ups && (a.coefA == nullptr || a.act_ws);
+    const long blocks8 = ((M + 255) / 256) * (cpad / 96);
+    const bool tile8 = dma && blocks8 >= dma_thr;
+    if (tile8) blocks = blocks8;
     int splits = 1;
-    const long target = cfg == 2 ? 1280 : 1024;
+    const long target = cfg == 2 ? 1280 : (tile8 ? 512 : (dma ? 768 : 1024));
     if (a.splitk_ws && blocks <= target / 2 && nk >= 16) {
         splits = (int)(target / blocks);
         if (splits > nk / 8) splits = nk / 8;
@@ -730,7 +979,27 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         else if (mode == 1) hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 1, false>), GRID, dim3(256), shm, st, p);   \
         else hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 2, false>), GRID, dim3(256), shm, st, p);                  \
     } while (0)
-    if (cfg == 0) {
+    if (dma) {
+        if (mode != 0) {   // materialise GroupNorm(+SiLU) once, then the DMA kernel reads it raw
+            HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
+            const long npix = a.in.pixels();
+            long g = (npix * (a.in.C / 4) + 255) / 256;
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix,
+                               a.in.C, a.coefA, a.coefB, a.act, a.act_ws);
+            p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0;
+        }
+        p.n_nblocks = cpad / 96;
+        if (tile8) {
+            p.n_mtiles = (int)((M + 255) / 256);
+            dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
+            hipLaunchKernelGGL((k_conv_dma<8, 3>), grid, dim3(512), (size_t)3 * 352 * 16 * sizeof(float), st, p);
+        } else {
+            p.n_mtiles = (int)((M + 127) / 128);
+            dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
+            hipLaunchKernelGGL((k_conv_dma<4, 3>), grid, dim3(256), (size_t)3 * 224 * 16 * sizeof(float), st, p);
+        }
+    } else if (cfg == 0) {
         p.n_mtiles = (int)((M + 127) / 128); p.n_nblocks = cpad / 96;
         dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
         HL_CONV_GO(4, 1, 1, 3, grid);

@@ -32,7 +32,7 @@ def hip_conv(x, w, b, ks, stride=1, ups=0, cA=None, cB=None, silu=0, res=None):
     Ho, Wo = (Hv + 2 * (ks // 2) - ks) // stride + 1, (Wv + 2 * (ks // 2) - ks) // stride + 1
     out = torch.empty((N, Ho, Wo, Cout), device=dev)
     # packed weights + room for split-K partial sums (taken for shapes that would under-fill the chip)
-    scratch = torch.empty(((Cout + 63) // 64 * 64) * C * ks * ks + 64 + (8 << 20), device=dev)
+    scratch = torch.empty(((Cout + 63) // 64 * 64) * C * ks * ks + 64 + (8 << 20) + N * C * H * W, device=dev)
     d = lambda t: None if t is None else t.contiguous().to(dev)  # noqa: E731
     wd, bd, cAd, cBd = d(w), d(b), d(cA), d(cB)
     rd = d(nhwc(res)) if res is not None else None
