@@ -12,6 +12,7 @@
 #include "hl_unet_kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace hl {
 namespace {
@@ -306,20 +307,23 @@ __global__ __launch_bounds__(WM *WN * 64, (MT * NT <= 3) ? 4 : 2) void k_conv(co
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_conv_dma: the same implicit GEMM (128x96 tile, 4 waves of 32x96, K order of kt_decode, raw input) with both
-// operand tiles staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, no VALU, no ds_write) into a
-// ring of NS stages, D = NS-1 tiles in flight, ONE raw s_barrier per k-tile and counted vmcnt waits.
+// k_conv_dma: the implicit GEMM of k_conv (K order of kt_decode, raw input) with both operand tiles staged by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no staging registers, no ds_write) into a ring of 3 stages, two tiles in flight,
+// ONE raw s_barrier per k-tile and counted vmcnt waits.  WM waves of 32x96 stack along M: 128x96 (4 waves) or
+// 256x96 (8 waves, half the weight staging per MAC).
 // LDS rows are unpadded 64-byte lines (a DMA instruction fills 1 KiB linearly: 16 rows); bank conflicts of the
 // ds_read_b128 fragment reads are avoided by XOR-swizzling the 16-byte quarter with (row>>2)&3, applied on the
-// per-lane SOURCE address of the DMA and on the read address.  Zero padding comes from a page of zeros.
+// per-lane SOURCE offset of the DMA and on the read address.  Zero padding, ragged rows and the nearest-x2
+// upsample (UPS) are all per-lane source offsets, recomputed only when the tap changes (every KG k-tiles).
 // The GroupNorm(+SiLU) prologue cannot ride a DMA, so normalised inputs are materialised once by k_gn_apply.
 // ---------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(256))) float g_zero_page[64];
 
-template <int WM, int NS>
-__global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : (NS == 2 ? 4 : 3)) void k_conv_dma(const ConvK p) {
-    constexpr int BM = WM * 32, BN = 96, ROWS = BM + BN, STAGE_F = ROWS * 16, D = NS - 1;
+template <int WM, int NS, bool UPS>
+__global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const ConvK p) {
+    static_assert(NS == 3, "the wait counts below assume a 3-stage ring");
+    constexpr int BM = WM * 32, BN = 96, ROWS = BM + BN, STAGE_F = ROWS * 16;
     constexpr int NB2 = (WM == 4) ? 2 : 1;   // B instructions per wave (6 in total, instruction b = wave + WM*j)
+    constexpr unsigned OOB = 0x80000000u;    // buffer offset past num_records (< 2 GiB): the load returns zeros
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -333,14 +337,23 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : (NS == 2 ? 4 : 3)) void k_
     const int pad = p.ks >> 1;
     const int ncc = p.Cin >> 4;
     const int hw_out = p.Hout * p.Wout;
+    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+
+    // Both operands are fetched through buffer descriptors: address = base + per-lane offset (VGPR) + a wave-uniform
+    // offset (SGPR), so walking K costs no vector ALU at all, and padding / ragged rows are lanes whose offset is
+    // out of range (hardware returns zeros).
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * p.in_pitch * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.w, (short)0, (int)((long)p.wrows * p.Ktot * 4), 0x00020000);
 
     // DMA instruction i of a tile fills rows 16i..16i+15: A rows by instructions wave + WM*j (j = 0,1), the 96 B rows
     // by instructions BM/16 + b with b = wave + WM*j < 6.
     // Lane L of an instruction writes physical quarter L&3 of row 16i + (L>>2).
     const int lrow = lane >> 2, pq = lane & 3;
-    long a_base[2];        // j = 0,1: A rows (pixels)
-    unsigned a_mask[2];
-    const float *pB[2];    // j = 2,3: B rows (output channels)
+    int iy0[2], ix0[2];    // top-left input coordinate of the 3x3 window (in the x2 grid when UPS); huge negative = no row
+    unsigned nb[2];        // byte offset of image n, plus this lane's quarter
+    unsigned a_cur[2];     // byte offset of this lane's 16 bytes for the current tap (or OOB)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = (wave + WM * j) * 16 + lrow;
@@ -351,59 +364,65 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : (NS == 2 ? 4 : 3)) void k_
         const int n = (int)(Pc / hw_out);
         const int rem = (int)(Pc - (long)n * hw_out);
         const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-        const int by = oy * p.stride - pad, bx = ox * p.stride - pad;
-        a_base[j] = (((long)n * p.Hin + by) * p.Win + bx) * p.in_pitch + ql * 4;
-        unsigned m = 0;
-        for (int t = 0; t < p.taps; ++t) {
-            const int ky = (p.ks == 3) ? t / 3 : 0, kx = (p.ks == 3) ? t - ky * 3 : 0;
-            const bool ok = in && by + ky >= 0 && by + ky < p.Hin && bx + kx >= 0 && bx + kx < p.Win;
-            m |= (ok ? 1u : 0u) << t;
-        }
-        a_mask[j] = m;
+        iy0[j] = in ? oy * p.stride - pad : -(1 << 20);
+        ix0[j] = ox * p.stride - pad;
+        nb[j] = (unsigned)n * (unsigned)(p.Hin * p.Win) * pitch4 + ql * 16;
     }
+    auto set_tap = [&](int tap) {
+        const int ky = (p.ks == 3) ? tap / 3 : 0, kx = (p.ks == 3) ? tap - ky * 3 : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+            const int Hv = UPS ? 2 * p.Hin : p.Hin, Wv = UPS ? 2 * p.Win : p.Win;
+            const bool ok = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+            const int sy = UPS ? iy >> 1 : iy, sx = UPS ? ix >> 1 : ix;
+            a_cur[j] = ok ? nb[j] + (unsigned)(sy * p.Win + sx) * pitch4 : OOB;
+        }
+    };
     const int nk_all = ncc * p.taps;
     const int kt0 = blockIdx.z * p.kt_per;
     const int nk = min(nk_all, kt0 + p.kt_per);
+    unsigned b_voff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int brow = (wave + WM * j) * 16 + lrow;         // valid < 96
-        const int row = BM + brow;
-        const int ql = pq ^ ((row >> 2) & 3);
+        const int ql = pq ^ (((BM + brow) >> 2) & 3);
         const int gn = n0 + brow;
-        const bool ok = brow < BN && gn < p.wrows;
-        pB[j] = ok ? p.w + (long)gn * p.Ktot + (long)kt0 * 16 + ql * 4 : g_zero_page + ql * 4;   // zero page never advances
+        b_voff[j] = (brow < BN && gn < p.wrows) ? (unsigned)gn * (unsigned)p.Ktot * 4u + ql * 16 : OOB;
     }
-    const bool b_ok0 = (wave * 16 + lrow) < BN && (n0 + wave * 16 + lrow) < p.wrows;
-    const bool b_ok1 = ((wave + WM) * 16 + lrow) < BN && (n0 + (wave + WM) * 16 + lrow) < p.wrows;
     const bool has_b0 = wave < 6;                              // B instruction wave
     const bool has_b1 = (NB2 == 2) && wave + WM < 6;           // B instruction wave + WM
+    const int n_w = 2 + (has_b0 ? 1 : 0) + (has_b1 ? 1 : 0);   // DMA instructions of this wave per tile
 
     int tap_i, cc_i;                                           // issue cursor
     kt_decode(kt0, ncc, p.taps, cc_i, tap_i);
     int cg_i = cc_i / KG, gend_i = min(ncc, (cg_i + 1) * KG);
+    int soffB = kt0 * 64;
+    set_tap(tap_i);
     auto issue = [&](int stage) {
-        const int ky = (p.ks == 3) ? tap_i / 3 : 0, kx = (p.ks == 3) ? tap_i - ky * 3 : 0;
-        const long delta = ((long)ky * p.Win + kx) * p.in_pitch + cc_i * 16;
         float *dst = lds + stage * STAGE_F + wave * 256;       // + WM*256 floats per j (WM instructions further)
+        const int soffA = cc_i * 64;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool ok = (a_mask[j] >> tap_i) & 1u;
-            const float *src = ok ? p.in + (a_base[j] + delta) : g_zero_page + pq * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(dst + j * (WM * 256)), 16, 0, 0);
-        }
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(dst + j * (WM * 256)), 16,
+                                                     a_cur[j], soffA, 0, 0);
         if (has_b0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pB[0],
-                                             (__attribute__((address_space(3))) void *)(dst + BM * 16), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(dst + BM * 16), 16,
+                                                     b_voff[0], soffB, 0, 0);
         if (has_b1)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pB[1],
-                                             (__attribute__((address_space(3))) void *)(dst + BM * 16 + WM * 256), 16, 0, 0);
-        if (b_ok0) pB[0] += 16;
-        if (b_ok1) pB[1] += 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(dst + BM * 16 + WM * 256),
+                                                     16, b_voff[1], soffB, 0, 0);
+        soffB += 64;
         if (++cc_i == gend_i) {
             if (++tap_i == p.taps) { tap_i = 0; ++cg_i; gend_i = min(ncc, (cg_i + 1) * KG); }
             cc_i = cg_i * KG;
+            set_tap(tap_i);
         }
+    };
+    auto wait_younger = [&]() {   // all but this wave's DMAs of the youngest tile have landed
+        if (n_w == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n_w == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     };
 
     // fragment read offsets (floats) inside a stage; the three B fragments sit 32 rows (512 floats) apart with the
@@ -423,35 +442,23 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : (NS == 2 ? 4 : 3)) void k_
 
     // Software pipeline over HALF k-tiles (8 of the 16 channels = 12 MFMAs): the LDS reads of the next half are in
     // flight while the MFMAs of the current half run, and the per-tile barrier is followed directly by MFMAs whose
-    // operands are already in registers.  Per tile t:
-    //     3 mfma h0(t) | read h1(t) | 9 mfma h0(t) | wait DMA(t+1), barrier | 3 mfma h1(t) | issue DMA(t+NS), read h0(t+1) | 9 mfma h1(t)
-    int issued = 0;                                            // tiles issued so far (relative)
+    // operands are already in registers.  Per tile t (stage t % 3, a compile-time constant in the unrolled body):
+    //     3 mfma h0(t) | read h1(t) | 9 mfma h0(t) | wait DMA(t+1), barrier | 3 mfma h1(t) | issue DMA(t+3), read h0(t+1) | 9 mfma h1(t)
     const int ntiles = nk - kt0;
-    auto wait_tile = [&](int t) {   // my DMAs of tile t have landed once only the younger tiles' instructions are outstanding
-        const int younger = issued - t - 1;
-        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (NS == 3) {   // one younger tile in flight: 2 A + (has_b0) + (has_b1) instructions of this wave
-            const int n_w = 2 + (has_b0 ? 1 : 0) + (has_b1 ? 1 : 0);
-            if (n_w == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (n_w == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-#pragma unroll
-    for (int t = 0; t < D; ++t)
-        if (t < ntiles) { issue(t % NS); ++issued; }
     f32x4 a0, a1, b0[3], b1[3];
     if (ntiles > 0) {
-        wait_tile(0);
+        issue(0);
+        if (ntiles > 1) { issue(1); wait_younger(); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (issued < ntiles) { issue(issued % NS); ++issued; }
+        if (ntiles > 2) issue(2);
         a0 = *reinterpret_cast<const f32x4 *>(lds + a_off0);
 #pragma unroll
         for (int j = 0; j < 3; ++j) b0[j] = *reinterpret_cast<const f32x4 *>(lds + b_off0 + j * 512);
     }
-    for (int t = 0; t < ntiles; ++t) {
-        const float *base = lds + (t % NS) * STAGE_F;
+    auto body = [&](auto uc, int t) {
+        constexpr int U = decltype(uc)::value, UN = (U + 1) % NS;
+        const float *base = lds + U * STAGE_F, *nbase = lds + UN * STAGE_F;
         // (the reads go AFTER the first MFMAs in program order: the compiler's wait for h0 is a full lgkmcnt(0))
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[j][0], acc[j], 0, 0, 0);
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : (NS == 2 ? 4 : 3)) void k_
         __builtin_amdgcn_sched_barrier(0);
         const bool more = t + 1 < ntiles;
         if (more) {
-            wait_tile(t + 1);
+            if (t + 2 < ntiles) wait_younger(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done reading tile t before its stage refills
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -476,8 +483,7 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : (NS == 2 ? 4 : 3)) void k_
         for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], b1[j][0], acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            if (issued < ntiles) { issue(issued % NS); ++issued; }
-            const float *nbase = lds + ((t + 1) % NS) * STAGE_F;
+            if (t + NS < ntiles) issue(U);
             a0 = *reinterpret_cast<const f32x4 *>(nbase + a_off0);
 #pragma unroll
             for (int j = 0; j < 3; ++j) b0[j] = *reinterpret_cast<const f32x4 *>(nbase + b_off0 + j * 512);
@@ -487,6 +493,11 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : (NS == 2 ? 4 : 3)) void k_
         for (int s = 1; s < 4; ++s)
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[j][s], acc[j], 0, 0, 0);
+    };
+    for (int t = 0; t < ntiles; t += NS) {
+        body(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < ntiles) body(std::integral_constant<int, 2>{}, t + 2);
     }
 
     // epilogue (same contract as k_conv)
@@ -947,7 +958,8 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     // the 8-wave 256x96 tile when that covers at least half the chip (2 workgroups/CU = 512 slots), else 4 waves x 128x96
     static const int dma_thr = getenv("HL_CONV_T8") ? atoi(getenv("HL_CONV_T8")) : 256;
     static const int dma_off = getenv("HL_CONV_NODMA") ? 1 : 0;
-    const bool dma = !dma_off && cfg == 0 && !a.ups && (a.coefA == nullptr || a.act_ws);
+    const bool dma = !dma_off && cfg == 0 && (a.coefA == nullptr || a.act_ws) &&
+                     (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && (long)cpad * p.Ktot * 4 < (1L << 31);
     const long blocks8 = ((M + 255) / 256) * (cpad / 96);
     const bool tile8 = dma && blocks8 >= dma_thr;
     if (tile8) blocks = blocks8;
@@ -981,6 +993,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     } while (0)
     if (dma) {
         if (mode != 0) {   // materialise GroupNorm(+SiLU) once, then the DMA kernel reads it raw
+            HL_REQUIRE(!a.ups, "conv2d: upsample with a GroupNorm prologue is not used by the UNet");
             HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
             const long npix = a.in.pixels();
             long g = (npix * (a.in.C / 4) + 255) / 256;
@@ -990,15 +1003,13 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0;
         }
         p.n_nblocks = cpad / 96;
-        if (tile8) {
-            p.n_mtiles = (int)((M + 255) / 256);
-            dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
-            hipLaunchKernelGGL((k_conv_dma<8, 3>), grid, dim3(512), (size_t)3 * 352 * 16 * sizeof(float), st, p);
-        } else {
-            p.n_mtiles = (int)((M + 127) / 128);
-            dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
-            hipLaunchKernelGGL((k_conv_dma<4, 3>), grid, dim3(256), (size_t)3 * 224 * 16 * sizeof(float), st, p);
-        }
+        p.n_mtiles = (int)((M + (tile8 ? 255 : 127)) / (tile8 ? 256 : 128));
+        dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
+        const size_t shm8 = (size_t)3 * 352 * 16 * sizeof(float), shm4 = (size_t)3 * 224 * 16 * sizeof(float);
+        if (tile8 && a.ups) hipLaunchKernelGGL((k_conv_dma<8, 3, true>), grid, dim3(512), shm8, st, p);
+        else if (tile8) hipLaunchKernelGGL((k_conv_dma<8, 3, false>), grid, dim3(512), shm8, st, p);
+        else if (a.ups) hipLaunchKernelGGL((k_conv_dma<4, 3, true>), grid, dim3(256), shm4, st, p);
+        else hipLaunchKernelGGL((k_conv_dma<4, 3, false>), grid, dim3(256), shm4, st, p);
     } else if (cfg == 0) {
         p.n_mtiles = (int)((M + 127) / 128); p.n_nblocks = cpad / 96;
         dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
