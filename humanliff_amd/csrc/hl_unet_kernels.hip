@@ -853,6 +853,142 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attention(const float *__restri
     }
 }
 
+// Key-split variant for short sequences (the UNet's 32x32 / 16x16 / 8x8 attention levels), where one wave per
+// 32-query tile leaves most of the 1024 SIMDs idle: the KW waves of a workgroup share ONE query tile and take every
+// KW-th key tile each, then merge their (max, sum, O) partials through LDS.  No workgroup barrier inside the key
+// loop: K rows go straight from global memory into the MFMA A operand (lane = key, the two halves of the wave take
+// alternate groups of 4 channels; Q is loaded with the same permutation), V tiles are staged in a wave-private LDS
+// region, and with PF the next tile's K and V are in flight (registers) while the current one is multiplied.
+template <int CH, int KW, bool PF>
+__global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__restrict__ qkv, int T, int C, int heads,
+                                                             float *__restrict__ out) {
+    constexpr int CT = CH / 32, NG = CH / 8, WLDS = CH * 33 + 64;
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [KW][WLDS]: V tile (32 x CH), later O^T (CH x 33) + m,l
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *sV = sh + wave * WLDS;
+    const int nh = blockIdx.y, n = nh / heads, head = nh % heads;
+    const int q0 = blockIdx.x * 32;
+    const float scale = 1.f / sqrtf(sqrtf((float)CH));
+    const long pitch = 3L * C;
+    const float *base = qkv + (long)n * T * pitch + (long)head * 3 * CH;
+
+    // contraction order: MFMA (m, i) multiplies channel 8m + 4*half + i
+    const int qj = min(q0 + (lane & 31), T - 1);
+    f32x4 qreg[NG];
+#pragma unroll
+    for (int m = 0; m < NG; ++m) {
+        qreg[m] = *reinterpret_cast<const f32x4 *>(base + (long)qj * pitch + 8 * m + 4 * half);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qreg[m][i] *= scale;
+    }
+    auto loadK = [&](int k0, f32x4(&kr)[NG]) {
+        const int kk = min(k0 + (lane & 31), T - 1);
+#pragma unroll
+        for (int m = 0; m < NG; ++m) kr[m] = *reinterpret_cast<const f32x4 *>(base + (long)kk * pitch + CH + 8 * m + 4 * half);
+    };
+    auto loadV = [&](int k0, f32x4(&vr)[NG]) {   // 32 keys x CH floats = NG float4 per lane, consecutive lanes along a row
+#pragma unroll
+        for (int e = 0; e < NG; ++e) {
+            const int idx = e * 64 + lane, key = idx / (CH / 4), c = (idx - key * (CH / 4)) * 4;
+            vr[e] = *reinterpret_cast<const f32x4 *>(base + (long)min(k0 + key, T - 1) * pitch + 2 * CH + c);
+        }
+    };
+    auto storeV = [&](const f32x4(&vr)[NG]) {
+#pragma unroll
+        for (int e = 0; e < NG; ++e) {
+            const int idx = e * 64 + lane, key = idx / (CH / 4), c = (idx - key * (CH / 4)) * 4;
+            *reinterpret_cast<f32x4 *>(sV + key * CH + c) = vr[e];
+        }
+    };
+
+    f32x16 o[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float mrun = -3.0e38f, lrun = 0.f;
+
+    f32x4 kc[NG], vn[NG], kn[NG];   // kn unused (and eliminated) without PF
+    int k0 = wave * 32;
+    if (k0 < T) { loadK(k0, kc); loadV(k0, vn); }
+    for (; k0 < T; k0 += KW * 32) {
+        storeV(vn);
+        const int k1 = k0 + KW * 32;
+        if constexpr (PF) { if (k1 < T) { loadK(k1, kn); loadV(k1, vn); } }
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < NG; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[m][i] * scale, qreg[m][i], st, 0, 0, 0);
+        // st[r] = score(key = (r&3)+8*(r>>2)+4*half, query = lane&31); mask keys beyond T
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= T) st[r] = -3.0e38f;
+            mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __expf(mrun - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = __expf(st[r] - mnew);
+            psum += st[r];
+        }
+        psum += __shfl_xor(psum, 32);
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int key = (s & 3) + 8 * (s >> 2) + 4 * half;  // the key this lane's st[s] belongs to
+                o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[key * CH + c * 32 + (lane & 31)], st[s], o[c], 0, 0, 0);
+            }
+        }
+        if constexpr (PF) {
+#pragma unroll
+            for (int m = 0; m < NG; ++m) kc[m] = kn[m];
+        } else if (k1 < T) {
+            loadK(k1, kc);
+            loadV(k1, vn);
+        }
+    }
+
+    // merge the KW partials: O^T of every wave to its LDS region as [channel][33] (+ running max / sum per query)
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sV[(c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 33 + (lane & 31)] = o[c][r];
+    if (half == 0) {
+        sV[CH * 33 + lane] = mrun;
+        sV[CH * 33 + 32 + lane] = lrun;
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * CH; e += KW * 64) {
+        const int q = e / CH, c = e - q * CH;
+        float ms = -3.0e38f;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) ms = fmaxf(ms, sh[w * WLDS + CH * 33 + q]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) {
+            const float f = __expf(sh[w * WLDS + CH * 33 + q] - ms);
+            num += sh[w * WLDS + c * 33 + q] * f;
+            den += sh[w * WLDS + CH * 33 + 32 + q] * f;
+        }
+        if (q0 + q < T) out[((long)n * T + q0 + q) * C + head * CH + c] = num / den;
+    }
+}
+
 // generic (slow) attention for head widths that are not a multiple of 32: one thread per (query, channel-chunk)
 __global__ void k_attention_generic(const float *__restrict__ qkv, int T, int C, int heads, int ch, float *__restrict__ out) {
     extern __shared__ float sh[];  // scores of one query row per wave: [waves][T]
@@ -1098,6 +1234,17 @@ int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipS
         else if (wpb == 2) hipLaunchKernelGGL((k_attention<CH_, 2>), grid, dim3(128), 0, st, qkv, T, C, heads, out); \
         else hipLaunchKernelGGL((k_attention<CH_, 1>), grid, dim3(64), 0, st, qkv, T, C, heads, out);                \
     } while (0)
+    // short sequences: split the keys over the 4 waves of a workgroup instead (one query tile per workgroup)
+    if ((long)qtiles * N * heads < 1024 && (ch == 96 || ch == 192) && (3L * C) % 4 == 0) {
+        dim3 gks(qtiles, N * heads);
+        if (ch == 96)
+            hipLaunchKernelGGL((k_attention_ks<96, 4, true>), gks, dim3(256), (size_t)4 * (96 * 33 + 64) * sizeof(float), st, qkv, T, C,
+                               heads, out);
+        else
+            hipLaunchKernelGGL((k_attention_ks<192, 4, false>), gks, dim3(256), (size_t)4 * (192 * 33 + 64) * sizeof(float), st, qkv, T,
+                               C, heads, out);
+        return check_launch("k_attention_ks");
+    }
     switch (ch) {
         case 32: HL_ATT(32); break;
         case 64: HL_ATT(64); break;

@@ -98,7 +98,8 @@ def test_conv_fused_groupnorm_silu_residual():
     assert (got - want).abs().max() < 3e-5
 
 
-@pytest.mark.parametrize("N,T,C,heads", [(2, 64, 128, 4), (1, 256, 384, 4), (2, 1024, 384, 4), (1, 64, 768, 4), (1, 100, 64, 4)])
+@pytest.mark.parametrize("N,T,C,heads", [(2, 64, 128, 4), (1, 256, 384, 4), (2, 1024, 384, 4), (1, 64, 768, 4), (1, 100, 64, 4),
+                                          (1, 100, 384, 4), (2, 200, 768, 4), (4, 1024, 384, 4), (16, 1024, 384, 4)])
 def test_attention_matches_torch(N, T, C, heads):
     from humanliff_amd import _lib
     g = torch.Generator().manual_seed(T + C)
