@@ -666,6 +666,66 @@ __global__ void k_gn_partial(const float *__restrict__ x, long pitch, int HW, in
     }
 }
 
+// Small tensors (HW*C <= 512K): one 256-thread workgroup per (group, image) reads the group's HW x C/32 slab and
+// writes the group's affine directly - 32*N workgroups in flight instead of N, no second launch.
+template <int V>
+__global__ __launch_bounds__(256) void k_gn_small(const float *__restrict__ x, long pitch, int HW, int C,
+                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                  const float *__restrict__ emb, long emb_pitch, float *__restrict__ cA,
+                                                  float *__restrict__ cB) {
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int cg = C / 32, per = cg / V;
+    const float *base = x + (long)n * HW * pitch + g * cg;
+    float s = 0.f, ss = 0.f;
+    const int items = HW * per;
+    for (int i = tid; i < items; i += 256) {
+        const int pix = i / per, sub = i - pix * per;
+        const float *q = base + (long)pix * pitch + sub * V;
+        if (V == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(q);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        } else if (V == 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(q);
+            s += v.x + v.y;
+            ss += v.x * v.x + v.y * v.y;
+        } else {
+            const float v = *q;
+            s += v;
+            ss += v * v;
+        }
+    }
+    double ds = (double)s, dss = (double)ss;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        ds += __shfl_xor(ds, d);
+        dss += __shfl_xor(dss, d);
+    }
+    __shared__ double red[8];
+    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = ds; red[(tid >> 6) * 2 + 1] = dss; }
+    __syncthreads();
+    ds = (red[0] + red[2]) + (red[4] + red[6]);
+    dss = (red[1] + red[3]) + (red[5] + red[7]);
+    const double cnt = (double)HW * cg;
+    const double mean = ds / cnt;
+    double var = dss / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    for (int j = tid; j < cg; j += 256) {
+        const int c = g * cg + j;
+        float a = rstd * gamma[c];
+        float b = beta[c] - (float)mean * a;
+        if (emb) {
+            const float sc = 1.f + emb[(long)n * emb_pitch + c];
+            const float sf = emb[(long)n * emb_pitch + C + c];
+            a = a * sc;
+            b = b * sc + sf;
+        }
+        cA[(long)n * C + c] = a;
+        cB[(long)n * C + c] = b;
+    }
+}
+
 // grid (32 groups, N), one wave each: lanes sum the chunk partials (double), then lanes < C/32 write
 // A = rstd*gamma [*(1+scale)], B = (beta - mean*rstd*gamma) [*(1+scale) + shift] for the group's channels
 __global__ __launch_bounds__(64) void k_gn_coef(const float *__restrict__ partial, int nchunks, int HW, int C,
@@ -1186,6 +1246,17 @@ int groupnorm_coef(const View &x, const float *gamma, const float *beta, const f
     HL_REQUIRE(x.C % 32 == 0, "GroupNorm32 needs C %% 32 == 0 (C=%d)", x.C);
     const int HW = x.H * x.W, cq = x.C / 4;
     const int nch = gn_chunks(HW, x.C);
+    if (nch == 1) {
+        const int cg = x.C / 32;
+        dim3 grid(32, x.N);
+        if (cg % 4 == 0 && ((uintptr_t)x.p % 16) == 0 && x.pitch % 4 == 0)
+            hipLaunchKernelGGL(k_gn_small<4>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
+        else if (cg % 2 == 0 && ((uintptr_t)x.p % 8) == 0 && x.pitch % 2 == 0)
+            hipLaunchKernelGGL(k_gn_small<2>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
+        else
+            hipLaunchKernelGGL(k_gn_small<1>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
+        return check_launch("k_gn_small");
+    }
     int k = (nch == 1 ? 1024 : 512) / cq;
     if (k < 1) k = 1;
     HL_REQUIRE(cq <= 1024, "groupnorm_coef: C too large");

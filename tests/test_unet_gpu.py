@@ -98,6 +98,31 @@ def test_conv_fused_groupnorm_silu_residual():
     assert (got - want).abs().max() < 3e-5
 
 
+@pytest.mark.parametrize("N,C,H,W,use_emb", [(2, 384, 16, 16, True), (3, 192, 8, 8, False), (1, 96, 12, 20, True),
+                                              (2, 1152, 8, 8, True), (2, 192, 64, 64, True), (1, 64, 128, 96, False)])
+def test_groupnorm_affine_matches_torch(N, C, H, W, use_emb):
+    """GroupNorm32 statistics folded to a per-(n,c) affine (nn.py:17-19,100; scale/shift of unet.py:212-216):
+    small tensors take the one-workgroup-per-group kernel, large ones the chunked two-pass."""
+    from humanliff_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn((N, C, H, W), generator=g) * 1.5 + 0.3
+    gamma, beta = torch.randn(C, generator=g) * 0.2 + 1, torch.randn(C, generator=g) * 0.2
+    emb = torch.randn((N, 2 * C), generator=g) * 0.3
+    xd, gd_, bd_, ed_ = nhwc(x).to(dev), gamma.to(dev), beta.to(dev), emb.to(dev)
+    cA, cB = torch.empty((N, C), device=dev), torch.empty((N, C), device=dev)
+    scratch = torch.empty(N * 128 * 64 + 64, device=dev)
+    _lib.check(L.hl_groupnorm_coef(_lib.ptr(xd), N, H, W, C, _lib.ptr(gd_), _lib.ptr(bd_), _lib.ptr(ed_) if use_emb else None,
+                                   _lib.ptr(cA), _lib.ptr(cB), _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    want = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+    if use_emb:
+        scale, shift = emb.chunk(2, dim=1)
+        want = want * (1 + scale[:, :, None, None]) + shift[:, :, None, None]
+    rec = x * cA.cpu()[:, :, None, None] + cB.cpu()[:, :, None, None]
+    assert (rec - want).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize("N,T,C,heads", [(2, 64, 128, 4), (1, 256, 384, 4), (2, 1024, 384, 4), (1, 64, 768, 4), (1, 100, 64, 4),
                                           (1, 100, 384, 4), (2, 200, 768, 4), (4, 1024, 384, 4), (16, 1024, 384, 4)])
 def test_attention_matches_torch(N, T, C, heads):
