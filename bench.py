@@ -37,7 +37,7 @@ COARSE_FLOP_PER_RAY = 128 * 79616
 # Fabric-side bytes per launch of the two dominant kernels from the separate rocprofv3 PMC passes (FETCH_SIZE
 # doubled per the gfx950 calibration, WRITE_SIZE as is): profiles/r01_pmc_hbm_traffic.md.  Not measured by this
 # script - PMC collection needs its own runs.
-PMC_TRAFFIC = {"k_conv_avg_launch_b4": 207e6, "k_march_fine_512x512": 3.8e9,
+PMC_TRAFFIC = {"k_conv_avg_launch_b4": 254e6, "k_march_fine_512x512": 3.95e9,
                "source": "profiles/r01_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
 
 F4 = dict(image_size=256, in_channels=27, out_channels=27, num_channels=192, num_res_blocks=3, num_heads=4,
@@ -122,7 +122,7 @@ def bench_unet(args, rank, world, dev):
     _lib.check(L.hl_unet_profile(handle, 0))
     conv_ms, conv_fl, conv_n = ms[0], fl[0], nl[0]
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    roof = {"bound": "mfma", "kernel": "k_conv (implicit-GEMM conv/1x1, v_mfma_f32_32x32x2_f32), all launches of one denoise step",
+    roof = {"bound": "mfma", "kernel": "k_conv_dma (implicit-GEMM conv/1x1, v_mfma_f32_32x32x2_f32; with its k_gn_apply pre-pass and k_splitk_finish), all launches of one denoise step",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": PMC_TRAFFIC["k_conv_avg_launch_b4"] if B == 4 else None, "traffic_source": PMC_TRAFFIC["source"],
