@@ -1,1 +1,1 @@
-from .renderer import Renderer, render, render_rays  # noqa: F401
+from .renderer import Renderer, render, render_rays, render_view  # noqa: F401

@@ -266,3 +266,27 @@ def render(chunk=1024 * 32, rays_o=None, rays_d=None, near=0., far=1., tri_plane
 
 
 render_rays = render
+
+
+def render_view(H, W, K, R, T, tri_planes, tp_input, renderer, n_samples=128, n_importance=128, white_bkgd=False, u=None,
+                generator=None):
+    """One full view without touching the host: rays + near/far by hl_camera_rays
+    (SynBodyView_datasets.py:316-433 on the device), then the fused render.
+
+    The reference builds the rays with numpy and uploads 6.3 MB per 512x512 view, and draws sample_pdf's uniforms on the
+    CPU (renderer.py:545: 134 MB per view at 128 samples).  Here `u` may be a device tensor (H*W, n_importance); when
+    None it is drawn on the device (`generator`: a device torch.Generator) - same distribution, different stream than the
+    reference's CPU generator, so use render() with host-drawn u where bit-level replay of a reference run matters.
+    Returns [rgb_map (H,W,3), acc_map (H,W), normal_map (H,W,3), depth_map (H,W)].
+    """
+    from ..SynBodyView_datasets import camera_rays
+    core = renderer.module if hasattr(renderer, "module") else renderer
+    dev = tri_planes.device
+    bounds = tp_input["world_bounds"].reshape(-1, 2, 3)[0].detach().cpu().numpy()
+    rays_o, rays_d, near, far, _ = camera_rays(H, W, K, R, T, bounds, dev, return_mask=False)
+    if n_importance > 0 and u is None:
+        u = torch.rand((H * W, n_importance), device=dev, generator=generator)
+    ret = core.render(tp_input, None, None, rays_o[None], rays_d[None], near[None, :, None], far[None, :, None], tri_planes,
+                      n_importance, white_bkgd, n_samples=n_samples, u=None if u is None else u.reshape(1, H * W, -1))
+    out = [ret[k] for k in ret]
+    return [out[0].reshape(H, W, 3), out[1].reshape(H, W), out[2].reshape(H, W, 3), out[3].reshape(H, W)]

@@ -51,6 +51,7 @@ SIGNATURES = {
     "hl_render_rays": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _u, _p, _p, _p, _p, _p]),
     "hl_render_coarse": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p]),
     "hl_render_importance": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _p, _p]),
+    "hl_camera_rays": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
     "hl_render_fine": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _u, _p, _p, _p, _p]),
     "hl_unet_packed_bytes": (_sz, [C.POINTER(UNetCfg)]),
     "hl_unet_create": (_i, [C.POINTER(UNetCfg), _i, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),

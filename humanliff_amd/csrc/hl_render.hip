@@ -582,6 +582,69 @@ __global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// per-view ray generation   [SynBodyView_datasets.py:316-329 get_rays, :370-403 get_near_far, :422-433]
+// One thread per pixel, float64 like the reference's numpy (K, R, T are float64 there), rounded to float32 exactly
+// where sample_ray_batch casts.  Term order follows oracle/camera_oracle.py (no FMA contraction in this build).
+// ---------------------------------------------------------------------------------------------
+struct CamArgs {
+    double Ki[9], R[9], T[3], o[3];   // inv(K), world->camera rotation, translation, camera centre -(R^T T)
+    double b[6];                      // padded bounds: min xyz, max xyz
+    int H, W;
+    float *rays_o, *rays_d, *near, *far;
+    unsigned char *mask;
+};
+
+__global__ __launch_bounds__(256) void k_camera_rays(const CamArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.H * a.W) return;
+    const double x = (double)(int)(i % a.W), y = (double)(int)(i / a.W);
+    double pc[3], q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pc[c] = (x * a.Ki[c * 3 + 0] + y * a.Ki[c * 3 + 1]) + a.Ki[c * 3 + 2];
+        q[c] = pc[c] - a.T[c];
+    }
+    float of[3], df[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double pw = (q[0] * a.R[0 * 3 + c] + q[1] * a.R[1 * 3 + c]) + q[2] * a.R[2 * 3 + c];
+        df[c] = (float)(pw - a.o[c]);
+        of[c] = (float)a.o[c];
+        if (df[c] == 0.0f) df[c] = 1e-8f;   // get_near_far writes this into the caller's ray_d
+    }
+    const double o[3] = {(double)of[0], (double)of[1], (double)of[2]};
+    const double d[3] = {(double)df[0], (double)df[1], (double)df[2]};
+    const float norm32 = sqrtf((df[0] * df[0] + df[1] * df[1]) + df[2] * df[2]);
+    const double eps = 1e-6;
+    int cnt = 0;
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {   // min_x, min_y, min_z, max_x, max_y, max_z
+        const int ax = k % 3;
+        const double t = (a.b[k] - o[ax]) / d[ax];
+        const double p0 = t * d[0] + o[0], p1 = t * d[1] + o[1], p2 = t * d[2] + o[2];
+        const bool inside = p0 >= a.b[0] - eps && p0 <= a.b[3] + eps && p1 >= a.b[1] - eps && p1 <= a.b[4] + eps &&
+                            p2 >= a.b[2] - eps && p2 <= a.b[5] + eps;
+        if (inside) {
+            const double e0 = p0 - o[0], e1 = p1 - o[1], e2 = p2 - o[2];
+            const double r = sqrt((e0 * e0 + e1 * e1) + e2 * e2) / (double)norm32;
+            if (cnt == 0) d0 = r;
+            else if (cnt == 1) d1 = r;
+            ++cnt;
+        }
+    }
+    const bool hit = cnt == 2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.rays_o[i * 3 + c] = of[c];
+        a.rays_d[i * 3 + c] = df[c];
+    }
+    a.near[i] = hit ? (float)fmin(d0, d1) : 0.f;
+    a.far[i] = hit ? (float)fmax(d0, d1) : 1.f;
+    if (a.mask) a.mask[i] = hit ? 1 : 0;
+}
+
 extern "C" {
 
 size_t hl_render_mlp_packed_bytes(void) { return (size_t)PACKED_FLOATS * sizeof(float); }
@@ -698,6 +761,24 @@ int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int
     }
     return render_fine_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, 0, n_rays, n_samples,
                             flags, rgb, acc, depth, stream);
+}
+
+int hl_camera_rays(const double *h_Kinv, const double *h_R, const double *h_T, const double *h_bounds, int H, int W,
+                   float *rays_o, float *rays_d, float *near, float *far, unsigned char *mask_at_box, void *stream) {
+    HL_REQUIRE(h_Kinv && h_R && h_T && h_bounds && rays_o && rays_d && near && far, "hl_camera_rays: null argument");
+    HL_REQUIRE(H > 0 && W > 0, "hl_camera_rays: bad image size %dx%d", H, W);
+    CamArgs a{};
+    for (int i = 0; i < 9; ++i) { a.Ki[i] = h_Kinv[i]; a.R[i] = h_R[i]; }
+    for (int c = 0; c < 3; ++c) {
+        a.T[c] = h_T[c];
+        a.o[c] = -((h_R[0 * 3 + c] * h_T[0] + h_R[1 * 3 + c] * h_T[1]) + h_R[2 * 3 + c] * h_T[2]);
+        a.b[c] = h_bounds[c] + -0.01;
+        a.b[3 + c] = h_bounds[3 + c] + 0.01;
+    }
+    a.H = H; a.W = W; a.rays_o = rays_o; a.rays_d = rays_d; a.near = near; a.far = far; a.mask = mask_at_box;
+    const long long n = (long long)H * W;
+    hipLaunchKernelGGL(k_camera_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_camera_rays");
 }
 
 }  // extern "C"

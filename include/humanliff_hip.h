@@ -104,6 +104,16 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
                    const float *z_all /* or NULL -> linspace */, int z_tiled, int64_t n_rays, int n_total_samples,
                    unsigned flags, float *rgb, float *acc, float *depth, void *stream);
 
+/* Per-view ray generation on the device.  Replaces get_rays
+ * (human_diffusion/SynBodyView_datasets.py:316-329), the float32 casts and the near=0 / far=1 fill of
+ * sample_ray_batch (:422-433) and get_near_far (:370-403) for one pinhole camera: float64 arithmetic like the
+ * reference's numpy, rounded to float32 where the reference casts.  h_Kinv = inv(K) (3,3), h_R (3,3) world->camera,
+ * h_T (3), h_bounds (2,3) are HOST float64 arrays copied into the launch; outputs are device arrays of H*W rays in
+ * row-major pixel order: rays_o, rays_d (R,3) (exact zeros of rays_d become 1e-8 as in the reference), near, far (R),
+ * mask_at_box (R) bytes or NULL. */
+int hl_camera_rays(const double *h_Kinv, const double *h_R, const double *h_T, const double *h_bounds, int H, int W,
+                   float *rays_o, float *rays_d, float *near, float *far, unsigned char *mask_at_box, void *stream);
+
 
 /* ------------------------------------------------------------------------
  * Path 1 — tri-plane UNet denoiser + Gaussian-diffusion sampler update

@@ -2,6 +2,7 @@
 vs the CPU oracle on the same seeded inputs.  Tolerances are fp32-roundoff class and written
 next to each check."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -10,6 +11,7 @@ import torch
 from tests.golden_util import load_render_case, psnr
 
 pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.fixture(scope="module")
@@ -196,3 +198,76 @@ def test_ragged_ray_counts(R, dev):
     assert out["rgb_map"].shape == (R, 3)
     assert (out["rgb_map"] - rgb).abs().max() < 2e-5
     assert (out["depth_map"] - depth).abs().max() < 5e-5
+
+
+# ---- per-view ray generation on the device ---------------------------------------------------
+def _cam_cases():
+    import numpy as np
+    g = np.load(os.path.join(GOLDEN, "camera_rays.npz"))
+    return [str(n) for n in g["names"]]
+
+
+@pytest.mark.parametrize("name", _cam_cases())
+def test_camera_rays_match_reference_golden(name, dev):
+    """hl_camera_rays against get_rays / get_near_far of the reference (float64 arithmetic rounded to float32: equal
+    up to one float32 ulp where the summation order of a 3-term dot differs)."""
+    import numpy as np
+    from humanliff_amd.SynBodyView_datasets import camera_rays
+    g = np.load(os.path.join(GOLDEN, "camera_rays.npz"))
+    H, W = [int(v) for v in g[f"{name}_HW"]]
+    ro, rd, near, far, mask = camera_rays(H, W, g[f"{name}_K"], g[f"{name}_R"], g[f"{name}_T"], g[f"{name}_bounds"], dev)
+    assert np.array_equal(mask.cpu().numpy(), g[f"{name}_mask"])
+    for got, want in [(ro, g[f"{name}_rays_o"]), (rd, g[f"{name}_rays_d"]), (near, g[f"{name}_near"]), (far, g[f"{name}_far"])]:
+        got = got.cpu().numpy()
+        ulp = np.spacing(np.abs(want).astype(np.float32))
+        assert (np.abs(got.astype(np.float64) - want.astype(np.float64)) <= ulp).all()
+        assert (got != want).mean() < 0.01
+
+
+def test_camera_rays_fullsize_match_oracle(dev):
+    """512x512 view: device rays equal the oracle's."""
+    import numpy as np
+    from oracle import camera_oracle as co
+    from humanliff_amd import synthetic as syn
+    from humanliff_amd.SynBodyView_datasets import camera_rays, get_rays
+    H = W = 512
+    K, c2w, cam = syn.orbit_camera(7, 36, H, W)
+    R = c2w.T.copy()
+    T = (-R @ cam).reshape(3, 1)
+    b = np.asarray(syn.WORLD_BOUNDS, dtype=np.float32)
+    ro, rd, near, far, mask = camera_rays(H, W, K, R, T, b, dev)
+    oro, ord_, onear, ofar, omask = co.camera_rays(H, W, K, R, T, b)
+    assert np.array_equal(mask.cpu().numpy(), omask)
+    for got, want in [(ro, oro), (rd, ord_), (near, onear), (far, ofar)]:
+        got = got.cpu().numpy()
+        ulp = np.spacing(np.abs(want))
+        assert (np.abs(got.astype(np.float64) - want.astype(np.float64)) <= ulp).all()
+        assert (got != want).mean() < 1e-3
+    ro2, rd2 = get_rays(H, W, K, R, T, dev)
+    assert ro2.shape == (H, W, 3) and torch.equal(rd2.reshape(-1, 3), rd)
+
+
+def test_render_view_equals_render_on_host_made_rays(dev):
+    """render_view (device rays + the fused render) == render() fed with the oracle's host-made rays and the same u."""
+    import numpy as np
+    from oracle import camera_oracle as co
+    from humanliff_amd import synthetic as syn
+    from humanliff_amd.NeRF import render_view
+    H = W = 96
+    K, c2w, cam = syn.orbit_camera(3, 36, H, W)
+    R = c2w.T.copy()
+    T = (-R @ cam).reshape(3, 1)
+    b = np.asarray(syn.WORLD_BOUNDS, dtype=np.float32)
+    r = make_renderer(syn.render_mlp_state(3), dev)
+    planes = syn.triplane(seed=11).to(dev)
+    tp = {"world_bounds": torch.from_numpy(b)[None].to(dev)}
+    u = torch.rand((H * W, 32), generator=torch.Generator().manual_seed(5)).to(dev)
+    got = render_view(H, W, K, R, T, planes, tp, r, n_samples=32, n_importance=32, u=u)
+    oro, ord_, onear, ofar, _ = co.camera_rays(H, W, K, R, T, b)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    want = r.render(tp, None, None, t(oro)[None], t(ord_)[None], t(onear)[None], t(ofar)[None], planes, 32, False, n_samples=32,
+                    u=u[None])
+    assert got[0].shape == (H, W, 3) and got[3].shape == (H, W)
+    # identical kernels on rays that agree to <= 1 ulp on <0.1 % of the elements
+    assert (got[0].reshape(-1, 3) - want["rgb_map"][0]).abs().max() < 1e-5
+    assert (got[3].reshape(-1) - want["depth_map"][0]).abs().max() < 1e-5
