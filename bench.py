@@ -130,6 +130,33 @@ def bench_unet(args, rank, world, dev):
             "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4),
             "other_ms": {"groupnorm": round(ms[1], 3), "attention": round(ms[2], 3), "emb_prep": round(ms[3], 3)}}
     del it
+    # ---- opt-in arithmetic mode (not the headline): fp32 products emulated with three bf16 planes per operand ----
+    roof["bf16x3_mode"] = None
+    if world == 1 and not args.no_bf16x3_leg:
+        xx = torch.randn((B, 27, 256, 256), generator=torch.Generator().manual_seed(99)).to(dev)
+        tt = torch.full((B,), 500, dtype=torch.int64, device=dev)
+        with torch.no_grad():
+            ref = model(xx, tt, x_cond, y=y)
+            model.set_conv_mode("bf16x3")
+            alt = model(xx, tt, x_cond, y=y)
+        it3 = diffusion.p_sample_loop_progressive(model, (B, 27, 256, 256), x_cond=x_cond, noise=x_T, clip_denoised=True,
+                                                  model_kwargs={"y": y}, device=dev)
+        next(it3); next(it3)
+        torch.cuda.synchronize()
+        k3 = max(2, min(args.steps, 6))
+        t3 = time.perf_counter()
+        for _ in range(k3):
+            next(it3)
+        torch.cuda.synchronize()
+        s3 = time.perf_counter() - t3
+        del it3
+        model.set_conv_mode("fp32")
+        roof["bf16x3_mode"] = {
+            "what": "UNetModel.set_conv_mode('bf16x3') / HL_CONV_BF16X3: same fp32 tensors and accumulators, products on "
+                    "v_mfma_f32_32x32x16_bf16 from exact 3-way bf16 splits (6 partial products, error <= 3*2^-24 per product); "
+                    "opt-in, NOT used for `value`",
+            "value": round(B * k3 / s3, 3), "unit": "denoise-steps/s", "steps": k3, "ms_per_step": round(s3 * 1e3 / k3, 3),
+            "max_abs_diff_vs_fp32_forward": float((alt - ref).abs().max()), "forward_output_mean_abs": float(ref.abs().mean())}
     return secs, roof, sd, model
 
 
@@ -246,6 +273,7 @@ def main():
     ap.add_argument("--views", type=int, default=2, help="512x512 views per GPU in the render leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--no-bf16x3-leg", action="store_true", help="skip the extra measurement of the opt-in bf16x3 conv mode")
     ap.add_argument("--no-overlap", action="store_true",
                     help="issue the control encoder on the caller's stream instead of the side stream (used for the "
                          "per-kernel rocprof trace: concurrent kernels stretch each other's durations)")

@@ -10,6 +10,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhumanliff_hip.so")
 
+HL_CONV_FP32 = 0
+HL_CONV_BF16X3 = 1
 HL_RENDER_WHITE_BKGD = 1
 HL_RENDER_NORMALIZE_DEPTH = 2
 
@@ -60,10 +62,12 @@ SIGNATURES = {
     "hl_unet_workspace_bytes": (_sz, [_p, _i, _i, _i]),
     "hl_unet_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "hl_unet_set_overlap": (_i, [_p, _i]),
+    "hl_unet_set_conv_mode": (_i, [_p, _i]),
     "hl_unet_profile": (_i, [_p, _i]),
     "hl_unet_profile_read": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "hl_diffusion_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _p]),
     "hl_conv2d_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
+    "hl_conv2d_nhwc_mode": (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
     "hl_groupnorm_coef": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "hl_attention_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "hl_timestep_embedding": (_i, [_p, _p, _i, _i, _p, _p]),

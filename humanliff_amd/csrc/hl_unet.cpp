@@ -23,6 +23,7 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct Conv {
     const float *w = nullptr;  // packed
+    const void *w_bf3 = nullptr;  // packed split-bf16 copy (layers that take the DMA tile), used when Net::conv_mode == 1
     const float *bias = nullptr;
     int Cin = 0, Cin_pad = 0, Cout = 0, ks = 1;
 };
@@ -80,6 +81,7 @@ struct Net {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_block;   // main encoder block i finished (its output feeds the skip sum)
     bool overlap = true;
+    int conv_mode = 0;   // 0: exact fp32 MFMA, 1: fp32 emulated with three bf16 planes per operand (k_conv_bf3)
     // optional per-category HIP-event timing of one forward (bench.py roofline leg)
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;
@@ -123,6 +125,15 @@ Conv make_conv(Net &n, const std::string &p, int Cin, int Cout, int ks) {
         c.w = dst;
     }
     n.packed_off += (fl + 63) / 64 * 64;
+    const size_t bf3 = hl::conv_packed_bf3_bytes(Cout, c.Cin_pad, ks);
+    if (bf3) {
+        if (!n.dry && w) {
+            void *dst = n.packed + n.packed_off;
+            if (hl::conv_pack_weights_bf3(w, Cout, Cin, c.Cin_pad, ks, dst, n.st) != 0 && n.err.empty()) n.err = hl_last_error();
+            c.w_bf3 = dst;
+        }
+        n.packed_off += (bf3 / 4 + 63) / 64 * 64;
+    }
     return c;
 }
 Norm make_norm(Net &n, const std::string &p, int C) {
@@ -154,7 +165,7 @@ int add_res(Net &n, std::vector<EmbPiece> &emb, const std::string &p, int Cin, i
             if (it != n.sd.end() && it->second.second == (int64_t)Cout * Cin * 9) ks = 3;
         }
         r.skip = make_conv(n, p + ".skip_connection", Cin, Cout, ks);
-        if (n.dry) n.packed_off += hl::conv_packed_floats(Cout, round_up(Cin, 16), 3);  // size for the worst case
+        if (n.dry) n.packed_off += hl::conv_packed_floats(Cout, round_up(Cin, 16), 3) * 3;  // size for the worst case (fp32 + bf16x3 copies)
     }
     n.res.push_back(r);
     return (int)n.res.size() - 1;
@@ -339,7 +350,7 @@ struct Exec {
         if (!run) return;
         ConvArgs a{};
         a.in = in; a.in.C = c.Cin_pad;
-        a.w = c.w; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
+        a.w = c.w; a.w_bf3 = n.conv_mode == 1 ? c.w_bf3 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
         a.coefA = cA; a.coefB = cB; a.act = act;
         a.out = out; a.res = res; a.res_pitch = res_pitch;
         a.out2 = out2; a.out2_pitch = out2_pitch; a.res2 = res2; a.res2_pitch = res2_pitch; a.out_nchw = nchw;
@@ -562,6 +573,13 @@ int hl_unet_set_overlap(void *handle, int enable) {
     return HL_OK;
 }
 
+int hl_unet_set_conv_mode(void *handle, int mode) {
+    HL_REQUIRE(handle, "hl_unet_set_conv_mode: null handle");
+    HL_REQUIRE(mode == HL_CONV_FP32 || mode == HL_CONV_BF16X3, "hl_unet_set_conv_mode: unknown mode %d", mode);
+    static_cast<Net *>(handle)->conv_mode = mode;
+    return HL_OK;
+}
+
 void hl_unet_destroy(void *handle) { delete static_cast<Net *>(handle); }
 
 size_t hl_unet_workspace_bytes(void *handle, int B, int H, int W) {
@@ -617,15 +635,22 @@ int hl_unet_profile_read(void *handle, double *h_ms, double *h_flops, int64_t *h
 }
 
 // ---- single ops for tests ------------------------------------------------------------------------
-int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout, int ks,
-                   int stride, int upsample, const float *coefA, const float *coefB, int silu, const float *residual,
-                   float *out, void *scratch, size_t scratch_bytes, void *stream) {
+static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,
+                         int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
+                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream) {
     HL_REQUIRE(Cin % 16 == 0, "hl_conv2d_nhwc: Cin must be a multiple of 16");
-    const size_t need = hl::conv_packed_floats(Cout, Cin, ks) * sizeof(float);
+    const size_t need32 = (hl::conv_packed_floats(Cout, Cin, ks) * sizeof(float) + 255) / 256 * 256;
+    const size_t need = need32 + (mode == HL_CONV_BF16X3 ? hl::conv_packed_bf3_bytes(Cout, Cin, ks) : 0);
     HL_REQUIRE(scratch && scratch_bytes >= need, "hl_conv2d_nhwc: scratch too small (%zu < %zu)", scratch_bytes, need);
     int rc = hl::conv_pack_weights(w_oihw, Cout, Cin, Cin, ks, static_cast<float *>(scratch), (hipStream_t)stream);
     if (rc) return rc;
     ConvArgs a{};
+    if (mode == HL_CONV_BF16X3 && need > need32) {
+        void *dst = static_cast<char *>(scratch) + need32;
+        rc = hl::conv_pack_weights_bf3(w_oihw, Cout, Cin, Cin, ks, dst, (hipStream_t)stream);
+        if (rc) return rc;
+        a.w_bf3 = dst;
+    }
     a.in.p = const_cast<float *>(in); a.in.N = N; a.in.H = H; a.in.W = W; a.in.C = Cin; a.in.pitch = Cin;
     a.w = static_cast<float *>(scratch); a.bias = bias; a.Cout = Cout; a.ks = ks; a.stride = stride; a.ups = upsample;
     a.coefA = coefA; a.coefB = coefB; a.act = silu;
@@ -646,6 +671,21 @@ int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w
         a.splitk_ws_bytes = scratch_bytes - used;
     }
     return hl::conv2d(a, (hipStream_t)stream);
+}
+
+int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout, int ks,
+                   int stride, int upsample, const float *coefA, const float *coefB, int silu, const float *residual,
+                   float *out, void *scratch, size_t scratch_bytes, void *stream) {
+    return conv2d_single(HL_CONV_FP32, in, N, H, W, Cin, w_oihw, bias, Cout, ks, stride, upsample, coefA, coefB, silu, residual, out,
+                         scratch, scratch_bytes, stream);
+}
+
+int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias,
+                        int Cout, int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
+                        const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream) {
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3, "hl_conv2d_nhwc_mode: unknown mode %d", conv_mode);
+    return conv2d_single(conv_mode, in, N, H, W, Cin, w_oihw, bias, Cout, ks, stride, upsample, coefA, coefB, silu, residual, out,
+                         scratch, scratch_bytes, stream);
 }
 
 int hl_groupnorm_coef(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta, const float *emb,

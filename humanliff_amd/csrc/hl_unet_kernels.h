@@ -15,6 +15,7 @@ struct View {
 struct ConvArgs {
     View in;             // C must be a multiple of 16 (pad channels are zero and have zero weights)
     const float *w;      // packed [Cout_pad][Ktot], K order = kt_decode() in hl_unet_kernels.hip (groups of two 16-channel chunks, taps inside)
+    const void *w_bf3;   // optional: the same weights split into three bf16 planes (conv_pack_weights_bf3); selects k_conv_bf3
     const float *bias;   // [Cout] or null
     int Cout;            // real output channels
     int ks;              // 1 or 3 (pad = ks/2)
@@ -40,6 +41,10 @@ size_t conv_splitk_ws_bytes();
 int conv2d(const ConvArgs &a, hipStream_t st);
 size_t conv_packed_floats(int Cout, int Cin_pad, int ks);
 int conv_pack_weights(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, float *packed, hipStream_t st);
+// split-bf16 copy for k_conv_bf3: [Cout_pad][K/16][plane*2 + k-half][8 bf16], 6 bytes per weight; 0 bytes if the layer
+// never takes the DMA tile (Cout_pad not a multiple of 96)
+size_t conv_packed_bf3_bytes(int Cout, int Cin_pad, int ks);
+int conv_pack_weights_bf3(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st);
 
 // GroupNorm(32 groups, eps 1e-5) statistics -> per-(n,c) affine  y = x*A + B   (nn.py:17-19,100)
 // optional scale/shift (ResBlock use_scale_shift_norm, unet.py:203-206): y = GN(x)*(1+scale)+shift,

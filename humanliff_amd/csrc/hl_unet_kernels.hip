@@ -42,7 +42,7 @@ __host__ __device__ inline void kt_decode(int kt, int ncc, int taps, int &cc, in
 struct ConvK {
     const float *in; long in_pitch; int N, Hin, Win, Cin;
     int Hout, Wout, ks, stride, ups, taps;
-    const float *w; long Ktot; const float *bias; int Cout;
+    const float *w; const void *w_bf3; long Ktot; const float *bias; int Cout;
     const float *cA; const float *cB; int act;
     float *out; long out_pitch; const float *res; long res_pitch;
     float *out2; long out2_pitch; const float *res2; long res2_pitch;
@@ -537,6 +537,274 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const C
     }
 }
 
+// k_conv_bf3: k_conv_dma with the fp32 products emulated on the bf16 matrix pipe (opt-in, see hl_unet_set_conv_mode).
+template <int WM, bool UPS>
+__global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_bf3(const ConvK p) {
+#if __HIP_DEVICE_COMPILE__   // device pass only: the host pass of this clang drops the launch stub when it parses the body
+    constexpr int NS = 3;
+    constexpr int BM = WM * 32, BN = 96, A_F = BM * 16, B_F = 6 * BN * 4, STAGE_F = A_F + B_F;
+    constexpr int NBJ = (9 + WM - 1) / WM;   // B instructions per wave at most (9 in total, instruction b = wave + WM*j)
+    constexpr unsigned OOB = 0x80000000u;    // buffer offset past num_records (< 2 GiB): the load returns zeros
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = p.n_mtiles * p.n_nblocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int mt_idx = wi / p.n_nblocks;
+    const long m0 = (long)mt_idx * BM;
+    const int n0 = (wi - mt_idx * p.n_nblocks) * BN;
+    const int pad = p.ks >> 1;
+    const int ncc = p.Cin >> 4;
+    const int hw_out = p.Hout * p.Wout;
+    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+
+    // Both operands are fetched through buffer descriptors: address = base + per-lane offset (VGPR) + a wave-uniform
+    // offset (SGPR), so walking K costs no vector ALU at all, and padding / ragged rows are lanes whose offset is
+    // out of range (hardware returns zeros).
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * p.in_pitch * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.w_bf3, (short)0, (int)((long)p.wrows * p.Ktot * 6), 0x00020000);
+
+    // DMA instruction i of a tile fills rows 16i..16i+15: A rows by instructions wave + WM*j (j = 0,1), the 96 B rows
+    // by instructions BM/16 + b with b = wave + WM*j < 6.
+    // Lane L of an instruction writes physical quarter L&3 of row 16i + (L>>2).
+    const int lrow = lane >> 2, pq = lane & 3;
+    int iy0[2], ix0[2];    // top-left input coordinate of the 3x3 window (in the x2 grid when UPS); huge negative = no row
+    unsigned nb[2];        // byte offset of image n, plus this lane's quarter
+    unsigned a_cur[2];     // byte offset of this lane's 16 bytes for the current tap (or OOB)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave + WM * j) * 16 + lrow;
+        const int ql = pq ^ ((row >> 2) & 3);
+        const long P = m0 + row;
+        const bool in = P < p.M;
+        const long Pc = in ? P : 0;
+        const int n = (int)(Pc / hw_out);
+        const int rem = (int)(Pc - (long)n * hw_out);
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        iy0[j] = in ? oy * p.stride - pad : -(1 << 20);
+        ix0[j] = ox * p.stride - pad;
+        nb[j] = (unsigned)n * (unsigned)(p.Hin * p.Win) * pitch4 + ql * 16;
+    }
+    auto set_tap = [&](int tap) {
+        const int ky = (p.ks == 3) ? tap / 3 : 0, kx = (p.ks == 3) ? tap - ky * 3 : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+            const int Hv = UPS ? 2 * p.Hin : p.Hin, Wv = UPS ? 2 * p.Win : p.Win;
+            const bool ok = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+            const int sy = UPS ? iy >> 1 : iy, sx = UPS ? ix >> 1 : ix;
+            a_cur[j] = ok ? nb[j] + (unsigned)(sy * p.Win + sx) * pitch4 : OOB;
+        }
+    };
+    const int nk_all = ncc * p.taps;
+    const int kt0 = blockIdx.z * p.kt_per;
+    const int nk = min(nk_all, kt0 + p.kt_per);
+    // B stage: 576 chunks of 16 bytes, chunk (part, n) at index part*96 + n, part = plane*2 + k-half (8 bf16 each):
+    // the 8 lanes a ds_read_b128 serves per cycle read 8 consecutive chunks.  DMA instruction b (0..8), lane L fills
+    // chunk 64b + L from the packed weights [row][k-tile][part][8 bf16].
+    unsigned b_voff[NBJ];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+        const int c = (wave + WM * j) * 64 + lane;
+        const int part = c / BN, nn = c - part * BN;
+        const int gn = n0 + nn;
+        b_voff[j] = (c < 6 * BN && gn < p.wrows) ? (unsigned)gn * (unsigned)p.Ktot * 6u + part * 16 : OOB;
+    }
+    int n_b = 0;                                               // B instructions of this wave
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) n_b += (wave + WM * j < 9) ? 1 : 0;
+    const int n_w = 2 + n_b;                                   // DMA instructions of this wave per tile
+
+    int tap_i, cc_i;                                           // issue cursor
+    kt_decode(kt0, ncc, p.taps, cc_i, tap_i);
+    int cg_i = cc_i / KG, gend_i = min(ncc, (cg_i + 1) * KG);
+    int soffB = kt0 * 96;
+    set_tap(tap_i);
+    auto issue = [&](int stage) {
+        float *dst = lds + stage * STAGE_F + wave * 256;       // + WM*256 floats per j (WM instructions further)
+        const int soffA = cc_i * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(dst + j * (WM * 256)), 16,
+                                                     a_cur[j], soffA, 0, 0);
+        float *dstb = lds + stage * STAGE_F + A_F + wave * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)dstb, 16, b_voff[0], soffB, 0, 0);
+        if (wave + WM < 9)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(dstb + WM * 256), 16,
+                                                     b_voff[1], soffB, 0, 0);
+        if (NBJ > 2 && wave + 2 * WM < 9)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(dstb + 2 * WM * 256), 16,
+                                                     b_voff[NBJ > 2 ? 2 : 0], soffB, 0, 0);
+        soffB += 96;
+        if (++cc_i == gend_i) {
+            if (++tap_i == p.taps) { tap_i = 0; ++cg_i; gend_i = min(ncc, (cg_i + 1) * KG); }
+            cc_i = cg_i * KG;
+            set_tap(tap_i);
+        }
+    };
+    auto wait_younger = [&]() {   // all but this wave's DMAs of the youngest tile have landed
+        if (n_w == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (n_w == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    };
+
+    // fragment read offsets (floats) inside a stage
+    const int ra = wave * 32 + (lane & 31);
+    const int sa = (ra >> 2) & 3;
+    const int a_off0 = ra * 16 + (((2 * half) ^ sa) << 2), a_off1 = ra * 16 + (((2 * half + 1) ^ sa) << 2);
+    const int b_off = A_F + (half * BN + (lane & 31)) * 4;     // + (plane*2*96 + j*32) * 4 floats
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // One v_mfma_f32_32x32x16_bf16 contracts the whole 16-channel k-tile (lane half h holds channels 8h..8h+7, exactly
+    // the two 16-byte quarters this lane reads of its A row).  fp32 x fp32 is emulated by splitting both operands into
+    // three bf16 planes (x = hi + mid + lo exactly: 3 x 8 significand bits, by truncation) and accumulating the six
+    // products whose weight is >= 2^-16 of the leading one in the fp32 accumulator:
+    //     a*b ~= ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh)        (dropped terms <= 3 * 2^-24 |a*b|)
+    // Weights are split once at pack time; the activation fragment is split here, after the LDS read.
+    const int ntiles = nk - kt0;
+    auto split3 = [&](const f32x4 x0, const f32x4 x1, bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
+        unsigned u[8], m[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = i < 4 ? x0[i] : x1[i - 4];
+            u[i] = __float_as_uint(x);
+            const float r1 = x - __uint_as_float(u[i] & 0xffff0000u);      // exact
+            m[i] = __float_as_uint(r1);
+            const float r2 = r1 - __uint_as_float(m[i] & 0xffff0000u);     // exact, <= 8 significant bits
+            l[i] = __float_as_uint(r2);
+        }
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // two truncated bf16 per dword: element 2i low, 2i+1 high
+            ph[i] = __builtin_amdgcn_perm(u[2 * i + 1], u[2 * i], 0x07060302);
+            pm[i] = __builtin_amdgcn_perm(m[2 * i + 1], m[2 * i], 0x07060302);
+            pl[i] = __builtin_amdgcn_perm(l[2 * i + 1], l[2 * i], 0x07060302);
+        }
+        hi = __builtin_bit_cast(bf16x8, ph);
+        mid = __builtin_bit_cast(bf16x8, pm);
+        lo = __builtin_bit_cast(bf16x8, pl);
+    };
+    // Pipeline in units of (k-tile t, 32-column block j) = 6 MFMAs: the weight planes of the next unit are read from LDS
+    // while the current unit multiplies; the barrier for tile t+1 sits in front of unit (t, 2), whose operands are
+    // already in registers, and the next activation fragment is read and split behind those MFMAs.
+    //   unit (t,0): read B(t,1) | 6 mfma     unit (t,1): read B(t,2) | 6 mfma
+    //   unit (t,2): wait DMA(t+1), barrier | issue DMA(t+3) | read A(t+1), B(t+1,0) | 6 mfma | split A(t+1)
+    auto readB = [&](const float *base, int j, bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+        h = *reinterpret_cast<const bf16x8 *>(base + b_off + (0 * BN + j * 32) * 4);
+        m = *reinterpret_cast<const bf16x8 *>(base + b_off + (2 * BN + j * 32) * 4);
+        l = *reinterpret_cast<const bf16x8 *>(base + b_off + (4 * BN + j * 32) * 4);
+    };
+    auto mma6 = [&](f32x16 &c, const bf16x8 ah, const bf16x8 am, const bf16x8 al, const bf16x8 bh, const bf16x8 bm, const bf16x8 bl) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);   // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    };
+    bf16x8 ah, am, al, b0h, b0m, b0l, b1h, b1m, b1l;
+    if (ntiles > 0) {
+        issue(0);
+        if (ntiles > 1) { issue(1); wait_younger(); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ntiles > 2) issue(2);
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(lds + a_off0);
+        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(lds + a_off1);
+        readB(lds, 0, b0h, b0m, b0l);
+        split3(x0, x1, ah, am, al);
+    }
+    auto body = [&](auto uc, int t) {
+        constexpr int U = decltype(uc)::value, UN = (U + 1) % NS;
+        const float *base = lds + U * STAGE_F, *nbase = lds + UN * STAGE_F;
+        readB(base, 1, b1h, b1m, b1l);
+        __builtin_amdgcn_sched_barrier(0);
+        mma6(acc[0], ah, am, al, b0h, b0m, b0l);
+        __builtin_amdgcn_sched_barrier(0);
+        readB(base, 2, b0h, b0m, b0l);
+        __builtin_amdgcn_sched_barrier(0);
+        mma6(acc[1], ah, am, al, b1h, b1m, b1l);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = t + 1 < ntiles;
+        f32x4 x0, x1;
+        if (more) {
+            if (t + 2 < ntiles) wait_younger(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done reading tile t before its stage refills
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        // unit (t,2): its weight planes are in b0*, so first park them, then start the reads of tile t+1
+        const bf16x8 ch = b0h, cm = b0m, cl = b0l;
+        f32x16 c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch, acc[2], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            if (t + NS < ntiles) issue(U);
+            x0 = *reinterpret_cast<const f32x4 *>(nbase + a_off0);
+            x1 = *reinterpret_cast<const f32x4 *>(nbase + a_off1);
+            readB(nbase, 0, b0h, b0m, b0l);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cm, c2, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cl, c2, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, ch, c2, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cm, c2, 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ch, c2, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) split3(x0, x1, ah, am, al);
+    };
+    for (int t = 0; t < ntiles; t += NS) {
+        body(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < ntiles) body(std::integral_constant<int, 2>{}, t + 2);
+    }
+
+    // epilogue (same contract as k_conv)
+    if (p.partial) {
+        float *dst = p.partial + (long)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = n0 + j * 32 + (lane & 31);
+            if (n >= p.Cout) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.M) dst[m * p.Cout + n] = acc[j][r];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int n = n0 + j * 32 + (lane & 31);
+        if (n >= p.Cout) continue;
+        const float bs = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= p.M) continue;
+            float v = acc[j][r] + bs;
+            if (p.res) v += p.res[m * p.res_pitch + n];
+            if (p.out_nchw) {
+                const long img = m / hw_out, rem = m - img * hw_out;
+                p.out[(img * p.Cout + n) * hw_out + rem] = v;
+            } else {
+                p.out[m * p.out_pitch + n] = v;
+            }
+            if (p.out2) p.out2[m * p.out2_pitch + n] = v + p.res2[m * p.res2_pitch + n];
+        }
+    }
+#endif
+}
+
 // y = x*A[n,c] + B[n,c] (and SiLU): the GroupNorm-apply pre-pass for k_conv_dma.  x has a channel pitch, y is dense.
 __global__ void k_gn_apply(const float *__restrict__ x, long pitch, long pixels_per_img, long npix, int C,
                            const float *__restrict__ cA, const float *__restrict__ cB, int act, float *__restrict__ y) {
@@ -591,6 +859,34 @@ __global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int 
         float v = 0.f;
         if (o < Cout && cin < Cin) v = w[((long)o * Cin + cin) * taps + tap];
         dst[i] = v;
+    }
+}
+
+// weights -> three truncated-bf16 planes (w = hi + mid + lo exactly), laid out as k_conv_bf3 stages them
+__global__ void k_pack_conv_bf3(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, int ks, int rows,
+                                unsigned short *__restrict__ dst) {
+    const int taps = ks * ks;
+    const long Ktot = (long)Cin_pad * taps;
+    const long n = (long)rows * Ktot;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i / Ktot);
+        const long k = i - (long)o * Ktot;
+        const int c16 = (int)(k & 15);
+        const long t = k >> 4;
+        int cc, tap;
+        kt_decode((int)t, Cin_pad >> 4, taps, cc, tap);
+        const int cin = cc * 16 + c16;
+        float v = 0.f;
+        if (o < Cout && cin < Cin) v = w[((long)o * Cin + cin) * taps + tap];
+        const unsigned uh = __float_as_uint(v) & 0xffff0000u;
+        const float r1 = v - __uint_as_float(uh);
+        const unsigned um = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(um);
+        const unsigned ul = __float_as_uint(r2);
+        unsigned short *q = dst + ((long)o * (Ktot >> 4) + t) * 48 + (c16 >> 3) * 8 + (c16 & 7);
+        q[0] = (unsigned short)(uh >> 16);
+        q[16] = (unsigned short)(um >> 16);
+        q[32] = (unsigned short)(ul >> 16);
     }
 }
 
@@ -1118,6 +1414,18 @@ int conv_pack_weights(const float *w, int Cout, int Cin, int Cin_pad, int ks, fl
     return check_launch("k_pack_conv");
 }
 
+size_t conv_packed_bf3_bytes(int Cout, int Cin_pad, int ks) {
+    const int rows = round_up(Cout, 64);
+    return rows % 96 == 0 ? (size_t)rows * Cin_pad * ks * ks * 6 : 0;
+}
+
+int conv_pack_weights_bf3(const float *w, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st) {
+    HL_REQUIRE(w && packed && Cin_pad % 16 == 0 && Cin <= Cin_pad && (ks == 1 || ks == 3), "conv_pack_weights_bf3: bad argument");
+    const int rows = round_up(Cout, 64);
+    hipLaunchKernelGGL(k_pack_conv_bf3, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, ks, rows, static_cast<unsigned short *>(packed));
+    return check_launch("k_pack_conv_bf3");
+}
+
 int conv2d(const ConvArgs &a, hipStream_t st) {
     HL_REQUIRE(a.in.p && a.w && a.out.p, "conv2d: null tensor");
     HL_REQUIRE(a.in.C % 16 == 0, "conv2d: Cin (%d) must be padded to a multiple of 16", a.in.C);
@@ -1131,7 +1439,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     const int Hv = a.ups ? 2 * a.in.H : a.in.H, Wv = a.ups ? 2 * a.in.W : a.in.W;
     HL_REQUIRE(a.out.H == (Hv + 2 * pad - a.ks) / a.stride + 1 && a.out.W == (Wv + 2 * pad - a.ks) / a.stride + 1 &&
                    a.out.N == a.in.N, "conv2d: output shape mismatch");
-    p.w = a.w; p.Ktot = (long)a.in.C * p.taps; p.bias = a.bias; p.Cout = a.Cout; p.wrows = round_up(a.Cout, 64);
+    p.w = a.w; p.w_bf3 = a.w_bf3; p.Ktot = (long)a.in.C * p.taps; p.bias = a.bias; p.Cout = a.Cout; p.wrows = round_up(a.Cout, 64);
     p.cA = a.coefA; p.cB = a.coefB; p.act = a.act;
     p.out = a.out.p; p.out_pitch = a.out.pitch; p.res = a.res; p.res_pitch = a.res_pitch;
     p.out2 = a.out2; p.out2_pitch = a.out2_pitch; p.res2 = a.res2; p.res2_pitch = a.res2_pitch;
@@ -1202,6 +1510,13 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         p.n_mtiles = (int)((M + (tile8 ? 255 : 127)) / (tile8 ? 256 : 128));
         dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
         const size_t shm8 = (size_t)3 * 352 * 16 * sizeof(float), shm4 = (size_t)3 * 224 * 16 * sizeof(float);
+        if (a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) {   // fp32 emulated on the bf16 matrix pipe (opt-in)
+            const size_t s8 = (size_t)3 * (256 * 16 + 6 * 96 * 4) * sizeof(float), s4 = (size_t)3 * (128 * 16 + 6 * 96 * 4) * sizeof(float);
+            if (tile8 && a.ups) hipLaunchKernelGGL((k_conv_bf3<8, true>), grid, dim3(512), s8, st, p);
+            else if (tile8) hipLaunchKernelGGL((k_conv_bf3<8, false>), grid, dim3(512), s8, st, p);
+            else if (a.ups) hipLaunchKernelGGL((k_conv_bf3<4, true>), grid, dim3(256), s4, st, p);
+            else hipLaunchKernelGGL((k_conv_bf3<4, false>), grid, dim3(256), s4, st, p);
+        } else
         if (tile8 && a.ups) hipLaunchKernelGGL((k_conv_dma<8, 3, true>), grid, dim3(512), shm8, st, p);
         else if (tile8) hipLaunchKernelGGL((k_conv_dma<8, 3, false>), grid, dim3(512), shm8, st, p);
         else if (a.ups) hipLaunchKernelGGL((k_conv_dma<4, 3, true>), grid, dim3(256), shm4, st, p);

@@ -146,6 +146,7 @@ class UNetModel(nn.Module):
             self.input_blocks_proj_cond = nn.ModuleList(
                 [zero_module(conv_nd(dims, c, c, 1, padding=0)) for c in cchans])
         self._hip = None       # (handle, packed buffer, key)
+        self._conv_mode = _lib.HL_CONV_FP32
         self._ws = {}          # (B,H,W,device) -> workspace tensor
 
     # ---- reference API kept for callers ----------------------------------------------------------
@@ -204,9 +205,23 @@ class UNetModel(nn.Module):
         with th.cuda.device(dev):
             _lib.check(L.hl_unet_create(C.byref(cfg), n, names, ptrs, numels, _lib.ptr(packed), _lib.stream_ptr(),
                                         C.byref(handle)), "hl_unet_create")
+        _lib.check(L.hl_unet_set_conv_mode(handle, self._conv_mode), "hl_unet_set_conv_mode")
         self._hip = (handle, packed, key)
         self._ws = {}
         return handle
+
+    def set_conv_mode(self, mode):
+        """Arithmetic of the large convolutions: "fp32" (default; exact fp32 MFMA, what the reference's fp32 path
+        specifies) or "bf16x3" (opt-in extension, not in the reference: the same fp32 tensors and accumulators, each
+        product formed on the bf16 matrix pipe from exact three-way bf16 splits of both factors, six partial products;
+        error per product <= 3*2^-24 - fp32 class, not bit-identical).  See include/humanliff_hip.h HL_CONV_*."""
+        modes = {"fp32": _lib.HL_CONV_FP32, "bf16x3": _lib.HL_CONV_BF16X3}
+        if mode not in modes:
+            raise ValueError(f"unknown conv mode {mode!r} (expected one of {sorted(modes)})")
+        self._conv_mode = modes[mode]
+        if self._hip is not None:
+            _lib.check(_lib.lib().hl_unet_set_conv_mode(self._hip[0], self._conv_mode), "hl_unet_set_conv_mode")
+        return self
 
     def __del__(self):
         try:

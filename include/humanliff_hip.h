@@ -162,6 +162,16 @@ int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float 
  * enable = 0 issues everything on the caller's stream. */
 int hl_unet_set_overlap(void *handle, int enable);
 
+/* Arithmetic of the large convolutions.  HL_CONV_FP32 (default): exact fp32 products and accumulation on
+ * v_mfma_f32_32x32x2_f32 - what the reference's fp32 path specifies.  HL_CONV_BF16X3 (opt-in): the same fp32 tensors
+ * and fp32 accumulators, but each product a*b is formed on the bf16 matrix pipe from exact three-way splits
+ * a = ah+am+al, b = bh+bm+bl (8 significand bits per bf16 plane) as ah*bh + ah*bm + am*bh + ah*bl + am*bm + al*bh; the three
+ * dropped terms are <= 3*2^-24 |a*b|, the size of one fp32 rounding.  Not bit-identical to HL_CONV_FP32; parity bounds
+ * are the same (tests/test_unet_gpu.py).  Affects only layers that take the DMA tile (Cout a multiple of 96). */
+#define HL_CONV_FP32 0
+#define HL_CONV_BF16X3 1
+int hl_unet_set_conv_mode(void *handle, int mode);
+
 /* Instrumentation for the roofline measurement (bench.py): with profiling enabled every kernel launch
  * of hl_unet_forward is bracketed by HIP events on the caller's stream.  hl_unet_profile_read waits for
  * them and returns, per category {0 conv/GEMM, 1 GroupNorm, 2 attention, 3 embeddings+prep}, the summed
@@ -187,6 +197,11 @@ int hl_diffusion_step(int mode, const float *x, const float *eps, const float *n
 int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,
                    int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                    const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream);
+/* hl_conv2d_nhwc with an explicit arithmetic mode (HL_CONV_*); HL_CONV_BF16X3 needs room for the split weights too:
+ * scratch >= 4*Cout_pad*K (rounded up to 256) + 6*Cout_pad*K bytes, Cout_pad = Cout rounded up to 64, K = Cin*ks*ks. */
+int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias,
+                        int Cout, int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
+                        const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream);
 int hl_groupnorm_coef(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta,
                       const float *emb /* (N,2C) or NULL */, float *coefA, float *coefB, void *scratch,
                       size_t scratch_bytes, void *stream);

@@ -22,7 +22,7 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).contiguous()
 
 
-def hip_conv(x, w, b, ks, stride=1, ups=0, cA=None, cB=None, silu=0, res=None):
+def hip_conv(x, w, b, ks, stride=1, ups=0, cA=None, cB=None, silu=0, res=None, mode=0):
     from humanliff_amd import _lib
     L = _lib.lib()
     N, C, H, W = x.shape
@@ -32,13 +32,13 @@ def hip_conv(x, w, b, ks, stride=1, ups=0, cA=None, cB=None, silu=0, res=None):
     Ho, Wo = (Hv + 2 * (ks // 2) - ks) // stride + 1, (Wv + 2 * (ks // 2) - ks) // stride + 1
     out = torch.empty((N, Ho, Wo, Cout), device=dev)
     # packed weights + room for split-K partial sums (taken for shapes that would under-fill the chip)
-    scratch = torch.empty(((Cout + 63) // 64 * 64) * C * ks * ks + 64 + (8 << 20) + N * C * H * W, device=dev)
+    scratch = torch.empty(((Cout + 63) // 64 * 64) * C * ks * ks * 3 + 256 + (8 << 20) + N * C * H * W, device=dev)
     d = lambda t: None if t is None else t.contiguous().to(dev)  # noqa: E731
     wd, bd, cAd, cBd = d(w), d(b), d(cA), d(cB)
     rd = d(nhwc(res)) if res is not None else None
-    _lib.check(L.hl_conv2d_nhwc(_lib.ptr(xin), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Cout, ks, stride, ups, _lib.ptr(cAd),
-                                _lib.ptr(cBd), silu, _lib.ptr(rd), _lib.ptr(out), _lib.ptr(scratch), scratch.numel() * 4,
-                                _lib.stream_ptr()))
+    _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(xin), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Cout, ks, stride, ups,
+                                     _lib.ptr(cAd), _lib.ptr(cBd), silu, _lib.ptr(rd), _lib.ptr(out), _lib.ptr(scratch),
+                                     scratch.numel() * 4, _lib.stream_ptr()))
     torch.cuda.synchronize()
     return nchw(out.cpu())
 
@@ -66,6 +66,32 @@ def test_conv_matches_torch(N, C, H, W, Cout, ks, stride, ups):
     want = F.conv2d(xi, w, b, stride=stride, padding=ks // 2)
     assert got.shape == want.shape
     assert (got - want).abs().max() < 2e-5          # outputs O(1), K up to 3456: fp32 accumulation-order noise
+
+
+@pytest.mark.parametrize("N,C,H,W,Cout,ks,stride,ups", [
+    (1, 192, 32, 32, 192, 3, 1, 0),    # 128x96 tile, split-K
+    (2, 192, 128, 128, 192, 3, 1, 0),  # 256x96 tile (8 waves)
+    (1, 96, 160, 96, 96, 3, 1, 0),     # ragged last pixel tile, Cout=96
+    (2, 96, 16, 16, 96, 3, 2, 0),      # stride 2
+    (2, 96, 24, 24, 96, 3, 1, 1),      # nearest x2 upsample
+    (2, 384, 8, 8, 1152, 1, 1, 0),     # 1x1 (qkv), split-K
+    (4, 768, 8, 8, 768, 3, 1, 0),      # K = 6912, 16 slabs
+])
+def test_conv_bf16x3_emulation_matches_torch(N, C, H, W, Cout, ks, stride, ups):
+    """HL_CONV_BF16X3: fp32 products emulated with three bf16 planes per operand - same bound as the exact fp32 kernel,
+    and the difference between the two modes is at accumulation-noise level."""
+    from humanliff_amd import _lib
+    g = torch.Generator().manual_seed(N * 1000 + C + H + Cout)
+    x = torch.randn((N, C, H, W), generator=g)
+    w = torch.randn((Cout, C, ks, ks), generator=g) / (C * ks * ks) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    got = hip_conv(x, w, b, ks, stride, ups, mode=_lib.HL_CONV_BF16X3)
+    exact = hip_conv(x, w, b, ks, stride, ups, mode=_lib.HL_CONV_FP32)
+    xi = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    want = F.conv2d(xi.double(), w.double(), b.double(), stride=stride, padding=ks // 2)
+    e_bf3, e_f32 = (got.double() - want).abs().max().item(), (exact.double() - want).abs().max().item()
+    assert e_bf3 < 2e-5                      # the fp32 kernel's bound (test_conv_matches_torch)
+    assert e_bf3 < 4 * e_f32 + 1e-6          # and within a small factor of the exact kernel's error vs float64
 
 
 def test_conv_fused_groupnorm_silu_residual():
