@@ -580,9 +580,6 @@ __global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-// C ABI
-// ---------------------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------------------
 // per-view ray generation   [SynBodyView_datasets.py:316-329 get_rays, :370-403 get_near_far, :422-433]
 // One thread per pixel, float64 like the reference's numpy (K, R, T are float64 there), rounded to float32 exactly
 // where sample_ray_batch casts.  Term order follows oracle/camera_oracle.py (no FMA contraction in this build).
@@ -645,6 +642,9 @@ __global__ __launch_bounds__(256) void k_camera_rays(const CamArgs a) {
     if (a.mask) a.mask[i] = hit ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
 extern "C" {
 
 size_t hl_render_mlp_packed_bytes(void) { return (size_t)PACKED_FLOATS * sizeof(float); }
