@@ -24,6 +24,7 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct Conv {
     const float *w = nullptr;  // packed
     const void *w_bf3 = nullptr;  // packed split-bf16 copy (layers that take the DMA tile), used when Net::conv_mode == 1
+    const float *w_wino = nullptr;  // Winograd-domain copy (3x3 layers), used when Net::conv_mode == 0
     const float *bias = nullptr;
     int Cin = 0, Cin_pad = 0, Cout = 0, ks = 1;
 };
@@ -81,7 +82,7 @@ struct Net {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_block;   // main encoder block i finished (its output feeds the skip sum)
     bool overlap = true;
-    int conv_mode = 0;   // 0: exact fp32 MFMA, 1: fp32 emulated with three bf16 planes per operand (k_conv_bf3)
+    int conv_mode = 0;   // HL_CONV_*: 0 fp32 (Winograd where it applies), 1 bf16x3 emulation, 2 fp32 direct only
     // optional per-category HIP-event timing of one forward (bench.py roofline leg)
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;
@@ -134,6 +135,15 @@ Conv make_conv(Net &n, const std::string &p, int Cin, int Cout, int ks) {
         }
         n.packed_off += (bf3 / 4 + 63) / 64 * 64;
     }
+    const size_t wino = hl::conv_packed_wino_bytes(Cout, c.Cin_pad, ks);
+    if (wino) {
+        if (!n.dry && w) {
+            float *dst = n.packed + n.packed_off;
+            if (hl::conv_pack_weights_wino(w, Cout, Cin, c.Cin_pad, dst, n.st) != 0 && n.err.empty()) n.err = hl_last_error();
+            c.w_wino = dst;
+        }
+        n.packed_off += (wino / 4 + 63) / 64 * 64;
+    }
     return c;
 }
 Norm make_norm(Net &n, const std::string &p, int C) {
@@ -165,7 +175,7 @@ int add_res(Net &n, std::vector<EmbPiece> &emb, const std::string &p, int Cin, i
             if (it != n.sd.end() && it->second.second == (int64_t)Cout * Cin * 9) ks = 3;
         }
         r.skip = make_conv(n, p + ".skip_connection", Cin, Cout, ks);
-        if (n.dry) n.packed_off += hl::conv_packed_floats(Cout, round_up(Cin, 16), 3) * 3;  // size for the worst case (fp32 + bf16x3 copies)
+        if (n.dry) n.packed_off += hl::conv_packed_floats(Cout, round_up(Cin, 16), 3) * 5;  // size for the worst case (fp32 + bf16x3 + Winograd copies)
     }
     n.res.push_back(r);
     return (int)n.res.size() - 1;
@@ -350,7 +360,8 @@ struct Exec {
         if (!run) return;
         ConvArgs a{};
         a.in = in; a.in.C = c.Cin_pad;
-        a.w = c.w; a.w_bf3 = n.conv_mode == 1 ? c.w_bf3 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
+        a.w = c.w; a.w_bf3 = n.conv_mode == HL_CONV_BF16X3 ? c.w_bf3 : nullptr;
+        a.w_wino = n.conv_mode == HL_CONV_FP32 ? c.w_wino : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
         a.coefA = cA; a.coefB = cB; a.act = act;
         a.out = out; a.res = res; a.res_pitch = res_pitch;
         a.out2 = out2; a.out2_pitch = out2_pitch; a.res2 = res2; a.res2_pitch = res2_pitch; a.out_nchw = nchw;
@@ -575,7 +586,7 @@ int hl_unet_set_overlap(void *handle, int enable) {
 
 int hl_unet_set_conv_mode(void *handle, int mode) {
     HL_REQUIRE(handle, "hl_unet_set_conv_mode: null handle");
-    HL_REQUIRE(mode == HL_CONV_FP32 || mode == HL_CONV_BF16X3, "hl_unet_set_conv_mode: unknown mode %d", mode);
+    HL_REQUIRE(mode == HL_CONV_FP32 || mode == HL_CONV_BF16X3 || mode == HL_CONV_FP32_DIRECT, "hl_unet_set_conv_mode: unknown mode %d", mode);
     static_cast<Net *>(handle)->conv_mode = mode;
     return HL_OK;
 }
@@ -640,7 +651,9 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
                          const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream) {
     HL_REQUIRE(Cin % 16 == 0, "hl_conv2d_nhwc: Cin must be a multiple of 16");
     const size_t need32 = (hl::conv_packed_floats(Cout, Cin, ks) * sizeof(float) + 255) / 256 * 256;
-    const size_t need = need32 + (mode == HL_CONV_BF16X3 ? hl::conv_packed_bf3_bytes(Cout, Cin, ks) : 0);
+    const size_t extra = mode == HL_CONV_BF16X3 ? hl::conv_packed_bf3_bytes(Cout, Cin, ks)
+                         : (mode == HL_CONV_FP32 ? hl::conv_packed_wino_bytes(Cout, Cin, ks) : 0);
+    const size_t need = need32 + (extra + 255) / 256 * 256;
     HL_REQUIRE(scratch && scratch_bytes >= need, "hl_conv2d_nhwc: scratch too small (%zu < %zu)", scratch_bytes, need);
     int rc = hl::conv_pack_weights(w_oihw, Cout, Cin, Cin, ks, static_cast<float *>(scratch), (hipStream_t)stream);
     if (rc) return rc;
@@ -650,6 +663,12 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
         rc = hl::conv_pack_weights_bf3(w_oihw, Cout, Cin, Cin, ks, dst, (hipStream_t)stream);
         if (rc) return rc;
         a.w_bf3 = dst;
+    }
+    if (mode == HL_CONV_FP32 && extra) {
+        float *dst = reinterpret_cast<float *>(static_cast<char *>(scratch) + need32);
+        rc = hl::conv_pack_weights_wino(w_oihw, Cout, Cin, Cin, dst, (hipStream_t)stream);
+        if (rc) return rc;
+        a.w_wino = dst;
     }
     a.in.p = const_cast<float *>(in); a.in.N = N; a.in.H = H; a.in.W = W; a.in.C = Cin; a.in.pitch = Cin;
     a.w = static_cast<float *>(scratch); a.bias = bias; a.Cout = Cout; a.ks = ks; a.stride = stride; a.ups = upsample;
@@ -676,14 +695,16 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
 int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout, int ks,
                    int stride, int upsample, const float *coefA, const float *coefB, int silu, const float *residual,
                    float *out, void *scratch, size_t scratch_bytes, void *stream) {
-    return conv2d_single(HL_CONV_FP32, in, N, H, W, Cin, w_oihw, bias, Cout, ks, stride, upsample, coefA, coefB, silu, residual, out,
+    // (plain entry point: direct convolution only, so the scratch contract of round 1 - packed weights + optional split-K /
+    // activation room - is unchanged; hl_conv2d_nhwc_mode(HL_CONV_FP32, ...) adds the Winograd copy)
+    return conv2d_single(HL_CONV_FP32_DIRECT, in, N, H, W, Cin, w_oihw, bias, Cout, ks, stride, upsample, coefA, coefB, silu, residual, out,
                          scratch, scratch_bytes, stream);
 }
 
 int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias,
                         int Cout, int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3, "hl_conv2d_nhwc_mode: unknown mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT, "hl_conv2d_nhwc_mode: unknown mode %d", conv_mode);
     return conv2d_single(conv_mode, in, N, H, W, Cin, w_oihw, bias, Cout, ks, stride, upsample, coefA, coefB, silu, residual, out,
                          scratch, scratch_bytes, stream);
 }

@@ -16,6 +16,7 @@ struct ConvArgs {
     View in;             // C must be a multiple of 16 (pad channels are zero and have zero weights)
     const float *w;      // packed [Cout_pad][Ktot], K order = kt_decode() in hl_unet_kernels.hip (groups of two 16-channel chunks, taps inside)
     const void *w_bf3;   // optional: the same weights split into three bf16 planes (conv_pack_weights_bf3); selects k_conv_bf3
+    const float *w_wino; // optional: Winograd-domain weights (conv_pack_weights_wino); selects k_conv_wino for large 3x3 layers
     const float *bias;   // [Cout] or null
     int Cout;            // real output channels
     int ks;              // 1 or 3 (pad = ks/2)
@@ -43,6 +44,9 @@ size_t conv_packed_floats(int Cout, int Cin_pad, int ks);
 int conv_pack_weights(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, float *packed, hipStream_t st);
 // split-bf16 copy for k_conv_bf3: [Cout_pad][K/16][plane*2 + k-half][8 bf16], 6 bytes per weight; 0 bytes if the layer
 // never takes the DMA tile (Cout_pad not a multiple of 96)
+// Winograd F(2x2,3x3) copy U = G g G^T: [Cout/64][Cin_pad/8][16][2][2][32][4] floats; 0 bytes if not applicable
+size_t conv_packed_wino_bytes(int Cout, int Cin_pad, int ks);
+int conv_pack_weights_wino(const float *w_oihw, int Cout, int Cin, int Cin_pad, float *packed, hipStream_t st);
 size_t conv_packed_bf3_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_bf3(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st);
 

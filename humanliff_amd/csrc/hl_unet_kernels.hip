@@ -42,7 +42,7 @@ __host__ __device__ inline void kt_decode(int kt, int ncc, int taps, int &cc, in
 struct ConvK {
     const float *in; long in_pitch; int N, Hin, Win, Cin;
     int Hout, Wout, ks, stride, ups, taps;
-    const float *w; const void *w_bf3; long Ktot; const float *bias; int Cout;
+    const float *w; const void *w_bf3; const float *w_wino; long Ktot; const float *bias; int Cout;
     const float *cA; const float *cB; int act;
     float *out; long out_pitch; const float *res; long res_pitch;
     float *out2; long out2_pitch; const float *res2; long res2_pitch;
@@ -534,6 +534,197 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const C
             }
             if (p.out2) p.out2[m * p.out2_pitch + n] = v + p.res2[m * p.res2_pitch + n];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_wino: 3x3 / stride 1 convolution by Winograd F(2x2, 3x3) in fp32, fused in one kernel
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A        16 multiplies per 2x2 outputs instead of 36 (2.25x fewer MFMAs)
+// A workgroup owns 8x8 output tiles of 2x2 pixels (a 16x16 pixel block) x 64 output channels x all 16 frequencies.
+// Wave w = 4g + i: tile group g (rows of tiles 4g..4g+3, 32 tiles = the MFMA M dimension) and frequency ROW i: it
+// keeps M[i][0..3] for 2 x 32 output channels = 8 accumulator tiles (128 registers).  Per k-tile of 8 input channels:
+//   * the 18x18 input patch and the 16 pre-transformed 64x8 weight slices U = G g G^T arrive by LDS-DMA (3-stage
+//     ring, buffer addressing, per-lane offsets fixed for the whole K walk; the zero padding is out-of-range lanes);
+//   * a lane (tile, channel-half) reads the two patch rows its frequency row needs (B^T row i), forms
+//     V[i][0..3] = (row transform) (column transform) with 32 adds, and issues 32 MFMAs against the weight slices.
+// After the K walk every wave applies the column half of A^T . A to its accumulators, the four frequency rows meet in
+// LDS, and each wave finishes one (column parity, channel block) of the outputs with the usual epilogue.
+// LDS layouts are chosen so that the 8 lanes a ds_read_b128 serves per cycle read consecutive 16-byte chunks:
+//   patch chunk  ((half*18 + row)*2 + (col&1))*9 + (col>>1)        (4 channels of one pixel)
+//   weight chunk ((f*2 + ct)*2 + half)*32 + cout                   (4 channels of one output channel)
+// ---------------------------------------------------------------------------------------------
+template <int DUMMY>
+__global__ __launch_bounds__(512, 2) void k_conv_wino(const ConvK p) {
+#if __HIP_DEVICE_COMPILE__   // device pass only (see k_conv_bf3)
+    constexpr int NS = 3, U_F = 16 * 2 * 2 * 32 * 4, P_CH = 704, P_F = P_CH * 4, STAGE_F = U_F + P_F;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, fi = wave & 3;                       // tile group, frequency row
+    const int total = p.n_mtiles * p.n_nblocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int tb = wi / p.n_nblocks, nb = wi - tb * p.n_nblocks;
+    const int n0 = nb * 64;
+    const int bw = p.Win >> 4, bh = p.Hin >> 4;
+    const int img = tb / (bw * bh), brem = tb - img * (bw * bh);
+    const int y0 = (brem / bw) * 16, x0 = (brem - (brem / bw) * bw) * 16;
+    const int nkt = p.Cin >> 3;
+    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * p.in_pitch * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.w_wino, (short)0, (int)((long)p.n_nblocks * nkt * U_F * 4), 0x00020000);
+
+    // DMA instructions of a k-tile: 32 weight instructions (plain 1 KiB copies) + 11 patch instructions; instruction
+    // q = wave + 8j: j = 0..3 weights, j = 4 patch `wave`, j = 5 patch 8 + wave (waves 0..2)
+    unsigned pv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = (wave + 8 * j) * 64 + lane;                 // patch chunk
+        const int jc = c % 9, t1 = c / 9, par = t1 & 1, t2 = t1 >> 1, row = t2 % 18, h = t2 / 18;
+        const int y = y0 - 1 + row, x = x0 - 1 + 2 * jc + par;
+        const bool ok = c < 648 && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+        pv[j] = ok ? (unsigned)((img * p.Hin + y) * p.Win + x) * pitch4 + h * 16 : OOB;
+    }
+    const bool has_p1 = wave < 3;
+    const int n_w = 5 + (has_p1 ? 1 : 0);
+    const unsigned uv = (unsigned)(wave * 64 + lane) * 16u;       // + 8 KiB per j
+    int soffU = nb * nkt * (U_F * 4), soffA = 0;
+    auto issue = [&](int stage) {
+        float *du = lds + stage * STAGE_F + wave * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void *)(du + j * 2048), 16,
+                                                     uv, soffU + j * 8192, 0, 0);
+        float *dp = lds + stage * STAGE_F + U_F + wave * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)dp, 16, pv[0], soffA, 0, 0);
+        if (has_p1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(dp + 2048), 16, pv[1],
+                                                     soffA, 0, 0);
+        soffU += U_F * 4;
+        soffA += 32;
+    };
+    auto wait_younger = [&]() {
+        if (n_w == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    };
+
+    // patch read offsets (floats): tile T = lane & 31 -> (ty, tx); rows rA, rB of B^T row fi; column c: parity c&1, + (c>>1)
+    const int T = lane & 31, ty = 4 * g + (T >> 3), tx = T & 7;
+    const int rA = (fi == 0) ? 0 : (fi == 2 ? 2 : 1), rB = (fi == 0) ? 2 : (fi == 1 ? 2 : (fi == 2 ? 1 : 3));
+    const float sB = (fi == 1) ? 1.f : -1.f;                      // T = d[rA] + sB * d[rB]
+    const int pA = U_F + (((half * 18 + 2 * ty + rA) * 2) * 9 + tx) * 4, pB = U_F + (((half * 18 + 2 * ty + rB) * 2) * 9 + tx) * 4;
+    // column c of a row: + ((c & 1) * 9 + (c >> 1)) * 4 floats  -> c0: 0, c1: 36, c2: 4, c3: 40
+    const int u_off = ((fi * 4 * 2) * 2 + half) * 32 * 4 + (lane & 31) * 4;   // + ((f' * 2 + ct) * 2) * 128 floats
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[f][c][r] = 0.f;
+
+    const int ntiles = nkt;
+    if (ntiles > 0) {
+        issue(0);
+        if (ntiles > 1) issue(1);
+    }
+    auto body = [&](auto uc, int t) {
+        constexpr int U = decltype(uc)::value;
+        const float *base = lds + U * STAGE_F;
+        if (t + 1 < ntiles) wait_younger(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // tile t visible to all; stage of tile t-1 free
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntiles) issue((U + 2) % NS);
+        f32x4 tc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int co = ((c & 1) * 9 + (c >> 1)) * 4;
+            const f32x4 da = *reinterpret_cast<const f32x4 *>(base + pA + co);
+            const f32x4 db = *reinterpret_cast<const f32x4 *>(base + pB + co);
+            tc[c] = da + sB * db;
+        }
+        f32x4 V[4];
+        V[0] = tc[0] - tc[2];
+        V[1] = tc[1] + tc[2];
+        V[2] = tc[2] - tc[1];
+        V[3] = tc[1] - tc[3];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f32x4 ub = *reinterpret_cast<const f32x4 *>(base + u_off + ((f * 2 + c) * 2) * 128);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[s], acc[f][c], 0, 0, 0);
+            }
+    };
+    for (int t = 0; t < ntiles; t += NS) {
+        body(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < ntiles) body(std::integral_constant<int, 2>{}, t + 2);
+    }
+
+    // column half of the output transform, then the four frequency rows meet in LDS
+    __syncthreads();
+    float *ex = lds + wave * 4096;                                // [b][ct][r][lane]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[0][c][r], m1 = acc[1][c][r], m2 = acc[2][c][r], m3 = acc[3][c][r];
+            ex[((0 * 2 + c) * 16 + r) * 64 + lane] = (m0 + m1) + m2;
+            ex[((1 * 2 + c) * 16 + r) * 64 + lane] = (m1 - m2) - m3;
+        }
+    __syncthreads();
+    // wave (g, fi) finishes column parity b = fi >> 1, channel block ct = fi & 1 of its tile group
+    const int b = fi >> 1, ct = fi & 1;
+    const int n = n0 + ct * 32 + (lane & 31);
+    const float bs = p.bias ? p.bias[n] : 0.f;
+    const long hw = (long)p.Hin * p.Win;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float *zz = lds + (g * 4) * 4096 + ((b * 2 + ct) * 16 + r) * 64 + lane;
+        const float z0 = zz[0], z1 = zz[4096], z2 = zz[2 * 4096], z3 = zz[3 * 4096];
+        const int Tr = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int oy = y0 + 2 * (4 * g + (Tr >> 3)), ox = x0 + 2 * (Tr & 7) + b;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float v = (a == 0 ? (z0 + z1) + z2 : (z1 - z2) - z3) + bs;
+            const long m = ((long)img * p.Hin + oy + a) * p.Win + ox;
+            if (p.res) v += p.res[m * p.res_pitch + n];
+            if (p.out_nchw) p.out[((long)img * p.Cout + n) * hw + (long)(oy + a) * p.Win + ox] = v;
+            else p.out[m * p.out_pitch + n] = v;
+            if (p.out2) p.out2[m * p.out2_pitch + n] = v + p.res2[m * p.res2_pitch + n];
+        }
+    }
+#endif
+}
+
+// weights -> U = G g G^T per (cout, cin), laid out as k_conv_wino stages them: [cout/64][cin/8][f][ct][half][32][4]
+__global__ void k_pack_conv_wino(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, float *__restrict__ dst) {
+    const int nkt = Cin_pad >> 3;
+    const long n = (long)Cout * Cin_pad * 16;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(e & 3), nn = (int)((e >> 2) & 31), hf = (int)((e >> 7) & 1), ct = (int)((e >> 8) & 1), f = (int)((e >> 9) & 15);
+        const long rest = e >> 13;
+        const int kt = (int)(rest % nkt), nb = (int)(rest / nkt);
+        const int co = nb * 64 + ct * 32 + nn, ci = kt * 8 + hf * 4 + s;
+        float v = 0.f;
+        if (ci < Cin && co < Cout) {
+            const float *g = w + ((long)co * Cin + ci) * 9;
+            const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            const int i = f >> 2, j = f & 3;
+            double acc = 0.0;
+            for (int u = 0; u < 3; ++u)
+                for (int vv = 0; vv < 3; ++vv) acc += G[i][u] * (double)g[u * 3 + vv] * G[j][vv];
+            v = (float)acc;
+        }
+        dst[e] = v;
     }
 }
 
@@ -1426,6 +1617,16 @@ int conv_pack_weights_bf3(const float *w, int Cout, int Cin, int Cin_pad, int ks
     return check_launch("k_pack_conv_bf3");
 }
 
+size_t conv_packed_wino_bytes(int Cout, int Cin_pad, int ks) {
+    return (ks == 3 && Cout % 64 == 0 && Cin_pad % 8 == 0) ? (size_t)Cout * Cin_pad * 16 * sizeof(float) : 0;
+}
+
+int conv_pack_weights_wino(const float *w, int Cout, int Cin, int Cin_pad, float *packed, hipStream_t st) {
+    HL_REQUIRE(w && packed && Cout % 64 == 0 && Cin_pad % 8 == 0 && Cin <= Cin_pad, "conv_pack_weights_wino: bad argument");
+    hipLaunchKernelGGL(k_pack_conv_wino, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, packed);
+    return check_launch("k_pack_conv_wino");
+}
+
 int conv2d(const ConvArgs &a, hipStream_t st) {
     HL_REQUIRE(a.in.p && a.w && a.out.p, "conv2d: null tensor");
     HL_REQUIRE(a.in.C % 16 == 0, "conv2d: Cin (%d) must be padded to a multiple of 16", a.in.C);
@@ -1439,7 +1640,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     const int Hv = a.ups ? 2 * a.in.H : a.in.H, Wv = a.ups ? 2 * a.in.W : a.in.W;
     HL_REQUIRE(a.out.H == (Hv + 2 * pad - a.ks) / a.stride + 1 && a.out.W == (Wv + 2 * pad - a.ks) / a.stride + 1 &&
                    a.out.N == a.in.N, "conv2d: output shape mismatch");
-    p.w = a.w; p.w_bf3 = a.w_bf3; p.Ktot = (long)a.in.C * p.taps; p.bias = a.bias; p.Cout = a.Cout; p.wrows = round_up(a.Cout, 64);
+    p.w = a.w; p.w_bf3 = a.w_bf3; p.w_wino = a.w_wino; p.Ktot = (long)a.in.C * p.taps; p.bias = a.bias; p.Cout = a.Cout; p.wrows = round_up(a.Cout, 64);
     p.cA = a.coefA; p.cB = a.coefB; p.act = a.act;
     p.out = a.out.p; p.out_pitch = a.out.pitch; p.res = a.res; p.res_pitch = a.res_pitch;
     p.out2 = a.out2; p.out2_pitch = a.out2_pitch; p.res2 = a.res2; p.res2_pitch = a.res2_pitch;
@@ -1462,6 +1663,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     // the 8-wave 256x96 tile when that covers at least half the chip (2 workgroups/CU = 512 slots), else 4 waves x 128x96
     static const int dma_thr = getenv("HL_CONV_T8") ? atoi(getenv("HL_CONV_T8")) : 256;
     static const int dma_off = getenv("HL_CONV_NODMA") ? 1 : 0;
+    static const long wino_thr = getenv("HL_CONV_WINO") ? atol(getenv("HL_CONV_WINO")) : 512;   // min workgroups; huge = off
     const bool dma = !dma_off && cfg == 0 && (a.coefA == nullptr || a.act_ws) &&
                      (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && (long)cpad * p.Ktot * 4 < (1L << 31);
     const long blocks8 = ((M + 255) / 256) * (cpad / 96);
@@ -1495,6 +1697,10 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         else if (mode == 1) hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 1, false>), GRID, dim3(256), shm, st, p);   \
         else hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 2, false>), GRID, dim3(256), shm, st, p);                  \
     } while (0)
+    // 3x3 / stride-1 layers large enough to fill the chip with 16x16-pixel x 64-channel workgroups: Winograd F(2x2,3x3)
+    const long wino_blocks = (long)a.in.N * (a.in.H / 16) * (a.in.W / 16) * (a.Cout / 64);
+    const bool wino = dma && a.w_wino && !a.w_bf3 && a.ks == 3 && a.stride == 1 && !a.ups && a.in.H % 16 == 0 && a.in.W % 16 == 0 &&
+                      a.Cout % 64 == 0 && wino_blocks >= wino_thr && (long)a.Cout * a.in.C * 64 < (1L << 31);
     if (dma) {
         if (mode != 0) {   // materialise GroupNorm(+SiLU) once, then the DMA kernel reads it raw
             HL_REQUIRE(!a.ups, "conv2d: upsample with a GroupNorm prologue is not used by the UNet");
@@ -1505,6 +1711,14 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix,
                                a.in.C, a.coefA, a.coefB, a.act, a.act_ws);
             p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0;
+        }
+        if (wino) {
+            p.partial = nullptr;
+            p.n_nblocks = a.Cout / 64;
+            p.n_mtiles = a.in.N * (a.in.H / 16) * (a.in.W / 16);
+            const size_t shmw = (size_t)3 * (16 * 2 * 2 * 32 * 4 + 704 * 4) * sizeof(float);
+            hipLaunchKernelGGL((k_conv_wino<0>), dim3((unsigned)(p.n_mtiles * p.n_nblocks)), dim3(512), shmw, st, p);
+            return check_launch("k_conv_wino");
         }
         p.n_nblocks = cpad / 96;
         p.n_mtiles = (int)((M + (tile8 ? 255 : 127)) / (tile8 ? 256 : 128));

@@ -170,6 +170,7 @@ int hl_unet_set_overlap(void *handle, int enable);
  * are the same (tests/test_unet_gpu.py).  Affects only layers that take the DMA tile (Cout a multiple of 96). */
 #define HL_CONV_FP32 0
 #define HL_CONV_BF16X3 1
+#define HL_CONV_FP32_DIRECT 2
 int hl_unet_set_conv_mode(void *handle, int mode);
 
 /* Instrumentation for the roofline measurement (bench.py): with profiling enabled every kernel launch

@@ -94,6 +94,40 @@ def test_conv_bf16x3_emulation_matches_torch(N, C, H, W, Cout, ks, stride, ups):
     assert e_bf3 < 4 * e_f32 + 1e-6          # and within a small factor of the exact kernel's error vs float64
 
 
+@pytest.mark.parametrize("N,C,H,W,Cout,with_gn", [
+    (4, 32, 128, 128, 192, False),    # 768 workgroups, 4 k-tiles
+    (1, 192, 256, 256, 192, False),   # production shape (batch 1): 24 k-tiles
+    (3, 96, 176, 208, 192, False),    # non-square, H, W multiples of 16 only
+    (2, 64, 256, 128, 192, True),     # GroupNorm+SiLU prologue (materialised), residual epilogue
+    (9, 48, 64, 64, 384, False),      # 6 channel blocks
+])
+def test_conv_winograd_matches_torch(N, C, H, W, Cout, with_gn):
+    """HL_CONV_FP32 takes Winograd F(2x2,3x3) for large 3x3 layers: fp32 arithmetic, 2.25x fewer multiplies; compared with
+    float64 torch and with the direct kernel (HL_CONV_FP32_DIRECT) on the same inputs."""
+    from humanliff_amd import _lib
+    g = torch.Generator().manual_seed(N * 1000 + C + H + Cout)
+    x = torch.randn((N, C, H, W), generator=g)
+    w = torch.randn((Cout, C, 3, 3), generator=g) / (C * 9) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    kw = {}
+    xin = x.double()
+    if with_gn:
+        cA, cB = torch.rand((N, C), generator=g) + 0.5, torch.randn((N, C), generator=g) * 0.3
+        res = torch.randn((N, Cout, H, W), generator=g)
+        kw = dict(cA=cA, cB=cB, silu=1, res=res)
+        hn = x.double() * cA.double()[:, :, None, None] + cB.double()[:, :, None, None]
+        xin = hn * torch.sigmoid(hn)
+    got = hip_conv(x, w, b, 3, mode=_lib.HL_CONV_FP32, **kw)
+    direct = hip_conv(x, w, b, 3, mode=_lib.HL_CONV_FP32_DIRECT, **kw)
+    want = F.conv2d(xin, w.double(), b.double(), padding=1)
+    if with_gn:
+        want = want + res.double()
+    assert not torch.equal(got, direct)                      # the Winograd kernel really ran
+    e_w, e_d = (got.double() - want).abs().max().item(), (direct.double() - want).abs().max().item()
+    assert e_w < 2e-5, (e_w, e_d)                            # the direct kernel's bound (outputs O(1))
+    assert e_w < 8 * e_d + 1e-6, (e_w, e_d)                  # F(2x2,3x3) amplifies rounding by a small constant
+
+
 def test_conv_fused_groupnorm_silu_residual():
     """GroupNorm(+scale/shift) -> SiLU -> conv3x3 + bias + residual, the ResBlock inner step (unet.py:198-219)."""
     from humanliff_amd import _lib
