@@ -515,24 +515,56 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const C
         }
         return;
     }
+    // per 32-column block: all loads (residual, second residual) are issued before any store, so they overlap
+    // instead of serialising behind the stores (res may alias out)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int n = n0 + j * 32 + (lane & 31);
         if (n >= p.Cout) continue;
         const float bs = p.bias ? p.bias[n] : 0.f;
+        const long mb = m0 + wave * 32 + 4 * half;
+        float v[16], v2[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m >= p.M) continue;
-            float v = acc[j][r] + bs;
-            if (p.res) v += p.res[m * p.res_pitch + n];
-            if (p.out_nchw) {
-                const long img = m / hw_out, rem = m - img * hw_out;
-                p.out[(img * p.Cout + n) * hw_out + rem] = v;
-            } else {
-                p.out[m * p.out_pitch + n] = v;
+        for (int r = 0; r < 16; ++r) v[r] = acc[j][r] + bs;
+        if (p.res) {
+            float rr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = mb + (r & 3) + 8 * (r >> 2);
+                rr[r] = m < p.M ? p.res[m * p.res_pitch + n] : 0.f;
             }
-            if (p.out2) p.out2[m * p.out2_pitch + n] = v + p.res2[m * p.res2_pitch + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += rr[r];
+        }
+        if (p.out2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = mb + (r & 3) + 8 * (r >> 2);
+                v2[r] = m < p.M ? p.res2[m * p.res2_pitch + n] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v2[r] += v[r];
+        }
+        if (p.out_nchw) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = mb + (r & 3) + 8 * (r >> 2);
+                const long img = m / hw_out, rem = m - img * hw_out;
+                if (m < p.M) p.out[(img * p.Cout + n) * hw_out + rem] = v[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) p.out[m * p.out_pitch + n] = v[r];
+            }
+        }
+        if (p.out2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) p.out2[m * p.out2_pitch + n] = v2[r];
+            }
         }
     }
 }
@@ -550,13 +582,19 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const C
 // After the K walk every wave applies the column half of A^T . A to its accumulators, the four frequency rows meet in
 // LDS, and each wave finishes one (column parity, channel block) of the outputs with the usual epilogue.
 // LDS layouts are chosen so that the 8 lanes a ds_read_b128 serves per cycle read consecutive 16-byte chunks:
-//   patch chunk  ((half*18 + row)*2 + (col&1))*9 + (col>>1)        (4 channels of one pixel)
+//   patch chunk  ((half*18 + row)*2 + (col&1))*10 + (col>>1)       (4 channels of one pixel; 10, not 9, per half-row so that
+//                                                                    the next row of tiles starts 128 bytes off modulo 256)
 //   weight chunk ((f*2 + ct)*2 + half)*32 + cout                   (4 channels of one output channel)
 // ---------------------------------------------------------------------------------------------
-template <int DUMMY>
-__global__ __launch_bounds__(512, 2) void k_conv_wino(const ConvK p) {
+template <int G, int DBG>
+__global__ __launch_bounds__(G * 256, 2) void k_conv_wino(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__   // device pass only (see k_conv_bf3)
-    constexpr int NS = 3, U_F = 16 * 2 * 2 * 32 * 4, P_CH = 704, P_F = P_CH * 4, STAGE_F = U_F + P_F;
+    // G tile groups of 32 tiles (4 rows of 8 tiles = 16 x 8 pixels) per workgroup, 4 waves (frequency rows) each.
+    // G = 2: 8 waves, 3-stage ring, one workgroup per CU; G = 1: 4 waves, 2-stage ring, two independent workgroups per CU
+    // (their prologues / epilogues / barriers overlap; the weights are streamed twice as often).
+    constexpr int NW = 4 * G, NS = (G == 1) ? 2 : 3, PR = 8 * G + 2;   // waves, ring stages, patch rows
+    constexpr int U_F = 16 * 2 * 2 * 32 * 4, P_REAL = 2 * PR * 2 * 10, NP = (P_REAL + 63) / 64, P_F = NP * 256, STAGE_F = U_F + P_F;
+    constexpr int NU = 32 / NW, NTOT = 32 + NP, NJ = (NTOT + NW - 1) / NW;   // weight instructions per wave, all, rounds
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -568,9 +606,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino(const ConvK p) {
     const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
     const int tb = wi / p.n_nblocks, nb = wi - tb * p.n_nblocks;
     const int n0 = nb * 64;
-    const int bw = p.Win >> 4, bh = p.Hin >> 4;
+    const int bw = p.Win >> 4, bh = p.Hin / (8 * G);
     const int img = tb / (bw * bh), brem = tb - img * (bw * bh);
-    const int y0 = (brem / bw) * 16, x0 = (brem - (brem / bw) * bw) * 16;
+    const int y0 = (brem / bw) * (8 * G), x0 = (brem - (brem / bw) * bw) * 16;
     const int nkt = p.Cin >> 3;
     const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
 
@@ -579,46 +617,51 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino(const ConvK p) {
     const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.w_wino, (short)0, (int)((long)p.n_nblocks * nkt * U_F * 4), 0x00020000);
 
-    // DMA instructions of a k-tile: 32 weight instructions (plain 1 KiB copies) + 11 patch instructions; instruction
-    // q = wave + 8j: j = 0..3 weights, j = 4 patch `wave`, j = 5 patch 8 + wave (waves 0..2)
-    unsigned pv[2];
+    // DMA instructions of a k-tile: 32 weight instructions (plain 1 KiB copies) then NP patch instructions; instruction
+    // q = wave + NW*j: the first NU rounds are weights, the rest patch instructions q - 32 (< NP)
+    unsigned pv[NJ - NU];
+    int n_p = 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = (wave + 8 * j) * 64 + lane;                 // patch chunk
-        const int jc = c % 9, t1 = c / 9, par = t1 & 1, t2 = t1 >> 1, row = t2 % 18, h = t2 / 18;
+    for (int j = 0; j < NJ - NU; ++j) {
+        const int pi = wave + NW * (NU + j) - 32;
+        const int c = pi * 64 + lane;                             // patch chunk
+        const int jc = c % 10, t1 = c / 10, par = t1 & 1, t2 = t1 >> 1, row = t2 % PR, h = t2 / PR;
         const int y = y0 - 1 + row, x = x0 - 1 + 2 * jc + par;
-        const bool ok = c < 648 && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+        const bool ok = pi < NP && c < P_REAL && jc < 9 && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
         pv[j] = ok ? (unsigned)((img * p.Hin + y) * p.Win + x) * pitch4 + h * 16 : OOB;
+        n_p += (pi < NP) ? 1 : 0;
     }
-    const bool has_p1 = wave < 3;
-    const int n_w = 5 + (has_p1 ? 1 : 0);
-    const unsigned uv = (unsigned)(wave * 64 + lane) * 16u;       // + 8 KiB per j
+    const int n_w = NU + n_p;                                     // DMA instructions of this wave per k-tile
+    const unsigned uv = (unsigned)(wave * 64 + lane) * 16u;       // + NW KiB per round
     int soffU = nb * nkt * (U_F * 4), soffA = 0;
     auto issue = [&](int stage) {
         float *du = lds + stage * STAGE_F + wave * 256;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void *)(du + j * 2048), 16,
-                                                     uv, soffU + j * 8192, 0, 0);
-        float *dp = lds + stage * STAGE_F + U_F + wave * 256;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)dp, 16, pv[0], soffA, 0, 0);
-        if (has_p1)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(dp + 2048), 16, pv[1],
-                                                     soffA, 0, 0);
+        for (int j = 0; j < NU; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void *)(du + j * (NW * 256)), 16,
+                                                     uv, soffU + j * (NW * 1024), 0, 0);
+        float *dp = lds + stage * STAGE_F + U_F + (wave + NW * NU - 32) * 256;
+        if (n_p > 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)dp, 16, pv[0], soffA, 0, 0);
+        if (NJ - NU > 1 && n_p > 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(dp + NW * 256), 16,
+                                                     pv[NJ - NU > 1 ? 1 : 0], soffA, 0, 0);
+        static_assert(NJ - NU <= 2, "at most two patch instructions per wave");
         soffU += U_F * 4;
         soffA += 32;
     };
-    auto wait_younger = [&]() {
+    auto wait_younger = [&]() {   // all but this wave's DMAs of the youngest k-tile have landed (3-stage ring only)
         if (n_w == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     };
+    static_assert(G == 1 || (NU == 4 && NJ == 6), "wait_younger assumes 5 or 6 instructions per wave for G = 2");
 
     // patch read offsets (floats): tile T = lane & 31 -> (ty, tx); rows rA, rB of B^T row fi; column c: parity c&1, + (c>>1)
     const int T = lane & 31, ty = 4 * g + (T >> 3), tx = T & 7;
     const int rA = (fi == 0) ? 0 : (fi == 2 ? 2 : 1), rB = (fi == 0) ? 2 : (fi == 1 ? 2 : (fi == 2 ? 1 : 3));
     const float sB = (fi == 1) ? 1.f : -1.f;                      // T = d[rA] + sB * d[rB]
-    const int pA = U_F + (((half * 18 + 2 * ty + rA) * 2) * 9 + tx) * 4, pB = U_F + (((half * 18 + 2 * ty + rB) * 2) * 9 + tx) * 4;
-    // column c of a row: + ((c & 1) * 9 + (c >> 1)) * 4 floats  -> c0: 0, c1: 36, c2: 4, c3: 40
+    const int pA = U_F + (((half * PR + 2 * ty + rA) * 2) * 10 + tx) * 4, pB = U_F + (((half * PR + 2 * ty + rB) * 2) * 10 + tx) * 4;
+    // column c of a row: + ((c & 1) * 10 + (c >> 1)) * 4 floats
     const int u_off = ((fi * 4 * 2) * 2 + half) * 32 * 4 + (lane & 31) * 4;   // + ((f' * 2 + ct) * 2) * 128 floats
 
     f32x16 acc[4][2];
@@ -629,44 +672,73 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino(const ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][c][r] = 0.f;
 
+    // Pipeline in units of (frequency f', channel block ct) = 4 MFMAs: the weight chunk of the next unit is read while the
+    // current one multiplies; the barrier for k-tile t+1 sits in front of unit 6, followed by the patch reads of t+1,
+    // whose transform is computed behind the last MFMAs of tile t.
     const int ntiles = nkt;
-    if (ntiles > 0) {
-        issue(0);
-        if (ntiles > 1) issue(1);
-    }
-    auto body = [&](auto uc, int t) {
-        constexpr int U = decltype(uc)::value;
-        const float *base = lds + U * STAGE_F;
-        if (t + 1 < ntiles) wait_younger(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // tile t visible to all; stage of tile t-1 free
-        asm volatile("" ::: "memory");
-        if (t + 2 < ntiles) issue((U + 2) % NS);
-        f32x4 tc[4];
+    auto read_patch = [&](const float *base, f32x4(&da)[4], f32x4(&db)[4]) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int co = ((c & 1) * 9 + (c >> 1)) * 4;
-            const f32x4 da = *reinterpret_cast<const f32x4 *>(base + pA + co);
-            const f32x4 db = *reinterpret_cast<const f32x4 *>(base + pB + co);
-            tc[c] = da + sB * db;
+            const int co = ((c & 1) * 10 + (c >> 1)) * 4;
+            da[c] = *reinterpret_cast<const f32x4 *>(base + pA + co);
+            db[c] = *reinterpret_cast<const f32x4 *>(base + pB + co);
         }
-        f32x4 V[4];
+    };
+    auto transform = [&](const f32x4(&da)[4], const f32x4(&db)[4], f32x4(&V)[4]) {
+        f32x4 tc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tc[c] = da[c] + sB * db[c];
         V[0] = tc[0] - tc[2];
         V[1] = tc[1] + tc[2];
         V[2] = tc[2] - tc[1];
         V[3] = tc[1] - tc[3];
+    };
+    f32x4 V[4], ub[2][2], da[4], db[4];   // ub[buffer][ct]
+    auto read_u = [&](const float *base, int f, f32x4(&u2)[2]) {
+        u2[0] = *reinterpret_cast<const f32x4 *>(base + u_off + ((f * 2 + 0) * 2) * 128);
+        u2[1] = *reinterpret_cast<const f32x4 *>(base + u_off + ((f * 2 + 1) * 2) * 128);
+    };
+    if (ntiles > 0) {
+        issue(0);
+        if (NS == 3 && ntiles > 1) { issue(1); wait_younger(); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ntiles > NS - 1) issue(NS - 1);
+        read_patch(lds, da, db);
+        read_u(lds, 0, ub[0]);
+        transform(da, db, V);
+    }
+    auto body = [&](auto uc, int t) {
+        constexpr int U = decltype(uc)::value, UN = (U + 1) % NS;
+        const float *base = lds + U * STAGE_F, *nbase = lds + UN * STAGE_F;
+        const bool more = t + 1 < ntiles;
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const f32x4 ub = *reinterpret_cast<const f32x4 *>(base + u_off + ((f * 2 + c) * 2) * 128);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[s], acc[f][c], 0, 0, 0);
+        for (int f = 0; f < 4; ++f) {   // unit = frequency f' (both channel blocks: two independent accumulator chains)
+            if (f < 3) read_u(base, f + 1, ub[(f + 1) & 1]);
+            if (f == 2 && more) {   // (the last weight chunks of tile t were read just above: nothing reads stage U after this)
+                if (DBG == 1 || DBG == 2) {} else
+                if (NS == 3 && t + 2 < ntiles) wait_younger(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done reading tile t before its stage refills
+                if (DBG != 5) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (DBG != 2 && t + NS < ntiles) issue(U);
+                read_patch(nbase, da, db);
             }
+            if (f == 3 && more) read_u(nbase, 0, ub[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][0][s], acc[f][0], 0, 0, 0);
+                acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][1][s], acc[f][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) transform(da, db, V);
     };
     for (int t = 0; t < ntiles; t += NS) {
         body(std::integral_constant<int, 0>{}, t);
         if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 < ntiles) body(std::integral_constant<int, 2>{}, t + 2);
+        if (NS == 3 && t + 2 < ntiles) body(std::integral_constant<int, NS == 3 ? 2 : 0>{}, t + 2);
     }
 
     // column half of the output transform, then the four frequency rows meet in LDS
@@ -681,26 +753,50 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino(const ConvK p) {
             ex[((1 * 2 + c) * 16 + r) * 64 + lane] = (m1 - m2) - m3;
         }
     __syncthreads();
-    // wave (g, fi) finishes column parity b = fi >> 1, channel block ct = fi & 1 of its tile group
+    // wave (g, fi) finishes column parity b = fi >> 1, channel block ct = fi & 1 of its tile group: 32 outputs per lane.
+    // All loads (residuals) are issued before any store, so they overlap instead of serialising behind the stores
+    // (res may alias out).
     const int b = fi >> 1, ct = fi & 1;
     const int n = n0 + ct * 32 + (lane & 31);
     const float bs = p.bias ? p.bias[n] : 0.f;
     const long hw = (long)p.Hin * p.Win;
+    float v[32];
+    long mm[32];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float *zz = lds + (g * 4) * 4096 + ((b * 2 + ct) * 16 + r) * 64 + lane;
         const float z0 = zz[0], z1 = zz[4096], z2 = zz[2 * 4096], z3 = zz[3 * 4096];
         const int Tr = (r & 3) + 8 * (r >> 2) + 4 * half;
         const int oy = y0 + 2 * (4 * g + (Tr >> 3)), ox = x0 + 2 * (Tr & 7) + b;
+        v[2 * r] = ((z0 + z1) + z2) + bs;
+        v[2 * r + 1] = ((z1 - z2) - z3) + bs;
+        mm[2 * r] = ((long)img * p.Hin + oy) * p.Win + ox;
+        mm[2 * r + 1] = mm[2 * r] + p.Win;
+    }
+    if (p.res) {
+        float rr[32];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            float v = (a == 0 ? (z0 + z1) + z2 : (z1 - z2) - z3) + bs;
-            const long m = ((long)img * p.Hin + oy + a) * p.Win + ox;
-            if (p.res) v += p.res[m * p.res_pitch + n];
-            if (p.out_nchw) p.out[((long)img * p.Cout + n) * hw + (long)(oy + a) * p.Win + ox] = v;
-            else p.out[m * p.out_pitch + n] = v;
-            if (p.out2) p.out2[m * p.out2_pitch + n] = v + p.res2[m * p.res2_pitch + n];
-        }
+        for (int k = 0; k < 32; ++k) rr[k] = p.res[mm[k] * p.res_pitch + n];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] += rr[k];
+    }
+    float v2[32];
+    if (p.out2) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v2[k] = p.res2[mm[k] * p.res2_pitch + n];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v2[k] += v[k];
+    }
+    if (p.out_nchw) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) p.out[((long)img * p.Cout + n) * hw + (mm[k] - (long)img * hw)] = v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) p.out[mm[k] * p.out_pitch + n] = v[k];
+    }
+    if (p.out2) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) p.out2[mm[k] * p.out2_pitch + n] = v2[k];
     }
 #endif
 }
@@ -973,24 +1069,56 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_bf3(const C
         }
         return;
     }
+    // per 32-column block: all loads (residual, second residual) are issued before any store, so they overlap
+    // instead of serialising behind the stores (res may alias out)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int n = n0 + j * 32 + (lane & 31);
         if (n >= p.Cout) continue;
         const float bs = p.bias ? p.bias[n] : 0.f;
+        const long mb = m0 + wave * 32 + 4 * half;
+        float v[16], v2[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m >= p.M) continue;
-            float v = acc[j][r] + bs;
-            if (p.res) v += p.res[m * p.res_pitch + n];
-            if (p.out_nchw) {
-                const long img = m / hw_out, rem = m - img * hw_out;
-                p.out[(img * p.Cout + n) * hw_out + rem] = v;
-            } else {
-                p.out[m * p.out_pitch + n] = v;
+        for (int r = 0; r < 16; ++r) v[r] = acc[j][r] + bs;
+        if (p.res) {
+            float rr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = mb + (r & 3) + 8 * (r >> 2);
+                rr[r] = m < p.M ? p.res[m * p.res_pitch + n] : 0.f;
             }
-            if (p.out2) p.out2[m * p.out2_pitch + n] = v + p.res2[m * p.res2_pitch + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += rr[r];
+        }
+        if (p.out2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = mb + (r & 3) + 8 * (r >> 2);
+                v2[r] = m < p.M ? p.res2[m * p.res2_pitch + n] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v2[r] += v[r];
+        }
+        if (p.out_nchw) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = mb + (r & 3) + 8 * (r >> 2);
+                const long img = m / hw_out, rem = m - img * hw_out;
+                if (m < p.M) p.out[(img * p.Cout + n) * hw_out + rem] = v[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) p.out[m * p.out_pitch + n] = v[r];
+            }
+        }
+        if (p.out2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) p.out2[m * p.out2_pitch + n] = v2[r];
+            }
         }
     }
 #endif
@@ -1699,7 +1827,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     } while (0)
     // 3x3 / stride-1 layers large enough to fill the chip with 16x16-pixel x 64-channel workgroups: Winograd F(2x2,3x3)
     const long wino_blocks = (long)a.in.N * (a.in.H / 16) * (a.in.W / 16) * (a.Cout / 64);
-    const bool wino = dma && a.w_wino && !a.w_bf3 && a.ks == 3 && a.stride == 1 && !a.ups && a.in.H % 16 == 0 && a.in.W % 16 == 0 &&
+    const bool wino = dma && a.w_wino && !a.w_bf3 && a.ks == 3 && a.stride == 1 && !a.ups && a.in.H % 8 == 0 && a.in.W % 16 == 0 &&
                       a.Cout % 64 == 0 && wino_blocks >= wino_thr && (long)a.Cout * a.in.C * 64 < (1L << 31);
     if (dma) {
         if (mode != 0) {   // materialise GroupNorm(+SiLU) once, then the DMA kernel reads it raw
@@ -1716,8 +1844,13 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             p.partial = nullptr;
             p.n_nblocks = a.Cout / 64;
             p.n_mtiles = a.in.N * (a.in.H / 16) * (a.in.W / 16);
-            const size_t shmw = (size_t)3 * (16 * 2 * 2 * 32 * 4 + 704 * 4) * sizeof(float);
-            hipLaunchKernelGGL((k_conv_wino<0>), dim3((unsigned)(p.n_mtiles * p.n_nblocks)), dim3(512), shmw, st, p);
+            // one tile group per workgroup (two workgroups per CU) unless the 32 x 16 variant is asked for
+            static const int wg2 = getenv("HL_WINO_G2") ? 1 : 0;
+            const bool g2 = wg2 && a.in.H % 16 == 0;
+            p.n_mtiles = a.in.N * (a.in.H / (g2 ? 16 : 8)) * (a.in.W / 16);
+            const unsigned nblk = (unsigned)(p.n_mtiles * p.n_nblocks);
+            if (g2) hipLaunchKernelGGL((k_conv_wino<2, 0>), dim3(nblk), dim3(512), (size_t)3 * (8192 + 12 * 256) * sizeof(float), st, p);
+            else hipLaunchKernelGGL((k_conv_wino<1, 0>), dim3(nblk), dim3(256), (size_t)2 * (8192 + 7 * 256) * sizeof(float), st, p);
             return check_launch("k_conv_wino");
         }
         p.n_nblocks = cpad / 96;

@@ -7,7 +7,7 @@ f = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)[0]
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 1000.0
 by = collections.defaultdict(dict)
 for r in csv.DictReader(open(f)):
-    if 'k_conv_dma' in r['Kernel_Name'] or 'k_conv_bf3' in r['Kernel_Name']:
+    if any(k in r['Kernel_Name'] for k in ('k_conv_dma', 'k_conv_bf3', 'k_conv_wino')):
         d = by[r['Dispatch_Id']]
         d[r['Counter_Name']] = float(r['Counter_Value'])
         d['t0'] = float(r['Start_Timestamp']); d['t1'] = float(r['End_Timestamp'])
