@@ -586,20 +586,21 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const C
 //                                                                    the next row of tiles starts 128 bytes off modulo 256)
 //   weight chunk ((f*2 + ct)*2 + half)*32 + cout                   (4 channels of one output channel)
 // ---------------------------------------------------------------------------------------------
-template <int G, int DBG>
-__global__ __launch_bounds__(G * 256, 2) void k_conv_wino(const ConvK p) {
+template <int G, int CW, int DBG>
+__global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__   // device pass only (see k_conv_bf3)
     // G tile groups of 32 tiles (4 rows of 8 tiles = 16 x 8 pixels) per workgroup, 4 waves (frequency rows) each.
     // G = 2: 8 waves, 3-stage ring, one workgroup per CU; G = 1: 4 waves, 2-stage ring, two independent workgroups per CU
     // (their prologues / epilogues / barriers overlap; the weights are streamed twice as often).
-    constexpr int NW = 4 * G, NS = (G == 1) ? 2 : 3, PR = 8 * G + 2;   // waves, ring stages, patch rows
+    // CW = 2: the two 32-channel blocks go to different waves (64 accumulator registers each -> 4 waves per SIMD).
+    constexpr int NW = 4 * G * CW, NCT = 2 / CW, NS = (G == 1) ? 2 : 3, PR = 8 * G + 2;   // waves, channel blocks per wave, ring stages, patch rows
     constexpr int U_F = 16 * 2 * 2 * 32 * 4, P_REAL = 2 * PR * 2 * 10, NP = (P_REAL + 63) / 64, P_F = NP * 256, STAGE_F = U_F + P_F;
     constexpr int NU = 32 / NW, NTOT = 32 + NP, NJ = (NTOT + NW - 1) / NW;   // weight instructions per wave, all, rounds
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave >> 2, fi = wave & 3;                       // tile group, frequency row
+    const int fi = wave & 3, ctw = (CW == 2) ? ((wave >> 2) & 1) : 0, g = wave >> (CW == 2 ? 3 : 2);   // frequency row, channel block, tile group
     const int total = p.n_mtiles * p.n_nblocks;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int q8 = total >> 3, r8 = total & 7;
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(G * 256, 2) void k_conv_wino(const ConvK p) {
         if (n_w == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     };
-    static_assert(G == 1 || (NU == 4 && NJ == 6), "wait_younger assumes 5 or 6 instructions per wave for G = 2");
+    static_assert(G == 1 || (CW == 1 && NU == 4 && NJ == 6), "wait_younger assumes 5 or 6 instructions per wave for G = 2");
 
     // patch read offsets (floats): tile T = lane & 31 -> (ty, tx); rows rA, rB of B^T row fi; column c: parity c&1, + (c>>1)
     const int T = lane & 31, ty = 4 * g + (T >> 3), tx = T & 7;
@@ -664,11 +665,11 @@ __global__ __launch_bounds__(G * 256, 2) void k_conv_wino(const ConvK p) {
     // column c of a row: + ((c & 1) * 10 + (c >> 1)) * 4 floats
     const int u_off = ((fi * 4 * 2) * 2 + half) * 32 * 4 + (lane & 31) * 4;   // + ((f' * 2 + ct) * 2) * 128 floats
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NCT];
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < NCT; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][c][r] = 0.f;
 
@@ -693,10 +694,10 @@ __global__ __launch_bounds__(G * 256, 2) void k_conv_wino(const ConvK p) {
         V[2] = tc[2] - tc[1];
         V[3] = tc[1] - tc[3];
     };
-    f32x4 V[4], ub[2][2], da[4], db[4];   // ub[buffer][ct]
-    auto read_u = [&](const float *base, int f, f32x4(&u2)[2]) {
-        u2[0] = *reinterpret_cast<const f32x4 *>(base + u_off + ((f * 2 + 0) * 2) * 128);
-        u2[1] = *reinterpret_cast<const f32x4 *>(base + u_off + ((f * 2 + 1) * 2) * 128);
+    f32x4 V[4], ub[2][NCT], da[4], db[4];   // ub[buffer][ct]
+    auto read_u = [&](const float *base, int f, f32x4(&u2)[NCT]) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) u2[c] = *reinterpret_cast<const f32x4 *>(base + u_off + ((f * 2 + (CW == 2 ? ctw : c)) * 2) * 128);
     };
     if (ntiles > 0) {
         issue(0);
@@ -727,13 +728,13 @@ __global__ __launch_bounds__(G * 256, 2) void k_conv_wino(const ConvK p) {
             if (f == 3 && more) read_u(nbase, 0, ub[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][0][s], acc[f][0], 0, 0, 0);
-                acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][1][s], acc[f][1], 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][c][s], acc[f][c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) transform(da, db, V);
+        if (more && DBG != 7) transform(da, db, V);
     };
     for (int t = 0; t < ntiles; t += NS) {
         body(std::integral_constant<int, 0>{}, t);
@@ -742,61 +743,67 @@ __global__ __launch_bounds__(G * 256, 2) void k_conv_wino(const ConvK p) {
     }
 
     // column half of the output transform, then the four frequency rows meet in LDS
+    if (DBG == 6) { if (acc[0][0][0] == 123.f) p.out[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7]; return; }
     __syncthreads();
-    float *ex = lds + wave * 4096;                                // [b][ct][r][lane]
+    constexpr int EXW = 2 * NCT * 16 * 64;                        // floats per wave: [b][ct][r][lane]
+    float *ex = lds + wave * EXW;
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float m0 = acc[0][c][r], m1 = acc[1][c][r], m2 = acc[2][c][r], m3 = acc[3][c][r];
-            ex[((0 * 2 + c) * 16 + r) * 64 + lane] = (m0 + m1) + m2;
-            ex[((1 * 2 + c) * 16 + r) * 64 + lane] = (m1 - m2) - m3;
+            ex[((0 * NCT + c) * 16 + r) * 64 + lane] = (m0 + m1) + m2;
+            ex[((1 * NCT + c) * 16 + r) * 64 + lane] = (m1 - m2) - m3;
         }
     __syncthreads();
-    // wave (g, fi) finishes column parity b = fi >> 1, channel block ct = fi & 1 of its tile group: 32 outputs per lane.
+    // CW = 1: wave (g, fi) finishes column parity b = fi >> 1, channel block ct = fi & 1 of its tile group (32 outputs per lane);
+    // CW = 2: wave (g, ctw, fi) finishes b = fi & 1 of its own channel block for accumulator rows 8*(fi>>1).. (16 outputs per lane).
     // All loads (residuals) are issued before any store, so they overlap instead of serialising behind the stores
     // (res may alias out).
-    const int b = fi >> 1, ct = fi & 1;
+    constexpr int NR = 16 / CW, NO = 2 * NR;
+    const int b = (CW == 2) ? (fi & 1) : (fi >> 1), ct = (CW == 2) ? ctw : (fi & 1), r0 = (CW == 2) ? 8 * (fi >> 1) : 0;
     const int n = n0 + ct * 32 + (lane & 31);
     const float bs = p.bias ? p.bias[n] : 0.f;
     const long hw = (long)p.Hin * p.Win;
-    float v[32];
-    long mm[32];
+    float v[NO];
+    long mm[NO];
+    const float *zbase = lds + ((CW == 2 ? (g * 2 + ctw) : g) * 4) * EXW + ((b * NCT + (CW == 2 ? 0 : ct)) * 16) * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float *zz = lds + (g * 4) * 4096 + ((b * 2 + ct) * 16 + r) * 64 + lane;
-        const float z0 = zz[0], z1 = zz[4096], z2 = zz[2 * 4096], z3 = zz[3 * 4096];
+    for (int rr_ = 0; rr_ < NR; ++rr_) {
+        const int r = r0 + rr_;
+        const float *zz = zbase + r * 64;
+        const float z0 = zz[0], z1 = zz[EXW], z2 = zz[2 * EXW], z3 = zz[3 * EXW];
         const int Tr = (r & 3) + 8 * (r >> 2) + 4 * half;
         const int oy = y0 + 2 * (4 * g + (Tr >> 3)), ox = x0 + 2 * (Tr & 7) + b;
-        v[2 * r] = ((z0 + z1) + z2) + bs;
-        v[2 * r + 1] = ((z1 - z2) - z3) + bs;
-        mm[2 * r] = ((long)img * p.Hin + oy) * p.Win + ox;
-        mm[2 * r + 1] = mm[2 * r] + p.Win;
+        v[2 * rr_] = ((z0 + z1) + z2) + bs;
+        v[2 * rr_ + 1] = ((z1 - z2) - z3) + bs;
+        mm[2 * rr_] = ((long)img * p.Hin + oy) * p.Win + ox;
+        mm[2 * rr_ + 1] = mm[2 * rr_] + p.Win;
     }
     if (p.res) {
-        float rr[32];
+        float rr[NO];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) rr[k] = p.res[mm[k] * p.res_pitch + n];
+        for (int k = 0; k < NO; ++k) rr[k] = p.res[mm[k] * p.res_pitch + n];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) v[k] += rr[k];
+        for (int k = 0; k < NO; ++k) v[k] += rr[k];
     }
-    float v2[32];
+    float v2[NO];
     if (p.out2) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) v2[k] = p.res2[mm[k] * p.res2_pitch + n];
+        for (int k = 0; k < NO; ++k) v2[k] = p.res2[mm[k] * p.res2_pitch + n];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) v2[k] += v[k];
+        for (int k = 0; k < NO; ++k) v2[k] += v[k];
     }
     if (p.out_nchw) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) p.out[((long)img * p.Cout + n) * hw + (mm[k] - (long)img * hw)] = v[k];
+        for (int k = 0; k < NO; ++k) p.out[((long)img * p.Cout + n) * hw + (mm[k] - (long)img * hw)] = v[k];
     } else {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) p.out[mm[k] * p.out_pitch + n] = v[k];
+        for (int k = 0; k < NO; ++k) p.out[mm[k] * p.out_pitch + n] = v[k];
     }
     if (p.out2) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) p.out2[mm[k] * p.out2_pitch + n] = v2[k];
+        for (int k = 0; k < NO; ++k) p.out2[mm[k] * p.out2_pitch + n] = v2[k];
     }
 #endif
 }
@@ -1826,7 +1833,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         else hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 2, false>), GRID, dim3(256), shm, st, p);                  \
     } while (0)
     // 3x3 / stride-1 layers large enough to fill the chip with 16x16-pixel x 64-channel workgroups: Winograd F(2x2,3x3)
-    const long wino_blocks = (long)a.in.N * (a.in.H / 16) * (a.in.W / 16) * (a.Cout / 64);
+    const long wino_blocks = (long)a.in.N * (a.in.H / 8) * (a.in.W / 16) * (a.Cout / 64);   // workgroups of 16 x 8 pixels x 64 channels
     const bool wino = dma && a.w_wino && !a.w_bf3 && a.ks == 3 && a.stride == 1 && !a.ups && a.in.H % 8 == 0 && a.in.W % 16 == 0 &&
                       a.Cout % 64 == 0 && wino_blocks >= wino_thr && (long)a.Cout * a.in.C * 64 < (1L << 31);
     if (dma) {
@@ -1849,8 +1856,13 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             const bool g2 = wg2 && a.in.H % 16 == 0;
             p.n_mtiles = a.in.N * (a.in.H / (g2 ? 16 : 8)) * (a.in.W / 16);
             const unsigned nblk = (unsigned)(p.n_mtiles * p.n_nblocks);
-            if (g2) hipLaunchKernelGGL((k_conv_wino<2, 0>), dim3(nblk), dim3(512), (size_t)3 * (8192 + 12 * 256) * sizeof(float), st, p);
-            else hipLaunchKernelGGL((k_conv_wino<1, 0>), dim3(nblk), dim3(256), (size_t)2 * (8192 + 7 * 256) * sizeof(float), st, p);
+            // (measured on 192->192 @256x256, batch 4: one tile group x both channel blocks per wave 256 TFLOP/s; two tile groups
+            //  249; channel blocks on separate waves - 4 waves/SIMD - 237)
+            static const int wcw2 = getenv("HL_WINO_CW2") ? 1 : 0;
+            const size_t sh1 = (size_t)2 * (8192 + 7 * 256) * sizeof(float);
+            if (g2) hipLaunchKernelGGL((k_conv_wino<2, 1, 0>), dim3(nblk), dim3(512), (size_t)3 * (8192 + 12 * 256) * sizeof(float), st, p);
+            else if (wcw2) hipLaunchKernelGGL((k_conv_wino<1, 2, 0>), dim3(nblk), dim3(512), sh1, st, p);
+            else hipLaunchKernelGGL((k_conv_wino<1, 1, 0>), dim3(nblk), dim3(256), sh1, st, p);
             return check_launch("k_conv_wino");
         }
         p.n_nblocks = cpad / 96;
