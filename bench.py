@@ -37,7 +37,7 @@ COARSE_FLOP_PER_RAY = 128 * 79616
 # Fabric-side bytes per launch of the two dominant kernels from the separate rocprofv3 PMC passes (FETCH_SIZE
 # doubled per the gfx950 calibration, WRITE_SIZE as is): profiles/r01_pmc_hbm_traffic.md.  Not measured by this
 # script - PMC collection needs its own runs.
-PMC_TRAFFIC = {"k_conv_avg_launch_b4": 254e6, "k_march_fine_512x512": 3.95e9,
+PMC_TRAFFIC = {"k_conv_avg_launch_b4": 297e6, "k_march_fine_512x512": 3.69e9,
                "source": "profiles/r01_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
 
 F4 = dict(image_size=256, in_channels=27, out_channels=27, num_channels=192, num_res_blocks=3, num_heads=4,
@@ -117,12 +117,17 @@ def bench_unet(args, rank, world, dev):
     handle = model._hip[0]
     _lib.check(L.hl_unet_profile(handle, 1))
     next(it)
-    ms, fl, nl = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int64 * 4)()
-    _lib.check(L.hl_unet_profile_read(handle, ms, fl, nl))
+    ms, fl, xf, nl = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int64 * 4)()
+    _lib.check(L.hl_unet_profile_read_ex(handle, ms, fl, xf, nl))
     _lib.check(L.hl_unet_profile(handle, 0))
     conv_ms, conv_fl, conv_n = ms[0], fl[0], nl[0]
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    roof = {"bound": "mfma", "kernel": "k_conv_dma (implicit-GEMM conv/1x1, v_mfma_f32_32x32x2_f32; with its k_gn_apply pre-pass and k_splitk_finish), all launches of one denoise step",
+    executed = xf[0] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    roof = {"bound": "mfma", "kernel": "k_conv_wino (Winograd F(2x2,3x3), large 3x3 layers) + k_conv_dma (direct implicit GEMM, the rest), "
+                                       "v_mfma_f32_32x32x2_f32; with their k_gn_apply pre-pass and k_splitk_finish; all launches of one denoise step",
+            "executed": {"tflops": round(executed, 2), "frac_of_peak": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+                         "note": "`achieved` counts ALGORITHMIC FLOPs (direct convolution, SURVEY 8(d)); the Winograd layers issue 16/36 of "
+                                 "their multiplies, so `frac` can exceed 1 while the matrix pipe itself runs at `executed.frac_of_peak`"},
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": PMC_TRAFFIC["k_conv_avg_launch_b4"] if B == 4 else None, "traffic_source": PMC_TRAFFIC["source"],

@@ -86,7 +86,7 @@ struct Net {
     // optional per-category HIP-event timing of one forward (bench.py roofline leg)
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;
-    struct Span { int cat; size_t a, b; double flops; };
+    struct Span { int cat; size_t a, b; double flops, exec; };   // algorithmic FLOPs and the FLOPs the kernel actually issued
     std::vector<Span> spans;
     size_t ev_used = 0;
     ~Net() {
@@ -343,11 +343,11 @@ struct Exec {
         hipEventRecord(n.ev_pool[a], st);
         return a;
     }
-    void span_end(int cat, size_t a, double flops) {
+    void span_end(int cat, size_t a, double flops, double exec = -1.0) {
         if (!n.prof) return;
         const size_t b = n.next_event();
         hipEventRecord(n.ev_pool[b], st);
-        n.spans.push_back({cat, a, b, flops});
+        n.spans.push_back({cat, a, b, flops, exec < 0 ? flops : exec});
     }
 
     void conv(const Conv &c, const View &in, const View &out, int stride, int ups, const float *cA, const float *cB, int act,
@@ -369,7 +369,9 @@ struct Exec {
         a.act_ws = act_ws; a.act_ws_bytes = act_need * sizeof(float);
         const size_t e0 = span_begin();
         ok(hl::conv2d(a, st));
-        span_end(CAT_CONV, e0, 2.0 * (double)out.pixels() * c.Cout * c.Cin * c.ks * c.ks);
+        const double fl = 2.0 * (double)out.pixels() * c.Cout * c.Cin * c.ks * c.ks;
+        // Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36; bf16x3: six bf16 MFMA products per fp32 product
+        span_end(CAT_CONV, e0, fl, a.path == 1 ? fl * (16.0 / 36.0) : (a.path == 2 ? fl * 6.0 : fl));
     }
     void coef(const View &x, const Norm &g, const float *emb, float *&cA, float *&cB) {
         cA = alloc((size_t)B * x.C);
@@ -630,15 +632,20 @@ int hl_unet_profile(void *handle, int enable) {
 }
 
 int hl_unet_profile_read(void *handle, double *h_ms, double *h_flops, int64_t *h_launches) {
+    return hl_unet_profile_read_ex(handle, h_ms, h_flops, nullptr, h_launches);
+}
+
+int hl_unet_profile_read_ex(void *handle, double *h_ms, double *h_flops, double *h_exec_flops, int64_t *h_launches) {
     HL_REQUIRE(handle && h_ms && h_flops && h_launches, "hl_unet_profile_read: null argument");
     Net &n = *static_cast<Net *>(handle);
-    for (int i = 0; i < CAT_N; ++i) { h_ms[i] = 0; h_flops[i] = 0; h_launches[i] = 0; }
+    for (int i = 0; i < CAT_N; ++i) { h_ms[i] = 0; h_flops[i] = 0; h_launches[i] = 0; if (h_exec_flops) h_exec_flops[i] = 0; }
     if (n.spans.empty()) return HL_OK;
     HL_HIP(hipEventSynchronize(n.ev_pool[n.spans.back().b]));
     for (auto &sp : n.spans) {
         float ms = 0.f;
         HL_HIP(hipEventElapsedTime(&ms, n.ev_pool[sp.a], n.ev_pool[sp.b]));
         h_ms[sp.cat] += ms; h_flops[sp.cat] += sp.flops; h_launches[sp.cat] += 1;
+        if (h_exec_flops) h_exec_flops[sp.cat] += sp.exec;
     }
     n.spans.clear();
     n.ev_used = 0;

@@ -35,6 +35,7 @@ struct ConvArgs {
     int out_nchw;        // write (N, Cout, H, W) instead of NHWC
     float *act_ws;       // optional scratch (pixels*Cin floats) for the materialised GroupNorm(+SiLU) input of k_conv_dma
     size_t act_ws_bytes;
+    mutable int path;    // set by conv2d: 0 direct implicit GEMM, 1 Winograd F(2x2,3x3), 2 bf16x3 emulation
     float *splitk_ws;    // optional scratch for split-K partial sums (small-M layers); null disables split-K
     size_t splitk_ws_bytes;
 };

@@ -1763,6 +1763,7 @@ int conv_pack_weights_wino(const float *w, int Cout, int Cin, int Cin_pad, float
 }
 
 int conv2d(const ConvArgs &a, hipStream_t st) {
+    a.path = 0;
     HL_REQUIRE(a.in.p && a.w && a.out.p, "conv2d: null tensor");
     HL_REQUIRE(a.in.C % 16 == 0, "conv2d: Cin (%d) must be padded to a multiple of 16", a.in.C);
     HL_REQUIRE(a.ks == 1 || a.ks == 3, "conv2d: kernel size %d", a.ks);
@@ -1848,6 +1849,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0;
         }
         if (wino) {
+            a.path = 1;
             p.partial = nullptr;
             p.n_nblocks = a.Cout / 64;
             p.n_mtiles = a.in.N * (a.in.H / 16) * (a.in.W / 16);
@@ -1870,6 +1872,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
         const size_t shm8 = (size_t)3 * 352 * 16 * sizeof(float), shm4 = (size_t)3 * 224 * 16 * sizeof(float);
         if (a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) {   // fp32 emulated on the bf16 matrix pipe (opt-in)
+            a.path = 2;
             const size_t s8 = (size_t)3 * (256 * 16 + 6 * 96 * 4) * sizeof(float), s4 = (size_t)3 * (128 * 16 + 6 * 96 * 4) * sizeof(float);
             if (tile8 && a.ups) hipLaunchKernelGGL((k_conv_bf3<8, true>), grid, dim3(512), s8, st, p);
             else if (tile8) hipLaunchKernelGGL((k_conv_bf3<8, false>), grid, dim3(512), s8, st, p);

@@ -180,6 +180,9 @@ int hl_unet_set_conv_mode(void *handle, int mode);
  * of 4).  Not meant for the timed production path. */
 int hl_unet_profile(void *handle, int enable);
 int hl_unet_profile_read(void *handle, double *h_ms, double *h_flops, int64_t *h_launches);
+/* same, plus the FLOPs the kernels actually issued to the matrix pipe (h_exec_flops, may be NULL): Winograd layers issue
+ * 16/36 of their algorithmic multiplies, HL_CONV_BF16X3 layers six bf16 products per fp32 product. */
+int hl_unet_profile_read_ex(void *handle, double *h_ms, double *h_flops, double *h_exec_flops, int64_t *h_launches);
 
 /* Fused sampler update (everything after the model call in p_sample / ddim_sample,
  * gaussian_diffusion.py:293-333, 356-388, 484-529) for EPSILON prediction with a fixed

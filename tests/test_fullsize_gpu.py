@@ -34,18 +34,21 @@ def test_production_unet_matches_oracle(production):
     assert err < 5e-4 * max(1.0, scale), (err, scale)          # fp32, 256 stacked convs with K up to 13824
     mse = float(((got - want) ** 2).mean())
     assert mse < 1e-9 * max(1.0, scale ** 2)
-    # the opt-in bf16x3 emulation of the fp32 products (HL_CONV_BF16X3) meets the same bounds against the oracle
-    model.set_conv_mode("bf16x3")
-    try:
-        with torch.no_grad():
-            got3 = model(x.to(dev), t.to(dev), xc.to(dev), y=y.to(dev)).cpu()
-    finally:
-        model.set_conv_mode("fp32")
-    err3 = float((got3 - want).abs().max())
-    assert not torch.equal(got3, got)        # the mode really switched kernels
-    assert err3 < 5e-4 * max(1.0, scale), (err3, err, scale)
-    assert float(((got3 - want) ** 2).mean()) < 1e-9 * max(1.0, scale ** 2)
-    print(f"production UNet max-abs vs oracle: fp32 {err:.3e}, bf16x3 {err3:.3e} (output scale {scale:.3f})")
+    # the other arithmetic modes meet the same bounds against the oracle: direct-only fp32 (no Winograd) and the opt-in
+    # bf16x3 emulation of the fp32 products
+    errs = {"fp32": err}
+    for mode in ("fp32_direct", "bf16x3"):
+        model.set_conv_mode(mode)
+        try:
+            with torch.no_grad():
+                alt = model(x.to(dev), t.to(dev), xc.to(dev), y=y.to(dev)).cpu()
+        finally:
+            model.set_conv_mode("fp32")
+        errs[mode] = float((alt - want).abs().max())
+        assert not torch.equal(alt, got)     # the mode really switched kernels
+        assert errs[mode] < 5e-4 * max(1.0, scale), (mode, errs, scale)
+        assert float(((alt - want) ** 2).mean()) < 1e-9 * max(1.0, scale ** 2)
+    print("production UNet max-abs vs oracle: " + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()) + f" (output scale {scale:.3f})")
 
 
 def test_production_batch_independence(production):
