@@ -1,13 +1,17 @@
 // Device kernels of the tri-plane UNet denoiser and the sampler update, MI355X (gfx950), fp32.
 //
 // What each kernel replaces in the reference (human_diffusion/improved_diffusion/):
-//   k_conv            nn.Conv2d 3x3 / 3x3 stride 2 / nearest-x2 + 3x3 / 1x1 / Conv1d k=1 (unet.py:68,100,149,
-//                     164-184,237-239,378,486-518) as ONE implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32),
-//                     with GroupNorm-apply(+scale/shift)+SiLU fused into the tile load and bias / residual /
-//                     skip-sum fused into the store.  NHWC activations, channel pitch so concats are free.
-//   k_gn_partial/coef GroupNorm32(32, C) statistics (nn.py:17-19,100) folded to a per-(n,c) affine.
+//   k_conv_wino       nn.Conv2d 3x3 stride 1 on the large levels (ResBlock in_layers / out_layers, unet.py:149,164) by fused
+//                     Winograd F(2x2,3x3), fp32.
+//   k_conv_dma        every other nn.Conv2d 3x3 / 3x3 stride 2 / nearest-x2 + 3x3 / 1x1 / Conv1d k=1 (unet.py:68,100,149,
+//                     164-184,237-239,378,486-518) as ONE implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), operands
+//                     staged by LDS-DMA; bias / residual / skip-sum fused into the store.  NHWC activations, channel
+//                     pitch so concats are free.  k_conv_bf3: the same with bf16x3-emulated products (opt-in).
+//   k_conv            the round's first kernel (register-staged, GroupNorm fused into the tile load): Cout <= 32, tiny layers.
+//   k_gn_apply        GroupNorm-apply(+scale/shift)+SiLU materialised ahead of a DMA conv (nn.py:100, unet.py:212-216).
+//   k_gn_partial/coef, k_gn_small  GroupNorm32(32, C) statistics (nn.py:17-19,100) folded to a per-(n,c) affine.
 //   k_linear_small    time_embed / emb_layers nn.Linear at batch <= 8 (unet.py:151-157,366-370).
-//   k_attention       QKVAttention (unet.py:255-274): fp32 flash-style, softmax in fp32.
+//   k_attention(_ks)  QKVAttention (unet.py:255-274): fp32 flash-style, softmax in fp32 (_ks: keys split over the waves).
 //   k_prep_inputs     x.type(dtype), x + x_cond (unet.py:588,596) and NCHW -> NHWC.
 #include "hl_unet_kernels.h"
 

@@ -162,12 +162,16 @@ int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float 
  * enable = 0 issues everything on the caller's stream. */
 int hl_unet_set_overlap(void *handle, int enable);
 
-/* Arithmetic of the large convolutions.  HL_CONV_FP32 (default): exact fp32 products and accumulation on
- * v_mfma_f32_32x32x2_f32 - what the reference's fp32 path specifies.  HL_CONV_BF16X3 (opt-in): the same fp32 tensors
- * and fp32 accumulators, but each product a*b is formed on the bf16 matrix pipe from exact three-way splits
- * a = ah+am+al, b = bh+bm+bl (8 significand bits per bf16 plane) as ah*bh + ah*bm + am*bh + ah*bl + am*bm + al*bh; the three
- * dropped terms are <= 3*2^-24 |a*b|, the size of one fp32 rounding.  Not bit-identical to HL_CONV_FP32; parity bounds
- * are the same (tests/test_unet_gpu.py).  Affects only layers that take the DMA tile (Cout a multiple of 96). */
+/* Arithmetic of the large convolutions - all modes keep fp32 tensors and fp32 accumulators.
+ * HL_CONV_FP32 (default): fp32 products on v_mfma_f32_32x32x2_f32; 3x3 / stride-1 layers that fill the chip take Winograd
+ *   F(2x2,3x3) (16 fp32 multiplies per 2x2 outputs instead of 36), everything else the direct implicit GEMM.
+ * HL_CONV_FP32_DIRECT: the direct implicit GEMM only - every product of the reference's sum is formed exactly once.
+ * HL_CONV_BF16X3 (opt-in, direct only): each product a*b is formed on the bf16 matrix pipe from exact three-way splits
+ *   a = ah+am+al, b = bh+bm+bl (8 significand bits per bf16 plane) as ah*bh + ah*bm + am*bh + ah*bl + am*bm + al*bh; the three
+ *   dropped terms are <= 3*2^-24 |a*b|, the size of one fp32 rounding.
+ * The modes are not bit-identical to each other; all meet the same parity bounds (tests/test_unet_gpu.py,
+ * tests/test_fullsize_gpu.py: production UNet vs the CPU oracle 4.5e-6 / 5.0e-6 / 5.1e-6 max-abs on O(0.5) outputs).
+ * Only layers with Cout a multiple of 96 (the DMA tile) are affected. */
 #define HL_CONV_FP32 0
 #define HL_CONV_BF16X3 1
 #define HL_CONV_FP32_DIRECT 2
