@@ -638,7 +638,8 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
     }
     const int n_w = NU + n_p;                                     // DMA instructions of this wave per k-tile
     const unsigned uv = (unsigned)(wave * 64 + lane) * 16u;       // + NW KiB per round
-    int soffU = nb * nkt * (U_F * 4), soffA = 0;
+    const int kt0 = blockIdx.z * p.kt_per;                        // split-K over input channels: this slab's k-tiles
+    int soffU = (nb * nkt + kt0) * (U_F * 4), soffA = kt0 * 32;
     auto issue = [&](int stage) {
         float *du = lds + stage * STAGE_F + wave * 256;
 #pragma unroll
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
     // Pipeline in units of (frequency f', channel block ct) = 4 MFMAs: the weight chunk of the next unit is read while the
     // current one multiplies; the barrier for k-tile t+1 sits in front of unit 6, followed by the patch reads of t+1,
     // whose transform is computed behind the last MFMAs of tile t.
-    const int ntiles = nkt;
+    const int ntiles = min(nkt, kt0 + p.kt_per) - kt0;
     auto read_patch = [&](const float *base, f32x4(&da)[4], f32x4(&db)[4]) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
     constexpr int NR = 16 / CW, NO = 2 * NR;
     const int b = (CW == 2) ? (fi & 1) : (fi >> 1), ct = (CW == 2) ? ctw : (fi & 1), r0 = (CW == 2) ? 8 * (fi >> 1) : 0;
     const int n = n0 + ct * 32 + (lane & 31);
-    const float bs = p.bias ? p.bias[n] : 0.f;
+    const float bs = (p.bias && !p.partial) ? p.bias[n] : 0.f;
     const long hw = (long)p.Hin * p.Win;
     float v[NO];
     long mm[NO];
@@ -783,6 +784,12 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
         v[2 * rr_ + 1] = ((z1 - z2) - z3) + bs;
         mm[2 * rr_] = ((long)img * p.Hin + oy) * p.Win + ox;
         mm[2 * rr_ + 1] = mm[2 * rr_] + p.Win;
+    }
+    if (p.partial) {   // split-K: the output transform is linear, so slabs are summed in the output domain by k_splitk_finish
+        float *dst = p.partial + (long)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) dst[mm[k] * p.Cout + n] = v[k];
+        return;
     }
     if (p.res) {
         float rr[NO];
@@ -1803,7 +1810,8 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     // the 8-wave 256x96 tile when that covers at least half the chip (2 workgroups/CU = 512 slots), else 4 waves x 128x96
     static const int dma_thr = getenv("HL_CONV_T8") ? atoi(getenv("HL_CONV_T8")) : 256;
     static const int dma_off = getenv("HL_CONV_NODMA") ? 1 : 0;
-    static const long wino_thr = getenv("HL_CONV_WINO") ? atol(getenv("HL_CONV_WINO")) : 512;   // min workgroups; huge = off
+    static const long wino_thr = getenv("HL_CONV_WINO") ? atol(getenv("HL_CONV_WINO")) : 512;   // workgroups wanted per launch; huge = off
+    static const long wino_min = getenv("HL_CONV_WINO_MIN") ? atol(getenv("HL_CONV_WINO_MIN")) : 384;   // fewer even after splitting: direct kernel
     const bool dma = !dma_off && cfg == 0 && (a.coefA == nullptr || a.act_ws) &&
                      (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && (long)cpad * p.Ktot * 4 < (1L << 31);
     const long blocks8 = ((M + 255) / 256) * (cpad / 96);
@@ -1837,10 +1845,26 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         else if (mode == 1) hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 1, false>), GRID, dim3(256), shm, st, p);   \
         else hipLaunchKernelGGL((k_conv<WM_, WN_, MT_, NT_, 2, false>), GRID, dim3(256), shm, st, p);                  \
     } while (0)
-    // 3x3 / stride-1 layers large enough to fill the chip with 16x16-pixel x 64-channel workgroups: Winograd F(2x2,3x3)
-    const long wino_blocks = (long)a.in.N * (a.in.H / 8) * (a.in.W / 16) * (a.Cout / 64);   // workgroups of 16 x 8 pixels x 64 channels
-    const bool wino = dma && a.w_wino && !a.w_bf3 && a.ks == 3 && a.stride == 1 && !a.ups && a.in.H % 8 == 0 && a.in.W % 16 == 0 &&
-                      a.Cout % 64 == 0 && wino_blocks >= wino_thr && (long)a.Cout * a.in.C * 64 < (1L << 31);
+    // 3x3 / stride-1 layers: Winograd F(2x2,3x3) with 16x8-pixel x 64-channel workgroups; layers that do not fill the chip
+    // that way split the input channels into slabs (the output transform is linear: k_splitk_finish sums outputs)
+    const long wino_blocks = (long)a.in.N * (a.in.H / 8) * (a.in.W / 16) * (a.Cout / 64);
+    bool wino = dma && a.w_wino && !a.w_bf3 && a.ks == 3 && a.stride == 1 && !a.ups && a.in.H % 8 == 0 && a.in.W % 16 == 0 &&
+                a.Cout % 64 == 0 && (long)a.Cout * a.in.C * 64 < (1L << 31);
+    int wsplits = 1;
+    if (wino && wino_blocks < wino_thr) {
+        const int nkt8 = a.in.C / 8;
+        wsplits = (int)((wino_thr + wino_blocks - 1) / wino_blocks);
+        if (wsplits > nkt8 / 6) wsplits = nkt8 / 6;              // at least 6 k-tiles (48 channels) per slab
+        if (wsplits > 16) wsplits = 16;
+        while (wsplits > 1 && (size_t)wsplits * M * a.Cout * sizeof(float) > a.splitk_ws_bytes) --wsplits;
+        if (!a.splitk_ws || wsplits < 2 || wino_blocks * wsplits < wino_min) wino = false;
+    }
+    if (wino) {
+        splits = wsplits;
+        p.kt_per = (a.in.C / 8 + splits - 1) / splits;
+        splits = (a.in.C / 8 + p.kt_per - 1) / p.kt_per;
+        p.partial = splits > 1 ? a.splitk_ws : nullptr;
+    }
     if (dma) {
         if (mode != 0) {   // materialise GroupNorm(+SiLU) once, then the DMA kernel reads it raw
             HL_REQUIRE(!a.ups, "conv2d: upsample with a GroupNorm prologue is not used by the UNet");
@@ -1854,21 +1878,26 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         }
         if (wino) {
             a.path = 1;
-            p.partial = nullptr;
             p.n_nblocks = a.Cout / 64;
             p.n_mtiles = a.in.N * (a.in.H / 16) * (a.in.W / 16);
             // one tile group per workgroup (two workgroups per CU) unless the 32 x 16 variant is asked for
             static const int wg2 = getenv("HL_WINO_G2") ? 1 : 0;
             const bool g2 = wg2 && a.in.H % 16 == 0;
             p.n_mtiles = a.in.N * (a.in.H / (g2 ? 16 : 8)) * (a.in.W / 16);
-            const unsigned nblk = (unsigned)(p.n_mtiles * p.n_nblocks);
+            const dim3 nblk((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
             // (measured on 192->192 @256x256, batch 4: one tile group x both channel blocks per wave 256 TFLOP/s; two tile groups
             //  249; channel blocks on separate waves - 4 waves/SIMD - 237)
             static const int wcw2 = getenv("HL_WINO_CW2") ? 1 : 0;
             const size_t sh1 = (size_t)2 * (8192 + 7 * 256) * sizeof(float);
-            if (g2) hipLaunchKernelGGL((k_conv_wino<2, 1, 0>), dim3(nblk), dim3(512), (size_t)3 * (8192 + 12 * 256) * sizeof(float), st, p);
-            else if (wcw2) hipLaunchKernelGGL((k_conv_wino<1, 2, 0>), dim3(nblk), dim3(512), sh1, st, p);
-            else hipLaunchKernelGGL((k_conv_wino<1, 1, 0>), dim3(nblk), dim3(256), sh1, st, p);
+            if (g2) hipLaunchKernelGGL((k_conv_wino<2, 1, 0>), nblk, dim3(512), (size_t)3 * (8192 + 12 * 256) * sizeof(float), st, p);
+            else if (wcw2) hipLaunchKernelGGL((k_conv_wino<1, 2, 0>), nblk, dim3(512), sh1, st, p);
+            else hipLaunchKernelGGL((k_conv_wino<1, 1, 0>), nblk, dim3(256), sh1, st, p);
+            if (splits > 1) {
+                long gf = (M * a.Cout + 255) / 256;
+                if (gf > 2048) gf = 2048;
+                hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)gf), dim3(256), 0, st, p, splits);
+                return check_launch("k_splitk_finish");
+            }
             return check_launch("k_conv_wino");
         }
         p.n_nblocks = cpad / 96;

@@ -100,6 +100,8 @@ def test_conv_bf16x3_emulation_matches_torch(N, C, H, W, Cout, ks, stride, ups):
     (3, 96, 176, 208, 192, False),    # non-square, H, W multiples of 16 only
     (2, 64, 256, 128, 192, True),     # GroupNorm+SiLU prologue (materialised), residual epilogue
     (9, 48, 64, 64, 384, False),      # 6 channel blocks
+    (4, 384, 32, 32, 384, True),      # 192 workgroups: input channels split into 3 slabs, summed by k_splitk_finish
+    (4, 768, 16, 16, 768, False),     # 96 workgroups x 6 slabs
 ])
 def test_conv_winograd_matches_torch(N, C, H, W, Cout, with_gn):
     """HL_CONV_FP32 takes Winograd F(2x2,3x3) for large 3x3 layers: fp32 arithmetic, 2.25x fewer multiplies; compared with
