@@ -590,7 +590,7 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const C
 //                                                                    the next row of tiles starts 128 bytes off modulo 256)
 //   weight chunk ((f*2 + ct)*2 + half)*32 + cout                   (4 channels of one output channel)
 // ---------------------------------------------------------------------------------------------
-template <int G, int CW, int DBG>
+template <int G, int CW, int DBG, bool UPS = false>
 __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__   // device pass only (see k_conv_bf3)
     // G tile groups of 32 tiles (4 rows of 8 tiles = 16 x 8 pixels) per workgroup, 4 waves (frequency rows) each.
@@ -611,7 +611,10 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
     const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
     const int tb = wi / p.n_nblocks, nb = wi - tb * p.n_nblocks;
     const int n0 = nb * 64;
-    const int bw = p.Win >> 4, bh = p.Hin / (8 * G);
+    // UPS: the convolution runs on the nearest-x2 upsampled image (unet.py:77-79); only the patch DMA knows - it fetches source
+    // pixel (y>>1, x>>1) - so the upsampled tensor is never materialised
+    const int Hv = UPS ? 2 * p.Hin : p.Hin, Wv = UPS ? 2 * p.Win : p.Win;
+    const int bw = Wv >> 4, bh = Hv / (8 * G);
     const int img = tb / (bw * bh), brem = tb - img * (bw * bh);
     const int y0 = (brem / bw) * (8 * G), x0 = (brem - (brem / bw) * bw) * 16;
     const int nkt = p.Cin >> 3;
@@ -632,8 +635,9 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
         const int c = pi * 64 + lane;                             // patch chunk
         const int jc = c % 10, t1 = c / 10, par = t1 & 1, t2 = t1 >> 1, row = t2 % PR, h = t2 / PR;
         const int y = y0 - 1 + row, x = x0 - 1 + 2 * jc + par;
-        const bool ok = pi < NP && c < P_REAL && jc < 9 && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
-        pv[j] = ok ? (unsigned)((img * p.Hin + y) * p.Win + x) * pitch4 + h * 16 : OOB;
+        const bool ok = pi < NP && c < P_REAL && jc < 9 && y >= 0 && y < Hv && x >= 0 && x < Wv;
+        const int ys = UPS ? y >> 1 : y, xs = UPS ? x >> 1 : x;
+        pv[j] = ok ? (unsigned)((img * p.Hin + ys) * p.Win + xs) * pitch4 + h * 16 : OOB;
         n_p += (pi < NP) ? 1 : 0;
     }
     const int n_w = NU + n_p;                                     // DMA instructions of this wave per k-tile
@@ -720,8 +724,14 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
         const bool more = t + 1 < ntiles;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {   // unit = frequency f' (both channel blocks: two independent accumulator chains)
+            // the reads for the next unit are issued AFTER this unit's operands have been waited for (the compiler waits
+            // with lgkmcnt(0)), behind its first MFMAs, and land under the remaining six
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+                acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][0], ub[f & 1][c][0], acc[f][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             if (f < 3) read_u(base, f + 1, ub[(f + 1) & 1]);
-            if (f == 2 && more) {   // (the last weight chunks of tile t were read just above: nothing reads stage U after this)
+            else if (more) {   // (every weight chunk of tile t has been read: nothing reads stage U after this)
                 if (DBG == 1 || DBG == 2) {} else
                 if (NS == 3 && t + 2 < ntiles) wait_younger(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done reading tile t before its stage refills
@@ -729,17 +739,20 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
                 asm volatile("" ::: "memory");
                 if (DBG != 2 && t + NS < ntiles) issue(U);
                 read_patch(nbase, da, db);
+                read_u(nbase, 0, ub[0]);
             }
-            if (f == 3 && more) read_u(nbase, 0, ub[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 1; s < 4; ++s)
 #pragma unroll
                 for (int c = 0; c < NCT; ++c)
                     acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][c][s], acc[f][c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more && DBG != 7) transform(da, db, V);
+        // nothing pending at the loop back-edge: lets the compiler count its LDS waits inside the body exactly (the reads of
+        // U(t+1, 0) were issued 8 MFMAs ago)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     for (int t = 0; t < ntiles; t += NS) {
         body(std::integral_constant<int, 0>{}, t);
@@ -769,7 +782,7 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
     const int b = (CW == 2) ? (fi & 1) : (fi >> 1), ct = (CW == 2) ? ctw : (fi & 1), r0 = (CW == 2) ? 8 * (fi >> 1) : 0;
     const int n = n0 + ct * 32 + (lane & 31);
     const float bs = (p.bias && !p.partial) ? p.bias[n] : 0.f;
-    const long hw = (long)p.Hin * p.Win;
+    const long hw = (long)Hv * Wv;
     float v[NO];
     long mm[NO];
     const float *zbase = lds + ((CW == 2 ? (g * 2 + ctw) : g) * 4) * EXW + ((b * NCT + (CW == 2 ? 0 : ct)) * 16) * 64 + lane;
@@ -782,8 +795,8 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
         const int oy = y0 + 2 * (4 * g + (Tr >> 3)), ox = x0 + 2 * (Tr & 7) + b;
         v[2 * rr_] = ((z0 + z1) + z2) + bs;
         v[2 * rr_ + 1] = ((z1 - z2) - z3) + bs;
-        mm[2 * rr_] = ((long)img * p.Hin + oy) * p.Win + ox;
-        mm[2 * rr_ + 1] = mm[2 * rr_] + p.Win;
+        mm[2 * rr_] = ((long)img * Hv + oy) * Wv + ox;
+        mm[2 * rr_ + 1] = mm[2 * rr_] + Wv;
     }
     if (p.partial) {   // split-K: the output transform is linear, so slabs are summed in the output domain by k_splitk_finish
         float *dst = p.partial + (long)blockIdx.z * p.M * p.Cout;
@@ -1847,9 +1860,9 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     } while (0)
     // 3x3 / stride-1 layers: Winograd F(2x2,3x3) with 16x8-pixel x 64-channel workgroups; layers that do not fill the chip
     // that way split the input channels into slabs (the output transform is linear: k_splitk_finish sums outputs)
-    const long wino_blocks = (long)a.in.N * (a.in.H / 8) * (a.in.W / 16) * (a.Cout / 64);
-    bool wino = dma && a.w_wino && !a.w_bf3 && a.ks == 3 && a.stride == 1 && !a.ups && a.in.H % 8 == 0 && a.in.W % 16 == 0 &&
-                a.Cout % 64 == 0 && (long)a.Cout * a.in.C * 64 < (1L << 31);
+    const long wino_blocks = (long)a.out.N * (a.out.H / 8) * (a.out.W / 16) * (a.Cout / 64);
+    bool wino = dma && a.w_wino && !a.w_bf3 && a.ks == 3 && a.stride == 1 && a.out.H % 8 == 0 && a.out.W % 16 == 0 &&
+                a.Cout % 64 == 0 && (long)a.Cout * a.in.C * 64 < (1L << 31);   // (stride 1: out = in, or 2x in when upsampling)
     int wsplits = 1;
     if (wino && wino_blocks < wino_thr) {
         const int nkt8 = a.in.C / 8;
@@ -1879,18 +1892,18 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         if (wino) {
             a.path = 1;
             p.n_nblocks = a.Cout / 64;
-            p.n_mtiles = a.in.N * (a.in.H / 16) * (a.in.W / 16);
             // one tile group per workgroup (two workgroups per CU) unless the 32 x 16 variant is asked for
             static const int wg2 = getenv("HL_WINO_G2") ? 1 : 0;
-            const bool g2 = wg2 && a.in.H % 16 == 0;
-            p.n_mtiles = a.in.N * (a.in.H / (g2 ? 16 : 8)) * (a.in.W / 16);
+            const bool g2 = wg2 && a.out.H % 16 == 0 && !a.ups;
+            p.n_mtiles = a.out.N * (a.out.H / (g2 ? 16 : 8)) * (a.out.W / 16);
             const dim3 nblk((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
             // (measured on 192->192 @256x256, batch 4: one tile group x both channel blocks per wave 256 TFLOP/s; two tile groups
             //  249; channel blocks on separate waves - 4 waves/SIMD - 237)
             static const int wcw2 = getenv("HL_WINO_CW2") ? 1 : 0;
             const size_t sh1 = (size_t)2 * (8192 + 7 * 256) * sizeof(float);
             if (g2) hipLaunchKernelGGL((k_conv_wino<2, 1, 0>), nblk, dim3(512), (size_t)3 * (8192 + 12 * 256) * sizeof(float), st, p);
-            else if (wcw2) hipLaunchKernelGGL((k_conv_wino<1, 2, 0>), nblk, dim3(512), sh1, st, p);
+            else if (wcw2 && !a.ups) hipLaunchKernelGGL((k_conv_wino<1, 2, 0>), nblk, dim3(512), sh1, st, p);
+            else if (a.ups) hipLaunchKernelGGL((k_conv_wino<1, 1, 0, true>), nblk, dim3(256), sh1, st, p);
             else hipLaunchKernelGGL((k_conv_wino<1, 1, 0>), nblk, dim3(256), sh1, st, p);
             if (splits > 1) {
                 long gf = (M * a.Cout + 255) / 256;

@@ -94,6 +94,23 @@ def test_conv_bf16x3_emulation_matches_torch(N, C, H, W, Cout, ks, stride, ups):
     assert e_bf3 < 4 * e_f32 + 1e-6          # and within a small factor of the exact kernel's error vs float64
 
 
+def test_conv_winograd_upsample_matches_torch():
+    """nearest x2 + 3x3 conv (Upsample, unet.py:77-79) through the Winograd kernel: the patch DMA reads source pixel (y>>1, x>>1)."""
+    from humanliff_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    N, C, H, W, Cout = 4, 96, 64, 48, 192
+    x = torch.randn((N, C, H, W), generator=g)
+    w = torch.randn((Cout, C, 3, 3), generator=g) / (C * 9) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    got = hip_conv(x, w, b, 3, ups=1, mode=_lib.HL_CONV_FP32)
+    direct = hip_conv(x, w, b, 3, ups=1, mode=_lib.HL_CONV_FP32_DIRECT)
+    want = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    assert got.shape == want.shape and not torch.equal(got, direct)
+    e_w, e_d = (got.double() - want).abs().max().item(), (direct.double() - want).abs().max().item()
+    assert e_w < 2e-5 and e_w < 8 * e_d + 1e-6, (e_w, e_d)
+
+
+
 @pytest.mark.parametrize("N,C,H,W,Cout,with_gn", [
     (4, 32, 128, 128, 192, False),    # 768 workgroups, 4 k-tiles
     (1, 192, 256, 256, 192, False),   # production shape (batch 1): 24 k-tiles
