@@ -590,7 +590,7 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const C
 //                                                                    the next row of tiles starts 128 bytes off modulo 256)
 //   weight chunk ((f*2 + ct)*2 + half)*32 + cout                   (4 channels of one output channel)
 // ---------------------------------------------------------------------------------------------
-template <int G, int CW, int DBG, bool UPS = false>
+template <int G, int CW, bool UPS = false>
 __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__   // device pass only (see k_conv_bf3)
     // G tile groups of 32 tiles (4 rows of 8 tiles = 16 x 8 pixels) per workgroup, 4 waves (frequency rows) each.
@@ -732,12 +732,11 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
             __builtin_amdgcn_sched_barrier(0);
             if (f < 3) read_u(base, f + 1, ub[(f + 1) & 1]);
             else if (more) {   // (every weight chunk of tile t has been read: nothing reads stage U after this)
-                if (DBG == 1 || DBG == 2) {} else
                 if (NS == 3 && t + 2 < ntiles) wait_younger(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done reading tile t before its stage refills
-                if (DBG != 5) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (DBG != 2 && t + NS < ntiles) issue(U);
+                if (t + NS < ntiles) issue(U);
                 read_patch(nbase, da, db);
                 read_u(nbase, 0, ub[0]);
             }
@@ -749,7 +748,7 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
                     acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][c][s], acc[f][c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more && DBG != 7) transform(da, db, V);
+        if (more) transform(da, db, V);
         // nothing pending at the loop back-edge: lets the compiler count its LDS waits inside the body exactly (the reads of
         // U(t+1, 0) were issued 8 MFMAs ago)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -761,7 +760,6 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
     }
 
     // column half of the output transform, then the four frequency rows meet in LDS
-    if (DBG == 6) { if (acc[0][0][0] == 123.f) p.out[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7]; return; }
     __syncthreads();
     constexpr int EXW = 2 * NCT * 16 * 64;                        // floats per wave: [b][ct][r][lane]
     float *ex = lds + wave * EXW;
@@ -1901,10 +1899,10 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             //  249; channel blocks on separate waves - 4 waves/SIMD - 237)
             static const int wcw2 = getenv("HL_WINO_CW2") ? 1 : 0;
             const size_t sh1 = (size_t)2 * (8192 + 7 * 256) * sizeof(float);
-            if (g2) hipLaunchKernelGGL((k_conv_wino<2, 1, 0>), nblk, dim3(512), (size_t)3 * (8192 + 12 * 256) * sizeof(float), st, p);
-            else if (wcw2 && !a.ups) hipLaunchKernelGGL((k_conv_wino<1, 2, 0>), nblk, dim3(512), sh1, st, p);
-            else if (a.ups) hipLaunchKernelGGL((k_conv_wino<1, 1, 0, true>), nblk, dim3(256), sh1, st, p);
-            else hipLaunchKernelGGL((k_conv_wino<1, 1, 0>), nblk, dim3(256), sh1, st, p);
+            if (g2) hipLaunchKernelGGL((k_conv_wino<2, 1>), nblk, dim3(512), (size_t)3 * (8192 + 12 * 256) * sizeof(float), st, p);
+            else if (wcw2 && !a.ups) hipLaunchKernelGGL((k_conv_wino<1, 2>), nblk, dim3(512), sh1, st, p);
+            else if (a.ups) hipLaunchKernelGGL((k_conv_wino<1, 1, true>), nblk, dim3(256), sh1, st, p);
+            else hipLaunchKernelGGL((k_conv_wino<1, 1>), nblk, dim3(256), sh1, st, p);
             if (splits > 1) {
                 long gf = (M * a.Cout + 255) / 256;
                 if (gf > 2048) gf = 2048;
