@@ -590,7 +590,7 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const C
 //                                                                    the next row of tiles starts 128 bytes off modulo 256)
 //   weight chunk ((f*2 + ct)*2 + half)*32 + cout                   (4 channels of one output channel)
 // ---------------------------------------------------------------------------------------------
-template <int G, int CW, bool UPS = false>
+template <int G, int CW, bool UPS = false, bool PRIV = false>
 __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__   // device pass only (see k_conv_bf3)
     // G tile groups of 32 tiles (4 rows of 8 tiles = 16 x 8 pixels) per workgroup, 4 waves (frequency rows) each.
@@ -708,56 +708,155 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
 #pragma unroll
         for (int c = 0; c < NCT; ++c) u2[c] = *reinterpret_cast<const f32x4 *>(base + u_off + ((f * 2 + (CW == 2 ? ctw : c)) * 2) * 128);
     };
-    if (ntiles > 0) {
-        issue(0);
-        if (NS == 3 && ntiles > 1) { issue(1); wait_younger(); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (ntiles > NS - 1) issue(NS - 1);
-        read_patch(lds, da, db);
-        read_u(lds, 0, ub[0]);
-        transform(da, db, V);
-    }
-    auto body = [&](auto uc, int t) {
-        constexpr int U = decltype(uc)::value, UN = (U + 1) % NS;
-        const float *base = lds + U * STAGE_F, *nbase = lds + UN * STAGE_F;
-        const bool more = t + 1 < ntiles;
+    if constexpr (PRIV) {
+        // PRIV (G = 1, CW = 1): the four waves of a workgroup use DISJOINT weight slices (their own frequency row), so each wave
+        // DMAs exactly its own 8 chunks per k-tile and nobody else reads them: no barrier is needed for the weights, and the
+        // refill of a chunk pair is issued right behind the MFMAs that consumed it - two DMA instructions per unit instead of
+        // a burst of ten behind the barrier, each with two k-tiles to land.  Only the patch (1-2 instructions per wave) stays
+        // behind the barrier.  Per wave the VMEM queue therefore carries, per k-tile, the fixed sequence
+        //     U(.,0) U(.,1) U(.,2) P(.) U(.,3)            (2, 2, 2, n_p, 2 instructions)
+        // for the tile two ahead, and every wait below is an exact count of the younger instructions in that queue.
+        static_assert(G == 1 && CW == 1, "PRIV needs one tile group and both channel blocks per wave");
+        const unsigned uvp = (unsigned)lane * 16u;
+        int soffP = (nb * nkt + kt0) * (U_F * 4) + (8 * fi) * 1024;   // this wave's first chunk of k-tile kt0
+        auto issue_u = [&](int stage, int f, int soff) {             // both channel blocks of frequency f'
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {   // unit = frequency f' (both channel blocks: two independent accumulator chains)
-            // the reads for the next unit are issued AFTER this unit's operands have been waited for (the compiler waits
-            // with lgkmcnt(0)), behind its first MFMAs, and land under the remaining six
-#pragma unroll
-            for (int c = 0; c < NCT; ++c)
-                acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][0], ub[f & 1][c][0], acc[f][c], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (f < 3) read_u(base, f + 1, ub[(f + 1) & 1]);
-            else if (more) {   // (every weight chunk of tile t has been read: nothing reads stage U after this)
-                if (NS == 3 && t + 2 < ntiles) wait_younger(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done reading tile t before its stage refills
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (t + NS < ntiles) issue(U);
-                read_patch(nbase, da, db);
-                read_u(nbase, 0, ub[0]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 1; s < 4; ++s)
-#pragma unroll
-                for (int c = 0; c < NCT; ++c)
-                    acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][c][s], acc[f][c], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int c = 0; c < 2; ++c)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsU, (__attribute__((address_space(3))) void *)(lds + stage * STAGE_F + (8 * fi + 2 * f + c) * 256), 16, uvp,
+                    soff + (2 * f + c) * 1024, 0, 0);
+        };
+        auto issue_p = [&](int stage) {
+            float *dp = lds + stage * STAGE_F + U_F + wave * 256;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)dp, 16, pv[0], soffA, 0, 0);
+            if (n_p > 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(dp + NW * 256), 16, pv[1],
+                                                         soffA, 0, 0);
+            soffA += 32;
+        };
+        auto issue_tile = [&](int stage) {   // the whole sequence at once (prologue only)
+            issue_u(stage, 0, soffP); issue_u(stage, 1, soffP); issue_u(stage, 2, soffP);
+            issue_p(stage);
+            issue_u(stage, 3, soffP);
+            soffP += U_F * 4;
+        };
+        auto wait_vm = [&](int n1, int n2) {   // s_waitcnt vmcnt(n_p == 1 ? n1 : n2)
+            const int n = n_p > 1 ? n2 : n1;
+            if (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (n == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else if (n == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            else if (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (n == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        if (ntiles > 0) {
+            issue_tile(0);
+            if (ntiles > 1) { issue_tile(1); wait_vm(11, 12); }           // younger than P(0): U(0,3) + the 8 + n_p of tile 1
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");         // younger than P(0): U(0,3)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            read_patch(lds, da, db);
+            read_u(lds, 0, ub[0]);
+            transform(da, db, V);
         }
-        if (more) transform(da, db, V);
-        // nothing pending at the loop back-edge: lets the compiler count its LDS waits inside the body exactly (the reads of
-        // U(t+1, 0) were issued 8 MFMAs ago)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    for (int t = 0; t < ntiles; t += NS) {
-        body(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, t + 1);
-        if (NS == 3 && t + 2 < ntiles) body(std::integral_constant<int, NS == 3 ? 2 : 0>{}, t + 2);
-    }
+        auto bodyp = [&](auto uc, int t) {
+            constexpr int U = decltype(uc)::value, UN = U ^ 1;
+            const float *base = lds + U * STAGE_F, *nbase = lds + UN * STAGE_F;
+            const bool more = t + 1 < ntiles, more2 = t + 2 < ntiles;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][0], ub[f & 1][c][0], acc[f][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (f < 3) {
+                    // U(t, f+1) was issued two tiles ago; younger: the rest of that tile's sequence, the 8 + n_p of tile t-1's and
+                    // the 2f of this tile's issues so far.  The last two tiles (no refills any more) simply drain the queue.
+                    if (!more2) { if (f == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                    else if (f == 0) wait_vm(14, 16);      // 4 + n_p + 8 + n_p
+                    else if (f == 1) wait_vm(14, 16);      // 2 + n_p + 8 + n_p + 2
+                    else wait_vm(13, 14);                  // 8 + n_p + 4
+                    read_u(base, f + 1, ub[(f + 1) & 1]);
+                } else if (more) {
+                    // P(t+1) (and the older U(t+1,0)) have landed once only U(t+1,3) and this tile's three refills are younger
+                    if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();            // patch of tile t+1 visible to all; every wave has consumed patch t
+                    asm volatile("" ::: "memory");
+                    if (more2) issue_p(U);
+                    read_patch(nbase, da, db);
+                    read_u(nbase, 0, ub[0]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 1; s < 4; ++s)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][c][s], acc[f][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more2) issue_u(U, f, soffP);              // the chunk pair just consumed refills for tile t+2
+            }
+            if (more2) soffP += U_F * 4;
+            if (more) transform(da, db, V);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        for (int t = 0; t < ntiles; t += 2) {
+            bodyp(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < ntiles) bodyp(std::integral_constant<int, 1>{}, t + 1);
+        }
+    } else {
+    if (ntiles > 0) {
+            issue(0);
+            if (NS == 3 && ntiles > 1) { issue(1); wait_younger(); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (ntiles > NS - 1) issue(NS - 1);
+            read_patch(lds, da, db);
+            read_u(lds, 0, ub[0]);
+            transform(da, db, V);
+        }
+        auto body = [&](auto uc, int t) {
+            constexpr int U = decltype(uc)::value, UN = (U + 1) % NS;
+            const float *base = lds + U * STAGE_F, *nbase = lds + UN * STAGE_F;
+            const bool more = t + 1 < ntiles;
+    #pragma unroll
+            for (int f = 0; f < 4; ++f) {   // unit = frequency f' (both channel blocks: two independent accumulator chains)
+                // the reads for the next unit are issued AFTER this unit's operands have been waited for (the compiler waits
+                // with lgkmcnt(0)), behind its first MFMAs, and land under the remaining six
+    #pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][0], ub[f & 1][c][0], acc[f][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (f < 3) read_u(base, f + 1, ub[(f + 1) & 1]);
+                else if (more) {   // (every weight chunk of tile t has been read: nothing reads stage U after this)
+                    if (NS == 3 && t + 2 < ntiles) wait_younger(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done reading tile t before its stage refills
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (t + NS < ntiles) issue(U);
+                    read_patch(nbase, da, db);
+                    read_u(nbase, 0, ub[0]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int s = 1; s < 4; ++s)
+    #pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+                        acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][c][s], acc[f][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) transform(da, db, V);
+            // nothing pending at the loop back-edge: lets the compiler count its LDS waits inside the body exactly (the reads of
+            // U(t+1, 0) were issued 8 MFMAs ago)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        for (int t = 0; t < ntiles; t += NS) {
+            body(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, t + 1);
+            if (NS == 3 && t + 2 < ntiles) body(std::integral_constant<int, NS == 3 ? 2 : 0>{}, t + 2);
+        }
+    
+}
 
     // column half of the output transform, then the four frequency rows meet in LDS
     __syncthreads();
@@ -1901,8 +2000,13 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             const size_t sh1 = (size_t)2 * (8192 + 7 * 256) * sizeof(float);
             if (g2) hipLaunchKernelGGL((k_conv_wino<2, 1>), nblk, dim3(512), (size_t)3 * (8192 + 12 * 256) * sizeof(float), st, p);
             else if (wcw2 && !a.ups) hipLaunchKernelGGL((k_conv_wino<1, 2>), nblk, dim3(512), sh1, st, p);
-            else if (a.ups) hipLaunchKernelGGL((k_conv_wino<1, 1, true>), nblk, dim3(256), sh1, st, p);
-            else hipLaunchKernelGGL((k_conv_wino<1, 1>), nblk, dim3(256), sh1, st, p);
+            else {
+                static const int priv = getenv("HL_WINO_PRIV") ? atoi(getenv("HL_WINO_PRIV")) : 1;   // private-weight DMA schedule (default)
+                if (priv && a.ups) hipLaunchKernelGGL((k_conv_wino<1, 1, true, true>), nblk, dim3(256), sh1, st, p);
+                else if (priv) hipLaunchKernelGGL((k_conv_wino<1, 1, false, true>), nblk, dim3(256), sh1, st, p);
+                else if (a.ups) hipLaunchKernelGGL((k_conv_wino<1, 1, true>), nblk, dim3(256), sh1, st, p);
+                else hipLaunchKernelGGL((k_conv_wino<1, 1>), nblk, dim3(256), sh1, st, p);
+            }
             if (splits > 1) {
                 long gf = (M * a.Cout + 255) / 256;
                 if (gf > 2048) gf = 2048;
