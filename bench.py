@@ -32,12 +32,14 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 UNET_GFLOP_PER_SAMPLE_STEP = 2015.4
 RENDER_FLOP_PER_RAY = 128 * 79616 + 256 * 132608   # 44 138 496 at 128+128
+FULL_FLOP_PER_POINT = 132608            # density + colour MLP at one sample point
 FINE_FLOP_PER_RAY = 256 * 132608
 COARSE_FLOP_PER_RAY = 128 * 79616
+FINE_FLOP_PER_RAY_TOTAL = FINE_FLOP_PER_RAY + COARSE_FLOP_PER_RAY   # the reference's schedule: 44 138 496 FLOP per ray
 # Fabric-side bytes per launch of the two dominant kernels from the separate rocprofv3 PMC passes (FETCH_SIZE
 # doubled per the gfx950 calibration, WRITE_SIZE as is): profiles/r01_pmc_hbm_traffic.md.  Not measured by this
 # script - PMC collection needs its own runs.
-PMC_TRAFFIC = {"k_conv_avg_launch_b4": 297e6, "k_march_fine_512x512": 4.1e9,
+PMC_TRAFFIC = {"k_conv_avg_launch_b4": 297e6, "k_march_fine_512x512": 4.1e9, "k_march_eval_512x512": 2.6e9,
                "source": "profiles/r01_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
 
 F4 = dict(image_size=256, in_channels=27, out_channels=27, num_channels=192, num_res_blocks=3, num_heads=4,
@@ -197,34 +199,42 @@ def bench_render(args, rank, world, dev):
     barrier(world)
     secs = max_over_ranks(time.perf_counter() - t0, world, dev)
     assert torch.isfinite(imgs[0]).all()
-    # ---- roofline leg: the three stages of one view timed with events on the launch stream ----
+    # ---- roofline leg: the four stages of one view (the default evaluate-once schedule) timed with events on the launch stream ----
     L = _lib.lib()
     R = H * W
+    T32 = (R + 31) // 32 * 32
     ro, rd, nr, fr = [t.contiguous() for t in rays[0]]
     packed, pp = r._packed_mlp(dev), r._packed_planes(planes[0])
-    sig = torch.empty((R, N), device=dev)
-    z_all = torch.empty((R, 2 * N), device=dev)
+    rec_c, rec_n = torch.empty((T32 * N, 4), device=dev), torch.empty((T32 * N, 4), device=dev)
+    z_new = torch.empty(T32 * N, device=dev)
     rgb, acc, dep = torch.empty((R, 3), device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
     bd = tp["world_bounds"][0].contiguous()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     p, s = _lib.ptr, _lib.stream_ptr
     ev[0].record()
-    _lib.check(L.hl_render_coarse(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), None, R, N, p(sig), s()))
+    _lib.check(L.hl_render_eval(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), None, 0, R, N, p(rec_c), s()))
     ev[1].record()
-    _lib.check(L.hl_render_importance(p(sig), p(rd), p(nr), p(fr), None, p(u), R, N, N, p(z_all), s()))
+    _lib.check(L.hl_render_importance_new(p(rec_c), p(rd), p(nr), p(fr), None, p(u), R, N, N, p(z_new), s()))
     ev[2].record()
-    _lib.check(L.hl_render_fine(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), p(z_all), 1, R, 2 * N, 2,
-                                p(rgb), p(acc), p(dep), s()))
+    _lib.check(L.hl_render_eval(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), p(z_new), 1, R, N, p(rec_n), s()))
     ev[3].record()
+    _lib.check(L.hl_render_composite(p(nr), p(fr), None, p(z_new), p(rec_c), p(rec_n), R, N, N, 2, p(rgb), p(acc), p(dep), s()))
+    ev[4].record()
     torch.cuda.synchronize()
-    t_c, t_i, t_f = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
-    achieved = R * FINE_FLOP_PER_RAY / (t_f * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "k_march<true> (fine pass: tri-plane gather + full MLP + compositing), one 512x512 view",
+    t_a, t_i, t_b, t_c = [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
+    eval_flop = R * N * FULL_FLOP_PER_POINT                     # one k_march<eval> launch: full MLP at 128 points per ray
+    achieved = eval_flop / (t_b * 1e-3) / 1e12
+    view_ms = t_a + t_i + t_b + t_c
+    roof = {"bound": "mfma", "kernel": "k_march<true,true> (evaluate pass: tri-plane gather + full MLP at 128 depths per ray, raw records "
+                                       "out), two launches per 512x512 view (coarse depths, importance depths)",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": PMC_TRAFFIC["k_march_fine_512x512"],
-            "traffic_source": PMC_TRAFFIC["source"], "launch_ms": round(t_f, 3),
-            "coarse": {"launch_ms": round(t_c, 3), "achieved": round(R * COARSE_FLOP_PER_RAY / (t_c * 1e-3) / 1e12, 2)},
-            "importance_ms": round(t_i, 3)}
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": PMC_TRAFFIC["k_march_eval_512x512"],
+            "traffic_source": PMC_TRAFFIC["source"], "launch_ms": round(t_b, 3),
+            "view": {"ms": round(view_ms, 3), "eval_coarse_ms": round(t_a, 3), "importance_ms": round(t_i, 3),
+                     "eval_importance_ms": round(t_b, 3), "composite_ms": round(t_c, 3),
+                     "algorithmic_tflops": round(R * FINE_FLOP_PER_RAY_TOTAL / (view_ms * 1e-3) / 1e12, 2),
+                     "note": "algorithmic = the reference's schedule, 128 x 79 616 + 256 x 132 608 FLOP per ray (SURVEY 8(d)); this "
+                             "schedule evaluates every point once (256 x 132 608) with bit-identical images"}}
     return secs, roof, views * R
 
 

@@ -111,7 +111,7 @@ class Renderer(nn.Module):
 
     # ---- reference API ---------------------------------------------------------------------------
     def render(self, tp_input, world_pts, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance=128,
-               white_bkgd=False, *, n_samples=None, u=None):
+               white_bkgd=False, *, n_samples=None, u=None, reevaluate=False):
         """Same contract as the reference's Renderer.render; returns the dict
         {'rgb_map','acc_map','normal_map','depth_map'} of detached tensors.
 
@@ -120,7 +120,10 @@ class Renderer(nn.Module):
         (triplane_sample_layered.py:277).  Extensions (keyword-only): z_vals=None with n_samples
         lets the kernel generate the linspace depths; u (bs*R, n_importance) supplies sample_pdf's
         uniforms, otherwise they are drawn exactly like the reference does - torch.rand on the
-        CPU generator, then copied to the device (renderer.py:545).
+        CPU generator, then copied to the device (renderer.py:545).  reevaluate=True makes the fine pass run
+        the network on all n_samples + n_importance depths like the reference (re-evaluating the coarse
+        points); by default every point is evaluated once and the two sorted halves are merged - the images
+        are bit-identical, the default does 23 % less arithmetic.
         """
         if self.use_canonical_space:
             raise NotImplementedError("use_canonical_space=True (SMPL inverse-LBS) is not built; "
@@ -153,7 +156,8 @@ class Renderer(nn.Module):
         rgb = torch.empty((bs, R, 3), dtype=torch.float32, device=dev)
         acc = torch.empty((bs, R), dtype=torch.float32, device=dev)
         depth = torch.empty((bs, R), dtype=torch.float32, device=dev)
-        flags = _lib.HL_RENDER_NORMALIZE_DEPTH | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0)
+        flags = _lib.HL_RENDER_NORMALIZE_DEPTH | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0) | \
+            (_lib.HL_RENDER_REEVALUATE if reevaluate else 0)
         f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
         for b in range(bs):
             pp = self._packed_planes(tri_planes[b])

@@ -15,6 +15,7 @@ HL_CONV_BF16X3 = 1
 HL_CONV_FP32_DIRECT = 2
 HL_RENDER_WHITE_BKGD = 1
 HL_RENDER_NORMALIZE_DEPTH = 2
+HL_RENDER_REEVALUATE = 4
 
 
 class HipLibraryMissing(RuntimeError):
@@ -55,6 +56,9 @@ SIGNATURES = {
     "hl_render_coarse": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p]),
     "hl_render_importance": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _p, _p]),
     "hl_camera_rays": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "hl_render_eval": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _p, _p]),
+    "hl_render_importance_new": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _p, _p]),
+    "hl_render_composite": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _u, _p, _p, _p, _p]),
     "hl_render_fine": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _u, _p, _p, _p, _p]),
     "hl_unet_packed_bytes": (_sz, [C.POINTER(UNetCfg)]),
     "hl_unet_create": (_i, [C.POINTER(UNetCfg), _i, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),

@@ -213,6 +213,7 @@ struct MarchArgs {
     int S;  // samples marched per ray
     unsigned flags;
     float *sigma_out;            // coarse
+    float4 *vals_out;            // STORE: raw (sigma, r, g, b) per sample, tile-major [R/32][S][32]
     float *rgb, *acc, *depth;    // fine
 };
 
@@ -222,7 +223,9 @@ __device__ __forceinline__ float linspace01(int s, int N) {
     return s < N / 2 ? step * (float)s : 1.0f - step * (float)(N - 1 - s);
 }
 
-template <bool FULL>
+// STORE (with FULL): evaluate the full MLP at every sample and write the raw outputs instead of compositing - the two halves
+// of the sample set (coarse, importance) are evaluated once each and merged by k_composite.
+template <bool FULL, bool STORE = false>
 __global__ __launch_bounds__(512, 2) void k_march(const MarchArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * CHUNK_FLOATS + SMALL_FLOATS];
     constexpr int NCH = FULL ? NCH_FULL : NCH_COARSE;
@@ -411,23 +414,40 @@ __global__ __launch_bounds__(512, 2) void k_march(const MarchArgs a) {
             const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
             HL_CHUNK_ADVANCE(19 % NCH)  // chunk 0 of the next sample
 
+            if constexpr (STORE) {
+                // The two halves of a ray hold the same four values: lanes 0-31 store (sigma, r), lanes 32-63 (g, b), 8 bytes each.
+                // The store is issued through inline asm on purpose: a compiler-visible VMEM write in this loop makes the
+                // waitcnt pass treat the vmcnt queue as mixed read/write and turn the counted waits of the weight prefetch
+                // and the plane gathers into vmcnt(0) (measured: 50 ms instead of 38 ms per 128-sample pass).  Hidden stores
+                // are safe for the compiler's load waits - an outstanding store can only make a counted wait stricter - and
+                // nothing in this kernel reads the records back.
+                if (tile * 32 < a.R) {
+                    const float2 rec = half ? make_float2(cg, cb) : make_float2(sigma_raw, cr);
+                    float *dst = reinterpret_cast<float *>(a.vals_out + (zt_base + 32LL * s)) + 2 * half;
+                    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst), "v"(rec) : "memory");
+                }
+            }
             // ---- alpha compositing  [renderer.py:185-186, 213, 221-229] ----
-            const float dist = (s + 1 < S) ? zn - zc : 1e10f;
-            const float alpha = 1.f - expf(-softplus_exact(sigma_raw) * dist);
-            const float w = alpha * T;
-            acc_w += w;
-            acc_r += (1.f / (1.f + expf(-cr))) * w;
-            acc_g += (1.f / (1.f + expf(-cg))) * w;
-            acc_b += (1.f / (1.f + expf(-cb))) * w;
-            acc_d += w * zc;
-            T *= (1.f - alpha + 1e-7f);
+            // (also in STORE mode, where its result is discarded: dropping it sends the register allocator of this ROCm down a
+            //  path with 6x the spills - 1.2 KB of scratch per lane - and a third of the throughput)
+            {
+                const float dist = (s + 1 < S) ? zn - zc : 1e10f;
+                const float alpha = 1.f - expf(-softplus_exact(sigma_raw) * dist);
+                const float w = alpha * T;
+                acc_w += w;
+                acc_r += (1.f / (1.f + expf(-cr))) * w;
+                acc_g += (1.f / (1.f + expf(-cg))) * w;
+                acc_b += (1.f / (1.f + expf(-cb))) * w;
+                acc_d += w * zc;
+                T *= (1.f - alpha + 1e-7f);
+            }
         }
         zc = zn;
     }
 #undef HL_CHUNK_ADVANCE
 
     if constexpr (FULL) {
-        if (valid && half == 0) {
+        if (valid && half == 0 && (!STORE || a.rgb != nullptr)) {
             if (a.flags & HL_RENDER_WHITE_BKGD) {
                 const float bg = 1.f - acc_w;
                 acc_r += bg; acc_g += bg; acc_b += bg;
@@ -473,6 +493,8 @@ struct ImpArgs {
     long long R;
     int N, Ni;
     float *z_all;
+    int sig_stride;   // floats between consecutive rays' sigma (1: sigma array, 4: .x of the float4 sample records)
+    int new_only;     // 1: write only the n_importance new depths, sorted, [R/32][Ni][32] (k_composite merges them with the coarse ones)
 };
 
 __global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
@@ -494,7 +516,7 @@ __global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
         const float nr = a.near[ray], fr = a.far[ray];
         const float dxx = a.rays_d[ray * 3], dyy = a.rays_d[ray * 3 + 1], dzz = a.rays_d[ray * 3 + 2];
         const float dn = sqrtf(dxx * dxx + dyy * dyy + dzz * dzz);
-        const float *sig = a.sigma + tile * 32 * (long long)N + j;          // [s][32]
+        const float *sig = a.sigma + (tile * 32 * (long long)N + j) * a.sig_stride;   // [s][32] (x sig_stride)
         float *zout = a.z_all + tile * 32 * (long long)tot_n + j;           // [s][32]
 
         auto zval = [&](int i) -> float {
@@ -511,7 +533,7 @@ __global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
                 zi = zval(i);
                 float dist = (i + 1 < N) ? zval(i + 1) - zi : 1e10f;
                 dist = dist * dn;
-                alpha = 1.f - expf(-softplus_exact(sig[32LL * i]) * dist);
+                alpha = 1.f - expf(-softplus_exact(sig[32LL * i * a.sig_stride]) * dist);
                 s_z[i] = zi;
             }
             const float fct = (i < N) ? (1.f - alpha + 1e-10f) : 1.f;
@@ -558,26 +580,112 @@ __global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
             const float t = (uq - c0) / den;
             s_z[N + q] = b0 + t * (b1 - b0);   // slots >= N: never read by the midpoint lookups above
         }
-        for (int q = Ni + lane; q < P - N; q += 64) s_z[N + q] = __builtin_inff();
+        // sort either the union (coarse + new, what the reference's torch.sort of the concatenation yields) or, for the
+        // evaluate-once pipeline, only the new depths (the coarse ones are sorted already; k_composite merges)
+        float *srt = a.new_only ? s_z + N : s_z;
+        const int cnt = a.new_only ? Ni : tot_n;
+        int Ps = 1;
+        while (Ps < cnt) Ps <<= 1;
+        for (int q = (a.new_only ? Ni : tot_n) + lane; q < (a.new_only ? Ps : P); q += 64) srt[q] = __builtin_inff();
         __syncthreads();
-        // bitonic sort of P values
-        for (int k = 2; k <= P; k <<= 1) {
+        for (int k = 2; k <= Ps; k <<= 1) {
             for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                for (int e = lane; e < P / 2; e += 64) {
+                for (int e = lane; e < Ps / 2; e += 64) {
                     const int pos = 2 * jj * (e / jj) + (e % jj), par = pos + jj;
                     const bool up = (pos & k) == 0;
-                    const float x = s_z[pos], y = s_z[par];
-                    if ((x > y) == up) { s_z[pos] = y; s_z[par] = x; }
+                    const float x = srt[pos], y = srt[par];
+                    if ((x > y) == up) { srt[pos] = y; srt[par] = x; }
                 }
                 __syncthreads();
             }
         }
-        for (int i = lane; i < tot_n; i += 64) zout[32LL * i] = s_z[i];
+        if (a.new_only) {
+            float *zn_out = a.z_all + tile * 32 * (long long)Ni + j;
+            for (int i = lane; i < Ni; i += 64) zn_out[32LL * i] = srt[i];
+        } else {
+            for (int i = lane; i < tot_n; i += 64) zout[32LL * i] = s_z[i];
+        }
         __syncthreads();
     }
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// merge + alpha compositing of the evaluate-once pipeline: one thread per ray walks its two sorted depth lists (coarse,
+// importance) and composites the stored raw MLP outputs in merged order - the arithmetic of k_march<true>'s compositing,
+// on the values k_march<true, true> stored.  [renderer.py:185-186, 213, 221-229, 252-253]
+// ---------------------------------------------------------------------------------------------
+struct CompArgs {
+    const float *near, *far;
+    const float *zc;        // coarse depths: caller rows (R, N) or null -> linspace
+    const float *zn;        // new depths, sorted, tile-major [R/32][Ni][32]
+    const float4 *vc, *vn;  // raw (sigma, r, g, b), tile-major [R/32][N][32] and [R/32][Ni][32]
+    long long R;
+    int N, Ni;
+    unsigned flags;
+    float *rgb, *acc, *depth;
+};
+
+__global__ __launch_bounds__(256) void k_composite(const CompArgs a) {
+    const long long ray = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (ray >= a.R) return;
+    const long long tile = ray >> 5;
+    const int r = (int)(ray & 31);
+    const int N = a.N, Ni = a.Ni, S = N + Ni;
+    const float nr = a.near[ray], fr = a.far[ray];
+    const float4 *vc = a.vc + tile * 32 * (long long)N + r, *vn = a.vn + tile * 32 * (long long)Ni + r;
+    const float *zn = a.zn + tile * 32 * (long long)Ni + r;
+    auto zcoarse = [&](int i) -> float {
+        if (a.zc) return a.zc[ray * N + i];
+        const float t = linspace01(i, N);
+        return nr * (1.f - t) + fr * t;
+    };
+    const float inf = __builtin_inff();
+    int ia = 0, ib = 0;
+    float za = zcoarse(0), zb = zn[0];
+    // current element
+    bool fromA = za <= zb;
+    float zcur = fromA ? za : zb;
+    float4 vcur = fromA ? vc[0] : vn[0];
+    if (fromA) { ++ia; za = ia < N ? zcoarse(ia) : inf; } else { ++ib; zb = ib < Ni ? zn[32LL * ib] : inf; }
+    float T = 1.f, acc_w = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f;
+    for (int s = 0; s < S; ++s) {
+        float znext = 0.f;
+        float4 vnext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s + 1 < S) {
+            const bool nA = za <= zb;
+            znext = nA ? za : zb;
+            vnext = nA ? vc[32LL * ia] : vn[32LL * ib];
+            if (nA) { ++ia; za = ia < N ? zcoarse(ia) : inf; } else { ++ib; zb = ib < Ni ? zn[32LL * ib] : inf; }
+        }
+        const float dist = (s + 1 < S) ? znext - zcur : 1e10f;
+        const float alpha = 1.f - expf(-softplus_exact(vcur.x) * dist);
+        const float w = alpha * T;
+        acc_w += w;
+        acc_r += (1.f / (1.f + expf(-vcur.y))) * w;
+        acc_g += (1.f / (1.f + expf(-vcur.z))) * w;
+        acc_b += (1.f / (1.f + expf(-vcur.w))) * w;
+        acc_d += w * zcur;
+        T *= (1.f - alpha + 1e-7f);
+        zcur = znext;
+        vcur = vnext;
+    }
+    if (a.flags & HL_RENDER_WHITE_BKGD) {
+        const float bg = 1.f - acc_w;
+        acc_r += bg; acc_g += bg; acc_b += bg;
+    }
+    if (a.flags & HL_RENDER_NORMALIZE_DEPTH) {
+        acc_d = (acc_d - nr) / (fr - nr + 1e-5f);
+        acc_d = acc_d > 1.f ? 1.f : acc_d;
+        acc_d = acc_d < 0.f ? 0.f : acc_d;
+    }
+    a.rgb[ray * 3 + 0] = acc_r;
+    a.rgb[ray * 3 + 1] = acc_g;
+    a.rgb[ray * 3 + 2] = acc_b;
+    a.acc[ray] = acc_w;
+    a.depth[ray] = acc_d;
+}
 
 // ---------------------------------------------------------------------------------------------
 // per-view ray generation   [SynBodyView_datasets.py:316-329 get_rays, :370-403 get_near_far, :422-433]
@@ -676,8 +784,9 @@ static inline int64_t tiles32(int64_t n_rays) { return (n_rays + 31) / 32; }
 
 size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance) {
     if (n_rays <= 0 || n_importance <= 0) return 256;
-    // tile-major [ceil(R/32)][samples][32]: sigma (n_samples) then z_all (n_samples + n_importance)
-    return (size_t)tiles32(n_rays) * 32 * (size_t)(n_samples + n_samples + n_importance) * sizeof(float) + 256;
+    // tile-major [ceil(R/32)][samples][32].  Evaluate-once pipeline: raw sample records (float4) of the n_samples coarse and
+    // the n_importance new points + the sorted new depths; HL_RENDER_REEVALUATE: sigma (n_samples) + z_all (both) - smaller
+    return (size_t)tiles32(n_rays) * 32 * ((size_t)(n_samples + n_importance) * 4 + n_importance) * sizeof(float) + 256;
 }
 
 static int fill_march(MarchArgs &a, const void *mlp, const void *planes, int H, int W, const float *bounds,
@@ -712,7 +821,7 @@ int hl_render_importance(const float *sigma, const float *rays_d, const float *n
     HL_REQUIRE(n_rays > 0 && n_samples >= 3 && n_importance >= 1, "hl_render_importance: bad sizes");
     if (n_samples > IMP_MAX_N || n_importance > IMP_MAX_N)
         return hl::fail(HL_ERR_UNSUPPORTED, "hl_render_importance: n_samples/n_importance > %d", IMP_MAX_N);
-    ImpArgs a{sigma, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_all_out};
+    ImpArgs a{sigma, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_all_out, 1, 0};
     hipLaunchKernelGGL(k_importance, dim3((unsigned)tiles32(n_rays)), dim3(256), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_importance");
 }
@@ -740,6 +849,40 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
                             n_total_samples, flags, rgb, acc, depth, stream);
 }
 
+int hl_render_eval(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
+                   const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
+                   int n_samples, float *records_out, void *stream) {
+    HL_REQUIRE(n_rays > 0 && n_samples >= 1 && records_out, "hl_render_eval: bad argument");
+    MarchArgs a{};
+    int rcode = fill_march(a, mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far);
+    if (rcode) return rcode;
+    a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
+    hipLaunchKernelGGL((k_march<true, true>), dim3((unsigned)((n_rays + 255) / 256)), dim3(512), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_march<eval>");
+}
+
+int hl_render_importance_new(const float *records, const float *rays_d, const float *near, const float *far, const float *z_vals,
+                             const float *u, int64_t n_rays, int n_samples, int n_importance, float *z_new_out, void *stream) {
+    HL_REQUIRE(records && rays_d && near && far && u && z_new_out, "hl_render_importance_new: null argument");
+    HL_REQUIRE(n_rays > 0 && n_samples >= 3 && n_importance >= 1, "hl_render_importance_new: bad sizes");
+    if (n_samples > IMP_MAX_N || n_importance > IMP_MAX_N)
+        return hl::fail(HL_ERR_UNSUPPORTED, "hl_render_importance_new: n_samples/n_importance > %d", IMP_MAX_N);
+    ImpArgs a{records, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_new_out, 4, 1};
+    hipLaunchKernelGGL(k_importance, dim3((unsigned)tiles32(n_rays)), dim3(256), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_importance<new>");
+}
+
+int hl_render_composite(const float *near, const float *far, const float *z_vals, const float *z_new, const float *rec_coarse,
+                        const float *rec_new, int64_t n_rays, int n_samples, int n_importance, unsigned flags, float *rgb,
+                        float *acc, float *depth, void *stream) {
+    HL_REQUIRE(near && far && z_new && rec_coarse && rec_new && rgb && acc && depth, "hl_render_composite: null argument");
+    HL_REQUIRE(n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_composite: bad sizes");
+    CompArgs c{near, far, z_vals, z_new, (const float4 *)rec_coarse, (const float4 *)rec_new, n_rays, n_samples, n_importance,
+               flags, rgb, acc, depth};
+    hipLaunchKernelGGL(k_composite, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c);
+    return hl::check_launch("k_composite");
+}
+
 int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
                    const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z_vals,
                    const float *u, int64_t n_rays, int n_samples, int n_importance, unsigned flags, float *rgb,
@@ -749,6 +892,25 @@ int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int
         HL_REQUIRE(n_importance == n_samples, "render: n_importance (%d) must equal n_samples (%d)", n_importance,
                    n_samples);
         HL_REQUIRE(u && workspace, "render: u and workspace are required when n_importance > 0");
+        if (!(flags & HL_RENDER_REEVALUATE)) {
+            // Evaluate-once pipeline.  The reference runs the network on all n_samples + n_importance sorted depths in the fine pass
+            // (renderer.py:252-256), i.e. re-evaluates the coarse points it already has densities for; the MLP output at a point
+            // depends only on (ray, depth), so here every point is evaluated exactly once with the full MLP - coarse points in pass
+            // A, the new ones in pass B - and k_composite merges the two sorted lists: same values, same compositing order,
+            // bit-identical images, 23 % fewer FLOPs (256 x 132 608 instead of 128 x 79 616 + 256 x 132 608 per ray).
+            const size_t T32 = (size_t)tiles32(n_rays) * 32;
+            float *vc = (float *)workspace, *vn = vc + T32 * n_samples * 4;
+            float *zn = vn + T32 * n_importance * 4;
+            int rcode = hl_render_eval(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, 0, n_rays, n_samples,
+                                       vc, stream);
+            if (rcode) return rcode;
+            rcode = hl_render_importance_new(vc, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, zn, stream);
+            if (rcode) return rcode;
+            rcode = hl_render_eval(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, zn, 1, n_rays, n_importance, vn,
+                                   stream);
+            if (rcode) return rcode;
+            return hl_render_composite(near, far, z_vals, zn, vc, vn, n_rays, n_samples, n_importance, flags, rgb, acc, depth, stream);
+        }
         float *sigma = (float *)workspace;
         float *z_all = sigma + (size_t)tiles32(n_rays) * 32 * n_samples;
         int rcode = hl_render_coarse(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, n_rays,

@@ -66,6 +66,8 @@ int hl_planes_pack(const float *planes, int H, int W, void *packed, void *stream
 
 #define HL_RENDER_WHITE_BKGD 1u      /* renderer.py:224-225 (per-ray intent)            */
 #define HL_RENDER_NORMALIZE_DEPTH 2u /* renderer.py:272-274 (human_diffusion twin only) */
+#define HL_RENDER_REEVALUATE 4u      /* hl_render_rays: run the fine pass over all n_samples+n_importance depths like the reference
+                                        (re-evaluating the coarse points) instead of evaluating every point once; same image */
 
 size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
 
@@ -80,10 +82,11 @@ size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance
  *   u        (R,n_importance) uniform draws of sample_pdf (renderer.py:545); required
  *            when n_importance > 0 (n_importance must then equal n_samples, renderer.py:250)
  *   rgb (R,3)  acc (R)  depth (R)   outputs; normal_map == rgb_map in the reference
- *   workspace  hl_render_workspace_bytes(); afterwards holds, tile-major, sigma_coarse
- *            [ceil(R/32)][n_samples][32] followed by the merged depths z_all
- *            [ceil(R/32)][n_samples+n_importance][32] (ray r = tile r/32, lane r%32): one 128-byte
- *            line per wave and sample instead of 4-byte accesses at a row stride
+ *   workspace  hl_render_workspace_bytes(); scratch, tile-major [ceil(R/32)][sample][32 rays] (ray r = tile r/32, lane r%32: one
+ *            line per wave and sample instead of 4-byte accesses at a row stride): the raw (sigma, r, g, b) records of the
+ *            n_samples coarse and the n_importance new points and the sorted new depths - every point is evaluated ONCE with the
+ *            full MLP and a merge kernel composites them in depth order (the reference re-evaluates the coarse points in its
+ *            fine pass; the outputs are bit-identical, HL_RENDER_REEVALUATE selects that schedule)
  */
 int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
                    const float *rays_o, const float *rays_d, const float *near, const float *far,
@@ -99,6 +102,21 @@ int hl_render_coarse(const void *mlp_packed, const void *planes_packed, int H, i
 int hl_render_importance(const float *sigma, const float *rays_d, const float *near, const float *far,
                          const float *z_vals, const float *u, int64_t n_rays, int n_samples, int n_importance,
                          float *z_all_out, void *stream);
+/* The stages of the default (evaluate-once) schedule of hl_render_rays.  A "record" is the raw network output of one sample
+ * point, float[4] = (sigma, r, g, b) before softplus / sigmoid; record and depth arrays are tile-major [ceil(R/32)][samples][32].
+ *   hl_render_eval            full MLP at every given depth (z: NULL -> linspace, caller rows (R,S) with z_tiled = 0, or tile-major
+ *                             with z_tiled = 1) -> records_out
+ *   hl_render_importance_new  sample_pdf on the coarse records' densities (renderer.py:158-170, 533-563) -> the n_importance NEW
+ *                             depths only, sorted (the reference sorts the union, :252-253; hl_render_composite merges instead)
+ *   hl_render_composite       merge the coarse and the new depths and alpha-composite their records in depth order (:172-231) */
+int hl_render_eval(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
+                   const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
+                   int n_samples, float *records_out, void *stream);
+int hl_render_importance_new(const float *records, const float *rays_d, const float *near, const float *far, const float *z_vals,
+                             const float *u, int64_t n_rays, int n_samples, int n_importance, float *z_new_out, void *stream);
+int hl_render_composite(const float *near, const float *far, const float *z_vals /* coarse rows or NULL */, const float *z_new,
+                        const float *rec_coarse, const float *rec_new, int64_t n_rays, int n_samples, int n_importance,
+                        unsigned flags, float *rgb, float *acc, float *depth, void *stream);
 int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
                    const float *rays_o, const float *rays_d, const float *near, const float *far,
                    const float *z_all /* or NULL -> linspace */, int z_tiled, int64_t n_rays, int n_total_samples,
