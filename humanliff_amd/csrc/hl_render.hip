@@ -252,7 +252,14 @@ __global__ __launch_bounds__(512, 2) void k_march(const MarchArgs a) {
     ldsv[512 + tid] = gw[512 + tid];
     ldsv[1024 + tid] = gw[1024 + tid];
     ldsv[1024 + 512 + tid] = gw[1024 + 512 + tid];
-    f32x4 st0 = gw[2048 + tid], st1 = gw[2048 + 512 + tid];
+    // the chunk prefetches go through a buffer descriptor: per-lane offset tid*16 + a compile-time scalar chunk offset, instead of
+    // 17 different 64-bit per-lane addresses (which the allocator spilled and reloaded from scratch inside the sample loop)
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)a.packed, (short)0, PACKED_FLOATS * 4, 0x00020000);
+    const int wv = tid * 16;
+    auto ldw = [&](int f4_index) -> f32x4 {   // float4 index of lane 0; this lane reads index + tid
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wv, f4_index * 16, 0));
+    };
+    f32x4 st0 = ldw(2048), st1 = ldw(2048 + 512);
     int cur = 0;  // float4 offset of the slot holding the chunk being consumed
 
     const float ox = a.rays_o[rc * 3 + 0], oy = a.rays_o[rc * 3 + 1], oz = a.rays_o[rc * 3 + 2];
@@ -300,8 +307,8 @@ __global__ __launch_bounds__(512, 2) void k_march(const MarchArgs a) {
     cur ^= 1024;                                                              \
     ldsv[(cur ^ 1024) + tid] = st0;                                           \
     ldsv[(cur ^ 1024) + 512 + tid] = st1;                                     \
-    st0 = gw[(cnext2) * 1024 + tid];                                          \
-    st1 = gw[(cnext2) * 1024 + 512 + tid];
+    st0 = ldw((cnext2) * 1024);                                               \
+    st1 = ldw((cnext2) * 1024 + 512);
 
     // Ring invariant while chunk g is consumed: slot `cur` holds g, the other slot holds (or is
     // being filled with) g+1, the staging registers hold (or are receiving) g+2.
