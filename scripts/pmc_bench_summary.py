@@ -11,9 +11,9 @@ FAMILIES = [("conv (k_conv_wino / k_conv_dma / k_conv + k_gn_apply + k_splitk_fi
             ("k_splitk_finish", r"k_splitk_finish"),
             ("GroupNorm statistics (k_gn_partial / k_gn_small / k_gn_coef)", r"k_gn_partial|k_gn_small|k_gn_coef"),
             ("attention", r"k_attention"),
-            ("k_march<true, true> (evaluate pass, 2 per view)", r"k_march<true, true>"),
-            ("k_march<true, false> (fine pass of the reevaluate schedule)", r"k_march<true, false>|k_march<true>"),
-            ("k_march<false, false> (coarse pass of the reevaluate schedule)", r"k_march<false, false>|k_march<false>"),
+            ("k_march<true, true> (evaluate pass, 2 per view)", r"k_march<true, true"),
+            ("k_march<true, false> (fine pass of the reevaluate schedule)", r"k_march<true, false"),
+            ("k_march<false, false> (coarse pass of the reevaluate schedule)", r"k_march<false, false"),
             ("k_composite", r"k_composite"),
             ("k_importance", r"k_importance")]
 
