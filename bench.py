@@ -239,7 +239,7 @@ def bench_render(args, rank, world, dev):
 
 
 def cpu_baseline_unet(sd, threads):
-    """Oracle UNet forward + DDPM update on the host, B=1: 1 warm-up + 1 timed step (a B=4 1000-step run
+    """Oracle UNet forward + DDPM update on the host, B=1: 1 warm-up + 3 timed steps, ~10 s (a B=4 1000-step run
     would take hours)."""
     from oracle import diffusion_oracle as do
     from oracle import unet_oracle as uo
@@ -249,7 +249,7 @@ def cpu_baseline_unet(sd, threads):
     x = torch.randn((1, 27, 256, 256), generator=g)
     xc = torch.zeros_like(x)
     y = torch.zeros((1,), dtype=torch.int64)
-    n_timed = 1
+    n_timed = 3
     with torch.no_grad():
         for i in range(1 + n_timed):
             if i == 1:
@@ -259,10 +259,10 @@ def cpu_baseline_unet(sd, threads):
             x, _ = do.p_sample_step(s, x, t, eps, torch.randn(x.shape, generator=g))
     dt = time.perf_counter() - t0
     return {"value": round(n_timed / dt, 4), "unit": "denoise-steps/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (PyTorch-CPU fp32 restatement) p_sample, production UNet, batch 1, {n_timed} timed step after 1 warm-up"}
+            "sample": f"oracle (PyTorch-CPU fp32 restatement) p_sample, production UNet, batch 1, {n_timed} timed steps after 1 warm-up"}
 
 
-def cpu_baseline_render(threads, n_rays=2048):
+def cpu_baseline_render(threads, n_rays=16384):
     from humanliff_amd import synthetic as syn
     from oracle import render_oracle as ro
     torch.set_num_threads(threads)
