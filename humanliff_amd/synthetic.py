@@ -140,3 +140,60 @@ def near_far_from_bounds(bounds, rays_o, rays_d, pad=0.01):
     near = np.where(hit, np.maximum(tmin, 0.0), 0.0)
     far = np.where(hit, tmax, 1.0)
     return near, far
+
+
+# ---- synthetic body model for the canonical-space deformation --------------------------------------
+SMPL_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+
+
+def smpl_like_model(n_vertices=6890, seed=21):
+    """A body model with the STRUCTURE of SMPL_NEUTRAL (the keys SMPL_to_tensor keeps, NeRF/renderer.py:343-352) and seeded
+    random content: the licensed asset is not available here.  24 joints on the SMPL kinematic tree."""
+    g = _gen(seed)
+    V, J = n_vertices, 24
+    box = torch.tensor([0.9, 1.7, 0.4])
+    v_template = (torch.rand((V, 3), generator=g) - 0.5) * box
+    logits = torch.randn((J, V), generator=g) * 3.0
+    J_regressor = torch.softmax(logits, dim=1)
+    w = torch.randn((V, J), generator=g) * 2.5
+    top = torch.topk(w, 4, dim=1)
+    weights = torch.zeros((V, J)).scatter_(1, top.indices, torch.softmax(top.values, dim=1))
+    return {
+        "v_template": v_template,
+        "shapedirs": torch.randn((V, 3, 10), generator=g) * 0.01,
+        "posedirs": torch.randn((V, 3, 207), generator=g) * 0.004,
+        "J_regressor": J_regressor,
+        "kintree_table": torch.tensor([SMPL_PARENTS, list(range(J))], dtype=torch.long),
+        "weights": weights,
+        "f": torch.zeros((1, 3), dtype=torch.long),
+    }
+
+
+def _rodrigues1(v):
+    a = torch.linalg.norm(v) + 1e-12
+    k = v / a
+    K = torch.tensor([[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]])
+    return torch.eye(3) + torch.sin(a) * K + (1 - torch.cos(a)) * (K @ K)
+
+
+def smpl_like_pose(n_vertices, model, seed=31, n_points=1024):
+    """tp_input pieces for one posed subject (what SynBodyView_datasets.py puts in 'params', 't_params', 'vertices',
+    't_world_bounds', :300-306) plus query points near the body and unit view directions, all float32, batch 1."""
+    g = _gen(seed)
+    V = n_vertices
+    poses = torch.randn((1, 72), generator=g) * 0.25
+    shapes = torch.randn((1, 10), generator=g) * 0.5
+    Rw = _rodrigues1(torch.randn(3, generator=g) * 0.4)[None]
+    Th = torch.randn((1, 1, 3), generator=g) * 0.2
+    verts_smpl = model["v_template"][None] + torch.randn((1, V, 3), generator=g) * 0.01
+    vertices = torch.matmul(verts_smpl, Rw.transpose(1, 2)) + Th          # so that (vertices - Th) @ R is verts_smpl
+    big = torch.zeros((1, 72))
+    big[0, 5] = 0.5
+    big[0, 8] = -0.5
+    t_params = {"poses": big, "shapes": torch.zeros((1, 10)), "R": torch.eye(3)[None], "Th": torch.zeros((1, 1, 3))}
+    idx = torch.randint(0, V, (n_points,), generator=g)
+    pts = vertices[:, idx] + torch.randn((1, n_points, 3), generator=g) * 0.03
+    vd = torch.randn((1, n_points, 3), generator=g)
+    vd = vd / torch.linalg.norm(vd, dim=-1, keepdim=True)
+    return {"params": {"poses": poses, "shapes": shapes, "R": Rw, "Th": Th}, "t_params": t_params, "vertices": vertices,
+            "t_world_bounds": torch.tensor([[[-1.0, -1.2, -0.6], [1.0, 1.2, 0.6]]]), "pts": pts, "viewdirs": vd}
