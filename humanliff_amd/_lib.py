@@ -55,6 +55,7 @@ SIGNATURES = {
     "hl_render_rays": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _u, _p, _p, _p, _p, _p]),
     "hl_render_coarse": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p]),
     "hl_render_importance": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _p, _p]),
+    "hl_deform_points": (_i, [_p, _p, _p, _p, _p, _p, _i, _i64, _p, _p, _p, _p]),
     "hl_camera_rays": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
     "hl_render_eval": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _p, _p]),
     "hl_render_importance_new": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _p, _p]),

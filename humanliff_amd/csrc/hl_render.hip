@@ -698,6 +698,87 @@ __global__ __launch_bounds__(256) void k_composite(const CompArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// canonical-space deformation   [renderer.py:52-132 deform_target2c / deform_target2c_op]
+// Everything the reference does after the 1-NN lookup depends on the query only through the id of the nearest body vertex
+// (blend weights, both blended joint transforms, the three blend-shape offsets), so the host mirror folds it into ONE table
+// row per vertex and this kernel is: world -> SMPL space, brute-force nearest vertex (vertices staged through LDS as float4,
+// squared distance as ((dx*dx + dy*dy) + dz*dz), first index wins ties), then the row's operations in the reference's order:
+//     can = Rinv (q - t);  can -= pose_off;  can -= shape_off;  can += pose_off_big;  can = Rbig can + tbig
+//     dir = Rbig (Rinv dir_smpl)
+// Table row (36 floats): t[3] Rinv[9] pose_off[3] shape_off[3] pose_off_big[3] Rbig[9] tbig[3] pad[3].
+// ---------------------------------------------------------------------------------------------
+struct DeformArgs {
+    const float *pts, *dirs;      // (P,3) world space; dirs may be null
+    float R[9], Th[3];            // world -> SMPL space: (p - Th) R
+    const float4 *verts;          // (V) SMPL-space body vertices, w unused
+    const float *table;           // (V,36)
+    int V;
+    long long P;
+    float *can_pts, *can_dirs;    // (P,3)
+    int *vid;                     // (P) nearest vertex ids or null
+};
+
+__device__ __forceinline__ void mat3_apply(const float *m, float x, float y, float z, float &ox, float &oy, float &oz) {
+    ox = (m[0] * x + m[1] * y) + m[2] * z;
+    oy = (m[3] * x + m[4] * y) + m[5] * z;
+    oz = (m[6] * x + m[7] * y) + m[8] * z;
+}
+
+constexpr int DEFORM_TILE = 2048;   // vertices per LDS tile (32 KB)
+
+__global__ __launch_bounds__(256) void k_deform_points(const DeformArgs a) {
+    __shared__ float4 sv[DEFORM_TILE];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < a.P;
+    const long long ic = live ? i : a.P - 1;
+    const float wx = a.pts[ic * 3 + 0] - a.Th[0], wy = a.pts[ic * 3 + 1] - a.Th[1], wz = a.pts[ic * 3 + 2] - a.Th[2];
+    // (p - Th) R: row vector times matrix
+    const float qx = (wx * a.R[0] + wy * a.R[3]) + wz * a.R[6];
+    const float qy = (wx * a.R[1] + wy * a.R[4]) + wz * a.R[7];
+    const float qz = (wx * a.R[2] + wy * a.R[5]) + wz * a.R[8];
+    float best = 3.0e38f;
+    int bid = 0;
+    for (int v0 = 0; v0 < a.V; v0 += DEFORM_TILE) {
+        const int n = min(DEFORM_TILE, a.V - v0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += 256) sv[k] = a.verts[v0 + k];
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < n; ++k) {
+            const float4 v = sv[k];                       // same address for the whole wave: LDS broadcast
+            const float dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            if (d < best) { best = d; bid = v0 + k; }
+        }
+    }
+    if (!live) return;
+    const float *row = a.table + (long long)bid * 36;
+    float cx, cy, cz;
+    mat3_apply(row + 3, qx - row[0], qy - row[1], qz - row[2], cx, cy, cz);
+    cx -= row[12]; cy -= row[13]; cz -= row[14];
+    cx -= row[15]; cy -= row[16]; cz -= row[17];
+    cx += row[18]; cy += row[19]; cz += row[20];
+    float ox, oy, oz;
+    mat3_apply(row + 21, cx, cy, cz, ox, oy, oz);
+    a.can_pts[i * 3 + 0] = ox + row[30];
+    a.can_pts[i * 3 + 1] = oy + row[31];
+    a.can_pts[i * 3 + 2] = oz + row[32];
+    if (a.vid) a.vid[i] = bid;
+    if (a.dirs) {
+        const float ex = a.dirs[i * 3 + 0] - a.Th[0], ey = a.dirs[i * 3 + 1] - a.Th[1], ez = a.dirs[i * 3 + 2] - a.Th[2];   // :128
+        const float sx = (ex * a.R[0] + ey * a.R[3]) + ez * a.R[6];
+        const float sy = (ex * a.R[1] + ey * a.R[4]) + ez * a.R[7];
+        const float sz = (ex * a.R[2] + ey * a.R[5]) + ez * a.R[8];
+        float tx, ty, tz;
+        mat3_apply(row + 3, sx, sy, sz, tx, ty, tz);
+        mat3_apply(row + 21, tx, ty, tz, ox, oy, oz);
+        a.can_dirs[i * 3 + 0] = ox;
+        a.can_dirs[i * 3 + 1] = oy;
+        a.can_dirs[i * 3 + 2] = oz;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-view ray generation   [SynBodyView_datasets.py:316-329 get_rays, :370-403 get_near_far, :422-433]
 // One thread per pixel, float64 like the reference's numpy (K, R, T are float64 there), rounded to float32 exactly
 // where sample_ray_batch casts.  Term order follows oracle/camera_oracle.py (no FMA contraction in this build).
@@ -955,6 +1036,22 @@ int hl_camera_rays(const double *h_Kinv, const double *h_R, const double *h_T, c
     const long long n = (long long)H * W;
     hipLaunchKernelGGL(k_camera_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_camera_rays");
+}
+
+int hl_deform_points(const float *pts, const float *dirs, const float *h_R, const float *h_Th, const float *verts_smpl4,
+                     const float *table, int n_vertices, int64_t n_points, float *can_pts, float *can_dirs, int *vertex_ids,
+                     void *stream) {
+    HL_REQUIRE(pts && h_R && h_Th && verts_smpl4 && table && can_pts, "hl_deform_points: null argument");
+    HL_REQUIRE(!dirs || can_dirs, "hl_deform_points: can_dirs is required when dirs are given");
+    HL_REQUIRE(n_vertices > 0 && n_points > 0, "hl_deform_points: bad sizes");
+    DeformArgs a{};
+    a.pts = pts; a.dirs = dirs;
+    for (int i = 0; i < 9; ++i) a.R[i] = h_R[i];
+    for (int i = 0; i < 3; ++i) a.Th[i] = h_Th[i];
+    a.verts = (const float4 *)verts_smpl4; a.table = table; a.V = n_vertices; a.P = n_points;
+    a.can_pts = can_pts; a.can_dirs = can_dirs; a.vid = vertex_ids;
+    hipLaunchKernelGGL(k_deform_points, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_deform_points");
 }
 
 }  // extern "C"

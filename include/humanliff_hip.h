@@ -132,6 +132,15 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
 int hl_camera_rays(const double *h_Kinv, const double *h_R, const double *h_T, const double *h_bounds, int H, int W,
                    float *rays_o, float *rays_d, float *near, float *far, unsigned char *mask_at_box, void *stream);
 
+/* Canonical-space deformation of query points.  Replaces Renderer.deform_target2c /
+ * deform_target2c_op (human_diffusion/NeRF/renderer.py:52-132, recon_NeRF/lib/renderer.py:60-140) including the external
+ * pytorch3d knn_points(K=1): world -> SMPL space with h_R (3,3) / h_Th (3) (host float32), brute-force nearest body vertex among
+ * verts_smpl4 (V,4: xyz of (vertices - Th) R, w ignored), then the per-vertex row of `table` (V,36: t[3] Rinv[9] pose_off[3]
+ * shape_off[3] pose_off_big[3] Rbig[9] tbig[3] pad[3], built by humanliff_amd.NeRF.deform.deform_tables) applied in the
+ * reference's order.  pts / dirs (P,3) device, dirs may be NULL; outputs can_pts, can_dirs (P,3), vertex_ids (P) or NULL. */
+int hl_deform_points(const float *pts, const float *dirs, const float *h_R, const float *h_Th, const float *verts_smpl4,
+                     const float *table, int n_vertices, int64_t n_points, float *can_pts, float *can_dirs, int *vertex_ids,
+                     void *stream);
 
 /* ------------------------------------------------------------------------
  * Path 1 — tri-plane UNet denoiser + Gaussian-diffusion sampler update

@@ -290,3 +290,40 @@ def test_evaluate_once_pipeline_is_bit_identical_to_reevaluation(dev, R, N, whit
     for k in ("rgb_map", "acc_map", "depth_map"):
         assert torch.equal(a[k], b[k]), k
     assert float(a["acc_map"].max()) > 0.05      # not a vacuous all-empty render
+
+
+# ---- canonical-space deformation ----------------------------------------------------------------
+@pytest.mark.parametrize("name", ["small", "mid"])
+def test_deform_matches_reference_golden(name, dev):
+    """hl_deform_points (1-NN + folded inverse / forward LBS) against the reference's deform_target2c on the synthetic body."""
+    import numpy as np
+    from humanliff_amd import synthetic as syn
+    from humanliff_amd.NeRF.deform import deform_target2c
+    g = np.load(os.path.join(GOLDEN, "deform.npz"))
+    V, P, seed = [int(v) for v in g[f"{name}_VP"]]
+    model = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in syn.smpl_like_model(V, seed).items()}
+    pose = syn.smpl_like_pose(V, model={k: v.cpu() if torch.is_tensor(v) else v for k, v in model.items()}, seed=seed + 10, n_points=P)
+    can, cd, box = deform_target2c(model, pose, pose["pts"].to(dev), pose["viewdirs"].to(dev))
+    assert np.abs(can.cpu().numpy() - g[f"{name}_can_pts"]).max() < 2e-5      # float32 chains of ~30 ops on O(1) values
+    assert np.abs(cd.cpu().numpy() - g[f"{name}_can_dirs"]).max() < 2e-5
+    assert torch.equal(box, pose["t_world_bounds"])
+    can2, none, _ = deform_target2c(model, pose, pose["pts"].to(dev))
+    assert none is None and torch.equal(can, can2)
+
+
+def test_deform_fullsize_matches_oracle(dev):
+    """6 890 vertices (SMPL size), 200 000 query points: nearest-vertex ids equal the oracle's brute force, points within 2e-5."""
+    from oracle import deform_oracle as do
+    from humanliff_amd import synthetic as syn
+    from humanliff_amd.NeRF.deform import deform_target2c
+    V, P = 6890, 200000
+    cpu_model = syn.smpl_like_model(V, 5)
+    pose = syn.smpl_like_pose(V, cpu_model, 15, n_points=P)
+    model = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in cpu_model.items()}
+    can, cd, _, ids = deform_target2c(model, pose, pose["pts"].to(dev), pose["viewdirs"].to(dev), return_ids=True)
+    sub = slice(0, 20000)
+    ocan, ocd, oid = do.deform_target2c(cpu_model, pose, pose["pts"][0, sub], pose["viewdirs"][0, sub])
+    same = ids.cpu()[sub].long() == oid
+    assert same.float().mean() > 0.9995        # a near-tie between two vertices may resolve differently in float32
+    assert (can.cpu()[0, sub][same] - ocan[same]).abs().max() < 2e-5
+    assert (cd.cpu()[0, sub][same] - ocd[same]).abs().max() < 2e-5
