@@ -57,8 +57,11 @@ class Renderer(nn.Module):
         self.alpha_linear = nn.Linear(d_hidden, 1)
         self.views_linear = nn.Linear(d_hidden + 27, d_hidden // 2)
         self.rgb_linear = nn.Linear(d_hidden // 2, 3)
-        # The reference also loads SMPL(-X) assets here (renderer.py:41-50); they are only used by the
-        # canonical-space deformation, which is outside this build's scope.
+        # The reference loads the SMPL(-X) asset here (renderer.py:41-50: assets/SMPL_NEUTRAL.pkl -> SMPL_to_tensor); it is only
+        # used by the canonical-space deformation.  The asset is licensed data and not shipped: assign the dict of tensors
+        # (keys v_template, shapedirs, posedirs, J_regressor, kintree_table, weights) to `SMPL_NEUTRAL` before rendering with
+        # use_canonical_space=True.
+        self.SMPL_NEUTRAL = None
         self._packed = None
         self._packed_key = None
         self._planes_cache = {}
@@ -126,8 +129,8 @@ class Renderer(nn.Module):
         are bit-identical, the default does 23 % less arithmetic.
         """
         if self.use_canonical_space:
-            raise NotImplementedError("use_canonical_space=True (SMPL inverse-LBS) is not built; "
-                                      "see DESIGN.md 'out of scope'")
+            return self._render_canonical(tp_input, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd,
+                                          n_samples, u)
         if self.triplane_ch != 27:
             raise NotImplementedError("the HIP ray-march kernel is specialised for triplane_ch=27")
         assert tri_planes.dim() == 5 and tri_planes.shape[1] == 3 and tri_planes.shape[2] == 9, \
@@ -172,6 +175,49 @@ class Renderer(nn.Module):
         # normal_map aliases rgb_map in the reference (renderer.py:228)
         return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
 
+
+    # ---- rendering through the canonical-space deformation -------------------------
+    def _render_canonical(self, tp_input, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd, n_samples, u):
+        """use_canonical_space=True (renderer.py:114-132, 192-201, 242-246): every sample point and its unit ray direction go through
+        deform_target2c (1-NN body vertex, inverse LBS, blend-shape offsets, forward LBS into the big pose) before the tri-plane
+        lookup in tp_input['t_world_bounds'].  One posed subject per call (batch 1)."""
+        from .deform import deform_tables
+        if self.SMPL_NEUTRAL is None:
+            raise RuntimeError("use_canonical_space=True needs the body model: set renderer.SMPL_NEUTRAL to the SMPL_to_tensor dict")
+        if self.triplane_ch != 27:
+            raise NotImplementedError("the HIP ray-march kernel is specialised for triplane_ch=27")
+        assert tri_planes.dim() == 5 and tri_planes.shape[:3] == (1, 3, 9), "tri_planes must be (1, 3, 9, H, W)"
+        _, _, _, H, W = tri_planes.shape
+        dev = tri_planes.device
+        rays_o, rays_d = rays_o.reshape(1, -1, 3), rays_d.reshape(1, -1, 3)
+        R = rays_o.shape[1]
+        near, far = near.reshape(1, R), far.reshape(1, R)
+        if z_vals is not None:
+            n_samples = z_vals.shape[2]
+        assert n_samples is not None and n_importance == n_samples, \
+            "the reference reshapes coarse densities to n_importance (renderer.py:250): counts must match"
+        if u is None:
+            u = torch.rand([R, n_importance]).to(dev)
+        verts4, table, Rh, Th = deform_tables(self.SMPL_NEUTRAL, tp_input['params'], tp_input['t_params'],
+                                              tp_input['vertices'].to(dev))
+        L = _lib.lib()
+        packed, pp = self._packed_mlp(dev), self._packed_planes(tri_planes[0])
+        ws = self._workspace(L.hl_render_canonical_workspace_bytes(R, n_samples, n_importance), dev)
+        rgb = torch.empty((1, R, 3), dtype=torch.float32, device=dev)
+        acc = torch.empty((1, R), dtype=torch.float32, device=dev)
+        depth = torch.empty((1, R), dtype=torch.float32, device=dev)
+        flags = _lib.HL_RENDER_NORMALIZE_DEPTH | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0)
+        f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+        ro, rd, nr, fr = f32(rays_o[0]), f32(rays_d[0]), f32(near[0]), f32(far[0])
+        bd = f32(tp_input['t_world_bounds'].reshape(-1, 2, 3)[0].to(dev))
+        zb = f32(z_vals[0]) if z_vals is not None else None
+        ub = f32(u.reshape(R, n_importance))
+        _lib.check(L.hl_render_rays_canonical(
+            _lib.ptr(packed), _lib.ptr(pp), H, W, _lib.ptr(bd), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(nr), _lib.ptr(fr), _lib.ptr(zb),
+            _lib.ptr(ub), R, n_samples, n_importance, flags, Rh.ctypes.data, Th.ctypes.data, _lib.ptr(verts4), _lib.ptr(table),
+            int(verts4.shape[0]), _lib.ptr(rgb), _lib.ptr(acc), _lib.ptr(depth), _lib.ptr(ws), _lib.stream_ptr()),
+            "hl_render_rays_canonical")
+        return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
 
     # ---- SURVEY.md section 8(f) rank 1: the density grid behind extract_geometry ---------------------
     def density_grid(self, tp_input, tri_planes=None, resolution=512, rays_per_launch=1 << 15):

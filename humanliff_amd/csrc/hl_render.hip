@@ -216,6 +216,7 @@ struct MarchArgs {
     unsigned flags;
     float *sigma_out;            // coarse
     float4 *vals_out;            // STORE: raw (sigma, r, g, b) per sample, tile-major [R/32][S][32]
+    const float4 *pts_c, *dirs_c;  // POINTS: canonical-space sample points / view directions, tile-major [R/32][S][32] (xyz, w unused)
     float *rgb, *acc, *depth;    // fine
 };
 
@@ -229,8 +230,11 @@ __device__ __forceinline__ float linspace01(int s, int N) {
 // of the sample set (coarse, importance) are evaluated once each and merged by k_composite.
 // NWV waves (of 32 rays) per workgroup share one weight ring.  8: one workgroup per CU (2 waves/SIMD, all in lock step through the
 // 19 barriers of a sample); 4: two independent workgroups per CU whose activation / gather phases overlap each other's MFMAs.
-template <bool FULL, bool STORE = false, int NWV = 8>
+// POINTS (with STORE): sample positions and view directions are read per sample (canonical-space rendering: k_deform_rays wrote
+// them) instead of being o + d*z and the ray's direction; the view-direction encoding is then evaluated per sample.
+template <bool FULL, bool STORE = false, int NWV = 8, bool POINTS = false>
 __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
+    static_assert(!POINTS || (FULL && STORE), "POINTS is an evaluate-pass mode");
     constexpr int NT = NWV * 64, NST = 1024 / NT;   // threads; float4 per thread and 16 KB chunk
     __shared__ __attribute__((aligned(16))) float lds[2 * CHUNK_FLOATS + SMALL_FLOATS];
     constexpr int NCH = FULL ? NCH_FULL : NCH_COARSE;
@@ -276,28 +280,37 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
     const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
 
     // view-direction encoding, this half's 14 of the 27 (+1 pad) entries   [fields.py:54-85]
-    f32x16 ev;
-    if constexpr (FULL) {
-        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float vd[3] = {dx / nrm, dy / nrm, dz / nrm};
+    // entry k: k<3 raw component; else j=(k-3)/3, comp=(k-3)%3, sin(vd*2^(j/2) + (j&1)*pi/2).  Lanes 0-31 hold k = s, lanes 32-63
+    // k = s + 14: the argument is selected per half BEFORE the sine, so each lane evaluates 14 sines, not 28.
+    auto view_encode = [&](float v0, float v1, float v2) -> f32x16 {
+        const float vd[3] = {v0, v1, v2};
+        f32x16 e;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            float lo = 0.f, hi = 0.f;
-            // entry k: k<3 raw component; else j=(k-3)/3, comp=(k-3)%3, sin(vd*2^(j/2) + (j&1)*pi/2)
-            auto enc = [&](int k) -> float {
-                if (k >= 27) return 0.f;
-                if (k < 3) return vd[k];
-                const int jj = (k - 3) / 3, comp = (k - 3) % 3;
-                const float f = (float)(1 << (jj >> 1));
-                const float ph = (jj & 1) ? 1.57079632679489661923f : 0.f;
-                return sinf(ph + vd[comp] * f);
-            };
+            float val = 0.f;
             if (s < 14) {
-                lo = enc(s);
-                hi = enc(s + 14);
+                const int kl = s, kh = s + 14;                                   // compile-time per unrolled s
+                const int jl = (kl - 3) / 3, cl = (kl - 3) % 3, jh = (kh - 3) / 3, ch = (kh - 3) % 3;
+                const float argl = kl < 3 ? 0.f : ((jl & 1) ? 1.57079632679489661923f : 0.f) + vd[kl < 3 ? 0 : cl] * (float)(1 << (jl >> 1));
+                const float argh = ((jh & 1) ? 1.57079632679489661923f : 0.f) + vd[ch] * (float)(1 << (jh >> 1));
+                if (kl < 3) {                    // low half: raw component; high half: a sine
+                    const float sh = sinf(argh);
+                    val = half ? sh : vd[kl];
+                } else if (kh >= 27) {           // high half: padding
+                    const float sl = sinf(argl);
+                    val = half ? 0.f : sl;
+                } else {
+                    val = sinf(half ? argh : argl);
+                }
             }
-            ev[s] = half ? hi : lo;
+            e[s] = val;
         }
+        return e;
+    };
+    f32x16 ev;
+    if constexpr (FULL && !POINTS) {
+        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+        ev = view_encode(dx / nrm, dy / nrm, dz / nrm);
     }
 
     float T = 1.f, acc_w = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f;
@@ -326,7 +339,14 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
             else { const float t = linspace01(s + 1, S); zn = nr * (1.f - t) + fr * t; }
         }
         // ---- tri-plane features of this half  [renderer.py:502-531] ----
-        const float px = ox + dx * zc, py = oy + dy * zc, pz = oz + dz * zc;
+        float px, py, pz;
+        if constexpr (POINTS) {
+            const float4 pc = a.pts_c[zt_base + 32LL * s], dc = a.dirs_c[zt_base + 32LL * s];
+            px = pc.x; py = pc.y; pz = pc.z;
+            ev = view_encode(dc.x, dc.y, dc.z);    // canonical directions are used as they are (renderer.py:150)
+        } else {
+            px = ox + dx * zc; py = oy + dy * zc; pz = oz + dz * zc;
+        }
         const float nx = 2.f * (px - bmin0) / bext0 - 1.f;
         const float ny = 2.f * (py - bmin1) / bext1 - 1.f;
         const float nz = 2.f * (pz - bmin2) / bext2 - 1.f;
@@ -707,15 +727,27 @@ __global__ __launch_bounds__(256) void k_composite(const CompArgs a) {
 //     dir = Rbig (Rinv dir_smpl)
 // Table row (36 floats): t[3] Rinv[9] pose_off[3] shape_off[3] pose_off_big[3] Rbig[9] tbig[3] pad[3].
 // ---------------------------------------------------------------------------------------------
-struct DeformArgs {
-    const float *pts, *dirs;      // (P,3) world space; dirs may be null
+struct DeformCommon {
     float R[9], Th[3];            // world -> SMPL space: (p - Th) R
     const float4 *verts;          // (V) SMPL-space body vertices, w unused
     const float *table;           // (V,36)
     int V;
+};
+struct DeformArgs {
+    DeformCommon c;
+    const float *pts, *dirs;      // (P,3) world space; dirs may be null
     long long P;
     float *can_pts, *can_dirs;    // (P,3)
     int *vid;                     // (P) nearest vertex ids or null
+};
+struct DeformRaysArgs {
+    DeformCommon c;
+    const float *rays_o, *rays_d, *near, *far;
+    const float *z;               // null (linspace), caller rows (R,S) or tile-major [R/32][S][32]
+    int z_tiled;
+    long long R;
+    int S;
+    float4 *pts_c, *dirs_c;       // tile-major [R/32][S][32]
 };
 
 __device__ __forceinline__ void mat3_apply(const float *m, float x, float y, float z, float &ox, float &oy, float &oz) {
@@ -726,22 +758,21 @@ __device__ __forceinline__ void mat3_apply(const float *m, float x, float y, flo
 
 constexpr int DEFORM_TILE = 2048;   // vertices per LDS tile (32 KB)
 
-__global__ __launch_bounds__(256) void k_deform_points(const DeformArgs a) {
-    __shared__ float4 sv[DEFORM_TILE];
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < a.P;
-    const long long ic = live ? i : a.P - 1;
-    const float wx = a.pts[ic * 3 + 0] - a.Th[0], wy = a.pts[ic * 3 + 1] - a.Th[1], wz = a.pts[ic * 3 + 2] - a.Th[2];
+// all 256 threads of the workgroup must call this (the vertex tiles are staged cooperatively); (wx,wy,wz) world-space query,
+// (ex,ey,ez) world-space direction (ignored unless with_dir).  Returns the nearest vertex id.
+__device__ __forceinline__ int deform_query(const DeformCommon &c, float4 *sv, float wx, float wy, float wz, bool with_dir, float ex,
+                                            float ey, float ez, float (&cp)[3], float (&cd)[3]) {
+    wx -= c.Th[0]; wy -= c.Th[1]; wz -= c.Th[2];
     // (p - Th) R: row vector times matrix
-    const float qx = (wx * a.R[0] + wy * a.R[3]) + wz * a.R[6];
-    const float qy = (wx * a.R[1] + wy * a.R[4]) + wz * a.R[7];
-    const float qz = (wx * a.R[2] + wy * a.R[5]) + wz * a.R[8];
+    const float qx = (wx * c.R[0] + wy * c.R[3]) + wz * c.R[6];
+    const float qy = (wx * c.R[1] + wy * c.R[4]) + wz * c.R[7];
+    const float qz = (wx * c.R[2] + wy * c.R[5]) + wz * c.R[8];
     float best = 3.0e38f;
     int bid = 0;
-    for (int v0 = 0; v0 < a.V; v0 += DEFORM_TILE) {
-        const int n = min(DEFORM_TILE, a.V - v0);
+    for (int v0 = 0; v0 < c.V; v0 += DEFORM_TILE) {
+        const int n = min(DEFORM_TILE, c.V - v0);
         __syncthreads();
-        for (int k = threadIdx.x; k < n; k += 256) sv[k] = a.verts[v0 + k];
+        for (int k = threadIdx.x; k < n; k += 256) sv[k] = c.verts[v0 + k];
         __syncthreads();
 #pragma unroll 4
         for (int k = 0; k < n; ++k) {
@@ -751,8 +782,7 @@ __global__ __launch_bounds__(256) void k_deform_points(const DeformArgs a) {
             if (d < best) { best = d; bid = v0 + k; }
         }
     }
-    if (!live) return;
-    const float *row = a.table + (long long)bid * 36;
+    const float *row = c.table + (long long)bid * 36;
     float cx, cy, cz;
     mat3_apply(row + 3, qx - row[0], qy - row[1], qz - row[2], cx, cy, cz);
     cx -= row[12]; cy -= row[13]; cz -= row[14];
@@ -760,21 +790,55 @@ __global__ __launch_bounds__(256) void k_deform_points(const DeformArgs a) {
     cx += row[18]; cy += row[19]; cz += row[20];
     float ox, oy, oz;
     mat3_apply(row + 21, cx, cy, cz, ox, oy, oz);
-    a.can_pts[i * 3 + 0] = ox + row[30];
-    a.can_pts[i * 3 + 1] = oy + row[31];
-    a.can_pts[i * 3 + 2] = oz + row[32];
-    if (a.vid) a.vid[i] = bid;
-    if (a.dirs) {
-        const float ex = a.dirs[i * 3 + 0] - a.Th[0], ey = a.dirs[i * 3 + 1] - a.Th[1], ez = a.dirs[i * 3 + 2] - a.Th[2];   // :128
-        const float sx = (ex * a.R[0] + ey * a.R[3]) + ez * a.R[6];
-        const float sy = (ex * a.R[1] + ey * a.R[4]) + ez * a.R[7];
-        const float sz = (ex * a.R[2] + ey * a.R[5]) + ez * a.R[8];
+    cp[0] = ox + row[30]; cp[1] = oy + row[31]; cp[2] = oz + row[32];
+    if (with_dir) {
+        ex -= c.Th[0]; ey -= c.Th[1]; ez -= c.Th[2];      // the reference subtracts Th from directions too (:128)
+        const float sx = (ex * c.R[0] + ey * c.R[3]) + ez * c.R[6];
+        const float sy = (ex * c.R[1] + ey * c.R[4]) + ez * c.R[7];
+        const float sz = (ex * c.R[2] + ey * c.R[5]) + ez * c.R[8];
         float tx, ty, tz;
         mat3_apply(row + 3, sx, sy, sz, tx, ty, tz);
-        mat3_apply(row + 21, tx, ty, tz, ox, oy, oz);
-        a.can_dirs[i * 3 + 0] = ox;
-        a.can_dirs[i * 3 + 1] = oy;
-        a.can_dirs[i * 3 + 2] = oz;
+        mat3_apply(row + 21, tx, ty, tz, cd[0], cd[1], cd[2]);
+    }
+    return bid;
+}
+
+__global__ __launch_bounds__(256) void k_deform_points(const DeformArgs a) {
+    __shared__ float4 sv[DEFORM_TILE];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < a.P;
+    const long long ic = live ? i : a.P - 1;
+    float cp[3], cd[3];
+    const bool wd = a.dirs != nullptr;
+    const int bid = deform_query(a.c, sv, a.pts[ic * 3 + 0], a.pts[ic * 3 + 1], a.pts[ic * 3 + 2], wd, wd ? a.dirs[ic * 3 + 0] : 0.f,
+                                 wd ? a.dirs[ic * 3 + 1] : 0.f, wd ? a.dirs[ic * 3 + 2] : 0.f, cp, cd);
+    if (!live) return;
+    a.can_pts[i * 3 + 0] = cp[0]; a.can_pts[i * 3 + 1] = cp[1]; a.can_pts[i * 3 + 2] = cp[2];
+    if (a.vid) a.vid[i] = bid;
+    if (wd) { a.can_dirs[i * 3 + 0] = cd[0]; a.can_dirs[i * 3 + 1] = cd[1]; a.can_dirs[i * 3 + 2] = cd[2]; }
+}
+
+// sample points of a batch of rays (o + d*z, the unit ray direction as view direction: renderer.py:192, 258-259) deformed into
+// canonical space, written tile-major for k_march<.., POINTS>: thread = (tile, sample, ray-in-tile), rays fastest
+__global__ __launch_bounds__(256) void k_deform_rays(const DeformRaysArgs a) {
+    __shared__ float4 sv[DEFORM_TILE];
+    const long long tiles_n = (a.R + 31) / 32;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, total = tiles_n * 32 * a.S;
+    const long long ic = idx < total ? idx : total - 1;
+    const long long tile = ic / (32LL * a.S);
+    const int rem = (int)(ic - tile * 32LL * a.S), s = rem >> 5, r = rem & 31;
+    const long long ray_raw = tile * 32 + r, ray = ray_raw < a.R ? ray_raw : a.R - 1;
+    const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
+    const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
+    float zc;
+    if (a.z) zc = a.z_tiled ? a.z[ic] : a.z[ray * a.S + s];
+    else { const float t = linspace01(s, a.S); zc = a.near[ray] * (1.f - t) + a.far[ray] * t; }
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    float cp[3], cd[3];
+    deform_query(a.c, sv, ox + dx * zc, oy + dy * zc, oz + dz * zc, true, dx / nrm, dy / nrm, dz / nrm, cp, cd);
+    if (idx < total) {
+        a.pts_c[idx] = make_float4(cp[0], cp[1], cp[2], 0.f);
+        a.dirs_c[idx] = make_float4(cd[0], cd[1], cd[2], 0.f);
     }
 }
 
@@ -1046,12 +1110,81 @@ int hl_deform_points(const float *pts, const float *dirs, const float *h_R, cons
     HL_REQUIRE(n_vertices > 0 && n_points > 0, "hl_deform_points: bad sizes");
     DeformArgs a{};
     a.pts = pts; a.dirs = dirs;
-    for (int i = 0; i < 9; ++i) a.R[i] = h_R[i];
-    for (int i = 0; i < 3; ++i) a.Th[i] = h_Th[i];
-    a.verts = (const float4 *)verts_smpl4; a.table = table; a.V = n_vertices; a.P = n_points;
+    for (int i = 0; i < 9; ++i) a.c.R[i] = h_R[i];
+    for (int i = 0; i < 3; ++i) a.c.Th[i] = h_Th[i];
+    a.c.verts = (const float4 *)verts_smpl4; a.c.table = table; a.c.V = n_vertices; a.P = n_points;
     a.can_pts = can_pts; a.can_dirs = can_dirs; a.vid = vertex_ids;
     hipLaunchKernelGGL(k_deform_points, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_deform_points");
+}
+
+int hl_deform_rays(const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z, int z_tiled,
+                   int64_t n_rays, int n_samples, const float *h_R, const float *h_Th, const float *verts_smpl4, const float *table,
+                   int n_vertices, float *pts_c, float *dirs_c, void *stream) {
+    HL_REQUIRE(rays_o && rays_d && near && far && h_R && h_Th && verts_smpl4 && table && pts_c && dirs_c, "hl_deform_rays: null argument");
+    HL_REQUIRE(n_rays > 0 && n_samples >= 1 && n_vertices > 0, "hl_deform_rays: bad sizes");
+    DeformRaysArgs a{};
+    for (int i = 0; i < 9; ++i) a.c.R[i] = h_R[i];
+    for (int i = 0; i < 3; ++i) a.c.Th[i] = h_Th[i];
+    a.c.verts = (const float4 *)verts_smpl4; a.c.table = table; a.c.V = n_vertices;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.near = near; a.far = far; a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples;
+    a.pts_c = (float4 *)pts_c; a.dirs_c = (float4 *)dirs_c;
+    const long long total = (long long)tiles32(n_rays) * 32 * n_samples;
+    hipLaunchKernelGGL(k_deform_rays, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_deform_rays");
+}
+
+int hl_render_eval_points(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *pts_c,
+                          const float *dirs_c, int64_t n_rays, int n_samples, float *records_out, void *stream) {
+    HL_REQUIRE(mlp_packed && planes_packed && bounds && pts_c && dirs_c && records_out, "hl_render_eval_points: null argument");
+    HL_REQUIRE(n_rays > 0 && n_samples >= 1 && H > 0 && W > 0, "hl_render_eval_points: bad sizes");
+    MarchArgs a{};
+    a.packed = (const float *)mlp_packed; a.planes = (const float4 *)planes_packed; a.H = H; a.W = W; a.bounds = bounds;
+    // rays are not read in POINTS mode beyond the placeholders below (the kernel loads o, d, near, far of its ray unconditionally)
+    a.rays_o = pts_c; a.rays_d = pts_c; a.near = pts_c; a.far = pts_c;
+    a.z = nullptr; a.z_tiled = 0; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
+    a.pts_c = (const float4 *)pts_c; a.dirs_c = (const float4 *)dirs_c;
+    hipLaunchKernelGGL((k_march<true, true, 8, true>), dim3((unsigned)((n_rays + 255) / 256)), dim3(512), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_march<eval points>");
+}
+
+size_t hl_render_canonical_workspace_bytes(int64_t n_rays, int n_samples, int n_importance) {
+    if (n_rays <= 0) return 256;
+    const size_t T32 = (size_t)tiles32(n_rays) * 32;
+    const int smax = n_samples > n_importance ? n_samples : n_importance;
+    return hl_render_workspace_bytes(n_rays, n_samples, n_importance > 0 ? n_importance : n_samples) + T32 * smax * 2 * sizeof(float4) + 256;
+}
+
+int hl_render_rays_canonical(const void *mlp_packed, const void *planes_packed, int H, int W, const float *t_bounds,
+                             const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z_vals,
+                             const float *u, int64_t n_rays, int n_samples, int n_importance, unsigned flags, const float *h_R,
+                             const float *h_Th, const float *verts_smpl4, const float *table, int n_vertices, float *rgb, float *acc,
+                             float *depth, void *workspace, void *stream) {
+    HL_REQUIRE(workspace && n_rays > 0 && n_samples >= 2, "hl_render_rays_canonical: bad argument");
+    HL_REQUIRE(n_importance == 0 || n_importance == n_samples, "render: n_importance (%d) must equal n_samples (%d)", n_importance,
+               n_samples);
+    HL_REQUIRE(n_importance == 0 || u, "render: u is required when n_importance > 0");
+    HL_REQUIRE(n_importance > 0, "hl_render_rays_canonical: n_importance = 0 is not built (the reference's configurations use 128)");
+    const size_t T32 = (size_t)tiles32(n_rays) * 32;
+    float *vc = (float *)workspace, *vn = vc + T32 * n_samples * 4;
+    float *zn = vn + T32 * n_importance * 4;
+    float *pc = zn + T32 * n_importance;                       // canonical points of the pass in flight, then directions
+    pc = (float *)(((uintptr_t)pc + 255) / 256 * 256);
+    const int smax = n_samples > n_importance ? n_samples : n_importance;
+    float *dc = pc + T32 * smax * 4;
+    int rc = hl_deform_rays(rays_o, rays_d, near, far, z_vals, 0, n_rays, n_samples, h_R, h_Th, verts_smpl4, table, n_vertices, pc, dc,
+                            stream);
+    if (rc) return rc;
+    rc = hl_render_eval_points(mlp_packed, planes_packed, H, W, t_bounds, pc, dc, n_rays, n_samples, vc, stream);
+    if (rc) return rc;
+    rc = hl_render_importance_new(vc, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, zn, stream);
+    if (rc) return rc;
+    rc = hl_deform_rays(rays_o, rays_d, near, far, zn, 1, n_rays, n_importance, h_R, h_Th, verts_smpl4, table, n_vertices, pc, dc,
+                        stream);
+    if (rc) return rc;
+    rc = hl_render_eval_points(mlp_packed, planes_packed, H, W, t_bounds, pc, dc, n_rays, n_importance, vn, stream);
+    if (rc) return rc;
+    return hl_render_composite(near, far, z_vals, zn, vc, vn, n_rays, n_samples, n_importance, flags, rgb, acc, depth, stream);
 }
 
 }  // extern "C"

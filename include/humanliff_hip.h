@@ -141,6 +141,23 @@ int hl_camera_rays(const double *h_Kinv, const double *h_R, const double *h_T, c
 int hl_deform_points(const float *pts, const float *dirs, const float *h_R, const float *h_Th, const float *verts_smpl4,
                      const float *table, int n_vertices, int64_t n_points, float *can_pts, float *can_dirs, int *vertex_ids,
                      void *stream);
+/* Rendering in canonical space (use_canonical_space=True, renderer.py:114-132, 192-201, 242-246): the stages and the driver.
+ *   hl_deform_rays             sample points o + d*z of every ray (z as in hl_render_eval) and its unit direction, deformed like
+ *                              hl_deform_points -> pts_c, dirs_c: float[4] per sample (xyz, w unused), tile-major [ceil(R/32)][S][32]
+ *   hl_render_eval_points      hl_render_eval on given canonical points / directions; `bounds` is tp_input['t_world_bounds']
+ *   hl_render_rays_canonical   evaluate-once schedule of hl_render_rays with the two stages above in front of each evaluate pass;
+ *                              workspace: hl_render_canonical_workspace_bytes() */
+int hl_deform_rays(const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z, int z_tiled,
+                   int64_t n_rays, int n_samples, const float *h_R, const float *h_Th, const float *verts_smpl4, const float *table,
+                   int n_vertices, float *pts_c, float *dirs_c, void *stream);
+int hl_render_eval_points(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *pts_c,
+                          const float *dirs_c, int64_t n_rays, int n_samples, float *records_out, void *stream);
+size_t hl_render_canonical_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
+int hl_render_rays_canonical(const void *mlp_packed, const void *planes_packed, int H, int W, const float *t_bounds,
+                             const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z_vals,
+                             const float *u, int64_t n_rays, int n_samples, int n_importance, unsigned flags, const float *h_R,
+                             const float *h_Th, const float *verts_smpl4, const float *table, int n_vertices, float *rgb, float *acc,
+                             float *depth, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------
  * Path 1 — tri-plane UNet denoiser + Gaussian-diffusion sampler update

@@ -159,7 +159,7 @@ def test_bad_arguments_raise(dev):
     with pytest.raises(AssertionError):   # n_samples != n_importance (renderer.py:250)
         r.render(tp, None, None, i["rays_o"][None].to(dev), i["rays_d"][None].to(dev), i["near"][None].to(dev),
                  i["far"][None].to(dev), i["planes"].to(dev), 16, False, n_samples=32)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):     # canonical space needs the body model (a licensed asset the caller provides)
         Renderer(use_canonical_space=True, triplane_ch=27).render(tp, None, None, None, None, None, None, i["planes"])
 
 
@@ -327,3 +327,57 @@ def test_deform_fullsize_matches_oracle(dev):
     assert same.float().mean() > 0.9995        # a near-tie between two vertices may resolve differently in float32
     assert (can.cpu()[0, sub][same] - ocan[same]).abs().max() < 2e-5
     assert (cd.cpu()[0, sub][same] - ocd[same]).abs().max() < 2e-5
+
+
+def test_canonical_space_render_matches_oracle(dev):
+    """use_canonical_space=True end to end: device deformation of every sample point + evaluate-once render, against the oracle's
+    deform_target2c + plane lookup + MLP + importance sampling + compositing on the same synthetic body, rays and uniforms."""
+    from oracle import deform_oracle as do, render_oracle as orc
+    from humanliff_amd import synthetic as syn
+    V, H, W, N = 1500, 40, 40, 32
+    cpu_model = syn.smpl_like_model(V, 7)
+    pose = syn.smpl_like_pose(V, cpu_model, 17, n_points=8)
+    mlp = syn.render_mlp_state(3)
+    r = make_renderer(mlp, dev)
+    r.use_canonical_space = True
+    r.SMPL_NEUTRAL = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in cpu_model.items()}
+    planes = syn.triplane(seed=11)
+    # rays towards the posed body: the orbit camera shifted to the body's world position
+    centre = pose["vertices"][0].mean(0)
+    lo, hi = pose["vertices"][0].min(0).values - 0.1, pose["vertices"][0].max(0).values + 0.1
+    ro, rd, _, _ = syn.orbit_rays(4, 36, H, W)
+    ro = ro + centre
+    nr, fr = syn.near_far_from_bounds(torch.stack([lo, hi]).double().numpy(), ro.double().numpy(), rd.double().numpy())
+    nr, fr = torch.from_numpy(nr).float(), torch.from_numpy(fr).float()
+    R = ro.shape[0]
+    u = torch.rand((R, N), generator=torch.Generator().manual_seed(9))
+    tp = {k: (v if not torch.is_tensor(v) else v) for k, v in pose.items()}
+    out = r.render(tp, None, None, ro[None].to(dev), rd[None].to(dev), nr[None].to(dev), fr[None].to(dev), planes.to(dev), N, False,
+                   n_samples=N, u=u.to(dev))
+    # oracle
+    tb = pose["t_world_bounds"][0]
+    t = torch.linspace(0.0, 1.0, steps=N)
+    z = nr[:, None] * (1.0 - t) + fr[:, None] * t
+    vd = rd / rd.norm(dim=1, keepdim=True)
+
+    def evaluate(zz):
+        S = zz.shape[1]
+        pts = (ro[:, None, :] + rd[:, None, :] * zz[:, :, None]).reshape(-1, 3)
+        can, cd, _ = do.deform_target2c(cpu_model, pose, pts, vd[:, None, :].expand(R, S, 3).reshape(-1, 3))
+        rgb_raw, sig = ro_mlp(can, cd)
+        return rgb_raw.reshape(R, S, 3), sig.reshape(R, S)
+
+    def ro_mlp(can, cd):
+        return orc.mlp(mlp, orc.plane_features(planes[0], can, tb), cd)
+
+    with torch.no_grad():
+        _, sig_c = evaluate(z)
+        z_all = orc.importance_z(sig_c, z, rd, u)
+        rgb_raw, sig = evaluate(z_all)
+        rgb, acc, depth = orc.composite(rgb_raw, sig, z_all, False)
+    got = out["rgb_map"][0].cpu()
+    err = (got - rgb).abs().max(dim=1).values
+    assert float(acc.max()) > 0.05                       # the body is actually hit
+    assert (err < 1e-4).float().mean() > 0.995           # a sample on a Voronoi boundary of the body may pick the other vertex
+    assert float(err.median()) < 2e-6
+    assert ((out["acc_map"][0].cpu() - acc).abs() < 1e-4).float().mean() > 0.995
