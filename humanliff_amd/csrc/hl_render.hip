@@ -803,6 +803,68 @@ __device__ __forceinline__ int deform_query(const DeformCommon &c, float4 *sv, f
     return bid;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Nearest body vertex for TWO queries per thread (packed fp32 math: one v_pk_* instruction serves both queries, and one LDS
+// broadcast read of a vertex serves 128 queries per wave).  Squared distance as fma(dz,dz, fma(dy,dy, dx*dx)).  Two levels: the
+// scan only keeps the minimum DISTANCE per chunk of 32 vertices (one v_min per query and vertex instead of a compare and two
+// selects) and the first chunk that holds the overall minimum; the winning chunk is then re-scanned for the first vertex at
+// exactly that distance - the same vertex a flat first-index-wins scan returns.
+constexpr int DEFORM_CHUNK = 32;
+__device__ __forceinline__ void nearest2(const DeformCommon &c, float4 *sv, f32x2 qx, f32x2 qy, f32x2 qz, int (&bid)[2]) {
+    f32x2 best = {3.0e38f, 3.0e38f};
+    int bch[2] = {0, 0};
+    for (int v0 = 0; v0 < c.V; v0 += DEFORM_TILE) {
+        const int n = min(DEFORM_TILE, c.V - v0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < DEFORM_TILE; k += 256)       // pad the last chunk with far-away points
+            sv[k] = k < n ? c.verts[v0 + k] : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 0.f);
+        __syncthreads();
+        for (int k0 = 0; k0 < n; k0 += DEFORM_CHUNK) {
+            f32x2 m = {3.0e38f, 3.0e38f};
+#pragma unroll
+            for (int k = 0; k < DEFORM_CHUNK; ++k) {
+                const float4 v = sv[k0 + k];
+                const f32x2 dx = qx - v.x, dy = qy - v.y, dz = qz - v.z;
+                const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                m = __builtin_elementwise_min(m, d);
+            }
+            if (m[0] < best[0]) { best[0] = m[0]; bch[0] = v0 + k0; }
+            if (m[1] < best[1]) { best[1] = m[1]; bch[1] = v0 + k0; }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        bid[q] = bch[q];
+        const int nn = min(DEFORM_CHUNK, c.V - bch[q]);
+        for (int k = nn - 1; k >= 0; --k) {                         // descending: the lowest matching index is written last
+            const float4 v = c.verts[bch[q] + k];
+            const float dx = qx[q] - v.x, dy = qy[q] - v.y, dz = qz[q] - v.z;
+            const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            if (d == best[q]) bid[q] = bch[q] + k;
+        }
+    }
+}
+
+// the table row of vertex `bid` applied to an SMPL-space query / direction, in the reference's order
+__device__ __forceinline__ void apply_row(const DeformCommon &c, int bid, float qx, float qy, float qz, bool with_dir, float sx, float sy,
+                                          float sz, float (&cp)[3], float (&cd)[3]) {
+    const float *row = c.table + (long long)bid * 36;
+    float cx, cy, cz;
+    mat3_apply(row + 3, qx - row[0], qy - row[1], qz - row[2], cx, cy, cz);
+    cx -= row[12]; cy -= row[13]; cz -= row[14];
+    cx -= row[15]; cy -= row[16]; cz -= row[17];
+    cx += row[18]; cy += row[19]; cz += row[20];
+    float ox, oy, oz;
+    mat3_apply(row + 21, cx, cy, cz, ox, oy, oz);
+    cp[0] = ox + row[30]; cp[1] = oy + row[31]; cp[2] = oz + row[32];
+    if (with_dir) {
+        float tx, ty, tz;
+        mat3_apply(row + 3, sx, sy, sz, tx, ty, tz);
+        mat3_apply(row + 21, tx, ty, tz, cd[0], cd[1], cd[2]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_deform_points(const DeformArgs a) {
     __shared__ float4 sv[DEFORM_TILE];
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -822,23 +884,49 @@ __global__ __launch_bounds__(256) void k_deform_points(const DeformArgs a) {
 // canonical space, written tile-major for k_march<.., POINTS>: thread = (tile, sample, ray-in-tile), rays fastest
 __global__ __launch_bounds__(256) void k_deform_rays(const DeformRaysArgs a) {
     __shared__ float4 sv[DEFORM_TILE];
+    // thread = (tile, sample pair, ray-in-tile), rays fastest; the pair is samples (s, s + ceil(S/2)) of the same ray
     const long long tiles_n = (a.R + 31) / 32;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, total = tiles_n * 32 * a.S;
+    const int SH = (a.S + 1) / 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, total = tiles_n * 32 * SH;
     const long long ic = idx < total ? idx : total - 1;
-    const long long tile = ic / (32LL * a.S);
-    const int rem = (int)(ic - tile * 32LL * a.S), s = rem >> 5, r = rem & 31;
+    const long long tile = ic / (32LL * SH);
+    const int rem = (int)(ic - tile * 32LL * SH), s0 = rem >> 5, r = rem & 31;
+    const int s1 = min(s0 + SH, a.S - 1);                           // odd S: the last thread row repeats the final sample
     const long long ray_raw = tile * 32 + r, ray = ray_raw < a.R ? ray_raw : a.R - 1;
     const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
     const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
-    float zc;
-    if (a.z) zc = a.z_tiled ? a.z[ic] : a.z[ray * a.S + s];
-    else { const float t = linspace01(s, a.S); zc = a.near[ray] * (1.f - t) + a.far[ray] * t; }
+    auto depth = [&](int s) -> float {
+        if (a.z) return a.z_tiled ? a.z[(tile * a.S + s) * 32 + r] : a.z[ray * a.S + s];
+        const float t = linspace01(s, a.S);
+        return a.near[ray] * (1.f - t) + a.far[ray] * t;
+    };
+    const DeformCommon &c = a.c;
+    float q[2][3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float zc = depth(k ? s1 : s0);
+        const float wx = (ox + dx * zc) - c.Th[0], wy = (oy + dy * zc) - c.Th[1], wz = (oz + dz * zc) - c.Th[2];
+        q[k][0] = (wx * c.R[0] + wy * c.R[3]) + wz * c.R[6];       // (p - Th) R
+        q[k][1] = (wx * c.R[1] + wy * c.R[4]) + wz * c.R[7];
+        q[k][2] = (wx * c.R[2] + wy * c.R[5]) + wz * c.R[8];
+    }
+    int bid[2];
+    nearest2(c, sv, f32x2{q[0][0], q[1][0]}, f32x2{q[0][1], q[1][1]}, f32x2{q[0][2], q[1][2]}, bid);
+    if (idx >= total) return;
+    // unit ray direction as view direction (renderer.py:258-259), through the same world -> SMPL map as the points (:128)
     const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-    float cp[3], cd[3];
-    deform_query(a.c, sv, ox + dx * zc, oy + dy * zc, oz + dz * zc, true, dx / nrm, dy / nrm, dz / nrm, cp, cd);
-    if (idx < total) {
-        a.pts_c[idx] = make_float4(cp[0], cp[1], cp[2], 0.f);
-        a.dirs_c[idx] = make_float4(cd[0], cd[1], cd[2], 0.f);
+    const float ex = dx / nrm - c.Th[0], ey = dy / nrm - c.Th[1], ez = dz / nrm - c.Th[2];
+    const float sx = (ex * c.R[0] + ey * c.R[3]) + ez * c.R[6];
+    const float sy = (ex * c.R[1] + ey * c.R[4]) + ez * c.R[7];
+    const float sz = (ex * c.R[2] + ey * c.R[5]) + ez * c.R[8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int s = k ? s1 : s0;
+        float cp[3], cd[3];
+        apply_row(c, bid[k], q[k][0], q[k][1], q[k][2], true, sx, sy, sz, cp, cd);
+        const long long o = (tile * a.S + s) * 32 + r;
+        a.pts_c[o] = make_float4(cp[0], cp[1], cp[2], 0.f);
+        a.dirs_c[o] = make_float4(cd[0], cd[1], cd[2], 0.f);
     }
 }
 
@@ -1129,7 +1217,7 @@ int hl_deform_rays(const float *rays_o, const float *rays_d, const float *near, 
     a.c.verts = (const float4 *)verts_smpl4; a.c.table = table; a.c.V = n_vertices;
     a.rays_o = rays_o; a.rays_d = rays_d; a.near = near; a.far = far; a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples;
     a.pts_c = (float4 *)pts_c; a.dirs_c = (float4 *)dirs_c;
-    const long long total = (long long)tiles32(n_rays) * 32 * n_samples;
+    const long long total = (long long)tiles32(n_rays) * 32 * ((n_samples + 1) / 2);   // two samples per thread
     hipLaunchKernelGGL(k_deform_rays, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_deform_rays");
 }
