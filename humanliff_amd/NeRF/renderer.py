@@ -6,8 +6,8 @@ Mirrors (same names, argument order and return structure):
     render              human_diffusion/scripts/triplane_sample_layered.py:250-288
                         (recon twin: recon_NeRF/run_nerf_batch.py:29-67; "render_rays" in BASELINE.json)
 
-Scope: use_canonical_space=False, test (inference) mode, triplane_ch=27 - the shipped SynBody
-sampling configuration.  Everything numerical happens in libhumanliff_hip.so; there is no
+Scope: triplane_ch=27; test=True (inference, the shipped SynBody sampling configuration) in world or canonical space, and
+test=False (training mode with gradients, world space).  Everything numerical happens in libhumanliff_hip.so; there is no
 PyTorch fallback (a missing library or a CPU tensor raises).
 """
 import ctypes as C
@@ -114,7 +114,7 @@ class Renderer(nn.Module):
 
     # ---- reference API ---------------------------------------------------------------------------
     def render(self, tp_input, world_pts, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance=128,
-               white_bkgd=False, *, n_samples=None, u=None, reevaluate=False):
+               white_bkgd=False, *, n_samples=None, u=None, reevaluate=False, noise=None):
         """Same contract as the reference's Renderer.render; returns the dict
         {'rgb_map','acc_map','normal_map','depth_map'} of detached tensors.
 
@@ -127,6 +127,10 @@ class Renderer(nn.Module):
         the network on all n_samples + n_importance depths like the reference (re-evaluating the coarse
         points); by default every point is evaluated once and the two sorted halves are merged - the images
         are bit-identical, the default does 23 % less arithmetic.
+
+        test=False (training mode, renderer.py:212, 280): the fine pass adds Gaussian noise to the raw densities (`noise`
+        (bs*R*(n_samples+n_importance), 1) supplies it, otherwise it is drawn on the device like the reference's randn_like) and
+        rgb_map / acc_map stay attached to the autograd graph of tri_planes and the MLP parameters - see NeRF/train.py.
         """
         if self.use_canonical_space:
             return self._render_canonical(tp_input, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd,
@@ -153,6 +157,9 @@ class Renderer(nn.Module):
             if u is None:
                 u = torch.rand([bs * R, n_importance]).to(dev)
             u = u.reshape(bs, R, n_importance)
+        if not self.test:
+            return self._render_training(tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,
+                                         noise)
         L = _lib.lib()
         packed = self._packed_mlp(dev)
         ws = self._workspace(L.hl_render_workspace_bytes(R, n_samples, n_importance), dev)
@@ -175,6 +182,36 @@ class Renderer(nn.Module):
         # normal_map aliases rgb_map in the reference (renderer.py:228)
         return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
 
+
+    # ---- training mode (test=False) ------------------------------------------------
+    def _render_training(self, tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,
+                         noise=None):
+        """Renderer.render with test=False (renderer.py:212, 276-281): Gaussian noise on the raw densities of the fine pass and
+        outputs attached to the autograd graph - gradients for tri_planes and the MLP come from the HIP backward kernels
+        (NeRF/train.py).  The noise is drawn like the reference's randn_like: one (bs*R*(n_samples+n_importance), 1) draw on the device."""
+        from .train import RenderRaysFunction
+        assert n_importance > 0, "training mode is built for the hierarchical schedule (n_importance = n_samples)"
+        bs, R = rays_o.shape[:2]
+        dev = tri_planes.device
+        S = n_samples + n_importance
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()  # noqa: E731
+        if z_vals is None:
+            t = torch.linspace(0., 1., steps=n_samples, device=dev)
+            z_vals = near[..., None] * (1. - t) + far[..., None] * t
+        if noise is None:
+            noise = torch.randn((bs * R * S, 1), device=dev)
+        noise = noise.reshape(bs, R, S)
+        flags = _lib.HL_RENDER_NORMALIZE_DEPTH | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0)
+        mlp = self._mlp_tensors()
+        outs = []
+        for b in range(bs):
+            geo = {"rays_o": f32(rays_o[b]), "rays_d": f32(rays_d[b]), "near": f32(near[b]), "far": f32(far[b]), "bounds": f32(bounds[b]),
+                   "z": f32(z_vals[b]), "u": f32(u[b]), "noise": f32(noise[b]), "flags": flags}
+            outs.append(RenderRaysFunction.apply(self, geo, tri_planes[b], *mlp))
+        rgb = torch.stack([o[0] for o in outs])
+        acc = torch.stack([o[1] for o in outs])
+        depth = torch.stack([o[2] for o in outs])
+        return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
 
     # ---- SURVEY.md section 8(f) rank 3: rendering through the canonical-space deformation -------------------------
     def _render_canonical(self, tp_input, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd, n_samples, u):

@@ -1,0 +1,115 @@
+"""Differentiable rendering for the tri-plane fitting loop.
+
+What the reference trains with (recon_NeRF/run_nerf_batch.py:236-265): Renderer.render in training mode (test=False; Gaussian noise on
+the raw densities, renderer.py:212) -> MSE on rgb_map / acc_map -> loss.backward() -> Adam on the MLP and the tri-planes.  Autograd of
+stock ops is replaced by one autograd.Function per subject whose forward and backward are the HIP kernels of hl_render.hip:
+
+    forward    hl_render_eval_acts (coarse depths) -> hl_render_importance_new -> hl_render_eval_acts (new depths)
+               -> hl_render_composite_noise                                    [saves the activation matrix]
+    backward   hl_render_composite_backward -> hl_render_mlp_backward x2       [layer deltas, tri-plane gradient]
+               weight gradient of every layer = deltas x activations^T over the sample points: seven plain GEMMs, left to
+               rocBLAS through torch.matmul (the only library calls on this path)
+
+Gradients exist for rgb_map (= normal_map, the same tensor as in the reference) and acc_map with respect to tri_planes and the seven
+Linear layers.  depth_map is returned without gradient (the reference's losses never use it).  As in the reference the importance
+depths are constants of the backward pass (torch.no_grad, renderer.py:243-253), and rays / depths / bounds get no gradient.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+
+def train_rows():
+    a, d = C.c_int(0), C.c_int(0)
+    _lib.lib().hl_render_train_rows(C.byref(a), C.byref(d))
+    return a.value, d.value
+
+
+class RenderRaysFunction(torch.autograd.Function):
+    """One subject: planes (3,9,H,W) + the 14 MLP tensors (order of renderer._MLP_ORDER, weight then bias) -> rgb, acc, depth."""
+
+    @staticmethod
+    def forward(ctx, renderer, geo, planes, *mlp):
+        L = _lib.lib()
+        dev = planes.device
+        ro, rd, nr, fr, bd, zb, ub, noise, flags = (geo[k] for k in ("rays_o", "rays_d", "near", "far", "bounds", "z", "u", "noise", "flags"))
+        R, N = zb.shape
+        Ni = ub.shape[1]
+        H, W = planes.shape[-2:]
+        T32 = (R + 31) // 32 * 32
+        P = T32 * (N + Ni)
+        act_rows, _ = train_rows()
+        packed = renderer._packed_mlp(dev)
+        pp = renderer._packed_planes(planes)
+        act = torch.empty((act_rows, P), dtype=torch.float32, device=dev)
+        vc = torch.empty(T32 * N * 4, dtype=torch.float32, device=dev)
+        vn = torch.empty(T32 * Ni * 4, dtype=torch.float32, device=dev)
+        zn = torch.empty(T32 * Ni, dtype=torch.float32, device=dev)
+        rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        acc = torch.empty((R,), dtype=torch.float32, device=dev)
+        depth = torch.empty((R,), dtype=torch.float32, device=dev)
+        p, st = _lib.ptr, _lib.stream_ptr()
+        _lib.check(L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), 0, R, N, p(vc), p(act), P, 0,
+                                         st), "hl_render_eval_acts")
+        _lib.check(L.hl_render_importance_new(p(vc), p(rd), p(nr), p(fr), p(zb), p(ub), R, N, Ni, p(zn), st), "hl_render_importance_new")
+        _lib.check(L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, p(vn), p(act), P,
+                                         T32 * N, st), "hl_render_eval_acts")
+        _lib.check(L.hl_render_composite_noise(p(nr), p(fr), p(zb), p(zn), p(vc), p(vn), p(noise), R, N, Ni, flags, p(rgb), p(acc),
+                                               p(depth), st), "hl_render_composite_noise")
+        ctx.renderer, ctx.geo, ctx.packed = renderer, geo, packed
+        ctx.mlp_versions = [t._version for t in mlp]
+        ctx.save_for_backward(act, vc, vn, zn, *mlp)
+        ctx.hw = (H, W)
+        ctx.mark_non_differentiable(depth)
+        return rgb, acc, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_acc, _g_depth):
+        L = _lib.lib()
+        act, vc, vn, zn, *mlp = ctx.saved_tensors
+        geo = ctx.geo
+        ro, rd, nr, fr, bd, zb, ub, noise, flags = (geo[k] for k in ("rays_o", "rays_d", "near", "far", "bounds", "z", "u", "noise", "flags"))
+        dev = act.device
+        R, N = zb.shape
+        Ni = ub.shape[1]
+        H, W = ctx.hw
+        T32 = (R + 31) // 32 * 32
+        P = T32 * (N + Ni)
+        _, del_rows = train_rows()
+        g_rgb = (torch.zeros((R, 3), device=dev) if g_rgb is None else g_rgb).to(torch.float32).contiguous()
+        g_acc = (torch.zeros((R,), device=dev) if g_acc is None else g_acc).to(torch.float32).contiguous()
+        p, st = _lib.ptr, _lib.stream_ptr()
+        d_rec = torch.empty((P, 4), dtype=torch.float32, device=dev)          # rows [0, T32*N): coarse pass, then the new depths
+        dvc, dvn = d_rec[:T32 * N], d_rec[T32 * N:]
+        scratch = torch.empty(L.hl_render_composite_backward_scratch_bytes(R, N, Ni) // 4, dtype=torch.float32, device=dev)
+        _lib.check(L.hl_render_composite_backward(p(nr), p(fr), p(zb), p(zn), p(vc), p(vn), p(noise), p(g_rgb), p(g_acc), R, N, Ni, flags,
+                                                  p(dvc), p(dvn), p(scratch), st), "hl_render_composite_backward")
+        # transposed weights of the values the forward pass used
+        params = _lib.RenderMlpParams(*[C.c_void_p(t.data_ptr()) for t in mlp])
+        bwd = torch.empty(L.hl_render_mlp_bwd_packed_bytes() // 4, dtype=torch.float32, device=dev)
+        _lib.check(L.hl_render_mlp_pack_bwd(C.byref(params), p(bwd), st), "hl_render_mlp_pack_bwd")
+        delta = torch.empty((del_rows, P), dtype=torch.float32, device=dev)
+        d_planes = torch.zeros((27, H, W), dtype=torch.float32, device=dev)
+        _lib.check(L.hl_render_mlp_backward(p(ctx.packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), 0, R, N, p(dvc), p(act), P,
+                                            0, p(delta), P, 0, p(d_planes), st), "hl_render_mlp_backward")
+        _lib.check(L.hl_render_mlp_backward(p(ctx.packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, p(dvn), p(act), P,
+                                            T32 * N, p(delta), P, T32 * N, p(d_planes), st), "hl_render_mlp_backward")
+        # weight gradients: rows of `delta` x rows of `act` (include/humanliff_hip.h lists the row ranges)
+        d0, d1, d2, df, dv = delta[0:128], delta[128:256], delta[256:384], delta[384:512], delta[512:576]
+        a_f, a_f_x1, a_x0, a_x2, a_y_ev, a_v = act[0:27], act[0:155], act[155:283], act[283:411], act[411:566], act[566:630]
+        ds, dc = d_rec[:, 0], d_rec[:, 1:4]
+        grads = [
+            d0 @ a_f.t(), d0.sum(1),                    # pts_linears.0
+            d1 @ a_x0.t(), d1.sum(1),                   # pts_linears.1
+            d2 @ a_f_x1.t(), d2.sum(1),                 # pts_linears.2   input = [features, hidden]
+            df @ a_x2.t(), df.sum(1),                   # feature_linear
+            (a_x2 @ ds)[None], ds.sum()[None],          # alpha_linear
+            dv @ a_y_ev.t(), dv.sum(1),                 # views_linear    input = [feature, view encoding]
+            (a_v @ dc).t().contiguous(), dc.sum(0),     # rgb_linear
+        ]
+        needs = ctx.needs_input_grad   # (renderer, geo, planes, *mlp)
+        out = [None, None, d_planes.view(3, 9, H, W) if needs[2] else None]
+        out += [g if needs[3 + i] else None for i, g in enumerate(grads)]
+        return tuple(out)

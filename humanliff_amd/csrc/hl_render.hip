@@ -218,7 +218,47 @@ struct MarchArgs {
     float4 *vals_out;            // STORE: raw (sigma, r, g, b) per sample, tile-major [R/32][S][32]
     const float4 *pts_c, *dirs_c;  // POINTS: canonical-space sample points / view directions, tile-major [R/32][S][32] (xyz, w unused)
     float *rgb, *acc, *depth;    // fine
+    // training: ACTS stores every activation of the MLP, transposed - row = unit (ROW_* below), column =
+    // sample point in the pass's tile-major order - for the backward kernels; k_mlp_bwd's own inputs / outputs follow
+    float *act;
+    long long act_stride, act_off;   // floats per row; first column of this pass
+    const float *bwd_packed;         // hl_render_mlp_pack_bwd output
+    const float4 *d_rec;             // dL/d(sigma_raw, r_raw, g_raw, b_raw) per sample, same layout as vals_out
+    float *del;                      // row = unit (DROW_*), column = sample point: layer deltas for the weight gradients
+    long long del_stride, del_off;
+    float *dplanes;                  // (27, H, W) gradient of the tri-plane, accumulated atomically
 };
+// rows of the activation matrix ([features | hidden1] and [feature_linear | view encoding] are the concatenations the network feeds
+// to pts_linears.2 and views_linear, so their weight gradients are single products)
+constexpr int ROW_F = 0, ROW_X1 = 27, ROW_X0 = 155, ROW_X2 = 283, ROW_Y = 411, ROW_EV = 539, ROW_V = 566, ACT_ROWS = 630;
+constexpr int DROW_X0 = 0, DROW_X1 = 128, DROW_X2 = 256, DROW_Y = 384, DROW_V = 512, DEL_ROWS = 576;
+
+// Hidden (inline-asm) global store / atomic add: see the note at the record store of k_march - a compiler-visible VMEM write in the
+// sample loop turns every counted vmcnt wait of the weight ring into vmcnt(0).
+// The matrices are addressed through a buffer descriptor: per-lane byte offset (column, and the lane-half's share of the row) in a
+// VGPR, the row's byte offset in an SGPR - 64-bit per-row addresses would be hoisted out of the sample loop by the hundred and
+// spilled.  Offsets are 32-bit: a matrix is kept below 4 GiB (checked by the launchers).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 matrix_rsrc(const void *p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    return i32x4{(int)(unsigned)a, (int)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void hidden_store(i32x4 rs, unsigned voff, unsigned soff, float v) {
+    // The row offset is added on the VALU and the scalar offset left at 0: the hazard recogniser does not look into inline asm, and an
+    // SGPR written by the SALU (or by a v_readlane of a spilled descriptor) needs 5 wait states before a VMEM instruction reads it -
+    // hence also the s_nop (317 stores per sample and lane: 2 % of the sample's MFMA time).
+    const unsigned o = voff + soff;
+    asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, 0 offen" : : "v"(v), "v"(o), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void hidden_atomic_add(float *p, float v) { asm volatile("global_atomic_add_f32 %0, %1, off" : : "v"(p), "v"(v) : "memory"); }
+// rows row0 + unit_of(t, r, half): voff must already hold the column and half * 4 rows
+template <int NT>
+__device__ __forceinline__ void store_rows(i32x4 rs, unsigned voff, unsigned stride4, int row0, const f32x16 (&h)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hidden_store(rs, voff, (unsigned)(row0 + unit_of(t, r, 0)) * stride4, h[t][r]);
+}
 
 // torch.linspace(0,1,N)[s] (CPU/CUDA kernels are symmetric about the midpoint)
 __device__ __forceinline__ float linspace01(int s, int N) {
@@ -232,9 +272,10 @@ __device__ __forceinline__ float linspace01(int s, int N) {
 // 19 barriers of a sample); 4: two independent workgroups per CU whose activation / gather phases overlap each other's MFMAs.
 // POINTS (with STORE): sample positions and view directions are read per sample (canonical-space rendering: k_deform_rays wrote
 // them) instead of being o + d*z and the ray's direction; the view-direction encoding is then evaluated per sample.
-template <bool FULL, bool STORE = false, int NWV = 8, bool POINTS = false>
+template <bool FULL, bool STORE = false, int NWV = 8, bool POINTS = false, bool ACTS = false>
 __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
     static_assert(!POINTS || (FULL && STORE), "POINTS is an evaluate-pass mode");
+    static_assert(!ACTS || (FULL && STORE && !POINTS), "ACTS is an evaluate-pass mode");
     constexpr int NT = NWV * 64, NST = 1024 / NT;   // threads; float4 per thread and 16 KB chunk
     __shared__ __attribute__((aligned(16))) float lds[2 * CHUNK_FLOATS + SMALL_FLOATS];
     constexpr int NCH = FULL ? NCH_FULL : NCH_COARSE;
@@ -313,6 +354,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
         ev = view_encode(dx / nrm, dy / nrm, dz / nrm);
     }
 
+    const unsigned act_stride4 = ACTS ? (unsigned)a.act_stride * 4u : 0u;
+    const i32x4 act_rs = matrix_rsrc(a.act, ACTS ? (unsigned)ACT_ROWS * act_stride4 : 0u);
     float T = 1.f, acc_w = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f;
     float zc;  // depth of the current sample
     if (a.z) zc = a.z_tiled ? a.z[zt_base] : a.z[rc * S];
@@ -388,6 +431,20 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
             f[3 * i + 2] = live ? r2 : 0.f;
         }
 
+        const bool act_on = ACTS && tile * 32 < a.R;
+        unsigned acol = 0;       // byte offset of this sample point's column (+ this half's 4 rows) in the activation matrix
+        if constexpr (ACTS) {
+            const unsigned col4 = (unsigned)(a.act_off + zt_base + 32LL * s) * 4u;
+            acol = col4 + (unsigned)half * 4u * act_stride4;
+            if (act_on) {
+#pragma unroll
+                for (int j = 0; j < 15; ++j)
+                    if (j + 15 * half < 27) hidden_store(act_rs, col4 + (unsigned)half * 15u * act_stride4, (unsigned)(ROW_F + j) * act_stride4, f[j]);
+#pragma unroll
+                for (int j = 0; j < 14; ++j)
+                    if (j + 14 * half < 27) hidden_store(act_rs, col4 + (unsigned)half * 14u * act_stride4, (unsigned)(ROW_EV + j) * act_stride4, ev[j]);
+            }
+        }
         // ---- MLP  [renderer.py:134-156] ----
         f32x16 X[4], Y[4];
         // L0: features -> X (chunk 0)
@@ -401,6 +458,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
             X[k] = softplus16(X[k]);
             mma16<4, 4, 16>(Y, X[k], ldsv + cur, 0, lane);
         }
+        if constexpr (ACTS) { if (act_on) store_rows<4>(act_rs, acol, act_stride4, ROW_X0, X); }
         // L2: [features, softplus(Y)] -> X (chunks 5, 6-9)
         HL_CHUNK_ADVANCE(7 % NCH)
         load_bias<4>(X, small + SM_B2, half);
@@ -411,8 +469,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
             Y[k] = softplus16(Y[k]);
             mma16<4, 4, 16>(X, Y[k], ldsv + cur, 0, lane);
         }
+        if constexpr (ACTS) { if (act_on) store_rows<4>(act_rs, acol, act_stride4, ROW_X1, Y); }
 #pragma unroll
         for (int k = 0; k < 4; ++k) X[k] = softplus16(X[k]);
+        if constexpr (ACTS) { if (act_on) store_rows<4>(act_rs, acol, act_stride4, ROW_X2, X); }
         const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];
 
         if constexpr (!FULL) {
@@ -426,6 +486,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
                 HL_CHUNK_ADVANCE((k + 12) % NCH)
                 mma16<4, 4, 16>(Y, X[k], ldsv + cur, 0, lane);
             }
+            if constexpr (ACTS) { if (act_on) store_rows<4>(act_rs, acol, act_stride4, ROW_Y, Y); }
             // views_linear: [feature, enc(dir)] -> V (chunks 14,15,16), 64 units = 2 tiles
             f32x16 V[2];
             load_bias<2>(V, small + SM_BV, half);
@@ -439,6 +500,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
             mma16<2, 4, 14>(V, ev, ldsv + cur, 0, lane);
             V[0] = softplus16(V[0]);
             V[1] = softplus16(V[1]);
+            if constexpr (ACTS) { if (act_on) store_rows<2>(act_rs, acol, act_stride4, ROW_V, V); }
             const float cr = dot_lane<2>(V, small + SM_RW, half) + small[SM_RB + 0];
             const float cg = dot_lane<2>(V, small + SM_RW + 64, half) + small[SM_RB + 1];
             const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
@@ -655,6 +717,7 @@ struct CompArgs {
     int N, Ni;
     unsigned flags;
     float *rgb, *acc, *depth;
+    const float *noise;     // training: added to sigma_raw of sorted sample s of ray r, rows (R, N+Ni)  [renderer.py:212]; or null
 };
 
 __global__ __launch_bounds__(256) void k_composite(const CompArgs a) {
@@ -690,7 +753,8 @@ __global__ __launch_bounds__(256) void k_composite(const CompArgs a) {
             if (nA) { ++ia; za = ia < N ? zcoarse(ia) : inf; } else { ++ib; zb = ib < Ni ? zn[32LL * ib] : inf; }
         }
         const float dist = (s + 1 < S) ? znext - zcur : 1e10f;
-        const float alpha = 1.f - expf(-softplus_exact(vcur.x) * dist);
+        const float sraw = a.noise ? vcur.x + a.noise[ray * S + s] : vcur.x;
+        const float alpha = 1.f - expf(-softplus_exact(sraw) * dist);
         const float w = alpha * T;
         acc_w += w;
         acc_r += (1.f / (1.f + expf(-vcur.y))) * w;
@@ -996,6 +1060,321 @@ __global__ __launch_bounds__(256) void k_camera_rays(const CamArgs a) {
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Training: backward of render_core for the tri-plane fitting loop
+// (recon_NeRF/run_nerf_batch.py:236-265; human_diffusion/NeRF/renderer.py:172-231 with test=False).  The importance depths are
+// drawn under no_grad in the reference (renderer.py:243-253), so the gradient flows only through the evaluation of the 2N sample
+// points and the compositing:
+//   k_composite_bwd   dL/d(rgb, acc) per ray -> dL/d(sigma_raw, rgb_raw) per sample
+//   k_mlp_bwd         -> layer deltas (for the weight gradients) and, through the bilinear taps, the tri-plane gradient
+// ---------------------------------------------------------------------------------------------
+struct CompBwdArgs {
+    CompArgs c;
+    const float *g_rgb, *g_acc;   // (R,3), (R)
+    float4 *dvc, *dvn;            // out, same layout as c.vc / c.vn
+    float *sT;                    // scratch [R/32][N+Ni][32]: transmittance in front of sorted sample s
+    int *sSrc;                    // scratch: which list / index sorted sample s came from
+};
+
+// w_s = alpha_s T_s, T_{s+1} = T_s (1 - alpha_s + 1e-7), L = sum_s gw_s w_s with gw_s = g_rgb . c_s + g_acc.
+// dL/dalpha_s = T_s (gw_s - Q_s),  Q_s = sum_{k>s} gw_k alpha_k prod_{s<j<k} (1 - alpha_j + 1e-7),  Q_{s-1} = gw_s alpha_s + (1 - alpha_s + 1e-7) Q_s:
+// one forward walk (records T_s and the merge order), one backward walk; no division by the transmittance.
+__global__ __launch_bounds__(256) void k_composite_bwd(const CompBwdArgs b) {
+    const CompArgs &a = b.c;
+    const long long ray = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tiles_n = (a.R + 31) / 32;
+    if (ray >= tiles_n * 32) return;
+    const long long tile = ray >> 5;
+    const int r = (int)(ray & 31);
+    const int N = a.N, Ni = a.Ni, S = N + Ni;
+    float4 *dvc = b.dvc + tile * 32 * (long long)N + r, *dvn = b.dvn + tile * 32 * (long long)Ni + r;
+    if (ray >= a.R) {   // padding rays of the last tile: zero deltas, so that they drop out of every reduction over sample points
+        for (int i = 0; i < N; ++i) dvc[32LL * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < Ni; ++i) dvn[32LL * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float nr = a.near[ray], fr = a.far[ray];
+    const float4 *vc = a.vc + tile * 32 * (long long)N + r, *vn = a.vn + tile * 32 * (long long)Ni + r;
+    const float *zn = a.zn + tile * 32 * (long long)Ni + r;
+    float *sT = b.sT + tile * 32 * (long long)S + r;
+    int *sSrc = b.sSrc + tile * 32 * (long long)S + r;
+    auto zcoarse = [&](int i) -> float {
+        if (a.zc) return a.zc[ray * N + i];
+        const float t = linspace01(i, N);
+        return nr * (1.f - t) + fr * t;
+    };
+    auto sraw_of = [&](const float4 &v, int s) -> float { return a.noise ? v.x + a.noise[ray * S + s] : v.x; };
+    const float inf = __builtin_inff();
+    {   // forward walk: same merge and arithmetic as k_composite
+        int ia = 0, ib = 0;
+        float za = zcoarse(0), zb = zn[0];
+        bool fromA = za <= zb;
+        float zcur = fromA ? za : zb;
+        float4 vcur = fromA ? vc[0] : vn[0];
+        int code = fromA ? 0 : (int)0x80000000;
+        if (fromA) { ++ia; za = ia < N ? zcoarse(ia) : inf; } else { ++ib; zb = ib < Ni ? zn[32LL * ib] : inf; }
+        float T = 1.f;
+        for (int s = 0; s < S; ++s) {
+            float znext = 0.f;
+            float4 vnext = make_float4(0.f, 0.f, 0.f, 0.f);
+            int cnext = 0;
+            if (s + 1 < S) {
+                const bool nA = za <= zb;
+                znext = nA ? za : zb;
+                vnext = nA ? vc[32LL * ia] : vn[32LL * ib];
+                cnext = nA ? ia : (ib | (int)0x80000000);
+                if (nA) { ++ia; za = ia < N ? zcoarse(ia) : inf; } else { ++ib; zb = ib < Ni ? zn[32LL * ib] : inf; }
+            }
+            const float dist = (s + 1 < S) ? znext - zcur : 1e10f;
+            const float alpha = 1.f - expf(-softplus_exact(sraw_of(vcur, s)) * dist);
+            sT[32LL * s] = T;
+            sSrc[32LL * s] = code;
+            T *= (1.f - alpha + 1e-7f);
+            zcur = znext; vcur = vnext; code = cnext;
+        }
+    }
+    const float gr = b.g_rgb[ray * 3 + 0], gg = b.g_rgb[ray * 3 + 1], gb = b.g_rgb[ray * 3 + 2];
+    const float ga = b.g_acc[ray] - ((a.flags & HL_RENDER_WHITE_BKGD) ? gr + gg + gb : 0.f);   // rgb += 1 - acc
+    float Q = 0.f, znext = 0.f;
+    for (int s = S - 1; s >= 0; --s) {
+        const int code = sSrc[32LL * s];
+        const bool fromB = code < 0;
+        const int idx = code & 0x7fffffff;
+        const float T = sT[32LL * s];
+        const float zcur = fromB ? zn[32LL * idx] : zcoarse(idx);
+        const float4 v = fromB ? vn[32LL * idx] : vc[32LL * idx];
+        const float dist = (s + 1 < S) ? znext - zcur : 1e10f;
+        const float x = sraw_of(v, s);
+        const float e = expf(-softplus_exact(x) * dist);
+        const float alpha = 1.f - e;
+        const float cr = 1.f / (1.f + expf(-v.y)), cg = 1.f / (1.f + expf(-v.z)), cb = 1.f / (1.f + expf(-v.w));
+        const float gw = gr * cr + gg * cg + gb * cb + ga;
+        const float dalpha = T * (gw - Q);
+        Q = gw * alpha + (1.f - alpha + 1e-7f) * Q;
+        const float ex = expf(x);
+        const float dsp = x > 20.f ? 1.f : ex / (1.f + ex);           // F.softplus'(x), threshold 20
+        const float w = alpha * T;
+        const float4 d = make_float4(dalpha * (e * dist) * dsp, gr * w * cr * (1.f - cr), gg * w * cg * (1.f - cg), gb * w * cb * (1.f - cb));
+        if (fromB) dvn[32LL * idx] = d; else dvc[32LL * idx] = d;
+        znext = zcur;
+    }
+}
+
+// Transposed weights for the backward-data products, in the same 16 KB chunk geometry the forward ring uses
+// ([tile t][step/4][lane 64][4 steps]): delta_in[out] = sum_u W[u][col0 + out] delta_out[u], with the delta_out units u taken in
+// accumulator-register order (unit_of), so the deltas - like the activations in the forward pass - go from one layer's accumulators
+// straight into the next layer's B operand.
+constexpr int NCH_BWD = 16;
+__constant__ ChunkDesc c_chunks_bwd[NCH_BWD] = {
+    {4, 155, 0, 3, 0, 4, 16},  {4, 155, 0, 3, 16, 4, 16},                                                       // views^T (feature columns)
+    {3, 128, 0, 3, 0, 4, 16},  {3, 128, 0, 3, 16, 4, 16}, {3, 128, 0, 3, 32, 4, 16}, {3, 128, 0, 3, 48, 4, 16},  // feature^T
+    {2, 155, 0, 4, 0, 1, 64},                                                                                   // pts2^T, tri-plane feature columns
+    {2, 155, 27, 3, 0, 4, 16}, {2, 155, 27, 3, 16, 4, 16}, {2, 155, 27, 3, 32, 4, 16}, {2, 155, 27, 3, 48, 4, 16},  // pts2^T, hidden columns
+    {1, 128, 0, 3, 0, 4, 16},  {1, 128, 0, 3, 16, 4, 16}, {1, 128, 0, 3, 32, 4, 16}, {1, 128, 0, 3, 48, 4, 16},  // pts1^T
+    {0, 27, 0, 4, 0, 1, 64},                                                                                    // pts0^T
+};
+
+__global__ void k_pack_mlp_bwd(PackArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NCH_BWD * CHUNK_FLOATS) return;
+    const int c = idx / CHUNK_FLOATS, e = idx % CHUNK_FLOATS;
+    const ChunkDesc d = c_chunks_bwd[c];
+    const int ns4 = d.nsteps / 4;
+    const int k4 = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+    const int s4 = rest % ns4, t = rest / ns4;
+    float v = 0.f;
+    if (t < d.nt) {
+        const int sp = d.base + s4 * 4 + k4, half = lane >> 5, out = 32 * t + (lane & 31);
+        const int u = unit_of(sp >> 4, sp & 15, half);
+        if (d.kind == 3 || out < 27) v = a.w[d.w][u * d.ld + d.col0 + out];
+    }
+    a.out[idx] = v;
+}
+
+// One wave owns 32 rays as in k_march; per sample point: deltas of views_linear, feature_linear, pts_linears.2/1/0 by MFMA against
+// the transposed weights (ring of 16 chunks), each multiplied by softplus'(pre) = 1 - exp(-activation) read back from the
+// activation matrix, stored for the weight gradients; the two 27-wide feature deltas (skip connection + first layer) are summed
+// in one accumulator tile and scattered to the tri-plane gradient through the four bilinear taps of each feature.
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int NT = NWV * 64, NST = 1024 / NT;
+    __shared__ __attribute__((aligned(16))) float lds[2 * CHUNK_FLOATS + SMALL_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const long long tile = (long long)blockIdx.x * NWV + (tid >> 6);
+    const long long ray = tile * 32 + (lane & 31);
+    const long long rc = ray < a.R ? ray : a.R - 1;
+    const long long tiles_n = (a.R + 31) / 32;
+    const bool tile_on = tile < tiles_n;
+    const long long zt_base = (tile_on ? tile : tiles_n - 1) * 32 * (long long)a.S + (lane & 31);
+
+    f32x4 *ldsv = reinterpret_cast<f32x4 *>(lds);
+    const float *small = lds + 2 * CHUNK_FLOATS;
+    const f32x4 *gsmall = reinterpret_cast<const f32x4 *>(a.packed) + NCH_FULL * CHUNK_FLOATS / 4;
+    const f32x4 *gw = reinterpret_cast<const f32x4 *>(a.bwd_packed);
+    for (int i = tid; i < SMALL_FLOATS / 4; i += NT) ldsv[2 * CHUNK_FLOATS / 4 + i] = gsmall[i];
+#pragma unroll
+    for (int q = 0; q < 2 * NST; ++q) ldsv[q * NT + tid] = gw[q * NT + tid];
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)a.bwd_packed, (short)0, NCH_BWD * CHUNK_FLOATS * 4, 0x00020000);
+    const int wv = tid * 16;
+    auto ldw = [&](int f4_index) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wv, f4_index * 16, 0));
+    };
+    f32x4 st[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) st[q] = ldw(2048 + q * NT);
+    int cur = 0;
+
+    const float ox = a.rays_o[rc * 3 + 0], oy = a.rays_o[rc * 3 + 1], oz = a.rays_o[rc * 3 + 2];
+    const float dx = a.rays_d[rc * 3 + 0], dy = a.rays_d[rc * 3 + 1], dz = a.rays_d[rc * 3 + 2];
+    const float nr = a.near[rc], fr = a.far[rc];
+    const int S = a.S;
+    const float offH = (float)(1.0 / (double)a.H);
+    const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
+    const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
+    __syncthreads();
+
+#define HL_BWD_ADVANCE(g)                                                                                        \
+    __syncthreads();                                                                                             \
+    cur ^= 1024;                                                                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < NST; ++q_) ldsv[(cur ^ 1024) + q_ * NT + tid] = st[q_];              \
+    _Pragma("unroll") for (int q_ = 0; q_ < NST; ++q_) st[q_] = ldw((((g) + 2) % NCH_BWD) * 1024 + q_ * NT);
+
+    // activation -> softplus'(pre-activation) = sigmoid(pre) = 1 - exp(-softplus(pre))
+    const unsigned act_stride4 = (unsigned)a.act_stride * 4u, del_stride4 = (unsigned)a.del_stride * 4u;
+    const __amdgpu_buffer_rsrc_t act_rd = __builtin_amdgcn_make_buffer_rsrc((void *)a.act, (short)0, (int)((unsigned)ACT_ROWS * act_stride4), 0x00020000);
+    const i32x4 del_rs = matrix_rsrc(a.del, (unsigned)DEL_ROWS * del_stride4);
+    auto dact = [&](unsigned acol, int row0, int t, int r) -> float {
+        const float h = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(act_rd, (int)acol, (int)((unsigned)(row0 + unit_of(t, r, 0)) * act_stride4), 0));
+        return 1.f - __expf(-h);
+    };
+
+    for (int s = 0; s < S; ++s) {
+        const long long col = zt_base + 32LL * s;
+        const unsigned actp = (unsigned)(a.act_off + col) * 4u + (unsigned)half * 4u * act_stride4;
+        const unsigned delp = (unsigned)(a.del_off + col) * 4u + (unsigned)half * 4u * del_stride4;
+        const float4 d = a.d_rec[col];      // (dsigma, dr, dg, db); zero on padding rays
+        float zc;
+        if (a.z) zc = a.z_tiled ? a.z[col] : a.z[rc * S + s];
+        else { const float t = linspace01(s, S); zc = nr * (1.f - t) + fr * t; }
+
+        // ---- rgb_linear^T, softplus' of views_linear ----
+        f32x16 G[4], D[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = (t * 2 + half) * 16 + r;
+                const float g = small[SM_RW + o] * d.y + small[SM_RW + 64 + o] * d.z + small[SM_RW + 128 + o] * d.w;
+                G[t][r] = g * dact(actp, ROW_V, t, r);
+            }
+        if (tile_on) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hidden_store(del_rs, delp, (unsigned)(DROW_V + unit_of(t, r, 0)) * del_stride4, G[t][r]);
+        }
+        // ---- views_linear^T -> delta of feature_linear's output (no activation) ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) D[t][r] = 0.f;
+        mma16<4, 4, 16>(D, G[0], ldsv + cur, 0, lane);
+        HL_BWD_ADVANCE(1)
+        mma16<4, 4, 16>(D, G[1], ldsv + cur, 0, lane);
+        if (tile_on) store_rows<4>(del_rs, delp, del_stride4, DROW_Y, D);
+        // ---- feature_linear^T + alpha_linear^T, softplus' of pts_linears.2 ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G[t][r] = small[SM_AW + (t * 2 + half) * 16 + r] * d.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            HL_BWD_ADVANCE(2 + k)
+            mma16<4, 4, 16>(G, D[k], ldsv + cur, 0, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G[t][r] *= dact(actp, ROW_X2, t, r);
+        if (tile_on) store_rows<4>(del_rs, delp, del_stride4, DROW_X2, G);
+        // ---- pts_linears.2^T: tri-plane feature columns -> DF, hidden columns -> delta of pts_linears.1 ----
+        f32x16 DF[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) DF[0][r] = 0.f;
+        HL_BWD_ADVANCE(6)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mma16<1, 16, 16>(DF, G[k], ldsv + cur, 4 * k, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) D[t][r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            HL_BWD_ADVANCE(7 + k)
+            mma16<4, 4, 16>(D, G[k], ldsv + cur, 0, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) D[t][r] *= dact(actp, ROW_X1, t, r);
+        if (tile_on) store_rows<4>(del_rs, delp, del_stride4, DROW_X1, D);
+        // ---- pts_linears.1^T, softplus' of pts_linears.0 ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            HL_BWD_ADVANCE(11 + k)
+            mma16<4, 4, 16>(G, D[k], ldsv + cur, 0, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G[t][r] *= dact(actp, ROW_X0, t, r);
+        if (tile_on) store_rows<4>(del_rs, delp, del_stride4, DROW_X0, G);
+        // ---- pts_linears.0^T -> DF ----
+        HL_BWD_ADVANCE(15)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mma16<1, 16, 16>(DF, G[k], ldsv + cur, 4 * k, lane);
+        HL_BWD_ADVANCE(0)   // chunk 0 of the next sample
+
+        // ---- scatter DF through the bilinear taps  [renderer.py:502-531 transposed] ----
+        if (tile_on && ray < a.R) {
+            const float px = ox + dx * zc, py = oy + dy * zc, pz = oz + dz * zc;
+            const float nx = 2.f * (px - bmin0) / bext0 - 1.f;
+            const float ny = 2.f * (py - bmin1) / bext1 - 1.f;
+            const float nz = 2.f * (pz - bmin2) / bext2 - 1.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = (r & 3) + 8 * (r >> 2) + 4 * half;    // feature = plane*9 + group*3 + channel
+                if (k >= 27) continue;
+                const int q = k / 3, p = q / 3, g = q % 3;
+                float gu = (p == 2) ? nz : nx;
+                float gv = (p == 1) ? nz : ny;
+                gu = (g == 1) ? gu + offH : gu;
+                gv = (g == 2) ? gv + offH : gv;
+                const float ix = ((gu + 1.f) * (float)a.W - 1.f) / 2.f;
+                const float iy = ((gv + 1.f) * (float)a.H - 1.f) / 2.f;
+                const float x0f = floorf(ix), y0f = floorf(iy);
+                const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+                const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+                const bool vx0 = (x0 >= 0) & (x0 < a.W), vx1 = (x1 >= 0) & (x1 < a.W);
+                const bool vy0 = (y0 >= 0) & (y0 < a.H), vy1 = (y1 >= 0) & (y1 < a.H);
+                float *pl = a.dplanes + (long long)k * a.H * a.W;
+                const float v = DF[0][r];
+                if (vx0 & vy0) hidden_atomic_add(pl + y0 * a.W + x0, v * ((x1f - ix) * (y1f - iy)));
+                if (vx1 & vy0) hidden_atomic_add(pl + y0 * a.W + x1, v * ((ix - x0f) * (y1f - iy)));
+                if (vx0 & vy1) hidden_atomic_add(pl + y1 * a.W + x0, v * ((x1f - ix) * (iy - y0f)));
+                if (vx1 & vy1) hidden_atomic_add(pl + y1 * a.W + x1, v * ((ix - x0f) * (iy - y0f)));
+            }
+        }
+    }
+#undef HL_BWD_ADVANCE
+#endif
+}
+
 extern "C" {
 
 size_t hl_render_mlp_packed_bytes(void) { return (size_t)PACKED_FLOATS * sizeof(float); }
@@ -1122,12 +1501,100 @@ int hl_render_importance_new(const float *records, const float *rays_d, const fl
 int hl_render_composite(const float *near, const float *far, const float *z_vals, const float *z_new, const float *rec_coarse,
                         const float *rec_new, int64_t n_rays, int n_samples, int n_importance, unsigned flags, float *rgb,
                         float *acc, float *depth, void *stream) {
+    return hl_render_composite_noise(near, far, z_vals, z_new, rec_coarse, rec_new, nullptr, n_rays, n_samples, n_importance, flags, rgb,
+                                     acc, depth, stream);
+}
+
+int hl_render_composite_noise(const float *near, const float *far, const float *z_vals, const float *z_new, const float *rec_coarse,
+                              const float *rec_new, const float *noise, int64_t n_rays, int n_samples, int n_importance, unsigned flags,
+                              float *rgb, float *acc, float *depth, void *stream) {
     HL_REQUIRE(near && far && z_new && rec_coarse && rec_new && rgb && acc && depth, "hl_render_composite: null argument");
     HL_REQUIRE(n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_composite: bad sizes");
     CompArgs c{near, far, z_vals, z_new, (const float4 *)rec_coarse, (const float4 *)rec_new, n_rays, n_samples, n_importance,
-               flags, rgb, acc, depth};
+               flags, rgb, acc, depth, noise};
     hipLaunchKernelGGL(k_composite, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c);
     return hl::check_launch("k_composite");
+}
+
+// ---- training: backward of the evaluate-once pipeline ----
+size_t hl_render_mlp_bwd_packed_bytes(void) { return (size_t)NCH_BWD * CHUNK_FLOATS * sizeof(float); }
+
+int hl_render_mlp_pack_bwd(const hl_render_mlp_params *p, void *packed, void *stream) {
+    HL_REQUIRE(p && packed, "hl_render_mlp_pack_bwd: null argument");
+    PackArgs a{};
+    a.w[0] = p->pts0_w; a.w[1] = p->pts1_w; a.w[2] = p->pts2_w; a.w[3] = p->feat_w; a.w[4] = p->views_w;
+    for (int i = 0; i < 5; ++i) HL_REQUIRE(a.w[i], "hl_render_mlp_pack_bwd: null weight %d", i);
+    a.out = (float *)packed;
+    hipLaunchKernelGGL(k_pack_mlp_bwd, dim3((NCH_BWD * CHUNK_FLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_pack_mlp_bwd");
+}
+
+void hl_render_train_rows(int *act_rows, int *del_rows) {
+    if (act_rows) *act_rows = ACT_ROWS;
+    if (del_rows) *del_rows = DEL_ROWS;
+}
+
+int hl_render_eval_acts(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
+                        const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
+                        int n_samples, float *records_out, float *act, int64_t act_stride, int64_t act_off, void *stream) {
+    HL_REQUIRE(n_rays > 0 && n_samples >= 1 && records_out && act, "hl_render_eval_acts: bad argument");
+    HL_REQUIRE(act_off >= 0 && act_stride >= act_off + tiles32(n_rays) * 32 * n_samples, "hl_render_eval_acts: activation rows too short");
+    HL_REQUIRE((int64_t)ACT_ROWS * act_stride * 4 < (1LL << 32), "hl_render_eval_acts: activation matrix must stay below 4 GiB (row stride %lld)",
+               (long long)act_stride);
+    MarchArgs a{};
+    int rcode = fill_march(a, mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far);
+    if (rcode) return rcode;
+    a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
+    a.act = act; a.act_stride = act_stride; a.act_off = act_off;
+    hipLaunchKernelGGL((k_march<true, true, 8, false, true>), dim3((unsigned)((n_rays + 255) / 256)), dim3(512), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_march<eval, acts>");
+}
+
+size_t hl_render_composite_backward_scratch_bytes(int64_t n_rays, int n_samples, int n_importance) {
+    return (size_t)tiles32(n_rays) * 32 * (size_t)(n_samples + n_importance) * 8;
+}
+
+int hl_render_composite_backward(const float *near, const float *far, const float *z_vals, const float *z_new, const float *rec_coarse,
+                                 const float *rec_new, const float *noise, const float *g_rgb, const float *g_acc, int64_t n_rays,
+                                 int n_samples, int n_importance, unsigned flags, float *d_rec_coarse, float *d_rec_new, void *scratch,
+                                 void *stream) {
+    HL_REQUIRE(near && far && z_new && rec_coarse && rec_new && g_rgb && g_acc && d_rec_coarse && d_rec_new && scratch,
+               "hl_render_composite_backward: null argument");
+    HL_REQUIRE(n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_composite_backward: bad sizes");
+    CompBwdArgs b{};
+    b.c = CompArgs{near, far, z_vals, z_new, (const float4 *)rec_coarse, (const float4 *)rec_new, n_rays, n_samples, n_importance,
+                   flags, nullptr, nullptr, nullptr, noise};
+    b.g_rgb = g_rgb; b.g_acc = g_acc;
+    b.dvc = (float4 *)d_rec_coarse; b.dvn = (float4 *)d_rec_new;
+    b.sT = (float *)scratch;
+    b.sSrc = (int *)scratch + tiles32(n_rays) * 32 * (size_t)(n_samples + n_importance);
+    hipLaunchKernelGGL(k_composite_bwd, dim3((unsigned)((tiles32(n_rays) * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b);
+    return hl::check_launch("k_composite_bwd");
+}
+
+int hl_render_mlp_backward(const void *mlp_packed, const void *mlp_bwd_packed, int H, int W, const float *bounds, const float *rays_o,
+                           const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
+                           int n_samples, const float *d_records, const float *act, int64_t act_stride, int64_t act_off, float *del,
+                           int64_t del_stride, int64_t del_off, float *d_planes, void *stream) {
+    HL_REQUIRE(mlp_packed && mlp_bwd_packed && bounds && rays_o && rays_d && near && far && d_records && act && del && d_planes,
+               "hl_render_mlp_backward: null argument");
+    HL_REQUIRE(n_rays > 0 && n_samples >= 1 && H > 0 && W > 0, "hl_render_mlp_backward: bad sizes");
+    const int64_t cols = tiles32(n_rays) * 32 * n_samples;
+    HL_REQUIRE(act_off >= 0 && act_stride >= act_off + cols && del_off >= 0 && del_stride >= del_off + cols,
+               "hl_render_mlp_backward: activation / delta rows too short");
+    HL_REQUIRE((int64_t)ACT_ROWS * act_stride * 4 < (1LL << 32) && (int64_t)DEL_ROWS * del_stride * 4 < (1LL << 32),
+               "hl_render_mlp_backward: activation / delta matrices must stay below 4 GiB");
+    MarchArgs a{};
+    a.packed = (const float *)mlp_packed; a.bwd_packed = (const float *)mlp_bwd_packed;
+    a.H = H; a.W = W; a.bounds = bounds;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.near = near; a.far = far;
+    a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples;
+    a.d_rec = (const float4 *)d_records;
+    a.act = const_cast<float *>(act); a.act_stride = act_stride; a.act_off = act_off;
+    a.del = del; a.del_stride = del_stride; a.del_off = del_off;
+    a.dplanes = d_planes;
+    hipLaunchKernelGGL(k_mlp_bwd<8>, dim3((unsigned)((n_rays + 255) / 256)), dim3(512), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_mlp_bwd");
 }
 
 int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,

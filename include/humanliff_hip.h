@@ -122,6 +122,49 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
                    const float *z_all /* or NULL -> linspace */, int z_tiled, int64_t n_rays, int n_total_samples,
                    unsigned flags, float *rgb, float *acc, float *depth, void *stream);
 
+/* Training of the renderer: forward with saved activations + backward of the evaluate-once schedule, for
+ * the tri-plane fitting loop (recon_NeRF/run_nerf_batch.py:236-265: render -> img/acc loss -> backward -> Adam) and any other loss
+ * on rgb_map / acc_map of Renderer.render with test=False (human_diffusion/NeRF/renderer.py:172-281).  The importance depths are
+ * drawn under no_grad in the reference (:243-253), so gradients flow through the evaluation of the 2N sample points and the
+ * compositing only.  Matrices are "row = unit, column = sample point" (point order: the pass's tile-major record order at column
+ * offset *_off), row stride *_stride floats, hl_render_train_rows() rows:
+ *   activations (630 rows): [0,27) tri-plane features | [27,155) softplus(pts_linears.1) | [155,283) softplus(pts_linears.0) |
+ *                           [283,411) softplus(pts_linears.2) | [411,539) feature_linear | [539,566) view encoding |
+ *                           [566,630) softplus(views_linear)
+ *   deltas (576 rows, dL/d pre-activation): [0,128) pts_linears.0 | [128,256) pts_linears.1 | [256,384) pts_linears.2 |
+ *                           [384,512) feature_linear | [512,576) views_linear
+ * so that every weight gradient is one product delta_rows x activation_rows^T over the sample points (e.g. pts_linears.2.weight =
+ * deltas[256:384] x activations[0:155]^T; alpha_linear / rgb_linear take their deltas from the d_records columns) and every bias
+ * gradient a row sum.
+ *   hl_render_composite_noise     hl_render_composite with `noise` (R, n_samples+n_importance) added to the raw density of sorted
+ *                                 sample s of each ray (renderer.py:212, randn_like in training mode); NULL = none
+ *   hl_render_eval_acts           hl_render_eval that also writes the activation matrix
+ *   hl_render_composite_backward  g_rgb (R,3), g_acc (R) -> d_records of both passes (float[4] = d/d(sigma, r, g, b) raw, record
+ *                                 layout; zero on padding rays); scratch: hl_render_composite_backward_scratch_bytes()
+ *   hl_render_mlp_backward        one pass's d_records + activations -> its delta matrix, and d_planes (27,H,W) += the tri-plane
+ *                                 gradient (float atomics: summation order, hence the last bits, vary from run to run)
+ *   hl_render_mlp_pack_bwd        transposed weights for hl_render_mlp_backward (redo after every optimizer step, like
+ *                                 hl_render_mlp_pack) */
+int hl_render_composite_noise(const float *near, const float *far, const float *z_vals, const float *z_new, const float *rec_coarse,
+                              const float *rec_new, const float *noise, int64_t n_rays, int n_samples, int n_importance,
+                              unsigned flags, float *rgb, float *acc, float *depth, void *stream);
+size_t hl_render_mlp_bwd_packed_bytes(void);
+int hl_render_mlp_pack_bwd(const hl_render_mlp_params *h_params, void *packed_bwd, void *stream);
+void hl_render_train_rows(int *act_rows, int *del_rows);
+int hl_render_eval_acts(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
+                        const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
+                        int n_samples, float *records_out, float *act, int64_t act_stride, int64_t act_off, void *stream);
+size_t hl_render_composite_backward_scratch_bytes(int64_t n_rays, int n_samples, int n_importance);
+int hl_render_composite_backward(const float *near, const float *far, const float *z_vals, const float *z_new,
+                                 const float *rec_coarse, const float *rec_new, const float *noise, const float *g_rgb,
+                                 const float *g_acc, int64_t n_rays, int n_samples, int n_importance, unsigned flags,
+                                 float *d_rec_coarse, float *d_rec_new, void *scratch, void *stream);
+int hl_render_mlp_backward(const void *mlp_packed, const void *mlp_bwd_packed, int H, int W, const float *bounds,
+                           const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z,
+                           int z_tiled, int64_t n_rays, int n_samples, const float *d_records, const float *act,
+                           int64_t act_stride, int64_t act_off, float *del, int64_t del_stride, int64_t del_off, float *d_planes,
+                           void *stream);
+
 /* Per-view ray generation on the device.  Replaces get_rays
  * (human_diffusion/SynBodyView_datasets.py:316-329), the float32 casts and the near=0 / far=1 fill of
  * sample_ray_batch (:422-433) and get_near_far (:370-403) for one pinhole camera: float64 arithmetic like the

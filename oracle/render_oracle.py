@@ -125,9 +125,14 @@ def importance_z(sigma_raw, z, rays_d, u):
     return torch.sort(torch.cat([z, znew], dim=1), dim=1)[0]
 
 
-def composite(rgb_raw, sigma_raw, z, white_bkgd=False):
-    """rgb_raw (R,S,3), sigma_raw, z (R,S) -> rgb (R,3), acc (R,), depth (R,)."""
+def composite(rgb_raw, sigma_raw, z, white_bkgd=False, noise=None):
+    """rgb_raw (R,S,3), sigma_raw, z (R,S) -> rgb (R,3), acc (R,), depth (R,).
+
+    noise (R,S): the training-mode perturbation of the raw densities (renderer.py:212, `alpha + randn_like(alpha)`).
+    """
     R = z.shape[0]
+    if noise is not None:
+        sigma_raw = sigma_raw + noise
     dist = torch.cat([z[:, 1:] - z[:, :-1], torch.full((R, 1), 1e10)], dim=1)  # not scaled by |d|
     alpha = 1.0 - torch.exp(-F.softplus(sigma_raw) * dist)
     trans = torch.cumprod(torch.cat([torch.ones(R, 1), 1.0 - alpha + 1e-7], dim=1), dim=1)[:, :-1]
@@ -147,10 +152,12 @@ def coarse_sigma(p, planes, bounds, rays_o, rays_d, z):
 
 
 def render_rays(p, planes, bounds, rays_o, rays_d, near, far, n_samples, n_importance, u=None,
-                white_bkgd=False, normalize_depth=True, z_vals=None, return_aux=False):
+                white_bkgd=False, normalize_depth=True, z_vals=None, return_aux=False, noise=None):
     """One subject: planes (3,9,H,W), bounds (2,3), rays (R,3), near/far (R,).
 
     Returns rgb (R,3), acc (R,), depth (R,) [+ aux dict with sigma_coarse, z_all].
+    noise (R, n_samples+n_importance): training mode (test=False).  The importance depths are computed under no_grad like
+    the reference (renderer.py:243-253), so autograd through this function gives the reference's gradients for `planes` and `p`.
     """
     R = rays_o.shape[0]
     if z_vals is None:
@@ -160,8 +167,9 @@ def render_rays(p, planes, bounds, rays_o, rays_d, near, far, n_samples, n_impor
         z = z_vals
     aux = {}
     if n_importance > 0:
-        sig = coarse_sigma(p, planes, bounds, rays_o, rays_d, z)
-        z = importance_z(sig, z, rays_d, u)
+        with torch.no_grad():
+            sig = coarse_sigma(p, planes, bounds, rays_o, rays_d, z)
+            z = importance_z(sig, z, rays_d, u)
         aux["sigma_coarse"] = sig
     aux["z_all"] = z
     S = z.shape[1]
@@ -169,7 +177,7 @@ def render_rays(p, planes, bounds, rays_o, rays_d, near, far, n_samples, n_impor
     vd = rays_d / rays_d.norm(dim=1, keepdim=True)
     dirs = vd[:, None, :].expand(R, S, 3).reshape(-1, 3)
     rgb_raw, sig_f = mlp(p, plane_features(planes, pts.reshape(-1, 3), bounds), dirs)
-    rgb, acc, depth = composite(rgb_raw.reshape(R, S, 3), sig_f.reshape(R, S), z, white_bkgd)
+    rgb, acc, depth = composite(rgb_raw.reshape(R, S, 3), sig_f.reshape(R, S), z, white_bkgd, noise)
     if normalize_depth:
         depth = ((depth - near) / (far - near + 1e-5)).clamp(0, 1)
     if return_aux:

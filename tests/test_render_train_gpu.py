@@ -1,0 +1,115 @@
+"""GPU parity of the renderer's training mode: forward with density noise and the HIP backward kernels against
+gradient vectors from the reference's autograd (tests/golden/render_grad_*.npz) and against the oracle's autograd at a larger size.
+Gradients are sums of ~1e4..1e6 fp32 terms accumulated in a different order (MFMA chains, float atomics on the tri-plane, rocBLAS for
+the weight products): the bar is 2e-4 of the largest entry of each tensor (+2e-6 absolute), written next to each check."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_oracle_render_grad import MLP_KEYS, load_grad_case, oracle_grads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def make_renderer(mlp, dev):
+    from humanliff_amd.NeRF import Renderer
+    r = Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, smpl_type='smpl', test=False)
+    r.load_state_dict(mlp, strict=False)
+    return r.to(dev)
+
+
+def hip_grads(i, dev):
+    r = make_renderer(i["mlp"], dev)
+    planes = i["planes"].to(dev).clone().requires_grad_(True)          # (1,3,9,H,W)
+    N = i["n_samples"]
+    tp = {"world_bounds": i["bounds"][None].to(dev)}
+    out = r.render(tp, None, i["z"][None].to(dev), i["rays_o"][None].to(dev), i["rays_d"][None].to(dev), i["near"][None, :, None].to(dev),
+                   i["far"][None, :, None].to(dev), planes, N, i["white_bkgd"], u=i["u"].to(dev), noise=i["noise"].reshape(-1, 1).to(dev))
+    assert out["rgb_map"].requires_grad and out["acc_map"].requires_grad and not out["depth_map"].requires_grad
+    assert out["normal_map"] is out["rgb_map"]
+    loss = (out["rgb_map"][0] * i["G_rgb"].to(dev)).sum() + (out["acc_map"][0] * i["G_acc"].to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    sd = dict(r.named_parameters())
+    return out["rgb_map"][0].detach().cpu(), out["acc_map"][0].detach().cpu(), planes.grad[0].cpu(), {k: sd[k].grad.cpu() for k in MLP_KEYS}
+
+
+def close(got, ref, what):
+    err, scale = float((got - ref).abs().max()), float(ref.abs().max())
+    # floor: the density deltas are differences of O(1) terms (cotangents ~1), so a sum of them carries ~1e-6 of absolute rounding
+    assert err < 2e-6 + 2e-4 * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("name", ["a", "white"])
+def test_gradients_match_reference_golden(name, dev):
+    i, g = load_grad_case(name)
+    rgb, acc, d_planes, d_mlp = hip_grads(i, dev)
+    assert (rgb - torch.from_numpy(g["rgb"])).abs().max() < 2e-5
+    assert (acc - torch.from_numpy(g["acc"])).abs().max() < 2e-5
+    close(d_planes, torch.from_numpy(g["d_planes"]), "tri_planes")
+    for k in MLP_KEYS:
+        close(d_mlp[k], torch.from_numpy(g["d_" + k]), k)
+
+
+def test_gradients_match_oracle_larger(dev):
+    """1 000 rays x (48+48) samples on a 64x64 tri-plane, ragged last tile, stratified depths; cotangents like an MSE loss."""
+    from humanliff_amd import synthetic as syn
+    g = torch.Generator().manual_seed(3)
+    ro, rd, nr, fr = syn.orbit_rays(5, 8, 64, 64)
+    pick = torch.nonzero(fr != 1).flatten()
+    pick = pick[torch.randperm(pick.numel(), generator=g)[:1000]]
+    ro, rd, nr, fr = ro[pick], rd[pick], nr[pick], fr[pick]
+    N = 48
+    t = torch.linspace(0., 1., steps=N)
+    z = nr[:, None] * (1. - t) + fr[:, None] * t
+    mids = .5 * (z[:, 1:] + z[:, :-1])
+    z = torch.cat([z[:, :1], mids], -1) + (torch.cat([mids, z[:, -1:]], -1) - torch.cat([z[:, :1], mids], -1)) * torch.rand(z.shape, generator=g)
+    i = dict(planes=syn.triplane(seed=12, H=64, W=64), bounds=torch.tensor(syn.WORLD_BOUNDS), mlp=syn.render_mlp_state(4),
+             rays_o=ro, rays_d=rd, near=nr, far=fr, z=z, u=torch.rand((1000, N), generator=g), noise=torch.randn((1000, 2 * N), generator=g),
+             G_rgb=torch.randn((1000, 3), generator=g) / 1000, G_acc=torch.randn((1000,), generator=g) / 1000, n_samples=N, white_bkgd=False)
+    rgb, acc, d_planes, d_mlp = hip_grads(i, dev)
+    o_rgb, o_acc, o_planes, o_mlp = oracle_grads(i)
+    assert (rgb - o_rgb).abs().max() < 2e-5 and (acc - o_acc).abs().max() < 2e-5
+    close(d_planes, o_planes, "tri_planes")
+    for k in MLP_KEYS:
+        close(d_mlp[k], o_mlp[k], k)
+
+
+def test_fitting_loop_two_subjects(dev):
+    """The shape of recon_NeRF/run_nerf_batch.py:236-265: tri_planes is a Parameter indexed per subject, batch of two subjects, MSE on
+    rgb and acc, Adam on both parameter groups; the loss must go down and only the rendered subjects receive tri-plane gradient."""
+    from humanliff_amd import synthetic as syn
+    torch.manual_seed(0)
+    r = make_renderer(syn.render_mlp_state(3), dev)
+    tri = torch.nn.Parameter((0.1 * torch.randn((3, 4, 3, 9, 32, 32))).to(dev))
+    opt = torch.optim.Adam([{'params': list(r.parameters()), 'lr': 5e-4}, {'params': [tri], 'lr': 1e-2}], betas=(0.9, 0.999))
+    ro, rd, nr, fr = syn.orbit_rays(2, 8, 32, 32)
+    pick = torch.nonzero(fr != 1).flatten()[:256]
+    ro, rd, nr, fr = (t[pick].to(dev) for t in (ro, rd, nr, fr))
+    bs, R, N = 2, 256, 16
+    target = torch.tensor([0.2, 0.5, 0.8], device=dev).expand(bs, R, 3)     # reachable: the loss can go to ~0
+    tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].expand(bs, 2, 3).to(dev)}
+    ids, layer = torch.tensor([0, 2]), torch.tensor([1, 3])
+    losses = []
+    for it in range(30):
+        t = torch.linspace(0., 1., steps=N, device=dev)
+        z = (nr[:, None] * (1. - t) + fr[:, None] * t)[None].expand(bs, R, N)
+        out = r.render(tp, None, z, ro[None].expand(bs, R, 3), rd[None].expand(bs, R, 3), nr[None, :, None].expand(bs, R, 1),
+                       fr[None, :, None].expand(bs, R, 1), tri[ids, layer], N, False)
+        loss = ((out["rgb_map"] - target) ** 2).mean() + 0.1 * ((out["acc_map"] - 1.0) ** 2).mean()
+        loss.backward()
+        if it == 0:
+            gsum = tri.grad.abs().sum(dim=(2, 3, 4, 5)).cpu()
+            assert gsum[0, 1] > 0 and gsum[2, 3] > 0
+            gsum[0, 1] = gsum[2, 3] = 0
+            assert float(gsum.sum()) == 0.0
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.5 * np.mean(losses[:5]), losses
