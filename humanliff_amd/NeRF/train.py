@@ -6,9 +6,9 @@ stock ops is replaced by one autograd.Function per subject whose forward and bac
 
     forward    hl_render_eval_acts (coarse depths) -> hl_render_importance_new -> hl_render_eval_acts (new depths)
                -> hl_render_composite_noise                                    [saves the activation matrix]
-    backward   hl_render_composite_backward -> hl_render_mlp_backward x2       [layer deltas, tri-plane gradient]
-               weight gradient of every layer = deltas x activations^T over the sample points: seven plain GEMMs, left to
-               rocBLAS through torch.matmul (the only library calls on this path)
+    backward   hl_render_composite_backward -> hl_render_mlp_backward x2       [layer deltas]
+               hl_render_plane_grads                                           [tri-plane gradient: transposed bilinear lookup]
+               hl_render_weight_grads: weight gradient of every layer = deltas x activations^T over the sample points
 
 Gradients exist for rgb_map (= normal_map, the same tensor as in the reference) and acc_map with respect to tri_planes and the seven
 Linear layers.  depth_map is returned without gradient (the reference's losses never use it).  As in the reference the importance
@@ -83,32 +83,30 @@ class RenderRaysFunction(torch.autograd.Function):
         p, st = _lib.ptr, _lib.stream_ptr()
         d_rec = torch.empty((P, 4), dtype=torch.float32, device=dev)          # rows [0, T32*N): coarse pass, then the new depths
         dvc, dvn = d_rec[:T32 * N], d_rec[T32 * N:]
+        delta = torch.empty((del_rows, P), dtype=torch.float32, device=dev)
         scratch = torch.empty(L.hl_render_composite_backward_scratch_bytes(R, N, Ni) // 4, dtype=torch.float32, device=dev)
         _lib.check(L.hl_render_composite_backward(p(nr), p(fr), p(zb), p(zn), p(vc), p(vn), p(noise), p(g_rgb), p(g_acc), R, N, Ni, flags,
-                                                  p(dvc), p(dvn), p(scratch), st), "hl_render_composite_backward")
+                                                  p(dvc), p(dvn), p(delta), P, p(scratch), st), "hl_render_composite_backward")
         # transposed weights of the values the forward pass used
         params = _lib.RenderMlpParams(*[C.c_void_p(t.data_ptr()) for t in mlp])
         bwd = torch.empty(L.hl_render_mlp_bwd_packed_bytes() // 4, dtype=torch.float32, device=dev)
         _lib.check(L.hl_render_mlp_pack_bwd(C.byref(params), p(bwd), st), "hl_render_mlp_pack_bwd")
-        delta = torch.empty((del_rows, P), dtype=torch.float32, device=dev)
-        d_planes = torch.zeros((27, H, W), dtype=torch.float32, device=dev)
         _lib.check(L.hl_render_mlp_backward(p(ctx.packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), 0, R, N, p(dvc), p(act), P,
-                                            0, p(delta), P, 0, p(d_planes), st), "hl_render_mlp_backward")
+                                            0, p(delta), P, 0, st), "hl_render_mlp_backward")
         _lib.check(L.hl_render_mlp_backward(p(ctx.packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, p(dvn), p(act), P,
-                                            T32 * N, p(delta), P, T32 * N, p(d_planes), st), "hl_render_mlp_backward")
-        # weight gradients: rows of `delta` x rows of `act` (include/humanliff_hip.h lists the row ranges)
-        d0, d1, d2, df, dv = delta[0:128], delta[128:256], delta[256:384], delta[384:512], delta[512:576]
-        a_f, a_f_x1, a_x0, a_x2, a_y_ev, a_v = act[0:27], act[0:155], act[155:283], act[283:411], act[411:566], act[566:630]
-        ds, dc = d_rec[:, 0], d_rec[:, 1:4]
-        grads = [
-            d0 @ a_f.t(), d0.sum(1),                    # pts_linears.0
-            d1 @ a_x0.t(), d1.sum(1),                   # pts_linears.1
-            d2 @ a_f_x1.t(), d2.sum(1),                 # pts_linears.2   input = [features, hidden]
-            df @ a_x2.t(), df.sum(1),                   # feature_linear
-            (a_x2 @ ds)[None], ds.sum()[None],          # alpha_linear
-            dv @ a_y_ev.t(), dv.sum(1),                 # views_linear    input = [feature, view encoding]
-            (a_v @ dc).t().contiguous(), dc.sum(0),     # rgb_linear
-        ]
+                                            T32 * N, p(delta), P, T32 * N, st), "hl_render_mlp_backward")
+        d_planes = torch.empty((27, H, W), dtype=torch.float32, device=dev)
+        if ctx.needs_input_grad[2]:
+            _lib.check(L.hl_render_plane_grads(H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), p(zn), R, N, Ni, p(delta), P, p(d_planes), st),
+                       "hl_render_plane_grads")
+        # all 14 parameter gradients: rows of `delta` x rows of `act` over the sample points (include/humanliff_hip.h lists the rows)
+        flat = torch.zeros(sum(t.numel() for t in mlp), dtype=torch.float32, device=dev)
+        grads, o = [], 0
+        for t in mlp:
+            grads.append(flat[o:o + t.numel()].view(t.shape))
+            o += t.numel()
+        gp = _lib.RenderMlpParams(*[C.c_void_p(g.data_ptr()) for g in grads])
+        _lib.check(L.hl_render_weight_grads(p(delta), P, p(act), P, P, C.byref(gp), st), "hl_render_weight_grads")
         needs = ctx.needs_input_grad   # (renderer, geo, planes, *mlp)
         out = [None, None, d_planes.view(3, 9, H, W) if needs[2] else None]
         out += [g if needs[3 + i] else None for i, g in enumerate(grads)]

@@ -227,11 +227,13 @@ struct MarchArgs {
     float *del;                      // row = unit (DROW_*), column = sample point: layer deltas for the weight gradients
     long long del_stride, del_off;
     float *dplanes;                  // (27, H, W) gradient of the tri-plane, accumulated atomically
+    int s_per;                       // ACTS / k_mlp_bwd: samples per workgroup; blockIdx.y selects the range (a fitting batch has few
+                                     // rays - 2048 = 8 workgroups of 256 - so the launch is spread over the samples as well)
 };
 // rows of the activation matrix ([features | hidden1] and [feature_linear | view encoding] are the concatenations the network feeds
 // to pts_linears.2 and views_linear, so their weight gradients are single products)
 constexpr int ROW_F = 0, ROW_X1 = 27, ROW_X0 = 155, ROW_X2 = 283, ROW_Y = 411, ROW_EV = 539, ROW_V = 566, ACT_ROWS = 630;
-constexpr int DROW_X0 = 0, DROW_X1 = 128, DROW_X2 = 256, DROW_Y = 384, DROW_V = 512, DEL_ROWS = 576;
+constexpr int DROW_X0 = 0, DROW_X1 = 128, DROW_X2 = 256, DROW_Y = 384, DROW_V = 512, DROW_REC = 576, DROW_DF = 580, DEL_ROWS = 607;
 
 // Hidden (inline-asm) global store / atomic add: see the note at the record store of k_march - a compiler-visible VMEM write in the
 // sample loop turns every counted vmcnt wait of the weight ring into vmcnt(0).
@@ -358,8 +360,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
     const i32x4 act_rs = matrix_rsrc(a.act, ACTS ? (unsigned)ACT_ROWS * act_stride4 : 0u);
     float T = 1.f, acc_w = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f;
     float zc;  // depth of the current sample
-    if (a.z) zc = a.z_tiled ? a.z[zt_base] : a.z[rc * S];
-    else zc = nr * (1.f - linspace01(0, S)) + fr * linspace01(0, S);
+    int s_lo = 0, s_hi = S;
+    if constexpr (ACTS) {
+        s_lo = (int)blockIdx.y * a.s_per;
+        s_hi = min(S, s_lo + a.s_per);
+    }
+    if (a.z) zc = a.z_tiled ? a.z[zt_base + 32LL * s_lo] : a.z[rc * S + s_lo];
+    else zc = nr * (1.f - linspace01(s_lo, S)) + fr * linspace01(s_lo, S);
 
     __syncthreads();
 
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
     // HL_CHUNK_ADVANCE(g+2), executed when moving on to chunk g: (1) barrier - every wave is done
     // with g-1 and the writes of g are visible, (2) flip `cur`, (3) write the staged chunk g+1 into
     // the slot g-1 just released, (4) start loading g+2 from L2 (lands during g's MFMAs).
-    for (int s = 0; s < S; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
         // ---- next depth (needed for the section length) ----
         float zn = 0.f;
         if (s + 1 < S) {
@@ -1074,6 +1081,8 @@ struct CompBwdArgs {
     float4 *dvc, *dvn;            // out, same layout as c.vc / c.vn
     float *sT;                    // scratch [R/32][N+Ni][32]: transmittance in front of sorted sample s
     int *sSrc;                    // scratch: which list / index sorted sample s came from
+    float *del;                   // delta matrix: rows DROW_REC..+3 receive the same four values per sample point (row layout, for
+    long long del_stride;         //   the alpha_linear / rgb_linear weight gradients); columns: coarse pass first, then the new depths
 };
 
 // w_s = alpha_s T_s, T_{s+1} = T_s (1 - alpha_s + 1e-7), L = sum_s gw_s w_s with gw_s = g_rgb . c_s + g_acc.
@@ -1088,9 +1097,18 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const CompBwdArgs b) {
     const int r = (int)(ray & 31);
     const int N = a.N, Ni = a.Ni, S = N + Ni;
     float4 *dvc = b.dvc + tile * 32 * (long long)N + r, *dvn = b.dvn + tile * 32 * (long long)Ni + r;
+    float *drow_c = b.del + (long long)DROW_REC * b.del_stride + tile * 32 * (long long)N + r;
+    float *drow_n = b.del + (long long)DROW_REC * b.del_stride + tiles_n * 32 * (long long)N + tile * 32 * (long long)Ni + r;
+    auto put = [&](float4 *rec, float *row, int i, const float4 d) {
+        rec[32LL * i] = d;
+        row[32LL * i] = d.x;
+        row[32LL * i + b.del_stride] = d.y;
+        row[32LL * i + 2 * b.del_stride] = d.z;
+        row[32LL * i + 3 * b.del_stride] = d.w;
+    };
     if (ray >= a.R) {   // padding rays of the last tile: zero deltas, so that they drop out of every reduction over sample points
-        for (int i = 0; i < N; ++i) dvc[32LL * i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = 0; i < Ni; ++i) dvn[32LL * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < N; ++i) put(dvc, drow_c, i, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int i = 0; i < Ni; ++i) put(dvn, drow_n, i, make_float4(0.f, 0.f, 0.f, 0.f));
         return;
     }
     const float nr = a.near[ray], fr = a.far[ray];
@@ -1155,7 +1173,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const CompBwdArgs b) {
         const float dsp = x > 20.f ? 1.f : ex / (1.f + ex);           // F.softplus'(x), threshold 20
         const float w = alpha * T;
         const float4 d = make_float4(dalpha * (e * dist) * dsp, gr * w * cr * (1.f - cr), gg * w * cg * (1.f - cg), gb * w * cb * (1.f - cb));
-        if (fromB) dvn[32LL * idx] = d; else dvc[32LL * idx] = d;
+        if (fromB) put(dvn, drow_n, idx, d); else put(dvc, drow_c, idx, d);
         znext = zcur;
     }
 }
@@ -1206,7 +1224,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
     const long long rc = ray < a.R ? ray : a.R - 1;
     const long long tiles_n = (a.R + 31) / 32;
     const bool tile_on = tile < tiles_n;
-    const long long zt_base = (tile_on ? tile : tiles_n - 1) * 32 * (long long)a.S + (lane & 31);
+    const long long zt_base = (tile < tiles_n ? tile : tiles_n - 1) * 32 * (long long)a.S + (lane & 31);
 
     f32x4 *ldsv = reinterpret_cast<f32x4 *>(lds);
     const float *small = lds + 2 * CHUNK_FLOATS;
@@ -1249,7 +1267,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
         return 1.f - __expf(-h);
     };
 
-    for (int s = 0; s < S; ++s) {
+    const int s_lo = (int)blockIdx.y * a.s_per, s_hi = min(S, s_lo + a.s_per);
+    for (int s = s_lo; s < s_hi; ++s) {
         const long long col = zt_base + 32LL * s;
         const unsigned actp = (unsigned)(a.act_off + col) * 4u + (unsigned)half * 4u * act_stride4;
         const unsigned delp = (unsigned)(a.del_off + col) * 4u + (unsigned)half * 4u * del_stride4;
@@ -1340,38 +1359,183 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
         for (int k = 0; k < 4; ++k) mma16<1, 16, 16>(DF, G[k], ldsv + cur, 4 * k, lane);
         HL_BWD_ADVANCE(0)   // chunk 0 of the next sample
 
-        // ---- scatter DF through the bilinear taps  [renderer.py:502-531 transposed] ----
-        if (tile_on && ray < a.R) {
-            const float px = ox + dx * zc, py = oy + dy * zc, pz = oz + dz * zc;
-            const float nx = 2.f * (px - bmin0) / bext0 - 1.f;
-            const float ny = 2.f * (py - bmin1) / bext1 - 1.f;
-            const float nz = 2.f * (pz - bmin2) / bext2 - 1.f;
+        // ---- d/d(tri-plane features) -> rows DROW_DF.. (k_plane_scatter sends them through the bilinear taps) ----
+        if (tile_on) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = (r & 3) + 8 * (r >> 2) + 4 * half;    // feature = plane*9 + group*3 + channel
-                if (k >= 27) continue;
-                const int q = k / 3, p = q / 3, g = q % 3;
-                float gu = (p == 2) ? nz : nx;
-                float gv = (p == 1) ? nz : ny;
-                gu = (g == 1) ? gu + offH : gu;
-                gv = (g == 2) ? gv + offH : gv;
-                const float ix = ((gu + 1.f) * (float)a.W - 1.f) / 2.f;
-                const float iy = ((gv + 1.f) * (float)a.H - 1.f) / 2.f;
-                const float x0f = floorf(ix), y0f = floorf(iy);
-                const float x1f = x0f + 1.f, y1f = y0f + 1.f;
-                const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-                const bool vx0 = (x0 >= 0) & (x0 < a.W), vx1 = (x1 >= 0) & (x1 < a.W);
-                const bool vy0 = (y0 >= 0) & (y0 < a.H), vy1 = (y1 >= 0) & (y1 < a.H);
-                float *pl = a.dplanes + (long long)k * a.H * a.W;
-                const float v = DF[0][r];
-                if (vx0 & vy0) hidden_atomic_add(pl + y0 * a.W + x0, v * ((x1f - ix) * (y1f - iy)));
-                if (vx1 & vy0) hidden_atomic_add(pl + y0 * a.W + x1, v * ((ix - x0f) * (y1f - iy)));
-                if (vx0 & vy1) hidden_atomic_add(pl + y1 * a.W + x0, v * ((x1f - ix) * (iy - y0f)));
-                if (vx1 & vy1) hidden_atomic_add(pl + y1 * a.W + x1, v * ((ix - x0f) * (iy - y0f)));
-            }
+            for (int r = 0; r < 16; ++r)
+                if (unit_of(0, r, half) < 27) hidden_store(del_rs, delp, (unsigned)(DROW_DF + unit_of(0, r, 0)) * del_stride4, DF[0][r]);
         }
     }
 #undef HL_BWD_ADVANCE
+#endif
+}
+
+// Tri-plane gradient: transpose of the bilinear lookup [renderer.py:502-531].  Sending every sample point's 27 feature deltas
+// through their four taps with global float atomics costs 108 atomics per point (measured: 1.1 ms per 262 144 points, 2/3 of the
+// backward kernel, bound by the L2 atomic units).  Instead one workgroup OWNS a 64x64-texel tile of one (plane, group) image
+// - 3 channels, 48 KB of LDS - scans all sample points of the batch (recomputing the forward pass's texel coordinates bit for bit),
+// accumulates the taps that fall into its tile with LDS atomics, and writes the tile out with plain stores: no global atomics, no
+// zero-fill, and the result depends on the run only through the order of LDS additions.
+struct ScatterArgs {
+    const float *rays_o, *rays_d, *near, *far, *bounds;
+    const float *zc, *zn;        // coarse depths: rows (R,N) or null -> linspace; new depths: tile-major
+    long long R;
+    int N, Ni, H, W;
+    const float *del;            // rows DROW_DF..+26, columns: coarse pass then new depths
+    long long del_stride;
+    float *dplanes;              // (27, H, W), overwritten
+};
+constexpr int SC_TILE = 64;
+
+__global__ __launch_bounds__(1024) void k_plane_scatter(const ScatterArgs a) {
+    __shared__ float acc[3 * SC_TILE * SC_TILE];
+    const int q = blockIdx.x, p = q / 3, g = q % 3;
+    const int tiles_x = (a.W + SC_TILE - 1) / SC_TILE;
+    const int tx0 = (int)(blockIdx.y % tiles_x) * SC_TILE, ty0 = (int)(blockIdx.y / tiles_x) * SC_TILE;
+    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += 1024) acc[i] = 0.f;
+    __syncthreads();
+    const long long tiles_n = (a.R + 31) / 32;
+    const long long colsA = tiles_n * 32 * a.N, cols = colsA + tiles_n * 32 * a.Ni;
+    const float offH = (float)(1.0 / (double)a.H);
+    const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
+    const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
+    const float *df = a.del + (long long)(DROW_DF + 3 * q) * a.del_stride;
+    for (long long col = threadIdx.x; col < cols; col += 1024) {
+        const bool passB = col >= colsA;
+        const long long lc = passB ? col - colsA : col;
+        const int S = passB ? a.Ni : a.N;
+        const long long tile = lc / (32LL * S);
+        const int rem = (int)(lc - tile * 32LL * S), s = rem >> 5;
+        const long long ray = tile * 32 + (rem & 31);
+        if (ray >= a.R) continue;
+        float z;
+        if (passB) z = a.zn[lc];
+        else if (a.zc) z = a.zc[ray * a.N + s];
+        else { const float t = linspace01(s, a.N); z = a.near[ray] * (1.f - t) + a.far[ray] * t; }
+        const float px = a.rays_o[ray * 3 + 0] + a.rays_d[ray * 3 + 0] * z;
+        const float py = a.rays_o[ray * 3 + 1] + a.rays_d[ray * 3 + 1] * z;
+        const float pz = a.rays_o[ray * 3 + 2] + a.rays_d[ray * 3 + 2] * z;
+        const float nx = 2.f * (px - bmin0) / bext0 - 1.f;
+        const float ny = 2.f * (py - bmin1) / bext1 - 1.f;
+        const float nz = 2.f * (pz - bmin2) / bext2 - 1.f;
+        float gu = (p == 2) ? nz : nx;
+        float gv = (p == 1) ? nz : ny;
+        gu = (g == 1) ? gu + offH : gu;
+        gv = (g == 2) ? gv + offH : gv;
+        const float ix = ((gu + 1.f) * (float)a.W - 1.f) / 2.f;
+        const float iy = ((gv + 1.f) * (float)a.H - 1.f) / 2.f;
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        if (!(x0f >= (float)(tx0 - 1) && x0f < (float)(tx0 + SC_TILE) && y0f >= (float)(ty0 - 1) && y0f < (float)(ty0 + SC_TILE))) continue;
+        const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+        const int x0 = (int)x0f - tx0, y0 = (int)y0f - ty0, x1 = x0 + 1, y1 = y0 + 1;     // tile coordinates
+        // inside the tile (and, through the tile's extent, inside the image: taps outside contribute nothing - zeros padding)
+        const bool vx0 = (x0 >= 0) & (x0 < SC_TILE) & (x0 + tx0 < a.W), vx1 = (x1 >= 0) & (x1 < SC_TILE) & (x1 + tx0 < a.W);
+        const bool vy0 = (y0 >= 0) & (y0 < SC_TILE) & (y0 + ty0 < a.H), vy1 = (y1 >= 0) & (y1 < SC_TILE) & (y1 + ty0 < a.H);
+        const float w_nw = (x1f - ix) * (y1f - iy), w_ne = (ix - x0f) * (y1f - iy);
+        const float w_sw = (x1f - ix) * (iy - y0f), w_se = (ix - x0f) * (iy - y0f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = df[(long long)c * a.del_stride + col];
+            float *t = acc + c * SC_TILE * SC_TILE;
+            if (vx0 & vy0) atomicAdd(t + y0 * SC_TILE + x0, v * w_nw);
+            if (vx1 & vy0) atomicAdd(t + y0 * SC_TILE + x1, v * w_ne);
+            if (vx0 & vy1) atomicAdd(t + y1 * SC_TILE + x0, v * w_sw);
+            if (vx1 & vy1) atomicAdd(t + y1 * SC_TILE + x1, v * w_se);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += 1024) {
+        const int c = i / (SC_TILE * SC_TILE), y = (i / SC_TILE) % SC_TILE + ty0, x = i % SC_TILE + tx0;
+        if (y < a.H && x < a.W) a.dplanes[((long long)(3 * q + c) * a.H + y) * a.W + x] = acc[i];
+    }
+}
+
+// Weight gradients: C[m][n] += sum_p delta[a_row0 + m][p] * act[b_row0 + n][p] over the sample points - both operands are rows of
+// the two matrices, contiguous along the reduction.  One wave owns a 32-row slab of C (all its <= 5 column tiles) over a range of
+// points; per 32 points a lane reads 64 contiguous bytes of "its" row of each operand tile (lanes 0-31: points 0-15, lanes 32-63:
+// points 16-31) and feeds 16 k-steps of v_mfma_f32_32x32x2_f32, pairing point j of the first half with point 16+j of the second.
+// The row sums of delta (the bias gradients) fall out of the A operand on the VALU.  Partial results of the point ranges are added
+// to the (zero-initialised or accumulating) gradient tensors with float atomics.
+struct WgradJob {
+    int a_row0, M, b_row0, N;   // rows of the delta / activation matrix; C is (M, N) row-major
+    float *out, *bias_out;
+};
+constexpr int WGRAD_JOBS = 7, WGRAD_MAX_NB = 5;
+struct WgradArgs {
+    WgradJob job[WGRAD_JOBS];
+    int first_wave_job[WGRAD_JOBS + 1];   // prefix sums of ceil(M/32)
+    const float *del, *act;
+    long long del_stride, act_stride, n_cols;
+    int k_per_wave;                        // points per wave (multiple of 32)
+};
+
+__global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
+#if __HIP_DEVICE_COMPILE__
+    const int lane = threadIdx.x & 63, half = lane >> 5, row = lane & 31;
+    const int wj = blockIdx.x;
+    int j = 0;
+    while (wj >= a.first_wave_job[j + 1]) ++j;
+    const WgradJob jb = a.job[j];
+    const int mt = wj - a.first_wave_job[j];
+    const long long p_lo = ((long long)blockIdx.y * 4 + (threadIdx.x >> 6)) * a.k_per_wave;
+    if (p_lo >= a.n_cols) return;
+    const long long p_hi = p_lo + a.k_per_wave < a.n_cols ? p_lo + a.k_per_wave : a.n_cols;
+    const unsigned ds4 = (unsigned)a.del_stride * 4u, as4 = (unsigned)a.act_stride * 4u;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)a.del, (short)0, (int)((unsigned)DEL_ROWS * ds4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)a.act, (short)0, (int)((unsigned)ACT_ROWS * as4), 0x00020000);
+    const unsigned OOB = 0x80000000u;   // rows past M / N read zeros
+    const int m = 32 * mt + row;
+    const unsigned a_off = m < jb.M ? (unsigned)(jb.a_row0 + m) * ds4 + 64u * half : OOB;
+    const int NB = (jb.N + 31) / 32;
+    unsigned b_off[WGRAD_MAX_NB];
+#pragma unroll
+    for (int t = 0; t < WGRAD_MAX_NB; ++t) {
+        const int n = 32 * t + row;
+        b_off[t] = (t < NB && n < jb.N) ? (unsigned)(jb.b_row0 + n) * as4 + 64u * half : OOB;
+    }
+    f32x16 acc[WGRAD_MAX_NB];
+#pragma unroll
+    for (int t = 0; t < WGRAD_MAX_NB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t &rs, unsigned off, unsigned p4, int q) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 16u * q), (int)p4, 0));
+    };
+    for (long long p = p_lo; p < p_hi; p += 32) {
+        const unsigned p4 = (unsigned)p * 4u;
+        f32x4 av[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = ld4(rd, a_off, p4, q);
+#pragma unroll
+        for (int t = 0; t < WGRAD_MAX_NB; ++t) {
+            if (t < NB) {
+                f32x4 bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[q] = ld4(ra, b_off[t], p4, q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][k], bv[q][k], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bsum += (av[q][0] + av[q][1]) + (av[q][2] + av[q][3]);
+    }
+    // C[i][n]: lane holds column n = 32 t + row and rows i = 32 mt + unit_of(0, r, half)
+#pragma unroll
+    for (int t = 0; t < WGRAD_MAX_NB; ++t) {
+        const int n = 32 * t + row;
+        if (t < NB && n < jb.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 32 * mt + unit_of(0, r, half);
+                if (i < jb.M) atomicAdd(jb.out + (long long)i * jb.N + n, acc[t][r]);
+            }
+        }
+    }
+    bsum += __shfl_xor(bsum, 32);
+    if (half == 0 && m < jb.M && jb.bias_out) atomicAdd(jb.bias_out + m, bsum);
 #endif
 }
 
@@ -1517,6 +1681,12 @@ int hl_render_composite_noise(const float *near, const float *far, const float *
 }
 
 // ---- training: backward of the evaluate-once pipeline ----
+// one workgroup per CU is resident (8 waves of ~240 VGPRs): aim at two rounds of 256 workgroups
+static inline unsigned sample_splits(unsigned ray_groups, int n_samples) {
+    unsigned s = (512 + ray_groups - 1) / ray_groups;
+    if (s > (unsigned)n_samples) s = (unsigned)n_samples;
+    return s < 1 ? 1 : s;
+}
 size_t hl_render_mlp_bwd_packed_bytes(void) { return (size_t)NCH_BWD * CHUNK_FLOATS * sizeof(float); }
 
 int hl_render_mlp_pack_bwd(const hl_render_mlp_params *p, void *packed, void *stream) {
@@ -1546,7 +1716,11 @@ int hl_render_eval_acts(const void *mlp_packed, const void *planes_packed, int H
     if (rcode) return rcode;
     a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
     a.act = act; a.act_stride = act_stride; a.act_off = act_off;
-    hipLaunchKernelGGL((k_march<true, true, 8, false, true>), dim3((unsigned)((n_rays + 255) / 256)), dim3(512), 0, (hipStream_t)stream, a);
+    const unsigned groups = (unsigned)((n_rays + 255) / 256);
+    const unsigned splits = sample_splits(groups, n_samples);
+    a.s_per = (n_samples + (int)splits - 1) / (int)splits;
+    hipLaunchKernelGGL((k_march<true, true, 8, false, true>), dim3(groups, (unsigned)((n_samples + a.s_per - 1) / a.s_per)), dim3(512), 0,
+                       (hipStream_t)stream, a);
     return hl::check_launch("k_march<eval, acts>");
 }
 
@@ -1556,10 +1730,11 @@ size_t hl_render_composite_backward_scratch_bytes(int64_t n_rays, int n_samples,
 
 int hl_render_composite_backward(const float *near, const float *far, const float *z_vals, const float *z_new, const float *rec_coarse,
                                  const float *rec_new, const float *noise, const float *g_rgb, const float *g_acc, int64_t n_rays,
-                                 int n_samples, int n_importance, unsigned flags, float *d_rec_coarse, float *d_rec_new, void *scratch,
-                                 void *stream) {
-    HL_REQUIRE(near && far && z_new && rec_coarse && rec_new && g_rgb && g_acc && d_rec_coarse && d_rec_new && scratch,
+                                 int n_samples, int n_importance, unsigned flags, float *d_rec_coarse, float *d_rec_new, float *del,
+                                 int64_t del_stride, void *scratch, void *stream) {
+    HL_REQUIRE(near && far && z_new && rec_coarse && rec_new && g_rgb && g_acc && d_rec_coarse && d_rec_new && del && scratch,
                "hl_render_composite_backward: null argument");
+    HL_REQUIRE(del_stride >= tiles32(n_rays) * 32 * (int64_t)(n_samples + n_importance), "hl_render_composite_backward: delta rows too short");
     HL_REQUIRE(n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_composite_backward: bad sizes");
     CompBwdArgs b{};
     b.c = CompArgs{near, far, z_vals, z_new, (const float4 *)rec_coarse, (const float4 *)rec_new, n_rays, n_samples, n_importance,
@@ -1568,6 +1743,7 @@ int hl_render_composite_backward(const float *near, const float *far, const floa
     b.dvc = (float4 *)d_rec_coarse; b.dvn = (float4 *)d_rec_new;
     b.sT = (float *)scratch;
     b.sSrc = (int *)scratch + tiles32(n_rays) * 32 * (size_t)(n_samples + n_importance);
+    b.del = del; b.del_stride = del_stride;
     hipLaunchKernelGGL(k_composite_bwd, dim3((unsigned)((tiles32(n_rays) * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b);
     return hl::check_launch("k_composite_bwd");
 }
@@ -1575,8 +1751,8 @@ int hl_render_composite_backward(const float *near, const float *far, const floa
 int hl_render_mlp_backward(const void *mlp_packed, const void *mlp_bwd_packed, int H, int W, const float *bounds, const float *rays_o,
                            const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
                            int n_samples, const float *d_records, const float *act, int64_t act_stride, int64_t act_off, float *del,
-                           int64_t del_stride, int64_t del_off, float *d_planes, void *stream) {
-    HL_REQUIRE(mlp_packed && mlp_bwd_packed && bounds && rays_o && rays_d && near && far && d_records && act && del && d_planes,
+                           int64_t del_stride, int64_t del_off, void *stream) {
+    HL_REQUIRE(mlp_packed && mlp_bwd_packed && bounds && rays_o && rays_d && near && far && d_records && act && del,
                "hl_render_mlp_backward: null argument");
     HL_REQUIRE(n_rays > 0 && n_samples >= 1 && H > 0 && W > 0, "hl_render_mlp_backward: bad sizes");
     const int64_t cols = tiles32(n_rays) * 32 * n_samples;
@@ -1592,9 +1768,55 @@ int hl_render_mlp_backward(const void *mlp_packed, const void *mlp_bwd_packed, i
     a.d_rec = (const float4 *)d_records;
     a.act = const_cast<float *>(act); a.act_stride = act_stride; a.act_off = act_off;
     a.del = del; a.del_stride = del_stride; a.del_off = del_off;
-    a.dplanes = d_planes;
-    hipLaunchKernelGGL(k_mlp_bwd<8>, dim3((unsigned)((n_rays + 255) / 256)), dim3(512), 0, (hipStream_t)stream, a);
+    const unsigned groups = (unsigned)((n_rays + 255) / 256);
+    const unsigned splits = sample_splits(groups, n_samples);
+    a.s_per = (n_samples + (int)splits - 1) / (int)splits;
+    hipLaunchKernelGGL(k_mlp_bwd<8>, dim3(groups, (unsigned)((n_samples + a.s_per - 1) / a.s_per)), dim3(512), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_mlp_bwd");
+}
+
+int hl_render_plane_grads(int H, int W, const float *bounds, const float *rays_o, const float *rays_d, const float *near, const float *far,
+                          const float *z_vals, const float *z_new, int64_t n_rays, int n_samples, int n_importance, const float *del,
+                          int64_t del_stride, float *d_planes, void *stream) {
+    HL_REQUIRE(bounds && rays_o && rays_d && near && far && z_new && del && d_planes, "hl_render_plane_grads: null argument");
+    HL_REQUIRE(H > 0 && W > 0 && n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_plane_grads: bad sizes");
+    HL_REQUIRE(del_stride >= tiles32(n_rays) * 32 * (int64_t)(n_samples + n_importance), "hl_render_plane_grads: delta rows too short");
+    ScatterArgs a{rays_o, rays_d, near, far, bounds, z_vals, z_new, n_rays, n_samples, n_importance, H, W, del, del_stride, d_planes};
+    const unsigned tiles = (unsigned)(((W + SC_TILE - 1) / SC_TILE) * ((H + SC_TILE - 1) / SC_TILE));
+    hipLaunchKernelGGL(k_plane_scatter, dim3(9, tiles), dim3(1024), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_plane_scatter");
+}
+
+int hl_render_weight_grads(const float *del, int64_t del_stride, const float *act, int64_t act_stride, int64_t n_cols,
+                           const hl_render_mlp_grads *g, void *stream) {
+    HL_REQUIRE(del && act && g && n_cols > 0 && n_cols % 32 == 0 && del_stride >= n_cols && act_stride >= n_cols,
+               "hl_render_weight_grads: bad argument");
+    HL_REQUIRE((int64_t)ACT_ROWS * act_stride * 4 < (1LL << 31) && (int64_t)DEL_ROWS * del_stride * 4 < (1LL << 31),
+               "hl_render_weight_grads: activation / delta matrices must stay below 2 GiB");
+    WgradArgs a{};
+    a.job[0] = WgradJob{DROW_X0, 128, ROW_F, 27, g->pts0_w, g->pts0_b};
+    a.job[1] = WgradJob{DROW_X1, 128, ROW_X0, 128, g->pts1_w, g->pts1_b};
+    a.job[2] = WgradJob{DROW_X2, 128, ROW_F, 155, g->pts2_w, g->pts2_b};       // input = [features | hidden1] = rows 0..154
+    a.job[3] = WgradJob{DROW_Y, 128, ROW_X2, 128, g->feat_w, g->feat_b};
+    a.job[4] = WgradJob{DROW_V, 64, ROW_Y, 155, g->views_w, g->views_b};        // input = [feature | view encoding]
+    a.job[5] = WgradJob{DROW_REC, 1, ROW_X2, 128, g->alpha_w, g->alpha_b};
+    a.job[6] = WgradJob{DROW_REC + 1, 3, ROW_V, 64, g->rgb_w, g->rgb_b};
+    int n = 0;
+    for (int j = 0; j < WGRAD_JOBS; ++j) {
+        HL_REQUIRE(a.job[j].out && a.job[j].bias_out, "hl_render_weight_grads: null gradient pointer %d", j);
+        a.first_wave_job[j] = n;
+        n += (a.job[j].M + 31) / 32;
+    }
+    a.first_wave_job[WGRAD_JOBS] = n;
+    a.del = del; a.act = act; a.del_stride = del_stride; a.act_stride = act_stride; a.n_cols = n_cols;
+    // ~2500 waves: 20 row slabs x 128 point ranges, at least 1024 points each
+    int64_t ranges = 128;
+    int64_t per = ((n_cols + ranges - 1) / ranges + 31) / 32 * 32;
+    if (per < 1024) per = 1024;
+    a.k_per_wave = (int)per;
+    const unsigned gy = (unsigned)((n_cols + per * 4 - 1) / (per * 4));
+    hipLaunchKernelGGL(k_wgrad, dim3((unsigned)n, gy), dim3(256), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_wgrad");
 }
 
 int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,

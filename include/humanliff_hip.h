@@ -131,20 +131,31 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
  *   activations (630 rows): [0,27) tri-plane features | [27,155) softplus(pts_linears.1) | [155,283) softplus(pts_linears.0) |
  *                           [283,411) softplus(pts_linears.2) | [411,539) feature_linear | [539,566) view encoding |
  *                           [566,630) softplus(views_linear)
- *   deltas (576 rows, dL/d pre-activation): [0,128) pts_linears.0 | [128,256) pts_linears.1 | [256,384) pts_linears.2 |
- *                           [384,512) feature_linear | [512,576) views_linear
+ *   deltas (607 rows, dL/d pre-activation): [0,128) pts_linears.0 | [128,256) pts_linears.1 | [256,384) pts_linears.2 |
+ *                           [384,512) feature_linear | [512,576) views_linear | 576 alpha_linear | [577,580) rgb_linear |
+ *                           [580,607) dL/d tri-plane features
  * so that every weight gradient is one product delta_rows x activation_rows^T over the sample points (e.g. pts_linears.2.weight =
- * deltas[256:384] x activations[0:155]^T; alpha_linear / rgb_linear take their deltas from the d_records columns) and every bias
- * gradient a row sum.
+ * deltas[256:384] x activations[0:155]^T) and every bias gradient a row sum: hl_render_weight_grads.
  *   hl_render_composite_noise     hl_render_composite with `noise` (R, n_samples+n_importance) added to the raw density of sorted
  *                                 sample s of each ray (renderer.py:212, randn_like in training mode); NULL = none
  *   hl_render_eval_acts           hl_render_eval that also writes the activation matrix
  *   hl_render_composite_backward  g_rgb (R,3), g_acc (R) -> d_records of both passes (float[4] = d/d(sigma, r, g, b) raw, record
- *                                 layout; zero on padding rays); scratch: hl_render_composite_backward_scratch_bytes()
- *   hl_render_mlp_backward        one pass's d_records + activations -> its delta matrix, and d_planes (27,H,W) += the tri-plane
- *                                 gradient (float atomics: summation order, hence the last bits, vary from run to run)
+ *                                 layout; zero on padding rays) and rows 576..579 of the delta matrix `del` (columns: coarse pass,
+ *                                 then the new depths); scratch: hl_render_composite_backward_scratch_bytes()
+ *   hl_render_mlp_backward        one pass's d_records + activations -> its columns of the delta matrix
+ *   hl_render_plane_grads         feature deltas of both passes -> d_planes (27,H,W), overwritten: the transposed bilinear lookup;
+ *                                 each workgroup owns a tile of texels and accumulates in LDS (no global atomics; LDS float atomics:
+ *                                 summation order, hence the last bits, vary from run to run)
  *   hl_render_mlp_pack_bwd        transposed weights for hl_render_mlp_backward (redo after every optimizer step, like
- *                                 hl_render_mlp_pack) */
+ *                                 hl_render_mlp_pack)
+ *   hl_render_weight_grads        all 14 parameter gradients from the two matrices over n_cols sample points (multiple of 32), ADDED
+ *                                 to the tensors of `grads` (PyTorch layouts, zero them first) with float atomics */
+typedef struct hl_render_mlp_grads {
+    float *pts0_w, *pts0_b, *pts1_w, *pts1_b, *pts2_w, *pts2_b, *feat_w, *feat_b, *alpha_w, *alpha_b, *views_w, *views_b, *rgb_w,
+        *rgb_b;   /* same order and shapes as hl_render_mlp_params */
+} hl_render_mlp_grads;
+int hl_render_weight_grads(const float *del, int64_t del_stride, const float *act, int64_t act_stride, int64_t n_cols,
+                           const hl_render_mlp_grads *grads, void *stream);
 int hl_render_composite_noise(const float *near, const float *far, const float *z_vals, const float *z_new, const float *rec_coarse,
                               const float *rec_new, const float *noise, int64_t n_rays, int n_samples, int n_importance,
                               unsigned flags, float *rgb, float *acc, float *depth, void *stream);
@@ -158,12 +169,15 @@ size_t hl_render_composite_backward_scratch_bytes(int64_t n_rays, int n_samples,
 int hl_render_composite_backward(const float *near, const float *far, const float *z_vals, const float *z_new,
                                  const float *rec_coarse, const float *rec_new, const float *noise, const float *g_rgb,
                                  const float *g_acc, int64_t n_rays, int n_samples, int n_importance, unsigned flags,
-                                 float *d_rec_coarse, float *d_rec_new, void *scratch, void *stream);
+                                 float *d_rec_coarse, float *d_rec_new, float *del, int64_t del_stride, void *scratch,
+                                 void *stream);
 int hl_render_mlp_backward(const void *mlp_packed, const void *mlp_bwd_packed, int H, int W, const float *bounds,
                            const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z,
                            int z_tiled, int64_t n_rays, int n_samples, const float *d_records, const float *act,
-                           int64_t act_stride, int64_t act_off, float *del, int64_t del_stride, int64_t del_off, float *d_planes,
-                           void *stream);
+                           int64_t act_stride, int64_t act_off, float *del, int64_t del_stride, int64_t del_off, void *stream);
+int hl_render_plane_grads(int H, int W, const float *bounds, const float *rays_o, const float *rays_d, const float *near,
+                          const float *far, const float *z_vals /* coarse rows or NULL */, const float *z_new, int64_t n_rays,
+                          int n_samples, int n_importance, const float *del, int64_t del_stride, float *d_planes, void *stream);
 
 /* Per-view ray generation on the device.  Replaces get_rays
  * (human_diffusion/SynBodyView_datasets.py:316-329), the float32 casts and the near=0 / far=1 fill of
