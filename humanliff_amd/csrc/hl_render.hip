@@ -1372,8 +1372,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 
 // Tri-plane gradient: transpose of the bilinear lookup [renderer.py:502-531].  Sending every sample point's 27 feature deltas
 // through their four taps with global float atomics costs 108 atomics per point (measured: 1.1 ms per 262 144 points, 2/3 of the
-// backward kernel, bound by the L2 atomic units).  Instead one workgroup OWNS a 64x64-texel tile of one (plane, group) image
-// - 3 channels, 48 KB of LDS - scans all sample points of the batch (recomputing the forward pass's texel coordinates bit for bit),
+// backward kernel, bound by the L2 atomic units).  Instead one workgroup OWNS a 32x32-texel tile of one (plane, group) image
+// - 3 channels, 12 KB of LDS - scans all sample points of the batch (recomputing the forward pass's texel coordinates bit for bit),
 // accumulates the taps that fall into its tile with LDS atomics, and writes the tile out with plain stores: no global atomics, no
 // zero-fill, and the result depends on the run only through the order of LDS additions.
 struct ScatterArgs {
@@ -1385,36 +1385,24 @@ struct ScatterArgs {
     long long del_stride;
     float *dplanes;              // (27, H, W), overwritten
 };
-constexpr int SC_TILE = 64;
+constexpr int SC_TILE = 32, SC_THREADS = 512;
 
-__global__ __launch_bounds__(1024) void k_plane_scatter(const ScatterArgs a) {
+__global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs a) {
     __shared__ float acc[3 * SC_TILE * SC_TILE];
     const int q = blockIdx.x, p = q / 3, g = q % 3;
     const int tiles_x = (a.W + SC_TILE - 1) / SC_TILE;
     const int tx0 = (int)(blockIdx.y % tiles_x) * SC_TILE, ty0 = (int)(blockIdx.y / tiles_x) * SC_TILE;
-    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += 1024) acc[i] = 0.f;
+    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) acc[i] = 0.f;
     __syncthreads();
     const long long tiles_n = (a.R + 31) / 32;
-    const long long colsA = tiles_n * 32 * a.N, cols = colsA + tiles_n * 32 * a.Ni;
+    const long long colsA = tiles_n * 32 * a.N;
     const float offH = (float)(1.0 / (double)a.H);
     const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
     const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
     const float *df = a.del + (long long)(DROW_DF + 3 * q) * a.del_stride;
-    for (long long col = threadIdx.x; col < cols; col += 1024) {
-        const bool passB = col >= colsA;
-        const long long lc = passB ? col - colsA : col;
-        const int S = passB ? a.Ni : a.N;
-        const long long tile = lc / (32LL * S);
-        const int rem = (int)(lc - tile * 32LL * S), s = rem >> 5;
-        const long long ray = tile * 32 + (rem & 31);
-        if (ray >= a.R) continue;
-        float z;
-        if (passB) z = a.zn[lc];
-        else if (a.zc) z = a.zc[ray * a.N + s];
-        else { const float t = linspace01(s, a.N); z = a.near[ray] * (1.f - t) + a.far[ray] * t; }
-        const float px = a.rays_o[ray * 3 + 0] + a.rays_d[ray * 3 + 0] * z;
-        const float py = a.rays_o[ray * 3 + 1] + a.rays_d[ray * 3 + 1] * z;
-        const float pz = a.rays_o[ray * 3 + 2] + a.rays_d[ray * 3 + 2] * z;
+    // texel coordinates of the point at depth z of a ray - the forward pass's arithmetic, bit for bit
+    auto texel = [&](const float (&o)[3], const float (&d)[3], float z, float &ix, float &iy) {
+        const float px = o[0] + d[0] * z, py = o[1] + d[1] * z, pz = o[2] + d[2] * z;
         const float nx = 2.f * (px - bmin0) / bext0 - 1.f;
         const float ny = 2.f * (py - bmin1) / bext1 - 1.f;
         const float nz = 2.f * (pz - bmin2) / bext2 - 1.f;
@@ -1422,29 +1410,77 @@ __global__ __launch_bounds__(1024) void k_plane_scatter(const ScatterArgs a) {
         float gv = (p == 1) ? nz : ny;
         gu = (g == 1) ? gu + offH : gu;
         gv = (g == 2) ? gv + offH : gv;
-        const float ix = ((gu + 1.f) * (float)a.W - 1.f) / 2.f;
-        const float iy = ((gv + 1.f) * (float)a.H - 1.f) / 2.f;
-        const float x0f = floorf(ix), y0f = floorf(iy);
-        if (!(x0f >= (float)(tx0 - 1) && x0f < (float)(tx0 + SC_TILE) && y0f >= (float)(ty0 - 1) && y0f < (float)(ty0 + SC_TILE))) continue;
-        const float x1f = x0f + 1.f, y1f = y0f + 1.f;
-        const int x0 = (int)x0f - tx0, y0 = (int)y0f - ty0, x1 = x0 + 1, y1 = y0 + 1;     // tile coordinates
-        // inside the tile (and, through the tile's extent, inside the image: taps outside contribute nothing - zeros padding)
-        const bool vx0 = (x0 >= 0) & (x0 < SC_TILE) & (x0 + tx0 < a.W), vx1 = (x1 >= 0) & (x1 < SC_TILE) & (x1 + tx0 < a.W);
-        const bool vy0 = (y0 >= 0) & (y0 < SC_TILE) & (y0 + ty0 < a.H), vy1 = (y1 >= 0) & (y1 < SC_TILE) & (y1 + ty0 < a.H);
-        const float w_nw = (x1f - ix) * (y1f - iy), w_ne = (ix - x0f) * (y1f - iy);
-        const float w_sw = (x1f - ix) * (iy - y0f), w_se = (ix - x0f) * (iy - y0f);
+        ix = ((gu + 1.f) * (float)a.W - 1.f) / 2.f;
+        iy = ((gv + 1.f) * (float)a.H - 1.f) / 2.f;
+    };
+    // one thread per ray: the texel coordinates are linear in the depth, so the samples that can touch this tile lie in one depth
+    // interval [za, zb] (computed with a margin; the exact test below decides) and the scan of the ray's depths is a load and two
+    // compares per sample outside it
+    for (long long ray = threadIdx.x; ray < a.R; ray += SC_THREADS) {
+        const long long tile = ray >> 5;
+        const int rl = (int)(ray & 31);
+        const float o[3] = {a.rays_o[ray * 3 + 0], a.rays_o[ray * 3 + 1], a.rays_o[ray * 3 + 2]};
+        const float d[3] = {a.rays_d[ray * 3 + 0], a.rays_d[ray * 3 + 1], a.rays_d[ray * 3 + 2]};
+        const float nr = a.near[ray], fr = a.far[ray];
+        float x_a, y_a, x_b, y_b;
+        texel(o, d, 0.f, x_a, y_a);
+        texel(o, d, 1.f, x_b, y_b);
+        float za = -3.0e38f, zb = 3.0e38f;
+        auto clip = [&](float c0, float slope, float lo, float hi) {       // lo <= c0 + slope z < hi
+            if (fabsf(slope) < 1e-9f) { if (c0 < lo || c0 >= hi) { za = 1.f; zb = 0.f; } return; }
+            const float z1 = (lo - c0) / slope, z2 = (hi - c0) / slope;
+            za = fmaxf(za, fminf(z1, z2));
+            zb = fminf(zb, fmaxf(z1, z2));
+        };
+        clip(x_a, x_b - x_a, (float)tx0 - 1.05f, (float)(tx0 + SC_TILE) + 0.05f);
+        clip(y_a, y_b - y_a, (float)ty0 - 1.05f, (float)(ty0 + SC_TILE) + 0.05f);
+        if (!(za <= zb)) continue;
+        za -= 1e-4f * fabsf(za) + 1e-6f;
+        zb += 1e-4f * fabsf(zb) + 1e-6f;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int S = pass ? a.Ni : a.N;
+            const long long col0 = (pass ? colsA : 0) + tile * 32LL * S + rl;
+            const float *zt = pass ? a.zn + tile * 32LL * S + rl : nullptr;
+            for (int s0 = 0; s0 < S; s0 += 8) {
+                float zz[8];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float v = df[(long long)c * a.del_stride + col];
-            float *t = acc + c * SC_TILE * SC_TILE;
-            if (vx0 & vy0) atomicAdd(t + y0 * SC_TILE + x0, v * w_nw);
-            if (vx1 & vy0) atomicAdd(t + y0 * SC_TILE + x1, v * w_ne);
-            if (vx0 & vy1) atomicAdd(t + y1 * SC_TILE + x0, v * w_sw);
-            if (vx1 & vy1) atomicAdd(t + y1 * SC_TILE + x1, v * w_se);
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int si = s0 + jj < S ? s0 + jj : S - 1;
+                    if (pass) zz[jj] = zt[32LL * si];
+                    else if (a.zc) zz[jj] = a.zc[ray * a.N + si];
+                    else { const float t = linspace01(si, a.N); zz[jj] = nr * (1.f - t) + fr * t; }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float z = zz[jj];
+                    if (s0 + jj >= S || z < za || z > zb) continue;
+                    const long long col = col0 + 32LL * (s0 + jj);
+                    float ix, iy;
+                    texel(o, d, z, ix, iy);
+                    const float x0f = floorf(ix), y0f = floorf(iy);
+                    const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+                    if (!(x0f >= (float)(tx0 - 1) && x0f < (float)(tx0 + SC_TILE) && y0f >= (float)(ty0 - 1) && y0f < (float)(ty0 + SC_TILE))) continue;
+                    const int x0 = (int)x0f - tx0, y0 = (int)y0f - ty0, x1 = x0 + 1, y1 = y0 + 1;     // tile coordinates
+                    // inside the tile (and, through the tile's extent, inside the image: taps outside contribute nothing - zeros padding)
+                    const bool vx0 = (x0 >= 0) & (x0 < SC_TILE) & (x0 + tx0 < a.W), vx1 = (x1 >= 0) & (x1 < SC_TILE) & (x1 + tx0 < a.W);
+                    const bool vy0 = (y0 >= 0) & (y0 < SC_TILE) & (y0 + ty0 < a.H), vy1 = (y1 >= 0) & (y1 < SC_TILE) & (y1 + ty0 < a.H);
+                    const float w_nw = (x1f - ix) * (y1f - iy), w_ne = (ix - x0f) * (y1f - iy);
+                    const float w_sw = (x1f - ix) * (iy - y0f), w_se = (ix - x0f) * (iy - y0f);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = df[(long long)c * a.del_stride + col];
+                        float *t = acc + c * SC_TILE * SC_TILE;
+                        if (vx0 & vy0) atomicAdd(t + y0 * SC_TILE + x0, v * w_nw);
+                        if (vx1 & vy0) atomicAdd(t + y0 * SC_TILE + x1, v * w_ne);
+                        if (vx0 & vy1) atomicAdd(t + y1 * SC_TILE + x0, v * w_sw);
+                        if (vx1 & vy1) atomicAdd(t + y1 * SC_TILE + x1, v * w_se);
+                    }
+                }
+            }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += 1024) {
+    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) {
         const int c = i / (SC_TILE * SC_TILE), y = (i / SC_TILE) % SC_TILE + ty0, x = i % SC_TILE + tx0;
         if (y < a.H && x < a.W) a.dplanes[((long long)(3 * q + c) * a.H + y) * a.W + x] = acc[i];
     }
@@ -1783,7 +1819,7 @@ int hl_render_plane_grads(int H, int W, const float *bounds, const float *rays_o
     HL_REQUIRE(del_stride >= tiles32(n_rays) * 32 * (int64_t)(n_samples + n_importance), "hl_render_plane_grads: delta rows too short");
     ScatterArgs a{rays_o, rays_d, near, far, bounds, z_vals, z_new, n_rays, n_samples, n_importance, H, W, del, del_stride, d_planes};
     const unsigned tiles = (unsigned)(((W + SC_TILE - 1) / SC_TILE) * ((H + SC_TILE - 1) / SC_TILE));
-    hipLaunchKernelGGL(k_plane_scatter, dim3(9, tiles), dim3(1024), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_plane_scatter, dim3(9, tiles), dim3(SC_THREADS), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_plane_scatter");
 }
 
