@@ -1487,90 +1487,107 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs 
 }
 
 // Weight gradients: C[m][n] += sum_p delta[a_row0 + m][p] * act[b_row0 + n][p] over the sample points - both operands are rows of
-// the two matrices, contiguous along the reduction.  One wave owns a 32-row slab of C (all its <= 5 column tiles) over a range of
-// points; per 32 points a lane reads 64 contiguous bytes of "its" row of each operand tile (lanes 0-31: points 0-15, lanes 32-63:
-// points 16-31) and feeds 16 k-steps of v_mfma_f32_32x32x2_f32, pairing point j of the first half with point 16+j of the second.
-// The row sums of delta (the bias gradients) fall out of the A operand on the VALU.  Partial results of the point ranges are added
-// to the (zero-initialised or accumulating) gradient tensors with float atomics.
+// the two matrices, contiguous along the reduction.  A workgroup takes one layer and a range of points; per 32 points it stages the
+// layer's delta rows (<= 128) and activation rows (<= 155) through LDS with full-line loads (8 lanes x 16 B per row), then wave w
+// multiplies delta rows 32w..32w+31 against all activation rows: a lane reads 16 points of "its" row per operand tile (lanes 0-31:
+// points 0-15, lanes 32-63: points 16-31; row pitch 36 floats keeps the 16-byte reads conflict-free) and feeds 16 k-steps of
+// v_mfma_f32_32x32x2_f32, pairing point j with point 16+j.  The row sums of delta (the bias gradients) fall out of the A operand on
+// the VALU.  Partial results of the point ranges are added to the gradient tensors with float atomics.
 struct WgradJob {
     int a_row0, M, b_row0, N;   // rows of the delta / activation matrix; C is (M, N) row-major
     float *out, *bias_out;
 };
-constexpr int WGRAD_JOBS = 7, WGRAD_MAX_NB = 5;
+constexpr int WGRAD_JOBS = 7, WGRAD_MAX_NB = 5, WG_PITCH = 36, WG_AROWS = 128, WG_ROWS = WG_AROWS + 32 * WGRAD_MAX_NB, WG_LD = WG_ROWS / 32;
 struct WgradArgs {
     WgradJob job[WGRAD_JOBS];
-    int first_wave_job[WGRAD_JOBS + 1];   // prefix sums of ceil(M/32)
     const float *del, *act;
     long long del_stride, act_stride, n_cols;
-    int k_per_wave;                        // points per wave (multiple of 32)
+    int k_per_wg;                          // points per workgroup (multiple of 32)
 };
 
 __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 #if __HIP_DEVICE_COMPILE__
-    const int lane = threadIdx.x & 63, half = lane >> 5, row = lane & 31;
-    const int wj = blockIdx.x;
-    int j = 0;
-    while (wj >= a.first_wave_job[j + 1]) ++j;
-    const WgradJob jb = a.job[j];
-    const int mt = wj - a.first_wave_job[j];
-    const long long p_lo = ((long long)blockIdx.y * 4 + (threadIdx.x >> 6)) * a.k_per_wave;
+    __shared__ __attribute__((aligned(16))) float lds[WG_ROWS * WG_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, row = lane & 31;
+    const WgradJob jb = a.job[blockIdx.x];
+    const long long p_lo = (long long)blockIdx.y * a.k_per_wg;
     if (p_lo >= a.n_cols) return;
-    const long long p_hi = p_lo + a.k_per_wave < a.n_cols ? p_lo + a.k_per_wave : a.n_cols;
+    const long long p_hi = p_lo + a.k_per_wg < a.n_cols ? p_lo + a.k_per_wg : a.n_cols;
     const unsigned ds4 = (unsigned)a.del_stride * 4u, as4 = (unsigned)a.act_stride * 4u;
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)a.del, (short)0, (int)((unsigned)DEL_ROWS * ds4), 0x00020000);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)a.act, (short)0, (int)((unsigned)ACT_ROWS * as4), 0x00020000);
     const unsigned OOB = 0x80000000u;   // rows past M / N read zeros
-    const int m = 32 * mt + row;
-    const unsigned a_off = m < jb.M ? (unsigned)(jb.a_row0 + m) * ds4 + 64u * half : OOB;
-    const int NB = (jb.N + 31) / 32;
-    unsigned b_off[WGRAD_MAX_NB];
+    const int NB = (jb.N + 31) / 32, MT = (jb.M + 31) / 32;
+    // staging: thread = (row group tid >> 3, 16-byte piece tid & 7); pass i covers staged rows 32 i .. 32 i + 31
+    const int piece = tid & 7, rg = tid >> 3;
+    unsigned goff[WG_LD];
 #pragma unroll
-    for (int t = 0; t < WGRAD_MAX_NB; ++t) {
-        const int n = 32 * t + row;
-        b_off[t] = (t < NB && n < jb.N) ? (unsigned)(jb.b_row0 + n) * as4 + 64u * half : OOB;
+    for (int i = 0; i < WG_LD; ++i) {
+        const int r = 32 * i + rg;
+        if (i < WG_AROWS / 32) goff[i] = r < jb.M ? (unsigned)(jb.a_row0 + r) * ds4 + 16u * piece : OOB;
+        else goff[i] = (r - WG_AROWS) < jb.N ? (unsigned)(jb.b_row0 + r - WG_AROWS) * as4 + 16u * piece : OOB;
     }
+    f32x4 st[WG_LD];
+    auto fetch = [&](long long p) {
+        const int p4 = (int)((unsigned)p * 4u);
+#pragma unroll
+        for (int i = 0; i < WG_LD; ++i) {
+            const bool used = i < WG_AROWS / 32 ? i < MT : (i - WG_AROWS / 32) < NB;
+            if (used) st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i < WG_AROWS / 32 ? rd : ra, (int)goff[i], p4, 0));
+        }
+    };
     f32x16 acc[WGRAD_MAX_NB];
 #pragma unroll
     for (int t = 0; t < WGRAD_MAX_NB; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
-    auto ld4 = [&](const __amdgpu_buffer_rsrc_t &rs, unsigned off, unsigned p4, int q) -> f32x4 {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 16u * q), (int)p4, 0));
-    };
+    f32x4 *ldsv = reinterpret_cast<f32x4 *>(lds);
+    fetch(p_lo);
     for (long long p = p_lo; p < p_hi; p += 32) {
-        const unsigned p4 = (unsigned)p * 4u;
-        f32x4 av[4];
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) av[q] = ld4(rd, a_off, p4, q);
-#pragma unroll
-        for (int t = 0; t < WGRAD_MAX_NB; ++t) {
-            if (t < NB) {
-                f32x4 bv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bv[q] = ld4(ra, b_off[t], p4, q);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][k], bv[q][k], acc[t], 0, 0, 0);
-            }
+        for (int i = 0; i < WG_LD; ++i) {
+            const bool used = i < WG_AROWS / 32 ? i < MT : (i - WG_AROWS / 32) < NB;
+            if (used) ldsv[(32 * i + rg) * (WG_PITCH / 4) + piece] = st[i];
         }
+        __syncthreads();
+        if (p + 32 < p_hi) fetch(p + 32);
+        if (wave < MT) {
+            f32x4 av[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bsum += (av[q][0] + av[q][1]) + (av[q][2] + av[q][3]);
+            for (int q = 0; q < 4; ++q) av[q] = ldsv[(32 * wave + row) * (WG_PITCH / 4) + 4 * half + q];
+#pragma unroll
+            for (int t = 0; t < WGRAD_MAX_NB; ++t) {
+                if (t < NB) {
+                    f32x4 bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bv[q] = ldsv[(WG_AROWS + 32 * t + row) * (WG_PITCH / 4) + 4 * half + q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][k], bv[q][k], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bsum += (av[q][0] + av[q][1]) + (av[q][2] + av[q][3]);
+        }
     }
-    // C[i][n]: lane holds column n = 32 t + row and rows i = 32 mt + unit_of(0, r, half)
+    if (wave >= MT) return;
+    // C[i][n]: lane holds column n = 32 t + row and rows i = 32 wave + unit_of(0, r, half)
 #pragma unroll
     for (int t = 0; t < WGRAD_MAX_NB; ++t) {
         const int n = 32 * t + row;
         if (t < NB && n < jb.N) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = 32 * mt + unit_of(0, r, half);
+                const int i = 32 * wave + unit_of(0, r, half);
                 if (i < jb.M) atomicAdd(jb.out + (long long)i * jb.N + n, acc[t][r]);
             }
         }
     }
     bsum += __shfl_xor(bsum, 32);
+    const int m = 32 * wave + row;
     if (half == 0 && m < jb.M && jb.bias_out) atomicAdd(jb.bias_out + m, bsum);
 #endif
 }
@@ -1837,21 +1854,13 @@ int hl_render_weight_grads(const float *del, int64_t del_stride, const float *ac
     a.job[4] = WgradJob{DROW_V, 64, ROW_Y, 155, g->views_w, g->views_b};        // input = [feature | view encoding]
     a.job[5] = WgradJob{DROW_REC, 1, ROW_X2, 128, g->alpha_w, g->alpha_b};
     a.job[6] = WgradJob{DROW_REC + 1, 3, ROW_V, 64, g->rgb_w, g->rgb_b};
-    int n = 0;
-    for (int j = 0; j < WGRAD_JOBS; ++j) {
-        HL_REQUIRE(a.job[j].out && a.job[j].bias_out, "hl_render_weight_grads: null gradient pointer %d", j);
-        a.first_wave_job[j] = n;
-        n += (a.job[j].M + 31) / 32;
-    }
-    a.first_wave_job[WGRAD_JOBS] = n;
+    for (int j = 0; j < WGRAD_JOBS; ++j) HL_REQUIRE(a.job[j].out && a.job[j].bias_out, "hl_render_weight_grads: null gradient pointer %d", j);
     a.del = del; a.act = act; a.del_stride = del_stride; a.act_stride = act_stride; a.n_cols = n_cols;
-    // ~2500 waves: 20 row slabs x 128 point ranges, at least 1024 points each
-    int64_t ranges = 128;
-    int64_t per = ((n_cols + ranges - 1) / ranges + 31) / 32 * 32;
+    // 7 layers x 256 point ranges of at least 1024 points
+    int64_t per = ((n_cols + 255) / 256 + 31) / 32 * 32;
     if (per < 1024) per = 1024;
-    a.k_per_wave = (int)per;
-    const unsigned gy = (unsigned)((n_cols + per * 4 - 1) / (per * 4));
-    hipLaunchKernelGGL(k_wgrad, dim3((unsigned)n, gy), dim3(256), 0, (hipStream_t)stream, a);
+    a.k_per_wg = (int)per;
+    hipLaunchKernelGGL(k_wgrad, dim3(WGRAD_JOBS, (unsigned)((n_cols + per - 1) / per)), dim3(256), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_wgrad");
 }
 
