@@ -97,8 +97,10 @@ class RenderRaysFunction(torch.autograd.Function):
                                             T32 * N, p(delta), P, T32 * N, st), "hl_render_mlp_backward")
         d_planes = torch.empty((27, H, W), dtype=torch.float32, device=dev)
         if ctx.needs_input_grad[2]:
-            _lib.check(L.hl_render_plane_grads(H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), p(zn), R, N, Ni, p(delta), P, p(d_planes), st),
-                       "hl_render_plane_grads")
+            from .renderer import untile_rows
+            zr = untile_rows(zn, R, Ni).contiguous()      # the scatter walks one ray per wave: give it the depths of a ray in one line
+            _lib.check(L.hl_render_plane_grads(H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), p(zr), 1, R, N, Ni, p(delta), P, p(d_planes),
+                                               st), "hl_render_plane_grads")
         # all 14 parameter gradients: rows of `delta` x rows of `act` over the sample points (include/humanliff_hip.h lists the rows)
         flat = torch.zeros(sum(t.numel() for t in mlp), dtype=torch.float32, device=dev)
         grads, o = [], 0

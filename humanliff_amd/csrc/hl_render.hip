@@ -1378,7 +1378,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 // zero-fill, and the result depends on the run only through the order of LDS additions.
 struct ScatterArgs {
     const float *rays_o, *rays_d, *near, *far, *bounds;
-    const float *zc, *zn;        // coarse depths: rows (R,N) or null -> linspace; new depths: tile-major
+    const float *zc, *zn;        // coarse depths: rows (R,N) or null -> linspace; new depths: rows (R,Ni) (zn_rows) or tile-major
+    int zn_rows;
     long long R;
     int N, Ni, H, W;
     const float *del;            // rows DROW_DF..+26, columns: coarse pass then new depths
@@ -1413,71 +1414,79 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs 
         ix = ((gu + 1.f) * (float)a.W - 1.f) / 2.f;
         iy = ((gv + 1.f) * (float)a.H - 1.f) / 2.f;
     };
-    // one thread per ray: the texel coordinates are linear in the depth, so the samples that can touch this tile lie in one depth
-    // interval [za, zb] (computed with a margin; the exact test below decides) and the scan of the ray's depths is a load and two
-    // compares per sample outside it
-    for (long long ray = threadIdx.x; ray < a.R; ray += SC_THREADS) {
-        const long long tile = ray >> 5;
-        const int rl = (int)(ray & 31);
-        const float o[3] = {a.rays_o[ray * 3 + 0], a.rays_o[ray * 3 + 1], a.rays_o[ray * 3 + 2]};
-        const float d[3] = {a.rays_d[ray * 3 + 0], a.rays_d[ray * 3 + 1], a.rays_d[ray * 3 + 2]};
-        const float nr = a.near[ray], fr = a.far[ray];
+    // One WAVE per ray, lanes = 64 consecutive samples.  The texel coordinates are linear in the depth, so the samples that can touch
+    // this tile lie in one depth interval [za, zb] (computed with a margin; the exact test below decides): most rays miss the tile
+    // (tested 64 rays at a time, one per lane), and along a ray that crosses it the lanes inside the interval are neighbours
+    // (a thread-per-ray layout puts 64 unrelated rays in a wave and executes the tap code for nearly every sample of every ray).
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    auto bcast = [](float v, int j) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); };
+    for (long long base = (long long)wv * 64; base < a.R; base += SC_THREADS) {
+      // 64 rays at a time, one per lane: load them and intersect them with the tile in parallel, then visit the hits one by one
+      const long long lray = base + lane < a.R ? base + lane : a.R - 1;
+      const float lo_[3] = {a.rays_o[lray * 3 + 0], a.rays_o[lray * 3 + 1], a.rays_o[lray * 3 + 2]};
+      const float ld_[3] = {a.rays_d[lray * 3 + 0], a.rays_d[lray * 3 + 1], a.rays_d[lray * 3 + 2]};
+      const float lnr = a.near[lray], lfr = a.far[lray];
+      float lza = -3.0e38f, lzb = 3.0e38f;
+      {
         float x_a, y_a, x_b, y_b;
-        texel(o, d, 0.f, x_a, y_a);
-        texel(o, d, 1.f, x_b, y_b);
-        float za = -3.0e38f, zb = 3.0e38f;
+        texel(lo_, ld_, 0.f, x_a, y_a);
+        texel(lo_, ld_, 1.f, x_b, y_b);
         auto clip = [&](float c0, float slope, float lo, float hi) {       // lo <= c0 + slope z < hi
-            if (fabsf(slope) < 1e-9f) { if (c0 < lo || c0 >= hi) { za = 1.f; zb = 0.f; } return; }
+            if (fabsf(slope) < 1e-9f) { if (c0 < lo || c0 >= hi) { lza = 1.f; lzb = 0.f; } return; }
             const float z1 = (lo - c0) / slope, z2 = (hi - c0) / slope;
-            za = fmaxf(za, fminf(z1, z2));
-            zb = fminf(zb, fmaxf(z1, z2));
+            lza = fmaxf(lza, fminf(z1, z2));
+            lzb = fminf(lzb, fmaxf(z1, z2));
         };
         clip(x_a, x_b - x_a, (float)tx0 - 1.05f, (float)(tx0 + SC_TILE) + 0.05f);
         clip(y_a, y_b - y_a, (float)ty0 - 1.05f, (float)(ty0 + SC_TILE) + 0.05f);
-        if (!(za <= zb)) continue;
-        za -= 1e-4f * fabsf(za) + 1e-6f;
-        zb += 1e-4f * fabsf(zb) + 1e-6f;
+        lza -= 1e-4f * fabsf(lza) + 1e-6f;
+        lzb += 1e-4f * fabsf(lzb) + 1e-6f;
+      }
+      unsigned long long hits = __ballot((lza <= lzb) && (base + lane < a.R));
+      while (hits) {
+        const int j = __builtin_ctzll(hits);
+        hits &= hits - 1;
+        const long long ray = base + j;
+        const long long tile = ray >> 5;
+        const int rl = (int)(ray & 31);
+        const float o[3] = {bcast(lo_[0], j), bcast(lo_[1], j), bcast(lo_[2], j)};
+        const float d[3] = {bcast(ld_[0], j), bcast(ld_[1], j), bcast(ld_[2], j)};
+        const float nr = bcast(lnr, j), fr = bcast(lfr, j), za = bcast(lza, j), zb = bcast(lzb, j);
         for (int pass = 0; pass < 2; ++pass) {
             const int S = pass ? a.Ni : a.N;
             const long long col0 = (pass ? colsA : 0) + tile * 32LL * S + rl;
-            const float *zt = pass ? a.zn + tile * 32LL * S + rl : nullptr;
-            for (int s0 = 0; s0 < S; s0 += 8) {
-                float zz[8];
+            for (int s0 = 0; s0 < S; s0 += 64) {
+                const int si = s0 + lane;
+                if (si >= S) continue;
+                float z;
+                if (pass) z = a.zn_rows ? a.zn[ray * a.Ni + si] : a.zn[tile * 32LL * S + rl + 32LL * si];
+                else if (a.zc) z = a.zc[ray * a.N + si];
+                else { const float t = linspace01(si, a.N); z = nr * (1.f - t) + fr * t; }
+                if (z < za || z > zb) continue;
+                const long long col = col0 + 32LL * si;
+                float ix, iy;
+                texel(o, d, z, ix, iy);
+                const float x0f = floorf(ix), y0f = floorf(iy);
+                const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+                if (!(x0f >= (float)(tx0 - 1) && x0f < (float)(tx0 + SC_TILE) && y0f >= (float)(ty0 - 1) && y0f < (float)(ty0 + SC_TILE))) continue;
+                const int x0 = (int)x0f - tx0, y0 = (int)y0f - ty0, x1 = x0 + 1, y1 = y0 + 1;     // tile coordinates
+                // inside the tile (and, through the tile's extent, inside the image: taps outside contribute nothing - zeros padding)
+                const bool vx0 = (x0 >= 0) & (x0 < SC_TILE) & (x0 + tx0 < a.W), vx1 = (x1 >= 0) & (x1 < SC_TILE) & (x1 + tx0 < a.W);
+                const bool vy0 = (y0 >= 0) & (y0 < SC_TILE) & (y0 + ty0 < a.H), vy1 = (y1 >= 0) & (y1 < SC_TILE) & (y1 + ty0 < a.H);
+                const float w_nw = (x1f - ix) * (y1f - iy), w_ne = (ix - x0f) * (y1f - iy);
+                const float w_sw = (x1f - ix) * (iy - y0f), w_se = (ix - x0f) * (iy - y0f);
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int si = s0 + jj < S ? s0 + jj : S - 1;
-                    if (pass) zz[jj] = zt[32LL * si];
-                    else if (a.zc) zz[jj] = a.zc[ray * a.N + si];
-                    else { const float t = linspace01(si, a.N); zz[jj] = nr * (1.f - t) + fr * t; }
-                }
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const float z = zz[jj];
-                    if (s0 + jj >= S || z < za || z > zb) continue;
-                    const long long col = col0 + 32LL * (s0 + jj);
-                    float ix, iy;
-                    texel(o, d, z, ix, iy);
-                    const float x0f = floorf(ix), y0f = floorf(iy);
-                    const float x1f = x0f + 1.f, y1f = y0f + 1.f;
-                    if (!(x0f >= (float)(tx0 - 1) && x0f < (float)(tx0 + SC_TILE) && y0f >= (float)(ty0 - 1) && y0f < (float)(ty0 + SC_TILE))) continue;
-                    const int x0 = (int)x0f - tx0, y0 = (int)y0f - ty0, x1 = x0 + 1, y1 = y0 + 1;     // tile coordinates
-                    // inside the tile (and, through the tile's extent, inside the image: taps outside contribute nothing - zeros padding)
-                    const bool vx0 = (x0 >= 0) & (x0 < SC_TILE) & (x0 + tx0 < a.W), vx1 = (x1 >= 0) & (x1 < SC_TILE) & (x1 + tx0 < a.W);
-                    const bool vy0 = (y0 >= 0) & (y0 < SC_TILE) & (y0 + ty0 < a.H), vy1 = (y1 >= 0) & (y1 < SC_TILE) & (y1 + ty0 < a.H);
-                    const float w_nw = (x1f - ix) * (y1f - iy), w_ne = (ix - x0f) * (y1f - iy);
-                    const float w_sw = (x1f - ix) * (iy - y0f), w_se = (ix - x0f) * (iy - y0f);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float v = df[(long long)c * a.del_stride + col];
-                        float *t = acc + c * SC_TILE * SC_TILE;
-                        if (vx0 & vy0) atomicAdd(t + y0 * SC_TILE + x0, v * w_nw);
-                        if (vx1 & vy0) atomicAdd(t + y0 * SC_TILE + x1, v * w_ne);
-                        if (vx0 & vy1) atomicAdd(t + y1 * SC_TILE + x0, v * w_sw);
-                        if (vx1 & vy1) atomicAdd(t + y1 * SC_TILE + x1, v * w_se);
-                    }
+                for (int c = 0; c < 3; ++c) {
+                    const float v = df[(long long)c * a.del_stride + col];
+                    float *t = acc + c * SC_TILE * SC_TILE;
+                    if (vx0 & vy0) atomicAdd(t + y0 * SC_TILE + x0, v * w_nw);
+                    if (vx1 & vy0) atomicAdd(t + y0 * SC_TILE + x1, v * w_ne);
+                    if (vx0 & vy1) atomicAdd(t + y1 * SC_TILE + x0, v * w_sw);
+                    if (vx1 & vy1) atomicAdd(t + y1 * SC_TILE + x1, v * w_se);
                 }
             }
         }
+      }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) {
@@ -1829,12 +1838,12 @@ int hl_render_mlp_backward(const void *mlp_packed, const void *mlp_bwd_packed, i
 }
 
 int hl_render_plane_grads(int H, int W, const float *bounds, const float *rays_o, const float *rays_d, const float *near, const float *far,
-                          const float *z_vals, const float *z_new, int64_t n_rays, int n_samples, int n_importance, const float *del,
-                          int64_t del_stride, float *d_planes, void *stream) {
+                          const float *z_vals, const float *z_new, int z_new_rows, int64_t n_rays, int n_samples, int n_importance,
+                          const float *del, int64_t del_stride, float *d_planes, void *stream) {
     HL_REQUIRE(bounds && rays_o && rays_d && near && far && z_new && del && d_planes, "hl_render_plane_grads: null argument");
     HL_REQUIRE(H > 0 && W > 0 && n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_plane_grads: bad sizes");
     HL_REQUIRE(del_stride >= tiles32(n_rays) * 32 * (int64_t)(n_samples + n_importance), "hl_render_plane_grads: delta rows too short");
-    ScatterArgs a{rays_o, rays_d, near, far, bounds, z_vals, z_new, n_rays, n_samples, n_importance, H, W, del, del_stride, d_planes};
+    ScatterArgs a{rays_o, rays_d, near, far, bounds, z_vals, z_new, z_new_rows, n_rays, n_samples, n_importance, H, W, del, del_stride, d_planes};
     const unsigned tiles = (unsigned)(((W + SC_TILE - 1) / SC_TILE) * ((H + SC_TILE - 1) / SC_TILE));
     hipLaunchKernelGGL(k_plane_scatter, dim3(9, tiles), dim3(SC_THREADS), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_plane_scatter");

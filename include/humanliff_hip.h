@@ -176,8 +176,10 @@ int hl_render_mlp_backward(const void *mlp_packed, const void *mlp_bwd_packed, i
                            int z_tiled, int64_t n_rays, int n_samples, const float *d_records, const float *act,
                            int64_t act_stride, int64_t act_off, float *del, int64_t del_stride, int64_t del_off, void *stream);
 int hl_render_plane_grads(int H, int W, const float *bounds, const float *rays_o, const float *rays_d, const float *near,
-                          const float *far, const float *z_vals /* coarse rows or NULL */, const float *z_new, int64_t n_rays,
-                          int n_samples, int n_importance, const float *del, int64_t del_stride, float *d_planes, void *stream);
+                          const float *far, const float *z_vals /* coarse rows or NULL */, const float *z_new,
+                          int z_new_rows /* 1: rows (R, n_importance), faster; 0: tile-major as hl_render_importance_new wrote them */,
+                          int64_t n_rays, int n_samples, int n_importance, const float *del, int64_t del_stride, float *d_planes,
+                          void *stream);
 
 /* Per-view ray generation on the device.  Replaces get_rays
  * (human_diffusion/SynBodyView_datasets.py:316-329), the float32 casts and the near=0 / far=1 fill of
