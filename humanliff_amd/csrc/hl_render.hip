@@ -1178,6 +1178,158 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const CompBwdArgs b) {
     }
 }
 
+// Wave-per-ray version of the two compositing kernels for fitting batches (a few thousand rays: one thread per ray leaves the GPU
+// empty and walks 2 x 256 dependent loads).  The merge of the two sorted depth lists is done by ranks (position of a coarse depth =
+// its index + the number of new depths strictly below it; of a new depth = its index + the number of coarse depths <= it - the
+// order k_composite's "za <= zb" walk produces), transmittance by a multiplicative wave scan, and the backward recurrence
+// Q_{s-1} = gw_s alpha_s + (1 - alpha_s + 1e-7) Q_s by a suffix scan of affine maps.  Same formulas as the serial kernels; products
+// and sums are associated differently (last-bit differences).  N, Ni <= 256.
+constexpr int CW_MAX = 512;
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_composite_wave(const CompBwdArgs b) {
+    const CompArgs &a = b.c;
+    __shared__ float s_za[4][CW_MAX / 2], s_zb[4][CW_MAX / 2], s_z[4][CW_MAX + 1], s_al[4][CW_MAX], s_T[4][CW_MAX];
+    __shared__ int s_code[4][CW_MAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long tiles_n = (a.R + 31) / 32;
+    const long long ray_raw = (long long)blockIdx.x * 4 + wv;
+    const bool pad = ray_raw >= a.R;                       // padding rays of the last tile: zero deltas
+    const long long ray = pad ? a.R - 1 : ray_raw;
+    const bool live = ray_raw < tiles_n * 32;
+    const long long tile = ray_raw >> 5;
+    const int r = (int)(ray_raw & 31);
+    const int N = a.N, Ni = a.Ni, S = N + Ni;
+    float *za_ = s_za[wv], *zb_ = s_zb[wv], *zS = s_z[wv], *alS = s_al[wv], *TS = s_T[wv];
+    int *codeS = s_code[wv];
+    const long long tr = live ? tile : tiles_n - 1;
+    const float4 *vc = a.vc + tr * 32 * (long long)N + r, *vn = a.vn + tr * 32 * (long long)Ni + r;
+    const float *zn = a.zn + tr * 32 * (long long)Ni + r;
+    const float nr = a.near[ray], fr = a.far[ray];
+    for (int i = lane; i < N; i += 64) {
+        float z;
+        if (a.zc) z = a.zc[ray * N + i];
+        else { const float t = linspace01(i, N); z = nr * (1.f - t) + fr * t; }
+        za_[i] = z;
+    }
+    for (int j = lane; j < Ni; j += 64) zb_[j] = zn[32LL * j];
+    __syncthreads();
+    for (int i = lane; i < N; i += 64) {       // # new depths strictly below za[i]
+        const float z = za_[i];
+        int lo = 0, hi = Ni;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (zb_[mid] < z) lo = mid + 1; else hi = mid; }
+        zS[i + lo] = z; codeS[i + lo] = i;
+    }
+    for (int j = lane; j < Ni; j += 64) {      // # coarse depths <= zb[j]
+        const float z = zb_[j];
+        int lo = 0, hi = N;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (za_[mid] <= z) lo = mid + 1; else hi = mid; }
+        zS[j + lo] = z; codeS[j + lo] = j | (int)0x80000000;
+    }
+    __syncthreads();
+    auto record = [&](int code) -> float4 { return code < 0 ? vn[32LL * (code & 0x7fffffff)] : vc[32LL * code]; };
+    auto sraw = [&](const float4 &v, int s) -> float { return a.noise ? v.x + a.noise[ray * S + s] : v.x; };
+    // forward: alpha, transmittance, and (forward kernel) the composited outputs
+    float carry = 1.f, acc_w = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f;
+    for (int base = 0; base < S; base += 64) {
+        const int s = base + lane;
+        float alpha = 0.f, zc = 0.f;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < S) {
+            zc = zS[s];
+            v = record(codeS[s]);
+            const float dist = (s + 1 < S) ? zS[s + 1] - zc : 1e10f;
+            alpha = 1.f - expf(-softplus_exact(sraw(v, s)) * dist);
+            alS[s] = alpha;
+        }
+        const float fct = (s < S) ? (1.f - alpha + 1e-7f) : 1.f;
+        const float incl = wave_incl_scan_mul(fct, lane);
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;
+        if (s < S) TS[s] = T;
+        carry *= __shfl(incl, 63);
+        if constexpr (!BWD) {
+            const float w = alpha * T;
+            acc_w += w;
+            acc_r += (1.f / (1.f + expf(-v.y))) * w;
+            acc_g += (1.f / (1.f + expf(-v.z))) * w;
+            acc_b += (1.f / (1.f + expf(-v.w))) * w;
+            acc_d += w * zc;
+        }
+    }
+    if constexpr (!BWD) {
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) {
+            acc_w += __shfl_xor(acc_w, dd); acc_r += __shfl_xor(acc_r, dd); acc_g += __shfl_xor(acc_g, dd);
+            acc_b += __shfl_xor(acc_b, dd); acc_d += __shfl_xor(acc_d, dd);
+        }
+        if (lane == 0 && !pad) {
+            if (a.flags & HL_RENDER_WHITE_BKGD) { const float bg = 1.f - acc_w; acc_r += bg; acc_g += bg; acc_b += bg; }
+            if (a.flags & HL_RENDER_NORMALIZE_DEPTH) {
+                acc_d = (acc_d - nr) / (fr - nr + 1e-5f);
+                acc_d = acc_d > 1.f ? 1.f : acc_d;
+                acc_d = acc_d < 0.f ? 0.f : acc_d;
+            }
+            a.rgb[ray * 3 + 0] = acc_r; a.rgb[ray * 3 + 1] = acc_g; a.rgb[ray * 3 + 2] = acc_b;
+            a.acc[ray] = acc_w; a.depth[ray] = acc_d;
+        }
+    } else {
+        if (!live) return;
+        float4 *dvc = b.dvc + tile * 32 * (long long)N + r, *dvn = b.dvn + tile * 32 * (long long)Ni + r;
+        float *drow_c = b.del + (long long)DROW_REC * b.del_stride + tile * 32 * (long long)N + r;
+        float *drow_n = b.del + (long long)DROW_REC * b.del_stride + tiles_n * 32 * (long long)N + tile * 32 * (long long)Ni + r;
+        const float gr = b.g_rgb[ray * 3 + 0], gg = b.g_rgb[ray * 3 + 1], gb = b.g_rgb[ray * 3 + 2];
+        const float ga = b.g_acc[ray] - ((a.flags & HL_RENDER_WHITE_BKGD) ? gr + gg + gb : 0.f);   // rgb += 1 - acc
+        float Qc = 0.f;                                        // Q just past the chunk being processed
+        for (int base = ((S - 1) / 64) * 64; base >= 0; base -= 64) {
+            const int s = base + lane;
+            const bool on = s < S;
+            float alpha = 0.f, T = 0.f, zc = 0.f, x = 0.f, dist = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, gw = 0.f;
+            int code = 0;
+            if (on) {
+                code = codeS[s];
+                const float4 v = record(code);
+                alpha = alS[s]; T = TS[s]; zc = zS[s];
+                dist = (s + 1 < S) ? zS[s + 1] - zc : 1e10f;
+                x = sraw(v, s);
+                cr = 1.f / (1.f + expf(-v.y)); cg = 1.f / (1.f + expf(-v.z)); cb = 1.f / (1.f + expf(-v.w));
+                gw = gr * cr + gg * cg + gb * cb + ga;
+            }
+            // inclusive suffix scan of the maps M_s(Q) = bq + fq Q over the lanes: I_s = M_s o M_{s+1} o ... o M_{base+63}
+            float fq = on ? (1.f - alpha + 1e-7f) : 1.f, bq = on ? gw * alpha : 0.f;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const float f2 = __shfl_down(fq, dd), b2 = __shfl_down(bq, dd);
+                if (lane + dd < 64) { bq = bq + fq * b2; fq = fq * f2; }
+            }
+            // Q_s = I_{s+1}(Qc); the last lane sees Qc itself
+            float fn = __shfl_down(fq, 1), bn = __shfl_down(bq, 1);
+            if (lane == 63) { fn = 1.f; bn = 0.f; }
+            const float Q = bn + fn * Qc;
+            Qc = __shfl(bq, 0) + __shfl(fq, 0) * Qc;
+            if (on) {
+                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!pad) {
+                    const float e = expf(-softplus_exact(x) * dist);
+                    const float dalpha = T * (gw - Q);
+                    const float ex = expf(x);
+                    const float dsp = x > 20.f ? 1.f : ex / (1.f + ex);           // F.softplus'(x), threshold 20
+                    const float w = alpha * T;
+                    d = make_float4(dalpha * (e * dist) * dsp, gr * w * cr * (1.f - cr), gg * w * cg * (1.f - cg), gb * w * cb * (1.f - cb));
+                }
+                const int idx = code & 0x7fffffff;
+                float4 *rec = code < 0 ? dvn : dvc;
+                float *row = code < 0 ? drow_n : drow_c;
+                rec[32LL * idx] = d;
+                row[32LL * idx] = d.x;
+                row[32LL * idx + b.del_stride] = d.y;
+                row[32LL * idx + 2 * b.del_stride] = d.z;
+                row[32LL * idx + 3 * b.del_stride] = d.w;
+            }
+        }
+    }
+}
+
 // Transposed weights for the backward-data products, in the same 16 KB chunk geometry the forward ring uses
 // ([tile t][step/4][lane 64][4 steps]): delta_in[out] = sum_u W[u][col0 + out] delta_out[u], with the delta_out units u taken in
 // accumulator-register order (unit_of), so the deltas - like the activations in the forward pass - go from one layer's accumulators
@@ -1738,6 +1890,14 @@ int hl_render_composite_noise(const float *near, const float *far, const float *
     HL_REQUIRE(n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_composite: bad sizes");
     CompArgs c{near, far, z_vals, z_new, (const float4 *)rec_coarse, (const float4 *)rec_new, n_rays, n_samples, n_importance,
                flags, rgb, acc, depth, noise};
+    // fitting batches (training noise given, few rays): one wave per ray
+    static const bool serial = getenv("HL_COMPOSITE_SERIAL") != nullptr;   // developer switch: thread-per-ray kernel
+    if (noise && n_rays <= 65536 && n_samples <= CW_MAX / 2 && n_importance <= CW_MAX / 2 && !serial) {
+        CompBwdArgs b{};
+        b.c = c;
+        hipLaunchKernelGGL(k_composite_wave<false>, dim3((unsigned)(tiles32(n_rays) * 8)), dim3(256), 0, (hipStream_t)stream, b);
+        return hl::check_launch("k_composite_wave<fwd>");
+    }
     hipLaunchKernelGGL(k_composite, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c);
     return hl::check_launch("k_composite");
 }
@@ -1806,6 +1966,11 @@ int hl_render_composite_backward(const float *near, const float *far, const floa
     b.sT = (float *)scratch;
     b.sSrc = (int *)scratch + tiles32(n_rays) * 32 * (size_t)(n_samples + n_importance);
     b.del = del; b.del_stride = del_stride;
+    static const bool serial = getenv("HL_COMPOSITE_SERIAL") != nullptr;   // developer switch: thread-per-ray kernels
+    if (n_samples <= CW_MAX / 2 && n_importance <= CW_MAX / 2 && !serial) {
+        hipLaunchKernelGGL(k_composite_wave<true>, dim3((unsigned)(tiles32(n_rays) * 8)), dim3(256), 0, (hipStream_t)stream, b);
+        return hl::check_launch("k_composite_wave<bwd>");
+    }
     hipLaunchKernelGGL(k_composite_bwd, dim3((unsigned)((tiles32(n_rays) * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b);
     return hl::check_launch("k_composite_bwd");
 }
