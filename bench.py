@@ -11,6 +11,8 @@ UNet forward + fused posterior update + noise draw for the whole batch; value = 
 Secondary metric (configs[2]) in the "render" object: Mrays/sec of the tri-plane renderer, 512x512 views,
 128 coarse + 128 importance samples per ray.  Weak scaling: every rank runs its own subjects / views; the
 only collective is the final all-gather of samples and images (north star), inside the timed region.
+"fit" object (not a BASELINE metric): tri-plane fitting iterations/sec at the reference's training
+configuration (2 subjects x 2048 rays x 128+128 samples; forward, HIP backward, Adam).
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events (per-kernel-category events
 inside hl_unet_forward for the conv kernels; torch events around the stage launches for the ray-march
@@ -238,6 +240,82 @@ def bench_render(args, rank, world, dev):
     return secs, roof, views * R
 
 
+def bench_fit(args, rank, world, dev, iters=10):
+    """one tri-plane fitting iteration at the reference's training configuration
+    (recon_NeRF/configs/SynBody.txt: 2 subjects x n_rand 2048 rays x 128+128 stratified samples, density noise, MSE on rgb + 0.1 MSE on
+    acc, Adam on MLP and tri-planes; run_nerf_batch.py:236-265).  Every rank fits its own subjects (no exchange)."""
+    from humanliff_amd import synthetic as syn
+    from humanliff_amd.NeRF import Renderer
+    torch.manual_seed(rank)
+    r = Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, test=False)
+    r.load_state_dict(syn.render_mlp_state(3), strict=False)
+    r = r.to(dev)
+    tri = torch.nn.Parameter((0.1 * torch.randn((2, 4, 3, 9, 256, 256))).to(dev))
+    opt = torch.optim.Adam([{'params': list(r.parameters()), 'lr': 5e-4}, {'params': [tri], 'lr': 1e-2}], betas=(0.9, 0.999))
+    bs, R, N = 2, 2048, 128
+    ro, rd, nr, fr = syn.orbit_rays(2, 8, 128, 128)
+    pick = torch.nonzero(fr != 1).flatten()
+    pick = pick[torch.randperm(pick.numel())[:R]]
+    ro, rd, nr, fr = (t[pick].to(dev) for t in (ro, rd, nr, fr))
+    target = torch.rand((bs, R, 3), device=dev)
+    tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].expand(bs, 2, 3).to(dev)}
+    ids, layer = torch.tensor([0, 1]), torch.tensor([1, 3])
+    t = torch.linspace(0., 1., steps=N, device=dev)
+
+    def one():
+        z = (nr[:, None] * (1. - t) + fr[:, None] * t)[None].expand(bs, R, N)
+        mids = .5 * (z[..., 1:] + z[..., :-1])
+        upper, lower = torch.cat([mids, z[..., -1:]], -1), torch.cat([z[..., :1], mids], -1)
+        z = lower + (upper - lower) * torch.rand(z.shape, device=dev)
+        out = r.render(tp, None, z, ro[None].expand(bs, R, 3), rd[None].expand(bs, R, 3), nr[None, :, None].expand(bs, R, 1),
+                       fr[None, :, None].expand(bs, R, 1), tri[ids, layer], N, False)
+        loss = ((out["rgb_map"] - target) ** 2).mean() + 0.1 * ((out["acc_map"] - 1.0) ** 2).mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    for _ in range(3):
+        one()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        loss = one()
+    barrier(world)
+    secs = max_over_ranks(time.perf_counter() - t0, world, dev)
+    assert torch.isfinite(loss.detach()).all()
+    pts = bs * R * 2 * N
+    return {"metric": "fitting-iterations/sec", "value": round(world * iters / secs, 2), "unit": "it/s", "ms_per_iteration": round(secs * 1e3 / iters, 3),
+            "sample_points_per_sec": round(world * iters * pts / secs), "iterations": iters,
+            "config": {"workload": "recon_NeRF SynBody training step: 2 subjects x 2048 rays x (128+128) samples, 256x256x27 tri-planes, "
+                                   "forward + HIP backward + Adam", "sample_points_per_iteration": pts}}
+
+
+def cpu_baseline_fit(threads, n_rays=512):
+    """Oracle autograd (PyTorch-CPU) of the same loss on a bounded sample of rays; scaled to iterations of 4096 rays."""
+    from humanliff_amd import synthetic as syn
+    from oracle import render_oracle as ro
+    torch.set_num_threads(threads)
+    planes = syn.triplane(seed=11)[0].clone().requires_grad_(True)
+    mlp = {k: v.clone().requires_grad_(True) for k, v in syn.render_mlp_state(3).items()}
+    o, d, nr, fr = syn.orbit_rays(2, 8, 128, 128)
+    pick = torch.nonzero(fr != 1).flatten()[:n_rays]
+    o, d, nr, fr = o[pick], d[pick], nr[pick], fr[pick]
+    N = 128
+    t = torch.linspace(0., 1., steps=N)
+    z = nr[:, None] * (1. - t) + fr[:, None] * t
+    u, noise = torch.rand(n_rays, N), torch.randn(n_rays, 2 * N)
+    dt = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        rgb, acc, _ = ro.render_rays(mlp, planes, torch.tensor(syn.WORLD_BOUNDS), o, d, nr, fr, N, N, u=u, z_vals=z, noise=noise)
+        ((rgb ** 2).mean() + 0.1 * ((acc - 1.0) ** 2).mean()).backward()
+        dt.append(time.perf_counter() - t0)
+    return {"value": round(n_rays / 4096 / dt[-1], 4), "unit": "it/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32 restatement) forward + autograd backward of {n_rays} rays at 128+128 samples (second of two runs), "
+                      "scaled to the 4096 rays of an iteration; optimizer not included"}
+
+
 def cpu_baseline_unet(sd, threads):
     """Oracle UNet forward + DDPM update on the host, B=1: 1 warm-up + 3 timed steps, ~10 s (a B=4 1000-step run
     would take hours)."""
@@ -288,6 +366,7 @@ def main():
     ap.add_argument("--views", type=int, default=2, help="512x512 views per GPU in the render leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--no-fit", action="store_true", help="skip the tri-plane fitting leg (SURVEY 8(f) rank 4)")
     ap.add_argument("--no-bf16x3-leg", action="store_true", help="skip the extra measurement of the opt-in bf16x3 conv mode")
     ap.add_argument("--no-overlap", action="store_true",
                     help="issue the control encoder on the caller's stream instead of the side stream (used for the "
@@ -311,6 +390,10 @@ def main():
                   "views_per_gpu": args.views, "ms_per_view": round(rsecs * 1e3 / args.views, 3), "roofline": rroof,
                   "config": {"workload": "configs[2]: tri-plane NeRF render 512x512, n_samples=128 + n_importance=128, "
                                          "views of a 36-view orbit, random 256x256x27 tri-plane", "rays_per_view": 512 * 512}}
+    fit = None
+    if not args.no_fit:
+        torch.cuda.empty_cache()
+        fit = bench_fit(args, rank, world, dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # PyTorch-CPU stops scaling (and then collapses) beyond ~32 threads on this path: measured on the
@@ -319,6 +402,8 @@ def main():
         cpu = cpu_baseline_unet(sd, threads)
         if render is not None:
             render["cpu_baseline"] = cpu_baseline_render(threads)
+        if fit is not None:
+            fit["cpu_baseline"] = cpu_baseline_fit(threads)
     if rank == 0:
         line = {
             "metric": "denoise-steps/sec", "value": round(value, 3), "unit": "denoise-steps/s", "n_gpus": world,
@@ -329,7 +414,7 @@ def main():
                        "parallelism": f"replicas x{world} (subjects sharded, final all-gather only)",
                        "gflop_per_sample_step": UNET_GFLOP_PER_SAMPLE_STEP},
             "step_tflops": round(world * args.batch * args.steps * UNET_GFLOP_PER_SAMPLE_STEP / secs / 1e3, 2),
-            "roofline": roof, "cpu_baseline": cpu, "render": render,
+            "roofline": roof, "cpu_baseline": cpu, "render": render, "fit": fit,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
