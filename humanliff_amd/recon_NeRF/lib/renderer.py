@@ -1,0 +1,28 @@
+"""Drop-in for recon_NeRF/lib/renderer.py `Renderer` (the tri-plane fitting twin of human_diffusion/NeRF/renderer.py).
+
+Differences of the twin that are mirrored here (recon_NeRF/lib/renderer.py:13-50, 244-295):
+  * the tri-planes are a Parameter of the module, (num_instances, 4 cloth layers, 3, triplane_ch/3, triplane_dim, triplane_dim),
+    initialised N(0, 0.1), and `render` takes no `tri_planes` argument: it picks
+    self.tri_planes[tp_input['instance_idx'], tp_input['cloth_layer_index']];
+  * constructor signature without smpl_type.
+With test=False (training) the returned rgb_map / acc_map carry gradients for tri_planes and the MLP through the HIP backward
+kernels (humanliff_amd/NeRF/train.py), so run_nerf_batch.py's loss.backward() / Adam step work unchanged.
+Not mirrored: the twin leaves depth_map unclamped after normalisation (the human_diffusion twin clamps to [0,1], :272-274); depth_map
+here is clamped and carries no gradient.
+"""
+import torch
+import torch.nn as nn
+
+from ...NeRF.renderer import Renderer as _Renderer
+
+
+class Renderer(_Renderer):
+    def __init__(self, use_canonical_space=False, num_instances=1, triplane_dim=256, triplane_ch=18, test=False):
+        super().__init__(use_canonical_space=use_canonical_space, num_instances=num_instances, triplane_dim=triplane_dim,
+                         triplane_ch=triplane_ch, smpl_type='smpl', test=test)
+        self.tri_planes = nn.Parameter(torch.empty(num_instances, 4, 3, triplane_ch // 3, triplane_dim, triplane_dim))
+        nn.init.normal_(self.tri_planes, mean=0, std=0.1)
+
+    def render(self, tp_input, world_pts, z_vals, rays_o, rays_d, near, far, n_importance=128, white_bkgd=False, **kw):
+        tri_planes = self.tri_planes[tp_input['instance_idx'], tp_input['cloth_layer_index']]
+        return super().render(tp_input, world_pts, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd, **kw)

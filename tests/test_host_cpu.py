@@ -119,3 +119,18 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(base, f)).read()
                 assert "oracle" not in src, f"{f} mentions the oracle"
+
+
+def test_recon_twin_mirrors_reference_names():
+    """recon_NeRF/lib/renderer.py:13-29, 244 and run_nerf_batch.py:29: constructor / render argument names and the tri_planes Parameter."""
+    import inspect
+    from humanliff_amd.recon_NeRF import Renderer, render
+    r = Renderer(use_canonical_space=False, num_instances=2, triplane_dim=16, triplane_ch=27, test=False)
+    assert list(inspect.signature(Renderer.__init__).parameters)[1:] == ["use_canonical_space", "num_instances", "triplane_dim", "triplane_ch", "test"]
+    assert tuple(r.tri_planes.shape) == (2, 4, 3, 9, 16, 16) and r.tri_planes.requires_grad
+    assert list(inspect.signature(r.render).parameters)[:9] == ["tp_input", "world_pts", "z_vals", "rays_o", "rays_d", "near", "far",
+                                                                 "n_importance", "white_bkgd"]
+    assert list(inspect.signature(render).parameters) == ["chunk", "rays_o", "rays_d", "near", "far", "tp_input", "renderer", "n_samples",
+                                                          "perturb", "n_importance", "white_bkgd"]
+    keys = set(r.state_dict().keys())
+    assert {"tri_planes", "pts_linears.0.weight", "alpha_linear.bias", "views_linear.weight", "rgb_linear.bias"} <= keys
