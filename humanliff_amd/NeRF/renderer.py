@@ -184,6 +184,10 @@ class Renderer(nn.Module):
 
 
     # ---- training mode (test=False) ------------------------------------------------
+    @staticmethod
+    def _train_ray_chunk(samples_per_ray):
+        return max(32, ((2 ** 31 - 1) // (4 * 630 * samples_per_ray)) // 32 * 32)
+
     def _render_training(self, tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,
                          noise=None):
         """Renderer.render with test=False (renderer.py:212, 276-281): Gaussian noise on the raw densities of the fine pass and
@@ -203,11 +207,18 @@ class Renderer(nn.Module):
         noise = noise.reshape(bs, R, S)
         flags = _lib.HL_RENDER_NORMALIZE_DEPTH | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0)
         mlp = self._mlp_tensors()
+        # the activation / delta matrices of one call are addressed with 32-bit offsets and kept below 2 GiB (630 rows x 4 B per
+        # sample point): 2048 rays x 256 samples need 1.3 GB; larger ray batches go down in pieces (rays are independent)
+        rc = self._train_ray_chunk(S)
         outs = []
         for b in range(bs):
-            geo = {"rays_o": f32(rays_o[b]), "rays_d": f32(rays_d[b]), "near": f32(near[b]), "far": f32(far[b]), "bounds": f32(bounds[b]),
-                   "z": f32(z_vals[b]), "u": f32(u[b]), "noise": f32(noise[b]), "flags": flags}
-            outs.append(RenderRaysFunction.apply(self, geo, tri_planes[b], *mlp))
+            parts = []
+            for i in range(0, R, rc):
+                sl = slice(i, min(R, i + rc))
+                geo = {"rays_o": f32(rays_o[b, sl]), "rays_d": f32(rays_d[b, sl]), "near": f32(near[b, sl]), "far": f32(far[b, sl]),
+                       "bounds": f32(bounds[b]), "z": f32(z_vals[b, sl]), "u": f32(u[b, sl]), "noise": f32(noise[b, sl]), "flags": flags}
+                parts.append(RenderRaysFunction.apply(self, geo, tri_planes[b], *mlp))
+            outs.append(parts[0] if len(parts) == 1 else tuple(torch.cat([q[k] for q in parts]) for k in range(3)))
         rgb = torch.stack([o[0] for o in outs])
         acc = torch.stack([o[1] for o in outs])
         depth = torch.stack([o[2] for o in outs])

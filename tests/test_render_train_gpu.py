@@ -154,3 +154,16 @@ def test_recon_twin_training_step(dev):
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.5 * np.mean(losses[:5]), losses
     untouched = model.tri_planes.detach()[0, 0]          # (instance 0, layer 0) was never rendered: only the L1/TV terms could move it - they did not see it
     assert torch.isfinite(untouched).all()
+
+
+def test_large_ray_batches_are_split(dev, monkeypatch):
+    """Ray batches beyond the 2 GiB matrix limit go down in pieces: forcing 64-ray pieces must reproduce the one-piece gradients."""
+    from humanliff_amd.NeRF import Renderer
+    i, _ = load_grad_case("a")
+    ref = hip_grads(i, dev)
+    monkeypatch.setattr(Renderer, "_train_ray_chunk", staticmethod(lambda S: 64))
+    got = hip_grads(i, dev)
+    assert (got[0] - ref[0]).abs().max() < 1e-6 and (got[1] - ref[1]).abs().max() < 1e-6
+    close(got[2], ref[2], "tri_planes")
+    for k in MLP_KEYS:
+        close(got[3][k], ref[3][k], k)
