@@ -56,7 +56,7 @@ SIGNATURES = {
     "hl_render_coarse": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p]),
     "hl_render_importance": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _p, _p]),
     "hl_deform_points": (_i, [_p, _p, _p, _p, _p, _p, _i, _i64, _p, _p, _p, _p]),
-    "hl_deform_rays": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "hl_deform_rays": (_i, [_p, _p, _p, _p, _p, _i, _i64, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "hl_render_eval_points": (_i, [_p, _p, _i, _i, _p, _p, _p, _i64, _i, _p, _p]),
     "hl_render_canonical_workspace_bytes": (_sz, [_i64, _i, _i]),
     "hl_render_rays_canonical": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _u, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),

@@ -819,6 +819,7 @@ struct DeformRaysArgs {
     long long R;
     int S;
     float4 *pts_c, *dirs_c;       // tile-major [R/32][S][32]
+    unsigned long long *counter;  // k_deform_rays_cull: work counter
 };
 
 __device__ __forceinline__ void mat3_apply(const float *m, float x, float y, float z, float &ox, float &oy, float &oz) {
@@ -853,7 +854,17 @@ __device__ __forceinline__ int deform_query(const DeformCommon &c, float4 *sv, f
             if (d < best) { best = d; bid = v0 + k; }
         }
     }
-    const float *row = c.table + (long long)bid * 36;
+    // the row is fetched as 9 x 16 bytes (rows are 144 B apart, 16-byte aligned): 36 separate dword gathers, each touching up to 64
+    // different lines per wave, cost more than the culled nearest-vertex search
+    float row[36];
+    {
+        const float4 *row4 = reinterpret_cast<const float4 *>(c.table + (long long)bid * 36);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float4 t = row4[i];
+            row[4 * i + 0] = t.x; row[4 * i + 1] = t.y; row[4 * i + 2] = t.z; row[4 * i + 3] = t.w;
+        }
+    }
     float cx, cy, cz;
     mat3_apply(row + 3, qx - row[0], qy - row[1], qz - row[2], cx, cy, cz);
     cx -= row[12]; cy -= row[13]; cz -= row[14];
@@ -920,7 +931,17 @@ __device__ __forceinline__ void nearest2(const DeformCommon &c, float4 *sv, f32x
 // the table row of vertex `bid` applied to an SMPL-space query / direction, in the reference's order
 __device__ __forceinline__ void apply_row(const DeformCommon &c, int bid, float qx, float qy, float qz, bool with_dir, float sx, float sy,
                                           float sz, float (&cp)[3], float (&cd)[3]) {
-    const float *row = c.table + (long long)bid * 36;
+    // the row is fetched as 9 x 16 bytes (rows are 144 B apart, 16-byte aligned): 36 separate dword gathers, each touching up to 64
+    // different lines per wave, cost more than the culled nearest-vertex search
+    float row[36];
+    {
+        const float4 *row4 = reinterpret_cast<const float4 *>(c.table + (long long)bid * 36);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float4 t = row4[i];
+            row[4 * i + 0] = t.x; row[4 * i + 1] = t.y; row[4 * i + 2] = t.z; row[4 * i + 3] = t.w;
+        }
+    }
     float cx, cy, cz;
     mat3_apply(row + 3, qx - row[0], qy - row[1], qz - row[2], cx, cy, cz);
     cx -= row[12]; cy -= row[13]; cz -= row[14];
@@ -998,6 +1019,162 @@ __global__ __launch_bounds__(256) void k_deform_rays(const DeformRaysArgs a) {
         const long long o = (tile * a.S + s) * 32 + r;
         a.pts_c[o] = make_float4(cp[0], cp[1], cp[2], 0.f);
         a.dirs_c[o] = make_float4(cd[0], cd[1], cd[2], 0.f);
+    }
+}
+
+// k_deform_rays with group culling (exact): a wave takes the 64 sample points (16 neighbouring rays x 4 consecutive depths) of one
+// step, which lie within a few centimetres of each other, and brute-forces only the vertices that can be nearest to ANY of them:
+// with m the centroid of the 64 points, rho their largest distance to m and U an upper bound of m's distance to the body (distance
+// to some actual vertices), the nearest vertex v* of a point p of the group obeys |m - v*| <= |p - v*| + rho <= |p - v_m| + rho <=
+// U + 2 rho.  Vertices are screened in index order in two levels - bounding spheres of runs of 64 consecutive vertices (meshes are
+// index-local; costs nothing when they are not), then the vertices of the surviving runs - and appended to a per-wave list in LDS
+// that the 64 lanes then scan with the same distance expression and strict "<" as the full scan, so the result (first index wins
+// ties) is the full scan's.  The list is flushed whenever it fills up, so no group is too large.
+constexpr int DC_MAXV = 7168, DC_WAVES = 8, DC_LIST = 256, DC_SLOTS = DC_LIST / 2 + 4;   // list entries; slots incl. the padding of a flush
+__global__ __launch_bounds__(DC_WAVES * 64) void k_deform_rays_cull(const DeformRaysArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dc_lds[];
+    float4 *sv = reinterpret_cast<float4 *>(dc_lds);                 // [V] vertices
+    float4 *scl = sv + DC_MAXV;                                      // [V/64] bounding spheres of vertex runs
+    // this wave's candidate list, two entries per slot so that the scan runs on packed fp32: LA = (x0, x1, y0, y1), LB = (z0, z1, id0, id1)
+    float4 *LA = scl + DC_MAXV / 64 + (threadIdx.x >> 6) * DC_SLOTS * 2, *LB = LA + DC_SLOTS;
+    const DeformCommon &c = a.c;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int V = c.V, NC = (V + 63) / 64;
+    for (int i = threadIdx.x; i < NC * 64; i += DC_WAVES * 64) sv[i] = i < V ? c.verts[i] : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 0.f);
+    __syncthreads();
+    auto wsum = [](float v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; };
+    auto wmax = [](float v) { for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d)); return v; };
+    auto wmin = [](float v) { for (int d = 32; d > 0; d >>= 1) v = fminf(v, __shfl_xor(v, d)); return v; };
+    for (int k = wv; k < NC; k += DC_WAVES) {                        // bounding sphere of vertices 64k .. 64k+63
+        const bool on = 64 * k + lane < V;
+        const float4 v = sv[64 * k + lane];
+        const float n = wsum(on ? 1.f : 0.f);
+        const float cx = wsum(on ? v.x : 0.f) / n, cy = wsum(on ? v.y : 0.f) / n, cz = wsum(on ? v.z : 0.f) / n;
+        const float dx = v.x - cx, dy = v.y - cy, dz = v.z - cz;
+        const float r = wmax(on ? sqrtf(dx * dx + dy * dy + dz * dz) : 0.f);
+        if (lane == 0) scl[k] = make_float4(cx, cy, cz, r * 1.0001f + 1e-6f);
+    }
+    __syncthreads();
+    const long long tiles_n = (a.R + 31) / 32;
+    const int SP = (a.S + 3) / 4;                                    // a step: 16 neighbouring rays x depths 4 j .. 4 j + 3
+    const long long items = tiles_n * 2 * SP;
+    // unit ray direction as view direction (renderer.py:258-259), through the same world -> SMPL map as the points (:128)
+    // Steps along the silhouette (groups that mix rays through the body with rays that miss the box) keep every vertex and cost ~50x
+    // the others; they come in runs (a tile's 2 x SP steps, the tiles of an image column), so the steps are dealt to the waves through a
+    // multiplicative hash (a bijection on [0, M), M the next power of two) instead of round-robin.
+    unsigned long long M = 1;
+    while (M < (unsigned long long)items) M <<= 1;
+    for (;;) {
+        // dynamic: the next step off a global counter (zeroed by the launcher) - the expensive steps are too uneven for a static deal
+        unsigned long long it = 0;
+        if (lane == 0) it = atomicAdd(a.counter, 1ull);
+        it = __shfl(it, 0);
+        if (it >= M) break;
+        const long long item = (long long)((it * 0x9E3779B97F4A7C15ull) & (M - 1));
+        if (item >= items) continue;
+        const long long tile = item / (2 * SP);
+        const int sub = (int)(item - tile * 2 * SP);
+        const int s_raw = 4 * (sub >> 1) + (lane >> 4), r = 16 * (sub & 1) + (lane & 15);
+        const int s = s_raw < a.S ? s_raw : a.S - 1;
+        const long long ray_raw = tile * 32 + r, ray = ray_raw < a.R ? ray_raw : a.R - 1;
+        const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
+        const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
+        float zc;
+        if (a.z) zc = a.z_tiled ? a.z[(tile * a.S + s) * 32 + r] : a.z[ray * a.S + s];
+        else { const float t = linspace01(s, a.S); zc = a.near[ray] * (1.f - t) + a.far[ray] * t; }
+        const float wx = (ox + dx * zc) - c.Th[0], wy = (oy + dy * zc) - c.Th[1], wz = (oz + dz * zc) - c.Th[2];
+        const float qx = (wx * c.R[0] + wy * c.R[3]) + wz * c.R[6];       // (p - Th) R
+        const float qy = (wx * c.R[1] + wy * c.R[4]) + wz * c.R[7];
+        const float qz = (wx * c.R[2] + wy * c.R[5]) + wz * c.R[8];
+        // group geometry
+        const float mx = wsum(qx) * (1.f / 64.f), my = wsum(qy) * (1.f / 64.f), mz = wsum(qz) * (1.f / 64.f);
+        const float rho = wmax(sqrtf((qx - mx) * (qx - mx) + (qy - my) * (qy - my) + (qz - mz) * (qz - mz))) * 1.0001f + 1e-6f;
+        // U: m's distance to the body - one lane-parallel pass over the vertices (64 per step, loads independent of each other)
+        float u2 = 3.0e38f;
+#pragma unroll 4
+        for (int k = 0; k < NC; ++k) {
+            const float4 v = sv[64 * k + lane];
+            u2 = fminf(u2, (v.x - mx) * (v.x - mx) + (v.y - my) * (v.y - my) + (v.z - mz) * (v.z - mz));
+        }
+        const float lim = sqrtf(wmin(u2)) * 1.0001f + 2.f * rho + 1e-6f;     // |m - v*| <= lim for every point of the group
+        const float lim2 = lim * lim * 1.0001f;
+        // runs whose bounding sphere reaches into the ball
+        unsigned long long runs[(DC_MAXV / 64 + 63) / 64];
+#pragma unroll
+        for (int w = 0; w < (DC_MAXV / 64 + 63) / 64; ++w) {
+            const int k = 64 * w + lane;
+            bool hit = false;
+            if (k < NC) {
+                const float4 b = scl[k];
+                const float d = sqrtf((b.x - mx) * (b.x - mx) + (b.y - my) * (b.y - my) + (b.z - mz) * (b.z - mz));
+                hit = d - b.w <= lim;
+            }
+            runs[w] = __ballot(hit);
+        }
+        float best = 3.0e38f;
+        int bid = 0;
+        int fill = 0;
+        const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        auto pair_d = [&](int slot) -> f32x2 {       // squared distances to the two entries of a slot: the full scan's expression (nearest2)
+            const float4 A = LA[slot], B = LB[slot];
+            const f32x2 ddx = qx2 - f32x2{A.x, A.y}, ddy = qy2 - f32x2{A.z, A.w}, ddz = qz2 - f32x2{B.x, B.y};
+            return __builtin_elementwise_fma(ddz, ddz, __builtin_elementwise_fma(ddy, ddy, ddx * ddx));
+        };
+        auto put = [&](int pos, float x, float y, float z, int id) {
+            float *pa = reinterpret_cast<float *>(LA + (pos >> 1)) + (pos & 1), *pb = reinterpret_cast<float *>(LB + (pos >> 1)) + (pos & 1);
+            pa[0] = x; pa[2] = y; pb[0] = z; pb[2] = __builtin_bit_cast(float, id);
+        };
+        auto flush = [&]() {
+            if (lane < 8) put(fill + lane, 1.0e18f, 1.0e18f, 1.0e18f, 0);       // pad to whole groups of 4 slots
+            const int nslots = (fill + 1) >> 1;
+            int won = -1;                                                       // first slot of the group that improved `best`
+            for (int i0 = 0; i0 < nslots; i0 += 4) {
+                f32x2 m = __builtin_elementwise_min(__builtin_elementwise_min(pair_d(i0), pair_d(i0 + 1)),
+                                                    __builtin_elementwise_min(pair_d(i0 + 2), pair_d(i0 + 3)));
+                const float cm = fminf(m[0], m[1]);
+                if (cm < best) { best = cm; won = i0; }
+            }
+            if (won >= 0) {
+                for (int j = 3; j >= 0; --j) {                                   // descending: the lowest index is written last
+                    const f32x2 d = pair_d(won + j);
+                    const float4 B = LB[won + j];
+                    if (d[1] == best) bid = __builtin_bit_cast(int, B.w);
+                    if (d[0] == best) bid = __builtin_bit_cast(int, B.z);
+                }
+            }
+            fill = 0;
+        };
+#pragma unroll
+        for (int w = 0; w < (DC_MAXV / 64 + 63) / 64; ++w) {
+            unsigned long long mask = runs[w];
+            while (mask) {
+                const int k = 64 * w + __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int vi = 64 * k + lane;
+                const float4 v = sv[vi];
+                const float d2 = (v.x - mx) * (v.x - mx) + (v.y - my) * (v.y - my) + (v.z - mz) * (v.z - mz);
+                const bool keep = vi < V && d2 <= lim2;
+                const unsigned long long km = __ballot(keep);
+                if (keep) put(fill + __builtin_popcountll(km & ((1ull << lane) - 1ull)), v.x, v.y, v.z, vi);
+                fill += __builtin_popcountll(km);
+                if (fill > DC_LIST - 64) flush();
+            }
+        }
+        flush();
+        if (ray_raw < a.R || true) {       // padding rays of the last tile are written too (finite values for the march kernel)
+            const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float ex = dx / nrm - c.Th[0], ey = dy / nrm - c.Th[1], ez = dz / nrm - c.Th[2];
+            const float sx = (ex * c.R[0] + ey * c.R[3]) + ez * c.R[6];
+            const float sy = (ex * c.R[1] + ey * c.R[4]) + ez * c.R[7];
+            const float sz = (ex * c.R[2] + ey * c.R[5]) + ez * c.R[8];
+            float cp[3], cd[3];
+            apply_row(c, bid, qx, qy, qz, true, sx, sy, sz, cp, cd);
+            if (s_raw < a.S) {
+                const long long o = (tile * a.S + s) * 32 + r;
+                a.pts_c[o] = make_float4(cp[0], cp[1], cp[2], 0.f);
+                a.dirs_c[o] = make_float4(cd[0], cd[1], cd[2], 0.f);
+            }
+        }
     }
 }
 
@@ -2116,7 +2293,7 @@ int hl_deform_points(const float *pts, const float *dirs, const float *h_R, cons
 
 int hl_deform_rays(const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z, int z_tiled,
                    int64_t n_rays, int n_samples, const float *h_R, const float *h_Th, const float *verts_smpl4, const float *table,
-                   int n_vertices, float *pts_c, float *dirs_c, void *stream) {
+                   int n_vertices, float *pts_c, float *dirs_c, void *scratch, void *stream) {
     HL_REQUIRE(rays_o && rays_d && near && far && h_R && h_Th && verts_smpl4 && table && pts_c && dirs_c, "hl_deform_rays: null argument");
     HL_REQUIRE(n_rays > 0 && n_samples >= 1 && n_vertices > 0, "hl_deform_rays: bad sizes");
     DeformRaysArgs a{};
@@ -2125,6 +2302,22 @@ int hl_deform_rays(const float *rays_o, const float *rays_d, const float *near, 
     a.c.verts = (const float4 *)verts_smpl4; a.c.table = table; a.c.V = n_vertices;
     a.rays_o = rays_o; a.rays_d = rays_d; a.near = near; a.far = far; a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples;
     a.pts_c = (float4 *)pts_c; a.dirs_c = (float4 *)dirs_c;
+    static const bool brute = getenv("HL_DEFORM_BRUTE") != nullptr;    // developer switch: full scan for every sample point
+    if (n_vertices <= DC_MAXV && !brute) {
+        const size_t lds = (size_t)(DC_MAXV + DC_MAXV / 64 + DC_WAVES * DC_SLOTS * 2) * sizeof(float4);
+        static bool attr_set = false;
+        if (!attr_set) {
+            HL_HIP(hipFuncSetAttribute((const void *)k_deform_rays_cull, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        const long long items = (long long)tiles32(n_rays) * 2 * ((n_samples + 3) / 4);
+        const unsigned grid = (unsigned)(items / DC_WAVES + 1 < 256 ? items / DC_WAVES + 1 : 256);
+        HL_REQUIRE(scratch, "hl_deform_rays: scratch (8 bytes of device memory) is required");
+        a.counter = (unsigned long long *)scratch;
+        HL_HIP(hipMemsetAsync(a.counter, 0, sizeof(unsigned long long), (hipStream_t)stream));
+        hipLaunchKernelGGL(k_deform_rays_cull, dim3(grid), dim3(DC_WAVES * 64), lds, (hipStream_t)stream, a);
+        return hl::check_launch("k_deform_rays_cull");
+    }
     const long long total = (long long)tiles32(n_rays) * 32 * ((n_samples + 1) / 2);   // two samples per thread
     hipLaunchKernelGGL(k_deform_rays, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_deform_rays");
@@ -2148,7 +2341,7 @@ size_t hl_render_canonical_workspace_bytes(int64_t n_rays, int n_samples, int n_
     if (n_rays <= 0) return 256;
     const size_t T32 = (size_t)tiles32(n_rays) * 32;
     const int smax = n_samples > n_importance ? n_samples : n_importance;
-    return hl_render_workspace_bytes(n_rays, n_samples, n_importance > 0 ? n_importance : n_samples) + T32 * smax * 2 * sizeof(float4) + 256;
+    return hl_render_workspace_bytes(n_rays, n_samples, n_importance > 0 ? n_importance : n_samples) + T32 * smax * 2 * sizeof(float4) + 512;
 }
 
 int hl_render_rays_canonical(const void *mlp_packed, const void *planes_packed, int H, int W, const float *t_bounds,
@@ -2168,15 +2361,16 @@ int hl_render_rays_canonical(const void *mlp_packed, const void *planes_packed, 
     pc = (float *)(((uintptr_t)pc + 255) / 256 * 256);
     const int smax = n_samples > n_importance ? n_samples : n_importance;
     float *dc = pc + T32 * smax * 4;
+    void *dscr = dc + T32 * smax * 4;                           // work counter of the deformation kernel
     int rc = hl_deform_rays(rays_o, rays_d, near, far, z_vals, 0, n_rays, n_samples, h_R, h_Th, verts_smpl4, table, n_vertices, pc, dc,
-                            stream);
+                            dscr, stream);
     if (rc) return rc;
     rc = hl_render_eval_points(mlp_packed, planes_packed, H, W, t_bounds, pc, dc, n_rays, n_samples, vc, stream);
     if (rc) return rc;
     rc = hl_render_importance_new(vc, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, zn, stream);
     if (rc) return rc;
     rc = hl_deform_rays(rays_o, rays_d, near, far, zn, 1, n_rays, n_importance, h_R, h_Th, verts_smpl4, table, n_vertices, pc, dc,
-                        stream);
+                        dscr, stream);
     if (rc) return rc;
     rc = hl_render_eval_points(mlp_packed, planes_packed, H, W, t_bounds, pc, dc, n_rays, n_importance, vn, stream);
     if (rc) return rc;

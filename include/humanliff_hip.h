@@ -208,7 +208,7 @@ int hl_deform_points(const float *pts, const float *dirs, const float *h_R, cons
  *                              workspace: hl_render_canonical_workspace_bytes() */
 int hl_deform_rays(const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z, int z_tiled,
                    int64_t n_rays, int n_samples, const float *h_R, const float *h_Th, const float *verts_smpl4, const float *table,
-                   int n_vertices, float *pts_c, float *dirs_c, void *stream);
+                   int n_vertices, float *pts_c, float *dirs_c, void *scratch /* 8 bytes of device memory (work counter) */, void *stream);
 int hl_render_eval_points(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *pts_c,
                           const float *dirs_c, int64_t n_rays, int n_samples, float *records_out, void *stream);
 size_t hl_render_canonical_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);

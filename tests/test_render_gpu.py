@@ -381,3 +381,26 @@ def test_canonical_space_render_matches_oracle(dev):
     assert (err < 1e-4).float().mean() > 0.995           # a sample on a Voronoi boundary of the body may pick the other vertex
     assert float(err.median()) < 2e-6
     assert ((out["acc_map"][0].cpu() - acc).abs() < 1e-4).float().mean() > 0.995
+
+
+@pytest.mark.parametrize("mode", ["random", "local", "bench"])
+def test_deform_group_culling_is_the_full_scan(mode, dev, tmp_path):
+    """k_deform_rays_cull (nearest vertex among the candidates of a 64-point group) must return what the full scan returns, bit for
+    bit - vertex order without locality, index-local order, and the tight-box geometry with silhouette groups that keep every vertex.
+    The full scan is selected per process (HL_DEFORM_BRUTE), so both runs go through scripts/deform_cull_check.py."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for brute in (False, True):
+        env = dict(os.environ)
+        env.pop("HL_DEFORM_BRUTE", None)
+        if brute:
+            env["HL_DEFORM_BRUTE"] = "1"
+        out = str(tmp_path / f"{mode}_{int(brute)}.pt")
+        args = [sys.executable, os.path.join(root, "scripts", "deform_cull_check.py"), out] + ([] if mode == "random" else [mode])
+        r = subprocess.run(args, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(out))
+    assert torch.equal(outs[0]["pts"], outs[1]["pts"]) and torch.equal(outs[0]["dirs"], outs[1]["dirs"])
+    assert torch.isfinite(outs[0]["pts"]).all()
