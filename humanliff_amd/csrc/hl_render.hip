@@ -21,6 +21,10 @@
 //   One wave owns 32 rays (two lanes per ray: the halves split the 27 features / 27 view
 //   encodings and the hidden units); a workgroup is 8 waves = 256 rays and streams the packed
 //   weights (17 x 16 KB per sample) from L2 through a two-slot LDS ring, one barrier per chunk.
+//
+// Further down in this file: evaluate-once schedule (k_march<.., STORE> + k_composite), canonical-space deformation
+// (k_deform_rays_cull / k_deform_rays / k_deform_points, renderer.py:52-132), per-view ray generation (k_camera_rays), and the
+// training backward (k_march<.., ACTS>, k_composite_wave, k_mlp_bwd, k_plane_scatter, k_wgrad; recon_NeRF/run_nerf_batch.py:236-265).
 #include "hl_common.h"
 
 #include <cstdlib>
