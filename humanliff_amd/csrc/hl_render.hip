@@ -1836,8 +1836,11 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs 
 // v_mfma_f32_32x32x2_f32, pairing point j with point 16+j.  The row sums of delta (the bias gradients) fall out of the A operand on
 // the VALU.  Partial results of the point ranges are added to the gradient tensors with float atomics.
 struct WgradJob {
-    int a_row0, M, b_row0, N;   // rows of the delta / activation matrix; C is (M, N) row-major
-    float *out, *bias_out;
+    int a_row0, M, b_row0, N;   // rows of the A / B operand; C[i][n] goes to out[i * ld_i + n * ld_n]
+    int a_is_act;               // 0: A rows from the delta matrix, B rows from the activation matrix; 1: the other way round (the two
+                                // heads, 1 and 3 delta rows: as A they would occupy a whole 32-row slab of one wave per workgroup)
+    int ld_i, ld_n;
+    float *out, *bias_out;      // bias = row sums of the delta operand
 };
 constexpr int WGRAD_JOBS = 7, WGRAD_MAX_NB = 5, WG_PITCH = 36, WG_AROWS = 128, WG_ROWS = WG_AROWS + 32 * WGRAD_MAX_NB, WG_LD = WG_ROWS / 32;
 struct WgradArgs {
@@ -1860,14 +1863,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)a.act, (short)0, (int)((unsigned)ACT_ROWS * as4), 0x00020000);
     const unsigned OOB = 0x80000000u;   // rows past M / N read zeros
     const int NB = (jb.N + 31) / 32, MT = (jb.M + 31) / 32;
+    const unsigned a_s4 = jb.a_is_act ? as4 : ds4, b_s4 = jb.a_is_act ? ds4 : as4;
     // staging: thread = (row group tid >> 3, 16-byte piece tid & 7); pass i covers staged rows 32 i .. 32 i + 31
     const int piece = tid & 7, rg = tid >> 3;
     unsigned goff[WG_LD];
 #pragma unroll
     for (int i = 0; i < WG_LD; ++i) {
         const int r = 32 * i + rg;
-        if (i < WG_AROWS / 32) goff[i] = r < jb.M ? (unsigned)(jb.a_row0 + r) * ds4 + 16u * piece : OOB;
-        else goff[i] = (r - WG_AROWS) < jb.N ? (unsigned)(jb.b_row0 + r - WG_AROWS) * as4 + 16u * piece : OOB;
+        if (i < WG_AROWS / 32) goff[i] = r < jb.M ? (unsigned)(jb.a_row0 + r) * a_s4 + 16u * piece : OOB;
+        else goff[i] = (r - WG_AROWS) < jb.N ? (unsigned)(jb.b_row0 + r - WG_AROWS) * b_s4 + 16u * piece : OOB;
     }
     f32x4 st[WG_LD];
     auto fetch = [&](long long p) {
@@ -1875,7 +1879,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < WG_LD; ++i) {
             const bool used = i < WG_AROWS / 32 ? i < MT : (i - WG_AROWS / 32) < NB;
-            if (used) st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i < WG_AROWS / 32 ? rd : ra, (int)goff[i], p4, 0));
+            if (used) st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((i < WG_AROWS / 32) != (jb.a_is_act != 0) ? rd : ra, (int)goff[i], p4, 0));
         }
     };
     f32x16 acc[WGRAD_MAX_NB];
@@ -1911,8 +1915,16 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
                         for (int k = 0; k < 4; ++k) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][k], bv[q][k], acc[t], 0, 0, 0);
                 }
             }
+            if (!jb.a_is_act) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bsum += (av[q][0] + av[q][1]) + (av[q][2] + av[q][3]);
+                for (int q = 0; q < 4; ++q) bsum += (av[q][0] + av[q][1]) + (av[q][2] + av[q][3]);
+            } else if (wave == 0) {      // delta rows are the B operand (one column tile): their sums from this wave's B fragment
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = ldsv[(WG_AROWS + row) * (WG_PITCH / 4) + 4 * half + q];
+                    bsum += (bv[0] + bv[1]) + (bv[2] + bv[3]);
+                }
+            }
         }
     }
     if (wave >= MT) return;
@@ -1924,13 +1936,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = 32 * wave + unit_of(0, r, half);
-                if (i < jb.M) atomicAdd(jb.out + (long long)i * jb.N + n, acc[t][r]);
+                if (i < jb.M) atomicAdd(jb.out + (long long)i * jb.ld_i + (long long)n * jb.ld_n, acc[t][r]);
             }
         }
     }
     bsum += __shfl_xor(bsum, 32);
     const int m = 32 * wave + row;
-    if (half == 0 && m < jb.M && jb.bias_out) atomicAdd(jb.bias_out + m, bsum);
+    if (!jb.a_is_act) { if (half == 0 && m < jb.M && jb.bias_out) atomicAdd(jb.bias_out + m, bsum); }
+    else if (wave == 0 && half == 0 && row < jb.N && jb.bias_out) atomicAdd(jb.bias_out + row, bsum);
 #endif
 }
 
@@ -2202,13 +2215,14 @@ int hl_render_weight_grads(const float *del, int64_t del_stride, const float *ac
     HL_REQUIRE((int64_t)ACT_ROWS * act_stride * 4 < (1LL << 31) && (int64_t)DEL_ROWS * del_stride * 4 < (1LL << 31),
                "hl_render_weight_grads: activation / delta matrices must stay below 2 GiB");
     WgradArgs a{};
-    a.job[0] = WgradJob{DROW_X0, 128, ROW_F, 27, g->pts0_w, g->pts0_b};
-    a.job[1] = WgradJob{DROW_X1, 128, ROW_X0, 128, g->pts1_w, g->pts1_b};
-    a.job[2] = WgradJob{DROW_X2, 128, ROW_F, 155, g->pts2_w, g->pts2_b};       // input = [features | hidden1] = rows 0..154
-    a.job[3] = WgradJob{DROW_Y, 128, ROW_X2, 128, g->feat_w, g->feat_b};
-    a.job[4] = WgradJob{DROW_V, 64, ROW_Y, 155, g->views_w, g->views_b};        // input = [feature | view encoding]
-    a.job[5] = WgradJob{DROW_REC, 1, ROW_X2, 128, g->alpha_w, g->alpha_b};
-    a.job[6] = WgradJob{DROW_REC + 1, 3, ROW_V, 64, g->rgb_w, g->rgb_b};
+    a.job[0] = WgradJob{DROW_X0, 128, ROW_F, 27, 0, 27, 1, g->pts0_w, g->pts0_b};
+    a.job[1] = WgradJob{DROW_X1, 128, ROW_X0, 128, 0, 128, 1, g->pts1_w, g->pts1_b};
+    a.job[2] = WgradJob{DROW_X2, 128, ROW_F, 155, 0, 155, 1, g->pts2_w, g->pts2_b};       // input = [features | hidden1] = rows 0..154
+    a.job[3] = WgradJob{DROW_Y, 128, ROW_X2, 128, 0, 128, 1, g->feat_w, g->feat_b};
+    a.job[4] = WgradJob{DROW_V, 64, ROW_Y, 155, 0, 155, 1, g->views_w, g->views_b};        // input = [feature | view encoding]
+    // heads, operands swapped: A = activation rows (128 / 64), B = their 1 / 3 delta rows; C[i][n] -> weight[n][i]
+    a.job[5] = WgradJob{ROW_X2, 128, DROW_REC, 1, 1, 1, 128, g->alpha_w, g->alpha_b};
+    a.job[6] = WgradJob{ROW_V, 64, DROW_REC + 1, 3, 1, 1, 64, g->rgb_w, g->rgb_b};
     for (int j = 0; j < WGRAD_JOBS; ++j) HL_REQUIRE(a.job[j].out && a.job[j].bias_out, "hl_render_weight_grads: null gradient pointer %d", j);
     a.del = del; a.act = act; a.del_stride = del_stride; a.act_stride = act_stride; a.n_cols = n_cols;
     // 7 layers x 256 point ranges of at least 1024 points
