@@ -132,7 +132,7 @@ class Renderer(nn.Module):
         (bs*R*(n_samples+n_importance), 1) supplies it, otherwise it is drawn on the device like the reference's randn_like) and
         rgb_map / acc_map stay attached to the autograd graph of tri_planes and the MLP parameters - see NeRF/train.py.
         """
-        if self.use_canonical_space:
+        if self.use_canonical_space and self.test:
             return self._render_canonical(tp_input, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd,
                                           n_samples, u)
         if self.triplane_ch != 27:
@@ -150,7 +150,7 @@ class Renderer(nn.Module):
             assert z_vals.shape[:2] == (bs, R)
             n_samples = z_vals.shape[2]
         assert n_samples is not None and n_samples >= 2
-        bounds = tp_input['world_bounds'].reshape(bs, 2, 3)
+        bounds = tp_input['t_world_bounds' if self.use_canonical_space else 'world_bounds'].reshape(bs, 2, 3)
         if n_importance > 0:
             assert n_importance == n_samples, \
                 "the reference reshapes coarse densities to n_importance (renderer.py:250): counts must match"
@@ -159,7 +159,7 @@ class Renderer(nn.Module):
             u = u.reshape(bs, R, n_importance)
         if not self.test:
             return self._render_training(tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,
-                                         noise)
+                                         noise, tp_input if self.use_canonical_space else None)
         L = _lib.lib()
         packed = self._packed_mlp(dev)
         ws = self._workspace(L.hl_render_workspace_bytes(R, n_samples, n_importance), dev)
@@ -189,7 +189,7 @@ class Renderer(nn.Module):
         return max(32, ((2 ** 31 - 1) // (4 * 630 * samples_per_ray)) // 32 * 32)
 
     def _render_training(self, tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,
-                         noise=None):
+                         noise=None, tp_canonical=None):
         """Renderer.render with test=False (renderer.py:212, 276-281): Gaussian noise on the raw densities of the fine pass and
         outputs attached to the autograd graph - gradients for tri_planes and the MLP come from the HIP backward kernels
         (NeRF/train.py).  The noise is drawn like the reference's randn_like: one (bs*R*(n_samples+n_importance), 1) draw on the device."""
@@ -198,7 +198,7 @@ class Renderer(nn.Module):
         bs, R = rays_o.shape[:2]
         dev = tri_planes.device
         S = n_samples + n_importance
-        f32 = lambda t: t.detach().to(torch.float32).contiguous()  # noqa: E731
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         if z_vals is None:
             t = torch.linspace(0., 1., steps=n_samples, device=dev)
             z_vals = near[..., None] * (1. - t) + far[..., None] * t
@@ -212,10 +212,18 @@ class Renderer(nn.Module):
         rc = self._train_ray_chunk(S)
         outs = []
         for b in range(bs):
+            dfm = None
+            if tp_canonical is not None:      # per-subject deformation tables (NeRF/deform.py); `bounds` is t_world_bounds here
+                from .deform import deform_tables
+                if self.SMPL_NEUTRAL is None:
+                    raise RuntimeError("use_canonical_space=True needs the body model: set renderer.SMPL_NEUTRAL to the SMPL_to_tensor dict")
+                one = lambda d: {k: v[b:b + 1] for k, v in d.items()}  # noqa: E731
+                dfm = deform_tables(self.SMPL_NEUTRAL, one(tp_canonical['params']), one(tp_canonical['t_params']),
+                                    tp_canonical['vertices'][b:b + 1].to(dev))
             parts = []
             for i in range(0, R, rc):
                 sl = slice(i, min(R, i + rc))
-                geo = {"rays_o": f32(rays_o[b, sl]), "rays_d": f32(rays_d[b, sl]), "near": f32(near[b, sl]), "far": f32(far[b, sl]),
+                geo = {"deform": dfm, "rays_o": f32(rays_o[b, sl]), "rays_d": f32(rays_d[b, sl]), "near": f32(near[b, sl]), "far": f32(far[b, sl]),
                        "bounds": f32(bounds[b]), "z": f32(z_vals[b, sl]), "u": f32(u[b, sl]), "noise": f32(noise[b, sl]), "flags": flags}
                 parts.append(RenderRaysFunction.apply(self, geo, tri_planes[b], *mlp))
             outs.append(parts[0] if len(parts) == 1 else tuple(torch.cat([q[k] for q in parts]) for k in range(3)))

@@ -13,6 +13,10 @@ stock ops is replaced by one autograd.Function per subject whose forward and bac
 Gradients exist for rgb_map (= normal_map, the same tensor as in the reference) and acc_map with respect to tri_planes and the seven
 Linear layers.  depth_map is returned without gradient (the reference's losses never use it).  As in the reference the importance
 depths are constants of the backward pass (torch.no_grad, renderer.py:243-253), and rays / depths / bounds get no gradient.
+
+Canonical space (use_canonical_space=True, the TightCap fitting runs of README.md:123): geo["deform"] carries the per-subject tables of
+NeRF/deform.py; every evaluate pass is preceded by hl_deform_rays and reads the canonical points (hl_render_eval_points_acts), and the
+tri-plane gradient is scattered from those points (hl_render_plane_grads_points).  The deformation has no parameters.
 """
 import ctypes as C
 
@@ -51,11 +55,30 @@ class RenderRaysFunction(torch.autograd.Function):
         acc = torch.empty((R,), dtype=torch.float32, device=dev)
         depth = torch.empty((R,), dtype=torch.float32, device=dev)
         p, st = _lib.ptr, _lib.stream_ptr()
-        _lib.check(L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), 0, R, N, p(vc), p(act), P, 0,
-                                         st), "hl_render_eval_acts")
-        _lib.check(L.hl_render_importance_new(p(vc), p(rd), p(nr), p(fr), p(zb), p(ub), R, N, Ni, p(zn), st), "hl_render_importance_new")
-        _lib.check(L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, p(vn), p(act), P,
-                                         T32 * N, st), "hl_render_eval_acts")
+        dfm = geo.get("deform")      # canonical space: (verts4, table, R host, Th host); `bounds` is then t_world_bounds
+        pts = None
+        if dfm is None:
+            _lib.check(L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), 0, R, N, p(vc), p(act), P, 0,
+                                             st), "hl_render_eval_acts")
+            _lib.check(L.hl_render_importance_new(p(vc), p(rd), p(nr), p(fr), p(zb), p(ub), R, N, Ni, p(zn), st), "hl_render_importance_new")
+            _lib.check(L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, p(vn), p(act), P,
+                                             T32 * N, st), "hl_render_eval_acts")
+        else:
+            verts4, table, Rh, Th = dfm
+            nv = int(verts4.shape[0])
+            pts = [torch.empty((T32 * n, 4), dtype=torch.float32, device=dev) for n in (N, Ni)]
+            dirs = [torch.empty((T32 * n, 4), dtype=torch.float32, device=dev) for n in (N, Ni)]
+            scr = torch.empty(4, dtype=torch.float32, device=dev)
+            _lib.check(L.hl_deform_rays(p(ro), p(rd), p(nr), p(fr), p(zb), 0, R, N, Rh.ctypes.data, Th.ctypes.data, p(verts4), p(table), nv,
+                                        p(pts[0]), p(dirs[0]), p(scr), st), "hl_deform_rays")
+            _lib.check(L.hl_render_eval_points_acts(p(packed), p(pp), H, W, p(bd), p(pts[0]), p(dirs[0]), R, N, p(vc), p(act), P, 0, st),
+                       "hl_render_eval_points_acts")
+            _lib.check(L.hl_render_importance_new(p(vc), p(rd), p(nr), p(fr), p(zb), p(ub), R, N, Ni, p(zn), st), "hl_render_importance_new")
+            _lib.check(L.hl_deform_rays(p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, Rh.ctypes.data, Th.ctypes.data, p(verts4), p(table), nv,
+                                        p(pts[1]), p(dirs[1]), p(scr), st), "hl_deform_rays")
+            _lib.check(L.hl_render_eval_points_acts(p(packed), p(pp), H, W, p(bd), p(pts[1]), p(dirs[1]), R, Ni, p(vn), p(act), P, T32 * N, st),
+                       "hl_render_eval_points_acts")
+        ctx.pts = pts
         _lib.check(L.hl_render_composite_noise(p(nr), p(fr), p(zb), p(zn), p(vc), p(vn), p(noise), R, N, Ni, flags, p(rgb), p(acc),
                                                p(depth), st), "hl_render_composite_noise")
         ctx.renderer, ctx.geo, ctx.packed = renderer, geo, packed
@@ -96,7 +119,11 @@ class RenderRaysFunction(torch.autograd.Function):
         _lib.check(L.hl_render_mlp_backward(p(ctx.packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, p(dvn), p(act), P,
                                             T32 * N, p(delta), P, T32 * N, st), "hl_render_mlp_backward")
         d_planes = torch.empty((27, H, W), dtype=torch.float32, device=dev)
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] and ctx.pts is not None:
+            sb = torch.empty(L.hl_render_plane_grads_points_scratch_bytes(R, N, Ni) // 4, dtype=torch.float32, device=dev)
+            _lib.check(L.hl_render_plane_grads_points(H, W, p(bd), p(ctx.pts[0]), p(ctx.pts[1]), R, N, Ni, p(delta), P, p(d_planes), p(sb), st),
+                       "hl_render_plane_grads_points")
+        elif ctx.needs_input_grad[2]:
             from .renderer import untile_rows
             zr = untile_rows(zn, R, Ni).contiguous()      # the scatter walks one ray per wave: give it the depths of a ray in one line
             _lib.check(L.hl_render_plane_grads(H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), p(zr), 1, R, N, Ni, p(delta), P, p(d_planes),

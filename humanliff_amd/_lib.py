@@ -71,6 +71,9 @@ SIGNATURES = {
     "hl_render_eval_acts": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _p, _p, _i64, _i64, _p]),
     "hl_render_composite_backward_scratch_bytes": (_sz, [_i64, _i, _i]),
     "hl_render_composite_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _u, _p, _p, _p, _i64, _p, _p]),
+    "hl_render_eval_points_acts": (_i, [_p, _p, _i, _i, _p, _p, _p, _i64, _i, _p, _p, _i64, _i64, _p]),
+    "hl_render_plane_grads_points_scratch_bytes": (_sz, [_i64, _i, _i]),
+    "hl_render_plane_grads_points": (_i, [_i, _i, _p, _p, _p, _i64, _i, _i, _p, _i64, _p, _p, _p]),
     "hl_render_weight_grads": (_i, [_p, _i64, _p, _i64, _i64, C.POINTER(RenderMlpParams), _p]),
     "hl_render_mlp_backward": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _p, _p, _i64, _i64, _p, _i64, _i64, _p]),
     "hl_render_plane_grads": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _i64, _p, _p]),

@@ -281,7 +281,7 @@ __device__ __forceinline__ float linspace01(int s, int N) {
 template <bool FULL, bool STORE = false, int NWV = 8, bool POINTS = false, bool ACTS = false>
 __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
     static_assert(!POINTS || (FULL && STORE), "POINTS is an evaluate-pass mode");
-    static_assert(!ACTS || (FULL && STORE && !POINTS), "ACTS is an evaluate-pass mode");
+    static_assert(!ACTS || (FULL && STORE), "ACTS is an evaluate-pass mode");
     constexpr int NT = NWV * 64, NST = 1024 / NT;   // threads; float4 per thread and 16 KB chunk
     __shared__ __attribute__((aligned(16))) float lds[2 * CHUNK_FLOATS + SMALL_FLOATS];
     constexpr int NCH = FULL ? NCH_FULL : NCH_COARSE;
@@ -1828,6 +1828,121 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs 
     }
 }
 
+// Tri-plane gradient for sample points that are not on straight rays in tri-plane space (canonical-space training: the points went
+// through the body deformation).  Same ownership scheme as k_plane_scatter; the culling unit is a block of 64 consecutive samples of
+// one ray, whose bounding box in normalised plane coordinates k_block_bbox computes once: a workgroup tests 64 boxes per wave step
+// against its tile and walks only the blocks that can touch it (lanes = the block's samples).
+struct ScatterPtsArgs {
+    const float4 *pts[2];        // canonical sample points of the two passes, tile-major [R/32][S][32]
+    const float *bounds;         // (2,3) box of the canonical space (t_world_bounds)
+    long long R;
+    int N, Ni, H, W;
+    const float *del;
+    long long del_stride;
+    float *dplanes;
+    float *bbox;                 // [blocks][6]: min xyz, max xyz of the block's normalised coordinates
+};
+
+__device__ __forceinline__ void scatter_blocks(const ScatterPtsArgs &a, int &nbA, int &nbB) { nbA = (a.N + 63) / 64; nbB = (a.Ni + 63) / 64; }
+
+__global__ __launch_bounds__(256) void k_block_bbox(const ScatterPtsArgs a) {
+    // one wave per (ray, block): block index = ray * (nbA + nbB) + b
+    int nbA, nbB;
+    scatter_blocks(a, nbA, nbB);
+    const int lane = threadIdx.x & 63;
+    const long long blk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= a.R * (nbA + nbB)) return;
+    const long long ray = blk / (nbA + nbB);
+    const int b = (int)(blk - ray * (nbA + nbB));
+    const int pass = b >= nbA, S = pass ? a.Ni : a.N, s = 64 * (pass ? b - nbA : b) + lane;
+    const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
+    const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (s < S) {
+        const float4 p = a.pts[pass][((ray >> 5) * S + s) * 32 + (ray & 31)];
+        lo[0] = hi[0] = 2.f * (p.x - bmin0) / bext0 - 1.f;
+        lo[1] = hi[1] = 2.f * (p.y - bmin1) / bext1 - 1.f;
+        lo[2] = hi[2] = 2.f * (p.z - bmin2) / bext2 - 1.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int d = 32; d > 0; d >>= 1) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], d)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], d)); }
+    if (lane < 6) a.bbox[blk * 6 + lane] = lane < 3 ? lo[lane] : hi[lane - 3];
+}
+
+__global__ __launch_bounds__(SC_THREADS) void k_plane_scatter_pts(const ScatterPtsArgs a) {
+    __shared__ float acc[3 * SC_TILE * SC_TILE];
+    const int q = blockIdx.x, p = q / 3, g = q % 3;
+    const int tiles_x = (a.W + SC_TILE - 1) / SC_TILE;
+    const int tx0 = (int)(blockIdx.y % tiles_x) * SC_TILE, ty0 = (int)(blockIdx.y / tiles_x) * SC_TILE;
+    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) acc[i] = 0.f;
+    __syncthreads();
+    int nbA, nbB;
+    scatter_blocks(a, nbA, nbB);
+    const long long tiles_n = (a.R + 31) / 32;
+    const long long colsA = tiles_n * 32 * a.N;
+    const long long nblk = a.R * (nbA + nbB);
+    const float offH = (float)(1.0 / (double)a.H);
+    const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
+    const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
+    const float *df = a.del + (long long)(DROW_DF + 3 * q) * a.del_stride;
+    const int cu = (p == 2) ? 2 : 0, cv = (p == 1) ? 2 : 1;          // which normalised coordinate drives u / v of this plane
+    auto to_px = [](float gn, int size) { return ((gn + 1.f) * (float)size - 1.f) / 2.f; };
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (long long base = (long long)wv * 64; base < nblk; base += SC_THREADS) {
+        const long long lb = base + lane < nblk ? base + lane : nblk - 1;
+        const float *bb = a.bbox + lb * 6;
+        // texel range the block can touch (monotone maps; the group shift only moves it up by 1/H): [floor(lo), floor(hi) + 1]
+        const float ulo = to_px(bb[cu], a.W) - 0.01f, uhi = to_px(bb[3 + cu] + offH, a.W) + 1.01f;
+        const float vlo = to_px(bb[cv], a.H) - 0.01f, vhi = to_px(bb[3 + cv] + offH, a.H) + 1.01f;
+        const bool hit = base + lane < nblk && uhi >= (float)tx0 && ulo < (float)(tx0 + SC_TILE) && vhi >= (float)ty0 && vlo < (float)(ty0 + SC_TILE);
+        unsigned long long hits = __ballot(hit);
+        while (hits) {
+            const int j = __builtin_ctzll(hits);
+            hits &= hits - 1;
+            const long long blk = base + j;
+            const long long ray = blk / (nbA + nbB);
+            const int b = (int)(blk - ray * (nbA + nbB));
+            const int pass = b >= nbA, S = pass ? a.Ni : a.N, s = 64 * (pass ? b - nbA : b) + lane;
+            if (s >= S) continue;
+            const long long lc = ((ray >> 5) * S + s) * 32 + (ray & 31);
+            const float4 pt = a.pts[pass][lc];
+            const long long col = (pass ? colsA : 0) + lc;
+            const float nx = 2.f * (pt.x - bmin0) / bext0 - 1.f;
+            const float ny = 2.f * (pt.y - bmin1) / bext1 - 1.f;
+            const float nz = 2.f * (pt.z - bmin2) / bext2 - 1.f;
+            float gu = (p == 2) ? nz : nx;
+            float gv = (p == 1) ? nz : ny;
+            gu = (g == 1) ? gu + offH : gu;
+            gv = (g == 2) ? gv + offH : gv;
+            const float ix = ((gu + 1.f) * (float)a.W - 1.f) / 2.f;
+            const float iy = ((gv + 1.f) * (float)a.H - 1.f) / 2.f;
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+            if (!(x0f >= (float)(tx0 - 1) && x0f < (float)(tx0 + SC_TILE) && y0f >= (float)(ty0 - 1) && y0f < (float)(ty0 + SC_TILE))) continue;
+            const int x0 = (int)x0f - tx0, y0 = (int)y0f - ty0, x1 = x0 + 1, y1 = y0 + 1;
+            const bool vx0 = (x0 >= 0) & (x0 < SC_TILE) & (x0 + tx0 < a.W), vx1 = (x1 >= 0) & (x1 < SC_TILE) & (x1 + tx0 < a.W);
+            const bool vy0 = (y0 >= 0) & (y0 < SC_TILE) & (y0 + ty0 < a.H), vy1 = (y1 >= 0) & (y1 < SC_TILE) & (y1 + ty0 < a.H);
+            const float w_nw = (x1f - ix) * (y1f - iy), w_ne = (ix - x0f) * (y1f - iy);
+            const float w_sw = (x1f - ix) * (iy - y0f), w_se = (ix - x0f) * (iy - y0f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = df[(long long)c * a.del_stride + col];
+                float *t = acc + c * SC_TILE * SC_TILE;
+                if (vx0 & vy0) atomicAdd(t + y0 * SC_TILE + x0, v * w_nw);
+                if (vx1 & vy0) atomicAdd(t + y0 * SC_TILE + x1, v * w_ne);
+                if (vx0 & vy1) atomicAdd(t + y1 * SC_TILE + x0, v * w_sw);
+                if (vx1 & vy1) atomicAdd(t + y1 * SC_TILE + x1, v * w_se);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) {
+        const int c = i / (SC_TILE * SC_TILE), y = (i / SC_TILE) % SC_TILE + ty0, x = i % SC_TILE + tx0;
+        if (y < a.H && x < a.W) a.dplanes[((long long)(3 * q + c) * a.H + y) * a.W + x] = acc[i];
+    }
+}
+
 // Weight gradients: C[m][n] += sum_p delta[a_row0 + m][p] * act[b_row0 + n][p] over the sample points - both operands are rows of
 // the two matrices, contiguous along the reduction.  A workgroup takes one layer and a range of points; per 32 points it stages the
 // layer's delta rows (<= 128) and activation rows (<= 155) through LDS with full-line loads (8 lanes x 16 B per row), then wave w
@@ -2206,6 +2321,48 @@ int hl_render_plane_grads(int H, int W, const float *bounds, const float *rays_o
     const unsigned tiles = (unsigned)(((W + SC_TILE - 1) / SC_TILE) * ((H + SC_TILE - 1) / SC_TILE));
     hipLaunchKernelGGL(k_plane_scatter, dim3(9, tiles), dim3(SC_THREADS), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_plane_scatter");
+}
+
+int hl_render_eval_points_acts(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *pts_c,
+                               const float *dirs_c, int64_t n_rays, int n_samples, float *records_out, float *act, int64_t act_stride,
+                               int64_t act_off, void *stream) {
+    HL_REQUIRE(mlp_packed && planes_packed && bounds && pts_c && dirs_c && records_out && act, "hl_render_eval_points_acts: null argument");
+    HL_REQUIRE(n_rays > 0 && n_samples >= 1 && H > 0 && W > 0, "hl_render_eval_points_acts: bad sizes");
+    HL_REQUIRE(act_off >= 0 && act_stride >= act_off + tiles32(n_rays) * 32 * n_samples, "hl_render_eval_points_acts: activation rows too short");
+    HL_REQUIRE((int64_t)ACT_ROWS * act_stride * 4 < (1LL << 32), "hl_render_eval_points_acts: activation matrix must stay below 4 GiB");
+    MarchArgs a{};
+    a.packed = (const float *)mlp_packed; a.planes = (const float4 *)planes_packed; a.H = H; a.W = W; a.bounds = bounds;
+    a.rays_o = pts_c; a.rays_d = pts_c; a.near = pts_c; a.far = pts_c;      // placeholders, as in hl_render_eval_points
+    a.z = nullptr; a.z_tiled = 0; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
+    a.pts_c = (const float4 *)pts_c; a.dirs_c = (const float4 *)dirs_c;
+    a.act = act; a.act_stride = act_stride; a.act_off = act_off;
+    const unsigned groups = (unsigned)((n_rays + 255) / 256);
+    const unsigned splits = sample_splits(groups, n_samples);
+    a.s_per = (n_samples + (int)splits - 1) / (int)splits;
+    hipLaunchKernelGGL((k_march<true, true, 8, true, true>), dim3(groups, (unsigned)((n_samples + a.s_per - 1) / a.s_per)), dim3(512), 0,
+                       (hipStream_t)stream, a);
+    return hl::check_launch("k_march<eval points, acts>");
+}
+
+size_t hl_render_plane_grads_points_scratch_bytes(int64_t n_rays, int n_samples, int n_importance) {
+    return (size_t)n_rays * (size_t)((n_samples + 63) / 64 + (n_importance + 63) / 64) * 6 * sizeof(float) + 256;
+}
+
+int hl_render_plane_grads_points(int H, int W, const float *bounds, const float *pts_coarse, const float *pts_new, int64_t n_rays,
+                                 int n_samples, int n_importance, const float *del, int64_t del_stride, float *d_planes, void *scratch,
+                                 void *stream) {
+    HL_REQUIRE(bounds && pts_coarse && pts_new && del && d_planes && scratch, "hl_render_plane_grads_points: null argument");
+    HL_REQUIRE(H > 0 && W > 0 && n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_plane_grads_points: bad sizes");
+    HL_REQUIRE(del_stride >= tiles32(n_rays) * 32 * (int64_t)(n_samples + n_importance), "hl_render_plane_grads_points: delta rows too short");
+    ScatterPtsArgs a{{(const float4 *)pts_coarse, (const float4 *)pts_new}, bounds, n_rays, n_samples, n_importance, H, W, del, del_stride,
+                     d_planes, (float *)scratch};
+    const long long nblk = n_rays * ((n_samples + 63) / 64 + (n_importance + 63) / 64);
+    hipLaunchKernelGGL(k_block_bbox, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    int rcode = hl::check_launch("k_block_bbox");
+    if (rcode) return rcode;
+    const unsigned tiles = (unsigned)(((W + SC_TILE - 1) / SC_TILE) * ((H + SC_TILE - 1) / SC_TILE));
+    hipLaunchKernelGGL(k_plane_scatter_pts, dim3(9, tiles), dim3(SC_THREADS), 0, (hipStream_t)stream, a);
+    return hl::check_launch("k_plane_scatter_pts");
 }
 
 int hl_render_weight_grads(const float *del, int64_t del_stride, const float *act, int64_t act_stride, int64_t n_cols,

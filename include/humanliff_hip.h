@@ -150,6 +150,19 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
  *                                 hl_render_mlp_pack)
  *   hl_render_weight_grads        all 14 parameter gradients from the two matrices over n_cols sample points (multiple of 32), ADDED
  *                                 to the tensors of `grads` (PyTorch layouts, zero them first) with float atomics */
+/* Canonical-space training (use_canonical_space=True with test=False; README.md:123 TightCap fitting): the deformation has no
+ * parameters and the points get no gradient, so the backward is the one above with two substitutions -
+ *   hl_render_eval_points_acts     hl_render_eval_points that also writes the activation matrix (forward, per pass)
+ *   hl_render_plane_grads_points   hl_render_plane_grads for sample points that are not on straight rays in tri-plane space:
+ *                                  pts_coarse / pts_new are the canonical points hl_deform_rays wrote for the two passes, `bounds`
+ *                                  is tp_input['t_world_bounds']; scratch: hl_render_plane_grads_points_scratch_bytes() */
+int hl_render_eval_points_acts(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *pts_c,
+                               const float *dirs_c, int64_t n_rays, int n_samples, float *records_out, float *act, int64_t act_stride,
+                               int64_t act_off, void *stream);
+size_t hl_render_plane_grads_points_scratch_bytes(int64_t n_rays, int n_samples, int n_importance);
+int hl_render_plane_grads_points(int H, int W, const float *bounds, const float *pts_coarse, const float *pts_new, int64_t n_rays,
+                                 int n_samples, int n_importance, const float *del, int64_t del_stride, float *d_planes, void *scratch,
+                                 void *stream);
 typedef struct hl_render_mlp_grads {
     float *pts0_w, *pts0_b, *pts1_w, *pts1_b, *pts2_w, *pts2_b, *feat_w, *feat_b, *alpha_w, *alpha_b, *views_w, *views_b, *rgb_w,
         *rgb_b;   /* same order and shapes as hl_render_mlp_params */
