@@ -28,7 +28,7 @@ def joint_transforms(model, poses, shapes):
     v_shaped = model["v_template"] + (sd * shapes[None, None, :]).sum(-1)
     joints = model["J_regressor"] @ v_shaped
     rot = batch_rodrigues(poses.reshape(-1, 3))
-    parents = model["kintree_table"][0].tolist()
+    parents, levels = _tree(model["kintree_table"])
     J = joints.shape[0]
     rel = joints.clone()
     rel[1:] = joints[1:] - joints[parents[1:]]
@@ -36,13 +36,37 @@ def joint_transforms(model, poses, shapes):
     local[:, :3, :3] = rot
     local[:, :3, 3] = rel
     local[:, 3, 3] = 1.0
-    chain = [local[0]]
-    for i in range(1, J):
-        chain.append(chain[parents[i]] @ local[i])
-    G = torch.stack(chain)
+    # the kinematic chain level by level (all joints of one depth in one batched product): 9 launches for SMPL instead of 23
+    G = local.clone()
+    for idx, par in levels:
+        G[idx] = torch.matmul(G[par], local[idx])
+    chain = None
     jh = torch.cat([joints, torch.zeros((J, 1), dtype=joints.dtype, device=joints.device)], dim=1)
     G[:, :, 3] = G[:, :, 3] - (G * jh[:, None, :]).sum(-1)
     return G
+
+
+_TREE_CACHE = {}
+_TABLE_CACHE = {}
+
+
+def _tree(kintree_table):
+    """parents (python list) and, per depth level >= 1, (joint indices, their parents) as index tensors on the table's device."""
+    key = (kintree_table.data_ptr(), kintree_table._version, str(kintree_table.device))
+    hit = _TREE_CACHE.get(key)
+    if hit is None:
+        parents = [int(v) for v in kintree_table[0].tolist()]
+        depth = [0] * len(parents)
+        for i in range(1, len(parents)):
+            depth[i] = depth[parents[i]] + 1
+        levels = []
+        for d in range(1, max(depth) + 1):
+            idx = [i for i in range(len(parents)) if depth[i] == d]
+            levels.append((torch.tensor(idx, device=kintree_table.device), torch.tensor([parents[i] for i in idx], device=kintree_table.device)))
+        if len(_TREE_CACHE) > 16:
+            _TREE_CACHE.clear()
+        _TREE_CACHE[key] = hit = (parents, levels)
+    return hit
 
 
 def _pose_offsets(model, poses):
@@ -57,6 +81,17 @@ def deform_tables(model, params, t_params, vertices):
     """Per-subject tables of hl_deform_points for batch element 0: verts4 (V,4) = xyz of (vertices - Th) R, table (V,36),
     and the host float32 arrays R (3,3), Th (3,).  `model` holds the SMPL_to_tensor keys (renderer.py:343-352) on the device."""
     dev = vertices.device
+    # the same posed subject is rendered view after view: keep the last few tables, keyed by CONTENT (the bytes of the small pose
+    # tensors and two checksums of the vertices - storage addresses get reused by new tensors)
+    small = torch.cat([t.detach().reshape(-1).to(device=dev, dtype=torch.float32) for t in
+                       (params["R"][0], params["Th"][0], params["poses"][0], params["shapes"][0], t_params["poses"][0])])
+    vflat = vertices[0].detach().reshape(-1).to(torch.float64)
+    ramp = torch.arange(vflat.numel(), device=dev, dtype=torch.float64)
+    fp = torch.cat([small.to(torch.float64), vflat.sum()[None], (vflat * ramp).sum()[None]]).cpu().numpy().tobytes()
+    key = (fp, model["v_template"].data_ptr(), str(dev))
+    hit = _TABLE_CACHE.get(key)
+    if hit is not None:
+        return hit
     f = lambda t: t.to(device=dev, dtype=torch.float32)  # noqa: E731
     m = {k: (f(v) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in model.items()}
     Rw, Th = f(params["R"][0]), f(params["Th"][0]).reshape(3)
@@ -77,8 +112,12 @@ def deform_tables(model, params, t_params, vertices):
     table[:, 30:33] = Ab[:, :3, 3]
     verts4 = torch.zeros((V, 4), dtype=torch.float32, device=dev)
     verts4[:, :3] = (f(vertices[0]) - Th) @ Rw
-    return verts4.contiguous(), table.contiguous(), Rw.detach().cpu().numpy().astype(np.float32).copy(), \
-        Th.detach().cpu().numpy().astype(np.float32).copy()
+    out = (verts4.contiguous(), table.contiguous(), Rw.detach().cpu().numpy().astype(np.float32).copy(),
+           Th.detach().cpu().numpy().astype(np.float32).copy())
+    if len(_TABLE_CACHE) > 8:
+        _TABLE_CACHE.clear()
+    _TABLE_CACHE[key] = out
+    return out
 
 
 def deform_target2c(model, tp_input, pts, viewdir=None, return_ids=False):

@@ -132,6 +132,8 @@ class Renderer(nn.Module):
         (bs*R*(n_samples+n_importance), 1) supplies it, otherwise it is drawn on the device like the reference's randn_like) and
         rgb_map / acc_map stay attached to the autograd graph of tri_planes and the MLP parameters - see NeRF/train.py.
         """
+        if self.use_canonical_space and self.SMPL_NEUTRAL is None:
+            raise RuntimeError("use_canonical_space=True needs the body model: set renderer.SMPL_NEUTRAL to the SMPL_to_tensor dict")
         if self.use_canonical_space and self.test:
             return self._render_canonical(tp_input, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd,
                                           n_samples, u)
