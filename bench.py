@@ -285,10 +285,80 @@ def bench_fit(args, rank, world, dev, iters=10):
     secs = max_over_ranks(time.perf_counter() - t0, world, dev)
     assert torch.isfinite(loss.detach()).all()
     pts = bs * R * 2 * N
-    return {"metric": "fitting-iterations/sec", "value": round(world * iters / secs, 2), "unit": "it/s", "ms_per_iteration": round(secs * 1e3 / iters, 3),
+    stages = fit_stage_times(r, tri[0, 0].detach(), tp["world_bounds"][0].contiguous(), ro, rd, nr, fr, N, dev)
+    return {"stages_ms_per_subject": stages["ms"], "roofline": stages["roofline"], "metric": "fitting-iterations/sec", "value": round(world * iters / secs, 2), "unit": "it/s", "ms_per_iteration": round(secs * 1e3 / iters, 3),
             "sample_points_per_sec": round(world * iters * pts / secs), "iterations": iters,
             "config": {"workload": "recon_NeRF SynBody training step: 2 subjects x 2048 rays x (128+128) samples, 256x256x27 tri-planes, "
                                    "forward + HIP backward + Adam", "sample_points_per_iteration": pts}}
+
+
+def fit_stage_times(r, planes, bounds, ro, rd, nr, fr, N, dev):
+    """One subject's forward + backward through the C ABI stage by stage (the calls of NeRF/train.py), HIP events between them."""
+    import ctypes as C
+    from humanliff_amd import _lib
+    from humanliff_amd.NeRF.renderer import untile_rows
+    from humanliff_amd.NeRF.train import train_rows
+    L = _lib.lib()
+    p, st = _lib.ptr, _lib.stream_ptr()
+    R = ro.shape[0]
+    H, W = planes.shape[-2:]
+    T32 = (R + 31) // 32 * 32
+    P = T32 * 2 * N
+    act_rows, del_rows = train_rows()
+    packed, pp = r._packed_mlp(dev), r._packed_planes(planes)
+    t = torch.linspace(0., 1., steps=N, device=dev)
+    z = (nr[:, None] * (1. - t) + fr[:, None] * t).contiguous()
+    u = torch.rand((R, N), device=dev)
+    noise = torch.randn((R, 2 * N), device=dev)
+    g_rgb, g_acc = torch.randn((R, 3), device=dev) / R, torch.randn((R,), device=dev) / R
+    e = lambda n: torch.empty(n, dtype=torch.float32, device=dev)  # noqa: E731
+    act, delta = e((act_rows, P)), e((del_rows, P))
+    vc, vn, zn, d_rec = e(T32 * N * 4), e(T32 * N * 4), e(T32 * N), e((P, 4))
+    rgb, acc, dep = e((R, 3)), e(R), e(R)
+    scratch = e(L.hl_render_composite_backward_scratch_bytes(R, N, N) // 4)
+    mlp = r._mlp_tensors()
+    params = _lib.RenderMlpParams(*[C.c_void_p(t_.data_ptr()) for t_ in mlp])
+    bwd = e(L.hl_render_mlp_bwd_packed_bytes() // 4)
+    flat = torch.zeros(sum(t_.numel() for t_ in mlp), device=dev)
+    grads, o = [], 0
+    for t_ in mlp:
+        grads.append(flat[o:o + t_.numel()])
+        o += t_.numel()
+    gp = _lib.RenderMlpParams(*[C.c_void_p(g.data_ptr()) for g in grads])
+    d_planes = e((27, H, W))
+    ro, rd, nr, fr, bd = ro.contiguous(), rd.contiguous(), nr.contiguous(), fr.contiguous(), bounds
+    calls = [
+        ("eval_acts_coarse", lambda: L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(z), 0, R, N, p(vc), p(act), P, 0, st)),
+        ("importance", lambda: L.hl_render_importance_new(p(vc), p(rd), p(nr), p(fr), p(z), p(u), R, N, N, p(zn), st)),
+        ("eval_acts_new", lambda: L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, N, p(vn), p(act), P, T32 * N, st)),
+        ("composite", lambda: L.hl_render_composite_noise(p(nr), p(fr), p(z), p(zn), p(vc), p(vn), p(noise), R, N, N, 2, p(rgb), p(acc), p(dep), st)),
+        ("composite_backward", lambda: L.hl_render_composite_backward(p(nr), p(fr), p(z), p(zn), p(vc), p(vn), p(noise), p(g_rgb), p(g_acc), R, N, N, 2,
+                                                                      p(d_rec[:T32 * N]), p(d_rec[T32 * N:]), p(delta), P, p(scratch), st)),
+        ("pack_bwd", lambda: L.hl_render_mlp_pack_bwd(C.byref(params), p(bwd), st)),
+        ("mlp_backward_coarse", lambda: L.hl_render_mlp_backward(p(packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(z), 0, R, N, p(d_rec[:T32 * N]),
+                                                                 p(act), P, 0, p(delta), P, 0, st)),
+        ("mlp_backward_new", lambda: L.hl_render_mlp_backward(p(packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, N, p(d_rec[T32 * N:]),
+                                                              p(act), P, T32 * N, p(delta), P, T32 * N, st)),
+        ("plane_grads", lambda: L.hl_render_plane_grads(H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(z), p(untile_rows(zn, R, N).contiguous()), 1, R, N, N,
+                                                        p(delta), P, p(d_planes), st)),
+        ("weight_grads", lambda: L.hl_render_weight_grads(p(delta), P, p(act), P, P, C.byref(gp), st)),
+    ]
+    ms = {}
+    for rep in range(2):          # second round is the measurement
+        for name, fn in calls:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _lib.check(fn(), name)
+            b.record()
+            torch.cuda.synchronize()
+            ms[name] = round(a.elapsed_time(b), 4)
+    # dominant kernel: k_wgrad, bound by reading the two matrices: the seven products touch 1 365 rows of P floats (DESIGN.md section 3)
+    wg_bytes = 1365 * P * 4
+    ach = wg_bytes / (ms["weight_grads"] * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": "k_wgrad (14 parameter gradients = delta rows x activation rows^T over the sample points of one subject)",
+            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+            "launch_ms": ms["weight_grads"], "mfma_tflops": round(2 * 66304 * P / (ms["weight_grads"] * 1e-3) / 1e12, 2)}
+    return {"ms": ms, "roofline": roof}
 
 
 def cpu_baseline_fit(threads, n_rays=512):
