@@ -1705,8 +1705,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 
 // Tri-plane gradient: transpose of the bilinear lookup [renderer.py:502-531].  Sending every sample point's 27 feature deltas
 // through their four taps with global float atomics costs 108 atomics per point (measured: 1.1 ms per 262 144 points, 2/3 of the
-// backward kernel, bound by the L2 atomic units).  Instead one workgroup OWNS a 32x32-texel tile of one (plane, group) image
-// - 3 channels, 12 KB of LDS - scans all sample points of the batch (recomputing the forward pass's texel coordinates bit for bit),
+// backward kernel, bound by the L2 atomic units).  Instead one workgroup OWNS a 16x16-texel tile of one (plane, group) image
+// - 3 channels, 3 KB of LDS; 2 304 workgroups of 512 threads at 256x256: measured best of 8..64-texel tiles - scans all sample points of the batch (recomputing the forward pass's texel coordinates bit for bit),
 // accumulates the taps that fall into its tile with LDS atomics, and writes the tile out with plain stores: no global atomics, no
 // zero-fill, and the result depends on the run only through the order of LDS additions.
 struct ScatterArgs {
@@ -1719,7 +1719,7 @@ struct ScatterArgs {
     long long del_stride;
     float *dplanes;              // (27, H, W), overwritten
 };
-constexpr int SC_TILE = 32, SC_THREADS = 512;
+constexpr int SC_TILE = 16, SC_THREADS = 512;
 
 __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs a) {
     __shared__ float acc[3 * SC_TILE * SC_TILE];
