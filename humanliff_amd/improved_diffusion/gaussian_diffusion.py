@@ -272,7 +272,10 @@ class GaussianDiffusion:
         if noise is None:
             noise = th.randn_like(x_start)
         x_t = self.q_sample(x_start, t, noise=noise)
-        out = model(x_t, self._scale_timesteps(t), x_cond, **(model_kwargs or {}))
+        # with gradients enabled the network runs through its differentiable PyTorch-op twin (the HIP forward has no backward; SURVEY
+        # 8(b): training_losses keeps working through autograd); under no_grad, or for a model without one, the normal forward
+        fwd = model.forward_autograd if th.is_grad_enabled() and hasattr(model, "forward_autograd") else model
+        out = fwd(x_t, self._scale_timesteps(t), x_cond, **(model_kwargs or {}))
         target = {ModelMeanType.PREVIOUS_X: self.q_posterior_mean_variance(x_start=x_start, x_t=x_t, t=t)[0],
                   ModelMeanType.START_X: x_start, ModelMeanType.EPSILON: noise}[self.model_mean_type]
         assert out.shape == target.shape == x_start.shape

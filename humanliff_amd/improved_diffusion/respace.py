@@ -93,3 +93,20 @@ class _WrappedModel:
         if self.rescale_timesteps:
             new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
         return self.model(x, new_ts, x_cond, **kwargs)
+
+    def forward_autograd(self, x, ts, x_cond, **kwargs):
+        inner, self.model = self.model, _Autograd(self.model)
+        try:
+            return self(x, ts, x_cond, **kwargs)
+        finally:
+            self.model = inner
+
+
+class _Autograd:
+    """Calls a model through its training-only differentiable forward."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __call__(self, *args, **kwargs):
+        return self.model.forward_autograd(*args, **kwargs)

@@ -5,7 +5,8 @@ The torch modules declared here only own the parameters (so reference checkpoint
 load_state_dict and .to(device) works).  forward() hands the parameter pointers to the C ABI
 (hl_unet_create / hl_unet_forward); there is no PyTorch implementation of the math and no CPU path.
 Supported configuration: dims=2, use_scale_shift_norm=True, cond_type in {"controlnet", ""},
-use_3d_aware=False, inference (no autograd through the HIP kernels).
+use_3d_aware=False.  forward() is inference (no autograd through the HIP kernels); forward_autograd() is the training-only
+PyTorch-op twin that training_losses uses (unet_autograd.py).
 """
 import ctypes as C
 
@@ -232,10 +233,16 @@ class UNetModel(nn.Module):
         except Exception:
             pass
 
+    def forward_autograd(self, x, timesteps, x_cond=None, y=None):
+        """Training only: the same function in PyTorch ops, differentiable (unet_autograd.py).  GaussianDiffusion.training_losses
+        calls this when gradients are enabled; the samplers never do."""
+        from .unet_autograd import forward_autograd
+        return forward_autograd(self, x, timesteps, x_cond, y)
+
     def forward(self, x, timesteps, x_cond=None, y=None):
         """Same contract as the reference: x (N,C,H,W), timesteps (N,), x_cond (N,C,H,W), y (N,) -> (N,C_out,H,W)."""
         if th.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("autograd through the HIP UNet is not built (inference only)")
+            raise NotImplementedError("autograd through the HIP UNet is not built (inference only); training_losses uses forward_autograd")
         if self.num_classes is not None:
             assert y is not None and y.shape == (x.shape[0],)
         if self.cond_type == "controlnet":

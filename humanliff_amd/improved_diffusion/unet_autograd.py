@@ -1,0 +1,98 @@
+"""Differentiable forward of UNetModel in PyTorch ops - TRAINING ONLY.
+
+SURVEY.md 8(b) keeps `GaussianDiffusion.training_losses(model, x_start, x_cond, t, ...)` working through autograd ("fallback to torch
+ops is acceptable"): the HIP kernels of `UNetModel.forward` have no backward (UNet half: not built), so
+`training_losses` evaluates the network through this module when gradients are requested.  It is never used by the samplers:
+`UNetModel.forward` - the hot path - runs only on the HIP kernels and raises when asked for gradients.
+
+Same arithmetic as human_diffusion/improved_diffusion/unet.py:550-615 on the parameter-holder modules of unet.py: GroupNorm(32,
+eps 1e-5) -> SiLU -> conv ResBlocks with scale-shift conditioning (:203-206), per-head [q|k|v] attention with ch^-1/4 on q and k and
+fp32 softmax (:248-274), stride-2 conv downsampling, nearest x2 + conv upsampling, and the control encoder on x + x_cond whose
+feature map is REPLACED by its zero-conv projection before the next block (:594-606).  Convolutions run in whatever PyTorch
+dispatches to on the tensors' device (MIOpen on the GPU).
+"""
+import math
+
+import torch as th
+import torch.nn.functional as F
+
+from . import unet as U
+
+
+def _embedding(timesteps, dim, max_period=10000):
+    half = dim // 2
+    freqs = th.exp(-math.log(max_period) * th.arange(half, dtype=th.float32, device=timesteps.device) / half)
+    args = timesteps[:, None].float() * freqs[None]
+    return th.cat([th.cos(args), th.sin(args)], dim=-1)
+
+
+def _silu(x):
+    return x * th.sigmoid(x)
+
+
+def _norm(m, x):
+    return F.group_norm(x.float(), m.num_groups, m.weight, m.bias, m.eps)
+
+
+def _res_block(m, x, emb):
+    h = m.in_layers[2](_silu(_norm(m.in_layers[0], x)))
+    scale, shift = m.emb_layers[1](_silu(emb)).chunk(2, dim=1)
+    h = _norm(m.out_layers[0], h) * (1 + scale[:, :, None, None]) + shift[:, :, None, None]
+    h = m.out_layers[3](_silu(h))
+    return m.skip_connection(x) + h
+
+
+def _attention(m, x):
+    b, c, hh, ww = x.shape
+    xf = x.reshape(b, c, -1)
+    qkv = m.qkv(_norm(m.norm, xf))
+    qkv = qkv.reshape(b * m.num_heads, -1, qkv.shape[2])
+    ch = qkv.shape[1] // 3
+    q, k, v = qkv.split(ch, dim=1)
+    s = 1.0 / math.sqrt(math.sqrt(ch))
+    w = th.softmax(th.einsum("bct,bcs->bts", q * s, k * s).float(), dim=-1)
+    a = th.einsum("bts,bcs->bct", w, v).reshape(b, -1, hh * ww)
+    return (xf + m.proj_out(a)).reshape(b, c, hh, ww)
+
+
+def _run(seq, h, emb):
+    for m in seq:
+        if isinstance(m, U.ResBlock):
+            h = _res_block(m, h, emb)
+        elif isinstance(m, U.AttentionBlock):
+            h = _attention(m, h)
+        elif isinstance(m, U.Downsample):
+            h = m.op(h)
+        elif isinstance(m, U.Upsample):
+            h = m.conv(F.interpolate(h, scale_factor=2, mode="nearest"))
+        else:                                  # the bare first convolution of an encoder
+            h = m(h)
+    return h
+
+
+def forward_autograd(model, x, timesteps, x_cond=None, y=None):
+    """UNetModel.forward's contract (x (N,C,H,W), timesteps (N,), x_cond, y) with autograd; fp32."""
+    if model.num_classes is not None:
+        assert y is not None and y.shape == (x.shape[0],)
+    emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
+    if model.num_classes is not None:
+        emb = emb + model.label_emb(y)
+    hs = []
+    h = x.float()
+    for blk in model.input_blocks:
+        h = _run(blk, h, emb)
+        hs.append(h)
+    h = _run(model.middle_block, h, emb)
+    if model.cond_type == "controlnet":
+        assert x_cond is not None, "cond_type='controlnet' needs x_cond (zeros for the first layer)"
+        hs_cond = []
+        hc = x.float() + x_cond.float()
+        for blk, proj in zip(model.input_blocks_cond, model.input_blocks_proj_cond):
+            hc = proj(_run(blk, hc, emb))
+            hs_cond.append(hc)
+    for blk in model.output_blocks:
+        skip = hs.pop()
+        if model.cond_type == "controlnet":
+            skip = skip + hs_cond.pop()
+        h = _run(blk, th.cat([h, skip], dim=1), emb)
+    return model.out[2](_silu(_norm(model.out[0], h))).to(x.dtype)

@@ -1,0 +1,67 @@
+"""GaussianDiffusion.training_losses keeps working through autograd: with gradients enabled the network is evaluated
+by its training-only PyTorch-op twin (improved_diffusion/unet_autograd.py); losses and parameter gradients must equal the reference's
+(tests/golden/gen_golden_train_loss.py).  CPU - the twin is plain PyTorch; the hot path (UNetModel.forward) stays HIP-only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import GOLDEN
+from humanliff_amd import synthetic as syn
+from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+
+
+def tiny_model():
+    a = model_and_diffusion_defaults()
+    a.update(dict(in_channels=27, out_channels=27, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=True,
+                  cond_type="controlnet", rescale_timesteps=False, dropout=0.0, diffusion_steps=1000, noise_schedule="linear",
+                  timestep_respacing="", image_size=32, num_channels=32, num_res_blocks=1, attention_resolutions="16,8"))
+    model, diffusion = create_model_and_diffusion(**a)
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+    return model, diffusion
+
+
+def inputs():
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((2, 27, 32, 32), generator=g)
+    xc = torch.randn((2, 27, 32, 32), generator=g).clamp(-1, 1) * 0.7
+    return x, xc
+
+
+def test_training_losses_and_gradients_match_reference():
+    g = np.load(os.path.join(GOLDEN, "train_loss_tiny32.npz"))
+    model, diffusion = tiny_model()
+    x0, xc = inputs()
+    losses = diffusion.training_losses(model, x0.clamp(-1, 1), xc, torch.tensor([999, 17]), model_kwargs={"y": torch.tensor([3, 0])},
+                                       noise=torch.from_numpy(g["noise"]))
+    assert losses["loss"].requires_grad
+    assert np.abs(losses["loss"].detach().numpy() - g["loss"]).max() < 1e-5
+    assert np.abs(losses["mse"].detach().numpy() - g["mse"]).max() < 1e-5
+    losses["loss"].mean().backward()
+    sd = dict(model.named_parameters())
+    assert all(p.grad is not None for p in sd.values())
+    tot = sum(float(p.grad.double().abs().sum()) for p in sd.values())
+    assert abs(tot - float(g["grad_abs_sum"])) < 1e-4 * float(g["grad_abs_sum"])
+    for k in g["keys"]:
+        ref = torch.from_numpy(g["g_" + str(k)])
+        assert (sd[str(k)].grad - ref).abs().max() < 1e-6 + 1e-4 * ref.abs().max(), k
+
+
+def test_samplers_never_use_the_torch_twin(monkeypatch):
+    """The inference entry point must stay on the HIP kernels: forward() without a GPU tensor raises instead of falling back, and
+    training_losses under no_grad goes through forward() too."""
+    from humanliff_amd.improved_diffusion import unet_autograd
+    model, diffusion = tiny_model()
+    x0, xc = inputs()
+
+    def boom(*a, **k):
+        raise AssertionError("forward_autograd must not be called here")
+    monkeypatch.setattr(unet_autograd, "forward_autograd", boom)
+    with pytest.raises(RuntimeError):                 # CPU tensors: no CPU path
+        with torch.no_grad():
+            model(x0, torch.tensor([5, 6]), xc, y=torch.tensor([0, 1]))
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            diffusion.training_losses(model, x0, xc, torch.tensor([5, 6]), model_kwargs={"y": torch.tensor([0, 1])})
