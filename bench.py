@@ -275,19 +275,29 @@ def bench_fit(args, rank, world, dev, iters=10):
         opt.zero_grad()
         return loss
 
-    for _ in range(3):
-        one()
-    barrier(world)
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        loss = one()
-    barrier(world)
-    secs = max_over_ranks(time.perf_counter() - t0, world, dev)
-    assert torch.isfinite(loss.detach()).all()
+    def timed():
+        for _ in range(3):
+            one()
+        barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            loss = one()
+        barrier(world)
+        s = max_over_ranks(time.perf_counter() - t0, world, dev)
+        assert torch.isfinite(loss.detach()).all()
+        return s
+
+    secs = timed()                       # reference-faithful: sample_pdf's uniforms drawn on the CPU generator and uploaded
+    r.uniforms_on_device = True          # extension: drawn on the device
+    secs_dev = timed()
+    r.uniforms_on_device = False
     pts = bs * R * 2 * N
     stages = fit_stage_times(r, tri[0, 0].detach(), tp["world_bounds"][0].contiguous(), ro, rd, nr, fr, N, dev)
     return {"stages_ms_per_subject": stages["ms"], "roofline": stages["roofline"], "metric": "fitting-iterations/sec", "value": round(world * iters / secs, 2), "unit": "it/s", "ms_per_iteration": round(secs * 1e3 / iters, 3),
             "sample_points_per_sec": round(world * iters * pts / secs), "iterations": iters,
+            "uniforms_on_device": {"value": round(world * iters / secs_dev, 2), "unit": "it/s", "ms_per_iteration": round(secs_dev * 1e3 / iters, 3),
+                                   "what": "Renderer.uniforms_on_device = True: sample_pdf's uniforms from the device generator instead of "
+                                           "CPU draw + 2 MB upload per step (same distribution; NOT used for `value`)"},
             "config": {"workload": "recon_NeRF SynBody training step: 2 subjects x 2048 rays x (128+128) samples, 256x256x27 tri-planes, "
                                    "forward + HIP backward + Adam", "sample_points_per_iteration": pts}}
 

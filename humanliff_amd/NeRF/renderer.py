@@ -62,6 +62,7 @@ class Renderer(nn.Module):
         # (keys v_template, shapedirs, posedirs, J_regressor, kintree_table, weights) to `SMPL_NEUTRAL` before rendering with
         # use_canonical_space=True.
         self.SMPL_NEUTRAL = None
+        self.uniforms_on_device = False      # extension: draw sample_pdf's uniforms with the device generator (see render())
         self._packed = None
         self._packed_key = None
         self._planes_cache = {}
@@ -157,7 +158,9 @@ class Renderer(nn.Module):
             assert n_importance == n_samples, \
                 "the reference reshapes coarse densities to n_importance (renderer.py:250): counts must match"
             if u is None:
-                u = torch.rand([bs * R, n_importance]).to(dev)
+                # the reference draws sample_pdf's uniforms on the CPU generator and uploads them (renderer.py:545); `uniforms_on_device`
+                # (an extension, off by default) draws them on the device instead: same distribution, no 2 MB upload per fitting step
+                u = torch.rand([bs * R, n_importance], device=dev) if self.uniforms_on_device else torch.rand([bs * R, n_importance]).to(dev)
             u = u.reshape(bs, R, n_importance)
         if not self.test:
             return self._render_training(tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,

@@ -14,6 +14,7 @@ torch.manual_seed(0)
 r = Renderer(use_canonical_space=canonical, triplane_dim=256, triplane_ch=27, test=False)
 r.load_state_dict(syn.render_mlp_state(3), strict=False)
 r = r.to(dev)
+r.uniforms_on_device = os.environ.get('HL_U_DEVICE', '1') == '1'
 tri = torch.nn.Parameter((0.1 * torch.randn((2, 4, 3, 9, 256, 256))).to(dev))
 opt = torch.optim.Adam([{'params': list(r.parameters()), 'lr': 5e-4}, {'params': [tri], 'lr': 1e-2}], betas=(0.9, 0.999))
 bs, R, N = 2, 2048, 128
