@@ -364,7 +364,9 @@ def render(chunk=1024 * 32, rays_o=None, rays_d=None, near=0., far=1., tri_plane
             lower = torch.cat([zc[..., :1], mids], -1)
             zs.append(lower + (upper - lower) * torch.rand(zc.shape, device=rays_o.device))
         z = torch.cat(zs, 1)
-    if n_importance > 0:
+    if n_importance > 0 and getattr(core, "uniforms_on_device", False):
+        u = torch.rand([batch_size, R, n_importance], device=rays_o.device)      # extension, see Renderer.render
+    elif n_importance > 0:
         for i in range(0, R, chunk):
             cr = min(chunk, R - i)
             us.append(torch.rand([batch_size * cr, n_importance]).reshape(batch_size, cr, n_importance))
