@@ -57,8 +57,35 @@ def test_gradients_match_reference_golden(name, dev):
         close(d_mlp[k], torch.from_numpy(g["d_" + k]), k)
 
 
+def test_gradients_at_training_sample_counts(dev):
+    """The fitting configuration's per-ray sizes - 128 stratified + 128 importance samples, 256x256x27 tri-plane - on 512 rays (what the
+    oracle's autograd finishes in seconds); the gradient is a sum over rays, so this is the full-size arithmetic per ray."""
+    from humanliff_amd import synthetic as syn
+    g = torch.Generator().manual_seed(8)
+    ro, rd, nr, fr = syn.orbit_rays(1, 8, 96, 96)
+    pick = torch.nonzero(fr != 1).flatten()
+    pick = pick[torch.randperm(pick.numel(), generator=g)[:512]]
+    ro, rd, nr, fr = ro[pick], rd[pick], nr[pick], fr[pick]
+    N = 128
+    t = torch.linspace(0., 1., steps=N)
+    z = nr[:, None] * (1. - t) + fr[:, None] * t
+    mids = .5 * (z[:, 1:] + z[:, :-1])
+    lower, upper = torch.cat([z[:, :1], mids], -1), torch.cat([mids, z[:, -1:]], -1)
+    z = lower + (upper - lower) * torch.rand(z.shape, generator=g)
+    i = dict(planes=syn.triplane(seed=13), bounds=torch.tensor(syn.WORLD_BOUNDS), mlp=syn.render_mlp_state(5),
+             rays_o=ro, rays_d=rd, near=nr, far=fr, z=z, u=torch.rand((512, N), generator=g), noise=torch.randn((512, 2 * N), generator=g),
+             G_rgb=torch.randn((512, 3), generator=g) / 512, G_acc=torch.randn((512,), generator=g) / 512, n_samples=N, white_bkgd=True)
+    rgb, acc, d_planes, d_mlp = hip_grads(i, dev)
+    o_rgb, o_acc, o_planes, o_mlp = oracle_grads(i)
+    assert (rgb - o_rgb).abs().max() < 2e-5 and (acc - o_acc).abs().max() < 2e-5
+    close(d_planes, o_planes, "tri_planes")
+    for k in MLP_KEYS:
+        close(d_mlp[k], o_mlp[k], k)
+
+
 def test_gradients_match_oracle_larger(dev):
-    """1 000 rays x (48+48) samples on a 64x64 tri-plane, ragged last tile, stratified depths; cotangents like an MSE loss."""
+    """1 000 rays x (48+48) samples on a 72x72 tri-plane (ragged scatter tiles), ragged last ray tile, stratified depths; cotangents
+    like an MSE loss."""
     from humanliff_amd import synthetic as syn
     g = torch.Generator().manual_seed(3)
     ro, rd, nr, fr = syn.orbit_rays(5, 8, 64, 64)
@@ -70,7 +97,7 @@ def test_gradients_match_oracle_larger(dev):
     z = nr[:, None] * (1. - t) + fr[:, None] * t
     mids = .5 * (z[:, 1:] + z[:, :-1])
     z = torch.cat([z[:, :1], mids], -1) + (torch.cat([mids, z[:, -1:]], -1) - torch.cat([z[:, :1], mids], -1)) * torch.rand(z.shape, generator=g)
-    i = dict(planes=syn.triplane(seed=12, H=64, W=64), bounds=torch.tensor(syn.WORLD_BOUNDS), mlp=syn.render_mlp_state(4),
+    i = dict(planes=syn.triplane(seed=12, H=72, W=72), bounds=torch.tensor(syn.WORLD_BOUNDS), mlp=syn.render_mlp_state(4),
              rays_o=ro, rays_d=rd, near=nr, far=fr, z=z, u=torch.rand((1000, N), generator=g), noise=torch.randn((1000, 2 * N), generator=g),
              G_rgb=torch.randn((1000, 3), generator=g) / 1000, G_acc=torch.randn((1000,), generator=g) / 1000, n_samples=N, white_bkgd=False)
     rgb, acc, d_planes, d_mlp = hip_grads(i, dev)
