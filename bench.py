@@ -307,7 +307,7 @@ def fit_stage_times(r, planes, bounds, ro, rd, nr, fr, N, dev):
     import ctypes as C
     from humanliff_amd import _lib
     from humanliff_amd.NeRF.renderer import untile_rows
-    from humanliff_amd.NeRF.train import train_rows
+    from humanliff_amd.NeRF.train import _row_pad, train_rows
     L = _lib.lib()
     p, st = _lib.ptr, _lib.stream_ptr()
     R = ro.shape[0]
@@ -322,7 +322,8 @@ def fit_stage_times(r, planes, bounds, ro, rd, nr, fr, N, dev):
     noise = torch.randn((R, 2 * N), device=dev)
     g_rgb, g_acc = torch.randn((R, 3), device=dev) / R, torch.randn((R,), device=dev) / R
     e = lambda n: torch.empty(n, dtype=torch.float32, device=dev)  # noqa: E731
-    act, delta = e((act_rows, P)), e((del_rows, P))
+    LD = P + _row_pad()          # row pitch of the two matrices, as NeRF/train.py allocates them
+    act, delta = e((act_rows, LD)), e((del_rows, LD))
     vc, vn, zn, d_rec = e(T32 * N * 4), e(T32 * N * 4), e(T32 * N), e((P, 4))
     rgb, acc, dep = e((R, 3)), e(R), e(R)
     scratch = e(L.hl_render_composite_backward_scratch_bytes(R, N, N) // 4)
@@ -338,20 +339,20 @@ def fit_stage_times(r, planes, bounds, ro, rd, nr, fr, N, dev):
     d_planes = e((27, H, W))
     ro, rd, nr, fr, bd = ro.contiguous(), rd.contiguous(), nr.contiguous(), fr.contiguous(), bounds
     calls = [
-        ("eval_acts_coarse", lambda: L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(z), 0, R, N, p(vc), p(act), P, 0, st)),
+        ("eval_acts_coarse", lambda: L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(z), 0, R, N, p(vc), p(act), LD, 0, st)),
         ("importance", lambda: L.hl_render_importance_new(p(vc), p(rd), p(nr), p(fr), p(z), p(u), R, N, N, p(zn), st)),
-        ("eval_acts_new", lambda: L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, N, p(vn), p(act), P, T32 * N, st)),
+        ("eval_acts_new", lambda: L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, N, p(vn), p(act), LD, T32 * N, st)),
         ("composite", lambda: L.hl_render_composite_noise(p(nr), p(fr), p(z), p(zn), p(vc), p(vn), p(noise), R, N, N, 2, p(rgb), p(acc), p(dep), st)),
         ("composite_backward", lambda: L.hl_render_composite_backward(p(nr), p(fr), p(z), p(zn), p(vc), p(vn), p(noise), p(g_rgb), p(g_acc), R, N, N, 2,
-                                                                      p(d_rec[:T32 * N]), p(d_rec[T32 * N:]), p(delta), P, p(scratch), st)),
+                                                                      p(d_rec[:T32 * N]), p(d_rec[T32 * N:]), p(delta), LD, p(scratch), st)),
         ("pack_bwd", lambda: L.hl_render_mlp_pack_bwd(C.byref(params), p(bwd), st)),
         ("mlp_backward_coarse", lambda: L.hl_render_mlp_backward(p(packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(z), 0, R, N, p(d_rec[:T32 * N]),
-                                                                 p(act), P, 0, p(delta), P, 0, st)),
+                                                                 p(act), LD, 0, p(delta), LD, 0, st)),
         ("mlp_backward_new", lambda: L.hl_render_mlp_backward(p(packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, N, p(d_rec[T32 * N:]),
-                                                              p(act), P, T32 * N, p(delta), P, T32 * N, st)),
+                                                              p(act), LD, T32 * N, p(delta), LD, T32 * N, st)),
         ("plane_grads", lambda: L.hl_render_plane_grads(H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(z), p(untile_rows(zn, R, N).contiguous()), 1, R, N, N,
-                                                        p(delta), P, p(d_planes), st)),
-        ("weight_grads", lambda: L.hl_render_weight_grads(p(delta), P, p(act), P, P, C.byref(gp), st)),
+                                                        p(delta), LD, p(d_planes), st)),
+        ("weight_grads", lambda: L.hl_render_weight_grads(p(delta), LD, p(act), LD, P, C.byref(gp), st)),
     ]
     ms = {}
     for rep in range(2):          # second round is the measurement
@@ -366,7 +367,8 @@ def fit_stage_times(r, planes, bounds, ro, rd, nr, fr, N, dev):
     wg_bytes = 1365 * P * 4
     ach = wg_bytes / (ms["weight_grads"] * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": "k_wgrad (14 parameter gradients = delta rows x activation rows^T over the sample points of one subject)",
-            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": 2863.1e6,
+            "traffic_source": "profiles/r01_pmc_fit_traffic.md (rocprofv3 --pmc FETCH_SIZE, corrected x2; = the algorithmic 2.86 GB)",
             "launch_ms": ms["weight_grads"], "mfma_tflops": round(2 * 66304 * P / (ms["weight_grads"] * 1e-3) / 1e12, 2)}
     return {"ms": ms, "roofline": roof}
 

@@ -25,6 +25,14 @@ import torch
 from .. import _lib
 
 
+def _row_pad():
+    """Extra floats per matrix row.  The number of sample points is a power of two in the usual configurations (2048 rays x 256 samples
+    -> rows exactly 2 MiB apart), which sends the same column of every row to the same HBM channel; an odd multiple of 256 bytes spreads
+    them (HL_TRAIN_ROW_PAD overrides, in floats, multiple of 32)."""
+    import os
+    return int(os.environ.get("HL_TRAIN_ROW_PAD", "96"))
+
+
 def train_rows():
     a, d = C.c_int(0), C.c_int(0)
     _lib.lib().hl_render_train_rows(C.byref(a), C.byref(d))
@@ -47,7 +55,8 @@ class RenderRaysFunction(torch.autograd.Function):
         act_rows, _ = train_rows()
         packed = renderer._packed_mlp(dev)
         pp = renderer._packed_planes(planes)
-        act = torch.empty((act_rows, P), dtype=torch.float32, device=dev)
+        LD = P + _row_pad()       # row pitch: see _row_pad
+        act = torch.empty((act_rows, LD), dtype=torch.float32, device=dev)
         vc = torch.empty(T32 * N * 4, dtype=torch.float32, device=dev)
         vn = torch.empty(T32 * Ni * 4, dtype=torch.float32, device=dev)
         zn = torch.empty(T32 * Ni, dtype=torch.float32, device=dev)
@@ -58,10 +67,10 @@ class RenderRaysFunction(torch.autograd.Function):
         dfm = geo.get("deform")      # canonical space: (verts4, table, R host, Th host); `bounds` is then t_world_bounds
         pts = None
         if dfm is None:
-            _lib.check(L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), 0, R, N, p(vc), p(act), P, 0,
+            _lib.check(L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), 0, R, N, p(vc), p(act), LD, 0,
                                              st), "hl_render_eval_acts")
             _lib.check(L.hl_render_importance_new(p(vc), p(rd), p(nr), p(fr), p(zb), p(ub), R, N, Ni, p(zn), st), "hl_render_importance_new")
-            _lib.check(L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, p(vn), p(act), P,
+            _lib.check(L.hl_render_eval_acts(p(packed), p(pp), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, p(vn), p(act), LD,
                                              T32 * N, st), "hl_render_eval_acts")
         else:
             verts4, table, Rh, Th = dfm
@@ -71,12 +80,12 @@ class RenderRaysFunction(torch.autograd.Function):
             scr = torch.empty(4, dtype=torch.float32, device=dev)
             _lib.check(L.hl_deform_rays(p(ro), p(rd), p(nr), p(fr), p(zb), 0, R, N, Rh.ctypes.data, Th.ctypes.data, p(verts4), p(table), nv,
                                         p(pts[0]), p(dirs[0]), p(scr), st), "hl_deform_rays")
-            _lib.check(L.hl_render_eval_points_acts(p(packed), p(pp), H, W, p(bd), p(pts[0]), p(dirs[0]), R, N, p(vc), p(act), P, 0, st),
+            _lib.check(L.hl_render_eval_points_acts(p(packed), p(pp), H, W, p(bd), p(pts[0]), p(dirs[0]), R, N, p(vc), p(act), LD, 0, st),
                        "hl_render_eval_points_acts")
             _lib.check(L.hl_render_importance_new(p(vc), p(rd), p(nr), p(fr), p(zb), p(ub), R, N, Ni, p(zn), st), "hl_render_importance_new")
             _lib.check(L.hl_deform_rays(p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, Rh.ctypes.data, Th.ctypes.data, p(verts4), p(table), nv,
                                         p(pts[1]), p(dirs[1]), p(scr), st), "hl_deform_rays")
-            _lib.check(L.hl_render_eval_points_acts(p(packed), p(pp), H, W, p(bd), p(pts[1]), p(dirs[1]), R, Ni, p(vn), p(act), P, T32 * N, st),
+            _lib.check(L.hl_render_eval_points_acts(p(packed), p(pp), H, W, p(bd), p(pts[1]), p(dirs[1]), R, Ni, p(vn), p(act), LD, T32 * N, st),
                        "hl_render_eval_points_acts")
         ctx.pts = pts
         _lib.check(L.hl_render_composite_noise(p(nr), p(fr), p(zb), p(zn), p(vc), p(vn), p(noise), R, N, Ni, flags, p(rgb), p(acc),
@@ -106,27 +115,28 @@ class RenderRaysFunction(torch.autograd.Function):
         p, st = _lib.ptr, _lib.stream_ptr()
         d_rec = torch.empty((P, 4), dtype=torch.float32, device=dev)          # rows [0, T32*N): coarse pass, then the new depths
         dvc, dvn = d_rec[:T32 * N], d_rec[T32 * N:]
-        delta = torch.empty((del_rows, P), dtype=torch.float32, device=dev)
+        LD = P + _row_pad()
+        delta = torch.empty((del_rows, LD), dtype=torch.float32, device=dev)
         scratch = torch.empty(L.hl_render_composite_backward_scratch_bytes(R, N, Ni) // 4, dtype=torch.float32, device=dev)
         _lib.check(L.hl_render_composite_backward(p(nr), p(fr), p(zb), p(zn), p(vc), p(vn), p(noise), p(g_rgb), p(g_acc), R, N, Ni, flags,
-                                                  p(dvc), p(dvn), p(delta), P, p(scratch), st), "hl_render_composite_backward")
+                                                  p(dvc), p(dvn), p(delta), LD, p(scratch), st), "hl_render_composite_backward")
         # transposed weights of the values the forward pass used
         params = _lib.RenderMlpParams(*[C.c_void_p(t.data_ptr()) for t in mlp])
         bwd = torch.empty(L.hl_render_mlp_bwd_packed_bytes() // 4, dtype=torch.float32, device=dev)
         _lib.check(L.hl_render_mlp_pack_bwd(C.byref(params), p(bwd), st), "hl_render_mlp_pack_bwd")
-        _lib.check(L.hl_render_mlp_backward(p(ctx.packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), 0, R, N, p(dvc), p(act), P,
-                                            0, p(delta), P, 0, st), "hl_render_mlp_backward")
-        _lib.check(L.hl_render_mlp_backward(p(ctx.packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, p(dvn), p(act), P,
-                                            T32 * N, p(delta), P, T32 * N, st), "hl_render_mlp_backward")
+        _lib.check(L.hl_render_mlp_backward(p(ctx.packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), 0, R, N, p(dvc), p(act), LD,
+                                            0, p(delta), LD, 0, st), "hl_render_mlp_backward")
+        _lib.check(L.hl_render_mlp_backward(p(ctx.packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, Ni, p(dvn), p(act), LD,
+                                            T32 * N, p(delta), LD, T32 * N, st), "hl_render_mlp_backward")
         d_planes = torch.empty((27, H, W), dtype=torch.float32, device=dev)
         if ctx.needs_input_grad[2] and ctx.pts is not None:
             sb = torch.empty(L.hl_render_plane_grads_points_scratch_bytes(R, N, Ni) // 4, dtype=torch.float32, device=dev)
-            _lib.check(L.hl_render_plane_grads_points(H, W, p(bd), p(ctx.pts[0]), p(ctx.pts[1]), R, N, Ni, p(delta), P, p(d_planes), p(sb), st),
+            _lib.check(L.hl_render_plane_grads_points(H, W, p(bd), p(ctx.pts[0]), p(ctx.pts[1]), R, N, Ni, p(delta), LD, p(d_planes), p(sb), st),
                        "hl_render_plane_grads_points")
         elif ctx.needs_input_grad[2]:
             from .renderer import untile_rows
             zr = untile_rows(zn, R, Ni).contiguous()      # the scatter walks one ray per wave: give it the depths of a ray in one line
-            _lib.check(L.hl_render_plane_grads(H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), p(zr), 1, R, N, Ni, p(delta), P, p(d_planes),
+            _lib.check(L.hl_render_plane_grads(H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), p(zr), 1, R, N, Ni, p(delta), LD, p(d_planes),
                                                st), "hl_render_plane_grads")
         # all 14 parameter gradients: rows of `delta` x rows of `act` over the sample points (include/humanliff_hip.h lists the rows)
         flat = torch.zeros(sum(t.numel() for t in mlp), dtype=torch.float32, device=dev)
@@ -135,7 +145,7 @@ class RenderRaysFunction(torch.autograd.Function):
             grads.append(flat[o:o + t.numel()].view(t.shape))
             o += t.numel()
         gp = _lib.RenderMlpParams(*[C.c_void_p(g.data_ptr()) for g in grads])
-        _lib.check(L.hl_render_weight_grads(p(delta), P, p(act), P, P, C.byref(gp), st), "hl_render_weight_grads")
+        _lib.check(L.hl_render_weight_grads(p(delta), LD, p(act), LD, P, C.byref(gp), st), "hl_render_weight_grads")
         needs = ctx.needs_input_grad   # (renderer, geo, planes, *mlp)
         out = [None, None, d_planes.view(3, 9, H, W) if needs[2] else None]
         out += [g if needs[3 + i] else None for i, g in enumerate(grads)]
