@@ -237,7 +237,7 @@ struct MarchArgs {
 // rows of the activation matrix ([features | hidden1] and [feature_linear | view encoding] are the concatenations the network feeds
 // to pts_linears.2 and views_linear, so their weight gradients are single products)
 constexpr int ROW_F = 0, ROW_X1 = 27, ROW_X0 = 155, ROW_X2 = 283, ROW_Y = 411, ROW_EV = 539, ROW_V = 566, ACT_ROWS = 630;
-constexpr int DROW_X0 = 0, DROW_X1 = 128, DROW_X2 = 256, DROW_Y = 384, DROW_V = 512, DROW_REC = 576, DROW_DF = 580, DEL_ROWS = 607;
+constexpr int DROW_X0 = 0, DROW_X1 = 128, DROW_X2 = 256, DROW_Y = 384, DROW_V = 512, DROW_REC = 576, DROW_DF = 580, DROW_DFT = 607, DEL_ROWS = 634;
 
 // Hidden (inline-asm) global store / atomic add: see the note at the record store of k_march - a compiler-visible VMEM write in the
 // sample loop turns every counted vmcnt wait of the weight ring into vmcnt(0).
@@ -1703,6 +1703,40 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 #endif
 }
 
+// The feature-delta rows come out of k_mlp_bwd in the record order (tile-major: 32 rays per sample side by side); the scatter kernels
+// walk one ray per wave with lanes = samples, which in that order is a 4-byte gather per lane (measured 0.9-1.8 GB of sector traffic
+// for 57 MB of payload).  k_df_transpose rewrites the 27 rows ray-major (row DROW_DFT + k, column pass offset + ray * S + s).
+struct DfTransposeArgs {
+    float *del;
+    long long del_stride, R;
+    int N, Ni;
+};
+__global__ __launch_bounds__(256) void k_df_transpose(const DfTransposeArgs a) {
+    __shared__ float t[64][33];
+    const int k = blockIdx.x;
+    const long long tile = blockIdx.y;
+    const long long tiles_n = (a.R + 31) / 32, colsA = tiles_n * 32 * a.N;
+    const float *src = a.del + (long long)(DROW_DF + k) * a.del_stride;
+    float *dst = a.del + (long long)(DROW_DFT + k) * a.del_stride;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int S = pass ? a.Ni : a.N;
+        const long long base = pass ? colsA : 0;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+                const int s = s0 + (i >> 5), r = i & 31;
+                if (s < S) t[i >> 5][r] = src[base + (tile * S + s) * 32 + r];
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+                const int r = i >> 6, s = s0 + (i & 63);
+                const long long ray = tile * 32 + r;
+                if (s < S && ray < a.R) dst[base + ray * S + s] = t[i & 63][r];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Tri-plane gradient: transpose of the bilinear lookup [renderer.py:502-531].  Sending every sample point's 27 feature deltas
 // through their four taps with global float atomics costs 108 atomics per point (measured: 1.1 ms per 262 144 points, 2/3 of the
 // backward kernel, bound by the L2 atomic units).  Instead one workgroup OWNS a 16x16-texel tile of one (plane, group) image
@@ -1733,7 +1767,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs 
     const float offH = (float)(1.0 / (double)a.H);
     const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
     const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
-    const float *df = a.del + (long long)(DROW_DF + 3 * q) * a.del_stride;
+    const float *df = a.del + (long long)(DROW_DFT + 3 * q) * a.del_stride;      // ray-major copy (k_df_transpose)
     // texel coordinates of the point at depth z of a ray - the forward pass's arithmetic, bit for bit
     auto texel = [&](const float (&o)[3], const float (&d)[3], float z, float &ix, float &iy) {
         const float px = o[0] + d[0] * z, py = o[1] + d[1] * z, pz = o[2] + d[2] * z;
@@ -1787,7 +1821,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs 
         const float nr = bcast(lnr, j), fr = bcast(lfr, j), za = bcast(lza, j), zb = bcast(lzb, j);
         for (int pass = 0; pass < 2; ++pass) {
             const int S = pass ? a.Ni : a.N;
-            const long long col0 = (pass ? colsA : 0) + tile * 32LL * S + rl;
+            const long long col0 = (pass ? colsA : 0) + ray * S;
             for (int s0 = 0; s0 < S; s0 += 64) {
                 const int si = s0 + lane;
                 if (si >= S) continue;
@@ -1796,7 +1830,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs 
                 else if (a.zc) z = a.zc[ray * a.N + si];
                 else { const float t = linspace01(si, a.N); z = nr * (1.f - t) + fr * t; }
                 if (z < za || z > zb) continue;
-                const long long col = col0 + 32LL * si;
+                const long long col = col0 + si;
                 float ix, iy;
                 texel(o, d, z, ix, iy);
                 const float x0f = floorf(ix), y0f = floorf(iy);
@@ -1885,7 +1919,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter_pts(const ScatterP
     const float offH = (float)(1.0 / (double)a.H);
     const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
     const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
-    const float *df = a.del + (long long)(DROW_DF + 3 * q) * a.del_stride;
+    const float *df = a.del + (long long)(DROW_DFT + 3 * q) * a.del_stride;      // ray-major copy (k_df_transpose)
     const int cu = (p == 2) ? 2 : 0, cv = (p == 1) ? 2 : 1;          // which normalised coordinate drives u / v of this plane
     auto to_px = [](float gn, int size) { return ((gn + 1.f) * (float)size - 1.f) / 2.f; };
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1907,7 +1941,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter_pts(const ScatterP
             if (s >= S) continue;
             const long long lc = ((ray >> 5) * S + s) * 32 + (ray & 31);
             const float4 pt = a.pts[pass][lc];
-            const long long col = (pass ? colsA : 0) + lc;
+            const long long col = (pass ? colsA : 0) + ray * S + s;
             const float nx = 2.f * (pt.x - bmin0) / bext0 - 1.f;
             const float ny = 2.f * (pt.y - bmin1) / bext1 - 1.f;
             const float nz = 2.f * (pt.z - bmin2) / bext2 - 1.f;
@@ -2317,6 +2351,8 @@ int hl_render_plane_grads(int H, int W, const float *bounds, const float *rays_o
     HL_REQUIRE(bounds && rays_o && rays_d && near && far && z_new && del && d_planes, "hl_render_plane_grads: null argument");
     HL_REQUIRE(H > 0 && W > 0 && n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_plane_grads: bad sizes");
     HL_REQUIRE(del_stride >= tiles32(n_rays) * 32 * (int64_t)(n_samples + n_importance), "hl_render_plane_grads: delta rows too short");
+    DfTransposeArgs tr{const_cast<float *>(del), del_stride, n_rays, n_samples, n_importance};
+    hipLaunchKernelGGL(k_df_transpose, dim3(27, (unsigned)tiles32(n_rays)), dim3(256), 0, (hipStream_t)stream, tr);
     ScatterArgs a{rays_o, rays_d, near, far, bounds, z_vals, z_new, z_new_rows, n_rays, n_samples, n_importance, H, W, del, del_stride, d_planes};
     const unsigned tiles = (unsigned)(((W + SC_TILE - 1) / SC_TILE) * ((H + SC_TILE - 1) / SC_TILE));
     hipLaunchKernelGGL(k_plane_scatter, dim3(9, tiles), dim3(SC_THREADS), 0, (hipStream_t)stream, a);
@@ -2354,6 +2390,8 @@ int hl_render_plane_grads_points(int H, int W, const float *bounds, const float 
     HL_REQUIRE(bounds && pts_coarse && pts_new && del && d_planes && scratch, "hl_render_plane_grads_points: null argument");
     HL_REQUIRE(H > 0 && W > 0 && n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_plane_grads_points: bad sizes");
     HL_REQUIRE(del_stride >= tiles32(n_rays) * 32 * (int64_t)(n_samples + n_importance), "hl_render_plane_grads_points: delta rows too short");
+    DfTransposeArgs tr{const_cast<float *>(del), del_stride, n_rays, n_samples, n_importance};
+    hipLaunchKernelGGL(k_df_transpose, dim3(27, (unsigned)tiles32(n_rays)), dim3(256), 0, (hipStream_t)stream, tr);
     ScatterPtsArgs a{{(const float4 *)pts_coarse, (const float4 *)pts_new}, bounds, n_rays, n_samples, n_importance, H, W, del, del_stride,
                      d_planes, (float *)scratch};
     const long long nblk = n_rays * ((n_samples + 63) / 64 + (n_importance + 63) / 64);

@@ -131,9 +131,10 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
  *   activations (630 rows): [0,27) tri-plane features | [27,155) softplus(pts_linears.1) | [155,283) softplus(pts_linears.0) |
  *                           [283,411) softplus(pts_linears.2) | [411,539) feature_linear | [539,566) view encoding |
  *                           [566,630) softplus(views_linear)
- *   deltas (607 rows, dL/d pre-activation): [0,128) pts_linears.0 | [128,256) pts_linears.1 | [256,384) pts_linears.2 |
+ *   deltas (634 rows, dL/d pre-activation): [0,128) pts_linears.0 | [128,256) pts_linears.1 | [256,384) pts_linears.2 |
  *                           [384,512) feature_linear | [512,576) views_linear | 576 alpha_linear | [577,580) rgb_linear |
- *                           [580,607) dL/d tri-plane features
+ *                           [580,607) dL/d tri-plane features | [607,634) the same, ray-major (written by hl_render_plane_grads*,
+ *                           which therefore take `del` as scratch although it is declared const)
  * so that every weight gradient is one product delta_rows x activation_rows^T over the sample points (e.g. pts_linears.2.weight =
  * deltas[256:384] x activations[0:155]^T) and every bias gradient a row sum: hl_render_weight_grads.
  *   hl_render_composite_noise     hl_render_composite with `noise` (R, n_samples+n_importance) added to the raw density of sorted
