@@ -1595,10 +1595,19 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
     const unsigned act_stride4 = (unsigned)a.act_stride * 4u, del_stride4 = (unsigned)a.del_stride * 4u;
     const __amdgpu_buffer_rsrc_t act_rd = __builtin_amdgcn_make_buffer_rsrc((void *)a.act, (short)0, (int)((unsigned)ACT_ROWS * act_stride4), 0x00020000);
     const i32x4 del_rs = matrix_rsrc(a.del, (unsigned)DEL_ROWS * del_stride4);
-    auto dact = [&](unsigned acol, int row0, int t, int r) -> float {
-        const float h = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(act_rd, (int)acol, (int)((unsigned)(row0 + unit_of(t, r, 0)) * act_stride4), 0));
-        return 1.f - __expf(-h);
+    // The activations a block of deltas is multiplied with are fetched one block AHEAD, into ACT: the hidden stores carry a "memory"
+    // clobber, so the compiler cannot hoist a load above them itself, and a load issued where its value is needed waits out an HBM
+    // round trip (the matrix was written a millisecond ago and is long out of the caches) five times per sample.
+    auto fetch_act = [&](f32x16 (&dst)[4], unsigned acol, int row0, int ntiles) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < ntiles) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dst[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(act_rd, (int)acol, (int)((unsigned)(row0 + unit_of(t, r, 0)) * act_stride4), 0));
+            }
     };
+    auto dsp = [](float h) -> float { return 1.f - __expf(-h); };     // softplus'(pre) from softplus(pre)
 
     const int s_lo = (int)blockIdx.y * a.s_per, s_hi = min(S, s_lo + a.s_per);
     for (int s = s_lo; s < s_hi; ++s) {
@@ -1611,14 +1620,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
         else { const float t = linspace01(s, S); zc = nr * (1.f - t) + fr * t; }
 
         // ---- rgb_linear^T, softplus' of views_linear ----
-        f32x16 G[4], D[4];
+        f32x16 G[4], D[4], AV[4], ACT[4];
+        fetch_act(AV, actp, ROW_V, 2);
+        fetch_act(ACT, actp, ROW_X2, 4);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = (t * 2 + half) * 16 + r;
                 const float g = small[SM_RW + o] * d.y + small[SM_RW + 64 + o] * d.z + small[SM_RW + 128 + o] * d.w;
-                G[t][r] = g * dact(actp, ROW_V, t, r);
+                G[t][r] = g * dsp(AV[t][r]);
             }
         if (tile_on) {
 #pragma unroll
@@ -1648,7 +1659,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) G[t][r] *= dact(actp, ROW_X2, t, r);
+            for (int r = 0; r < 16; ++r) G[t][r] *= dsp(ACT[t][r]);
+        fetch_act(ACT, actp, ROW_X1, 4);
         if (tile_on) store_rows<4>(del_rs, delp, del_stride4, DROW_X2, G);
         // ---- pts_linears.2^T: tri-plane feature columns -> DF, hidden columns -> delta of pts_linears.1 ----
         f32x16 DF[1];
@@ -1669,7 +1681,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) D[t][r] *= dact(actp, ROW_X1, t, r);
+            for (int r = 0; r < 16; ++r) D[t][r] *= dsp(ACT[t][r]);
+        fetch_act(ACT, actp, ROW_X0, 4);
         if (tile_on) store_rows<4>(del_rs, delp, del_stride4, DROW_X1, D);
         // ---- pts_linears.1^T, softplus' of pts_linears.0 ----
 #pragma unroll
@@ -1684,7 +1697,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) G[t][r] *= dact(actp, ROW_X0, t, r);
+            for (int r = 0; r < 16; ++r) G[t][r] *= dsp(ACT[t][r]);
         if (tile_on) store_rows<4>(del_rs, delp, del_stride4, DROW_X0, G);
         // ---- pts_linears.0^T -> DF ----
         HL_BWD_ADVANCE(15)
