@@ -598,6 +598,7 @@ struct ImpArgs {
     float *z_all;
     int sig_stride;   // floats between consecutive rays' sigma (1: sigma array, 4: .x of the float4 sample records)
     int new_only;     // 1: write only the n_importance new depths, sorted, [R/32][Ni][32] (k_composite merges them with the coarse ones)
+    int rays_per_wave;  // 8: one workgroup per 32-ray tile; 1, 2, 4: the tile is spread over 8, 4, 2 workgroups (small ray batches)
 };
 
 __global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
@@ -607,13 +608,15 @@ __global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
     __shared__ float s_zA[4][2 * IMP_MAX_N];   // merged depths (padded to a power of two)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float *s_w = s_wA[wv], *s_z = s_zA[wv];
-    const long long tile = blockIdx.x;
+    const int parts = 8 / a.rays_per_wave;
+    const long long tile = blockIdx.x / parts;
+    const int part = (int)(blockIdx.x % parts);
     const int N = a.N, Ni = a.Ni;
     const int tot_n = N + Ni;
     int P = 1;
     while (P < tot_n) P <<= 1;
-    for (int rr = 0; rr < 8; ++rr) {
-        const int j = wv * 8 + rr;
+    for (int rr = 0; rr < a.rays_per_wave; ++rr) {
+        const int j = wv * 8 + part * a.rays_per_wave + rr;
         const long long ray_raw = tile * 32 + j;
         const long long ray = ray_raw < a.R ? ray_raw : a.R - 1;   // padded rays recompute the last one (never read back)
         const float nr = a.near[ray], fr = a.far[ray];
@@ -2137,6 +2140,13 @@ int hl_planes_pack(const float *planes, int H, int W, void *packed, void *stream
 }
 
 static inline int64_t tiles32(int64_t n_rays) { return (n_rays + 31) / 32; }
+// k_importance: a wave walks 8 rays of its tile one after the other; ray batches that would launch fewer than ~1024 workgroups that way
+// (fitting: 2048 rays = 64 tiles) give each wave fewer rays and the tile more workgroups
+static inline int imp_rays_per_wave(int64_t n_rays) {
+    int rpw = 8;
+    while (rpw > 1 && tiles32(n_rays) * (8 / rpw) < 1024) rpw >>= 1;
+    return rpw;
+}
 
 size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance) {
     if (n_rays <= 0 || n_importance <= 0) return 256;
@@ -2177,8 +2187,8 @@ int hl_render_importance(const float *sigma, const float *rays_d, const float *n
     HL_REQUIRE(n_rays > 0 && n_samples >= 3 && n_importance >= 1, "hl_render_importance: bad sizes");
     if (n_samples > IMP_MAX_N || n_importance > IMP_MAX_N)
         return hl::fail(HL_ERR_UNSUPPORTED, "hl_render_importance: n_samples/n_importance > %d", IMP_MAX_N);
-    ImpArgs a{sigma, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_all_out, 1, 0};
-    hipLaunchKernelGGL(k_importance, dim3((unsigned)tiles32(n_rays)), dim3(256), 0, (hipStream_t)stream, a);
+    ImpArgs a{sigma, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_all_out, 1, 0, imp_rays_per_wave(n_rays)};
+    hipLaunchKernelGGL(k_importance, dim3((unsigned)(tiles32(n_rays) * (8 / a.rays_per_wave))), dim3(256), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_importance");
 }
 
@@ -2227,8 +2237,8 @@ int hl_render_importance_new(const float *records, const float *rays_d, const fl
     HL_REQUIRE(n_rays > 0 && n_samples >= 3 && n_importance >= 1, "hl_render_importance_new: bad sizes");
     if (n_samples > IMP_MAX_N || n_importance > IMP_MAX_N)
         return hl::fail(HL_ERR_UNSUPPORTED, "hl_render_importance_new: n_samples/n_importance > %d", IMP_MAX_N);
-    ImpArgs a{records, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_new_out, 4, 1};
-    hipLaunchKernelGGL(k_importance, dim3((unsigned)tiles32(n_rays)), dim3(256), 0, (hipStream_t)stream, a);
+    ImpArgs a{records, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_new_out, 4, 1, imp_rays_per_wave(n_rays)};
+    hipLaunchKernelGGL(k_importance, dim3((unsigned)(tiles32(n_rays) * (8 / a.rays_per_wave))), dim3(256), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_importance<new>");
 }
 
