@@ -289,13 +289,11 @@ class Renderer(nn.Module):
         direction (0, 0, 1) and explicit depths Z, so the sample points are bit-identical to the reference's
         meshgrid.  Returns a (resolution,)*3 fp32 tensor on the tri-plane's device.
         """
-        if self.use_canonical_space:
-            raise NotImplementedError("use_canonical_space=True is not built")
         assert tri_planes is not None and tri_planes.shape[0] == 1 and tri_planes.shape[1:3] == (3, 9)
         dev = tri_planes.device
         H, W = tri_planes.shape[-2:]
         N = int(resolution)
-        bounds = tp_input['world_bounds'].reshape(-1, 2, 3)[0].to(torch.float32).contiguous()
+        bounds = tp_input['world_bounds'].reshape(-1, 2, 3)[0].to(device=dev, dtype=torch.float32).contiguous()
         lo, hi = bounds[0].cpu(), bounds[1].cpu()
         X = torch.linspace(float(lo[0]), float(hi[0]), N)
         Y = torch.linspace(float(lo[1]), float(hi[1]), N)
@@ -308,7 +306,30 @@ class Renderer(nn.Module):
         packed, pp = self._packed_mlp(dev), self._packed_planes(tri_planes[0])
         out = torch.empty((N * N, N), dtype=torch.float32, device=dev)
         rays_per_launch = max(32, rays_per_launch // 32 * 32)
-        tmp = torch.empty(((rays_per_launch + 31) // 32) * 32 * N, dtype=torch.float32, device=dev)
+        T32 = ((rays_per_launch + 31) // 32) * 32
+        if self.use_canonical_space:
+            # renderer.py:311-314: the lattice spans world_bounds, every point goes through deform_target2c and is looked up in
+            # t_world_bounds.  Same column-rays; hl_deform_rays writes their canonical points, hl_render_eval_points evaluates them
+            # (full MLP: the density is the first value of the record)
+            from .deform import deform_tables
+            if self.SMPL_NEUTRAL is None:
+                raise RuntimeError("use_canonical_space=True needs the body model: set renderer.SMPL_NEUTRAL to the SMPL_to_tensor dict")
+            verts4, table, Rh, Th = deform_tables(self.SMPL_NEUTRAL, tp_input['params'], tp_input['t_params'], tp_input['vertices'].to(dev))
+            tb = tp_input['t_world_bounds'].reshape(-1, 2, 3)[0].to(device=dev, dtype=torch.float32).contiguous()
+            pc, dc = torch.empty((T32 * N, 4), device=dev), torch.empty((T32 * N, 4), device=dev)
+            rec, scr = torch.empty((T32 * N, 4), device=dev), torch.empty(4, device=dev)
+            for i in range(0, N * N, rays_per_launch):
+                j = min(N * N, i + rays_per_launch)
+                z = Z.to(dev)[None].expand(j - i, N).contiguous()
+                ro, rd = rays_o[i:j].contiguous(), rays_d[i:j].contiguous()
+                _lib.check(L.hl_deform_rays(_lib.ptr(ro), _lib.ptr(rd), _lib.ptr(zero[i:j]), _lib.ptr(zero[i:j]), _lib.ptr(z), 0, j - i, N,
+                                            Rh.ctypes.data, Th.ctypes.data, _lib.ptr(verts4), _lib.ptr(table), int(verts4.shape[0]), _lib.ptr(pc),
+                                            _lib.ptr(dc), _lib.ptr(scr), _lib.stream_ptr()), "hl_deform_rays")
+                _lib.check(L.hl_render_eval_points(_lib.ptr(packed), _lib.ptr(pp), H, W, _lib.ptr(tb), _lib.ptr(pc), _lib.ptr(dc), j - i, N,
+                                                   _lib.ptr(rec), _lib.stream_ptr()), "hl_render_eval_points")
+                out[i:j] = untile_rows(rec[:, 0].contiguous(), j - i, N)
+            return (-out).reshape(N, N, N)
+        tmp = torch.empty(T32 * N, dtype=torch.float32, device=dev)
         for i in range(0, N * N, rays_per_launch):
             j = min(N * N, i + rays_per_launch)
             z = Z.to(dev)[None].expand(j - i, N).contiguous()

@@ -404,3 +404,31 @@ def test_deform_group_culling_is_the_full_scan(mode, dev, tmp_path):
         outs.append(torch.load(out))
     assert torch.equal(outs[0]["pts"], outs[1]["pts"]) and torch.equal(outs[0]["dirs"], outs[1]["dirs"])
     assert torch.isfinite(outs[0]["pts"]).all()
+
+
+def test_canonical_density_grid_matches_oracle(dev):
+    """extract_geometry's density field with use_canonical_space=True (renderer.py:296-321): lattice over world_bounds, every point through
+    deform_target2c, looked up in t_world_bounds."""
+    from oracle import deform_oracle as do, render_oracle as orc
+    from humanliff_amd import synthetic as syn
+    V, N = 1200, 20
+    cpu_model = syn.smpl_like_model(V, 7)
+    pose = syn.smpl_like_pose(V, cpu_model, 17, n_points=8)
+    mlp = syn.render_mlp_state(3)
+    r = make_renderer(mlp, dev)
+    r.use_canonical_space = True
+    r.SMPL_NEUTRAL = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in cpu_model.items()}
+    planes = syn.triplane(seed=11, H=64, W=64)
+    lo, hi = pose["vertices"][0].min(0).values - 0.1, pose["vertices"][0].max(0).values + 0.1
+    tp = dict(pose)
+    tp["world_bounds"] = torch.stack([lo, hi])[None]
+    u = r.density_grid(tp, planes.to(dev), resolution=N, rays_per_launch=160).cpu()
+    X, Y, Z = (torch.linspace(float(lo[k]), float(hi[k]), N) for k in range(3))
+    xx, yy, zz = torch.meshgrid(X, Y, Z, indexing="ij")
+    pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], 1)
+    with torch.no_grad():
+        can, _, ids = do.deform_target2c(cpu_model, pose, pts, None)
+        sig = orc.mlp(mlp, orc.plane_features(planes[0], can, pose["t_world_bounds"][0]))
+    err = (u.reshape(-1) + sig).abs()
+    assert (err < 5e-5).float().mean() > 0.999          # near-tie nearest vertices may resolve differently in float32
+    assert torch.isfinite(u).all()
