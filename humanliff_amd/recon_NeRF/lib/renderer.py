@@ -26,3 +26,13 @@ class Renderer(_Renderer):
     def render(self, tp_input, world_pts, z_vals, rays_o, rays_d, near, far, n_importance=128, white_bkgd=False, **kw):
         tri_planes = self.tri_planes[tp_input['instance_idx'], tp_input['cloth_layer_index']]
         return super().render(tp_input, world_pts, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd, **kw)
+
+    def _own_planes(self, tp_input):
+        return self.tri_planes[tp_input['instance_idx'], tp_input['cloth_layer_index']].detach()
+
+    def density_grid(self, tp_input, resolution=512, **kw):
+        return super().density_grid(tp_input, self._own_planes(tp_input)[:1], resolution, **kw)
+
+    def extract_geometry(self, tp_input, resolution, threshold=0.0):
+        """recon_NeRF/lib/renderer.py:304 (no tri_planes argument: the module's own, first subject of the batch)."""
+        return super().extract_geometry(tp_input, self._own_planes(tp_input)[:1], resolution, threshold)
