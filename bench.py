@@ -80,6 +80,48 @@ def max_over_ranks(seconds, world, dev):
     return float(t.item())
 
 
+class ClockSampler:
+    """Samples the shader clock (sclk) of the busiest GPU from sysfs while a leg runs (a thread reading
+    /sys/class/drm/card*/device/pp_dpm_sclk every 50 ms; the active level is the line marked '*')."""
+
+    def __init__(self, period=0.05):
+        import glob
+        self.files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.period, self.samples, self._stop, self._th = period, [], False, None
+
+    @staticmethod
+    def _read(path):
+        try:
+            for line in open(path).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].strip().split("M")[0])
+        except Exception:
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop:
+            vals = [v for v in (self._read(f) for f in self.files) if v is not None]
+            if vals:
+                self.samples.append(max(vals))
+            time.sleep(self.period)
+
+    def start(self):
+        import threading
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th is not None:
+            self._th.join()
+        if not self.samples:
+            return {"sclk_mhz_mean": None, "sclk_mhz_min": None, "sclk_samples": 0, "sclk_source": "pp_dpm_sclk not readable on this box"}
+        return {"sclk_mhz_mean": round(sum(self.samples) / len(self.samples), 1), "sclk_mhz_min": min(self.samples),
+                "sclk_mhz_max": max(self.samples), "sclk_samples": len(self.samples),
+                "sclk_source": "max over /sys/class/drm/card*/device/pp_dpm_sclk (active level), sampled every 50 ms during the leg"}
+
+
 def build_unet(dev, seed=1):
     from humanliff_amd import synthetic as syn
     from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion
@@ -127,17 +169,34 @@ def bench_unet(args, rank, world, dev):
     conv_ms, conv_fl, conv_n = ms[0], fl[0], nl[0]
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     executed = xf[0] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # `achieved` / `frac`: FLOPs the matrix pipe actually EXECUTES (Winograd F(2x2,3x3) issues 16 of the 36 multiplies of a direct 3x3
+    # convolution) over the conv-path time, against the fp32 MFMA peak - a real fraction (<= 1).  The algorithmic figure (direct-convolution
+    # FLOPs of SURVEY 8(d) over the same time) is reported next to it as `algorithmic`; it can exceed the peak.
     roof = {"bound": "mfma", "kernel": "k_conv_wino (Winograd F(2x2,3x3), large 3x3 layers) + k_conv_dma (direct implicit GEMM, the rest), "
-                                       "v_mfma_f32_32x32x2_f32; with their k_gn_apply pre-pass and k_splitk_finish; all launches of one denoise step",
-            "executed": {"tflops": round(executed, 2), "frac_of_peak": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
-                         "note": "`achieved` counts ALGORITHMIC FLOPs (direct convolution, SURVEY 8(d)); the Winograd layers issue 16/36 of "
-                                 "their multiplies, so `frac` can exceed 1 while the matrix pipe itself runs at `executed.frac_of_peak`"},
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                                       "v_mfma_f32_32x32x2_f32; with their pre/post passes (k_gn_apply, k_splitk_finish); all launches of one denoise step",
+            "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+            "algorithmic": {"tflops": round(achieved, 2), "speedup_vs_executed": round(achieved / executed, 3) if executed > 0 else None,
+                            "x_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                            "note": "direct-convolution FLOPs (SURVEY 8(d): 2*M*Cout*Cin*taps) over the same time; not a roofline fraction"},
             "traffic": PMC_TRAFFIC["k_conv_avg_launch_b4"] if B == 4 else None, "traffic_source": PMC_TRAFFIC["source"],
-            "launches_per_step": int(conv_n), "gflop_per_step": round(conv_fl / 1e9, 1), "ms_per_step": round(conv_ms, 3),
-            "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4),
+            "launches_per_step": int(conv_n), "gflop_per_step": round(conv_fl / 1e9, 1), "executed_gflop_per_step": round(xf[0] / 1e9, 1),
+            "ms_per_step": round(conv_ms, 3), "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4),
             "other_ms": {"groupnorm": round(ms[1], 3), "attention": round(ms[2], 3), "emb_prep": round(ms[3], 3)}}
+    # ---- sustained leg: the loop keeps running for >= 200 more steps; steps/s and the shader clock sampled meanwhile ----
+    roof["sustained"] = None
+    if world == 1 and args.sustained_steps > 0:
+        clk = ClockSampler()
+        torch.cuda.synchronize()
+        clk.start()
+        ts = time.perf_counter()
+        for _ in range(args.sustained_steps):
+            out = next(it)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - ts
+        roof["sustained"] = {"steps": args.sustained_steps, "value": round(B * args.sustained_steps / dt, 3), "unit": "denoise-steps/s",
+                             "ms_per_step": round(dt * 1e3 / args.sustained_steps, 3), "seconds": round(dt, 2), **clk.stop()}
+        assert torch.isfinite(out["sample"]).all()
     del it
     # ---- opt-in arithmetic mode (not the headline): fp32 products emulated with three bf16 planes per operand ----
     roof["bf16x3_mode"] = None
@@ -167,6 +226,72 @@ def bench_unet(args, rank, world, dev):
             "value": round(B * k3 / s3, 3), "unit": "denoise-steps/s", "steps": k3, "ms_per_step": round(s3 * 1e3 / k3, 3),
             "max_abs_diff_vs_fp32_forward": float((alt - ref).abs().max()), "forward_output_mean_abs": float(ref.abs().mean())}
     return secs, roof, sd, model
+
+
+def _psnr(a, b):
+    import math
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return 200.0 if mse == 0 else -10.0 * math.log10(mse)
+
+
+def e2e_chain(model, dev, golden=None):
+    """BASELINE configs[0] / [3] / [4] at one-GPU scale, against the REFERENCE's own outputs (tests/golden/chain_f4_ddim10.npz, made by
+    tests/golden/gen_golden_chain.py from /root/reference): the flow of scripts/triplane_sample_layered.py:112-177 on the production
+    network - per cloth layer y = layer, x_cond = the previous layer's sample, ddim_sample_loop (DDIM-10, B = 1) on injected noise,
+    sample.reshape(1,3,9,256,256), render() of one 128x128 orbit view at 32+32 samples.  Returns per-layer error figures (tri-plane
+    values are in [-1,1], colours in [0,1]); used by tests/test_e2e_gpu.py and by the `parity` object of the bench line."""
+    import numpy as np
+    from humanliff_amd import synthetic as syn
+    from humanliff_amd.NeRF import Renderer, render
+    from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
+    g = np.load(golden or os.path.join(ROOT, "tests", "golden", "chain_f4_ddim10.npz"))
+    diffusion = create_gaussian_diffusion(steps=1000, learn_sigma=False, noise_schedule="linear", timestep_respacing="ddim10")
+    rend = Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, smpl_type="smpl", test=True)
+    rend.load_state_dict(syn.render_mlp_state(3), strict=False)
+    rend = rend.to(dev)
+    IMG, NS, stride = int(g["img"]), int(g["n_samples"]), int(g["stride"])
+    rays_o, rays_d, near, far = syn.orbit_rays(int(g["view"]), int(g["n_views"]), IMG, IMG)
+    assert np.allclose([float(rays_d.double().sum()), float(rays_d.double().abs().sum())], g["rays_ck"], rtol=0, atol=1e-6)
+    tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].to(dev)}
+    n = {"i": 0}
+
+    def draw(shape):          # the generator's injected noise stream: draw i = randn from manual_seed(9000 + i)
+        gg = torch.Generator().manual_seed(9000 + n["i"])
+        n["i"] += 1
+        return torch.randn(tuple(shape), generator=gg)
+
+    shape = (1, 27, 256, 256)
+    x_cond = torch.zeros(shape, device=dev)
+    layers = []
+    orig = torch.randn_like
+    torch.randn_like = lambda ref: draw(ref.shape).to(ref.device)
+    try:
+        for layer in range(int(g["n_layers"])):
+            y = torch.full((1,), layer, dtype=torch.int64, device=dev)
+            x_T = draw(shape).to(dev)
+            sample = diffusion.ddim_sample_loop(model, shape, x_cond=x_cond, noise=x_T, clip_denoised=True, model_kwargs={"y": y})
+            s = sample.cpu()
+            want_sub = torch.from_numpy(g[f"sample{layer}_sub"])
+            got_sub = s[:, :, ::stride, ::stride]
+            e_tri = max(float((got_sub - want_sub).abs().max()), float((s[0, :, 100, :] - torch.from_numpy(g[f"sample{layer}_row100"])).abs().max()))
+            ck = float(s.double().abs().sum())
+            tri_planes = sample[0:1].reshape(1, 3, -1, 256, 256)                       # :158
+            torch.manual_seed(5)                                                       # sample_pdf's uniforms: CPU generator, like the reference
+            rgb, acc, _, depth = render(chunk=IMG * IMG, rays_o=rays_o[None].to(dev), rays_d=rays_d[None].to(dev), near=near[None].to(dev),
+                                        far=far[None].to(dev), tri_planes=tri_planes, tp_input=tp, renderer=rend, n_samples=NS, perturb=0.,
+                                        n_importance=NS)
+            w = lambda k: torch.from_numpy(g[f"{k}{layer}"])  # noqa: E731
+            layers.append({"layer": layer, "triplane_max_abs": e_tri, "triplane_psnr_db": round(_psnr(got_sub, want_sub), 2),
+                           "triplane_abs_sum_rel": abs(ck - float(g[f"sample{layer}_ck"][1])) / float(g[f"sample{layer}_ck"][1]),
+                           "triplane_channel_mean_max_abs": float(np.abs(s.double().mean(dim=(0, 2, 3)).numpy() - g[f"sample{layer}_chmean"]).max()),
+                           "image_max_abs": float((rgb[0].cpu() - w("rgb")).abs().max()), "image_psnr_db": round(_psnr(rgb[0].cpu(), w("rgb")), 2),
+                           "acc_max_abs": float((acc[0].cpu() - w("acc")).abs().max()), "depth_max_abs": float((depth[0].cpu() - w("depth")).abs().max())})
+            x_cond = sample                                                            # :124-134: the next layer is conditioned on this one
+    finally:
+        torch.randn_like = orig
+    return {"layers": layers, "ndraws": n["i"], "ndraws_reference": int(g["ndraws"]),
+            "against": "the reference's outputs on identical noise (tests/golden/chain_f4_ddim10.npz <- tests/golden/gen_golden_chain.py)",
+            "workload": "F4 net, DDIM-10, B=1, 2 cloth layers chained through x_cond -> reshape(1,3,9,256,256) -> one 128x128 view @32+32"}
 
 
 def bench_render(args, rank, world, dev):
@@ -398,45 +523,91 @@ def cpu_baseline_fit(threads, n_rays=512):
                       "scaled to the 4096 rays of an iteration; optimizer not included"}
 
 
-def cpu_baseline_unet(sd, threads):
-    """Oracle UNet forward + DDPM update on the host, B=1: 1 warm-up + 3 timed steps, ~10 s (a B=4 1000-step run
-    would take hours)."""
+def cpu_baseline_unet(sd, threads, model=None, dev=None):
+    """Oracle UNet forward + DDPM update on the host: B=1 (1 warm-up + 3 timed steps, ~13 s) and B=4 - the configuration `value` is
+    quoted on - (1 timed step, ~13 s; a B=4 1000-step run would take hours).  With `model` the same four B=1 steps are run on the GPU
+    on the same x_T / noise and compared (`parity`)."""
     from oracle import diffusion_oracle as do
     from oracle import unet_oracle as uo
     torch.set_num_threads(threads)
     s = do.Schedule(do.linear_betas(1000), list(range(1000)))
     g = torch.Generator().manual_seed(7)
-    x = torch.randn((1, 27, 256, 256), generator=g)
+    x = x_T = torch.randn((1, 27, 256, 256), generator=g)
     xc = torch.zeros_like(x)
     y = torch.zeros((1,), dtype=torch.int64)
     n_timed = 3
+    noises = []
     with torch.no_grad():
         for i in range(1 + n_timed):
             if i == 1:
                 t0 = time.perf_counter()
             t = torch.tensor([999 - i])
             eps = uo.unet_forward(sd, x, t, xc, y)
-            x, _ = do.p_sample_step(s, x, t, eps, torch.randn(x.shape, generator=g))
-    dt = time.perf_counter() - t0
-    return {"value": round(n_timed / dt, 4), "unit": "denoise-steps/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (PyTorch-CPU fp32 restatement) p_sample, production UNet, batch 1, {n_timed} timed steps after 1 warm-up"}
+            noises.append(torch.randn(x.shape, generator=g))
+            x, _ = do.p_sample_step(s, x, t, eps, noises[-1])
+        dt = time.perf_counter() - t0
+        x4 = torch.randn((4, 27, 256, 256), generator=g)
+        t4 = time.perf_counter()
+        eps4 = uo.unet_forward(sd, x4, torch.full((4,), 500), torch.zeros_like(x4), torch.zeros((4,), dtype=torch.int64))
+        do.p_sample_step(s, x4, torch.full((4,), 500), eps4, torch.randn(x4.shape, generator=g))
+        dt4 = time.perf_counter() - t4
+    out = {"value": round(n_timed / dt, 4), "unit": "denoise-steps/sec", "cores": threads, "kind": "port",
+           "sample": f"oracle (PyTorch-CPU fp32 restatement) p_sample, production UNet, batch 1, {n_timed} timed steps after 1 warm-up",
+           "batch4": {"value": round(4 / dt4, 4), "unit": "denoise-steps/sec", "sample": "same, batch 4 (the configuration `value` is quoted on), 1 timed step"}}
+    parity = None
+    if model is not None:
+        from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
+        d = create_gaussian_diffusion(steps=1000, timestep_respacing="")
+        k = {"i": 0}
+        orig = torch.randn_like
+
+        def inj(ref):
+            k["i"] += 1
+            return noises[k["i"] - 1].to(ref.device)
+        torch.randn_like = inj
+        try:
+            xg = x_T.to(dev)
+            with torch.no_grad():
+                for i in range(1 + n_timed):
+                    xg = d.p_sample(model, xg, xc.to(dev), torch.tensor([999 - i], device=dev), model_kwargs={"y": y.to(dev)})["sample"]
+        finally:
+            torch.randn_like = orig
+        parity = {"steps": 1 + n_timed, "max_abs": float((xg.cpu() - x).abs().max()), "psnr_db": round(_psnr(xg.cpu(), x), 2),
+                  "value_scale": float(x.abs().max()),
+                  "what": "x after 4 recurrent p_sample steps (t = 999..996) of the production net, B=1, HIP vs the oracle on identical x_T / noise"}
+    return out, parity
 
 
-def cpu_baseline_render(threads, n_rays=16384):
+def cpu_baseline_render(threads, n_rays=16384, dev=None):
+    """Oracle render of a bounded sample of one 512x512 view; with `dev` the same rays / uniforms go through the HIP renderer and the
+    two images are compared (`parity`: PSNR / max-abs, colours in [0,1])."""
     from humanliff_amd import synthetic as syn
     from oracle import render_oracle as ro
     torch.set_num_threads(threads)
-    planes = syn.triplane(seed=11)[0]
+    planes = syn.triplane(seed=11)
     mlp = syn.render_mlp_state(3)
     o, d, nr, fr = syn.orbit_rays(0, 36, 512, 512)
     sl = slice(512 * 256, 512 * 256 + n_rays)
     u = syn.importance_u(n_rays, 128, seed=5)
     t0 = time.perf_counter()
     with torch.no_grad():
-        ro.render_rays(mlp, planes, torch.tensor(syn.WORLD_BOUNDS), o[sl], d[sl], nr[sl], fr[sl], 128, 128, u=u)
+        rgb, acc, depth = ro.render_rays(mlp, planes[0], torch.tensor(syn.WORLD_BOUNDS), o[sl], d[sl], nr[sl], fr[sl], 128, 128, u=u)
     dt = time.perf_counter() - t0
-    return {"value": round(n_rays / dt / 1e6, 6), "unit": "Mrays/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (PyTorch-CPU fp32 restatement) render of {n_rays} rays of one 512x512 view at 128+128 samples"}
+    out = {"value": round(n_rays / dt / 1e6, 6), "unit": "Mrays/sec", "cores": threads, "kind": "port",
+           "sample": f"oracle (PyTorch-CPU fp32 restatement) render of {n_rays} rays of one 512x512 view at 128+128 samples"}
+    parity = None
+    if dev is not None:
+        from humanliff_amd.NeRF import Renderer
+        r = Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, smpl_type='smpl', test=True)
+        r.load_state_dict(mlp, strict=False)
+        r = r.to(dev)
+        got = r.render({"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].to(dev)}, None, None, o[sl][None].to(dev), d[sl][None].to(dev),
+                       nr[sl][None].to(dev), fr[sl][None].to(dev), planes.to(dev), 128, False, n_samples=128, u=u.to(dev))
+        parity = {"rays": n_rays, "psnr_db": round(_psnr(got["rgb_map"][0].cpu(), rgb), 2),
+                  "max_abs": float((got["rgb_map"][0].cpu() - rgb).abs().max()), "acc_max_abs": float((got["acc_map"][0].cpu() - acc).abs().max()),
+                  "depth_max_abs": float((got["depth_map"][0].cpu() - depth).abs().max()),
+                  "what": "rgb of the same 16 384 rays / uniforms at 128+128 samples, HIP vs the oracle (north-star bar: PSNR >= 45 dB)"}
+    return out, parity
 
 
 def main():
@@ -446,7 +617,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="subjects per GPU in the denoise loop (configs[1]: 4)")
     ap.add_argument("--views", type=int, default=2, help="512x512 views per GPU in the render leg")
+    ap.add_argument("--sustained-steps", type=int, default=200,
+                    help="extra untimed-for-`value` steps of the same loop after the timed region: sustained steps/s + shader clock (N=1 only; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity legs (end-to-end chain vs the reference's vectors, HIP vs oracle samples)")
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--no-fit", action="store_true", help="skip the tri-plane fitting leg (SURVEY 8(f) rank 4)")
     ap.add_argument("--no-bf16x3-leg", action="store_true", help="skip the extra measurement of the opt-in bf16x3 conv mode")
@@ -463,8 +637,12 @@ def main():
 
     secs, roof, sd, model = bench_unet(args, rank, world, dev)
     value = world * args.batch * args.steps / secs
-    del model
-    torch.cuda.empty_cache()
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity:
+        chain = e2e_chain(model, dev)
+        parity = {"psnr_db": min(l["image_psnr_db"] for l in chain["layers"]), "max_abs": max(l["image_max_abs"] for l in chain["layers"]),
+                  "triplane_psnr_db": min(l["triplane_psnr_db"] for l in chain["layers"]),
+                  "triplane_max_abs": max(l["triplane_max_abs"] for l in chain["layers"]), "end_to_end": chain}
     render = None
     if not args.no_render:
         rsecs, rroof, rays_per_rank = bench_render(args, rank, world, dev)
@@ -481,9 +659,11 @@ def main():
         # PyTorch-CPU stops scaling (and then collapses) beyond ~32 threads on this path: measured on the
         # MI355X host (256 logical CPUs) 3x3 conv 192->192@256^2: 49/47/40/90/208 ms at 8/16/32/64/128 threads
         threads = min(len(os.sched_getaffinity(0)), 32)
-        cpu = cpu_baseline_unet(sd, threads)
+        cpu, step_parity = cpu_baseline_unet(sd, threads, None if args.no_parity else model, dev)
+        if parity is not None:
+            parity["denoise_steps_vs_oracle"] = step_parity
         if render is not None:
-            render["cpu_baseline"] = cpu_baseline_render(threads)
+            render["cpu_baseline"], render["parity"] = cpu_baseline_render(threads, dev=None if args.no_parity else dev)
         if fit is not None:
             fit["cpu_baseline"] = cpu_baseline_fit(threads)
     if rank == 0:
@@ -496,7 +676,7 @@ def main():
                        "parallelism": f"replicas x{world} (subjects sharded, final all-gather only)",
                        "gflop_per_sample_step": UNET_GFLOP_PER_SAMPLE_STEP},
             "step_tflops": round(world * args.batch * args.steps * UNET_GFLOP_PER_SAMPLE_STEP / secs / 1e3, 2),
-            "roofline": roof, "cpu_baseline": cpu, "render": render, "fit": fit,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "render": render, "fit": fit,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -136,6 +136,6 @@ def deform_target2c(model, tp_input, pts, viewdir=None, return_ids=False):
     with torch.cuda.device(pts.device):
         _lib.check(_lib.lib().hl_deform_points(_lib.ptr(p), _lib.ptr(d), Rh.ctypes.data, Th.ctypes.data, _lib.ptr(verts4),
                                                _lib.ptr(table), int(verts4.shape[0]), P, _lib.ptr(can), _lib.ptr(cd),
-                                               _lib.ptr(ids), _lib.stream_ptr()), "hl_deform_points")
+                                               _lib.ptr(ids, torch.int32), _lib.stream_ptr()), "hl_deform_points")
     out = (can[None], cd[None] if cd is not None else None, tp_input["t_world_bounds"])
     return out + (ids,) if return_ids else out

@@ -62,10 +62,12 @@ class Renderer(nn.Module):
         # (keys v_template, shapedirs, posedirs, J_regressor, kintree_table, weights) to `SMPL_NEUTRAL` before rendering with
         # use_canonical_space=True.
         self.SMPL_NEUTRAL = None
+        # depth_map = (depth - near) / (far - near + 1e-5), clamped to [0,1] by this twin (renderer.py:271-274); the recon_NeRF twin
+        # (recon_NeRF/lib/renderer.py:288) does not clamp and clears the second flag
+        self._depth_flags = _lib.HL_RENDER_NORMALIZE_DEPTH | _lib.HL_RENDER_CLAMP_DEPTH
         self.uniforms_on_device = False      # extension: draw sample_pdf's uniforms with the device generator (see render())
         self._packed = None
         self._packed_key = None
-        self._planes_cache = {}
         self._ws = None
 
     # ---- packing caches ------------------------------------------------------------------------
@@ -94,19 +96,22 @@ class Renderer(nn.Module):
         return self._packed
 
     def _packed_planes(self, planes):
-        """planes (3,9,H,W) fp32 device view of one subject -> packed texel-major copy (cached)."""
-        key = (planes.data_ptr(), planes._version, tuple(planes.shape))
-        hit = self._planes_cache.get(key)
-        if hit is None:
-            L = _lib.lib()
-            H, W = planes.shape[-2:]
-            src = planes.contiguous()
-            buf = torch.empty(L.hl_planes_packed_bytes(H, W) // 4, dtype=torch.float32, device=planes.device)
-            _lib.check(L.hl_planes_pack(_lib.ptr(src), H, W, _lib.ptr(buf), _lib.stream_ptr()), "hl_planes_pack")
-            if len(self._planes_cache) > 8:
-                self._planes_cache.clear()
-            self._planes_cache[key] = hit = buf
-        return hit
+        """planes (3,9,H,W) fp32 device view of one subject -> packed texel-major copy.
+
+        Repacked on every call (17 MB of traffic, a few microseconds next to a 75 ms view or an 8 ms fitting step).  An address /
+        version keyed cache is unsafe here: callers hand in freshly allocated tensors (`self.tri_planes[idx, layer]` of the recon
+        twin, `sample.clamp().reshape()` of the sampling script) whose `_version` is 0 and whose storage address the caching
+        allocator reuses as soon as the previous one is freed - different contents would hit a stale packed copy."""
+        if not planes.is_cuda:
+            raise RuntimeError("tri_planes must live on the GPU; humanliff_amd has no CPU path")
+        if planes.dtype != torch.float32:
+            raise RuntimeError(f"tri_planes must be float32 (got {planes.dtype})")
+        L = _lib.lib()
+        H, W = planes.shape[-2:]
+        src = planes.detach().contiguous()
+        buf = torch.empty(L.hl_planes_packed_bytes(H, W) // 4, dtype=torch.float32, device=planes.device)
+        _lib.check(L.hl_planes_pack(_lib.ptr(src), H, W, _lib.ptr(buf), _lib.stream_ptr(planes.device)), "hl_planes_pack")
+        return buf
 
     def _workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() * 4 < nbytes or self._ws.device != device:
@@ -133,6 +138,13 @@ class Renderer(nn.Module):
         (bs*R*(n_samples+n_importance), 1) supplies it, otherwise it is drawn on the device like the reference's randn_like) and
         rgb_map / acc_map stay attached to the autograd graph of tri_planes and the MLP parameters - see NeRF/train.py.
         """
+        if not tri_planes.is_cuda:
+            raise RuntimeError("Renderer.render needs CUDA(HIP) tensors; there is no CPU path")
+        with _lib.on(tri_planes.device):      # launches go to the tri-planes' device, whatever the caller's current device is
+            return self._render(tp_input, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd, n_samples, u,
+                                reevaluate, noise)
+
+    def _render(self, tp_input, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd, n_samples, u, reevaluate, noise):
         if self.use_canonical_space and self.SMPL_NEUTRAL is None:
             raise RuntimeError("use_canonical_space=True needs the body model: set renderer.SMPL_NEUTRAL to the SMPL_to_tensor dict")
         if self.use_canonical_space and self.test:
@@ -171,7 +183,7 @@ class Renderer(nn.Module):
         rgb = torch.empty((bs, R, 3), dtype=torch.float32, device=dev)
         acc = torch.empty((bs, R), dtype=torch.float32, device=dev)
         depth = torch.empty((bs, R), dtype=torch.float32, device=dev)
-        flags = _lib.HL_RENDER_NORMALIZE_DEPTH | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0) | \
+        flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0) | \
             (_lib.HL_RENDER_REEVALUATE if reevaluate else 0)
         f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
         for b in range(bs):
@@ -210,7 +222,7 @@ class Renderer(nn.Module):
         if noise is None:
             noise = torch.randn((bs * R * S, 1), device=dev)
         noise = noise.reshape(bs, R, S)
-        flags = _lib.HL_RENDER_NORMALIZE_DEPTH | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0)
+        flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0)
         mlp = self._mlp_tensors()
         # the activation / delta matrices of one call are addressed with 32-bit offsets and kept below 2 GiB (630 rows x 4 B per
         # sample point): 2048 rays x 256 samples need 1.3 GB; larger ray batches go down in pieces (rays are independent)
@@ -267,7 +279,7 @@ class Renderer(nn.Module):
         rgb = torch.empty((1, R, 3), dtype=torch.float32, device=dev)
         acc = torch.empty((1, R), dtype=torch.float32, device=dev)
         depth = torch.empty((1, R), dtype=torch.float32, device=dev)
-        flags = _lib.HL_RENDER_NORMALIZE_DEPTH | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0)
+        flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0)
         f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
         ro, rd, nr, fr = f32(rays_o[0]), f32(rays_d[0]), f32(near[0]), f32(far[0])
         bd = f32(tp_input['t_world_bounds'].reshape(-1, 2, 3)[0].to(dev))
@@ -290,6 +302,10 @@ class Renderer(nn.Module):
         meshgrid.  Returns a (resolution,)*3 fp32 tensor on the tri-plane's device.
         """
         assert tri_planes is not None and tri_planes.shape[0] == 1 and tri_planes.shape[1:3] == (3, 9)
+        with _lib.on(tri_planes.device):
+            return self._density_grid(tp_input, tri_planes, resolution, rays_per_launch)
+
+    def _density_grid(self, tp_input, tri_planes, resolution, rays_per_launch):
         dev = tri_planes.device
         H, W = tri_planes.shape[-2:]
         N = int(resolution)

@@ -40,7 +40,7 @@ def camera_rays(H, W, K, R, T, bounds, device=None, return_mask=True):
     mask = torch.empty((n,), device=device, dtype=torch.uint8) if return_mask else None
     with torch.cuda.device(device):
         _lib.check(_lib.lib().hl_camera_rays(pKi, pR, pT, pB, int(H), int(W), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(near),
-                                             _lib.ptr(far), _lib.ptr(mask) if return_mask else None, _lib.stream_ptr()))
+                                             _lib.ptr(far), _lib.ptr(mask, torch.uint8) if return_mask else None, _lib.stream_ptr()))
     return rays_o, rays_d, near, far, (mask.bool() if return_mask else None)
 
 

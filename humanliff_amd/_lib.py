@@ -16,6 +16,7 @@ HL_CONV_FP32_DIRECT = 2
 HL_RENDER_WHITE_BKGD = 1
 HL_RENDER_NORMALIZE_DEPTH = 2
 HL_RENDER_REEVALUATE = 4
+HL_RENDER_CLAMP_DEPTH = 8
 
 
 class HipLibraryMissing(RuntimeError):
@@ -89,7 +90,7 @@ SIGNATURES = {
     "hl_unet_profile": (_i, [_p, _i]),
     "hl_unet_profile_read": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "hl_unet_profile_read_ex": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    "hl_diffusion_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _p]),
+    "hl_diffusion_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "hl_conv2d_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
     "hl_conv2d_nhwc_mode": (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
     "hl_groupnorm_coef": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -121,14 +122,28 @@ def check(rc, what=""):
         raise HipCallError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
 
-def ptr(t):
-    """Device pointer of a contiguous fp32/int64 CUDA(HIP) tensor, or None."""
+_PTR_DTYPES = (torch.float32, torch.int64)
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or None.  The pointers of the C ABI are `float*` or `int64_t*`
+    (include/humanliff_hip.h) unless a call site names another `dtype` (the uint8 box mask of hl_camera_rays, the int32 vertex
+    ids of hl_deform_points); anything else would be reinterpreted bytewise by the kernels, so it is refused here."""
     if t is None:
         return None
     assert t.is_cuda, "humanliff_amd kernels need device tensors (no CPU path)"
     assert t.is_contiguous()
+    if (t.dtype != dtype) if dtype is not None else (t.dtype not in _PTR_DTYPES):
+        raise TypeError(f"humanliff_amd kernel argument must be {dtype or 'float32 / int64'}, got {t.dtype}")
     return C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on `device` (default: the current device)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on(device):
+    """Context that makes `device` the current HIP device for the launches inside it: the library launches on the caller's stream,
+    and a stream can only be used from its own device."""
+    return torch.cuda.device(device)

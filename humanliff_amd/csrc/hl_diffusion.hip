@@ -16,11 +16,15 @@ template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void k_step(const float *__restrict__ x, const float *__restrict__ eps,
                                               const float *__restrict__ noise, const float *__restrict__ coef,
                                               const int64_t *__restrict__ t, float *__restrict__ sample,
-                                              float *__restrict__ x0_out, long n, int clip, int has_noise) {
+                                              float *__restrict__ x0_out, long n, int T, int clip, int has_noise) {
     const int b = blockIdx.y;
     const int64_t tb = t[b];
-    const float *c = coef + tb * 8;
-    const float r = c[0], rm1 = c[1], c0 = c[2], c1 = c[3];
+    // a timestep outside the (T,8) table (the reference's numpy indexing raises IndexError, gaussian_diffusion.py:859) never
+    // reads out of bounds: row 0 is read and every output of this sample becomes NaN
+    const bool in_range = tb >= 0 && tb < (int64_t)T;
+    const float *c = coef + (in_range ? tb : 0) * 8;
+    const float poison = in_range ? 0.f : __builtin_nanf("");
+    const float r = c[0] + poison, rm1 = c[1], c0 = c[2], c1 = c[3];
     const float nz = has_noise ? (tb != 0 ? 1.f : 0.f) * c[4] : 0.f;
     const long base = (long)b * n;
     auto one = [&](float xv, float ev, float nv, float &sv, float &x0v) {
@@ -61,13 +65,13 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ x, const
 }  // namespace
 
 extern "C" int hl_diffusion_step(int mode, const float *x, const float *eps, const float *noise, const float *coef,
-                                 const int64_t *t, float *sample, float *pred_xstart, int64_t n_per_sample, int B, int clip,
+                                 const int64_t *t, float *sample, float *pred_xstart, int64_t n_per_sample, int B, int T, int clip,
                                  void *stream) {
     HL_REQUIRE(x && eps && coef && t && sample, "hl_diffusion_step: null argument");
     const int has_noise = noise != nullptr;
     if (!noise) noise = x;  // never contributes (factor 0); keeps the loads in bounds
     HL_REQUIRE(mode == 0 || mode == 1, "hl_diffusion_step: mode %d", mode);
-    HL_REQUIRE(n_per_sample > 0 && B > 0, "hl_diffusion_step: bad sizes");
+    HL_REQUIRE(n_per_sample > 0 && B > 0 && T > 0, "hl_diffusion_step: bad sizes");
     const bool vec = (n_per_sample % 4 == 0) && (((uintptr_t)x | (uintptr_t)eps | (uintptr_t)noise | (uintptr_t)sample |
                                                    (uintptr_t)pred_xstart) % 16 == 0);
     const long work = vec ? n_per_sample / 4 : n_per_sample;
@@ -75,7 +79,7 @@ extern "C" int hl_diffusion_step(int mode, const float *x, const float *eps, con
     if (gx > 1024) gx = 1024;
     dim3 grid((unsigned)gx, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-#define HL_GO(M, V) hipLaunchKernelGGL((k_step<M, V>), grid, dim3(256), 0, st, x, eps, noise, coef, t, sample, pred_xstart, (long)n_per_sample, clip, has_noise)
+#define HL_GO(M, V) hipLaunchKernelGGL((k_step<M, V>), grid, dim3(256), 0, st, x, eps, noise, coef, t, sample, pred_xstart, (long)n_per_sample, T, clip, has_noise)
     if (mode == 0) { if (vec) HL_GO(0, true); else HL_GO(0, false); }
     else { if (vec) HL_GO(1, true); else HL_GO(1, false); }
 #undef HL_GO

@@ -557,8 +557,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
             }
             if (a.flags & HL_RENDER_NORMALIZE_DEPTH) {
                 acc_d = (acc_d - nr) / (fr - nr + 1e-5f);
-                acc_d = acc_d > 1.f ? 1.f : acc_d;
-                acc_d = acc_d < 0.f ? 0.f : acc_d;
+                if (a.flags & HL_RENDER_CLAMP_DEPTH) {
+                    acc_d = acc_d > 1.f ? 1.f : acc_d;
+                    acc_d = acc_d < 0.f ? 0.f : acc_d;
+                }
             }
             a.rgb[ray * 3 + 0] = acc_r;
             a.rgb[ray * 3 + 1] = acc_g;
@@ -785,8 +787,10 @@ __global__ __launch_bounds__(256) void k_composite(const CompArgs a) {
     }
     if (a.flags & HL_RENDER_NORMALIZE_DEPTH) {
         acc_d = (acc_d - nr) / (fr - nr + 1e-5f);
-        acc_d = acc_d > 1.f ? 1.f : acc_d;
-        acc_d = acc_d < 0.f ? 0.f : acc_d;
+        if (a.flags & HL_RENDER_CLAMP_DEPTH) {
+            acc_d = acc_d > 1.f ? 1.f : acc_d;
+            acc_d = acc_d < 0.f ? 0.f : acc_d;
+        }
     }
     a.rgb[ray * 3 + 0] = acc_r;
     a.rgb[ray * 3 + 1] = acc_g;
@@ -1451,8 +1455,10 @@ __global__ __launch_bounds__(256) void k_composite_wave(const CompBwdArgs b) {
             if (a.flags & HL_RENDER_WHITE_BKGD) { const float bg = 1.f - acc_w; acc_r += bg; acc_g += bg; acc_b += bg; }
             if (a.flags & HL_RENDER_NORMALIZE_DEPTH) {
                 acc_d = (acc_d - nr) / (fr - nr + 1e-5f);
-                acc_d = acc_d > 1.f ? 1.f : acc_d;
-                acc_d = acc_d < 0.f ? 0.f : acc_d;
+                if (a.flags & HL_RENDER_CLAMP_DEPTH) {
+                    acc_d = acc_d > 1.f ? 1.f : acc_d;
+                    acc_d = acc_d < 0.f ? 0.f : acc_d;
+                }
             }
             a.rgb[ray * 3 + 0] = acc_r; a.rgb[ray * 3 + 1] = acc_g; a.rgb[ray * 3 + 2] = acc_b;
             a.acc[ray] = acc_w; a.depth[ray] = acc_d;

@@ -132,7 +132,7 @@ class GaussianDiffusion:
         if self.model_mean_type != ModelMeanType.EPSILON:
             raise NotImplementedError("only epsilon prediction (predict_xstart=False) is built")
 
-    def _step(self, mode, x, eps, noise, t, clip, eta=0.0, want_x0=True):
+    def _step(self, mode, x, eps, noise, t, clip, eta=0.0, want_x0=True, trusted=False):
         self._require_eps_model()
         if not x.is_cuda:
             raise RuntimeError("sampling needs CUDA(HIP) tensors; there is no CPU path")
@@ -142,10 +142,19 @@ class GaussianDiffusion:
         out = th.empty_like(xf)
         x0 = th.empty_like(xf) if want_x0 else None
         B = x.shape[0]
-        tt = t.to(th.int64).contiguous()
-        _lib.check(_lib.lib().hl_diffusion_step(mode, _lib.ptr(xf), _lib.ptr(ef), _lib.ptr(nf), _lib.ptr(tab), _lib.ptr(tt),
-                                                _lib.ptr(out), _lib.ptr(x0), xf.numel() // B, B, 1 if clip else 0,
-                                                _lib.stream_ptr()), "hl_diffusion_step")
+        tt = t.to(device=x.device, dtype=th.int64).contiguous()
+        # the kernel reads row t of the (T,8) table.  The reference's numpy indexing raises IndexError for an out-of-range timestep
+        # (e.g. ORIGINAL-schedule indices handed to a respaced diffusion): direct callers of p_sample / ddim_sample / p_mean_variance
+        # get the same check here (one device read-back); the sampling loops generate their own indices and skip it (`trusted`).
+        # The kernel never reads outside the table either way: it writes NaN for an out-of-range row.
+        if not trusted:
+            lo, hi = int(tt.min()), int(tt.max())
+            if lo < 0 or hi >= self.num_timesteps:
+                raise IndexError(f"timestep {hi if hi >= self.num_timesteps else lo} is out of range for a {self.num_timesteps}-step schedule")
+        with _lib.on(x.device):
+            _lib.check(_lib.lib().hl_diffusion_step(mode, _lib.ptr(xf), _lib.ptr(ef), _lib.ptr(nf), _lib.ptr(tab), _lib.ptr(tt),
+                                                    _lib.ptr(out), _lib.ptr(x0), xf.numel() // B, B, self.num_timesteps,
+                                                    1 if clip else 0, _lib.stream_ptr()), "hl_diffusion_step")
         return out, x0
 
     # ---- q(.) helpers (plain tensor algebra on whatever device the inputs live on) ------------------
@@ -202,44 +211,46 @@ class GaussianDiffusion:
                 "log_variance": _extract_into_tensor(logvar, t, x.shape),
                 "pred_xstart": x0}
 
-    def p_sample(self, model, x, x_cond, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+    def _sample(self, mode, model, x, t, x_cond, clip_denoised, denoised_fn, model_kwargs, eta=0.0, trusted=False):
         if denoised_fn is not None:
             raise NotImplementedError("denoised_fn is not built into the fused update")
         eps = self._model_eps(model, x, t, x_cond, model_kwargs)
-        noise = th.randn_like(x)
-        sample, x0 = self._step(0, x, eps, noise, t, clip_denoised)
+        noise = th.randn_like(x)  # ddim: drawn even when eta == 0, like the reference (:520)
+        sample, x0 = self._step(mode, x, eps, noise, t, clip_denoised, eta=eta, trusted=trusted)
         return {"sample": sample, "pred_xstart": x0}
+
+    def p_sample(self, model, x, x_cond, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        return self._sample(0, model, x, t, x_cond, clip_denoised, denoised_fn, model_kwargs)
 
     def ddim_sample(self, model, x, t, x_cond=None, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn is not built into the fused update")
-        eps = self._model_eps(model, x, t, x_cond, model_kwargs)
-        noise = th.randn_like(x)  # drawn even when eta == 0, like the reference (:520)
-        sample, x0 = self._step(1, x, eps, noise, t, clip_denoised, eta=eta)
-        return {"sample": sample, "pred_xstart": x0}
+        return self._sample(1, model, x, t, x_cond, clip_denoised, denoised_fn, model_kwargs, eta=eta)
 
-    def _loop(self, step, model, shape, noise, device, progress):
+    def _loop_model(self, model):
+        """The callable the loop hands to the model slot (SpacedDiffusion wraps it once per loop)."""
+        return model
+
+    def _loop(self, mode, model, shape, x_cond, noise, clip_denoised, denoised_fn, model_kwargs, device, progress, eta=0.0):
         if device is None:
             device = next(model.parameters()).device
         assert isinstance(shape, (tuple, list))
         img = noise if noise is not None else th.randn(*shape, device=device)
         T, B = self.num_timesteps, shape[0]
         t_all = th.arange(T, device=device, dtype=th.int64)[:, None].expand(T, B).contiguous()
+        model = self._loop_model(model)
         order = range(T - 1, -1, -1)
         if progress:
             from tqdm.auto import tqdm
             order = tqdm(order)
         for i in order:
             with th.no_grad():
-                out = step(img, t_all[i])
+                out = GaussianDiffusion._sample(self, mode, model, img, t_all[i], x_cond, clip_denoised, denoised_fn, model_kwargs,
+                                                eta=eta, trusted=True)
                 yield out
                 img = out["sample"]
 
     def p_sample_loop_progressive(self, model, shape, x_cond=None, noise=None, clip_denoised=True, denoised_fn=None,
                                   model_kwargs=None, device=None, progress=False):
-        return self._loop(lambda img, t: self.p_sample(model, img, x_cond, t, clip_denoised=clip_denoised,
-                                                       denoised_fn=denoised_fn, model_kwargs=model_kwargs),
-                          model, shape, noise, device, progress)
+        return self._loop(0, model, shape, x_cond, noise, clip_denoised, denoised_fn, model_kwargs, device, progress)
 
     def p_sample_loop(self, model, shape, x_cond=None, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                       device=None, progress=False):
@@ -252,9 +263,7 @@ class GaussianDiffusion:
 
     def ddim_sample_loop_progressive(self, model, shape, x_cond=None, noise=None, clip_denoised=True, denoised_fn=None,
                                      model_kwargs=None, device=None, progress=False, eta=0.0):
-        return self._loop(lambda img, t: self.ddim_sample(model, img, t, x_cond=x_cond, clip_denoised=clip_denoised,
-                                                          denoised_fn=denoised_fn, model_kwargs=model_kwargs, eta=eta),
-                          model, shape, noise, device, progress)
+        return self._loop(1, model, shape, x_cond, noise, clip_denoised, denoised_fn, model_kwargs, device, progress, eta=eta)
 
     def ddim_sample_loop(self, model, shape, x_cond=None, noise=None, clip_denoised=True, denoised_fn=None,
                          model_kwargs=None, device=None, progress=False, eta=0.0):
@@ -272,10 +281,9 @@ class GaussianDiffusion:
         if noise is None:
             noise = th.randn_like(x_start)
         x_t = self.q_sample(x_start, t, noise=noise)
-        # with gradients enabled the network runs through its differentiable PyTorch-op twin (the HIP forward has no backward; SURVEY
-        # 8(b): training_losses keeps working through autograd); under no_grad, or for a model without one, the normal forward
-        fwd = model.forward_autograd if th.is_grad_enabled() and hasattr(model, "forward_autograd") else model
-        out = fwd(x_t, self._scale_timesteps(t), x_cond, **(model_kwargs or {}))
+        # `model` may be the bare UNetModel, a DDP / DataParallel wrapper around it (train_util.py:236 passes ddp_model) or any
+        # callable: it is simply called.  UNetModel.forward itself picks its differentiable path when gradients are enabled
+        out = model(x_t, self._scale_timesteps(t), x_cond, **(model_kwargs or {}))
         target = {ModelMeanType.PREVIOUS_X: self.q_posterior_mean_variance(x_start=x_start, x_t=x_t, t=t)[0],
                   ModelMeanType.START_X: x_start, ModelMeanType.EPSILON: noise}[self.model_mean_type]
         assert out.shape == target.shape == x_start.shape

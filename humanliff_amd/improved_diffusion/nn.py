@@ -56,6 +56,7 @@ def timestep_embedding(timesteps, dim, max_period=10000):
     else:
         ti = timesteps.to(th.int64).contiguous()
     out = th.empty((timesteps.shape[0], dim), dtype=th.float32, device=timesteps.device)
-    _lib.check(_lib.lib().hl_timestep_embedding(_lib.ptr(ti), _lib.ptr(tf), timesteps.shape[0], dim, _lib.ptr(out),
-                                                _lib.stream_ptr()), "hl_timestep_embedding")
+    with _lib.on(timesteps.device):
+        _lib.check(_lib.lib().hl_timestep_embedding(_lib.ptr(ti), _lib.ptr(tf), timesteps.shape[0], dim, _lib.ptr(out),
+                                                    _lib.stream_ptr()), "hl_timestep_embedding")
     return out

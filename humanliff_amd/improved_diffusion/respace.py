@@ -47,6 +47,7 @@ class SpacedDiffusion(GaussianDiffusion):
                 last = acp
                 self.timestep_map.append(i)
         kwargs["betas"] = np.array(new_betas)
+        self._wrapped = {}
         super().__init__(**kwargs)
 
     def p_mean_variance(self, model, *args, **kwargs):
@@ -61,13 +62,20 @@ class SpacedDiffusion(GaussianDiffusion):
     def training_losses(self, model, *args, **kwargs):
         return super().training_losses(self._wrap_model(model), *args, **kwargs)
 
-    def _loop(self, step, model, *args, **kwargs):
-        return super()._loop(step, model, *args, **kwargs)
+    def _loop_model(self, model):
+        return self._wrap_model(model)
 
     def _wrap_model(self, model):
+        """One wrapper per model object, kept on the diffusion (the reference builds a new one - and a new device tensor of the
+        timestep map - on every call, respace.py:97-122).  The entry holds the model itself, so its id cannot be recycled."""
         if isinstance(model, _WrappedModel):
             return model
-        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+        hit = self._wrapped.get(id(model))
+        if hit is None or hit.model is not model:
+            if len(self._wrapped) >= 4:
+                self._wrapped.clear()
+            hit = self._wrapped[id(model)] = _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+        return hit
 
     def _scale_timesteps(self, t):
         return t  # scaling is done by the wrapped model
@@ -92,21 +100,5 @@ class _WrappedModel:
         new_ts = m[ts]
         if self.rescale_timesteps:
             new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
+        # plain call: a DDP / DataParallel wrapper keeps its forward hooks (gradient sync), any callable works
         return self.model(x, new_ts, x_cond, **kwargs)
-
-    def forward_autograd(self, x, ts, x_cond, **kwargs):
-        inner, self.model = self.model, _Autograd(self.model)
-        try:
-            return self(x, ts, x_cond, **kwargs)
-        finally:
-            self.model = inner
-
-
-class _Autograd:
-    """Calls a model through its training-only differentiable forward."""
-
-    def __init__(self, model):
-        self.model = model
-
-    def __call__(self, *args, **kwargs):
-        return self.model.forward_autograd(*args, **kwargs)

@@ -177,9 +177,20 @@ class UNetModel(nn.Module):
         c.controlnet = 1 if self.cond_type == "controlnet" else 0
         return c
 
+    def _apply(self, fn, *a, **kw):       # .to() / .cuda() / .float(): parameter objects may be replaced
+        self._sd_cache = None
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):  # assign=True replaces parameter objects
+        self._sd_cache = None
+        return super().load_state_dict(*a, **kw)
+
     def _bind(self):
-        sd = self.state_dict(keep_vars=True)
-        key = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        # the (name, tensor) list of the state_dict is built once; per forward only the cheap (address, version) probe runs
+        sd = getattr(self, "_sd_cache", None)
+        if sd is None:
+            sd = self._sd_cache = dict(self.state_dict(keep_vars=True))
+        key = [(v.data_ptr(), v._version) for v in sd.values()]
         if self._hip is not None and self._hip[2] == key:
             return self._hip[0]
         L = _lib.lib()
@@ -233,6 +244,9 @@ class UNetModel(nn.Module):
         except Exception:
             pass
 
+    def _any_param_requires_grad(self):
+        return any(p.requires_grad for p in self.parameters())
+
     def forward_autograd(self, x, timesteps, x_cond=None, y=None):
         """Training only: the same function in PyTorch ops, differentiable (unet_autograd.py).  GaussianDiffusion.training_losses
         calls this when gradients are enabled; the samplers never do."""
@@ -241,14 +255,16 @@ class UNetModel(nn.Module):
 
     def forward(self, x, timesteps, x_cond=None, y=None):
         """Same contract as the reference: x (N,C,H,W), timesteps (N,), x_cond (N,C,H,W), y (N,) -> (N,C_out,H,W)."""
-        if th.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("autograd through the HIP UNet is not built (inference only); training_losses uses forward_autograd")
         if self.num_classes is not None:
             assert y is not None and y.shape == (x.shape[0],)
         if self.cond_type == "controlnet":
             assert x_cond is not None, "cond_type='controlnet' needs x_cond (zeros for the first layer)"
         if not x.is_cuda:
             raise RuntimeError("UNetModel.forward needs CUDA(HIP) tensors; there is no CPU path")
+        if th.is_grad_enabled() and self.training and (x.requires_grad or self._any_param_requires_grad()):
+            # training call (train_util.py:236 reaches this through the DDP wrapper): gradients are wanted, take the differentiable path.
+            # Sampling never gets here: the loops run under no_grad and the scripts call model.eval()
+            return self.forward_autograd(x, timesteps, x_cond, y)
         handle = self._bind()
         L = _lib.lib()
         B, Cc, H, W = x.shape

@@ -7,12 +7,14 @@ Differences of the twin that are mirrored here (recon_NeRF/lib/renderer.py:13-50
   * constructor signature without smpl_type.
 With test=False (training) the returned rgb_map / acc_map carry gradients for tri_planes and the MLP through the HIP backward
 kernels (humanliff_amd/NeRF/train.py), so run_nerf_batch.py's loss.backward() / Adam step work unchanged.
-Not mirrored: the twin leaves depth_map unclamped after normalisation (the human_diffusion twin clamps to [0,1], :272-274); depth_map
-here is clamped and carries no gradient.
+  * depth_map is normalised but NOT clamped to [0,1] (:288; the human_diffusion twin clamps, NeRF/renderer.py:272-274).
+Pinned by tests/golden/recon_twin.npz, generated from the reference twin itself (tests/golden/gen_golden_recon.py).
+depth_map carries no gradient (the fitting losses of run_nerf_batch.py:250-262 never use it).
 """
 import torch
 import torch.nn as nn
 
+from ... import _lib
 from ...NeRF.renderer import Renderer as _Renderer
 
 
@@ -22,6 +24,7 @@ class Renderer(_Renderer):
                          triplane_ch=triplane_ch, smpl_type='smpl', test=test)
         self.tri_planes = nn.Parameter(torch.empty(num_instances, 4, 3, triplane_ch // 3, triplane_dim, triplane_dim))
         nn.init.normal_(self.tri_planes, mean=0, std=0.1)
+        self._depth_flags = _lib.HL_RENDER_NORMALIZE_DEPTH
 
     def render(self, tp_input, world_pts, z_vals, rays_o, rays_d, near, far, n_importance=128, white_bkgd=False, **kw):
         tri_planes = self.tri_planes[tp_input['instance_idx'], tp_input['cloth_layer_index']]

@@ -65,9 +65,11 @@ size_t hl_planes_packed_bytes(int H, int W);
 int hl_planes_pack(const float *planes, int H, int W, void *packed, void *stream);
 
 #define HL_RENDER_WHITE_BKGD 1u      /* renderer.py:224-225 (per-ray intent)            */
-#define HL_RENDER_NORMALIZE_DEPTH 2u /* renderer.py:272-274 (human_diffusion twin only) */
+#define HL_RENDER_NORMALIZE_DEPTH 2u /* depth = (depth - near) / (far - near + 1e-5): NeRF/renderer.py:271, recon_NeRF/lib/renderer.py:288 */
 #define HL_RENDER_REEVALUATE 4u      /* hl_render_rays: run the fine pass over all n_samples+n_importance depths like the reference
                                         (re-evaluating the coarse points) instead of evaluating every point once; same image */
+#define HL_RENDER_CLAMP_DEPTH 8u     /* clamp the normalised depth to [0,1]: NeRF/renderer.py:272-274 - the human_diffusion twin only,
+                                        recon_NeRF/lib/renderer.py leaves it unclamped */
 
 size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
 
@@ -312,10 +314,11 @@ int hl_unet_profile_read_ex(void *handle, double *h_ms, double *h_flops, double 
  *   mode 0 (p_sample):  x0 = clip(r*x - rm1*eps); sample = (c0*x0 + c1*x) + (t!=0) * c2 * noise
  *   mode 1 (ddim):      x0 = clip(r*x - rm1*eps); e = (r*x - x0)/rm1;
  *                       sample = (x0*c0 + c1*e) + (t!=0) * c2 * noise
- * t: (B) int64 indices into the table; n_per_sample = C*H*W; noise may be NULL (no noise term:
+ * t: (B) int64 indices into the table of T rows (a t outside [0, T) reads nothing out of bounds and turns that
+ * sample's outputs into NaN; the reference raises IndexError, which the Python binding reproduces); n_per_sample = C*H*W; noise may be NULL (no noise term:
  * `sample` is then the model mean of p_mean_variance); pred_xstart may be NULL. */
 int hl_diffusion_step(int mode, const float *x, const float *eps, const float *noise, const float *coef,
-                      const int64_t *t, float *sample, float *pred_xstart, int64_t n_per_sample, int B, int clip,
+                      const int64_t *t, float *sample, float *pred_xstart, int64_t n_per_sample, int B, int T, int clip,
                       void *stream);
 
 /* Single ops of the UNet path, exposed for parity tests and profiling (NHWC fp32). */

@@ -20,6 +20,8 @@ reference computes (citations are into /root/reference/):
   composite        human_diffusion/NeRF/renderer.py:172-231
   render_rays      human_diffusion/NeRF/renderer.py:234-281 and the chunk body of
                    human_diffusion/scripts/triplane_sample_layered.py:262-279
+  render_rays_recon  recon_NeRF/lib/renderer.py:244-295 (the fitting twin: module-owned tri-planes gathered by
+                   (instance_idx, cloth_layer_index), unclamped depth); pinned by tests/golden/recon_twin.npz
 """
 import math
 
@@ -152,12 +154,14 @@ def coarse_sigma(p, planes, bounds, rays_o, rays_d, z):
 
 
 def render_rays(p, planes, bounds, rays_o, rays_d, near, far, n_samples, n_importance, u=None,
-                white_bkgd=False, normalize_depth=True, z_vals=None, return_aux=False, noise=None):
+                white_bkgd=False, normalize_depth=True, z_vals=None, return_aux=False, noise=None, clamp_depth=True):
     """One subject: planes (3,9,H,W), bounds (2,3), rays (R,3), near/far (R,).
 
     Returns rgb (R,3), acc (R,), depth (R,) [+ aux dict with sigma_coarse, z_all].
     noise (R, n_samples+n_importance): training mode (test=False).  The importance depths are computed under no_grad like
     the reference (renderer.py:243-253), so autograd through this function gives the reference's gradients for `planes` and `p`.
+    clamp_depth=False: the recon_NeRF twin, which normalises the depth but does not clamp it (recon_NeRF/lib/renderer.py:288 vs
+    human_diffusion/NeRF/renderer.py:272-274).
     """
     R = rays_o.shape[0]
     if z_vals is None:
@@ -179,9 +183,25 @@ def render_rays(p, planes, bounds, rays_o, rays_d, near, far, n_samples, n_impor
     rgb_raw, sig_f = mlp(p, plane_features(planes, pts.reshape(-1, 3), bounds), dirs)
     rgb, acc, depth = composite(rgb_raw.reshape(R, S, 3), sig_f.reshape(R, S), z, white_bkgd, noise)
     if normalize_depth:
-        depth = ((depth - near) / (far - near + 1e-5)).clamp(0, 1)
+        depth = (depth - near) / (far - near + 1e-5)
+        if clamp_depth:
+            depth = depth.clamp(0, 1)
     if return_aux:
         aux["sigma_fine"] = sig_f.reshape(R, S)
         aux["rgb_raw"] = rgb_raw.reshape(R, S, 3)
         return rgb, acc, depth, aux
     return rgb, acc, depth
+
+
+def render_rays_recon(p, module_planes, tp_input, rays_o, rays_d, z_vals, near, far, n_importance, u, white_bkgd=False, noise=None):
+    """recon_NeRF/lib/renderer.py:244-295.  module_planes (num_instances, 4, 3, 9, H, W) is the module's Parameter; tp_input carries
+    'instance_idx', 'cloth_layer_index' (bs,) and 'world_bounds' (bs,2,3); rays (bs,R,3), z_vals (bs,R,N), near / far (bs,R) are the
+    ARGUMENTS used for the depth normalisation only; u (bs,R,Ni), noise (bs,R,N+Ni) or None.
+    Returns rgb (bs,R,3), acc (bs,R), depth (bs,R) - depth normalised, not clamped."""
+    tri = module_planes[tp_input["instance_idx"], tp_input["cloth_layer_index"]]      # :251 (advanced indexing: a new tensor)
+    outs = []
+    for b in range(tri.shape[0]):
+        outs.append(render_rays(p, tri[b], tp_input["world_bounds"][b], rays_o[b], rays_d[b], near[b], far[b], z_vals.shape[2],
+                                n_importance, u=u[b] if u is not None else None, white_bkgd=white_bkgd, z_vals=z_vals[b],
+                                noise=noise[b] if noise is not None else None, clamp_depth=False))
+    return tuple(torch.stack([o[k] for o in outs]) for k in range(3))

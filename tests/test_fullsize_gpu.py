@@ -31,7 +31,7 @@ def test_production_unet_matches_oracle(production):
     scale = float(want.abs().mean())
     err = float((got - want).abs().max())
     assert scale > 0.05                      # a vacuous all-zero output would not count
-    assert err < 5e-4 * max(1.0, scale), (err, scale)          # fp32, 256 stacked convs with K up to 13824
+    assert err < 5e-5 * max(1.0, scale), (err, scale)          # fp32, 256 stacked convs with K up to 13824; measured 4.5e-6 on outputs O(0.5)
     mse = float(((got - want) ** 2).mean())
     assert mse < 1e-9 * max(1.0, scale ** 2)
     # the other arithmetic modes meet the same bounds against the oracle: direct-only fp32 (no Winograd) and the opt-in
@@ -46,7 +46,7 @@ def test_production_unet_matches_oracle(production):
             model.set_conv_mode("fp32")
         errs[mode] = float((alt - want).abs().max())
         assert not torch.equal(alt, got)     # the mode really switched kernels
-        assert errs[mode] < 5e-4 * max(1.0, scale), (mode, errs, scale)
+        assert errs[mode] < 5e-5 * max(1.0, scale), (mode, errs, scale)      # measured 5.0e-6 / 5.1e-6
         assert float(((alt - want) ** 2).mean()) < 1e-9 * max(1.0, scale ** 2)
     print("production UNet max-abs vs oracle: " + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()) + f" (output scale {scale:.3f})")
 

@@ -109,3 +109,31 @@ def test_full_loops(tag, spec, ddim):
         out = do.sample_loop(s, lambda x, t: uo.unet_forward(sd, x, t, xc, y), x_T, draw, ddim)
     assert n["i"] == int(g[f"{tag}_ndraws"])
     assert (out - torch.from_numpy(g[f"{tag}_sample"])).abs().max() < 5e-5
+
+
+def test_ddim50_loop_drift_against_reference():
+    """50 recurrent steps (BASELINE configs[3]'s schedule) on the tiny net: the oracle stays within fp32 noise of the reference's
+    loop (tests/golden/gen_golden_drift.py) - the mid-loop state (not yet clamped by the last step) as well as the final sample."""
+    g = np.load(os.path.join(GOLDEN, "diffusion_drift.npz"))
+    _, ks, sd, _, xc, _, _ = load_unet_case("tiny32")
+    s = do.Schedule(do.linear_betas(1000), do.kept_timesteps(1000, "ddim50"))
+    y = torch.tensor([1, 2])
+    n = {"i": 0}
+
+    def draw(shape):
+        gg = torch.Generator().manual_seed(7000 + n["i"])
+        n["i"] += 1
+        return torch.randn(tuple(shape), generator=gg)
+
+    x = draw((2, 27, 32, 32))
+    tmap = torch.tensor(s.timestep_map, dtype=torch.int64)
+    half = None
+    with torch.no_grad():
+        for k, i in enumerate(reversed(range(s.T))):
+            t = torch.full((2,), i, dtype=torch.int64)
+            x = do.ddim_step(s, x, t, uo.unet_forward(sd, x, tmap[t], xc, y), draw(x.shape))[0]
+            if k == s.T // 2 - 1:
+                half = x.clone()
+    assert n["i"] == int(g["tiny32_ddim50_ndraws"])
+    assert (half - torch.from_numpy(g["tiny32_ddim50_half"])).abs().max() < 1e-4
+    assert (x - torch.from_numpy(g["tiny32_ddim50_sample"])).abs().max() < 1e-4

@@ -34,7 +34,7 @@ def test_training_losses_and_gradients_match_reference():
     g = np.load(os.path.join(GOLDEN, "train_loss_tiny32.npz"))
     model, diffusion = tiny_model()
     x0, xc = inputs()
-    losses = diffusion.training_losses(model, x0.clamp(-1, 1), xc, torch.tensor([999, 17]), model_kwargs={"y": torch.tensor([3, 0])},
+    losses = diffusion.training_losses(model.forward_autograd, x0.clamp(-1, 1), xc, torch.tensor([999, 17]), model_kwargs={"y": torch.tensor([3, 0])},
                                        noise=torch.from_numpy(g["noise"]))
     assert losses["loss"].requires_grad
     assert np.abs(losses["loss"].detach().numpy() - g["loss"]).max() < 1e-5

@@ -341,7 +341,7 @@ def test_full_sampling_loops_match_reference(tag, spec, ddim):
         torch.randn_like = orig
     assert n["i"] == int(gl[f"{tag}_ndraws"])               # same RNG call pattern as the reference
     err = (out.cpu() - torch.from_numpy(gl[f"{tag}_sample"])).abs().max()
-    assert err < 5e-4, float(err)                           # 8-10 recurrent UNet evaluations
+    assert err < 1e-4, float(err)                           # 8-10 recurrent UNet evaluations (50 DDIM steps measure 1.9e-5, test_e2e_gpu.py)
 
 
 def test_c_abi_error_convention():
@@ -358,7 +358,7 @@ def test_c_abi_error_convention():
     rc = L.hl_conv2d_nhwc(_lib.ptr(x), 1, 8, 8, 24, _lib.ptr(w), None, 32, 3, 1, 0, None, None, 0, None, _lib.ptr(out),
                           _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr())
     assert rc == -1 and b"multiple of 16" in L.hl_last_error()
-    rc = L.hl_diffusion_step(7, _lib.ptr(out), _lib.ptr(out), None, _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), None, 16, 1, 1,
+    rc = L.hl_diffusion_step(7, _lib.ptr(out), _lib.ptr(out), None, _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), None, 16, 1, 10, 1,
                              _lib.stream_ptr())
     assert rc == -1 and b"mode" in L.hl_last_error()
     rc = L.hl_render_importance(_lib.ptr(out), _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), None, _lib.ptr(out), 4, 1024, 1024,
@@ -368,7 +368,7 @@ def test_c_abi_error_convention():
     a = model_and_diffusion_defaults()
     a.update(dict(in_channels=27, out_channels=27, class_cond=True, image_size=32, num_channels=32, num_res_blocks=1))
     m, _ = create_model_and_diffusion(**a)
-    m = m.to(dev)
+    m = m.to(dev).eval()
     cfg = m._cfg()
     sd = {k: v for k, v in m.state_dict().items() if k != "middle_block.1.qkv.weight"}
     n = len(sd)
