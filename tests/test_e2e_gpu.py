@@ -211,11 +211,11 @@ def test_fitting_forward_sees_the_optimizer_step_with_gathered_planes():
         out = r.render(*args, **kw)["rgb_map"]
         outs.append(out.detach().clone())
         (out ** 2).sum().backward()
-        r.tri_planes.grad.mul_(0.05 / r.tri_planes.grad.abs().max())     # a visible step: the largest entry moves by 0.05
+        r.tri_planes.grad.mul_(0.2 / r.tri_planes.grad.abs().max())      # a visible step: the largest entry moves by 0.2
         opt.step()
         opt.zero_grad()
     for a, b in zip(outs[:-1], outs[1:]):
-        assert (a - b).abs().max() > 1e-4          # every forward saw the planes of the step before it
+        assert (a - b).abs().max() > 1e-4          # every forward saw the planes of the step before it (measured ~4e-4; a stale pack gives 0)
 
 
 def test_out_of_range_timestep_raises_like_the_reference():
