@@ -324,6 +324,11 @@ struct Exec {
     float *act_ws = nullptr, *act_ws2 = nullptr;           // materialised GroupNorm(+SiLU) inputs (k_conv_dma path)
     size_t act_need = 0;                                   // floats, largest normalised conv input seen
     int rc = 0;
+    // GroupNorm statistics travel from the kernel that stores a tensor to the layer that normalises it (ConvArgs::stats): keyed by
+    // the address of channel 0 of the stored region, so a decoder "concat" finds its two producers at x.p and x.p + C0
+    struct StatReg { const float *buf; int Cn, slots; };
+    std::unordered_map<const float *, StatReg> stat_reg;
+    bool want_stats = true;
 
     float *alloc(size_t floats) {
         float *p = run ? reinterpret_cast<float *>(ws + off) : nullptr;
@@ -357,6 +362,10 @@ struct Exec {
             const size_t need = (size_t)in.pixels() * c.Cin_pad;
             if (need > act_need) act_need = need;
         }
+        // room for the output statistics (same allocations in the sizing pass)
+        const bool st_ok = want_stats && !nchw;
+        float *st1 = st_ok ? alloc(hl::conv_stats_floats(out.pixels(), c.Cout)) : nullptr;
+        float *st2 = (st_ok && out2_pitch != 0) ? alloc(hl::conv_stats_floats(out.pixels(), c.Cout)) : nullptr;
         if (!run) return;
         ConvArgs a{};
         a.in = in; a.in.C = c.Cin_pad;
@@ -367,18 +376,40 @@ struct Exec {
         a.out2 = out2; a.out2_pitch = out2_pitch; a.res2 = res2; a.res2_pitch = res2_pitch; a.out_nchw = nchw;
         a.splitk_ws = splitk_ws; a.splitk_ws_bytes = hl::conv_splitk_ws_bytes();
         a.act_ws = act_ws; a.act_ws_bytes = act_need * sizeof(float);
+        a.stats = st1; a.stats2 = st2;
         const size_t e0 = span_begin();
         ok(hl::conv2d(a, st));
         const double fl = 2.0 * (double)out.pixels() * c.Cout * c.Cin * c.ks * c.ks;
         // Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36; bf16x3: six bf16 MFMA products per fp32 product
         span_end(CAT_CONV, e0, fl, a.path == 1 ? fl * (16.0 / 36.0) : (a.path == 2 ? fl * 6.0 : fl));
+        // whoever stored the tensor last owns its statistics
+        if (a.stat_slots > 0) {
+            stat_reg[out.p] = {st1, c.Cout, a.stat_slots};
+            if (out2) stat_reg[out2] = {st2, c.Cout, a.stat_slots};
+        } else {
+            stat_reg.erase(out.p);
+            if (out2) stat_reg.erase(out2);
+        }
     }
     void coef(const View &x, const Norm &g, const float *emb, float *&cA, float *&cB) {
         cA = alloc((size_t)B * x.C);
         cB = alloc((size_t)B * x.C);
         if (run) {
             const size_t e0 = span_begin();
-            ok(hl::groupnorm_coef(x, g.gamma, g.beta, emb, n.emb_total, cA, cB, gn_scratch, st));
+            // statistics emitted by the producer(s) of x, if every channel of x is covered; otherwise one pass over the tensor
+            hl::StatSrc src[2];
+            int nsrc = 0;
+            auto it = stat_reg.find(x.p);
+            if (it != stat_reg.end() && it->second.Cn <= x.C) {
+                src[nsrc++] = {it->second.buf, it->second.Cn, it->second.slots};
+                if (it->second.Cn < x.C) {
+                    auto it2 = stat_reg.find(x.p + it->second.Cn);
+                    if (it2 != stat_reg.end() && it->second.Cn + it2->second.Cn == x.C) src[nsrc++] = {it2->second.buf, it2->second.Cn, it2->second.slots};
+                    else nsrc = 0;
+                }
+            }
+            if (nsrc) ok(hl::groupnorm_coef_stats(x, src, nsrc, g.gamma, g.beta, emb, n.emb_total, cA, cB, st));
+            else ok(hl::groupnorm_coef(x, g.gamma, g.beta, emb, n.emb_total, cA, cB, gn_scratch, st));
             span_end(CAT_GN, e0, 0.0);
         }
     }
@@ -389,7 +420,9 @@ struct Exec {
         conv(r.c1, x, h, 1, 0, a1, b1, 1, nullptr, 0);
         coef(h, r.n2, run ? emb_all + r.emb_off : nullptr, a2, b2);
         if (r.has_skip) {
+            want_stats = false;          // dst is finished by c2 below
             conv(r.skip, x, dst, 1, 0, nullptr, nullptr, 0, nullptr, 0);
+            want_stats = true;
             conv(r.c2, h, dst, 1, 0, a2, b2, 1, dst.p, dst.pitch);
         } else {
             conv(r.c2, h, dst, 1, 0, a2, b2, 1, x.p, x.pitch);
@@ -399,7 +432,9 @@ struct Exec {
         float *ca, *cb;
         coef(x, a.norm, nullptr, ca, cb);
         View qkv = plain(H / x.H, 3 * a.C);
+        want_stats = false;              // qkv is not normalised
         conv(a.qkv, x, qkv, 1, 0, ca, cb, 0, nullptr, 0);
+        want_stats = true;
         View o = plain(H / x.H, a.C);
         if (run) {
             const size_t e0 = span_begin();
@@ -513,6 +548,8 @@ struct Exec {
                 const int Ch = cat[j].C - hs[i].C;
                 hipMemcpy2DAsync(cat[j].p + Ch, cat[j].pitch * sizeof(float), hs[i].p, hs[i].pitch * sizeof(float),
                                  (size_t)hs[i].C * sizeof(float), (size_t)hs[i].pixels(), hipMemcpyDeviceToDevice, st);
+                auto sr = stat_reg.find(hs[i].p);   // the copy has the statistics of its source
+                if (sr != stat_reg.end()) stat_reg[cat[j].p + Ch] = sr->second; else stat_reg.erase(cat[j].p + Ch);
             }
         }
         // decoder
@@ -655,7 +692,8 @@ int hl_unet_profile_read_ex(void *handle, double *h_ms, double *h_flops, double 
 // ---- single ops for tests ------------------------------------------------------------------------
 static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,
                          int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
-                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream) {
+                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream,
+                         float *stats = nullptr, int *stat_slots = nullptr) {
     HL_REQUIRE(Cin % 16 == 0, "hl_conv2d_nhwc: Cin must be a multiple of 16");
     const size_t need32 = (hl::conv_packed_floats(Cout, Cin, ks) * sizeof(float) + 255) / 256 * 256;
     const size_t extra = mode == HL_CONV_BF16X3 ? hl::conv_packed_bf3_bytes(Cout, Cin, ks)
@@ -696,7 +734,36 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
         a.splitk_ws = reinterpret_cast<float *>(static_cast<char *>(scratch) + used);
         a.splitk_ws_bytes = scratch_bytes - used;
     }
-    return hl::conv2d(a, (hipStream_t)stream);
+    a.stats = stats;
+    rc = hl::conv2d(a, (hipStream_t)stream);
+    if (stat_slots) *stat_slots = a.stat_slots;
+    return rc;
+}
+
+int hl_conv2d_nhwc_gn(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,
+                      int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu, const float *residual,
+                      float *out, const float *gamma, const float *beta, float *next_coefA, float *next_coefB, int *h_used_stats,
+                      void *scratch, size_t scratch_bytes, void *stream) {
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT, "hl_conv2d_nhwc_gn: unknown mode %d", conv_mode);
+    HL_REQUIRE(gamma && beta && next_coefA && next_coefB && scratch, "hl_conv2d_nhwc_gn: null argument");
+    const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
+    const int Ho = (Hv + 2 * pad - ks) / stride + 1, Wo = (Wv + 2 * pad - ks) / stride + 1;
+    const size_t stf = (hl::conv_stats_floats((long)N * Ho * Wo, Cout) * sizeof(float) + 255) / 256 * 256;
+    const size_t gnf = (hl::gn_scratch_floats(N) * sizeof(float) + 255) / 256 * 256;
+    HL_REQUIRE(scratch_bytes > stf + gnf, "hl_conv2d_nhwc_gn: scratch too small");
+    float *stats = static_cast<float *>(scratch);
+    float *gn_scr = reinterpret_cast<float *>(static_cast<char *>(scratch) + stf);
+    int slots = 0;
+    int rc = conv2d_single(conv_mode, in, N, H, W, Cin, w_oihw, bias, Cout, ks, stride, upsample, coefA, coefB, silu, residual, out,
+                           static_cast<char *>(scratch) + stf + gnf, scratch_bytes - stf - gnf, stream, stats, &slots);
+    if (rc) return rc;
+    View v; v.p = out; v.N = N; v.H = Ho; v.W = Wo; v.C = Cout; v.pitch = Cout;
+    if (h_used_stats) *h_used_stats = slots;
+    if (slots > 0) {
+        hl::StatSrc src{stats, Cout, slots};
+        return hl::groupnorm_coef_stats(v, &src, 1, gamma, beta, nullptr, 0, next_coefA, next_coefB, (hipStream_t)stream);
+    }
+    return hl::groupnorm_coef(v, gamma, beta, nullptr, 0, next_coefA, next_coefB, gn_scr, (hipStream_t)stream);
 }
 
 int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout, int ks,

@@ -38,7 +38,15 @@ struct ConvArgs {
     mutable int path;    // set by conv2d: 0 direct implicit GEMM, 1 Winograd F(2x2,3x3), 2 bf16x3 emulation
     float *splitk_ws;    // optional scratch for split-K partial sums (small-M layers); null disables split-K
     size_t splitk_ws_bytes;
+    // GroupNorm statistics of the OUTPUT for the layer that will normalise it, emitted by the epilogue of whichever kernel stores
+    // the tensor: per slot of consecutive pixels and per channel (sum, sumsq), [slot][Cout][2].  `stats` (and `stats2` for out2)
+    // need conv_stats_floats(out pixels, Cout) floats each; null = not wanted.  On return stat_slots is the number of slots PER
+    // IMAGE that were written, or 0 when this path emits none (register-staged / bf16x3 / NCHW / odd sizes): the consumer then
+    // computes the statistics from the tensor (groupnorm_coef).
+    float *stats, *stats2;
+    mutable int stat_slots;
 };
+inline size_t conv_stats_floats(long out_pixels, int Cout) { return (size_t)(out_pixels / 32 + 1) * Cout * 2; }
 size_t conv_splitk_ws_bytes();
 int conv2d(const ConvArgs &a, hipStream_t st);
 size_t conv_packed_floats(int Cout, int Cin_pad, int ks);
@@ -55,6 +63,11 @@ int conv_pack_weights_bf3(const float *w_oihw, int Cout, int Cin, int Cin_pad, i
 // optional scale/shift (ResBlock use_scale_shift_norm, unet.py:203-206): y = GN(x)*(1+scale)+shift,
 // where emb (N, emb_pitch) holds [scale(C) | shift(C)] starting at emb + n*emb_pitch.
 size_t gn_scratch_floats(int N);
+// the same affine from the statistics the producers emitted (ConvArgs::stats): source 0 covers channels [0, src[0].Cn) of the view,
+// source 1 (decoder concats: the control branch's half) the rest; `slots` = ConvArgs::stat_slots of the producing launch
+struct StatSrc { const float *p; int Cn, slots; };
+int groupnorm_coef_stats(const View &x, const StatSrc *src, int nsrc, const float *gamma, const float *beta, const float *emb,
+                         long emb_pitch, float *coefA, float *coefB, hipStream_t st);
 int groupnorm_coef(const View &x, const float *gamma, const float *beta, const float *emb, long emb_pitch, float *coefA,
                    float *coefB, float *scratch, hipStream_t st);
 

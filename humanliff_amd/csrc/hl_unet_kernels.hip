@@ -54,7 +54,27 @@ struct ConvK {
     int kt_per;        // k-tiles per split (blockIdx.z); gridDim.z == 1 -> whole K
     int n_mtiles, n_nblocks;
     float *partial;    // split-K: raw accumulators [z][M][Cout]
+    // GroupNorm statistics of the OUTPUT, emitted by the epilogue for the layer that will normalise it (nn.py:17-19): per slot of
+    // consecutive output pixels (32 rows of M; a Winograd workgroup: one column parity of its 16x8 block = 64 pixels) and per
+    // output channel (sum, sum of squares) of the stored value (after bias / residual), [slot][Cout][2]; null = not wanted.
+    // st2: the same for out2.  Deterministic (no atomics); k_gn_coef_st folds the slots of an image.
+    float *st1, *st2;
 };
+
+// (sum, sumsq) of a lane's values -> combined over the two lane halves (same channel, other pixels) -> [slot][Cout][2]
+template <int NV>
+__device__ __forceinline__ void emit_stats(float *st, long slot, int Cout, int n, int half, const float (&v)[NV], const bool (&ok)[NV]) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const float x = ok[k] ? v[k] : 0.f;
+        s += x;
+        q += x * x;
+    }
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    if (half == 0) *reinterpret_cast<float2 *>(st + (slot * Cout + n) * 2) = make_float2(s, q);
+}
 
 // MODE 0: raw input, 1: per-(n,c) affine (GroupNorm), 2: affine + SiLU.
 // K order: see kt_decode.  Inside a tap every pointer just advances by 16 floats; a tap change recomputes the
@@ -549,6 +569,13 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const C
 #pragma unroll
             for (int r = 0; r < 16; ++r) v2[r] += v[r];
         }
+        if ((p.st1 || p.st2) && m0 + wave * 32 < p.M) {   // slot = this wave's 32 rows of M (the launcher checked: one image per slot)
+            bool okr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) okr[r] = mb + (r & 3) + 8 * (r >> 2) < p.M;
+            if (p.st1) emit_stats<16>(p.st1, (m0 + wave * 32) >> 5, p.Cout, n, half, v, okr);
+            if (p.st2) emit_stats<16>(p.st2, (m0 + wave * 32) >> 5, p.Cout, n, half, v2, okr);
+        }
         if (p.out_nchw) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -590,14 +617,18 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const C
 //                                                                    the next row of tiles starts 128 bytes off modulo 256)
 //   weight chunk ((f*2 + ct)*2 + half)*32 + cout                   (4 channels of one output channel)
 // ---------------------------------------------------------------------------------------------
-template <int G, int CW, bool UPS = false, bool PRIV = false>
-__global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK p) {
+template <bool UPS>
+__global__ __launch_bounds__(256, 2) void k_conv_wino(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__   // device pass only (see k_conv_bf3)
-    // G tile groups of 32 tiles (4 rows of 8 tiles = 16 x 8 pixels) per workgroup, 4 waves (frequency rows) each.
-    // G = 2: 8 waves, 3-stage ring, one workgroup per CU; G = 1: 4 waves, 2-stage ring, two independent workgroups per CU
-    // (their prologues / epilogues / barriers overlap; the weights are streamed twice as often).
-    // CW = 2: the two 32-channel blocks go to different waves (64 accumulator registers each -> 4 waves per SIMD).
-    constexpr int NW = 4 * G * CW, NCT = 2 / CW, NS = (G == 1) ? 2 : 3, PR = 8 * G + 2;   // waves, channel blocks per wave, ring stages, patch rows
+    // One tile group of 32 tiles (4 rows of 8 tiles = 16 x 8 pixels) per workgroup, 4 waves (frequency rows), 2-stage ring, two
+    // independent workgroups per CU (their prologues / epilogues / barriers overlap).  (Round 1 also carried a two-group 8-wave
+    // variant and one with the channel blocks on separate waves; both measured slower - 249 / 237 vs 261 TFLOP/s - and are gone.)
+    // (Round 2 tried a variant that takes the RAW tensor and applies the consuming layer's GroupNorm affine + SiLU to the patch in LDS,
+    //  in place, by the wave that DMA'd it - no k_gn_apply pass.  It was 25-30 % slower per launch (760 -> 995 us at 256x256): the
+    //  8 x (fma, exp, rcp, 2 mul) per lane and k-tile plus the coefficient fetch sit between the patch DMA and the barrier that
+    //  publishes it, whichever way they were placed; the separate pass costs 6 % of the step and mostly overlaps the other stream.)
+    constexpr int G = 1, CW = 1;
+    constexpr int NW = 4 * G * CW, NCT = 2 / CW, PR = 8 * G + 2;   // waves, channel blocks per wave, patch rows (2-stage ring)
     constexpr int U_F = 16 * 2 * 2 * 32 * 4, P_REAL = 2 * PR * 2 * 10, NP = (P_REAL + 63) / 64, P_F = NP * 256, STAGE_F = U_F + P_F;
     constexpr int NU = 32 / NW, NTOT = 32 + NP, NJ = (NTOT + NW - 1) / NW;   // weight instructions per wave, all, rounds
     constexpr unsigned OOB = 0x80000000u;
@@ -640,31 +671,9 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
         pv[j] = ok ? (unsigned)((img * p.Hin + ys) * p.Win + xs) * pitch4 + h * 16 : OOB;
         n_p += (pi < NP) ? 1 : 0;
     }
-    const int n_w = NU + n_p;                                     // DMA instructions of this wave per k-tile
-    const unsigned uv = (unsigned)(wave * 64 + lane) * 16u;       // + NW KiB per round
     const int kt0 = blockIdx.z * p.kt_per;                        // split-K over input channels: this slab's k-tiles
-    int soffU = (nb * nkt + kt0) * (U_F * 4), soffA = kt0 * 32;
-    auto issue = [&](int stage) {
-        float *du = lds + stage * STAGE_F + wave * 256;
-#pragma unroll
-        for (int j = 0; j < NU; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void *)(du + j * (NW * 256)), 16,
-                                                     uv, soffU + j * (NW * 1024), 0, 0);
-        float *dp = lds + stage * STAGE_F + U_F + (wave + NW * NU - 32) * 256;
-        if (n_p > 0)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)dp, 16, pv[0], soffA, 0, 0);
-        if (NJ - NU > 1 && n_p > 1)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(dp + NW * 256), 16,
-                                                     pv[NJ - NU > 1 ? 1 : 0], soffA, 0, 0);
-        static_assert(NJ - NU <= 2, "at most two patch instructions per wave");
-        soffU += U_F * 4;
-        soffA += 32;
-    };
-    auto wait_younger = [&]() {   // all but this wave's DMAs of the youngest k-tile have landed (3-stage ring only)
-        if (n_w == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    };
-    static_assert(G == 1 || (CW == 1 && NU == 4 && NJ == 6), "wait_younger assumes 5 or 6 instructions per wave for G = 2");
+    int soffA = kt0 * 32;
+    static_assert(NJ - NU <= 2, "at most two patch instructions per wave");
 
     // patch read offsets (floats): tile T = lane & 31 -> (ty, tx); rows rA, rB of B^T row fi; column c: parity c&1, + (c>>1)
     const int T = lane & 31, ty = 4 * g + (T >> 3), tx = T & 7;
@@ -708,15 +717,14 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
 #pragma unroll
         for (int c = 0; c < NCT; ++c) u2[c] = *reinterpret_cast<const f32x4 *>(base + u_off + ((f * 2 + (CW == 2 ? ctw : c)) * 2) * 128);
     };
-    if constexpr (PRIV) {
-        // PRIV (G = 1, CW = 1): the four waves of a workgroup use DISJOINT weight slices (their own frequency row), so each wave
+    {
+        // The four waves of a workgroup use DISJOINT weight slices (their own frequency row), so each wave
         // DMAs exactly its own 8 chunks per k-tile and nobody else reads them: no barrier is needed for the weights, and the
         // refill of a chunk pair is issued right behind the MFMAs that consumed it - two DMA instructions per unit instead of
         // a burst of ten behind the barrier, each with two k-tiles to land.  Only the patch (1-2 instructions per wave) stays
         // behind the barrier.  Per wave the VMEM queue therefore carries, per k-tile, the fixed sequence
         //     U(.,0) U(.,1) U(.,2) P(.) U(.,3)            (2, 2, 2, n_p, 2 instructions)
         // for the tile two ahead, and every wait below is an exact count of the younger instructions in that queue.
-        static_assert(G == 1 && CW == 1, "PRIV needs one tile group and both channel blocks per wave");
         const unsigned uvp = (unsigned)lane * 16u;
         int soffP = (nb * nkt + kt0) * (U_F * 4) + (8 * fi) * 1024;   // this wave's first chunk of k-tile kt0
         auto issue_u = [&](int stage, int f, int soff) {             // both channel blocks of frequency f'
@@ -804,59 +812,7 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
             bodyp(std::integral_constant<int, 0>{}, t);
             if (t + 1 < ntiles) bodyp(std::integral_constant<int, 1>{}, t + 1);
         }
-    } else {
-    if (ntiles > 0) {
-            issue(0);
-            if (NS == 3 && ntiles > 1) { issue(1); wait_younger(); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (ntiles > NS - 1) issue(NS - 1);
-            read_patch(lds, da, db);
-            read_u(lds, 0, ub[0]);
-            transform(da, db, V);
-        }
-        auto body = [&](auto uc, int t) {
-            constexpr int U = decltype(uc)::value, UN = (U + 1) % NS;
-            const float *base = lds + U * STAGE_F, *nbase = lds + UN * STAGE_F;
-            const bool more = t + 1 < ntiles;
-    #pragma unroll
-            for (int f = 0; f < 4; ++f) {   // unit = frequency f' (both channel blocks: two independent accumulator chains)
-                // the reads for the next unit are issued AFTER this unit's operands have been waited for (the compiler waits
-                // with lgkmcnt(0)), behind its first MFMAs, and land under the remaining six
-    #pragma unroll
-                for (int c = 0; c < NCT; ++c)
-                    acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][0], ub[f & 1][c][0], acc[f][c], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (f < 3) read_u(base, f + 1, ub[(f + 1) & 1]);
-                else if (more) {   // (every weight chunk of tile t has been read: nothing reads stage U after this)
-                    if (NS == 3 && t + 2 < ntiles) wait_younger(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done reading tile t before its stage refills
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if (t + NS < ntiles) issue(U);
-                    read_patch(nbase, da, db);
-                    read_u(nbase, 0, ub[0]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-                for (int s = 1; s < 4; ++s)
-    #pragma unroll
-                    for (int c = 0; c < NCT; ++c)
-                        acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][c][s], acc[f][c], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (more) transform(da, db, V);
-            // nothing pending at the loop back-edge: lets the compiler count its LDS waits inside the body exactly (the reads of
-            // U(t+1, 0) were issued 8 MFMAs ago)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        };
-        for (int t = 0; t < ntiles; t += NS) {
-            body(std::integral_constant<int, 0>{}, t);
-            if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, t + 1);
-            if (NS == 3 && t + 2 < ntiles) body(std::integral_constant<int, NS == 3 ? 2 : 0>{}, t + 2);
-        }
-    
-}
+    }
 
     // column half of the output transform, then the four frequency rows meet in LDS
     __syncthreads();
@@ -914,6 +870,13 @@ __global__ __launch_bounds__(G * CW * 256, 2 * CW) void k_conv_wino(const ConvK 
         for (int k = 0; k < NO; ++k) v2[k] = p.res2[mm[k] * p.res2_pitch + n];
 #pragma unroll
         for (int k = 0; k < NO; ++k) v2[k] += v[k];
+    }
+    if (p.st1 || p.st2) {   // slot = (tile block, column parity): 64 pixels of one image
+        bool all[NO];
+#pragma unroll
+        for (int k = 0; k < NO; ++k) all[k] = true;
+        if (p.st1) emit_stats<NO>(p.st1, (long)tb * 2 + b, p.Cout, n, half, v, all);
+        if (p.st2) emit_stats<NO>(p.st2, (long)tb * 2 + b, p.Cout, n, half, v2, all);
     }
     if (p.out_nchw) {
 #pragma unroll
@@ -1291,6 +1254,52 @@ __global__ void k_splitk_finish(const ConvK p, int splits) {
     }
 }
 
+// The same, organised for the GroupNorm statistics of the result: a workgroup owns one slot of 32 consecutive pixels x 64 output
+// channels (grid (M/32, Cout/64)); its 4 waves take 8 pixels each, a lane one channel; the four partial (sum, sumsq) pairs of a
+// channel meet in LDS in a fixed order.  Same arithmetic and order of the slab sum as k_splitk_finish.
+__global__ __launch_bounds__(256) void k_splitk_finish_st(const ConvK p, int splits) {
+    __shared__ float red[2][4][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.y * 64 + lane;
+    const long total = p.M * p.Cout;
+    float s1 = 0.f, q1 = 0.f, s2 = 0.f, q2 = 0.f;
+    if (n < p.Cout) {
+        const float bs = p.bias ? p.bias[n] : 0.f;
+        float v[8], r1[8], r2[8];
+        const long mb = (long)blockIdx.x * 32 + wave * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        for (int z = 0; z < splits; ++z)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += p.partial[(long)z * total + (mb + k) * p.Cout + n];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { r1[k] = p.res ? p.res[(mb + k) * p.res_pitch + n] : 0.f; r2[k] = p.out2 ? p.res2[(mb + k) * p.res2_pitch + n] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] += bs;
+            if (p.res) v[k] += r1[k];
+            p.out[(mb + k) * p.out_pitch + n] = v[k];
+            s1 += v[k]; q1 += v[k] * v[k];
+            if (p.out2) {
+                const float w = v[k] + r2[k];
+                p.out2[(mb + k) * p.out2_pitch + n] = w;
+                s2 += w; q2 += w * w;
+            }
+        }
+    }
+    red[0][wave][0][lane] = s1; red[0][wave][1][lane] = q1;
+    red[1][wave][0][lane] = s2; red[1][wave][1][lane] = q2;
+    __syncthreads();
+    if (wave < 2 && n < p.Cout) {
+        float *st = wave == 0 ? p.st1 : p.st2;
+        if (st) {
+            const float s = ((red[wave][0][0][lane] + red[wave][1][0][lane]) + red[wave][2][0][lane]) + red[wave][3][0][lane];
+            const float q = ((red[wave][0][1][lane] + red[wave][1][1][lane]) + red[wave][2][1][lane]) + red[wave][3][1][lane];
+            *reinterpret_cast<float2 *>(st + ((long)blockIdx.x * p.Cout + n) * 2) = make_float2(s, q);
+        }
+    }
+}
+
 __global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, int ks, int rows, float *__restrict__ dst) {
     const int taps = ks * ks;
     const long Ktot = (long)Cin_pad * taps;
@@ -1502,6 +1511,61 @@ __global__ __launch_bounds__(64) void k_gn_coef(const float *__restrict__ partia
             const float sh = emb[(long)n * emb_pitch + C + c];
             a = a * sc;
             b = b * sc + sh;
+        }
+        cA[(long)n * C + c] = a;
+        cB[(long)n * C + c] = b;
+    }
+}
+
+// GroupNorm affine from the per-slot statistics the producing kernels emitted (ConvK::st1 / st2) - the tensor itself is not read
+// again.  The normalised view may be a decoder "concat" whose two channel ranges came from two producers: source 0 covers channels
+// [0, C0) with slots0 slots per image, source 1 the rest.  grid (32 groups, N), 256 threads; fixed summation order.
+struct StatSrcK { const float *p; int Cn, slots; };
+__global__ __launch_bounds__(256) void k_gn_coef_st(StatSrcK s0, StatSrcK s1, int HW, int C, const float *__restrict__ gamma,
+                                                    const float *__restrict__ beta, const float *__restrict__ emb, long emb_pitch,
+                                                    float *__restrict__ cA, float *__restrict__ cB) {
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int cg = C / 32, c_lo = g * cg, c_hi = c_lo + cg;
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const StatSrcK &src = which ? s1 : s0;
+        const int base = which ? s0.Cn : 0;                        // first channel of the view this source covers
+        const int lo = max(c_lo, base) - base, hi = min(c_hi, base + src.Cn) - base;   // the group's channels inside this source
+        if (src.p == nullptr || hi <= lo) continue;
+        const int nch = hi - lo, items = nch * src.slots;
+        const float *q = src.p + (long)n * src.slots * src.Cn * 2;
+        for (int i = tid; i < items; i += 256) {
+            const int slot = i / nch, c = lo + (i - slot * nch);
+            const float2 v = *reinterpret_cast<const float2 *>(q + ((long)slot * src.Cn + c) * 2);
+            s += (double)v.x;
+            ss += (double)v.y;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        s += __shfl_xor(s, d);
+        ss += __shfl_xor(ss, d);
+    }
+    __shared__ double red[8];
+    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s; red[(tid >> 6) * 2 + 1] = ss; }
+    __syncthreads();
+    s = (red[0] + red[2]) + (red[4] + red[6]);
+    ss = (red[1] + red[3]) + (red[5] + red[7]);
+    const double cnt = (double)HW * cg;
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    for (int j = tid; j < cg; j += 256) {
+        const int c = c_lo + j;
+        float a = rstd * gamma[c];
+        float b = beta[c] - (float)mean * a;
+        if (emb) {
+            const float sc = 1.f + emb[(long)n * emb_pitch + c];
+            const float sf = emb[(long)n * emb_pitch + C + c];
+            a = a * sc;
+            b = b * sc + sf;
         }
         cA[(long)n * C + c] = a;
         cB[(long)n * C + c] = b;
@@ -1883,6 +1947,8 @@ int conv_pack_weights_wino(const float *w, int Cout, int Cin, int Cin_pad, float
     return check_launch("k_pack_conv_wino");
 }
 
+static inline long hw_o_early(const ConvArgs &a) { return (long)a.out.H * a.out.W; }
+
 int conv2d(const ConvArgs &a, hipStream_t st) {
     a.path = 0;
     HL_REQUIRE(a.in.p && a.w && a.out.p, "conv2d: null tensor");
@@ -1918,11 +1984,10 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     else { cfg = 2; blocks = ((M + 63) / 64) * (cpad / 64); }
     // main-tile layers that need no upsampling go through k_conv_dma (GroupNorm materialised by k_gn_apply first);
     // the 8-wave 256x96 tile when that covers at least half the chip (2 workgroups/CU = 512 slots), else 4 waves x 128x96
-    static const int dma_thr = getenv("HL_CONV_T8") ? atoi(getenv("HL_CONV_T8")) : 256;
-    static const int dma_off = getenv("HL_CONV_NODMA") ? 1 : 0;
-    static const long wino_thr = getenv("HL_CONV_WINO") ? atol(getenv("HL_CONV_WINO")) : 512;   // workgroups wanted per launch; huge = off
-    static const long wino_min = getenv("HL_CONV_WINO_MIN") ? atol(getenv("HL_CONV_WINO_MIN")) : 384;   // fewer even after splitting: direct kernel
-    const bool dma = !dma_off && cfg == 0 && (a.coefA == nullptr || a.act_ws) &&
+    constexpr int dma_thr = 256;      // 256x96 tiles when they give at least this many workgroups
+    constexpr long wino_thr = 512;    // Winograd: workgroups wanted per launch (smaller layers split the input channels)
+    constexpr long wino_min = 384;    // fewer even after splitting: direct kernel
+    const bool dma = cfg == 0 && (a.coefA == nullptr || a.act_ws) &&
                      (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && (long)cpad * p.Ktot * 4 < (1L << 31);
     const long blocks8 = ((M + 255) / 256) * (cpad / 96);
     const bool tile8 = dma && blocks8 >= dma_thr;
@@ -1941,6 +2006,23 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     p.partial = splits > 1 ? a.splitk_ws : nullptr;
     const int mode = a.coefA ? (a.act ? 2 : 1) : 0;
     HL_REQUIRE(a.coefA || !a.act, "conv2d: SiLU without the GroupNorm affine is not used by the UNet");
+    // GroupNorm statistics of the output (ConvK::st1 / st2): slots of 32 consecutive pixels must not straddle images
+    a.stat_slots = 0;
+    const bool st_rows32 = a.stats && !a.out_nchw && hw_o_early(a) % 32 == 0;
+    auto finish = [&](const char *what) -> int {   // split-K: the slab sum (+ statistics when wanted)
+        int rc = check_launch(what);
+        if (rc) return rc;
+        if (st_rows32 && M % 32 == 0) {
+            p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
+            a.stat_slots = (int)(hw_o_early(a) / 32);
+            hipLaunchKernelGGL(k_splitk_finish_st, dim3((unsigned)(M / 32), (unsigned)((a.Cout + 63) / 64)), dim3(256), 0, st, p, splits);
+        } else {
+            long gf = (M * a.Cout + 255) / 256;
+            if (gf > 2048) gf = 2048;
+            hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)gf), dim3(256), 0, st, p, splits);
+        }
+        return check_launch("k_splitk_finish");
+    };
     const long hw_o = (long)a.out.H * a.out.W;
 #define HL_CONV_GO(WM_, WN_, MT_, NT_, GRID)                                                         \
     do {                                                                                             \
@@ -1976,8 +2058,8 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         p.partial = splits > 1 ? a.splitk_ws : nullptr;
     }
     if (dma) {
-        if (mode != 0) {   // materialise GroupNorm(+SiLU) once, then the DMA kernel reads it raw
-            HL_REQUIRE(!a.ups, "conv2d: upsample with a GroupNorm prologue is not used by the UNet");
+        HL_REQUIRE(mode == 0 || !a.ups, "conv2d: upsample with a GroupNorm prologue is not used by the UNet");
+        if (mode != 0) {   // materialise GroupNorm(+SiLU) once, then the DMA kernels read it raw
             HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
             const long npix = a.in.pixels();
             long g = (npix * (a.in.C / 4) + 255) / 256;
@@ -1989,36 +2071,26 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         if (wino) {
             a.path = 1;
             p.n_nblocks = a.Cout / 64;
-            // one tile group per workgroup (two workgroups per CU) unless the 32 x 16 variant is asked for
-            static const int wg2 = getenv("HL_WINO_G2") ? 1 : 0;
-            const bool g2 = wg2 && a.out.H % 16 == 0 && !a.ups;
-            p.n_mtiles = a.out.N * (a.out.H / (g2 ? 16 : 8)) * (a.out.W / 16);
+            p.n_mtiles = a.out.N * (a.out.H / 8) * (a.out.W / 16);
             const dim3 nblk((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
-            // (measured on 192->192 @256x256, batch 4: one tile group x both channel blocks per wave 256 TFLOP/s; two tile groups
-            //  249; channel blocks on separate waves - 4 waves/SIMD - 237)
-            static const int wcw2 = getenv("HL_WINO_CW2") ? 1 : 0;
             const size_t sh1 = (size_t)2 * (8192 + 7 * 256) * sizeof(float);
-            if (g2) hipLaunchKernelGGL((k_conv_wino<2, 1>), nblk, dim3(512), (size_t)3 * (8192 + 12 * 256) * sizeof(float), st, p);
-            else if (wcw2 && !a.ups) hipLaunchKernelGGL((k_conv_wino<1, 2>), nblk, dim3(512), sh1, st, p);
-            else {
-                static const int priv = getenv("HL_WINO_PRIV") ? atoi(getenv("HL_WINO_PRIV")) : 1;   // private-weight DMA schedule (default)
-                if (priv && a.ups) hipLaunchKernelGGL((k_conv_wino<1, 1, true, true>), nblk, dim3(256), sh1, st, p);
-                else if (priv) hipLaunchKernelGGL((k_conv_wino<1, 1, false, true>), nblk, dim3(256), sh1, st, p);
-                else if (a.ups) hipLaunchKernelGGL((k_conv_wino<1, 1, true>), nblk, dim3(256), sh1, st, p);
-                else hipLaunchKernelGGL((k_conv_wino<1, 1>), nblk, dim3(256), sh1, st, p);
+            if (splits == 1 && a.stats && !a.out_nchw) {   // statistics from the epilogue: slot = (16x8 block, column parity)
+                p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
+                a.stat_slots = (a.out.H / 8) * (a.out.W / 16) * 2;
             }
-            if (splits > 1) {
-                long gf = (M * a.Cout + 255) / 256;
-                if (gf > 2048) gf = 2048;
-                hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)gf), dim3(256), 0, st, p, splits);
-                return check_launch("k_splitk_finish");
-            }
+            if (a.ups) hipLaunchKernelGGL((k_conv_wino<true>), nblk, dim3(256), sh1, st, p);
+            else hipLaunchKernelGGL((k_conv_wino<false>), nblk, dim3(256), sh1, st, p);
+            if (splits > 1) return finish("k_conv_wino");
             return check_launch("k_conv_wino");
         }
         p.n_nblocks = cpad / 96;
         p.n_mtiles = (int)((M + (tile8 ? 255 : 127)) / (tile8 ? 256 : 128));
         dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
         const size_t shm8 = (size_t)3 * 352 * 16 * sizeof(float), shm4 = (size_t)3 * 224 * 16 * sizeof(float);
+        if (splits == 1 && st_rows32 && !(a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31))) {   // statistics from the epilogue: slot = a wave's 32 rows
+            p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
+            a.stat_slots = (int)(hw_o_early(a) / 32);
+        }
         if (a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) {   // fp32 emulated on the bf16 matrix pipe (opt-in)
             a.path = 2;
             const size_t s8 = (size_t)3 * (256 * 16 + 6 * 96 * 4) * sizeof(float), s4 = (size_t)3 * (128 * 16 + 6 * 96 * 4) * sizeof(float);
@@ -2045,14 +2117,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         HL_CONV_GO(2, 2, 1, 1, grid);
     }
 #undef HL_CONV_GO
-    if (splits > 1) {
-        int rc = check_launch("k_conv");
-        if (rc) return rc;
-        long g = (M * a.Cout + 255) / 256;
-        if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)g), dim3(256), 0, st, p, splits);
-        return check_launch("k_splitk_finish");
-    }
+    if (splits > 1) return finish("k_conv");
     return check_launch("k_conv");
 }
 
@@ -2093,6 +2158,18 @@ int groupnorm_coef(const View &x, const float *gamma, const float *beta, const f
     if (rc || nch == 1) return rc;
     hipLaunchKernelGGL(k_gn_coef, dim3(32, x.N), dim3(64), 0, st, scratch, nch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
     return check_launch("k_gn_coef");
+}
+
+int groupnorm_coef_stats(const View &x, const StatSrc *src, int nsrc, const float *gamma, const float *beta, const float *emb,
+                         long emb_pitch, float *cA, float *cB, hipStream_t st) {
+    HL_REQUIRE(src && (nsrc == 1 || nsrc == 2) && gamma && beta && cA && cB, "groupnorm_coef_stats: bad argument");
+    HL_REQUIRE(x.C % 32 == 0, "GroupNorm32 needs C %% 32 == 0 (C=%d)", x.C);
+    HL_REQUIRE(src[0].Cn + (nsrc == 2 ? src[1].Cn : 0) == x.C, "groupnorm_coef_stats: the statistics cover %d of %d channels",
+               src[0].Cn + (nsrc == 2 ? src[1].Cn : 0), x.C);
+    StatSrcK s0{src[0].p, src[0].Cn, src[0].slots}, s1{nullptr, 0, 0};
+    if (nsrc == 2) s1 = StatSrcK{src[1].p, src[1].Cn, src[1].slots};
+    hipLaunchKernelGGL(k_gn_coef_st, dim3(32, x.N), dim3(256), 0, st, s0, s1, x.H * x.W, x.C, gamma, beta, emb, emb_pitch, cA, cB);
+    return check_launch("k_gn_coef_st");
 }
 
 int linear_small(const float *in, long in_pitch, int B, int K, const float *W, const float *bias, int O, int silu_in,

@@ -132,7 +132,7 @@ class GaussianDiffusion:
         if self.model_mean_type != ModelMeanType.EPSILON:
             raise NotImplementedError("only epsilon prediction (predict_xstart=False) is built")
 
-    def _step(self, mode, x, eps, noise, t, clip, eta=0.0, want_x0=True, trusted=False):
+    def _step(self, mode, x, eps, noise, t, clip, eta=0.0, want_x0=True):
         self._require_eps_model()
         if not x.is_cuda:
             raise RuntimeError("sampling needs CUDA(HIP) tensors; there is no CPU path")
@@ -143,14 +143,6 @@ class GaussianDiffusion:
         x0 = th.empty_like(xf) if want_x0 else None
         B = x.shape[0]
         tt = t.to(device=x.device, dtype=th.int64).contiguous()
-        # the kernel reads row t of the (T,8) table.  The reference's numpy indexing raises IndexError for an out-of-range timestep
-        # (e.g. ORIGINAL-schedule indices handed to a respaced diffusion): direct callers of p_sample / ddim_sample / p_mean_variance
-        # get the same check here (one device read-back); the sampling loops generate their own indices and skip it (`trusted`).
-        # The kernel never reads outside the table either way: it writes NaN for an out-of-range row.
-        if not trusted:
-            lo, hi = int(tt.min()), int(tt.max())
-            if lo < 0 or hi >= self.num_timesteps:
-                raise IndexError(f"timestep {hi if hi >= self.num_timesteps else lo} is out of range for a {self.num_timesteps}-step schedule")
         with _lib.on(x.device):
             _lib.check(_lib.lib().hl_diffusion_step(mode, _lib.ptr(xf), _lib.ptr(ef), _lib.ptr(nf), _lib.ptr(tab), _lib.ptr(tt),
                                                     _lib.ptr(out), _lib.ptr(x0), xf.numel() // B, B, self.num_timesteps,
@@ -192,6 +184,16 @@ class GaussianDiffusion:
         return t.float() * (1000.0 / self.num_timesteps) if self.rescale_timesteps else t
 
     # ---- p(.) ------------------------------------------------------------------------------------------
+    def _check_timesteps(self, t):
+        """Direct callers of p_sample / ddim_sample / p_mean_variance: a timestep outside this (possibly respaced) schedule - e.g. an
+        ORIGINAL-schedule index handed to a respaced diffusion - raises IndexError before anything is launched, like the reference's
+        table lookups (gaussian_diffusion.py:859; on a GPU the reference dies with a device-side assert in respace.py:119 instead).
+        One device read-back; the sampling loops generate their own indices and skip it.  The update kernel never reads outside its
+        table either way (it writes NaN for such a row)."""
+        lo, hi = int(t.min()), int(t.max())
+        if lo < 0 or hi >= self.num_timesteps:
+            raise IndexError(f"timestep {hi if hi >= self.num_timesteps else lo} is out of range for a {self.num_timesteps}-step schedule")
+
     def _model_eps(self, model, x, t, x_cond, model_kwargs):
         B, Cc = x.shape[:2]
         assert t.shape == (B,)
@@ -203,6 +205,7 @@ class GaussianDiffusion:
     def p_mean_variance(self, model, x, t, x_cond=None, clip_denoised=True, denoised_fn=None, model_kwargs=None):
         if denoised_fn is not None:
             raise NotImplementedError("denoised_fn is not built into the fused update")
+        self._check_timesteps(t)
         eps = self._model_eps(model, x, t, x_cond, model_kwargs)
         mean, x0 = self._step(0, x, eps, None, t, clip_denoised)
         var, logvar = self._fixed_variance()
@@ -214,9 +217,11 @@ class GaussianDiffusion:
     def _sample(self, mode, model, x, t, x_cond, clip_denoised, denoised_fn, model_kwargs, eta=0.0, trusted=False):
         if denoised_fn is not None:
             raise NotImplementedError("denoised_fn is not built into the fused update")
+        if not trusted:
+            self._check_timesteps(t)
         eps = self._model_eps(model, x, t, x_cond, model_kwargs)
         noise = th.randn_like(x)  # ddim: drawn even when eta == 0, like the reference (:520)
-        sample, x0 = self._step(mode, x, eps, noise, t, clip_denoised, eta=eta, trusted=trusted)
+        sample, x0 = self._step(mode, x, eps, noise, t, clip_denoised, eta=eta)
         return {"sample": sample, "pred_xstart": x0}
 
     def p_sample(self, model, x, x_cond, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):

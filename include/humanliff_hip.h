@@ -330,6 +330,15 @@ int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w
 int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias,
                         int Cout, int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream);
+/* hl_conv2d_nhwc_mode followed by the GroupNorm32 affine of its OUTPUT (nn.py:17-19,100: y = out*A[n,c] + B[n,c] for the layer
+ * that normalises `out` next): the statistics come from the epilogue of the kernel that stored `out` (per-slot partial sums, folded
+ * in a fixed order) - the tensor is not read again; *h_used_stats returns the slots per image that were emitted, 0 when the kernel
+ * path taken emits none and the statistics were computed from the tensor instead.  scratch as hl_conv2d_nhwc_mode plus
+ * (N*Hout*Wout/32 + 1)*Cout*8 + N*32 KiB bytes. */
+int hl_conv2d_nhwc_gn(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,
+                      int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu, const float *residual,
+                      float *out, const float *gamma, const float *beta, float *next_coefA, float *next_coefB, int *h_used_stats,
+                      void *scratch, size_t scratch_bytes, void *stream);
 int hl_groupnorm_coef(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta,
                       const float *emb /* (N,2C) or NULL */, float *coefA, float *coefB, void *scratch,
                       size_t scratch_bytes, void *stream);

@@ -415,3 +415,62 @@ def test_training_twin_matches_hip_forward_and_trains():
         hip2 = model(x0, t, xc, y=y)
         twin2 = model.forward_autograd(x0, t, xc, y=y)
     assert (hip2 - twin2).abs().max() < 2e-4 * max(1.0, float(twin2.abs().max())) and (hip2 - hip).abs().max() > 1e-4
+
+
+@pytest.mark.parametrize("N,C,H,W,Cout,ks,stride,ups,mode,with_gn,expect_stats", [
+    (2, 64, 256, 128, 192, 3, 1, 0, 0, True, True),     # Winograd after the k_gn_apply pass, residual; slot = (16x8 block, parity)
+    (4, 384, 32, 32, 384, 3, 1, 0, 0, True, True),      # Winograd over 3 input-channel slabs: statistics from k_splitk_finish_st
+    (2, 96, 32, 64, 192, 3, 1, 1, 0, False, True),      # nearest x2 + 3x3 (Upsample) through the Winograd kernel
+    (2, 192, 64, 64, 384, 1, 1, 0, 2, False, True),     # 1x1 skip / zero-conv on the direct kernel: slot = a wave's 32 rows
+    (2, 96, 32, 32, 96, 3, 2, 0, 2, False, True),       # stride 2 (Downsample)
+    (4, 768, 8, 8, 768, 3, 1, 0, 2, True, True),        # 8x8 level: 16 slabs, 64 pixels per image = 2 slots
+    (1, 96, 160, 96, 96, 3, 1, 0, 2, False, True),      # ragged last pixel tile of the 256-row tiling
+    (2, 64, 16, 16, 64, 3, 1, 0, 2, False, True),       # register-staged small-tile kernel over K slabs: statistics from k_splitk_finish_st
+    (2, 96, 12, 12, 96, 3, 1, 0, 2, False, False),      # 144 pixels per image: 32-row slots would straddle images
+])
+def test_conv_epilogue_groupnorm_statistics(N, C, H, W, Cout, ks, stride, ups, mode, with_gn, expect_stats):
+    """The kernel that stores a tensor also emits the GroupNorm statistics the next layer needs (per slot of pixels and channel
+    (sum, sumsq), folded in a fixed order): the affine from them must equal GroupNorm32 of the stored tensor (nn.py:17-19,100)."""
+    from humanliff_amd import _lib
+    L = _lib.lib()
+    if Cout % 32:
+        pytest.skip("GroupNorm32 needs C % 32 == 0")
+    g = torch.Generator().manual_seed(N * 1000 + C + H + Cout)
+    x = torch.randn((N, C, H, W), generator=g) * 1.3 + 0.2
+    w = torch.randn((Cout, C, ks, ks), generator=g) / (C * ks * ks) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    gamma, beta = torch.randn(Cout, generator=g) * 0.2 + 1, torch.randn(Cout, generator=g) * 0.2
+    cA = cB = res = None
+    Hv, Wv = (2 * H, 2 * W) if ups else (H, W)
+    Ho, Wo = (Hv + 2 * (ks // 2) - ks) // stride + 1, (Wv + 2 * (ks // 2) - ks) // stride + 1
+    if with_gn:
+        cA, cB = torch.rand((N, C), generator=g) + 0.5, torch.randn((N, C), generator=g) * 0.3
+        res = torch.randn((N, Cout, Ho, Wo), generator=g)
+    d = lambda t: None if t is None else t.contiguous().to(dev)  # noqa: E731
+    xin, wd, bd, cAd, cBd, gd_, be_ = d(nhwc(x)), d(w), d(b), d(cA), d(cB), d(gamma), d(beta)
+    rd = d(nhwc(res)) if res is not None else None
+    out = torch.empty((N, Ho, Wo, Cout), device=dev)
+    nA, nB = torch.empty((N, Cout), device=dev), torch.empty((N, Cout), device=dev)
+    scratch = torch.empty(((Cout + 63) // 64 * 64) * C * ks * ks * 3 + 256 + (8 << 20) + N * C * H * W + N * Ho * Wo * Cout // 8 + N * 8192,
+                          device=dev)
+    import ctypes
+    used = ctypes.c_int(-1)
+    _lib.check(L.hl_conv2d_nhwc_gn(mode, _lib.ptr(xin), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Cout, ks, stride, ups, _lib.ptr(cAd),
+                                   _lib.ptr(cBd), 1 if with_gn else 0, _lib.ptr(rd), _lib.ptr(out), _lib.ptr(gd_), _lib.ptr(be_),
+                                   _lib.ptr(nA), _lib.ptr(nB), ctypes.byref(used), _lib.ptr(scratch), scratch.numel() * 4,
+                                   _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert (used.value > 0) == expect_stats, used.value
+    # the convolution itself (the statistics ride its epilogue: nothing about the stored values may change)
+    ref = hip_conv(x, w, b, ks, stride, ups, cA=cA, cB=cB, silu=1 if with_gn else 0, res=res, mode=mode)
+    y = nchw(out.cpu())
+    assert torch.equal(y, ref)
+    # GroupNorm32 of the stored tensor, in float64
+    yd = y.double().reshape(N, 32, -1)
+    mean, var = yd.mean(dim=2), yd.var(dim=2, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    cg = Cout // 32
+    wantA = (rstd[:, :, None] * gamma.double().reshape(1, 32, cg)).reshape(N, Cout)
+    wantB = beta.double()[None] - (mean[:, :, None].expand(N, 32, cg).reshape(N, Cout)) * wantA
+    assert (nA.cpu().double() - wantA).abs().max() < 2e-6 * wantA.abs().max()
+    assert (nB.cpu().double() - wantB).abs().max() < 2e-6 * max(1.0, float(wantB.abs().max()))
