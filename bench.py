@@ -147,14 +147,14 @@ def bench_unet(args, rank, world, dev):
         _lib.check(_lib.lib().hl_unet_set_overlap(model._hip[0], 0))
     for _ in range(max(args.warmup - 1, 0)):
         out = next(it)
+    gathered = torch.empty((world * B, 27, 256, 256), device=dev) if world > 1 else None   # rank-major, like the reference's gather
     barrier(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = next(it)
-    if world > 1:   # final gather of the samples (triplane_sample_layered.py:211-212)
+    if world > 1:   # final gather of the samples (triplane_sample_layered.py:211-212): one collective into the preallocated result
         import torch.distributed as dist
-        gathered = [torch.empty_like(out["sample"]) for _ in range(world)]
-        dist.all_gather(gathered, out["sample"])
+        dist.all_gather_into_tensor(gathered, out["sample"].contiguous())
     barrier(world)
     secs = max_over_ranks(time.perf_counter() - t0, world, dev)
     assert torch.isfinite(out["sample"]).all()
@@ -315,14 +315,17 @@ def bench_render(args, rank, world, dev):
         return r.render(tp, None, None, ro[None], rd[None], nr[None], fr[None], planes, N, False, n_samples=N, u=u)
 
     one(views)   # warm-up view (also packs MLP + planes)
+    mine = torch.empty((views, 1, H * W, 3), device=dev)
+    gathered = torch.empty((world * views, 1, H * W, 3), device=dev) if world > 1 else None
     barrier(world)
     t0 = time.perf_counter()
-    imgs = [one(v)["rgb_map"] for v in range(views)]
-    if world > 1:   # north star: RCCL all-gather of the final images
+    imgs = []
+    for v in range(views):
+        mine[v] = one(v)["rgb_map"]
+        imgs.append(mine[v])
+    if world > 1:   # north star: RCCL all-gather of the final images, one collective into the preallocated result
         import torch.distributed as dist
-        mine = torch.stack(imgs)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
+        dist.all_gather_into_tensor(gathered, mine)
     barrier(world)
     secs = max_over_ranks(time.perf_counter() - t0, world, dev)
     assert torch.isfinite(imgs[0]).all()

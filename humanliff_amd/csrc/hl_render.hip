@@ -2229,11 +2229,9 @@ int hl_render_eval(const void *mlp_packed, const void *planes_packed, int H, int
     int rcode = fill_march(a, mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far);
     if (rcode) return rcode;
     a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
-    // (developer switch: 4-wave workgroups, two per CU with independent barriers - measured equal, 74.5 vs 74.7 ms per view, at
-    //  twice the weight traffic, so 8 waves stay the default)
-    static const int nw4 = getenv("HL_MARCH_W4") ? 1 : 0;
-    if (nw4) hipLaunchKernelGGL((k_march<true, true, 4>), dim3((unsigned)((n_rays + 127) / 128)), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_march<true, true, 8>), dim3((unsigned)((n_rays + 255) / 256)), dim3(512), 0, (hipStream_t)stream, a);
+    // (4-wave workgroups, two per CU with independent barriers, measured equal - 74.5 vs 74.7 ms per view - at twice the weight
+    //  traffic: 8 waves it is)
+    hipLaunchKernelGGL((k_march<true, true, 8>), dim3((unsigned)((n_rays + 255) / 256)), dim3(512), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_march<eval>");
 }
 
@@ -2263,8 +2261,7 @@ int hl_render_composite_noise(const float *near, const float *far, const float *
     CompArgs c{near, far, z_vals, z_new, (const float4 *)rec_coarse, (const float4 *)rec_new, n_rays, n_samples, n_importance,
                flags, rgb, acc, depth, noise};
     // fitting batches (training noise given, few rays): one wave per ray
-    static const bool serial = getenv("HL_COMPOSITE_SERIAL") != nullptr;   // developer switch: thread-per-ray kernel
-    if (noise && n_rays <= 65536 && n_samples <= CW_MAX / 2 && n_importance <= CW_MAX / 2 && !serial) {
+    if (noise && n_rays <= 65536 && n_samples <= CW_MAX / 2 && n_importance <= CW_MAX / 2) {
         CompBwdArgs b{};
         b.c = c;
         hipLaunchKernelGGL(k_composite_wave<false>, dim3((unsigned)(tiles32(n_rays) * 8)), dim3(256), 0, (hipStream_t)stream, b);
@@ -2338,8 +2335,7 @@ int hl_render_composite_backward(const float *near, const float *far, const floa
     b.sT = (float *)scratch;
     b.sSrc = (int *)scratch + tiles32(n_rays) * 32 * (size_t)(n_samples + n_importance);
     b.del = del; b.del_stride = del_stride;
-    static const bool serial = getenv("HL_COMPOSITE_SERIAL") != nullptr;   // developer switch: thread-per-ray kernels
-    if (n_samples <= CW_MAX / 2 && n_importance <= CW_MAX / 2 && !serial) {
+    if (n_samples <= CW_MAX / 2 && n_importance <= CW_MAX / 2) {
         hipLaunchKernelGGL(k_composite_wave<true>, dim3((unsigned)(tiles32(n_rays) * 8)), dim3(256), 0, (hipStream_t)stream, b);
         return hl::check_launch("k_composite_wave<bwd>");
     }

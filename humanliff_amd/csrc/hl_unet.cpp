@@ -90,14 +90,18 @@ struct Net {
     std::vector<Span> spans;
     size_t ev_used = 0;
     ~Net() {
-        for (auto e : ev_pool) hipEventDestroy(e);
-        for (auto e : ev_block) hipEventDestroy(e);
+        for (auto e : ev_pool) if (e) hipEventDestroy(e);
+        for (auto e : ev_block) if (e) hipEventDestroy(e);
         if (ev_fork) hipEventDestroy(ev_fork);
         if (ev_join) hipEventDestroy(ev_join);
         if (side) hipStreamDestroy(side);
     }
     size_t next_event() {
-        if (ev_used == ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); ev_pool.push_back(e); }
+        if (ev_used == ev_pool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) { if (err.empty()) err = "hipEventCreate failed (profiling events)"; e = nullptr; }
+            ev_pool.push_back(e);
+        }
         return ev_used++;
     }
 };
@@ -345,13 +349,14 @@ struct Exec {
     size_t span_begin() {
         if (!n.prof) return 0;
         const size_t a = n.next_event();
-        hipEventRecord(n.ev_pool[a], st);
+        if (n.ev_pool[a]) hipEventRecord(n.ev_pool[a], st);
         return a;
     }
     void span_end(int cat, size_t a, double flops, double exec = -1.0) {
         if (!n.prof) return;
+        if (!n.err.empty() && !rc) rc = hl::fail(HL_ERR_RUNTIME, "hl_unet_forward: %s", n.err.c_str());
         const size_t b = n.next_event();
-        hipEventRecord(n.ev_pool[b], st);
+        if (n.ev_pool[b]) hipEventRecord(n.ev_pool[b], st);
         n.spans.push_back({cat, a, b, flops, exec < 0 ? flops : exec});
     }
 
@@ -607,11 +612,16 @@ int hl_unet_create(const hl_unet_cfg *cfg, int n_tensors, const char *const *nam
         return rc;
     }
     if (n->cfg.controlnet) {
-        hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking);
-        hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming);
-        hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming);
-        n->ev_block.resize(n->in_blocks.size());
-        for (auto &e : n->ev_block) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        // side stream + events of the two-tower overlap; any failure just leaves the overlap off (Exec::forward checks n.side)
+        bool okc = hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking) == hipSuccess;
+        okc = okc && hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming) == hipSuccess;
+        okc = okc && hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming) == hipSuccess;
+        n->ev_block.assign(n->in_blocks.size(), nullptr);
+        for (auto &e : n->ev_block) okc = okc && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!okc) {
+            (void)hipGetLastError();
+            if (n->side) { hipStreamDestroy(n->side); n->side = nullptr; }
+        }
     }
     *handle = n;
     return HL_OK;

@@ -3,7 +3,7 @@ pass, counters of scripts/pmc_wino.txt).  usage: python scripts/pmc_sq_summary.p
 Derived columns (per dispatch, then averaged over the dispatches of a shape):
   clock GHz   = GRBM_GUI_ACTIVE / 8 XCDs / duration          (only in passes that carry GRBM_GUI_ACTIVE)
   mfma busy   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)
-  per-wave instruction counts = SQ_INSTS_* / SQ_WAVES
+  per-wave instruction counts = SQ_INSTS_* / (grid threads / 64)
 """
 import collections, csv, glob, re, sys
 
@@ -18,7 +18,8 @@ for d in dirs:
                 continue
             k = disp[r["Dispatch_Id"]]
             k[r["Counter_Name"]] = float(r["Counter_Value"])
-            k["_name"] = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("hl::(anonymous namespace)::", "").replace("hl::", "")
+            k["_name"] = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")).replace("hl::", "")
+            k["_waves"] = int(r["Grid_Size"]) / 64.0
             k["_grid"] = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
             k["_us"] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
         for k in disp.values():
@@ -27,12 +28,14 @@ for d in dirs:
                 if not c.startswith("_"):
                     shape[key][c].append(v)
             shape[key]["_us"].append(k["_us"])
+            shape[key]["_waves"].append(k["_waves"])
             if "GRBM_GUI_ACTIVE" in k:
                 cyc = k["GRBM_GUI_ACTIVE"] / 8
                 shape[key]["clock_ghz"].append(cyc / k["_us"] / 1e3)
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in k:
                     shape[key]["mfma_busy"].append(k["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024))
 mean = lambda v: sum(v) / len(v) if v else float("nan")  # noqa: E731
+ratio = lambda a, b: (mean(a) / mean(b)) if a and b and mean(b) else float("nan")  # noqa: E731
 cols = ["SQ_WAVES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU"]
 lines = ["| kernel | workgroups | launches | avg us | clock GHz | mfma busy | MFMA/wave | VALU/wave | LDS/wave | VMEM rd/wave | SALU/wave | "
          "wait-inst-any / wave-cycles | LDS bank-conflict / LDS active | TA addr FIFO full / busy |", "|" + "---|" * 14]
@@ -40,11 +43,11 @@ for (name, grid), cs in sorted(shape.items(), key=lambda kv: -sum(kv[1]["_us"]))
     tot_us = sum(cs["_us"]) / max(1, len(dirs))
     if tot_us < 500:
         continue
-    w = mean(cs["SQ_WAVES"]) if cs["SQ_WAVES"] else float("nan")
-    per = [mean(cs[c]) / w if cs[c] else float("nan") for c in cols[1:]]
-    wait = mean(cs["SQ_WAIT_INST_ANY"]) / mean(cs["SQ_WAVE_CYCLES"]) if cs["SQ_WAIT_INST_ANY"] and cs["SQ_WAVE_CYCLES"] else float("nan")
-    bank = mean(cs["SQ_LDS_BANK_CONFLICT"]) / mean(cs["SQ_LDS_IDX_ACTIVE"]) if cs["SQ_LDS_BANK_CONFLICT"] and cs["SQ_LDS_IDX_ACTIVE"] else float("nan")
-    ta = mean(cs["SQ_VMEM_TA_ADDR_FIFO_FULL"]) / mean(cs["SQ_BUSY_CYCLES"]) if cs["SQ_VMEM_TA_ADDR_FIFO_FULL"] and cs["SQ_BUSY_CYCLES"] else float("nan")
+    w = mean(cs["_waves"])
+    per = [mean(cs[c]) / w if cs[c] and w else float("nan") for c in cols[1:]]
+    wait = ratio(cs["SQ_WAIT_INST_ANY"], cs["SQ_WAVE_CYCLES"])
+    bank = ratio(cs["SQ_LDS_BANK_CONFLICT"], cs["SQ_LDS_IDX_ACTIVE"])
+    ta = ratio(cs["SQ_VMEM_TA_ADDR_FIFO_FULL"], cs["SQ_BUSY_CYCLES"])
     lines.append(f"| `{name}` | {grid} | {len(cs['_us']) // max(1, len(dirs))} | {mean(cs['_us']):.1f} | {mean(cs['clock_ghz']):.3f} | {mean(cs['mfma_busy']):.3f} | "
                  + " | ".join(f"{v:.0f}" for v in per) + f" | {wait:.3f} | {bank:.3f} | {ta:.3f} |")
 open(out, "w").write("\n".join(lines) + "\n")

@@ -8,4 +8,4 @@ while read -r line; do
   rocprofv3 --kernel-trace --pmc ${line#pmc: } --output-format csv -d $O/p$i -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bf16x3-leg --no-overlap --no-render --no-fit --no-parity --sustained-steps 0 > $O/p$i.log 2>&1
 done < scripts/pmc_wino.txt
 python scripts/pmc_sq_summary.py $O/summary.md $O/p1 $O/p2 $O/p3
-rm -rf $O/p1 $O/p2 $O/p3
+python scripts/pmc_report.py $O/p2 "k_conv_wino<false>" | head -40 > $O/raw_p2.txt; rm -rf $O/p1 $O/p2 $O/p3

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--batch", type=int, default=4, help="subjects sampled together on one GPU")
+    ap.add_argument("--float-images", action="store_true", help="gather fp32 images instead of uint8")
     args = ap.parse_args()
     rank, world, dev = hd.init_distributed()
     cfg = dict(bench.F4, timestep_respacing=f"ddim{args.ddim}")
@@ -46,28 +47,28 @@ def main():
         return diffusion.ddim_sample_loop(model, (len(ids),) + shape, x_cond=x_cond, noise=noise, clip_denoised=True,
                                           model_kwargs={"y": y}, device=dev)
 
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    samples = hd.sample_layered_sharded(sample_fn, args.subjects, args.layers, shape, args.batch, dev)
-    torch.cuda.synchronize(); t1 = time.perf_counter()
     tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].to(dev)}
-    idx, _ = hd.shard_indices(args.subjects)
     H = W = args.res
-    imgs = torch.empty((len(idx), args.views, H, W, 3), device=dev)
-    for k, sidx in enumerate(idx):
-        planes = samples[sidx, -1].clamp(-1, 1).reshape(1, 3, 9, 256, 256)
-        for v in range(args.views):
-            K, c2w, cam = syn.orbit_camera(v, args.views, H, W)
-            R = c2w.T.copy(); T = (-R @ cam).reshape(3, 1)
-            imgs[k, v] = render_view(H, W, K, R, T, planes, tp, r, n_samples=128, n_importance=128)[0]
-    images = hd.gather_shards(imgs, args.subjects)
+
+    def render_fn(sid, sample, v):
+        planes = sample.clamp(-1, 1).reshape(1, 3, 9, 256, 256)                   # triplane_sample_layered.py:158
+        K, c2w, cam = syn.orbit_camera(v, args.views, H, W)
+        R = c2w.T.copy(); T = (-R @ cam).reshape(3, 1)
+        return render_view(H, W, K, R, T, planes, tp, r, n_samples=128, n_importance=128)[0]
+
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    # sampling, rendering and the gathers (samples: one all-gather; images: per subject, uint8, asynchronous behind the next
+    # subject's renders) - humanliff_amd.distributed.sample_and_render, the same code the world-size-2 CPU test drives
+    samples, images = hd.sample_and_render(sample_fn, render_fn, args.subjects, args.layers, shape, args.batch, args.views, (H, W, 3), dev,
+                                           as_uint8=not args.float_images)
     torch.cuda.synchronize(); t2 = time.perf_counter()
+    t1 = t0
     if rank == 0:
         steps = args.subjects * args.layers * args.ddim
         rays = args.subjects * args.views * H * W
-        print(f"ranks {world}: sampled {args.subjects} subjects x {args.layers} layers x DDIM-{args.ddim} in {t1 - t0:.2f} s "
-              f"({steps / (t1 - t0):.1f} denoise-steps/s); rendered {args.subjects * args.views} views {H}x{W} in {t2 - t1:.2f} s "
-              f"({rays / (t2 - t1) / 1e6:.2f} Mrays/s); samples {tuple(samples.shape)} images {tuple(images.shape)} "
-              f"finite {bool(torch.isfinite(images).all())} mean {float(images.mean()):.4f}")
+        print(f"ranks {world}: {args.subjects} subjects x {args.layers} layers x DDIM-{args.ddim} ({steps} denoise steps) + "
+              f"{args.subjects * args.views} views {H}x{W} ({rays / 1e6:.1f} Mrays) + gathers in {t2 - t0:.2f} s; "
+              f"samples {tuple(samples.shape)} images {tuple(images.shape)} {images.dtype} mean {float(images.float().mean()):.4f}")
 
 
 if __name__ == "__main__":

@@ -43,13 +43,37 @@ def _worker(rank, world, port, q):
             x = x * 2 + s + k
             want[s, k] = x
     ok2 = torch.equal(out, want)
-    ok3 = all(i % world == rank for _, ids in calls for i in ids)      # subject s stays on rank s mod world
+    per = (6 + world - 1) // world
+    ok3 = all(i // per == rank for _, ids in calls for i in ids)       # a subject's layers all run on the rank that owns its block
     # 3) view sharding
     imgs = hd.render_views_sharded(lambda v: torch.full((3, 2, 2), float(v)), 7, (3, 2, 2), dev)
     ok4 = torch.equal(imgs[:, 0, 0, 0], torch.arange(7, dtype=torch.float32))
+    # 4) uint8 image gather into a preallocated buffer (truncation like the reference's (clip*255).astype(uint8))
+    buf = torch.empty((2 * ((7 + 1) // 2), 2, 2), dtype=torch.uint8)
+    idx7, _ = hd.shard_indices(7)
+    loc = torch.stack([torch.full((2, 2), v / 10.0 + 0.0039) for v in idx7])
+    g8 = hd.gather_shards(loc, 7, as_uint8=True, out=buf)
+    ok5 = g8.dtype == torch.uint8 and g8.data_ptr() == buf.data_ptr() and \
+        torch.equal(g8[:, 0, 0], torch.tensor([int((v / 10.0 + 0.0039) * 255.0) for v in range(7)], dtype=torch.uint8))
+    # 5) the end-to-end flow of scripts/sample_and_render.py (sampling -> per-subject renders -> asynchronous per-subject gathers),
+    #    with the HIP network / renderer replaced by arithmetic stand-ins: 5 subjects (ragged), 2 layers, 3 views
+    rendered = []
+
+    def render_fn(sid, sample, v):
+        rendered.append((sid, v))
+        return (sample[:1, :2, :2].permute(1, 2, 0).expand(2, 2, 3) * 0 + (sid * 10 + v) / 100.0).contiguous()
+
+    smp, img = hd.sample_and_render(sample_fn, render_fn, 5, 2, (2, 4, 4), 2, 3, (2, 2, 3), dev, as_uint8=True)
+    want_img = torch.tensor([[int(((s * 10 + v) / 100.0) * 255.0) for v in range(3)] for s in range(5)], dtype=torch.uint8)
+    ok6 = tuple(smp.shape) == (5, 2, 2, 4, 4) and tuple(img.shape) == (5, 3, 2, 2, 3) and img.dtype == torch.uint8 and \
+        torch.equal(img[:, :, 0, 0, 0], want_img) and torch.equal(smp, want[:5, :2])
+    per5 = (5 + world - 1) // world
+    ok7 = all(min(s, 4) // per5 == rank for s, _ in rendered)          # every rank renders only the subjects it sampled
+    smp_f, img_f = hd.sample_and_render(sample_fn, render_fn, 5, 2, (2, 4, 4), 2, 3, (2, 2, 3), dev, as_uint8=False)
+    ok8 = img_f.dtype == torch.float32 and torch.allclose(img_f[:, :, 0, 0, 0], torch.tensor([[(s * 10 + v) / 100.0 for v in range(3)] for s in range(5)]))
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, ok1, ok2, ok3, ok4))
+    q.put((rank, ok1, ok2, ok3, ok4, ok5, ok6, ok7, ok8))
 
 
 @pytest.mark.timeout(120)
@@ -73,6 +97,11 @@ def test_single_process_paths():
     idx, valid = hd.shard_indices(3, rank=0, world=1)
     assert idx == [0, 1, 2] and all(valid)
     idx, valid = hd.shard_indices(5, rank=1, world=2)
-    assert idx == [1, 3, 4] and valid == [True, True, False]
+    assert idx == [3, 4, 4] and valid == [True, True, False]          # contiguous blocks, the tail slot repeats the last item
+    assert hd.shard_indices(5, rank=0, world=2)[0] == [0, 1, 2]
+    g = hd.ImageGather(3, (2,), torch.float32, torch.device("cpu"))
+    for k in range(3):
+        g.put(k, torch.tensor([k, k + 0.5]))
+    assert torch.equal(g.result(), torch.tensor([[0, 0.5], [1, 1.5], [2, 2.5]]))
     t = torch.arange(6.).reshape(3, 2)
     assert torch.equal(hd.gather_shards(t, 3), t)
