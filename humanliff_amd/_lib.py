@@ -94,6 +94,12 @@ SIGNATURES = {
     "hl_conv2d_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
     "hl_conv2d_nhwc_mode": (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
     "hl_conv2d_nhwc_gn": (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, C.POINTER(C.c_int), _p, _sz, _p]),
+    "hl_conv2d_wgrad_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p]),
+    "hl_gn_apply_nhwc": (_i, [_p, _i64, _i, _i, _i, _p, _p, _i, _p, _p]),
+    "hl_gn_backward_reduce": (_i, [_p, _i64, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
+    "hl_gn_backward_apply": (_i, [_p, _i64, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "hl_upsample2_backward_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "hl_zero_stuff2_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "hl_groupnorm_coef": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "hl_attention_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "hl_timestep_embedding": (_i, [_p, _p, _i, _i, _p, _p]),

@@ -71,6 +71,10 @@ int groupnorm_coef_stats(const View &x, const StatSrc *src, int nsrc, const floa
 int groupnorm_coef(const View &x, const float *gamma, const float *beta, const float *emb, long emb_pitch, float *coefA,
                    float *coefB, float *scratch, hipStream_t st);
 
+// y (dense NHWC) = act ? silu(x*A + B) : x*A + B with the per-(n,c) affine of groupnorm_coef (the pre-pass of the DMA convs; the
+// GroupNorm forward of the training path)
+int gn_apply(const View &x, const float *coefA, const float *coefB, int act, float *y, hipStream_t st);
+
 // out[b][o] = bias[o] + sum_k act(in[b][k]) * W[o][k] (+ addrow[idx[b]][o]);  B <= 8
 int linear_small(const float *in, long in_pitch, int B, int K, const float *W, const float *bias, int O, int silu_in,
                  const float *addrow, const int64_t *idx, float *out, long out_pitch, hipStream_t st);

@@ -2160,6 +2160,14 @@ int groupnorm_coef(const View &x, const float *gamma, const float *beta, const f
     return check_launch("k_gn_coef");
 }
 
+int gn_apply(const View &x, const float *cA, const float *cB, int act, float *y, hipStream_t st) {
+    const long npix = x.pixels();
+    long g = (npix * (x.C / 4) + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, x.p, x.pitch, (long)x.H * x.W, npix, x.C, cA, cB, act, y);
+    return check_launch("k_gn_apply");
+}
+
 int groupnorm_coef_stats(const View &x, const StatSrc *src, int nsrc, const float *gamma, const float *beta, const float *emb,
                          long emb_pitch, float *cA, float *cB, hipStream_t st) {
     HL_REQUIRE(src && (nsrc == 1 || nsrc == 2) && gamma && beta && cA && cB, "groupnorm_coef_stats: bad argument");

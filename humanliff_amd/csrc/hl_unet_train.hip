@@ -1,0 +1,305 @@
+// Backward kernels of the tri-plane UNet (UNet half), MI355X (gfx950), fp32.
+//
+// What the reference trains with: GaussianDiffusion.training_losses (gaussian_diffusion.py:688-772) -> MSE on the network output ->
+// loss.backward() through UNetModel.forward (unet.py:550-615), driven by TrainLoop.forward_backward (train_util.py:200-285).  Autograd
+// of the stock ops is replaced, op by op (humanliff_amd/improved_diffusion/unet_train.py holds the autograd.Functions), by
+//   conv forward / backward-data   the FORWARD conv kernels of hl_unet_kernels.hip: backward-data of a 3x3 / 1x1 convolution is the
+//                                  same convolution of the output gradient with the flipped, channel-transposed weights
+//   k_conv_wgrad                   backward-weights + bias:  dW[co][ci][ky][kx] = sum_p dY[p][co] * X[p*stride + (ky,kx) - pad][ci]
+//                                  as a GEMM over the pixels on v_mfma_f32_32x32x2_f32
+//   k_gn_apply (hl_unet_kernels)   GroupNorm32 (+scale/shift) (+SiLU) apply, nn.py:100, unet.py:198-219
+//   k_gn_bwd_reduce / _apply       its backward: per-(n,c) reductions, then dx = k1*du + k2*x + k3
+// fp32 atomics accumulate the K-split partial sums (weight gradients, GroupNorm reductions): a training step is not bit-reproducible
+// run to run, like the reference's cuDNN backward.
+#include "hl_unet_kernels.h"
+
+namespace hl {
+namespace {
+
+__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v)); }
+
+// ---------------------------------------------------------------------------------------------
+// backward-weights
+// ---------------------------------------------------------------------------------------------
+// GEMM view: M = output channels, N = input channels (of one tap), K = output pixels.  NHWC makes BOTH operands MFMA-ready straight
+// from memory: v_mfma_f32_32x32x2_f32 wants A[m][k] in lane (m, k) and B[k][n] in lane (n, k) - lane (l & 31, l >> 5) reads channel
+// l & 31 of pixel 2q + (l >> 5): 32 consecutive floats per pixel.  One 8-byte load per lane serves two channel tiles (row m of tile r
+// is channel c0 + 2m + r - any assignment of channels to rows works as long as the store undoes it), so a k-step of two pixels costs a
+// wave 2 x 512 B of loads for 4 MFMAs (a 64 x 64 block of dW for one tap).
+// Grid: x = (co block, ci block, tap), y = pixel slab; the 4 waves of a workgroup interleave the pixel pairs of the slab and add their
+// blocks to dW with float atomics (dW zeroed by the caller).  Zero padding / the nearest-x2 upsample / stride 2 are per-lane source
+// offsets; lanes outside the image or the tensor read zeros through the buffer descriptor's range check.
+struct WgradK {
+    const float *x; long x_pitch; int N, Hin, Win, Cx;        // conv input (NHWC, Cx channels present, Cx even)
+    const float *dy; long dy_pitch; int Hout, Wout, Cy;       // output gradient (NHWC, Cy channels present, Cy even)
+    int ks, stride, ups;
+    float *dw; int Cout_w, Cin_w;                              // dW (Cout_w, Cin_w, ks, ks) - the reference's OIHW parameter layout
+    float *db;                                                 // (Cout_w) or null
+    int n_co, n_ci; long P, slab;                              // blocks of 64 channels; output pixels; pixels per (workgroup) slab
+};
+
+__global__ __launch_bounds__(256) void k_conv_wgrad(const WgradK p) {
+    constexpr unsigned OOB = 0x80000000u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, m = lane & 31;
+    const int taps = p.ks * p.ks;
+    int bi = blockIdx.x;
+    const int tap = bi % taps; bi /= taps;
+    const int cib = bi % p.n_ci, cob = bi / p.n_ci;
+    const int co0 = cob * 64, ci0 = cib * 64;
+    const int ky = p.ks == 3 ? tap / 3 : 0, kx = p.ks == 3 ? tap - ky * 3 : 0, pad = p.ks >> 1;
+    const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)p.dy, (short)0, (int)(p.P * p.dy_pitch * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.x, (short)0, (int)((long)p.N * p.Hin * p.Win * p.x_pitch * 4), 0x00020000);
+    const bool a_ok = co0 + 2 * m < p.Cy, b_ok = ci0 + 2 * m < p.Cx;          // (channel counts are even: the pair is in or out together)
+    const long s0 = (long)blockIdx.y * p.slab, s1 = min(p.P, s0 + p.slab);
+    // this lane's first output pixel and its (n, y, x)
+    long pix = s0 + 2 * wave + kh;
+    const int hw = p.Hout * p.Wout;
+    int n = (int)(pix / hw), rem = (int)(pix - (long)n * hw);
+    int yo = rem / p.Wout, xo = rem - yo * p.Wout;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bs0 = 0.f, bs1 = 0.f;
+    const bool want_b = p.db != nullptr && tap == 0 && cib == 0;
+    auto offs = [&](unsigned &oa, unsigned &ob) {
+        const bool in = pix < s1;
+        const int yi = yo * p.stride + ky - pad, xi = xo * p.stride + kx - pad;
+        const bool v = in && yi >= 0 && yi < Hv && xi >= 0 && xi < Wv;
+        const int ys = p.ups ? yi >> 1 : yi, xs = p.ups ? xi >> 1 : xi;
+        oa = (in && a_ok) ? (unsigned)((pix * p.dy_pitch + co0 + 2 * m) * 4) : OOB;
+        ob = (v && b_ok) ? (unsigned)((((long)n * p.Hin + ys) * p.Win + xs) * p.x_pitch + ci0 + 2 * m) * 4u : OOB;
+    };
+    auto advance = [&]() {   // the wave's next pixel pair is 8 pixels on
+        pix += 8;
+        xo += 8;
+        while (xo >= p.Wout) { xo -= p.Wout; if (++yo == p.Hout) { yo = 0; ++n; } }
+    };
+    const long npairs = (s1 - s0 + 1) / 2;                      // pixel pairs of the slab; this wave takes pairs wave, wave+4, ...
+    const long mine = npairs > wave ? (npairs - wave + 3) / 4 : 0;
+    for (long it = 0; it < mine; it += 4) {                     // four k-steps of loads in flight
+        float2 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned oa, ob;
+            offs(oa, ob);
+            if (it + u >= mine) { oa = OOB; ob = OOB; }
+            a[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsY, oa, 0, 0));
+            b[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsX, ob, 0, 0));
+            advance();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc[1][1], 0, 0, 0);
+            bs0 += a[u].x; bs1 += a[u].y;
+        }
+    }
+    // dW[co][ci][ky][kx]: accumulator r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
+    const int ci = ci0 + 2 * m;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int co = co0 + 2 * row + i, cc = ci + j;
+                if (co < p.Cout_w && cc < p.Cin_w) atomicAdd(p.dw + ((long)co * p.Cin_w + cc) * taps + tap, acc[i][j][r]);
+            }
+    if (want_b) {
+        bs0 += __shfl_xor(bs0, 32);
+        bs1 += __shfl_xor(bs1, 32);
+        if (kh == 0) {
+            if (co0 + 2 * m < p.Cout_w) atomicAdd(p.db + co0 + 2 * m, bs0);
+            if (co0 + 2 * m + 1 < p.Cout_w) atomicAdd(p.db + co0 + 2 * m + 1, bs1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm (+SiLU) backward
+// ---------------------------------------------------------------------------------------------
+// forward: u = A[n,c] * x + B[n,c]  (A, B fold GroupNorm32 statistics, affine and the ResBlock's scale / shift), out = act ? silu(u) : u.
+// With du = dout * (act ? silu'(u) : 1) the two reductions everything else follows from are, per (n, c):
+//     S1 = sum_p du,    S2 = sum_p du * x
+// (parameter gradients, the scale / shift gradients and the three per-(n,c) coefficients of dx = k1*du + k2*x + k3 are small (N,C)
+// tensor algebra done by the caller).  grid (chunks, N); a thread owns a float4 of channels; float atomics into S (N, C, 2), zeroed.
+__global__ void k_gn_bwd_reduce(const float *__restrict__ x, long x_pitch, const float *__restrict__ dout, long d_pitch, int HW, int C,
+                                int nchunks, const float *__restrict__ cA, const float *__restrict__ cB, int act, float *__restrict__ S) {
+    const int cq = C >> 2;
+    const int k = blockDim.x / cq;
+    const int c4 = threadIdx.x % cq, prow = threadIdx.x / cq;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    if (prow >= k) return;
+    const int per = (HW + nchunks - 1) / nchunks;
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(cA + (long)n * C + c4 * 4), b = *reinterpret_cast<const f32x4 *>(cB + (long)n * C + c4 * 4);
+    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pp = p0 + prow; pp < p1; pp += k) {
+        const long pix = (long)n * HW + pp;
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + pix * x_pitch + c4 * 4);
+        f32x4 dv = *reinterpret_cast<const f32x4 *>(dout + pix * d_pitch + c4 * 4);
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float u = a[i] * xv[i] + b[i], sg = sigmoid_f(u);
+                dv[i] *= sg * (1.f + u * (1.f - sg));
+            }
+        }
+        s1 += dv;
+        s2 += dv * xv;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        atomicAdd(S + ((long)n * C + c4 * 4 + i) * 2, s1[i]);
+        atomicAdd(S + ((long)n * C + c4 * 4 + i) * 2 + 1, s2[i]);
+    }
+}
+
+// dx = k1[n,c] * du + k2[n,c] * x + k3[n,c]  (+ dx_add: the gradient arriving over the residual branch), du as above
+__global__ void k_gn_bwd_apply(const float *__restrict__ x, long x_pitch, const float *__restrict__ dout, long d_pitch, long pixels_per_img,
+                               long npix, int C, const float *__restrict__ cA, const float *__restrict__ cB, int act,
+                               const float *__restrict__ k1, const float *__restrict__ k2, const float *__restrict__ k3,
+                               const float *__restrict__ dx_add, long add_pitch, float *__restrict__ dx, long dx_pitch) {
+    const int cq = C >> 2;
+    const long n4 = npix * cq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cq;
+        const int c = (int)(i - pix * cq) * 4;
+        const long n = pix / pixels_per_img;
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + pix * x_pitch + c);
+        f32x4 dv = *reinterpret_cast<const f32x4 *>(dout + pix * d_pitch + c);
+        if (act) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(cA + n * C + c), b = *reinterpret_cast<const f32x4 *>(cB + n * C + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u = a[j] * xv[j] + b[j], sg = sigmoid_f(u);
+                dv[j] *= sg * (1.f + u * (1.f - sg));
+            }
+        }
+        const f32x4 q1 = *reinterpret_cast<const f32x4 *>(k1 + n * C + c), q2 = *reinterpret_cast<const f32x4 *>(k2 + n * C + c),
+                    q3 = *reinterpret_cast<const f32x4 *>(k3 + n * C + c);
+        f32x4 o = q1 * dv + q2 * xv + q3;
+        if (dx_add) o += *reinterpret_cast<const f32x4 *>(dx_add + pix * add_pitch + c);
+        *reinterpret_cast<f32x4 *>(dx + pix * dx_pitch + c) = o;
+    }
+}
+
+// nearest x2 upsample backward (unet.py:77): dx[n, y, x, c] = sum of the 2x2 block of d(upsampled)
+__global__ void k_upsample2_bwd(const float *__restrict__ du, int N, int H, int W, int C, float *__restrict__ dx) {
+    const int cq = C >> 2;
+    const long n4 = (long)N * H * W * cq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cq;
+        const int c = (int)(i - pix * cq) * 4;
+        const int x = (int)(pix % W);
+        const long t = pix / W;
+        const int y = (int)(t % H);
+        const long n = t / H;
+        const float *q = du + (((n * 2 * H + 2 * y) * 2 * W) + 2 * x) * (long)C + c;
+        const f32x4 s = (*reinterpret_cast<const f32x4 *>(q) + *reinterpret_cast<const f32x4 *>(q + C)) +
+                        (*reinterpret_cast<const f32x4 *>(q + 2L * W * C) + *reinterpret_cast<const f32x4 *>(q + 2L * W * C + C));
+        *reinterpret_cast<f32x4 *>(dx + pix * C + c) = s;
+    }
+}
+
+// stride-2 convolution backward-data helper: z (N, 2Ho, 2Wo, C) with z[2y][2x] = dy[y][x], zeros elsewhere (then a flipped 3x3 conv of z)
+__global__ void k_zero_stuff2(const float *__restrict__ dy, int N, int Ho, int Wo, int C, float *__restrict__ z) {
+    const int cq = C >> 2;
+    const long n4 = (long)N * 2 * Ho * 2 * Wo * cq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cq;
+        const int c = (int)(i - pix * cq) * 4;
+        const int x = (int)(pix % (2 * Wo));
+        const long t = pix / (2 * Wo);
+        const int y = (int)(t % (2 * Ho));
+        const long n = t / (2 * Ho);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(x & 1) && !(y & 1)) v = *reinterpret_cast<const f32x4 *>(dy + (((n * Ho + (y >> 1)) * Wo) + (x >> 1)) * (long)C + c);
+        *reinterpret_cast<f32x4 *>(z + pix * C + c) = v;
+    }
+}
+
+}  // namespace
+}  // namespace hl
+
+using namespace hl;
+
+extern "C" {
+
+int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
+                         float *dw, int Cout, int Cin, float *db, void *stream) {
+    HL_REQUIRE(x && dy && dw, "hl_conv2d_wgrad_nhwc: null argument");
+    HL_REQUIRE((ks == 1 || ks == 3) && (stride == 1 || (stride == 2 && !upsample)), "hl_conv2d_wgrad_nhwc: kernel size / stride");
+    HL_REQUIRE(Cx % 2 == 0 && Cy % 2 == 0 && Cin <= Cx && Cout <= Cy, "hl_conv2d_wgrad_nhwc: channel counts (x %d, dy %d) must be even and cover the weight (%d, %d)", Cx, Cy, Cout, Cin);
+    const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
+    WgradK p{};
+    p.x = x; p.x_pitch = Cx; p.N = N; p.Hin = H; p.Win = W; p.Cx = Cx;
+    p.dy = dy; p.dy_pitch = Cy; p.Hout = (Hv + 2 * pad - ks) / stride + 1; p.Wout = (Wv + 2 * pad - ks) / stride + 1; p.Cy = Cy;
+    p.ks = ks; p.stride = stride; p.ups = upsample; p.dw = dw; p.Cout_w = Cout; p.Cin_w = Cin; p.db = db;
+    p.n_co = (Cout + 63) / 64; p.n_ci = (Cin + 63) / 64;
+    p.P = (long)N * p.Hout * p.Wout;
+    HL_REQUIRE(p.P * Cy * 4 < (1L << 31) && (long)N * H * W * Cx * 4 < (1L << 31), "hl_conv2d_wgrad_nhwc: tensors of 2 GiB and more are not addressed");
+    const long tiles = (long)p.n_co * p.n_ci * ks * ks;
+    long slabs = (2048 + tiles - 1) / tiles;                     // ~2048 workgroups
+    const long max_slabs = (p.P + 255) / 256;                    // at least 256 pixels (32 pairs per wave) per workgroup
+    if (slabs > max_slabs) slabs = max_slabs;
+    if (slabs < 1) slabs = 1;
+    p.slab = ((p.P + slabs - 1) / slabs + 7) / 8 * 8;            // multiple of 8: the waves' pair interleave starts aligned
+    slabs = (p.P + p.slab - 1) / p.slab;
+    hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)tiles, (unsigned)slabs), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("k_conv_wgrad");
+}
+
+int hl_gn_apply_nhwc(const float *x, long x_pitch, int N, int HW, int C, const float *coefA, const float *coefB, int silu, float *y,
+                     void *stream) {
+    HL_REQUIRE(x && coefA && coefB && y && C % 4 == 0 && x_pitch % 4 == 0, "hl_gn_apply_nhwc: bad argument");
+    View v; v.p = const_cast<float *>(x); v.N = N; v.H = HW; v.W = 1; v.C = C; v.pitch = x_pitch;
+    return gn_apply(v, coefA, coefB, silu, y, (hipStream_t)stream);
+}
+
+int hl_gn_backward_reduce(const float *x, long x_pitch, const float *dout, int N, int HW, int C, const float *coefA, const float *coefB,
+                          int silu, float *S, void *stream) {
+    HL_REQUIRE(x && dout && coefA && coefB && S && C % 4 == 0 && x_pitch % 4 == 0 && C <= 4096, "hl_gn_backward_reduce: bad argument");
+    const int cq = C / 4;
+    int k = 256 / cq; if (k < 1) k = 1;
+    const int threads = cq * k;
+    int chunks = HW / (k * 16); if (chunks < 1) chunks = 1; if (chunks > 256) chunks = 256;
+    hipLaunchKernelGGL(k_gn_bwd_reduce, dim3(chunks, N), dim3(threads), 0, (hipStream_t)stream, x, x_pitch, dout, (long)C, HW, C, chunks, coefA,
+                       coefB, silu, S);
+    return check_launch("k_gn_bwd_reduce");
+}
+
+int hl_gn_backward_apply(const float *x, long x_pitch, const float *dout, int N, int HW, int C, const float *coefA, const float *coefB,
+                         int silu, const float *k1, const float *k2, const float *k3, const float *dx_add, float *dx, void *stream) {
+    HL_REQUIRE(x && dout && coefA && coefB && k1 && k2 && k3 && dx && C % 4 == 0 && x_pitch % 4 == 0, "hl_gn_backward_apply: bad argument");
+    const long npix = (long)N * HW;
+    long g = (npix * (C / 4) + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_gn_bwd_apply, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, x_pitch, dout, (long)C, (long)HW, npix, C, coefA,
+                       coefB, silu, k1, k2, k3, dx_add, (long)C, dx, (long)C);
+    return check_launch("k_gn_bwd_apply");
+}
+
+int hl_upsample2_backward_nhwc(const float *d_up, int N, int H, int W, int C, float *dx, void *stream) {
+    HL_REQUIRE(d_up && dx && C % 4 == 0, "hl_upsample2_backward_nhwc: bad argument");
+    long g = ((long)N * H * W * (C / 4) + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_upsample2_bwd, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, d_up, N, H, W, C, dx);
+    return check_launch("k_upsample2_bwd");
+}
+
+int hl_zero_stuff2_nhwc(const float *dy, int N, int Ho, int Wo, int C, float *z, void *stream) {
+    HL_REQUIRE(dy && z && C % 4 == 0, "hl_zero_stuff2_nhwc: bad argument");
+    long g = ((long)N * 4 * Ho * Wo * (C / 4) + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_zero_stuff2, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dy, N, Ho, Wo, C, z);
+    return check_launch("k_zero_stuff2");
+}
+
+}  // extern "C"

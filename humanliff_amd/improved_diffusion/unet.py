@@ -5,8 +5,8 @@ The torch modules declared here only own the parameters (so reference checkpoint
 load_state_dict and .to(device) works).  forward() hands the parameter pointers to the C ABI
 (hl_unet_create / hl_unet_forward); there is no PyTorch implementation of the math and no CPU path.
 Supported configuration: dims=2, use_scale_shift_norm=True, cond_type in {"controlnet", ""},
-use_3d_aware=False.  forward() is inference (no autograd through the HIP kernels); forward_autograd() is the training-only
-PyTorch-op twin that training_losses uses (unet_autograd.py).
+use_3d_aware=False.  Under no_grad / eval() forward() is the fused inference path; with gradients enabled on a model in training
+mode it is the differentiable path of unet_train.py (HIP forward and backward kernels behind autograd.Functions).
 """
 import ctypes as C
 
@@ -248,8 +248,9 @@ class UNetModel(nn.Module):
         return any(p.requires_grad for p in self.parameters())
 
     def forward_autograd(self, x, timesteps, x_cond=None, y=None):
-        """Training only: the same function in PyTorch ops, differentiable (unet_autograd.py).  GaussianDiffusion.training_losses
-        calls this when gradients are enabled; the samplers never do."""
+        """The same function in plain PyTorch ops, differentiable (unet_autograd.py): the CPU-checkable statement of the network that
+        the gradient tests compare with the reference's vectors and with the HIP training path.  Nothing in the product calls it:
+        training goes through forward() -> unet_train.forward_train (HIP forward and backward), sampling through the HIP forward."""
         from .unet_autograd import forward_autograd
         return forward_autograd(self, x, timesteps, x_cond, y)
 
@@ -262,9 +263,11 @@ class UNetModel(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("UNetModel.forward needs CUDA(HIP) tensors; there is no CPU path")
         if th.is_grad_enabled() and self.training and (x.requires_grad or self._any_param_requires_grad()):
-            # training call (train_util.py:236 reaches this through the DDP wrapper): gradients are wanted, take the differentiable path.
+            # training call (train_util.py:236 reaches this through the DDP wrapper): gradients are wanted, take the differentiable path -
+            # the same network as a chain of autograd.Functions whose forward and backward are HIP kernels (unet_train.py).
             # Sampling never gets here: the loops run under no_grad and the scripts call model.eval()
-            return self.forward_autograd(x, timesteps, x_cond, y)
+            from .unet_train import forward_train
+            return forward_train(self, x, timesteps, x_cond, y)
         handle = self._bind()
         L = _lib.lib()
         B, Cc, H, W = x.shape

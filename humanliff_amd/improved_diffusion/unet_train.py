@@ -1,0 +1,286 @@
+"""Differentiable UNetModel.forward on the HIP kernels - the training path (UNet half).
+
+What the reference trains with: GaussianDiffusion.training_losses (gaussian_diffusion.py:688-772) -> mse -> loss.backward() through
+UNetModel.forward (unet.py:550-615), called by TrainLoop.forward_backward through the DDP wrapper (train_util.py:200-285).  Here the
+same function is a chain of torch.autograd.Functions whose forward AND backward are the library's kernels (C ABI of
+include/humanliff_hip.h), activations NHWC fp32:
+
+    _Conv          forward   hl_conv2d_nhwc_mode (Winograd / direct fp32 MFMA kernels of the inference path)
+                   d input   the same forward kernels on the output gradient with flipped, channel-transposed weights
+                             (stride 2: hl_zero_stuff2_nhwc first; nearest-x2 upsample: hl_upsample2_backward_nhwc afterwards)
+                   d weight  hl_conv2d_wgrad_nhwc (pixels-as-K MFMA GEMM), bias gradient in the same launch
+    _GroupNormAct  forward   hl_groupnorm_coef (statistics) + hl_gn_apply_nhwc (affine, scale/shift, SiLU)
+                   backward  hl_gn_backward_reduce + hl_gn_backward_apply; parameter / scale-shift gradients from the (N,C) reductions
+    _Attention     forward   hl_attention_nhwc (fp32 flash-style kernel)
+                   backward  recomputed probabilities, five batched GEMMs through torch.bmm (rocBLAS - a plain library GEMM; 2 % of the
+                             network's FLOPs)
+The (N, 768)-sized embedding MLP (time_embed, label_emb, the ResBlocks' emb_layers: 0.004 % of the FLOPs), residual adds and channel
+concatenations are torch tensor ops.  No convolution, normalisation or attention runs through MIOpen / torch.nn.functional.
+
+UNetModel.forward takes this path when gradients are enabled on a model in training mode (unet.py); the samplers (no_grad, eval) never
+do.  The PyTorch-op twin (unet_autograd.py) remains as the CPU-checkable statement of the same function that the gradient tests compare
+both against the reference's vectors.
+"""
+import ctypes as C
+import math
+
+import torch as th
+import torch.nn.functional as F
+
+from .. import _lib
+from . import unet as U
+
+_MODE = _lib.HL_CONV_FP32
+
+
+def _conv_raw(x, w, b, ks, stride=1, ups=0):
+    """x (N,H,W,Cx) NHWC dense, Cx % 16 == 0; w (Cout, Cx, ks, ks) contiguous; -> (N,Ho,Wo,Cout)."""
+    L = _lib.lib()
+    N, H, W, Cx = x.shape
+    Cout = w.shape[0]
+    assert w.shape[1] == Cx and Cx % 16 == 0, (tuple(w.shape), Cx)
+    Hv, Wv = (2 * H, 2 * W) if ups else (H, W)
+    Ho, Wo = (Hv + 2 * (ks // 2) - ks) // stride + 1, (Wv + 2 * (ks // 2) - ks) // stride + 1
+    out = th.empty((N, Ho, Wo, Cout), device=x.device, dtype=th.float32)
+    rows = (Cout + 63) // 64 * 64
+    scratch = th.empty(rows * Cx * ks * ks * 3 + 256 + (16 << 20) + N * Cx * H * W, device=x.device, dtype=th.float32)
+    with _lib.on(x.device):
+        _lib.check(L.hl_conv2d_nhwc_mode(_MODE, _lib.ptr(x), N, H, W, Cx, _lib.ptr(w), _lib.ptr(b), Cout, ks, stride, ups, None, None, 0,
+                                         None, _lib.ptr(out), _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()), "hl_conv2d_nhwc_mode")
+    return out
+
+
+def _pad_c(x, mult):
+    c = x.shape[-1]
+    return x if c % mult == 0 else F.pad(x, (0, mult - c % mult))
+
+
+class _Conv(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, ups):
+        w4 = w.unsqueeze(-1) if w.dim() == 3 else w              # Conv1d k=1 (attention qkv / proj_out) is a 1x1 conv
+        ks = w4.shape[2]
+        Cin = w4.shape[1]
+        wp = w4 if x.shape[-1] == Cin else F.pad(w4, (0, 0, 0, 0, 0, x.shape[-1] - Cin))    # zero weights for the padded input channels
+        y = _conv_raw(x, wp.contiguous(), b, ks, stride, ups)
+        ctx.save_for_backward(x, w4)
+        ctx.meta = (ks, stride, ups, w.shape, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w4 = ctx.saved_tensors
+        ks, stride, ups, wshape, has_b = ctx.meta
+        L = _lib.lib()
+        dy = dy.contiguous()
+        N, Ho, Wo, Cout = dy.shape
+        Cin = w4.shape[1]
+        dyp = _pad_c(dy, 16)                                      # (the 27-channel output conv: pad the gradient's channels with zeros)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # backward-data = forward conv of dy with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]
+            wt = w4.flip(2, 3).transpose(0, 1)
+            wt = F.pad(wt, (0, 0, 0, 0, 0, dyp.shape[-1] - Cout)).contiguous()
+            Cxp = x.shape[-1]
+            if Cxp != Cin:                                         # input was channel-padded (27 -> 32): zero rows for the pad
+                wt = F.pad(wt, (0, 0, 0, 0, 0, 0, 0, Cxp - Cin)).contiguous()
+            if stride == 2:
+                z = th.empty((N, 2 * Ho, 2 * Wo, dyp.shape[-1]), device=dy.device, dtype=th.float32)
+                with _lib.on(dy.device):
+                    _lib.check(L.hl_zero_stuff2_nhwc(_lib.ptr(dyp), N, Ho, Wo, dyp.shape[-1], _lib.ptr(z), _lib.stream_ptr()), "hl_zero_stuff2_nhwc")
+                dx = _conv_raw(z, wt, None, ks, 1, 0)
+            elif ups:
+                du = _conv_raw(dyp, wt, None, ks, 1, 0)           # gradient of the upsampled image (2H, 2W)
+                dx = th.empty_like(x)
+                with _lib.on(dy.device):
+                    _lib.check(L.hl_upsample2_backward_nhwc(_lib.ptr(du), N, x.shape[1], x.shape[2], x.shape[3], _lib.ptr(dx), _lib.stream_ptr()),
+                               "hl_upsample2_backward_nhwc")
+            else:
+                dx = _conv_raw(dyp, wt, None, ks, 1, 0)
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            dw = th.zeros(w4.shape, device=dy.device, dtype=th.float32)
+            db = th.zeros((Cout,), device=dy.device, dtype=th.float32) if has_b else None
+            dy2 = _pad_c(dy, 2)
+            with _lib.on(dy.device):
+                _lib.check(L.hl_conv2d_wgrad_nhwc(_lib.ptr(x), N, x.shape[1], x.shape[2], x.shape[3], _lib.ptr(dy2), dy2.shape[-1], ks, stride, ups,
+                                                  _lib.ptr(dw), Cout, Cin, _lib.ptr(db), _lib.stream_ptr()), "hl_conv2d_wgrad_nhwc")
+            dw = dw.reshape(wshape)
+        return dx, dw, db, None, None
+
+
+def conv(x, m, stride=1, ups=0):
+    return _Conv.apply(x, m.weight, m.bias, stride, ups)
+
+
+class _GroupNormAct(th.autograd.Function):
+    """y = silu?( GroupNorm32(x) [* (1 + scale) + shift] )   (nn.py:17-19,100; unet.py:198-219, use_scale_shift_norm)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, ss, silu):
+        L = _lib.lib()
+        N, H, W, Cc = x.shape
+        dev = x.device
+        one, zero = th.ones(Cc, device=dev), th.zeros(Cc, device=dev)
+        rstd, nmr = th.empty((N, Cc), device=dev), th.empty((N, Cc), device=dev)       # per channel: rstd of its group, -mean*rstd
+        scr = th.empty(N * 128 * 64 + 64, device=dev)
+        with _lib.on(dev):
+            _lib.check(L.hl_groupnorm_coef(_lib.ptr(x), N, H, W, Cc, _lib.ptr(one), _lib.ptr(zero), None, _lib.ptr(rstd), _lib.ptr(nmr),
+                                           _lib.ptr(scr), scr.numel() * 4, _lib.stream_ptr()), "hl_groupnorm_coef")
+        mean = -nmr / rstd
+        g1 = gamma[None] * rstd
+        A, B = g1, beta[None] + gamma[None] * nmr
+        if ss is not None:
+            sc, sh = ss[:, :Cc], ss[:, Cc:]
+            A, B = A * (1 + sc), B * (1 + sc) + sh
+        A, B = A.contiguous(), B.contiguous()
+        y = th.empty((N, H, W, Cc), device=dev)
+        with _lib.on(dev):
+            _lib.check(L.hl_gn_apply_nhwc(_lib.ptr(x), Cc, N, H * W, Cc, _lib.ptr(A), _lib.ptr(B), 1 if silu else 0, _lib.ptr(y), _lib.stream_ptr()),
+                       "hl_gn_apply_nhwc")
+        ctx.save_for_backward(x, A, B, rstd, mean, gamma, beta, ss if ss is not None else th.empty(0, device=dev))
+        ctx.silu = silu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, A, B, rstd, mean, gamma, beta, ss = ctx.saved_tensors
+        has_ss = ss.numel() > 0
+        L = _lib.lib()
+        N, H, W, Cc = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        S = th.zeros((N, Cc, 2), device=dev)
+        with _lib.on(dev):
+            _lib.check(L.hl_gn_backward_reduce(_lib.ptr(x), Cc, _lib.ptr(dy), N, H * W, Cc, _lib.ptr(A), _lib.ptr(B), 1 if ctx.silu else 0, _lib.ptr(S),
+                                               _lib.stream_ptr()), "hl_gn_backward_reduce")
+        S1, S2 = S[..., 0], S[..., 1]
+        one_s = 1 + ss[:, :Cc] if has_ss else 1.0
+        ghat = gamma[None] * one_s                                     # d u / d x_hat
+        xhS = rstd * (S2 - mean * S1)                                  # sum_p du * x_hat
+        cpg = Cc // 32
+        m = float(cpg * H * W)
+        grp = lambda t: t.reshape(N, 32, cpg).sum(2, keepdim=True).expand(N, 32, cpg).reshape(N, Cc)  # noqa: E731
+        M1, M2 = grp(ghat * S1) / m, grp(ghat * xhS) / m
+        k1 = (rstd * ghat).contiguous()
+        k2 = (-rstd * rstd * M2).contiguous()
+        k3 = (-rstd * M1 + rstd * rstd * mean * M2).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = th.empty_like(x)
+            with _lib.on(dev):
+                _lib.check(L.hl_gn_backward_apply(_lib.ptr(x), Cc, _lib.ptr(dy), N, H * W, Cc, _lib.ptr(A), _lib.ptr(B), 1 if ctx.silu else 0,
+                                                  _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(k3), None, _lib.ptr(dx), _lib.stream_ptr()), "hl_gn_backward_apply")
+        dgamma = (one_s * xhS).sum(0)
+        dbeta = (one_s * S1).sum(0) if has_ss else S1.sum(0)
+        dss = th.cat([gamma[None] * xhS + beta[None] * S1, S1], dim=1) if has_ss else None
+        return dx, dgamma, dbeta, dss, None
+
+
+def gn_act(x, m, ss=None, silu=True):
+    return _GroupNormAct.apply(x, m.weight, m.bias, ss, silu)
+
+
+class _Attention(th.autograd.Function):
+    """QKVAttention (unet.py:255-274) on qkv (N, T, 3C) with channel = head*3ch + {q|k|v}*ch + c -> (N, T, C)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        N, T, C3 = qkv.shape
+        Cc = C3 // 3
+        out = th.empty((N, T, Cc), device=qkv.device)
+        with _lib.on(qkv.device):
+            _lib.check(_lib.lib().hl_attention_nhwc(_lib.ptr(qkv), N, T, Cc, heads, _lib.ptr(out), _lib.stream_ptr()), "hl_attention_nhwc")
+        ctx.save_for_backward(qkv)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        heads = ctx.heads
+        N, T, C3 = qkv.shape
+        ch = C3 // 3 // heads
+        v5 = qkv.reshape(N, T, heads, 3, ch).permute(0, 2, 3, 1, 4)           # (N, heads, 3, T, ch)
+        q, k, v = (v5[:, :, i].reshape(N * heads, T, ch) for i in range(3))
+        s2 = 1.0 / math.sqrt(ch)                                             # (ch^-1/4)^2: the scale sits on q AND k (unet.py:262-266)
+        P = th.softmax(th.bmm(q, k.transpose(1, 2)) * s2, dim=-1)
+        dO = do.reshape(N, T, heads, ch).permute(0, 2, 1, 3).reshape(N * heads, T, ch)
+        dV = th.bmm(P.transpose(1, 2), dO)
+        dP = th.bmm(dO, v.transpose(1, 2))
+        dS = P * (dP - (dP * P).sum(-1, keepdim=True))
+        dQ = th.bmm(dS, k) * s2
+        dK = th.bmm(dS.transpose(1, 2), q) * s2
+        d5 = th.stack([dQ, dK, dV], dim=1).reshape(N, heads, 3, T, ch).permute(0, 3, 1, 2, 4)   # (N, T, heads, 3, ch)
+        return d5.reshape(N, T, C3).contiguous(), None
+
+
+# ---- the network (unet.py:550-615) on those ops ---------------------------------------------------------------------------------------
+def _embedding(timesteps, dim):
+    from .nn import timestep_embedding
+    return timestep_embedding(timesteps, dim)                               # hl_timestep_embedding (no parameters)
+
+
+def _silu(x):
+    return x * th.sigmoid(x)
+
+
+def _res_block(m, x, emb):
+    h = conv(gn_act(x, m.in_layers[0]), m.in_layers[2])
+    ss = m.emb_layers[1](_silu(emb))                                        # (N, 2*Cout): [scale | shift] (unet.py:203-206)
+    h = conv(gn_act(h, m.out_layers[0], ss), m.out_layers[3])
+    skip = x if isinstance(m.skip_connection, th.nn.Identity) else conv(x, m.skip_connection)
+    return skip + h
+
+
+def _attention(m, x):
+    N, H, W, Cc = x.shape
+    qkv = conv(gn_act(x, m.norm, None, silu=False), m.qkv)                  # Conv1d k=1 == 1x1 conv
+    a = _Attention.apply(qkv.reshape(N, H * W, 3 * Cc), m.num_heads)
+    return x + conv(a.reshape(N, H, W, Cc), m.proj_out)
+
+
+def _run(seq, h, emb):
+    for m in seq:
+        if isinstance(m, U.ResBlock):
+            h = _res_block(m, h, emb)
+        elif isinstance(m, U.AttentionBlock):
+            h = _attention(m, h)
+        elif isinstance(m, U.Downsample):
+            h = conv(h, m.op, stride=2)
+        elif isinstance(m, U.Upsample):
+            h = conv(h, m.conv, ups=1)
+        else:                                                               # the bare first convolution of an encoder
+            h = conv(h, m)
+    return h
+
+
+def forward_train(model, x, timesteps, x_cond=None, y=None):
+    """UNetModel.forward's contract (x (N,C,H,W), timesteps (N,), x_cond, y) -> (N,C_out,H,W), differentiable through HIP kernels."""
+    if not x.is_cuda:
+        raise RuntimeError("the HIP training path needs CUDA(HIP) tensors; there is no CPU path")
+    if model.num_classes is not None:
+        assert y is not None and y.shape == (x.shape[0],)
+    emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
+    if model.num_classes is not None:
+        emb = emb + model.label_emb(y)
+    to_nhwc = lambda t: _pad_c(t.float().permute(0, 2, 3, 1), 16).contiguous()  # noqa: E731   (27 -> 32 channels, zeros)
+    hs = []
+    h = to_nhwc(x)
+    for blk in model.input_blocks:
+        h = _run(blk, h, emb)
+        hs.append(h)
+    h = _run(model.middle_block, h, emb)
+    if model.cond_type == "controlnet":
+        assert x_cond is not None, "cond_type='controlnet' needs x_cond (zeros for the first layer)"
+        hs_cond = []
+        hc = to_nhwc(x + x_cond)
+        for blk, proj in zip(model.input_blocks_cond, model.input_blocks_proj_cond):
+            hc = conv(_run(blk, hc, emb), proj)
+            hs_cond.append(hc)
+    for blk in model.output_blocks:
+        skip = hs.pop()
+        if model.cond_type == "controlnet":
+            skip = skip + hs_cond.pop()
+        h = _run(blk, th.cat([h, skip], dim=-1), emb)
+    out = conv(gn_act(h, model.out[0]), model.out[2])                       # (N, H, W, C_out)
+    return out.permute(0, 3, 1, 2).contiguous().to(x.dtype)

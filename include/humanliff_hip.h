@@ -330,6 +330,32 @@ int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w
 int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias,
                         int Cout, int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream);
+/* ---- backward of the UNet (gaussian_diffusion.py:688-772 -> loss.backward() through unet.py:550-615) --------
+ * Backward-DATA of a convolution is a forward convolution (hl_conv2d_nhwc_mode) of the output gradient with the flipped,
+ * channel-transposed weights; stride 2 goes through hl_zero_stuff2_nhwc first, the nearest-x2 upsample through
+ * hl_upsample2_backward_nhwc afterwards.  humanliff_amd/improved_diffusion/unet_train.py holds the autograd.Functions.
+ *
+ * hl_conv2d_wgrad_nhwc: dW[co][ci][ky][kx] += sum_p dY[p][co] * X[p*stride + (ky,kx) - pad][ci] and db[co] += sum_p dY[p][co]
+ * (float atomics: dw (Cout, Cin, ks, ks) - the reference's OIHW parameter layout - and db (Cout) or NULL must be zeroed by the caller).
+ * x (N,H,W,Cx), dy (N,Hout,Wout,Cy) dense NHWC with Cx >= Cin, Cy >= Cout even (zero-padded channels are ignored); `upsample`:
+ * the convolution ran on the nearest-x2 upsampled x. */
+int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
+                         float *dw, int Cout, int Cin, float *db, void *stream);
+/* y (N,HW,C dense) = silu ? silu(x*A + B) : x*A + B with the per-(n,c) affine of hl_groupnorm_coef; x has a channel pitch. */
+int hl_gn_apply_nhwc(const float *x, long x_pitch, int N, int HW, int C, const float *coefA, const float *coefB, int silu, float *y,
+                     void *stream);
+/* backward of y = silu?(x*A + B): with du = dout * silu'(x*A + B) (or dout), S[n][c] = (sum_p du, sum_p du*x) - float atomics into
+ * the zeroed S (N,C,2); then dx = k1[n,c]*du + k2[n,c]*x + k3[n,c] (+ dx_add), the (N,C) coefficients being the caller's small
+ * tensor algebra on S, the group statistics and the affine parameters (unet_train.py). */
+int hl_gn_backward_reduce(const float *x, long x_pitch, const float *dout, int N, int HW, int C, const float *coefA, const float *coefB,
+                          int silu, float *S, void *stream);
+int hl_gn_backward_apply(const float *x, long x_pitch, const float *dout, int N, int HW, int C, const float *coefA, const float *coefB,
+                         int silu, const float *k1, const float *k2, const float *k3, const float *dx_add, float *dx, void *stream);
+/* dx (N,H,W,C) = sums of the 2x2 blocks of d_up (N,2H,2W,C): backward of the nearest-x2 upsample (unet.py:77). */
+int hl_upsample2_backward_nhwc(const float *d_up, int N, int H, int W, int C, float *dx, void *stream);
+/* z (N,2Ho,2Wo,C): z[2y][2x] = dy[y][x], zero elsewhere - backward-data of a stride-2 3x3 conv = flipped 3x3 conv of z. */
+int hl_zero_stuff2_nhwc(const float *dy, int N, int Ho, int Wo, int C, float *z, void *stream);
+
 /* hl_conv2d_nhwc_mode followed by the GroupNorm32 affine of its OUTPUT (nn.py:17-19,100: y = out*A[n,c] + B[n,c] for the layer
  * that normalises `out` next): the statistics come from the epilogue of the kernel that stored `out` (per-slot partial sums, folded
  * in a fixed order) - the tensor is not read again; *h_used_stats returns the slots per image that were emitted, 0 when the kernel

@@ -388,33 +388,22 @@ def test_c_abi_error_convention():
           y=torch.tensor([0], device=dev))
 
 
-def test_training_twin_matches_hip_forward_and_trains():
-    """forward_autograd (the training-only PyTorch-op twin that training_losses uses) evaluates the same function as the
-    HIP forward, on the GPU through MIOpen, and one Adam step on training_losses lowers the loss."""
+def test_training_path_matches_inference_forward_and_twin():
+    """The three statements of the network agree on the GPU: the fused inference forward, the differentiable HIP path (unet_train.py)
+    and the PyTorch-op twin (unet_autograd.py, MIOpen here)."""
     from tests.test_train_loss_cpu import inputs, tiny_model
+    from humanliff_amd.improved_diffusion.unet_train import forward_train
     model, diffusion = tiny_model()
     model = model.to(dev)
     x0, xc = (t.to(dev) for t in inputs())
     t, y = torch.tensor([999, 17], device=dev), torch.tensor([3, 0], device=dev)
     with torch.no_grad():
         hip = model(x0, t, xc, y=y)
+        train = forward_train(model, x0, t, xc, y)
         twin = model.forward_autograd(x0, t, xc, y=y)
-    assert (hip - twin).abs().max() < 2e-4 * max(1.0, float(twin.abs().max()))      # MIOpen vs the HIP kernels: different summation orders
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    g = torch.Generator(device=dev).manual_seed(3)
-    noise = torch.randn(x0.shape, device=dev, generator=g)
-    first = None
-    for it in range(5):
-        loss = diffusion.training_losses(model, x0.clamp(-1, 1), xc, t, model_kwargs={"y": y}, noise=noise)["loss"].mean()
-        loss.backward()
-        opt.step()
-        opt.zero_grad()
-        first = float(loss.detach()) if first is None else first
-    assert float(loss.detach()) < first
-    with torch.no_grad():        # the updated weights are picked up by the HIP path (re-bound by parameter version)
-        hip2 = model(x0, t, xc, y=y)
-        twin2 = model.forward_autograd(x0, t, xc, y=y)
-    assert (hip2 - twin2).abs().max() < 2e-4 * max(1.0, float(twin2.abs().max())) and (hip2 - hip).abs().max() > 1e-4
+    scale = max(1.0, float(twin.abs().max()))
+    assert (hip - train).abs().max() < 5e-5 * scale            # same kernels, different fusion (materialised GroupNorm, no concat buffers)
+    assert (hip - twin).abs().max() < 2e-4 * scale             # MIOpen vs the HIP kernels: different summation orders
 
 
 @pytest.mark.parametrize("N,C,H,W,Cout,ks,stride,ups,mode,with_gn,expect_stats", [

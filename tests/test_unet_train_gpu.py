@@ -1,0 +1,179 @@
+"""HIP backward of the UNet: the backward kernels op by op against PyTorch's autograd of the same op, and
+GaussianDiffusion.training_losses(...).backward() end to end against the REFERENCE's loss and parameter gradients
+(tests/golden/train_loss_tiny32.npz <- tests/golden/gen_golden_train_loss.py).  Everything goes through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.golden_util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda:0")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,ks,stride,ups", [
+    (2, 64, 32, 32, 64, 3, 1, 0),       # one 64x64 block per tap
+    (2, 192, 64, 64, 192, 3, 1, 0),     # production channel count: 3 x 3 blocks x 9 taps, K slabs
+    (1, 96, 40, 24, 160, 3, 1, 0),      # ragged channel blocks (96 = 64 + 32, 160 = 128 + 32), non-square
+    (2, 64, 32, 32, 64, 3, 2, 0),       # Downsample: stride 2
+    (2, 64, 16, 16, 96, 3, 1, 1),       # Upsample: conv on the nearest-x2 image
+    (2, 128, 16, 16, 384, 1, 1, 0),     # 1x1 (qkv / skip / zero-conv)
+    (1, 32, 32, 32, 27, 3, 1, 0),       # the 27-channel output conv (gradient padded to 28 channels by the caller)
+    (3, 27, 16, 16, 32, 3, 1, 0),       # the 27-channel input conv (input padded to 32 channels by the caller)
+    (2, 32, 4, 4, 32, 3, 1, 0),         # 16 pixels per image: slabs and pixel pairs cross images
+])
+def test_conv_backward_matches_torch_autograd(N, Cin, H, W, Cout, ks, stride, ups):
+    """_Conv: d input through the forward conv kernels on flipped weights, d weight / d bias by k_conv_wgrad."""
+    from humanliff_amd.improved_diffusion import unet_train as ut
+    g = torch.Generator().manual_seed(N * 100 + Cin + Cout + H)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, ks, ks), generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    xi = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest") if ups else xr, wr, br, stride=stride, padding=ks // 2)
+    cot = torch.randn(yr.shape, generator=g)
+    (yr * cot.double()).sum().backward()
+    xd = ut._pad_c(nhwc(x), 16).to(dev).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ut._Conv.apply(xd, wd, bd, stride, ups)
+    assert (nchw(y.detach().cpu()) - F.conv2d(xi, w, b, stride=stride, padding=ks // 2)).abs().max() < 3e-5
+    (y * nhwc(cot).to(dev)).sum().backward()
+    dx = nchw(xd.grad.cpu())[:, :Cin]
+    sx, sw, sb = float(xr.grad.abs().max()), float(wr.grad.abs().max()), float(br.grad.abs().max())
+    assert (dx.double() - xr.grad).abs().max() < 2e-5 * max(1.0, sx)
+    assert (wd.grad.cpu().double() - wr.grad).abs().max() < 1e-5 * sw          # K up to 8192 pixels per element, fp32 partial sums
+    assert (bd.grad.cpu().double() - br.grad).abs().max() < 1e-5 * sb
+
+
+@pytest.mark.parametrize("N,C,H,W,use_ss,silu", [(2, 64, 16, 16, True, True), (2, 192, 32, 32, True, True), (1, 96, 20, 12, False, True),
+                                                   (3, 128, 8, 8, False, False), (2, 384, 64, 64, True, True)])
+def test_groupnorm_backward_matches_torch_autograd(N, C, H, W, use_ss, silu):
+    """_GroupNormAct: GroupNorm32 [* (1 + scale) + shift] [SiLU] forward and every gradient (x, gamma, beta, scale/shift)."""
+    from humanliff_amd.improved_diffusion import unet_train as ut
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn((N, C, H, W), generator=g) * 1.5 + 0.3
+    gamma, beta = torch.randn(C, generator=g) * 0.2 + 1, torch.randn(C, generator=g) * 0.2
+    ss = torch.randn((N, 2 * C), generator=g) * 0.3 if use_ss else None
+    cot = torch.randn((N, C, H, W), generator=g)
+    leaf = lambda t: None if t is None else t.double().requires_grad_(True)  # noqa: E731
+    xr, gr, br, sr = leaf(x), leaf(gamma), leaf(beta), leaf(ss)
+    u = F.group_norm(xr, 32, gr, br, eps=1e-5)
+    if use_ss:
+        u = u * (1 + sr[:, :C, None, None]) + sr[:, C:, None, None]
+    yr = u * torch.sigmoid(u) if silu else u
+    (yr * cot.double()).sum().backward()
+    xd = nhwc(x).to(dev).requires_grad_(True)
+    gd_, bd_ = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    sd_ = ss.to(dev).requires_grad_(True) if use_ss else None
+    y = ut._GroupNormAct.apply(xd, gd_, bd_, sd_, silu)
+    assert (nchw(y.detach().cpu()).double() - yr.detach()).abs().max() < 2e-5
+    (y * nhwc(cot).to(dev)).sum().backward()
+    rel = lambda a, b: float((a.cpu().double() - b).abs().max() / max(1e-6, float(b.abs().max())))  # noqa: E731
+    assert rel(nchw(xd.grad), xr.grad) < 2e-5
+    assert rel(gd_.grad, gr.grad) < 2e-5 and rel(bd_.grad, br.grad) < 2e-5
+    if use_ss:
+        assert rel(sd_.grad, sr.grad) < 2e-5
+
+
+def test_attention_backward_matches_torch_autograd():
+    from humanliff_amd.improved_diffusion import unet_train as ut
+    g = torch.Generator().manual_seed(9)
+    N, T, C, heads = 2, 256, 128, 4
+    qkv = torch.randn((N, 3 * C, T), generator=g)
+    cot = torch.randn((N, C, T), generator=g)
+    ch = C // heads
+    qr = qkv.double().requires_grad_(True)
+    q, k, v = qr.reshape(N * heads, 3 * ch, T).split(ch, dim=1)
+    s = 1.0 / (ch ** 0.25)
+    wgt = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s), dim=-1)
+    out = torch.einsum("bts,bcs->bct", wgt, v).reshape(N, C, T)
+    (out * cot.double()).sum().backward()
+    qd = qkv.permute(0, 2, 1).contiguous().to(dev).requires_grad_(True)
+    o = ut._Attention.apply(qd, heads)
+    assert (o.detach().cpu().permute(0, 2, 1).double() - out.detach()).abs().max() < 2e-5
+    (o * cot.permute(0, 2, 1).contiguous().to(dev)).sum().backward()
+    ref = qr.grad.permute(0, 2, 1)
+    assert (qd.grad.cpu().double() - ref).abs().max() < 2e-5 * float(ref.abs().max())
+
+
+def test_training_losses_backward_matches_reference_on_hip():
+    """GaussianDiffusion.training_losses -> backward() through UNetModel.forward on the GPU: loss and parameter gradients equal the
+    REFERENCE's (improved_diffusion imported unmodified by tests/golden/gen_golden_train_loss.py), and the PyTorch-op twin is never
+    entered."""
+    from tests.test_train_loss_cpu import inputs, tiny_model
+    from humanliff_amd.improved_diffusion import unet_autograd
+    g = np.load(os.path.join(GOLDEN, "train_loss_tiny32.npz"))
+    model, diffusion = tiny_model()
+    model = model.to(dev).train()
+    x0, xc = (t.to(dev) for t in inputs())
+
+    def boom(*a, **k):
+        raise AssertionError("the PyTorch-op twin must not run on the GPU training path")
+    orig = unet_autograd.forward_autograd
+    unet_autograd.forward_autograd = boom
+    try:
+        losses = diffusion.training_losses(model, x0.clamp(-1, 1), xc, torch.tensor([999, 17], device=dev),
+                                           model_kwargs={"y": torch.tensor([3, 0], device=dev)}, noise=torch.from_numpy(g["noise"]).to(dev))
+        assert losses["loss"].requires_grad
+        assert np.abs(losses["loss"].detach().cpu().numpy() - g["loss"]).max() < 1e-5
+        losses["loss"].mean().backward()
+    finally:
+        unet_autograd.forward_autograd = orig
+    sd = dict(model.named_parameters())
+    assert all(p.grad is not None for p in sd.values())
+    tot = sum(float(p.grad.double().abs().sum()) for p in sd.values())
+    assert abs(tot - float(g["grad_abs_sum"])) < 2e-4 * float(g["grad_abs_sum"])
+    worst = 0.0
+    for k in g["keys"]:
+        ref = torch.from_numpy(g["g_" + str(k)])
+        err = float((sd[str(k)].grad.cpu() - ref).abs().max() / ref.abs().max())
+        worst = max(worst, err)
+        assert err < 2e-4, (str(k), err)
+    print(f"training_losses on HIP: loss max-abs {np.abs(losses['loss'].detach().cpu().numpy() - g['loss']).max():.2e}, "
+          f"worst relative gradient error over {len(g['keys'])} reference tensors {worst:.2e}, sum|grad| rel {abs(tot - float(g['grad_abs_sum'])) / float(g['grad_abs_sum']):.2e}")
+
+
+def test_ddp_style_wrapper_trains_on_hip():
+    """train_util.py:236 hands training_losses the DDP-wrapped model: a wrapper whose forward calls the module must work and step."""
+    from tests.test_train_loss_cpu import inputs, tiny_model
+
+    class Wrapper(torch.nn.Module):          # the call pattern of DistributedDataParallel: forward(*a, **k) -> self.module(*a, **k)
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+            self.calls = 0
+
+        def forward(self, *a, **k):
+            self.calls += 1
+            return self.module(*a, **k)
+
+    model, diffusion = tiny_model()
+    wrapped = Wrapper(model.to(dev).train())
+    x0, xc = (t.to(dev) for t in inputs())
+    t, y = torch.tensor([999, 17], device=dev), torch.tensor([3, 0], device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    noise = torch.randn(x0.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    vals = []
+    for _ in range(5):
+        loss = diffusion.training_losses(wrapped, x0.clamp(-1, 1), xc, t, model_kwargs={"y": y}, noise=noise)["loss"].mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        vals.append(float(loss.detach()))
+    assert wrapped.calls == 5 and vals[-1] < vals[0]
+    model.eval()
+    with torch.no_grad():                    # the updated weights are picked up by the inference path (re-bound by parameter version)
+        out = model(x0, t, xc, y=y)
+    assert torch.isfinite(out).all()
