@@ -294,6 +294,45 @@ def e2e_chain(model, dev, golden=None):
             "workload": "F4 net, DDIM-10, B=1, 2 cloth layers chained through x_cond -> reshape(1,3,9,256,256) -> one 128x128 view @32+32"}
 
 
+def bench_train(model, diffusion, dev, rank, world, iters=3, B=2):
+    """SURVEY 8(f) rank 4, UNet half (not a BASELINE metric): one training step of the production network at the reference's
+    microbatch (README.md:104 `--microbatch 2`): GaussianDiffusion.training_losses -> backward through the HIP kernels
+    (improved_diffusion/unet_train.py) -> AdamW.  Every rank trains its own replica (no gradient exchange is measured here)."""
+    was_training = model.training
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.0)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    x0 = torch.randn((B, 27, 256, 256), device=dev, generator=g).clamp(-1, 1)
+    xc = torch.zeros_like(x0)
+    y = torch.zeros((B,), dtype=torch.int64, device=dev)
+
+    def step():
+        t = torch.randint(0, 1000, (B,), device=dev, generator=g)
+        loss = diffusion.training_losses(model, x0, xc, t, model_kwargs={"y": y})["loss"].mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        loss = step()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev) / iters
+    assert torch.isfinite(loss.detach()).all()
+    model.train(was_training)
+    del opt
+    for p in model.parameters():
+        p.grad = None
+    return {"metric": "UNet training samples/sec", "value": round(world * B / dt, 3), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 2),
+            "batch_per_gpu": B, "iterations": iters,
+            "algorithmic_tflops": round(world * 3 * UNET_GFLOP_PER_SAMPLE_STEP * B / dt / 1e3, 2),
+            "config": {"workload": "production F4 UNet, training_losses (MSE) + backward on the HIP kernels + AdamW, microbatch 2 (README.md:104)",
+                       "flop_count": "3 x 2015.4 GFLOP per sample (forward, backward-data, backward-weights; direct-convolution FLOPs)"}}
+
+
 def bench_render(args, rank, world, dev):
     from humanliff_amd import _lib, synthetic as syn
     from humanliff_amd.NeRF import Renderer
@@ -625,6 +664,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity legs (end-to-end chain vs the reference's vectors, HIP vs oracle samples)")
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the UNet training-step leg (SURVEY 8(f) rank 4)")
     ap.add_argument("--no-fit", action="store_true", help="skip the tri-plane fitting leg (SURVEY 8(f) rank 4)")
     ap.add_argument("--no-bf16x3-leg", action="store_true", help="skip the extra measurement of the opt-in bf16x3 conv mode")
     ap.add_argument("--no-overlap", action="store_true",
@@ -646,6 +686,20 @@ def main():
         parity = {"psnr_db": min(l["image_psnr_db"] for l in chain["layers"]), "max_abs": max(l["image_max_abs"] for l in chain["layers"]),
                   "triplane_psnr_db": min(l["triplane_psnr_db"] for l in chain["layers"]),
                   "triplane_max_abs": max(l["triplane_max_abs"] for l in chain["layers"]), "end_to_end": chain}
+    cpu = step_parity = None
+    threads = min(len(os.sched_getaffinity(0)), 32)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # PyTorch-CPU stops scaling (and then collapses) beyond ~32 threads on this path: measured on the
+        # MI355X host (256 logical CPUs) 3x3 conv 192->192@256^2: 49/47/40/90/208 ms at 8/16/32/64/128 threads
+        cpu, step_parity = cpu_baseline_unet(sd, threads, None if args.no_parity else model, dev)
+        if parity is not None:
+            parity["denoise_steps_vs_oracle"] = step_parity
+    train = None
+    if not args.no_train:
+        from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
+        train = bench_train(model, create_gaussian_diffusion(steps=1000), dev, rank, world)
+    del model
+    torch.cuda.empty_cache()
     render = None
     if not args.no_render:
         rsecs, rroof, rays_per_rank = bench_render(args, rank, world, dev)
@@ -657,14 +711,7 @@ def main():
     if not args.no_fit:
         torch.cuda.empty_cache()
         fit = bench_fit(args, rank, world, dev)
-    cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # PyTorch-CPU stops scaling (and then collapses) beyond ~32 threads on this path: measured on the
-        # MI355X host (256 logical CPUs) 3x3 conv 192->192@256^2: 49/47/40/90/208 ms at 8/16/32/64/128 threads
-        threads = min(len(os.sched_getaffinity(0)), 32)
-        cpu, step_parity = cpu_baseline_unet(sd, threads, None if args.no_parity else model, dev)
-        if parity is not None:
-            parity["denoise_steps_vs_oracle"] = step_parity
         if render is not None:
             render["cpu_baseline"], render["parity"] = cpu_baseline_render(threads, dev=None if args.no_parity else dev)
         if fit is not None:
@@ -679,7 +726,7 @@ def main():
                        "parallelism": f"replicas x{world} (subjects sharded, final all-gather only)",
                        "gflop_per_sample_step": UNET_GFLOP_PER_SAMPLE_STEP},
             "step_tflops": round(world * args.batch * args.steps * UNET_GFLOP_PER_SAMPLE_STEP / secs / 1e3, 2),
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "render": render, "fit": fit,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "render": render, "fit": fit, "train": train,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

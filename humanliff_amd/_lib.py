@@ -98,6 +98,8 @@ SIGNATURES = {
     "hl_gn_apply_nhwc": (_i, [_p, _i64, _i, _i, _i, _p, _p, _i, _p, _p]),
     "hl_gn_backward_reduce": (_i, [_p, _i64, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "hl_gn_backward_apply": (_i, [_p, _i64, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "hl_groupnorm_train_forward": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "hl_groupnorm_train_backward": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "hl_upsample2_backward_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "hl_zero_stuff2_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "hl_groupnorm_coef": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),

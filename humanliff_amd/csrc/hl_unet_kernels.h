@@ -68,8 +68,9 @@ size_t gn_scratch_floats(int N);
 struct StatSrc { const float *p; int Cn, slots; };
 int groupnorm_coef_stats(const View &x, const StatSrc *src, int nsrc, const float *gamma, const float *beta, const float *emb,
                          long emb_pitch, float *coefA, float *coefB, hipStream_t st);
+// gstat (optional): (N, 32, 2) = (mean, rstd) of every group, for the backward pass of the training path
 int groupnorm_coef(const View &x, const float *gamma, const float *beta, const float *emb, long emb_pitch, float *coefA,
-                   float *coefB, float *scratch, hipStream_t st);
+                   float *coefB, float *scratch, hipStream_t st, float *gstat = nullptr);
 
 // y (dense NHWC) = act ? silu(x*A + B) : x*A + B with the per-(n,c) affine of groupnorm_coef (the pre-pass of the DMA convs; the
 // GroupNorm forward of the training path)

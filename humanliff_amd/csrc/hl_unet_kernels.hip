@@ -1352,7 +1352,7 @@ __global__ void k_pack_conv_bf3(const float *__restrict__ w, int Cout, int Cin, 
 // grid (nchunks, N); blockDim = (C/4) * k threads; thread owns one float4 channel column.
 __global__ void k_gn_partial(const float *__restrict__ x, long pitch, int HW, int C, int nchunks, float *__restrict__ partial,
                              const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ emb,
-                             long emb_pitch, float *__restrict__ cA, float *__restrict__ cB) {
+                             long emb_pitch, float *__restrict__ cA, float *__restrict__ cB, float *__restrict__ gstat) {
     extern __shared__ float sh[];  // [k][C] sums then [k][C] sumsq
     const int cq = C >> 2;
     const int k = blockDim.x / cq;
@@ -1415,6 +1415,7 @@ __global__ void k_gn_partial(const float *__restrict__ x, long pitch, int HW, in
         }
         cA[(long)n * C + c] = a;
         cB[(long)n * C + c] = b;
+        if (gstat && c % cg == 0) { gstat[((long)n * 32 + c / cg) * 2] = (float)mean; gstat[((long)n * 32 + c / cg) * 2 + 1] = rstd; }
     }
 }
 
@@ -1424,7 +1425,7 @@ template <int V>
 __global__ __launch_bounds__(256) void k_gn_small(const float *__restrict__ x, long pitch, int HW, int C,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
                                                   const float *__restrict__ emb, long emb_pitch, float *__restrict__ cA,
-                                                  float *__restrict__ cB) {
+                                                  float *__restrict__ cB, float *__restrict__ gstat) {
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int cg = C / 32, per = cg / V;
     const float *base = x + (long)n * HW * pitch + g * cg;
@@ -1475,6 +1476,7 @@ __global__ __launch_bounds__(256) void k_gn_small(const float *__restrict__ x, l
         }
         cA[(long)n * C + c] = a;
         cB[(long)n * C + c] = b;
+        if (gstat && c % cg == 0) { gstat[((long)n * 32 + c / cg) * 2] = (float)mean; gstat[((long)n * 32 + c / cg) * 2 + 1] = rstd; }
     }
 }
 
@@ -1483,7 +1485,7 @@ __global__ __launch_bounds__(256) void k_gn_small(const float *__restrict__ x, l
 __global__ __launch_bounds__(64) void k_gn_coef(const float *__restrict__ partial, int nchunks, int HW, int C,
                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                 const float *__restrict__ emb, long emb_pitch, float *__restrict__ cA,
-                                                float *__restrict__ cB) {
+                                                float *__restrict__ cB, float *__restrict__ gstat) {
     const int g = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
     const int cg = C / 32;
     double s = 0.0, ss = 0.0;
@@ -1514,6 +1516,7 @@ __global__ __launch_bounds__(64) void k_gn_coef(const float *__restrict__ partia
         }
         cA[(long)n * C + c] = a;
         cB[(long)n * C + c] = b;
+        if (gstat && c % cg == 0) { gstat[((long)n * 32 + c / cg) * 2] = (float)mean; gstat[((long)n * 32 + c / cg) * 2 + 1] = rstd; }
     }
 }
 
@@ -1523,7 +1526,7 @@ __global__ __launch_bounds__(64) void k_gn_coef(const float *__restrict__ partia
 struct StatSrcK { const float *p; int Cn, slots; };
 __global__ __launch_bounds__(256) void k_gn_coef_st(StatSrcK s0, StatSrcK s1, int HW, int C, const float *__restrict__ gamma,
                                                     const float *__restrict__ beta, const float *__restrict__ emb, long emb_pitch,
-                                                    float *__restrict__ cA, float *__restrict__ cB) {
+                                                    float *__restrict__ cA, float *__restrict__ cB, float *__restrict__ gstat) {
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int cg = C / 32, c_lo = g * cg, c_hi = c_lo + cg;
     double s = 0.0, ss = 0.0;
@@ -1569,6 +1572,7 @@ __global__ __launch_bounds__(256) void k_gn_coef_st(StatSrcK s0, StatSrcK s1, in
         }
         cA[(long)n * C + c] = a;
         cB[(long)n * C + c] = b;
+        if (gstat && c % cg == 0) { gstat[((long)n * 32 + c / cg) * 2] = (float)mean; gstat[((long)n * 32 + c / cg) * 2 + 1] = rstd; }
     }
 }
 
@@ -2131,7 +2135,7 @@ static int gn_chunks(int HW, int C) {
 size_t gn_scratch_floats(int N) { return (size_t)N * 128 * 32 * 2; }
 
 int groupnorm_coef(const View &x, const float *gamma, const float *beta, const float *emb, long emb_pitch, float *cA, float *cB,
-                   float *scratch, hipStream_t st) {
+                   float *scratch, hipStream_t st, float *gstat) {
     HL_REQUIRE(x.p && gamma && beta && cA && cB && scratch, "groupnorm_coef: null argument");
     HL_REQUIRE(x.C % 32 == 0, "GroupNorm32 needs C %% 32 == 0 (C=%d)", x.C);
     const int HW = x.H * x.W, cq = x.C / 4;
@@ -2140,11 +2144,11 @@ int groupnorm_coef(const View &x, const float *gamma, const float *beta, const f
         const int cg = x.C / 32;
         dim3 grid(32, x.N);
         if (cg % 4 == 0 && ((uintptr_t)x.p % 16) == 0 && x.pitch % 4 == 0)
-            hipLaunchKernelGGL(k_gn_small<4>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
+            hipLaunchKernelGGL(k_gn_small<4>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat);
         else if (cg % 2 == 0 && ((uintptr_t)x.p % 8) == 0 && x.pitch % 2 == 0)
-            hipLaunchKernelGGL(k_gn_small<2>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
+            hipLaunchKernelGGL(k_gn_small<2>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat);
         else
-            hipLaunchKernelGGL(k_gn_small<1>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
+            hipLaunchKernelGGL(k_gn_small<1>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat);
         return check_launch("k_gn_small");
     }
     int k = (nch == 1 ? 1024 : 512) / cq;
@@ -2153,10 +2157,10 @@ int groupnorm_coef(const View &x, const float *gamma, const float *beta, const f
     const int threads = cq * k > 64 ? cq * k : 64;
     const size_t shm = (size_t)2 * k * x.C * sizeof(float);
     hipLaunchKernelGGL(k_gn_partial, dim3(nch, x.N), dim3(threads), shm, st, x.p, x.pitch, HW, x.C, nch, scratch, gamma, beta, emb,
-                       emb_pitch, cA, cB);
+                       emb_pitch, cA, cB, gstat);
     int rc = check_launch("k_gn_partial");
     if (rc || nch == 1) return rc;
-    hipLaunchKernelGGL(k_gn_coef, dim3(32, x.N), dim3(64), 0, st, scratch, nch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB);
+    hipLaunchKernelGGL(k_gn_coef, dim3(32, x.N), dim3(64), 0, st, scratch, nch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat);
     return check_launch("k_gn_coef");
 }
 
@@ -2176,7 +2180,7 @@ int groupnorm_coef_stats(const View &x, const StatSrc *src, int nsrc, const floa
                src[0].Cn + (nsrc == 2 ? src[1].Cn : 0), x.C);
     StatSrcK s0{src[0].p, src[0].Cn, src[0].slots}, s1{nullptr, 0, 0};
     if (nsrc == 2) s1 = StatSrcK{src[1].p, src[1].Cn, src[1].slots};
-    hipLaunchKernelGGL(k_gn_coef_st, dim3(32, x.N), dim3(256), 0, st, s0, s1, x.H * x.W, x.C, gamma, beta, emb, emb_pitch, cA, cB);
+    hipLaunchKernelGGL(k_gn_coef_st, dim3(32, x.N), dim3(256), 0, st, s0, s1, x.H * x.W, x.C, gamma, beta, emb, emb_pitch, cA, cB, nullptr);
     return check_launch("k_gn_coef_st");
 }
 

@@ -102,18 +102,33 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WgradK p) {
             bs0 += a[u].x; bs1 += a[u].y;
         }
     }
+    // the four waves' blocks meet in LDS (fixed order), then ONE set of float atomics per workgroup: the L2 atomic units (~25 G/s)
+    // were the whole kernel time when every wave added its own 4096 values
+    __shared__ float red[3][4][16][64];                          // waves 1..3: [i*2+j][r][lane]
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - 1][i * 2 + j][r][lane] = acc[i][j][r];
+    }
+    __syncthreads();
     // dW[co][ci][ky][kx]: accumulator r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
-    const int ci = ci0 + 2 * m;
+    if (wave == 0) {
+        const int ci = ci0 + 2 * m;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int co = co0 + 2 * row + i, cc = ci + j;
-                if (co < p.Cout_w && cc < p.Cin_w) atomicAdd(p.dw + ((long)co * p.Cin_w + cc) * taps + tap, acc[i][j][r]);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float v = ((acc[i][j][r] + red[0][i * 2 + j][r][lane]) + red[1][i * 2 + j][r][lane]) + red[2][i * 2 + j][r][lane];
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int co = co0 + 2 * row + i, cc = ci + j;
+                    if (co < p.Cout_w && cc < p.Cin_w) atomicAdd(p.dw + ((long)co * p.Cin_w + cc) * taps + tap, v);
+                }
+    }
     if (want_b) {
         bs0 += __shfl_xor(bs0, 32);
         bs1 += __shfl_xor(bs1, 32);
@@ -138,12 +153,14 @@ __global__ void k_gn_bwd_reduce(const float *__restrict__ x, long x_pitch, const
     const int k = blockDim.x / cq;
     const int c4 = threadIdx.x % cq, prow = threadIdx.x / cq;
     const int n = blockIdx.y, chunk = blockIdx.x;
-    if (prow >= k) return;
+    extern __shared__ float sh[];                                 // [C][2]
+    for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) sh[e] = 0.f;
+    __syncthreads();
     const int per = (HW + nchunks - 1) / nchunks;
     const int p0 = chunk * per, p1 = min(HW, p0 + per);
     const f32x4 a = *reinterpret_cast<const f32x4 *>(cA + (long)n * C + c4 * 4), b = *reinterpret_cast<const f32x4 *>(cB + (long)n * C + c4 * 4);
     f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int pp = p0 + prow; pp < p1; pp += k) {
+    for (int pp = p0 + prow; pp < p1 && prow < k; pp += k) {
         const long pix = (long)n * HW + pp;
         const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + pix * x_pitch + c4 * 4);
         f32x4 dv = *reinterpret_cast<const f32x4 *>(dout + pix * d_pitch + c4 * 4);
@@ -157,11 +174,14 @@ __global__ void k_gn_bwd_reduce(const float *__restrict__ x, long x_pitch, const
         s1 += dv;
         s2 += dv * xv;
     }
+    // the k pixel rows of the workgroup meet in LDS, then one global atomic per channel and workgroup
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        atomicAdd(S + ((long)n * C + c4 * 4 + i) * 2, s1[i]);
-        atomicAdd(S + ((long)n * C + c4 * 4 + i) * 2 + 1, s2[i]);
+        atomicAdd(sh + (c4 * 4 + i) * 2, s1[i]);
+        atomicAdd(sh + (c4 * 4 + i) * 2 + 1, s2[i]);
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) atomicAdd(S + (long)n * C * 2 + e, sh[e]);
 }
 
 // dx = k1[n,c] * du + k2[n,c] * x + k3[n,c]  (+ dx_add: the gradient arriving over the residual branch), du as above
@@ -190,6 +210,54 @@ __global__ void k_gn_bwd_apply(const float *__restrict__ x, long x_pitch, const 
         f32x4 o = q1 * dv + q2 * xv + q3;
         if (dx_add) o += *reinterpret_cast<const f32x4 *>(dx_add + pix * add_pitch + c);
         *reinterpret_cast<f32x4 *>(dx + pix * dx_pitch + c) = o;
+    }
+}
+
+// The (N,C)-sized algebra between the two passes, one wave per group: with x_hat = (x - mean) * rstd, g = gamma * (1 + scale),
+// D = g * du:   dx = rstd * (D - mean_grp(D) - x_hat * mean_grp(D * x_hat))  =  k1 * du + k2 * x + k3   with
+//     k1 = rstd * g,   k2 = -rstd^2 * M2,   k3 = -rstd * M1 + rstd^2 * mean * M2,   M1 = sum_c g S1 / m,  M2 = sum_c g xhS / m,
+//     xhS = sum_p du * x_hat = rstd * (S2 - mean * S1),   m = (C/32) * HW;
+// d gamma = sum_n (1 + scale) xhS,  d beta = sum_n (1 + scale) S1,  d scale = gamma * xhS + beta * S1,  d shift = S1.
+__global__ __launch_bounds__(64) void k_gn_bwd_coef(const float *__restrict__ S, const float *__restrict__ gstat, const float *__restrict__ gamma,
+                                                    const float *__restrict__ beta, const float *__restrict__ ss, int N, int HW, int C,
+                                                    float *__restrict__ k1, float *__restrict__ k2, float *__restrict__ k3,
+                                                    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dss) {
+    const int g = blockIdx.x, lane = threadIdx.x, cg = C / 32;
+    const float m = (float)cg * (float)HW;
+    for (int c0 = 0; c0 < cg; c0 += 64) {                          // (cg <= 64 for every C <= 2048: one trip)
+        const int j = c0 + lane, c = g * cg + j;
+        const bool on = j < cg;
+        float dg = 0.f, dbt = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float mean = gstat[((long)n * 32 + g) * 2], rstd = gstat[((long)n * 32 + g) * 2 + 1];
+            // group sums over ALL channels of the group (also when cg > 64: every lane walks its strided share)
+            float a1 = 0.f, a2 = 0.f;
+            for (int jj = lane; jj < cg; jj += 64) {
+                const int cc = g * cg + jj;
+                const float s1 = S[((long)n * C + cc) * 2], s2 = S[((long)n * C + cc) * 2 + 1];
+                const float gh = gamma[cc] * (ss ? 1.f + ss[(long)n * 2 * C + cc] : 1.f);
+                a1 += gh * s1;
+                a2 += gh * (rstd * (s2 - mean * s1));
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); }
+            const float M1 = a1 / m, M2 = a2 / m;
+            if (on) {
+                const float s1 = S[((long)n * C + c) * 2], s2 = S[((long)n * C + c) * 2 + 1];
+                const float one_s = ss ? 1.f + ss[(long)n * 2 * C + c] : 1.f;
+                const float xhS = rstd * (s2 - mean * s1);
+                k1[(long)n * C + c] = rstd * gamma[c] * one_s;
+                k2[(long)n * C + c] = -rstd * rstd * M2;
+                k3[(long)n * C + c] = -rstd * M1 + rstd * rstd * mean * M2;
+                dg += one_s * xhS;
+                dbt += one_s * s1;
+                if (dss) {
+                    dss[(long)n * 2 * C + c] = gamma[c] * xhS + beta[c] * s1;
+                    dss[(long)n * 2 * C + C + c] = s1;
+                }
+            }
+        }
+        if (on) { dgamma[c] = dg; dbeta[c] = dbt; }
     }
 }
 
@@ -249,8 +317,8 @@ int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const floa
     p.P = (long)N * p.Hout * p.Wout;
     HL_REQUIRE(p.P * Cy * 4 < (1L << 31) && (long)N * H * W * Cx * 4 < (1L << 31), "hl_conv2d_wgrad_nhwc: tensors of 2 GiB and more are not addressed");
     const long tiles = (long)p.n_co * p.n_ci * ks * ks;
-    long slabs = (2048 + tiles - 1) / tiles;                     // ~2048 workgroups
-    const long max_slabs = (p.P + 255) / 256;                    // at least 256 pixels (32 pairs per wave) per workgroup
+    long slabs = (1024 + tiles - 1) / tiles;                     // ~1024 workgroups (4 per CU); every workgroup ends in 4096 atomics
+    const long max_slabs = (p.P + 1023) / 1024;                  // at least 1024 pixels (128 pairs per wave) per workgroup
     if (slabs > max_slabs) slabs = max_slabs;
     if (slabs < 1) slabs = 1;
     p.slab = ((p.P + slabs - 1) / slabs + 7) / 8 * 8;            // multiple of 8: the waves' pair interleave starts aligned
@@ -273,8 +341,8 @@ int hl_gn_backward_reduce(const float *x, long x_pitch, const float *dout, int N
     int k = 256 / cq; if (k < 1) k = 1;
     const int threads = cq * k;
     int chunks = HW / (k * 16); if (chunks < 1) chunks = 1; if (chunks > 256) chunks = 256;
-    hipLaunchKernelGGL(k_gn_bwd_reduce, dim3(chunks, N), dim3(threads), 0, (hipStream_t)stream, x, x_pitch, dout, (long)C, HW, C, chunks, coefA,
-                       coefB, silu, S);
+    hipLaunchKernelGGL(k_gn_bwd_reduce, dim3(chunks, N), dim3(threads), (size_t)2 * C * sizeof(float), (hipStream_t)stream, x, x_pitch, dout, (long)C,
+                       HW, C, chunks, coefA, coefB, silu, S);
     return check_launch("k_gn_bwd_reduce");
 }
 
@@ -286,6 +354,33 @@ int hl_gn_backward_apply(const float *x, long x_pitch, const float *dout, int N,
     hipLaunchKernelGGL(k_gn_bwd_apply, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, x_pitch, dout, (long)C, (long)HW, npix, C, coefA,
                        coefB, silu, k1, k2, k3, dx_add, (long)C, dx, (long)C);
     return check_launch("k_gn_bwd_apply");
+}
+
+int hl_groupnorm_train_forward(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta, const float *scale_shift,
+                               int silu, float *coefA, float *coefB, float *gstat, float *y, void *scratch, size_t scratch_bytes, void *stream) {
+    HL_REQUIRE(x && gamma && beta && coefA && coefB && gstat && y, "hl_groupnorm_train_forward: null argument");
+    HL_REQUIRE(scratch && scratch_bytes >= gn_scratch_floats(N) * sizeof(float), "hl_groupnorm_train_forward: scratch too small");
+    View v; v.p = const_cast<float *>(x); v.N = N; v.H = H; v.W = W; v.C = C; v.pitch = C;
+    int rc = groupnorm_coef(v, gamma, beta, scale_shift, 2L * C, coefA, coefB, static_cast<float *>(scratch), (hipStream_t)stream, gstat);
+    if (rc) return rc;
+    return gn_apply(v, coefA, coefB, silu, y, (hipStream_t)stream);
+}
+
+int hl_groupnorm_train_backward(const float *x, const float *dout, int N, int H, int W, int C, const float *coefA, const float *coefB, int silu,
+                                const float *gstat, const float *gamma, const float *beta, const float *scale_shift, float *dx,
+                                float *dgamma, float *dbeta, float *dscale_shift, void *scratch, size_t scratch_bytes, void *stream) {
+    HL_REQUIRE(x && dout && coefA && coefB && gstat && gamma && beta && dgamma && dbeta, "hl_groupnorm_train_backward: null argument");
+    HL_REQUIRE(C % 32 == 0 && (scale_shift == nullptr) == (dscale_shift == nullptr), "hl_groupnorm_train_backward: bad argument");
+    HL_REQUIRE(scratch && scratch_bytes >= (size_t)N * C * 5 * sizeof(float), "hl_groupnorm_train_backward: scratch too small (N*C*5 floats)");
+    float *S = static_cast<float *>(scratch), *k1 = S + (size_t)N * C * 2, *k2 = k1 + (size_t)N * C, *k3 = k2 + (size_t)N * C;
+    HL_HIP(hipMemsetAsync(S, 0, (size_t)N * C * 2 * sizeof(float), (hipStream_t)stream));
+    int rc = hl_gn_backward_reduce(x, C, dout, N, H * W, C, coefA, coefB, silu, S, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gn_bwd_coef, dim3(32), dim3(64), 0, (hipStream_t)stream, S, gstat, gamma, beta, scale_shift, N, H * W, C, k1, k2, k3, dgamma,
+                       dbeta, dscale_shift);
+    rc = check_launch("k_gn_bwd_coef");
+    if (rc || !dx) return rc;
+    return hl_gn_backward_apply(x, C, dout, N, H * W, C, coefA, coefB, silu, k1, k2, k3, nullptr, dx, stream);
 }
 
 int hl_upsample2_backward_nhwc(const float *d_up, int N, int H, int W, int C, float *dx, void *stream) {

@@ -9,8 +9,8 @@ include/humanliff_hip.h), activations NHWC fp32:
                    d input   the same forward kernels on the output gradient with flipped, channel-transposed weights
                              (stride 2: hl_zero_stuff2_nhwc first; nearest-x2 upsample: hl_upsample2_backward_nhwc afterwards)
                    d weight  hl_conv2d_wgrad_nhwc (pixels-as-K MFMA GEMM), bias gradient in the same launch
-    _GroupNormAct  forward   hl_groupnorm_coef (statistics) + hl_gn_apply_nhwc (affine, scale/shift, SiLU)
-                   backward  hl_gn_backward_reduce + hl_gn_backward_apply; parameter / scale-shift gradients from the (N,C) reductions
+    _GroupNormAct  forward   hl_groupnorm_train_forward (statistics -> affine with scale/shift -> apply + SiLU)
+                   backward  hl_groupnorm_train_backward (per-(n,c) reductions, the (N,C) algebra, dx; parameter / scale-shift gradients)
     _Attention     forward   hl_attention_nhwc (fp32 flash-style kernel)
                    backward  recomputed probabilities, five batched GEMMs through torch.bmm (rocBLAS - a plain library GEMM; 2 % of the
                              network's FLOPs)
@@ -120,59 +120,36 @@ class _GroupNormAct(th.autograd.Function):
         L = _lib.lib()
         N, H, W, Cc = x.shape
         dev = x.device
-        one, zero = th.ones(Cc, device=dev), th.zeros(Cc, device=dev)
-        rstd, nmr = th.empty((N, Cc), device=dev), th.empty((N, Cc), device=dev)       # per channel: rstd of its group, -mean*rstd
-        scr = th.empty(N * 128 * 64 + 64, device=dev)
-        with _lib.on(dev):
-            _lib.check(L.hl_groupnorm_coef(_lib.ptr(x), N, H, W, Cc, _lib.ptr(one), _lib.ptr(zero), None, _lib.ptr(rstd), _lib.ptr(nmr),
-                                           _lib.ptr(scr), scr.numel() * 4, _lib.stream_ptr()), "hl_groupnorm_coef")
-        mean = -nmr / rstd
-        g1 = gamma[None] * rstd
-        A, B = g1, beta[None] + gamma[None] * nmr
-        if ss is not None:
-            sc, sh = ss[:, :Cc], ss[:, Cc:]
-            A, B = A * (1 + sc), B * (1 + sc) + sh
-        A, B = A.contiguous(), B.contiguous()
+        A, B = th.empty((N, Cc), device=dev), th.empty((N, Cc), device=dev)
+        gstat = th.empty((N, 32, 2), device=dev)                      # (mean, rstd) per group
         y = th.empty((N, H, W, Cc), device=dev)
+        scr = th.empty(N * 8192, device=dev)
+        ssc = ss.contiguous() if ss is not None else None
         with _lib.on(dev):
-            _lib.check(L.hl_gn_apply_nhwc(_lib.ptr(x), Cc, N, H * W, Cc, _lib.ptr(A), _lib.ptr(B), 1 if silu else 0, _lib.ptr(y), _lib.stream_ptr()),
-                       "hl_gn_apply_nhwc")
-        ctx.save_for_backward(x, A, B, rstd, mean, gamma, beta, ss if ss is not None else th.empty(0, device=dev))
+            _lib.check(L.hl_groupnorm_train_forward(_lib.ptr(x), N, H, W, Cc, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(ssc), 1 if silu else 0,
+                                                    _lib.ptr(A), _lib.ptr(B), _lib.ptr(gstat), _lib.ptr(y), _lib.ptr(scr), scr.numel() * 4,
+                                                    _lib.stream_ptr()), "hl_groupnorm_train_forward")
+        ctx.save_for_backward(x, A, B, gstat, gamma, beta, ssc if ssc is not None else th.empty(0, device=dev))
         ctx.silu = silu
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, A, B, rstd, mean, gamma, beta, ss = ctx.saved_tensors
+        x, A, B, gstat, gamma, beta, ss = ctx.saved_tensors
         has_ss = ss.numel() > 0
         L = _lib.lib()
         N, H, W, Cc = x.shape
         dev = x.device
         dy = dy.contiguous()
-        S = th.zeros((N, Cc, 2), device=dev)
+        dx = th.empty_like(x) if ctx.needs_input_grad[0] else None
+        dgamma, dbeta = th.empty(Cc, device=dev), th.empty(Cc, device=dev)
+        dss = th.empty((N, 2 * Cc), device=dev) if has_ss else None
+        scr = th.empty(N * Cc * 5, device=dev)
         with _lib.on(dev):
-            _lib.check(L.hl_gn_backward_reduce(_lib.ptr(x), Cc, _lib.ptr(dy), N, H * W, Cc, _lib.ptr(A), _lib.ptr(B), 1 if ctx.silu else 0, _lib.ptr(S),
-                                               _lib.stream_ptr()), "hl_gn_backward_reduce")
-        S1, S2 = S[..., 0], S[..., 1]
-        one_s = 1 + ss[:, :Cc] if has_ss else 1.0
-        ghat = gamma[None] * one_s                                     # d u / d x_hat
-        xhS = rstd * (S2 - mean * S1)                                  # sum_p du * x_hat
-        cpg = Cc // 32
-        m = float(cpg * H * W)
-        grp = lambda t: t.reshape(N, 32, cpg).sum(2, keepdim=True).expand(N, 32, cpg).reshape(N, Cc)  # noqa: E731
-        M1, M2 = grp(ghat * S1) / m, grp(ghat * xhS) / m
-        k1 = (rstd * ghat).contiguous()
-        k2 = (-rstd * rstd * M2).contiguous()
-        k3 = (-rstd * M1 + rstd * rstd * mean * M2).contiguous()
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = th.empty_like(x)
-            with _lib.on(dev):
-                _lib.check(L.hl_gn_backward_apply(_lib.ptr(x), Cc, _lib.ptr(dy), N, H * W, Cc, _lib.ptr(A), _lib.ptr(B), 1 if ctx.silu else 0,
-                                                  _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(k3), None, _lib.ptr(dx), _lib.stream_ptr()), "hl_gn_backward_apply")
-        dgamma = (one_s * xhS).sum(0)
-        dbeta = (one_s * S1).sum(0) if has_ss else S1.sum(0)
-        dss = th.cat([gamma[None] * xhS + beta[None] * S1, S1], dim=1) if has_ss else None
+            _lib.check(L.hl_groupnorm_train_backward(_lib.ptr(x), _lib.ptr(dy), N, H, W, Cc, _lib.ptr(A), _lib.ptr(B), 1 if ctx.silu else 0,
+                                                     _lib.ptr(gstat), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(ss) if has_ss else None, _lib.ptr(dx),
+                                                     _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dss), _lib.ptr(scr), scr.numel() * 4,
+                                                     _lib.stream_ptr()), "hl_groupnorm_train_backward")
         return dx, dgamma, dbeta, dss, None
 
 

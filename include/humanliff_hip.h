@@ -351,6 +351,16 @@ int hl_gn_backward_reduce(const float *x, long x_pitch, const float *dout, int N
                           int silu, float *S, void *stream);
 int hl_gn_backward_apply(const float *x, long x_pitch, const float *dout, int N, int HW, int C, const float *coefA, const float *coefB,
                          int silu, const float *k1, const float *k2, const float *k3, const float *dx_add, float *dx, void *stream);
+/* The two as the training path uses them (unet_train.py), the (N,C) algebra between the passes in a kernel of its own:
+ * forward   y = silu?( GroupNorm32(x) [* (1 + scale) + shift] ), x / y dense (N,H,W,C); scale_shift (N,2C) = [scale | shift] or NULL
+ *           (unet.py:203-206); also returns the affine coefA / coefB (N,C) and gstat (N,32,2) = (mean, rstd) per group for the backward.
+ *           scratch: N * 32 KiB.
+ * backward  dx (may be NULL), dgamma / dbeta (C) (written, not accumulated), dscale_shift (N,2C) (iff scale_shift); scratch: N*C*5 floats. */
+int hl_groupnorm_train_forward(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta, const float *scale_shift,
+                               int silu, float *coefA, float *coefB, float *gstat, float *y, void *scratch, size_t scratch_bytes, void *stream);
+int hl_groupnorm_train_backward(const float *x, const float *dout, int N, int H, int W, int C, const float *coefA, const float *coefB, int silu,
+                                const float *gstat, const float *gamma, const float *beta, const float *scale_shift, float *dx,
+                                float *dgamma, float *dbeta, float *dscale_shift, void *scratch, size_t scratch_bytes, void *stream);
 /* dx (N,H,W,C) = sums of the 2x2 blocks of d_up (N,2H,2W,C): backward of the nearest-x2 upsample (unet.py:77). */
 int hl_upsample2_backward_nhwc(const float *d_up, int N, int H, int W, int C, float *dx, void *stream);
 /* z (N,2Ho,2Wo,C): z[2y][2x] = dy[y][x], zero elsewhere - backward-data of a stride-2 3x3 conv = flipped 3x3 conv of z. */
