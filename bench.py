@@ -404,6 +404,20 @@ def bench_render(args, rank, world, dev):
                      "algorithmic_tflops": round(R * FINE_FLOP_PER_RAY_TOTAL / (view_ms * 1e-3) / 1e12, 2),
                      "note": "algorithmic = the reference's schedule, 128 x 79 616 + 256 x 132 608 FLOP per ray (SURVEY 8(d)); this "
                              "schedule evaluates every point once (256 x 132 608) with bit-identical images"}}
+    # ---- extract_geometry's density field at the reference's resolution (renderer.py:290-321): 512^3 lattice points
+    #      through the tri-plane lookup + density MLP (79 616 FLOP per point), the input of marching cubes ----
+    if world == 1:
+        r.density_grid(tp, planes, resolution=64)      # warm-up
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        grid = r.density_grid(tp, planes, resolution=512)
+        torch.cuda.synchronize()
+        dg = time.perf_counter() - tg
+        roof["density_grid"] = {"resolution": 512, "points": 512 ** 3, "ms": round(dg * 1e3, 2),
+                                "tflops": round(512 ** 3 * 79616 / dg / 1e12, 2), "finite": bool(torch.isfinite(grid).all()),
+                                "what": "Renderer.density_grid(resolution=512): the field extract_geometry hands to marching cubes, on k_march<false> "
+                                        "(coarse density pass), including the host-side launch loop and the untile copies"}
+        del grid
     return secs, roof, views * R
 
 

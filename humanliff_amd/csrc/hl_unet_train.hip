@@ -126,13 +126,17 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WgradK p) {
                     const float v = ((acc[i][j][r] + red[0][i * 2 + j][r][lane]) + red[1][i * 2 + j][r][lane]) + red[2][i * 2 + j][r][lane];
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
                     const int co = co0 + 2 * row + i, cc = ci + j;
-                    if (co < p.Cout_w && cc < p.Cin_w) atomicAdd(p.dw + ((long)co * p.Cin_w + cc) * taps + tap, v);
+                    if (co < p.Cout_w && cc < p.Cin_w) {
+                        float *q = p.dw + ((long)co * p.Cin_w + cc) * taps + tap;
+                        if (gridDim.y == 1) *q = v; else atomicAdd(q, v);     // a single slab owns its block of dW: plain stores
+                    }
                 }
     }
     if (want_b) {
         bs0 += __shfl_xor(bs0, 32);
         bs1 += __shfl_xor(bs1, 32);
         if (kh == 0) {
+            // (the four waves of the workgroup add their shares: atomics also with a single slab)
             if (co0 + 2 * m < p.Cout_w) atomicAdd(p.db + co0 + 2 * m, bs0);
             if (co0 + 2 * m + 1 < p.Cout_w) atomicAdd(p.db + co0 + 2 * m + 1, bs1);
         }

@@ -1,6 +1,6 @@
 """UNet training step at the reference's configuration (README.md:104: production F4 network, microbatch 2, MSE loss):
 GaussianDiffusion.training_losses -> backward through the HIP kernels (unet_train.py) -> AdamW step.
-    python scripts/unet_train_bench.py [iters] [batch]"""
+    python scripts/unet_train_bench.py [iters] [batch] [twin]      (twin: the same step through the PyTorch-op twin on MIOpen / rocBLAS)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +9,7 @@ import bench
 dev = torch.device("cuda:0")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+twin = len(sys.argv) > 3 and sys.argv[3] == "twin"
 model, diffusion, _ = bench.build_unet(dev)
 model.train()
 opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.0)
@@ -20,7 +21,7 @@ y = torch.zeros((B,), dtype=torch.int64, device=dev)
 
 def step():
     t = torch.randint(0, 1000, (B,), device=dev, generator=g)
-    loss = diffusion.training_losses(model, x0, xc, t, model_kwargs={"y": y})["loss"].mean()
+    loss = diffusion.training_losses(model.forward_autograd if twin else model, x0, xc, t, model_kwargs={"y": y})["loss"].mean()
     loss.backward()
     opt.step()
     opt.zero_grad(set_to_none=True)
@@ -34,5 +35,5 @@ for _ in range(iters):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / iters
 fl = 3 * 2015.4e9 * B          # forward + backward-data + backward-weights, direct-convolution FLOPs
-print(f"UNet training step, batch {B}: {dt * 1e3:.1f} ms/step = {B / dt:.2f} samples/s = {fl / dt / 1e12:.1f} TFLOP/s algorithmic "
+print(f"UNet training step ({'PyTorch-op twin, MIOpen' if twin else 'HIP kernels'}), batch {B}: {dt * 1e3:.1f} ms/step = {B / dt:.2f} samples/s = {fl / dt / 1e12:.1f} TFLOP/s algorithmic "
       f"(3 x 2015.4 GFLOP per sample); loss {float(loss):.4f}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
