@@ -649,8 +649,13 @@ def cpu_baseline_render(threads, n_rays=16384, dev=None):
     with torch.no_grad():
         rgb, acc, depth = ro.render_rays(mlp, planes[0], torch.tensor(syn.WORLD_BOUNDS), o[sl], d[sl], nr[sl], fr[sl], 128, 128, u=u)
     dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    with torch.no_grad():       # the 4 096-ray point of SURVEY 8(d) (the reference's own chunking granularity class)
+        ro.render_rays(mlp, planes[0], torch.tensor(syn.WORLD_BOUNDS), o[sl][:4096], d[sl][:4096], nr[sl][:4096], fr[sl][:4096], 128, 128, u=u[:4096])
+    dt4 = time.perf_counter() - t1
     out = {"value": round(n_rays / dt / 1e6, 6), "unit": "Mrays/sec", "cores": threads, "kind": "port",
-           "sample": f"oracle (PyTorch-CPU fp32 restatement) render of {n_rays} rays of one 512x512 view at 128+128 samples"}
+           "sample": f"oracle (PyTorch-CPU fp32 restatement) render of {n_rays} rays of one 512x512 view at 128+128 samples",
+           "rays4096": {"value": round(4096 / dt4 / 1e6, 6), "unit": "Mrays/sec", "sample": "same, 4 096 rays"}}
     parity = None
     if dev is not None:
         from humanliff_amd.NeRF import Renderer

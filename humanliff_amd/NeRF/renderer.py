@@ -293,7 +293,7 @@ class Renderer(nn.Module):
         return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
 
     # ---- the density grid behind extract_geometry ---------------------
-    def density_grid(self, tp_input, tri_planes=None, resolution=512, rays_per_launch=1 << 15):
+    def density_grid(self, tp_input, tri_planes=None, resolution=512, rays_per_launch=1 << 17):
         """u[x,y,z] = -sigma_raw at the lattice linspace(bound_min, bound_max, resolution)^3, exactly the field
         the reference hands to marching cubes (renderer.py:290-321) - 134 M density-MLP evaluations at 512^3.
 
@@ -346,9 +346,11 @@ class Renderer(nn.Module):
                 out[i:j] = untile_rows(rec[:, 0].contiguous(), j - i, N)
             return (-out).reshape(N, N, N)
         tmp = torch.empty(T32 * N, dtype=torch.float32, device=dev)
+        # (131 072 columns per launch = 512 workgroups: with 32 768 - 128 workgroups - half of the CUs sat idle, 512^3 took 184 ms)
+        zfull = Z.to(dev)[None].expand(min(rays_per_launch, N * N), N).contiguous()
         for i in range(0, N * N, rays_per_launch):
             j = min(N * N, i + rays_per_launch)
-            z = Z.to(dev)[None].expand(j - i, N).contiguous()
+            z = zfull[:j - i]
             ro, rd = rays_o[i:j].contiguous(), rays_d[i:j].contiguous()
             _lib.check(L.hl_render_coarse(_lib.ptr(packed), _lib.ptr(pp), H, W, _lib.ptr(bounds), _lib.ptr(ro), _lib.ptr(rd),
                                           _lib.ptr(zero[i:j]), _lib.ptr(zero[i:j]), _lib.ptr(z), j - i, N, _lib.ptr(tmp),

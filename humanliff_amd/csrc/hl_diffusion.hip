@@ -16,7 +16,8 @@ template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void k_step(const float *__restrict__ x, const float *__restrict__ eps,
                                               const float *__restrict__ noise, const float *__restrict__ coef,
                                               const int64_t *__restrict__ t, float *__restrict__ sample,
-                                              float *__restrict__ x0_out, long n, int T, int clip, int has_noise) {
+                                              float *__restrict__ x0_out, long n, int T, int clip, int has_noise, int x0_given,
+                                              const float *__restrict__ logvar) {
     const int b = blockIdx.y;
     const int64_t tb = t[b];
     // a timestep outside the (T,8) table (the reference's numpy indexing raises IndexError, gaussian_diffusion.py:859) never
@@ -27,9 +28,11 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ x, const
     const float r = c[0] + poison, rm1 = c[1], c0 = c[2], c1 = c[3];
     const float nz = has_noise ? (tb != 0 ? 1.f : 0.f) * c[4] : 0.f;
     const long base = (long)b * n;
-    auto one = [&](float xv, float ev, float nv, float &sv, float &x0v) {
-        float x0 = r * xv - rm1 * ev;
-        if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    // logvar (learned variances, gaussian_diffusion.py:262-276): per-element model_log_variance replaces the table's sigma
+    auto one = [&](float xv, float ev, float nv, float lv, float &sv, float &x0v) {
+        // x0_given: `eps` holds pred_xstart already processed by the caller (denoised_fn + clamp, gaussian_diffusion.py:293-299)
+        float x0 = x0_given ? ev + poison : r * xv - rm1 * ev;
+        if (clip && !x0_given) x0 = fminf(fmaxf(x0, -1.f), 1.f);
         float mean;
         if (MODE == 0) {
             mean = c0 * x0 + c1 * xv;
@@ -37,7 +40,8 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ x, const
             const float e2 = (r * xv - x0) / rm1;
             mean = x0 * c0 + c1 * e2;
         }
-        sv = mean + nz * nv;
+        const float sg = logvar ? (has_noise && tb != 0 ? expf(0.5f * lv) : 0.f) : nz;
+        sv = mean + sg * nv;
         x0v = x0;
     };
     if (VEC) {
@@ -46,16 +50,17 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ x, const
             const f32x4 xv = reinterpret_cast<const f32x4 *>(x + base)[i];
             const f32x4 ev = reinterpret_cast<const f32x4 *>(eps + base)[i];
             const f32x4 nv = reinterpret_cast<const f32x4 *>(noise + base)[i];
+            const f32x4 lv = logvar ? reinterpret_cast<const f32x4 *>(logvar + base)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 sv, zv;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { float s, z; one(xv[k], ev[k], nv[k], s, z); sv[k] = s; zv[k] = z; }
+            for (int k = 0; k < 4; ++k) { float s, z; one(xv[k], ev[k], nv[k], lv[k], s, z); sv[k] = s; zv[k] = z; }
             reinterpret_cast<f32x4 *>(sample + base)[i] = sv;
             if (x0_out) reinterpret_cast<f32x4 *>(x0_out + base)[i] = zv;
         }
     } else {
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
             float s, z;
-            one(x[base + i], eps[base + i], noise[base + i], s, z);
+            one(x[base + i], eps[base + i], noise[base + i], logvar ? logvar[base + i] : 0.f, s, z);
             sample[base + i] = s;
             if (x0_out) x0_out[base + i] = z;
         }
@@ -66,20 +71,22 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ x, const
 
 extern "C" int hl_diffusion_step(int mode, const float *x, const float *eps, const float *noise, const float *coef,
                                  const int64_t *t, float *sample, float *pred_xstart, int64_t n_per_sample, int B, int T, int clip,
-                                 void *stream) {
+                                 const float *log_variance, void *stream) {
     HL_REQUIRE(x && eps && coef && t && sample, "hl_diffusion_step: null argument");
     const int has_noise = noise != nullptr;
     if (!noise) noise = x;  // never contributes (factor 0); keeps the loads in bounds
-    HL_REQUIRE(mode == 0 || mode == 1, "hl_diffusion_step: mode %d", mode);
+    HL_REQUIRE(mode >= 0 && mode <= 3, "hl_diffusion_step: mode %d", mode);
+    const int x0_given = mode >> 1;
+    mode &= 1;
     HL_REQUIRE(n_per_sample > 0 && B > 0 && T > 0, "hl_diffusion_step: bad sizes");
     const bool vec = (n_per_sample % 4 == 0) && (((uintptr_t)x | (uintptr_t)eps | (uintptr_t)noise | (uintptr_t)sample |
-                                                   (uintptr_t)pred_xstart) % 16 == 0);
+                                                   (uintptr_t)pred_xstart | (uintptr_t)log_variance) % 16 == 0);
     const long work = vec ? n_per_sample / 4 : n_per_sample;
     long gx = (work + 255) / 256;
     if (gx > 1024) gx = 1024;
     dim3 grid((unsigned)gx, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-#define HL_GO(M, V) hipLaunchKernelGGL((k_step<M, V>), grid, dim3(256), 0, st, x, eps, noise, coef, t, sample, pred_xstart, (long)n_per_sample, T, clip, has_noise)
+#define HL_GO(M, V) hipLaunchKernelGGL((k_step<M, V>), grid, dim3(256), 0, st, x, eps, noise, coef, t, sample, pred_xstart, (long)n_per_sample, T, clip, has_noise, x0_given, log_variance)
     if (mode == 0) { if (vec) HL_GO(0, true); else HL_GO(0, false); }
     else { if (vec) HL_GO(1, true); else HL_GO(1, false); }
 #undef HL_GO

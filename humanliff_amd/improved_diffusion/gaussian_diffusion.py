@@ -8,8 +8,9 @@ Changed: the per-step scalars live in device tables built once (the reference re
 six times per step, :850-863); timesteps come from a device-resident table (the reference builds a tensor
 from a Python list every step, :474); everything after the model call is ONE kernel.
 
-Sampling covers the shipped configuration: EPSILON prediction with FIXED_LARGE / FIXED_SMALL variance.
-Learned variances, x0 / x_{t-1} prediction and the VLB losses raise NotImplementedError.
+Sampling covers EPSILON and START_X prediction with fixed (FIXED_LARGE - the shipped configuration - / FIXED_SMALL) or learned
+(LEARNED / LEARNED_RANGE, learn_sigma=True) variances and an optional denoised_fn; x_{t-1} prediction and the VLB training losses
+raise NotImplementedError.
 """
 import enum
 import math
@@ -100,7 +101,7 @@ class GaussianDiffusion:
             return v, np.log(v)
         if self.model_var_type == ModelVarType.FIXED_SMALL:
             return self.posterior_variance, self.posterior_log_variance_clipped
-        raise NotImplementedError("learned variances (learn_sigma=True) are not built; shipped config is FIXED_LARGE")
+        raise ValueError(f"{self.model_var_type} has no fixed variance table")
 
     def _table(self, kind, device, eta=0.0):
         """(T,8) fp32 coefficient table for hl_diffusion_step + the index tensors of the loop."""
@@ -114,10 +115,10 @@ class GaussianDiffusion:
         tab[:, 0] = f32(self.sqrt_recip_alphas_cumprod)
         tab[:, 1] = f32(self.sqrt_recipm1_alphas_cumprod)
         if kind == "ddpm":
-            _, logvar = self._fixed_variance()
             tab[:, 2] = f32(self.posterior_mean_coef1)
             tab[:, 3] = f32(self.posterior_mean_coef2)
-            tab[:, 4] = th.exp(0.5 * f32(logvar))
+            if self.model_var_type in (ModelVarType.FIXED_LARGE, ModelVarType.FIXED_SMALL):
+                tab[:, 4] = th.exp(0.5 * f32(self._fixed_variance()[1]))     # (learned variances come per element, hl_diffusion_step log_variance)
         else:
             ab, abp = f32(self.alphas_cumprod), f32(self.alphas_cumprod_prev)
             sigma = eta * th.sqrt((1 - abp) / (1 - ab)) * th.sqrt(1 - ab / abp)
@@ -128,15 +129,11 @@ class GaussianDiffusion:
         self._tables[key] = hit
         return hit
 
-    def _require_eps_model(self):
-        if self.model_mean_type != ModelMeanType.EPSILON:
-            raise NotImplementedError("only epsilon prediction (predict_xstart=False) is built")
-
-    def _step(self, mode, x, eps, noise, t, clip, eta=0.0, want_x0=True):
-        self._require_eps_model()
+    def _step(self, mode, x, eps, noise, t, clip, eta=0.0, want_x0=True, x0_given=False, logvar=None):
         if not x.is_cuda:
             raise RuntimeError("sampling needs CUDA(HIP) tensors; there is no CPU path")
         tab = self._table("ddpm" if mode == 0 else "ddim", x.device, eta)
+        lvf = logvar.to(th.float32).contiguous() if (logvar is not None and mode == 0) else None
         xf, ef = x.to(th.float32).contiguous(), eps.to(th.float32).contiguous()
         nf = noise.to(th.float32).contiguous() if noise is not None else None
         out = th.empty_like(xf)
@@ -144,9 +141,9 @@ class GaussianDiffusion:
         B = x.shape[0]
         tt = t.to(device=x.device, dtype=th.int64).contiguous()
         with _lib.on(x.device):
-            _lib.check(_lib.lib().hl_diffusion_step(mode, _lib.ptr(xf), _lib.ptr(ef), _lib.ptr(nf), _lib.ptr(tab), _lib.ptr(tt),
+            _lib.check(_lib.lib().hl_diffusion_step(mode + (2 if x0_given else 0), _lib.ptr(xf), _lib.ptr(ef), _lib.ptr(nf), _lib.ptr(tab), _lib.ptr(tt),
                                                     _lib.ptr(out), _lib.ptr(x0), xf.numel() // B, B, self.num_timesteps,
-                                                    1 if clip else 0, _lib.stream_ptr()), "hl_diffusion_step")
+                                                    1 if clip else 0, _lib.ptr(lvf), _lib.stream_ptr()), "hl_diffusion_step")
         return out, x0
 
     # ---- q(.) helpers (plain tensor algebra on whatever device the inputs live on) ------------------
@@ -194,34 +191,56 @@ class GaussianDiffusion:
         if lo < 0 or hi >= self.num_timesteps:
             raise IndexError(f"timestep {hi if hi >= self.num_timesteps else lo} is out of range for a {self.num_timesteps}-step schedule")
 
-    def _model_eps(self, model, x, t, x_cond, model_kwargs):
+    def _model_out(self, model, x, t, x_cond, model_kwargs):
+        """The model call of p_mean_variance (:258-277) -> (mean-type output (B,C,...), model_log_variance or None).
+        Learned variances (learn_sigma=True): the network emits 2C channels; LEARNED reads the second half as the log-variance,
+        LEARNED_RANGE interpolates between the posterior's clipped log-variance and log(beta) with frac = (v + 1) / 2."""
         B, Cc = x.shape[:2]
         assert t.shape == (B,)
-        eps = model(x, self._scale_timesteps(t), x_cond, **(model_kwargs or {}))
-        if eps.shape != x.shape:
-            raise NotImplementedError("model output has extra channels (learn_sigma=True): not built")
-        return eps
+        out = model(x, self._scale_timesteps(t), x_cond, **(model_kwargs or {}))
+        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
+            assert out.shape == (B, Cc * 2, *x.shape[2:])
+            out, v = th.split(out, Cc, dim=1)
+            if self.model_var_type == ModelVarType.LEARNED:
+                return out, v
+            min_log = _extract_into_tensor(self.posterior_log_variance_clipped, t, x.shape)
+            max_log = _extract_into_tensor(np.log(self.betas), t, x.shape)
+            frac = (v + 1) / 2
+            return out, frac * max_log + (1 - frac) * min_log
+        assert out.shape == x.shape
+        return out, None
+
+    def _update(self, mode, x, t, out, logvar, noise, clip_denoised, denoised_fn, eta=0.0):
+        """Everything after the model call, one fused kernel: EPSILON prediction goes in as eps; START_X prediction, or any
+        denoised_fn, as the processed pred_xstart (process_xstart, :293-299)."""
+        if self.model_mean_type == ModelMeanType.PREVIOUS_X:
+            raise NotImplementedError("model_mean_type PREVIOUS_X is not built (no script of the reference selects it)")
+        if self.model_mean_type == ModelMeanType.START_X or denoised_fn is not None:
+            x0 = out if self.model_mean_type == ModelMeanType.START_X else self._predict_xstart_from_eps(x, t, out)
+            if denoised_fn is not None:
+                x0 = denoised_fn(x0)
+            if clip_denoised:
+                x0 = x0.clamp(-1, 1)
+            return self._step(mode, x, x0, noise, t, False, eta=eta, x0_given=True, logvar=logvar)
+        return self._step(mode, x, out, noise, t, clip_denoised, eta=eta, logvar=logvar)
 
     def p_mean_variance(self, model, x, t, x_cond=None, clip_denoised=True, denoised_fn=None, model_kwargs=None):
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn is not built into the fused update")
         self._check_timesteps(t)
-        eps = self._model_eps(model, x, t, x_cond, model_kwargs)
-        mean, x0 = self._step(0, x, eps, None, t, clip_denoised)
-        var, logvar = self._fixed_variance()
-        return {"mean": mean,
-                "variance": _extract_into_tensor(var, t, x.shape),
-                "log_variance": _extract_into_tensor(logvar, t, x.shape),
-                "pred_xstart": x0}
+        out, logvar = self._model_out(model, x, t, x_cond, model_kwargs)
+        mean, x0 = self._update(0, x, t, out, None, None, clip_denoised, denoised_fn)
+        if logvar is None:
+            var, lv = self._fixed_variance()
+            variance, log_variance = _extract_into_tensor(var, t, x.shape), _extract_into_tensor(lv, t, x.shape)
+        else:
+            variance, log_variance = th.exp(logvar), logvar
+        return {"mean": mean, "variance": variance, "log_variance": log_variance, "pred_xstart": x0}
 
     def _sample(self, mode, model, x, t, x_cond, clip_denoised, denoised_fn, model_kwargs, eta=0.0, trusted=False):
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn is not built into the fused update")
         if not trusted:
             self._check_timesteps(t)
-        eps = self._model_eps(model, x, t, x_cond, model_kwargs)
+        out, logvar = self._model_out(model, x, t, x_cond, model_kwargs)
         noise = th.randn_like(x)  # ddim: drawn even when eta == 0, like the reference (:520)
-        sample, x0 = self._step(mode, x, eps, noise, t, clip_denoised, eta=eta)
+        sample, x0 = self._update(mode, x, t, out, logvar, noise, clip_denoised, denoised_fn, eta=eta)
         return {"sample": sample, "pred_xstart": x0}
 
     def p_sample(self, model, x, x_cond, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):

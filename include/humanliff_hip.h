@@ -314,12 +314,16 @@ int hl_unet_profile_read_ex(void *handle, double *h_ms, double *h_flops, double 
  *   mode 0 (p_sample):  x0 = clip(r*x - rm1*eps); sample = (c0*x0 + c1*x) + (t!=0) * c2 * noise
  *   mode 1 (ddim):      x0 = clip(r*x - rm1*eps); e = (r*x - x0)/rm1;
  *                       sample = (x0*c0 + c1*e) + (t!=0) * c2 * noise
+ *   mode 2 / 3:         as 0 / 1 with `eps` holding the already processed pred_xstart (the caller applied denoised_fn and the
+ *                       clamp, gaussian_diffusion.py:293-299); `clip` is ignored
+ *   log_variance:       NULL = fixed variance (c2 of the table); else the per-element model_log_variance of a learned-variance model
+ *                       (gaussian_diffusion.py:262-276), same shape as x: the noise term of mode 0 / 2 becomes (t!=0)*exp(lv/2)*noise
  * t: (B) int64 indices into the table of T rows (a t outside [0, T) reads nothing out of bounds and turns that
  * sample's outputs into NaN; the reference raises IndexError, which the Python binding reproduces); n_per_sample = C*H*W; noise may be NULL (no noise term:
  * `sample` is then the model mean of p_mean_variance); pred_xstart may be NULL. */
 int hl_diffusion_step(int mode, const float *x, const float *eps, const float *noise, const float *coef,
                       const int64_t *t, float *sample, float *pred_xstart, int64_t n_per_sample, int B, int T, int clip,
-                      void *stream);
+                      const float *log_variance, void *stream);
 
 /* Single ops of the UNet path, exposed for parity tests and profiling (NHWC fp32). */
 int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,

@@ -231,7 +231,36 @@ def test_out_of_range_timestep_raises_like_the_reference():
     out = torch.empty_like(x)
     tt = torch.tensor([10], device=dev)
     _lib.check(_lib.lib().hl_diffusion_step(1, _lib.ptr(x), _lib.ptr(x), None, _lib.ptr(tab), _lib.ptr(tt), _lib.ptr(out), None, x.numel(), 1,
-                                            10, 1, _lib.stream_ptr()))
+                                            10, 1, None, _lib.stream_ptr()))
     assert torch.isnan(out).all()
     with pytest.raises(TypeError):
         _lib.ptr(torch.zeros(4, device=dev, dtype=torch.float16))
+
+
+def test_denoised_fn_is_applied_like_process_xstart():
+    """denoised_fn (gaussian_diffusion.py:293-299: pred_xstart -> denoised_fn -> clamp) with the fused update taking the processed
+    x0 as given (hl_diffusion_step modes 2 / 3): identity reproduces the plain path; a real function matches the closed form."""
+    from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
+    d = create_gaussian_diffusion(steps=1000, timestep_respacing="ddim50")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 27, 8, 8), generator=g).to(dev)
+    e = torch.randn((2, 27, 8, 8), generator=g).to(dev)
+    nz = torch.randn((2, 27, 8, 8), generator=g).to(dev)
+    t = torch.tensor([49, 0], device=dev)
+    model = lambda xx, tt, xc, **k: e  # noqa: E731
+    with patched_randn_like(lambda shape: nz.cpu()):
+        plain_p = d.p_sample(model, x, None, t)
+        ident_p = d.p_sample(model, x, None, t, denoised_fn=lambda z: z)
+        plain_d = d.ddim_sample(model, x, t, eta=0.5)
+        ident_d = d.ddim_sample(model, x, t, eta=0.5, denoised_fn=lambda z: z)
+        half_p = d.p_sample(model, x, None, t, denoised_fn=lambda z: 0.5 * z)
+        pm = d.p_mean_variance(model, x, t, denoised_fn=lambda z: 0.5 * z)
+    for a, b in ((plain_p, ident_p), (plain_d, ident_d)):
+        assert (a["sample"] - b["sample"]).abs().max() < 1e-6 and (a["pred_xstart"] - b["pred_xstart"]).abs().max() < 1e-6
+    x0 = (0.5 * d._predict_xstart_from_eps(x, t, e)).clamp(-1, 1)
+    mean, _, logvar = d.q_posterior_mean_variance(x0, x, t)
+    assert (pm["pred_xstart"] - x0).abs().max() < 1e-6 and (pm["mean"] - mean).abs().max() < 1e-6
+    import numpy as np
+    lv = torch.from_numpy(np.log(np.append(d.posterior_variance[1], d.betas[1:]))).float().to(dev)[t].view(-1, 1, 1, 1)   # FIXED_LARGE
+    want = mean + (t != 0).float().view(-1, 1, 1, 1) * torch.exp(0.5 * lv) * nz
+    assert (half_p["sample"] - want).abs().max() < 1e-5

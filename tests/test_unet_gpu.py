@@ -359,7 +359,7 @@ def test_c_abi_error_convention():
                           _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr())
     assert rc == -1 and b"multiple of 16" in L.hl_last_error()
     rc = L.hl_diffusion_step(7, _lib.ptr(out), _lib.ptr(out), None, _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), None, 16, 1, 10, 1,
-                             _lib.stream_ptr())
+                             None, _lib.stream_ptr())
     assert rc == -1 and b"mode" in L.hl_last_error()
     rc = L.hl_render_importance(_lib.ptr(out), _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), None, _lib.ptr(out), 4, 1024, 1024,
                                 _lib.ptr(out), _lib.stream_ptr())
