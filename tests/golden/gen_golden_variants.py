@@ -1,0 +1,70 @@
+"""Golden vectors FROM THE REFERENCE for the sampler branches outside the shipped configuration (files SURVEY 8(a) marks on the path):
+learned variances (learn_sigma=True: LEARNED_RANGE, LEARNED; gaussian_diffusion.py:262-276), START_X prediction (predict_xstart=True,
+:302-303) and denoised_fn (:293-296), single steps of p_sample / ddim_sample / p_mean_variance with a stub model and injected noise.
+
+    python tests/golden/gen_golden_variants.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+sys.path.insert(0, "/root/reference/human_diffusion")
+
+from improved_diffusion import gaussian_diffusion as gd  # noqa: E402
+from improved_diffusion.respace import SpacedDiffusion, space_timesteps  # noqa: E402
+
+
+def stub(x, t, x_cond, y=None, two=False):
+    """+,-,*,clamp only (bit-identical on every host); `two`: 2C output channels, the second half in [-1,1] (variance fraction)."""
+    tt = t.float().view(-1, 1, 1, 1) * 0.001
+    e = (0.6 * x + 0.25 * x_cond - tt).clamp(-1.5, 1.5) * 1.3
+    if not two:
+        return e
+    v = (0.4 * x - 0.3 * x_cond + tt).clamp(-1, 1)
+    return torch.cat([e, v], dim=1)
+
+
+def main():
+    betas = gd.get_named_beta_schedule("linear", 1000)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((3, 27, 8, 8), generator=g)
+    xc = torch.randn((3, 27, 8, 8), generator=g) * 0.5
+    noise = torch.randn((3, 27, 8, 8), generator=g)
+    out = {}
+    orig = torch.randn_like
+    torch.randn_like = lambda ref: noise.clone()
+    try:
+        for tag, mean_t, var_t, two in [("range", gd.ModelMeanType.EPSILON, gd.ModelVarType.LEARNED_RANGE, True),
+                                        ("learned", gd.ModelMeanType.EPSILON, gd.ModelVarType.LEARNED, True),
+                                        ("x0", gd.ModelMeanType.START_X, gd.ModelVarType.FIXED_LARGE, False),
+                                        ("x0range", gd.ModelMeanType.START_X, gd.ModelVarType.LEARNED_RANGE, True)]:
+            d = SpacedDiffusion(use_timesteps=space_timesteps(1000, "ddim50"), betas=betas, model_mean_type=mean_t, model_var_type=var_t,
+                                loss_type=gd.LossType.MSE, rescale_timesteps=False)
+            t = torch.tensor([49, 0, 17])
+            model = lambda a, b, c, **k: stub(a, b, c, two=two)  # noqa: E731
+            for clip in (True, False):
+                c = int(clip)
+                ps = d.p_sample(model, x, xc, t, clip_denoised=clip)
+                dd = d.ddim_sample(model, x, t, x_cond=xc, clip_denoised=clip, eta=0.3)
+                pm = d.p_mean_variance(model, x, t, x_cond=xc, clip_denoised=clip)
+                fn = d.p_sample(model, x, xc, t, clip_denoised=clip, denoised_fn=lambda z: 0.5 * z + 0.1)
+                out[f"{tag}_{c}_p_sample"] = ps["sample"].numpy()
+                out[f"{tag}_{c}_p_x0"] = ps["pred_xstart"].numpy()
+                out[f"{tag}_{c}_ddim"] = dd["sample"].numpy()
+                out[f"{tag}_{c}_mean"] = pm["mean"].numpy()
+                out[f"{tag}_{c}_logvar"] = pm["log_variance"].numpy()
+                out[f"{tag}_{c}_fn_sample"] = fn["sample"].numpy()
+            out[f"{tag}_t"] = t.numpy()
+    finally:
+        torch.randn_like = orig
+    np.savez_compressed(os.path.join(HERE, "diffusion_variants.npz"), **out)
+    print("ok", len(out), "arrays", os.path.getsize(os.path.join(HERE, "diffusion_variants.npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

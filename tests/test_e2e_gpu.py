@@ -264,3 +264,72 @@ def test_denoised_fn_is_applied_like_process_xstart():
     lv = torch.from_numpy(np.log(np.append(d.posterior_variance[1], d.betas[1:]))).float().to(dev)[t].view(-1, 1, 1, 1)   # FIXED_LARGE
     want = mean + (t != 0).float().view(-1, 1, 1, 1) * torch.exp(0.5 * lv) * nz
     assert (half_p["sample"] - want).abs().max() < 1e-5
+
+
+def _variant_stub(x, t, x_cond, two=False):
+    """The stand-in model of tests/golden/gen_golden_variants.py (+, -, *, clamp only; `two`: 2C output channels)."""
+    tt = t.float().view(-1, 1, 1, 1) * 0.001
+    e = (0.6 * x + 0.25 * x_cond - tt).clamp(-1.5, 1.5) * 1.3
+    if not two:
+        return e
+    return torch.cat([e, (0.4 * x - 0.3 * x_cond + tt).clamp(-1, 1)], dim=1)
+
+
+@pytest.mark.parametrize("tag,mean_t,var_t,two", [("range", "EPSILON", "LEARNED_RANGE", True), ("learned", "EPSILON", "LEARNED", True),
+                                                  ("x0", "START_X", "FIXED_LARGE", False), ("x0range", "START_X", "LEARNED_RANGE", True)])
+@pytest.mark.parametrize("clip", [True, False])
+def test_sampler_variants_match_reference(tag, mean_t, var_t, two, clip):
+    """Learned variances (learn_sigma=True), START_X prediction and denoised_fn: the fused update (x0-given modes, per-element
+    log-variance) against the reference's p_sample / ddim_sample / p_mean_variance (tests/golden/gen_golden_variants.py)."""
+    from humanliff_amd.improved_diffusion import gaussian_diffusion as gd
+    from humanliff_amd.improved_diffusion.respace import SpacedDiffusion, space_timesteps
+    g = np.load(os.path.join(GOLDEN, "diffusion_variants.npz"))
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn((3, 27, 8, 8), generator=gen)
+    xc = torch.randn((3, 27, 8, 8), generator=gen) * 0.5
+    noise = torch.randn((3, 27, 8, 8), generator=gen)
+    d = SpacedDiffusion(use_timesteps=space_timesteps(1000, "ddim50"), betas=gd.get_named_beta_schedule("linear", 1000),
+                        model_mean_type=getattr(gd.ModelMeanType, mean_t), model_var_type=getattr(gd.ModelVarType, var_t),
+                        loss_type=gd.LossType.MSE, rescale_timesteps=False)
+    t = torch.from_numpy(g[f"{tag}_t"]).to(dev)
+    model = lambda a, b, c, **k: _variant_stub(a.cpu(), b.cpu(), c.cpu(), two=two).to(dev)  # noqa: E731   (a test prop, like the generator's)
+    c = int(clip)
+    with patched_randn_like(lambda shape: noise):
+        ps = d.p_sample(model, x.to(dev), xc.to(dev), t, clip_denoised=clip)
+        dd = d.ddim_sample(model, x.to(dev), t, x_cond=xc.to(dev), clip_denoised=clip, eta=0.3)
+        pm = d.p_mean_variance(model, x.to(dev), t, x_cond=xc.to(dev), clip_denoised=clip)
+        fn = d.p_sample(model, x.to(dev), xc.to(dev), t, clip_denoised=clip, denoised_fn=lambda z: 0.5 * z + 0.1)
+    near = lambda a, k: float((a.cpu() - torch.from_numpy(g[f"{tag}_{c}_{k}"])).abs().max())  # noqa: E731
+    # fp32 chains of ~10 ops on O(1..5) values (unclipped x0 reaches 30 at t = 49): 1e-5 relative
+    scale = max(1.0, float(np.abs(g[f"{tag}_{c}_p_x0"]).max()))
+    assert near(ps["pred_xstart"], "p_x0") < 1e-5 * scale
+    assert near(ps["sample"], "p_sample") < 1e-5 * scale
+    assert near(dd["sample"], "ddim") < 1e-5 * scale
+    assert near(pm["mean"], "mean") < 1e-5 * scale
+    assert near(pm["log_variance"], "logvar") < 1e-5
+    assert near(fn["sample"], "fn_sample") < 1e-5 * scale
+
+
+def test_learn_sigma_network_samples_end_to_end():
+    """create_model_and_diffusion(learn_sigma=True): the network emits 2C channels (script_util.py:138), LEARNED_RANGE variances drive
+    p_sample_loop; the HIP forward equals the oracle's and the loop runs to a finite, clipped sample."""
+    from oracle import unet_oracle as uo
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+    a = model_and_diffusion_defaults()
+    a.update(dict(in_channels=27, out_channels=27, class_cond=True, learn_sigma=True, num_heads=4, rescale_timesteps=False, image_size=32,
+                  num_channels=32, num_res_blocks=1, attention_resolutions="16,8", timestep_respacing="8"))
+    model, diffusion = create_model_and_diffusion(**a)
+    sd = syn.state_from_shapes([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=1)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    assert model.out_channels == 54
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 27, 32, 32), generator=g)
+    xc = torch.randn((2, 27, 32, 32), generator=g).clamp(-1, 1) * 0.7
+    t, y = torch.tensor([900, 30]), torch.tensor([1, 2])
+    with torch.no_grad():
+        got = model(x.to(dev), t.to(dev), xc.to(dev), y=y.to(dev)).cpu()
+        want = uo.unet_forward(sd, x, t, xc, y, num_heads=4)
+    assert got.shape == (2, 54, 32, 32) and (got - want).abs().max() < 1e-4
+    out = diffusion.p_sample_loop(model, (2, 27, 32, 32), x_cond=xc.to(dev), noise=x.to(dev), model_kwargs={"y": y.to(dev)})
+    assert out.shape == (2, 27, 32, 32) and torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6
