@@ -700,37 +700,33 @@ int hl_unet_profile_read_ex(void *handle, double *h_ms, double *h_flops, double 
 }
 
 // ---- single ops for tests ------------------------------------------------------------------------
+// One convolution through the kernels of the network.  Cin = channels of `in` (multiple of 16); the weight tensor covers
+// Cin_w <= Cin of them (the rest are zero-padded channels with zero weights).  tf = 1: `w` is laid out (Cin_w, Cout, ks, ks) and is
+// read flipped and channel-transposed - the backward-data convolution of the training path.  Only the weight layout the chosen
+// kernel reads is packed (conv2d in plan mode decides first).
 static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,
                          int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                          const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream,
-                         float *stats = nullptr, int *stat_slots = nullptr) {
+                         float *stats = nullptr, int *stat_slots = nullptr, int tf = 0, int Cin_w = -1, long out_pitch = 0) {
     HL_REQUIRE(Cin % 16 == 0, "hl_conv2d_nhwc: Cin must be a multiple of 16");
+    if (Cin_w < 0) Cin_w = Cin;
+    HL_REQUIRE(Cin_w <= Cin, "hl_conv2d_nhwc: the weight has more input channels than the tensor");
     const size_t need32 = (hl::conv_packed_floats(Cout, Cin, ks) * sizeof(float) + 255) / 256 * 256;
     const size_t extra = mode == HL_CONV_BF16X3 ? hl::conv_packed_bf3_bytes(Cout, Cin, ks)
                          : (mode == HL_CONV_FP32 ? hl::conv_packed_wino_bytes(Cout, Cin, ks) : 0);
     const size_t need = need32 + (extra + 255) / 256 * 256;
     HL_REQUIRE(scratch && scratch_bytes >= need, "hl_conv2d_nhwc: scratch too small (%zu < %zu)", scratch_bytes, need);
-    int rc = hl::conv_pack_weights(w_oihw, Cout, Cin, Cin, ks, static_cast<float *>(scratch), (hipStream_t)stream);
-    if (rc) return rc;
+    HL_REQUIRE(!tf || mode != HL_CONV_BF16X3, "hl_conv2d_nhwc: the bf16x3 mode has no backward-data weights");
     ConvArgs a{};
-    if (mode == HL_CONV_BF16X3 && need > need32) {
-        void *dst = static_cast<char *>(scratch) + need32;
-        rc = hl::conv_pack_weights_bf3(w_oihw, Cout, Cin, Cin, ks, dst, (hipStream_t)stream);
-        if (rc) return rc;
-        a.w_bf3 = dst;
-    }
-    if (mode == HL_CONV_FP32 && extra) {
-        float *dst = reinterpret_cast<float *>(static_cast<char *>(scratch) + need32);
-        rc = hl::conv_pack_weights_wino(w_oihw, Cout, Cin, Cin, dst, (hipStream_t)stream);
-        if (rc) return rc;
-        a.w_wino = dst;
-    }
+    void *extra_dst = static_cast<char *>(scratch) + need32;
     a.in.p = const_cast<float *>(in); a.in.N = N; a.in.H = H; a.in.W = W; a.in.C = Cin; a.in.pitch = Cin;
     a.w = static_cast<float *>(scratch); a.bias = bias; a.Cout = Cout; a.ks = ks; a.stride = stride; a.ups = upsample;
+    if (mode == HL_CONV_BF16X3 && need > need32) a.w_bf3 = extra_dst;
+    if (mode == HL_CONV_FP32 && extra) a.w_wino = static_cast<float *>(extra_dst);
     a.coefA = coefA; a.coefB = coefB; a.act = silu;
     const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     a.out.p = out; a.out.N = N; a.out.H = (Hv + 2 * pad - ks) / stride + 1; a.out.W = (Wv + 2 * pad - ks) / stride + 1;
-    a.out.C = Cout; a.out.pitch = Cout;
+    a.out.C = Cout; a.out.pitch = out_pitch ? out_pitch : Cout;
     a.res = residual; a.res_pitch = Cout;
     // whatever scratch is left after the packed weights serves split-K (small-M shapes)
     size_t used = (need + 255) / 256 * 256;
@@ -745,9 +741,55 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
         a.splitk_ws_bytes = scratch_bytes - used;
     }
     a.stats = stats;
+    a.plan_only = 1;
+    int rc = hl::conv2d(a, (hipStream_t)stream);
+    if (rc) return rc;
+    a.plan_only = 0;
+    if (a.path == 1) {
+        rc = hl::conv_pack_weights_wino(w_oihw, Cout, Cin_w, Cin, static_cast<float *>(extra_dst), (hipStream_t)stream, tf);
+    } else {
+        rc = hl::conv_pack_weights(w_oihw, Cout, Cin_w, Cin, ks, static_cast<float *>(scratch), (hipStream_t)stream, tf);
+        if (!rc && a.path == 2) rc = hl::conv_pack_weights_bf3(w_oihw, Cout, Cin_w, Cin, ks, extra_dst, (hipStream_t)stream);
+        a.w_wino = nullptr;
+    }
+    if (rc) return rc;
     rc = hl::conv2d(a, (hipStream_t)stream);
     if (stat_slots) *stat_slots = a.stat_slots;
     return rc;
+}
+
+int hl_conv2d_nhwc_bwd_data(int conv_mode, const float *dy, int N, int Ho, int Wo, int Cy, const float *w_oihw, int Cout, int Cin, int ks,
+                            int stride, int upsample, float *dx, int Cx, void *scratch, size_t scratch_bytes, void *stream) {
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_FP32_DIRECT, "hl_conv2d_nhwc_bwd_data: mode %d", conv_mode);
+    HL_REQUIRE(dy && w_oihw && dx && scratch, "hl_conv2d_nhwc_bwd_data: null argument");
+    HL_REQUIRE(Cy % 16 == 0 && Cout <= Cy && Cin <= Cx && (ks == 1 || ks == 3) && (stride == 1 || (stride == 2 && !upsample && ks == 3)),
+               "hl_conv2d_nhwc_bwd_data: bad argument");
+    // d input = convolution of d output with W'[ci][co][ky][kx] = W[co][ci][ks-1-ky][ks-1-kx]  (packed straight from w, tf = 1);
+    // stride 2: on the zero-stuffed gradient; nearest-x2 upsample in front of the conv: the 2x2 blocks of the result are summed
+    hipStream_t st = (hipStream_t)stream;
+    char *sc = static_cast<char *>(scratch);
+    int rc;
+    if (stride == 2) {
+        const size_t zb = ((size_t)N * 4 * Ho * Wo * Cy * sizeof(float) + 255) / 256 * 256;
+        HL_REQUIRE(scratch_bytes > zb, "hl_conv2d_nhwc_bwd_data: scratch too small");
+        float *z = reinterpret_cast<float *>(sc);
+        rc = hl_zero_stuff2_nhwc(dy, N, Ho, Wo, Cy, z, stream);
+        if (rc) return rc;
+        return conv2d_single(conv_mode, z, N, 2 * Ho, 2 * Wo, Cy, w_oihw, nullptr, Cin, ks, 1, 0, nullptr, nullptr, 0, nullptr, dx, sc + zb,
+                             scratch_bytes - zb, stream, nullptr, nullptr, 1, Cout, Cx);
+    }
+    if (upsample) {      // dy lives on the (2H, 2W) grid = (Ho, Wo); dx on (Ho/2, Wo/2)
+        const size_t ub = ((size_t)N * Ho * Wo * Cx * sizeof(float) + 255) / 256 * 256;
+        HL_REQUIRE(scratch_bytes > ub && Cx % 4 == 0, "hl_conv2d_nhwc_bwd_data: scratch too small");
+        float *du = reinterpret_cast<float *>(sc);
+        if (Cx != Cin) HL_HIP(hipMemsetAsync(du, 0, ub, st));
+        rc = conv2d_single(conv_mode, dy, N, Ho, Wo, Cy, w_oihw, nullptr, Cin, ks, 1, 0, nullptr, nullptr, 0, nullptr, du, sc + ub, scratch_bytes - ub,
+                           stream, nullptr, nullptr, 1, Cout, Cx);
+        if (rc) return rc;
+        return hl_upsample2_backward_nhwc(du, N, Ho / 2, Wo / 2, Cx, dx, stream);
+    }
+    return conv2d_single(conv_mode, dy, N, Ho, Wo, Cy, w_oihw, nullptr, Cin, ks, 1, 0, nullptr, nullptr, 0, nullptr, dx, scratch, scratch_bytes, stream,
+                         nullptr, nullptr, 1, Cout, Cx);
 }
 
 int hl_conv2d_nhwc_gn(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,

@@ -45,17 +45,19 @@ struct ConvArgs {
     // computes the statistics from the tensor (groupnorm_coef).
     float *stats, *stats2;
     mutable int stat_slots;
+    int plan_only;       // 1: no launch, only set `path` (w / w_wino / w_bf3 are then just non-null markers of what could be packed)
 };
 inline size_t conv_stats_floats(long out_pixels, int Cout) { return (size_t)(out_pixels / 32 + 1) * Cout * 2; }
 size_t conv_splitk_ws_bytes();
 int conv2d(const ConvArgs &a, hipStream_t st);
 size_t conv_packed_floats(int Cout, int Cin_pad, int ks);
-int conv_pack_weights(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, float *packed, hipStream_t st);
+// tf = 1: the source is laid out (Cin, Cout, ks, ks) and is read flipped and channel-transposed (backward-data weights)
+int conv_pack_weights(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, float *packed, hipStream_t st, int tf = 0);
 // split-bf16 copy for k_conv_bf3: [Cout_pad][K/16][plane*2 + k-half][8 bf16], 6 bytes per weight; 0 bytes if the layer
 // never takes the DMA tile (Cout_pad not a multiple of 96)
 // Winograd F(2x2,3x3) copy U = G g G^T: [Cout/64][Cin_pad/8][16][2][2][32][4] floats; 0 bytes if not applicable
 size_t conv_packed_wino_bytes(int Cout, int Cin_pad, int ks);
-int conv_pack_weights_wino(const float *w_oihw, int Cout, int Cin, int Cin_pad, float *packed, hipStream_t st);
+int conv_pack_weights_wino(const float *w_oihw, int Cout, int Cin, int Cin_pad, float *packed, hipStream_t st, int tf = 0);
 size_t conv_packed_bf3_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_bf3(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st);
 

@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(const ConvK p) {
 }
 
 // weights -> U = G g G^T per (cout, cin), laid out as k_conv_wino stages them: [cout/64][cin/8][f][ct][half][32][4]
-__global__ void k_pack_conv_wino(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, float *__restrict__ dst) {
+__global__ void k_pack_conv_wino(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, float *__restrict__ dst, int tf) {
     const int nkt = Cin_pad >> 3;
     const long n = (long)Cout * Cin_pad * 16;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
@@ -903,12 +903,12 @@ __global__ void k_pack_conv_wino(const float *__restrict__ w, int Cout, int Cin,
         const int co = nb * 64 + ct * 32 + nn, ci = kt * 8 + hf * 4 + s;
         float v = 0.f;
         if (ci < Cin && co < Cout) {
-            const float *g = w + ((long)co * Cin + ci) * 9;
+            const float *g = tf ? w + ((long)ci * Cout + co) * 9 : w + ((long)co * Cin + ci) * 9;
             const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
             const int i = f >> 2, j = f & 3;
             double acc = 0.0;
             for (int u = 0; u < 3; ++u)
-                for (int vv = 0; vv < 3; ++vv) acc += G[i][u] * (double)g[u * 3 + vv] * G[j][vv];
+                for (int vv = 0; vv < 3; ++vv) acc += G[i][u] * (double)g[tf ? 8 - (u * 3 + vv) : u * 3 + vv] * G[j][vv];
             v = (float)acc;
         }
         dst[e] = v;
@@ -1300,7 +1300,9 @@ __global__ __launch_bounds__(256) void k_splitk_finish_st(const ConvK p, int spl
     }
 }
 
-__global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, int ks, int rows, float *__restrict__ dst) {
+// tf (backward-data of the training path): the logical weight is W'[o][c][ky][kx] = W[c][o][ks-1-ky][ks-1-kx] of a source laid out
+// (Cin, Cout, ks, ks) - the flipped, channel-transposed kernel - read in place, no flipped copy is ever materialised
+__global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, int ks, int rows, float *__restrict__ dst, int tf) {
     const int taps = ks * ks;
     const long Ktot = (long)Cin_pad * taps;
     const long n = (long)rows * Ktot;
@@ -1313,7 +1315,7 @@ __global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int 
         kt_decode((int)t, Cin_pad >> 4, taps, cc, tap);         // the order k_conv walks K
         const int cin = cc * 16 + c16;
         float v = 0.f;
-        if (o < Cout && cin < Cin) v = w[((long)o * Cin + cin) * taps + tap];
+        if (o < Cout && cin < Cin) v = tf ? w[((long)cin * Cout + o) * taps + (taps - 1 - tap)] : w[((long)o * Cin + cin) * taps + tap];
         dst[i] = v;
     }
 }
@@ -1922,10 +1924,10 @@ size_t conv_splitk_ws_bytes() { return (size_t)64 << 20; }
 
 size_t conv_packed_floats(int Cout, int Cin_pad, int ks) { return (size_t)round_up(Cout, 64) * Cin_pad * ks * ks; }
 
-int conv_pack_weights(const float *w, int Cout, int Cin, int Cin_pad, int ks, float *packed, hipStream_t st) {
+int conv_pack_weights(const float *w, int Cout, int Cin, int Cin_pad, int ks, float *packed, hipStream_t st, int tf) {
     HL_REQUIRE(w && packed && Cin_pad % 16 == 0 && Cin <= Cin_pad && (ks == 1 || ks == 3), "conv_pack_weights: bad argument");
     const int rows = round_up(Cout, 64);
-    hipLaunchKernelGGL(k_pack_conv, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, ks, rows, packed);
+    hipLaunchKernelGGL(k_pack_conv, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, ks, rows, packed, tf);
     return check_launch("k_pack_conv");
 }
 
@@ -1945,9 +1947,9 @@ size_t conv_packed_wino_bytes(int Cout, int Cin_pad, int ks) {
     return (ks == 3 && Cout % 64 == 0 && Cin_pad % 8 == 0) ? (size_t)Cout * Cin_pad * 16 * sizeof(float) : 0;
 }
 
-int conv_pack_weights_wino(const float *w, int Cout, int Cin, int Cin_pad, float *packed, hipStream_t st) {
+int conv_pack_weights_wino(const float *w, int Cout, int Cin, int Cin_pad, float *packed, hipStream_t st, int tf) {
     HL_REQUIRE(w && packed && Cout % 64 == 0 && Cin_pad % 8 == 0 && Cin <= Cin_pad, "conv_pack_weights_wino: bad argument");
-    hipLaunchKernelGGL(k_pack_conv_wino, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, packed);
+    hipLaunchKernelGGL(k_pack_conv_wino, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, packed, tf);
     return check_launch("k_pack_conv_wino");
 }
 
@@ -2060,6 +2062,10 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         p.kt_per = (a.in.C / 8 + splits - 1) / splits;
         splits = (a.in.C / 8 + p.kt_per - 1) / p.kt_per;
         p.partial = splits > 1 ? a.splitk_ws : nullptr;
+    }
+    if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
+        a.path = (dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0);
+        return HL_OK;
     }
     if (dma) {
         HL_REQUIRE(mode == 0 || !a.ups, "conv2d: upsample with a GroupNorm prologue is not used by the UNet");

@@ -6,8 +6,9 @@ same function is a chain of torch.autograd.Functions whose forward AND backward 
 include/humanliff_hip.h), activations NHWC fp32:
 
     _Conv          forward   hl_conv2d_nhwc_mode (Winograd / direct fp32 MFMA kernels of the inference path)
-                   d input   the same forward kernels on the output gradient with flipped, channel-transposed weights
-                             (stride 2: hl_zero_stuff2_nhwc first; nearest-x2 upsample: hl_upsample2_backward_nhwc afterwards)
+                   d input   hl_conv2d_nhwc_bwd_data: the same forward kernels on the output gradient, the weights read flipped and
+                             channel-transposed while they are re-laid (stride 2: zero-stuffed gradient first; nearest-x2 upsample:
+                             2x2 block sums afterwards)
                    d weight  hl_conv2d_wgrad_nhwc (pixels-as-K MFMA GEMM), bias gradient in the same launch
     _GroupNormAct  forward   hl_groupnorm_train_forward (statistics -> affine with scale/shift -> apply + SiLU)
                    backward  hl_groupnorm_train_backward (per-(n,c) reductions, the (N,C) algebra, dx; parameter / scale-shift gradients)
@@ -78,25 +79,16 @@ class _Conv(th.autograd.Function):
         dyp = _pad_c(dy, 16)                                      # (the 27-channel output conv: pad the gradient's channels with zeros)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            # backward-data = forward conv of dy with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]
-            wt = w4.flip(2, 3).transpose(0, 1)
-            wt = F.pad(wt, (0, 0, 0, 0, 0, dyp.shape[-1] - Cout)).contiguous()
-            Cxp = x.shape[-1]
-            if Cxp != Cin:                                         # input was channel-padded (27 -> 32): zero rows for the pad
-                wt = F.pad(wt, (0, 0, 0, 0, 0, 0, 0, Cxp - Cin)).contiguous()
-            if stride == 2:
-                z = th.empty((N, 2 * Ho, 2 * Wo, dyp.shape[-1]), device=dy.device, dtype=th.float32)
-                with _lib.on(dy.device):
-                    _lib.check(L.hl_zero_stuff2_nhwc(_lib.ptr(dyp), N, Ho, Wo, dyp.shape[-1], _lib.ptr(z), _lib.stream_ptr()), "hl_zero_stuff2_nhwc")
-                dx = _conv_raw(z, wt, None, ks, 1, 0)
-            elif ups:
-                du = _conv_raw(dyp, wt, None, ks, 1, 0)           # gradient of the upsampled image (2H, 2W)
-                dx = th.empty_like(x)
-                with _lib.on(dy.device):
-                    _lib.check(L.hl_upsample2_backward_nhwc(_lib.ptr(du), N, x.shape[1], x.shape[2], x.shape[3], _lib.ptr(dx), _lib.stream_ptr()),
-                               "hl_upsample2_backward_nhwc")
-            else:
-                dx = _conv_raw(dyp, wt, None, ks, 1, 0)
+            # backward-data = forward conv kernels on dy with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx], read in place from w4
+            Cxp, Cyp = x.shape[-1], dyp.shape[-1]
+            dx = th.empty_like(x) if Cxp == Cin else th.zeros_like(x)
+            rows = (Cin + 63) // 64 * 64
+            extra = N * 4 * Ho * Wo * Cyp if stride == 2 else (N * Ho * Wo * Cxp if ups else 0)
+            scratch = th.empty(rows * Cyp * ks * ks * 3 + 512 + (16 << 20) + extra, device=dy.device, dtype=th.float32)
+            with _lib.on(dy.device):
+                _lib.check(L.hl_conv2d_nhwc_bwd_data(_MODE, _lib.ptr(dyp), N, Ho, Wo, Cyp, _lib.ptr(w4.contiguous()), Cout, Cin, ks, stride, ups,
+                                                     _lib.ptr(dx), Cxp, _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()),
+                           "hl_conv2d_nhwc_bwd_data")
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dw = th.zeros(w4.shape, device=dy.device, dtype=th.float32)
             db = th.zeros((Cout,), device=dy.device, dtype=th.float32) if has_b else None

@@ -335,14 +335,21 @@ int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int
                         int Cout, int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream);
 /* ---- backward of the UNet (gaussian_diffusion.py:688-772 -> loss.backward() through unet.py:550-615) --------
- * Backward-DATA of a convolution is a forward convolution (hl_conv2d_nhwc_mode) of the output gradient with the flipped,
- * channel-transposed weights; stride 2 goes through hl_zero_stuff2_nhwc first, the nearest-x2 upsample through
+ * Backward-DATA of a convolution is a forward convolution of the output gradient with the flipped, channel-transposed weights
+ * (hl_conv2d_nhwc_bwd_data); stride 2 goes through hl_zero_stuff2_nhwc first, the nearest-x2 upsample through
  * hl_upsample2_backward_nhwc afterwards.  humanliff_amd/improved_diffusion/unet_train.py holds the autograd.Functions.
  *
  * hl_conv2d_wgrad_nhwc: dW[co][ci][ky][kx] += sum_p dY[p][co] * X[p*stride + (ky,kx) - pad][ci] and db[co] += sum_p dY[p][co]
  * (float atomics: dw (Cout, Cin, ks, ks) - the reference's OIHW parameter layout - and db (Cout) or NULL must be zeroed by the caller).
  * x (N,H,W,Cx), dy (N,Hout,Wout,Cy) dense NHWC with Cx >= Cin, Cy >= Cout even (zero-padded channels are ignored); `upsample`:
  * the convolution ran on the nearest-x2 upsampled x. */
+/* hl_conv2d_nhwc_bwd_data: d input of a convolution from d output, through the forward kernels: dy (N,Ho,Wo,Cy) dense NHWC with
+ * Cy >= Cout a multiple of 16 (zero-padded channels), w the convolution's own (Cout, Cin, ks, ks) weights - read flipped and
+ * channel-transposed while they are re-laid for the kernel, no flipped copy is made -, dx (N,H,W,Cx) with Cx >= Cin (channels
+ * [Cin, Cx) are not written).  stride 2 (ks 3): H = 2*Ho; upsample: the convolution ran on the nearest-x2 image, (Ho,Wo) = (2H,2W).
+ * scratch: the re-laid weights (3 * round_up(Cin,64) * Cy * ks^2 floats) + 16 MiB + the zero-stuffed / upsampled gradient. */
+int hl_conv2d_nhwc_bwd_data(int conv_mode, const float *dy, int N, int Ho, int Wo, int Cy, const float *w_oihw, int Cout, int Cin, int ks,
+                            int stride, int upsample, float *dx, int Cx, void *scratch, size_t scratch_bytes, void *stream);
 int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                          float *dw, int Cout, int Cin, float *db, void *stream);
 /* y (N,HW,C dense) = silu ? silu(x*A + B) : x*A + B with the per-(n,c) affine of hl_groupnorm_coef; x has a channel pitch. */
