@@ -4,7 +4,7 @@
 The torch modules declared here only own the parameters (so reference checkpoints load with
 load_state_dict and .to(device) works).  forward() hands the parameter pointers to the C ABI
 (hl_unet_create / hl_unet_forward); there is no PyTorch implementation of the math and no CPU path.
-Supported configuration: dims=2, use_scale_shift_norm=True, cond_type in {"controlnet", ""},
+Supported configuration: dims=2, use_scale_shift_norm=True, cond_type in {"controlnet", "concat", ""},
 use_3d_aware=False.  Under no_grad / eval() forward() is the fused inference path; with gradients enabled on a model in training
 mode it is the differentiable path of unet_train.py (HIP forward and backward kernels behind autograd.Functions).
 """
@@ -100,10 +100,10 @@ class UNetModel(nn.Module):
         super().__init__()
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
-        if dims != 2 or not conv_resample or use_3d_aware or not use_scale_shift_norm or cond_type not in ("controlnet", ""):
+        if dims != 2 or not conv_resample or use_3d_aware or not use_scale_shift_norm or cond_type not in ("controlnet", "", "concat"):
             raise NotImplementedError(
                 "the MI355X build covers dims=2, conv_resample=True, use_scale_shift_norm=True, "
-                "cond_type in {'controlnet',''}, use_3d_aware=False (the shipped HumanLiff configuration)")
+                "cond_type in {'controlnet', '', 'concat'}, use_3d_aware=False (the shipped HumanLiff configuration is controlnet)")
         if dropout != 0:
             raise NotImplementedError("dropout > 0 is a training feature; inference build only")
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
@@ -260,6 +260,9 @@ class UNetModel(nn.Module):
             assert y is not None and y.shape == (x.shape[0],)
         if self.cond_type == "controlnet":
             assert x_cond is not None, "cond_type='controlnet' needs x_cond (zeros for the first layer)"
+        if self.cond_type == "concat":        # unet.py:572-573: the condition rides along as extra input channels (in_channels counts both)
+            assert x_cond is not None, "cond_type='concat' needs x_cond"
+            x, x_cond = th.cat([x, x_cond], dim=1), None
         if not x.is_cuda:
             raise RuntimeError("UNetModel.forward needs CUDA(HIP) tensors; there is no CPU path")
         if th.is_grad_enabled() and self.training and (x.requires_grad or self._any_param_requires_grad()):

@@ -1,15 +1,15 @@
-"""Differentiable forward of UNetModel in PyTorch ops - TRAINING ONLY.
+"""UNetModel.forward in plain PyTorch ops, differentiable - the CPU-checkable statement of the network.
 
-SURVEY.md 8(b) keeps `GaussianDiffusion.training_losses(model, x_start, x_cond, t, ...)` working through autograd ("fallback to torch
-ops is acceptable"): the HIP kernels of `UNetModel.forward` have no backward (UNet half: not built), so
-`training_losses` evaluates the network through this module when gradients are requested.  It is never used by the samplers:
-`UNetModel.forward` - the hot path - runs only on the HIP kernels and raises when asked for gradients.
+Nothing in the product calls this: sampling runs the fused HIP forward (unet.py -> hl_unet_forward), training the HIP forward +
+backward behind autograd.Functions (unet_train.py).  It exists for the gradient tests: tests/test_train_loss_cpu.py pins it to the
+reference's loss and parameter gradients on the CPU, tests/test_unet_train_gpu.py pins the HIP training path to the same vectors (with
+this module patched to raise), and tests/test_unet_gpu.py checks that all three statements agree on the GPU; scripts/unet_train_bench.py
+can time it (MIOpen / rocBLAS) next to the HIP path.
 
 Same arithmetic as human_diffusion/improved_diffusion/unet.py:550-615 on the parameter-holder modules of unet.py: GroupNorm(32,
 eps 1e-5) -> SiLU -> conv ResBlocks with scale-shift conditioning (:203-206), per-head [q|k|v] attention with ch^-1/4 on q and k and
 fp32 softmax (:248-274), stride-2 conv downsampling, nearest x2 + conv upsampling, and the control encoder on x + x_cond whose
-feature map is REPLACED by its zero-conv projection before the next block (:594-606).  Convolutions run in whatever PyTorch
-dispatches to on the tensors' device (MIOpen on the GPU).
+feature map is REPLACED by its zero-conv projection before the next block (:594-606).
 """
 import math
 
@@ -74,6 +74,8 @@ def forward_autograd(model, x, timesteps, x_cond=None, y=None):
     """UNetModel.forward's contract (x (N,C,H,W), timesteps (N,), x_cond, y) with autograd; fp32."""
     if model.num_classes is not None:
         assert y is not None and y.shape == (x.shape[0],)
+    if model.cond_type == "concat":          # unet.py:572-573
+        x, x_cond = th.cat([x, x_cond], dim=1), None
     emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
     if model.num_classes is not None:
         emb = emb + model.label_emb(y)

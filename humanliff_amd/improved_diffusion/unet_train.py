@@ -229,6 +229,8 @@ def forward_train(model, x, timesteps, x_cond=None, y=None):
         raise RuntimeError("the HIP training path needs CUDA(HIP) tensors; there is no CPU path")
     if model.num_classes is not None:
         assert y is not None and y.shape == (x.shape[0],)
+    if model.cond_type == "concat":          # unet.py:572-573
+        x, x_cond = th.cat([x, x_cond], dim=1), None
     emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
     if model.num_classes is not None:
         emb = emb + model.label_emb(y)

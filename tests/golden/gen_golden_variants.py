@@ -66,5 +66,31 @@ def main():
     print("ok", len(out), "arrays", os.path.getsize(os.path.join(HERE, "diffusion_variants.npz")) // 1024, "KiB")
 
 
+def unet_concat():
+    """cond_type='concat' (unet.py:572-573: x = cat([x, x_cond], 1), in_channels counts both) and cond_type='' on the tiny net."""
+    from improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+    from humanliff_amd import synthetic as syn
+    out = {}
+    for tag, cond, cin in (("concat", "concat", 54), ("plain", "", 27)):
+        a = model_and_diffusion_defaults()
+        a.update(dict(in_channels=cin, out_channels=27, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=True,
+                      cond_type=cond, rescale_timesteps=False, dropout=0.0, image_size=32, num_channels=32, num_res_blocks=1,
+                      attention_resolutions="16,8"))
+        model, _ = create_model_and_diffusion(**a)
+        model.eval()
+        ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+        model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn((2, 27, 32, 32), generator=g)
+        xc = torch.randn((2, 27, 32, 32), generator=g).clamp(-1, 1) * 0.7
+        with torch.no_grad():
+            y = model(x, torch.tensor([999, 17]), xc if cond else None, y=torch.tensor([3, 0]))
+        out[f"{tag}_out"] = y.numpy()
+        out[f"{tag}_nkeys"] = len(ks)
+        print(tag, "keys", len(ks), "out abs mean", float(y.abs().mean()))
+    np.savez_compressed(os.path.join(HERE, "unet_cond_types.npz"), **out)
+
+
 if __name__ == "__main__":
     main()
+    unet_concat()

@@ -333,3 +333,26 @@ def test_learn_sigma_network_samples_end_to_end():
     assert got.shape == (2, 54, 32, 32) and (got - want).abs().max() < 1e-4
     out = diffusion.p_sample_loop(model, (2, 27, 32, 32), x_cond=xc.to(dev), noise=x.to(dev), model_kwargs={"y": y.to(dev)})
     assert out.shape == (2, 27, 32, 32) and torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6
+
+
+@pytest.mark.parametrize("tag,cond,cin", [("concat", "concat", 54), ("plain", "", 27)])
+def test_unet_cond_types_match_reference(tag, cond, cin):
+    """cond_type='concat' (x_cond rides along as input channels, unet.py:572-573) and cond_type='' (no conditioning branch) on the tiny
+    net against the reference's forward (tests/golden/gen_golden_variants.py)."""
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+    g = np.load(os.path.join(GOLDEN, "unet_cond_types.npz"))
+    a = model_and_diffusion_defaults()
+    a.update(dict(in_channels=cin, out_channels=27, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=True,
+                  cond_type=cond, rescale_timesteps=False, dropout=0.0, image_size=32, num_channels=32, num_res_blocks=1,
+                  attention_resolutions="16,8"))
+    model, _ = create_model_and_diffusion(**a)
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert len(ks) == int(g[f"{tag}_nkeys"])
+    model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+    model = model.to(dev).eval()
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn((2, 27, 32, 32), generator=gen)
+    xc = torch.randn((2, 27, 32, 32), generator=gen).clamp(-1, 1) * 0.7
+    with torch.no_grad():
+        y = model(x.to(dev), torch.tensor([999, 17], device=dev), xc.to(dev) if cond else None, y=torch.tensor([3, 0], device=dev)).cpu()
+    assert (y - torch.from_numpy(g[f"{tag}_out"])).abs().max() < 1e-4
