@@ -17,6 +17,7 @@ struct ConvArgs {
     const float *w;      // packed [Cout_pad][Ktot], K order = kt_decode() in hl_unet_kernels.hip (groups of two 16-channel chunks, taps inside)
     const void *w_bf3;   // optional: the same weights split into three bf16 planes (conv_pack_weights_bf3); selects k_conv_bf3
     const float *w_wino; // optional: Winograd-domain weights (conv_pack_weights_wino); selects k_conv_wino for large 3x3 layers
+    const float *w_wino4;// optional: Winograd F(4x4,3x3) weights (conv_pack_weights_wino4); selects k_conv_wino4 where it fills the chip
     const float *bias;   // [Cout] or null
     int Cout;            // real output channels
     int ks;              // 1 or 3 (pad = ks/2)
@@ -35,7 +36,7 @@ struct ConvArgs {
     int out_nchw;        // write (N, Cout, H, W) instead of NHWC
     float *act_ws;       // optional scratch (pixels*Cin floats) for the materialised GroupNorm(+SiLU) input of k_conv_dma
     size_t act_ws_bytes;
-    mutable int path;    // set by conv2d: 0 direct implicit GEMM, 1 Winograd F(2x2,3x3), 2 bf16x3 emulation
+    mutable int path;    // set by conv2d: 0 direct implicit GEMM, 1 Winograd F(2x2,3x3), 2 bf16x3 emulation, 3 Winograd F(4x4,3x3)
     float *splitk_ws;    // optional scratch for split-K partial sums (small-M layers); null disables split-K
     size_t splitk_ws_bytes;
     // GroupNorm statistics of the OUTPUT for the layer that will normalise it, emitted by the epilogue of whichever kernel stores
@@ -58,6 +59,9 @@ int conv_pack_weights(const float *w_oihw, int Cout, int Cin, int Cin_pad, int k
 // Winograd F(2x2,3x3) copy U = G g G^T: [Cout/64][Cin_pad/8][16][2][2][32][4] floats; 0 bytes if not applicable
 size_t conv_packed_wino_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_wino(const float *w_oihw, int Cout, int Cin, int Cin_pad, float *packed, hipStream_t st, int tf = 0);
+// Winograd F(4x4,3x3) copy (points 0, +-3/4, +-3/2, inf): [Cout/32][Cin_pad/8][36][2][32][4] floats; 0 bytes if not applicable
+size_t conv_packed_wino4_bytes(int Cout, int Cin_pad, int ks);
+int conv_pack_weights_wino4(const float *w_oihw, int Cout, int Cin, int Cin_pad, float *packed, hipStream_t st, int tf = 0);
 size_t conv_packed_bf3_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_bf3(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st);
 

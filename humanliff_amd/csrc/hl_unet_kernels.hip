@@ -915,6 +915,382 @@ __global__ void k_pack_conv_wino(const float *__restrict__ w, int Cout, int Cin,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_conv_wino4: 3x3 / stride 1 convolution by Winograd F(4x4, 3x3) in fp32, fused in one kernel
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A        36 multiplies per 4x4 outputs instead of 144 (4x fewer MFMAs than direct,
+//                                                  1.78x fewer than F(2x2,3x3))
+// Interpolation points (0, +a, -a, +b, -b, inf) with a = 3/4, b = 3/2 instead of the textbook (0, +-1, +-2, inf): every entry of
+// B^T and A^T is still exact in fp32, and the error against float64 on a 192-channel layer is 3x the F(2x2) kernel's instead of
+// 6x (rms 7e-7 on outputs of std 0.6; scripts/wino_points.py).  Rows of B^T (each with leading coefficient 1):
+//     0   : a2b2 d0 - (a2+b2) d2 + d4                       +-a : (-b2 d2 + d4) +- a (-b2 d1 + d3)
+//     inf : a2b2 d1 - (a2+b2) d3 + d5                       +-b : (-a2 d2 + d4) +- b (-a2 d1 + d3)
+// A workgroup owns 8x4 tiles of 4x4 outputs (a 32x16 pixel block, 32 tiles = the MFMA M dimension) x 32 output channels x all 36
+// frequencies; wave (fr, fc) of its 4 waves owns the 3x3 frequency block rows {0,+a,-a} or {+b,-b,inf} x columns likewise:
+// 9 accumulator tiles = 144 registers, 2 waves / SIMD, two workgroups per CU (2 x 78.75 KB of LDS).
+// Per k-tile of 8 input channels:
+//   * the 34x18 input patch arrives by LDS-DMA into a 2-stage ring (22 instructions per workgroup) and the wave's nine 32x8
+//     weight slices U = G g G^T by LDS-DMA into nine PRIVATE single-buffered 1 KiB slots: a slot is refilled for the next k-tile
+//     right behind the MFMAs that consumed it, so the weights need no barrier and every wait is an exact vmcnt over the fixed
+//     per-wave instruction sequence  P(t+2) U(t+1,0) ... U(t+1,8);
+//   * transform phase: a lane (tile, channel half) reads the 5x5 window positions its frequency block needs (a block uses rows /
+//     columns 0..4 or 1..5 of the 6x6 window), 25 ds_read_b128, and forms V[3][3] with 48 fused multiply-adds per channel;
+//   * MFMA phase: 36 MFMAs against the weight slots.  The two phases of a wave do not overlap (no registers for a second V); the
+//     other workgroup's wave on the same SIMD fills the matrix pipe meanwhile.
+// After the K walk the 36 frequencies of a (tile, channel) meet in LDS (two rounds of 16 tiles, 72 KB each) and every thread applies
+// A^T . A to two tiles per round and finishes their 4x4 pixels with the usual epilogue.
+// Patch chunk (4 channels of one pixel): ((half*18 + row)*38 + (col&3)*9 + (col>>2)): the columns a tile row of lanes reads are
+// consecutive chunks and a row of tiles starts 8 chunks further modulo 16, which makes every 16-lane group of a ds_read_b128 hit
+// 16 different 16-byte slots.  Weight slot: [half][32 couts][4 channels] = the lane order of the DMA.
+// ---------------------------------------------------------------------------------------------
+constexpr float W4_A = 0.75f, W4_B = 1.5f;
+constexpr float W4_C0 = W4_A * W4_A * W4_B * W4_B, W4_C2 = -(W4_A * W4_A + W4_B * W4_B);
+__device__ __forceinline__ f32x4 fma4(float c, f32x4 x, f32x4 y) { return __builtin_elementwise_fma((f32x4)(c), x, y); }
+// three rows of B^T applied to five consecutive window elements: BLK 0 = rows (0, +a, -a) on d0..d4, BLK 1 = rows (+b, -b, inf) on d1..d5
+template <int BLK>
+__device__ __forceinline__ void w4_fwd(const f32x4 (&x)[5], f32x4 (&o)[3]) {
+    if constexpr (BLK == 0) {
+        o[0] = fma4(W4_C0, x[0], fma4(W4_C2, x[2], x[4]));
+        const f32x4 e = fma4(-W4_B * W4_B, x[2], x[4]), t = fma4(-W4_B * W4_B, x[1], x[3]);
+        o[1] = fma4(W4_A, t, e);
+        o[2] = fma4(-W4_A, t, e);
+    } else {
+        const f32x4 e = fma4(-W4_A * W4_A, x[1], x[3]), t = fma4(-W4_A * W4_A, x[0], x[2]);
+        o[0] = fma4(W4_B, t, e);
+        o[1] = fma4(-W4_B, t, e);
+        o[2] = fma4(W4_C0, x[0], fma4(W4_C2, x[2], x[4]));
+    }
+}
+// one side of the output transform: four outputs from the six frequencies (0, +a, -a, +b, -b, inf)
+__device__ __forceinline__ void w4_out(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    y[0] = (m0 + s1) + s2;
+    y[1] = fmaf(W4_B, d2, W4_A * d1);
+    y[2] = fmaf(W4_B * W4_B, s2, (W4_A * W4_A) * s1);
+    y[3] = fmaf(W4_B * W4_B * W4_B, d2, fmaf(W4_A * W4_A * W4_A, d1, m5));
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool UPS>
+__global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
+#if __HIP_DEVICE_COMPILE__   // device pass only (see k_conv_bf3)
+    constexpr int PRW = 38, PROWS = 18, P_REAL = 2 * PROWS * PRW, NP = (P_REAL + 63) / 64, P_F = P_REAL * 4;   // patch: chunks / row, rows, chunks, DMAs, floats
+    constexpr int U_F = 36 * 256;                                                                            // 36 weight slots of 1 KiB
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = p.n_mtiles * p.n_nblocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int tb = wi / p.n_nblocks, nb = wi - tb * p.n_nblocks;
+    const int n0 = nb * 32;
+    const int Hv = UPS ? 2 * p.Hin : p.Hin, Wv = UPS ? 2 * p.Win : p.Win;
+    const int bw = Wv >> 5, bh = Hv >> 4;
+    const int img = tb / (bw * bh), brem = tb - img * (bw * bh);
+    const int y0 = (brem / bw) * 16, x0 = (brem - (brem / bw) * bw) * 32;
+    const int nkt = p.Cin >> 3;
+    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+    const int kt0 = blockIdx.z * p.kt_per;                        // split-K over input channels: this slab's k-tiles
+    const int ntiles = min(nkt, kt0 + p.kt_per) - kt0;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * p.in_pitch * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.w_wino, (short)0, (int)((long)p.n_nblocks * nkt * U_F * 4), 0x00020000);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // everything inside the K walk is compiled once per wave: its frequency block (FR, FC) and its share of the patch DMAs
+    auto run = [&](auto wc) {
+        constexpr int W = decltype(wc)::value, FR = W >> 1, FC = W & 1, NPW = (NP - W + 3) / 4;
+        unsigned pv[NPW];
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int c = (W + 4 * j) * 64 + lane;                    // patch chunk
+            const int h = c / (PROWS * PRW), rem = c - h * (PROWS * PRW), row = rem / PRW, q = rem - row * PRW;
+            const int col = (q % 9) * 4 + q / 9;
+            const int y = y0 - 1 + row, x = x0 - 1 + col;
+            const bool ok = c < P_REAL && q < 36 && col < 34 && y >= 0 && y < Hv && x >= 0 && x < Wv;
+            const int ys = UPS ? y >> 1 : y, xs = UPS ? x >> 1 : x;
+            pv[j] = ok ? (unsigned)((img * p.Hin + ys) * p.Win + xs) * pitch4 + h * 16 : OOB;
+        }
+        int soffA = kt0 * 32;
+        int soffU = ((nb * nkt + kt0) * 36 + W * 9) * 1024;           // this wave's first slice of k-tile kt0
+        const unsigned uvp = (unsigned)lane * 16u;
+        const int T = lane & 31, ty = T >> 3, tx = T & 7;
+        const float *pread = lds + U_F + ((half * PROWS + 4 * ty + FR) * PRW + tx) * 4;   // + stage*P_F + (rr*PRW + coff(c))*4
+        const float *uread = lds + W * 9 * 256 + lane * 4;                                // + f*256
+
+        auto issue_p = [&](int stage) {
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+                // the last instruction is ragged (P_REAL is not a multiple of 64): its tail lanes are switched off, so that a stage
+                // is exactly P_REAL chunks and two workgroups fit a CU's 160 KB
+                if ((W + 4 * j + 1) * 64 <= P_REAL || lane < P_REAL - (W + 4 * j) * 64)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rsA, (__attribute__((address_space(3))) void *)(lds + U_F + stage * P_F + (W + 4 * j) * 256), 16, pv[j], soffA, 0, 0);
+            }
+            soffA += 32;
+        };
+        auto issue_u = [&](int f) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void *)(lds + (W * 9 + f) * 256), 16, uvp,
+                                                     soffU + f * 1024, 0, 0);
+        };
+        f32x4 V[9], ub[2];
+        // columns in the order the horizontal sums want them (each partial is one fma chain), so that only three partials per
+        // frequency row are live next to the column being transformed: (0,+a,-a) needs 4,2,0,3,1; (+b,-b,inf) needs 3,1,4,2,0
+        f32x4 x[5];
+        auto load_col = [&](int stage, int k) {
+            constexpr int ord0[5] = {4, 2, 0, 3, 1}, ord1[5] = {3, 1, 4, 2, 0};
+            const int c = FC + (FC == 0 ? ord0[k] : ord1[k]), coff = ((c & 3) * 9 + (c >> 2)) * 4;
+            const float *pb = pread + stage * P_F + coff;
+#pragma unroll
+            for (int rr = 0; rr < 5; ++rr) x[rr] = *reinterpret_cast<const f32x4 *>(pb + rr * PRW * 4);
+        };
+        auto transform = [&](int stage) {   // the first column is already on its way (load_col(stage, 0))
+            f32x4 P[3][3];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                f32x4 o[3];
+                w4_fwd<FR>(x, o);
+                // (asm pins: the instruction selector otherwise issues all 25 reads first and keeps them live)
+                asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]) : : "memory");
+                if (k < 4) load_col(stage, k + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii) {
+                    const f32x4 y = o[ii];
+                    if constexpr (FC == 0) {
+                        if (k == 0) P[ii][0] = y;
+                        else if (k == 1) { P[ii][1] = fma4(-W4_B * W4_B, y, P[ii][0]); P[ii][0] = fma4(W4_C2, y, P[ii][0]); }
+                        else if (k == 2) P[ii][0] = fma4(W4_C0, y, P[ii][0]);
+                        else if (k == 3) P[ii][2] = y;
+                        else P[ii][2] = fma4(-W4_B * W4_B, y, P[ii][2]);
+                    } else {
+                        if (k == 0) P[ii][0] = y;
+                        else if (k == 1) P[ii][0] = fma4(-W4_A * W4_A, y, P[ii][0]);
+                        else if (k == 2) P[ii][2] = y;
+                        else if (k == 3) { P[ii][2] = fma4(W4_C2, y, P[ii][2]); P[ii][1] = y; }
+                        else { P[ii][1] = fma4(-W4_A * W4_A, y, P[ii][1]); P[ii][2] = fma4(W4_C0, y, P[ii][2]); }
+                    }
+                }
+                auto pin = [&](int j) { asm volatile("" : "+v"(P[0][j]), "+v"(P[1][j]), "+v"(P[2][j]) : : "memory"); };
+                if (k < 4) {
+                    pin(0);
+                    if (FC == 0 ? k >= 1 : k >= 3) pin(1);
+                    if (FC == 0 ? k >= 3 : k >= 2) pin(2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii) {
+                if constexpr (FC == 0) {
+                    V[ii * 3 + 0] = P[ii][0];
+                    V[ii * 3 + 1] = fma4(W4_A, P[ii][2], P[ii][1]);
+                    V[ii * 3 + 2] = fma4(-W4_A, P[ii][2], P[ii][1]);
+                } else {
+                    V[ii * 3 + 0] = fma4(W4_B, P[ii][1], P[ii][0]);
+                    V[ii * 3 + 1] = fma4(-W4_B, P[ii][1], P[ii][0]);
+                    V[ii * 3 + 2] = P[ii][2];
+                }
+            }
+            // the transform is finished HERE: without a use in this block the compiler sinks the arithmetic behind the barrier
+            // and keeps all 25 window reads live instead (spills)
+            asm volatile("" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(V[4]), "+v"(V[5]), "+v"(V[6]), "+v"(V[7]), "+v"(V[8]));
+        };
+        if (ntiles > 0) {
+            issue_p(0);
+            if (ntiles > 1) issue_p(1);
+#pragma unroll
+            for (int f = 0; f < 9; ++f) issue_u(f);
+            soffU += 36 * 1024;
+            wait_vmcnt<9>();                                          // the patches have landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            load_col(0, 0);
+        }
+        auto body = [&](auto sc, int t) {
+            constexpr int S = decltype(sc)::value;
+            const bool more = t + 1 < ntiles, more2 = t + 2 < ntiles;
+            transform(S);
+            if (more) {
+                // every wave has read patch t; patch t+1 (issued one k-tile ago, only the nine U(t, .) are younger) is published
+                wait_vmcnt<9>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (more2) issue_p(S);
+            }
+            // U(t, f) was issued one k-tile ago; younger when slot f+1 is read in unit f: U(t, f+2..8), the NPW of P(t+2), the f refills
+            // of this k-tile = 7 + NPW (the first read: 8 + NPW).  Without P: 7 / 8; the last k-tile drains the queue.
+            if (more2) wait_vmcnt<8 + NPW>(); else if (more) wait_vmcnt<8>(); else wait_vmcnt<0>();
+            ub[0] = *reinterpret_cast<const f32x4 *>(uread);
+#pragma unroll
+            for (int f = 0; f < 9; ++f) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][0], ub[f & 1][0], acc[f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (f < 8) {
+                    if (more2) wait_vmcnt<7 + NPW>(); else if (more) wait_vmcnt<7>();
+                    ub[(f + 1) & 1] = *reinterpret_cast<const f32x4 *>(uread + (f + 1) * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 1; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][s], acc[f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) issue_u(f);                                 // the slot just consumed refills for k-tile t+1
+                if (f == 6 && more) load_col(S ^ 1, 0);               // first window column of k-tile t+1 (published at the barrier above)
+            }
+            if (more) soffU += 36 * 1024;
+        };
+        for (int t = 0; t < ntiles; t += 2) {
+            body(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, t + 1);
+        }
+    };
+    switch (wave) {
+        case 0: run(std::integral_constant<int, 0>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        default: run(std::integral_constant<int, 3>{}); break;
+    }
+
+    // the 36 frequencies of a (tile, channel) meet in LDS: two rounds of 16 tiles; [freq][tile][cout]
+    const int fbase = (3 * (wave >> 1)) * 6 + 3 * (wave & 1);
+    const int n = n0 + (lane & 31);
+    const float bs = (p.bias && !p.partial) ? p.bias[n] : 0.f;
+    const long hw = (long)Hv * Wv;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 9; ++f) {
+            const int F = fbase + (f / 3) * 6 + (f % 3);
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = 8 * q + rr, mloc = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+                lds[(F * 16 + mloc) * 32 + (lane & 31)] = acc[f][r];
+            }
+        }
+        __syncthreads();
+        float s1 = 0.f, q1 = 0.f, s2 = 0.f, q2 = 0.f;                  // GroupNorm statistics of this lane's channel over its two tiles
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int mloc = wave * 4 + half * 2 + pp;
+            const float *zz = lds + mloc * 32 + (lane & 31);
+            float z[4][6];                                            // rows of A^T applied: z[p][j]
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float col[4];
+                w4_out(zz[(0 * 6 + j) * 512], zz[(1 * 6 + j) * 512], zz[(2 * 6 + j) * 512], zz[(3 * 6 + j) * 512], zz[(4 * 6 + j) * 512],
+                       zz[(5 * 6 + j) * 512], col);
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) z[pr][j] = col[pr];
+            }
+            const int Tg = q * 16 + mloc, oy = y0 + 4 * (Tg >> 3), ox = x0 + 4 * (Tg & 7);
+            const long m0 = ((long)img * Hv + oy) * Wv + ox;          // pixel (pr, qc) of the tile: m0 + pr*Wv + qc
+            float v[16];
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                float row[4];
+                w4_out(z[pr][0], z[pr][1], z[pr][2], z[pr][3], z[pr][4], z[pr][5], row);
+#pragma unroll
+                for (int qc = 0; qc < 4; ++qc) v[pr * 4 + qc] = row[qc] + bs;
+            }
+            if (p.partial) {   // split-K: the output transform is linear, so slabs are summed in the output domain by k_splitk_finish
+                float *dst = p.partial + (long)blockIdx.z * p.M * p.Cout + m0 * p.Cout + n;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) dst[((k >> 2) * Wv + (k & 3)) * p.Cout] = v[k];
+                continue;
+            }
+            if (p.res) {
+                const float *rp = p.res + m0 * p.res_pitch + n;
+                float rr[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) rr[k] = rp[((k >> 2) * Wv + (k & 3)) * p.res_pitch];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] += rr[k];
+            }
+            float v2[16];
+            if (p.out2) {
+                const float *rp = p.res2 + m0 * p.res2_pitch + n;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v2[k] = rp[((k >> 2) * Wv + (k & 3)) * p.res2_pitch];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v2[k] += v[k];
+            }
+            if (p.st1) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { s1 += v[k]; q1 += v[k] * v[k]; }
+            }
+            if (p.st2) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { s2 += v2[k]; q2 += v2[k] * v2[k]; }
+            }
+            if (p.out_nchw) {
+                float *op = p.out + ((long)img * p.Cout + n) * hw + (m0 - (long)img * hw);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) op[(k >> 2) * Wv + (k & 3)] = v[k];
+            } else {
+                float *op = p.out + m0 * p.out_pitch + n;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) op[((k >> 2) * Wv + (k & 3)) * p.out_pitch] = v[k];
+            }
+            if (p.out2) {
+                float *op = p.out2 + m0 * p.out2_pitch + n;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) op[((k >> 2) * Wv + (k & 3)) * p.out2_pitch] = v2[k];
+            }
+        }
+        // slot = (tile block, round, wave): two lane halves x two tiles = 64 pixels of one image
+        if (!p.partial && p.st1) {
+            s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
+            if (half == 0) *reinterpret_cast<float2 *>(p.st1 + ((((long)tb * 2 + q) * 4 + wave) * p.Cout + n) * 2) = make_float2(s1, q1);
+        }
+        if (!p.partial && p.st2) {
+            s2 += __shfl_xor(s2, 32); q2 += __shfl_xor(q2, 32);
+            if (half == 0) *reinterpret_cast<float2 *>(p.st2 + ((((long)tb * 2 + q) * 4 + wave) * p.Cout + n) * 2) = make_float2(s2, q2);
+        }
+    }
+#endif
+}
+
+// weights -> U = G g G^T (6x6) per (cout, cin) for k_conv_wino4: [cout/32][cin/8][wave 4][f 9][half][32][4]; wave (fr, fc), f = 3*ii + jj:
+// frequency (3*fr + ii, 3*fc + jj) in the order (0, +a, -a, +b, -b, inf)
+__global__ void k_pack_conv_wino4(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, float *__restrict__ dst, int tf) {
+    const int nkt = Cin_pad >> 3;
+    const long n = (long)Cout * Cin_pad * 36;
+    const double a = W4_A, b = W4_B, n0 = a * a * b * b, na = 2 * a * a * (a * a - b * b), nb_ = 2 * b * b * (b * b - a * a);
+    const double G[6][3] = {{1 / n0, 0, 0}, {1 / na, a / na, a * a / na}, {1 / na, -a / na, a * a / na},
+                            {1 / nb_, b / nb_, b * b / nb_}, {1 / nb_, -b / nb_, b * b / nb_}, {0, 0, 1}};
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(e & 3), nn = (int)((e >> 2) & 31), hf = (int)((e >> 7) & 1);
+        const long r1 = e >> 8;
+        const int wf = (int)(r1 % 36);
+        const long r2 = r1 / 36;
+        const int kt = (int)(r2 % nkt), nb = (int)(r2 / nkt);
+        const int wv = wf / 9, f = wf - wv * 9;
+        const int i = 3 * (wv >> 1) + f / 3, j = 3 * (wv & 1) + f % 3;
+        const int co = nb * 32 + nn, ci = kt * 8 + hf * 4 + s;
+        float v = 0.f;
+        if (ci < Cin && co < Cout) {
+            const float *g = tf ? w + ((long)ci * Cout + co) * 9 : w + ((long)co * Cin + ci) * 9;
+            double acc = 0.0;
+            for (int u = 0; u < 3; ++u)
+                for (int vv = 0; vv < 3; ++vv) acc += G[i][u] * (double)g[tf ? 8 - (u * 3 + vv) : u * 3 + vv] * G[j][vv];
+            v = (float)acc;
+        }
+        dst[e] = v;
+    }
+}
+
 // k_conv_bf3: k_conv_dma with the fp32 products emulated on the bf16 matrix pipe (opt-in, see hl_unet_set_conv_mode).
 template <int WM, bool UPS>
 __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_bf3(const ConvK p) {
@@ -1953,6 +2329,16 @@ int conv_pack_weights_wino(const float *w, int Cout, int Cin, int Cin_pad, float
     return check_launch("k_pack_conv_wino");
 }
 
+size_t conv_packed_wino4_bytes(int Cout, int Cin_pad, int ks) {
+    return (ks == 3 && Cout % 32 == 0 && Cin_pad % 8 == 0) ? (size_t)Cout * Cin_pad * 36 * sizeof(float) : 0;
+}
+
+int conv_pack_weights_wino4(const float *w, int Cout, int Cin, int Cin_pad, float *packed, hipStream_t st, int tf) {
+    HL_REQUIRE(w && packed && Cout % 32 == 0 && Cin_pad % 8 == 0 && Cin <= Cin_pad, "conv_pack_weights_wino4: bad argument");
+    hipLaunchKernelGGL(k_pack_conv_wino4, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, packed, tf);
+    return check_launch("k_pack_conv_wino4");
+}
+
 static inline long hw_o_early(const ConvArgs &a) { return (long)a.out.H * a.out.W; }
 
 int conv2d(const ConvArgs &a, hipStream_t st) {
@@ -2063,8 +2449,20 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         splits = (a.in.C / 8 + p.kt_per - 1) / p.kt_per;
         p.partial = splits > 1 ? a.splitk_ws : nullptr;
     }
+    // the same layers by Winograd F(4x4,3x3) (32x16-pixel x 32-channel workgroups, a quarter of the direct multiplies) where that
+    // alone fills the chip
+    constexpr long wino4_thr = 512;
+    const long wino4_blocks = (long)a.out.N * (a.out.H / 16) * (a.out.W / 32) * (a.Cout / 32);
+    const bool wino4 = dma && a.w_wino4 && !a.w_bf3 && a.ks == 3 && a.stride == 1 && a.out.H % 16 == 0 && a.out.W % 32 == 0 &&
+                       a.Cout % 32 == 0 && (long)a.Cout * a.in.C * 144 < (1L << 31) && wino4_blocks >= wino4_thr;
+    if (wino4) {
+        wino = false;
+        splits = 1;
+        p.kt_per = a.in.C / 8;
+        p.partial = nullptr;
+    }
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
-        a.path = (dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0);
+        a.path = (dma && wino4) ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0));
         return HL_OK;
     }
     if (dma) {
@@ -2077,6 +2475,22 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix,
                                a.in.C, a.coefA, a.coefB, a.act, a.act_ws);
             p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0;
+        }
+        if (wino4) {
+            a.path = 3;
+            p.w_wino = a.w_wino4;
+            p.n_nblocks = a.Cout / 32;
+            p.n_mtiles = a.out.N * (a.out.H / 16) * (a.out.W / 32);
+            const dim3 nblk((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
+            const size_t sh4 = (size_t)(36 * 256 + 2 * 1368 * 4) * sizeof(float);   // 78.75 KB: two workgroups per CU
+            if (splits == 1 && a.stats && !a.out_nchw) {   // statistics from the epilogue: slot = (32x16 block, round, wave) = 64 pixels
+                p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
+                a.stat_slots = (a.out.H / 16) * (a.out.W / 32) * 8;
+            }
+            if (a.ups) hipLaunchKernelGGL((k_conv_wino4<true>), nblk, dim3(256), sh4, st, p);
+            else hipLaunchKernelGGL((k_conv_wino4<false>), nblk, dim3(256), sh4, st, p);
+            if (splits > 1) return finish("k_conv_wino4");
+            return check_launch("k_conv_wino4");
         }
         if (wino) {
             a.path = 1;

@@ -229,7 +229,7 @@ class UNetModel(nn.Module):
         same fp32 tensors and accumulators, each product formed on the bf16 matrix pipe from exact three-way bf16
         splits of both factors, six partial products; error per product <= 3*2^-24 - fp32 class, not bit-identical).
         See include/humanliff_hip.h HL_CONV_*."""
-        modes = {"fp32": _lib.HL_CONV_FP32, "bf16x3": _lib.HL_CONV_BF16X3, "fp32_direct": _lib.HL_CONV_FP32_DIRECT}
+        modes = {"fp32": _lib.HL_CONV_FP32, "bf16x3": _lib.HL_CONV_BF16X3, "fp32_direct": _lib.HL_CONV_FP32_DIRECT, "fp32_f43": _lib.HL_CONV_FP32_F43}
         if mode not in modes:
             raise ValueError(f"unknown conv mode {mode!r} (expected one of {sorted(modes)})")
         self._conv_mode = modes[mode]

@@ -294,6 +294,7 @@ int hl_unet_set_overlap(void *handle, int enable);
 #define HL_CONV_FP32 0
 #define HL_CONV_BF16X3 1
 #define HL_CONV_FP32_DIRECT 2
+#define HL_CONV_FP32_F43 3
 int hl_unet_set_conv_mode(void *handle, int mode);
 
 /* Instrumentation for the roofline measurement (bench.py): with profiling enabled every kernel launch

@@ -32,7 +32,7 @@ def hip_conv(x, w, b, ks, stride=1, ups=0, cA=None, cB=None, silu=0, res=None, m
     Ho, Wo = (Hv + 2 * (ks // 2) - ks) // stride + 1, (Wv + 2 * (ks // 2) - ks) // stride + 1
     out = torch.empty((N, Ho, Wo, Cout), device=dev)
     # packed weights + room for split-K partial sums (taken for shapes that would under-fill the chip)
-    scratch = torch.empty(((Cout + 63) // 64 * 64) * C * ks * ks * 3 + 256 + (8 << 20) + N * C * H * W, device=dev)
+    scratch = torch.empty(((Cout + 63) // 64 * 64) * C * ks * ks * 5 + 256 + (8 << 20) + N * C * H * W, device=dev)
     d = lambda t: None if t is None else t.contiguous().to(dev)  # noqa: E731
     wd, bd, cAd, cBd = d(w), d(b), d(cA), d(cB)
     rd = d(nhwc(res)) if res is not None else None
@@ -145,6 +145,46 @@ def test_conv_winograd_matches_torch(N, C, H, W, Cout, with_gn):
     e_w, e_d = (got.double() - want).abs().max().item(), (direct.double() - want).abs().max().item()
     assert e_w < 2e-5, (e_w, e_d)                            # the direct kernel's bound (outputs O(1))
     assert e_w < 8 * e_d + 1e-6, (e_w, e_d)                  # F(2x2,3x3) amplifies rounding by a small constant
+
+
+@pytest.mark.parametrize("N,C,H,W,Cout,with_gn,ups", [
+    (4, 32, 128, 128, 192, False, 0),   # 768 workgroups, 4 k-tiles
+    (1, 192, 256, 256, 192, False, 0),  # production shape (batch 1): 24 k-tiles
+    (3, 96, 176, 224, 192, False, 0),   # non-square: H a multiple of 16, W of 32
+    (2, 64, 256, 128, 192, True, 0),    # GroupNorm+SiLU prologue (materialised), residual epilogue
+    (9, 48, 64, 64, 384, False, 0),     # 12 channel blocks, odd k-tile count (6) and batch
+    (2, 16, 128, 256, 192, False, 0),   # two k-tiles
+    (4, 96, 64, 48, 192, False, 1),     # nearest x2 upsample in front (the patch DMA reads source pixel (y>>1, x>>1))
+])
+def test_conv_winograd_f43_matches_torch(N, C, H, W, Cout, with_gn, ups):
+    """HL_CONV_FP32_F43: the same layers by Winograd F(4x4,3x3) with the points (0, +-3/4, +-3/2, inf) - a quarter of the direct
+    multiplies, fp32 throughout; compared with float64 torch and with the direct kernel on the same inputs."""
+    from humanliff_amd import _lib
+    g = torch.Generator().manual_seed(N * 1000 + C + H + Cout)
+    x = torch.randn((N, C, H, W), generator=g)
+    w = torch.randn((Cout, C, 3, 3), generator=g) / (C * 9) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    kw = {}
+    xin = x.double()
+    if with_gn:
+        cA, cB = torch.rand((N, C), generator=g) + 0.5, torch.randn((N, C), generator=g) * 0.3
+        res = torch.randn((N, Cout, H, W), generator=g)
+        kw = dict(cA=cA, cB=cB, silu=1, res=res)
+        hn = x.double() * cA.double()[:, :, None, None] + cB.double()[:, :, None, None]
+        xin = hn * torch.sigmoid(hn)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    got = hip_conv(x, w, b, 3, ups=ups, mode=_lib.HL_CONV_FP32_F43, **kw)
+    f23 = hip_conv(x, w, b, 3, ups=ups, mode=_lib.HL_CONV_FP32, **kw)
+    direct = hip_conv(x, w, b, 3, ups=ups, mode=_lib.HL_CONV_FP32_DIRECT, **kw)
+    want = F.conv2d(xin, w.double(), b.double(), padding=1)
+    if with_gn:
+        want = want + res.double()
+    assert not torch.equal(got, direct) and not torch.equal(got, f23)   # the F(4x4) kernel really ran
+    e_w, e_d = (got.double() - want).abs().max().item(), (direct.double() - want).abs().max().item()
+    r_w, r_d = (got.double() - want).pow(2).mean().sqrt().item(), (direct.double() - want).pow(2).mean().sqrt().item()
+    assert e_w < 4e-5, (e_w, e_d)                            # outputs O(1)
+    assert r_w < 8 * r_d + 1e-7, (r_w, r_d)                  # rms error within a small constant of the direct kernel's
 
 
 def test_conv_fused_groupnorm_silu_residual():
@@ -440,7 +480,7 @@ def test_conv_epilogue_groupnorm_statistics(N, C, H, W, Cout, ks, stride, ups, m
     rd = d(nhwc(res)) if res is not None else None
     out = torch.empty((N, Ho, Wo, Cout), device=dev)
     nA, nB = torch.empty((N, Cout), device=dev), torch.empty((N, Cout), device=dev)
-    scratch = torch.empty(((Cout + 63) // 64 * 64) * C * ks * ks * 3 + 256 + (8 << 20) + N * C * H * W + N * Ho * Wo * Cout // 8 + N * 8192,
+    scratch = torch.empty(((Cout + 63) // 64 * 64) * C * ks * ks * 5 + 256 + (8 << 20) + N * C * H * W + N * Ho * Wo * Cout // 8 + N * 8192,
                           device=dev)
     import ctypes
     used = ctypes.c_int(-1)
