@@ -926,7 +926,7 @@ __global__ void k_pack_conv_wino(const float *__restrict__ w, int Cout, int Cin,
 //     inf : a2b2 d1 - (a2+b2) d3 + d5                       +-b : (-a2 d2 + d4) +- b (-a2 d1 + d3)
 // A workgroup owns 8x4 tiles of 4x4 outputs (a 32x16 pixel block, 32 tiles = the MFMA M dimension) x 32 output channels x all 36
 // frequencies; wave (fr, fc) of its 4 waves owns the 3x3 frequency block rows {0,+a,-a} or {+b,-b,inf} x columns likewise:
-// 9 accumulator tiles = 144 registers, 2 waves / SIMD, two workgroups per CU (2 x 78.75 KB of LDS).
+// 9 accumulator tiles = 144 registers, 2 waves / SIMD, two workgroups per CU (2 x 76.5 KB of LDS).
 // Per k-tile of 8 input channels:
 //   * the 34x18 input patch arrives by LDS-DMA into a 2-stage ring (22 instructions per workgroup) and the wave's nine 32x8
 //     weight slices U = G g G^T by LDS-DMA into nine PRIVATE single-buffered 1 KiB slots: a slot is refilled for the next k-tile
@@ -938,13 +938,24 @@ __global__ void k_pack_conv_wino(const float *__restrict__ w, int Cout, int Cin,
 //     other workgroup's wave on the same SIMD fills the matrix pipe meanwhile.
 // After the K walk the 36 frequencies of a (tile, channel) meet in LDS (two rounds of 16 tiles, 72 KB each) and every thread applies
 // A^T . A to two tiles per round and finishes their 4x4 pixels with the usual epilogue.
-// Patch chunk (4 channels of one pixel): ((half*18 + row)*38 + (col&3)*9 + (col>>2)): the columns a tile row of lanes reads are
-// consecutive chunks and a row of tiles starts 8 chunks further modulo 16, which makes every 16-lane group of a ds_read_b128 hit
-// 16 different 16-byte slots.  Weight slot: [half][32 couts][4 channels] = the lane order of the DMA.
+// Patch chunk (4 channels of one pixel): (row*36 + (col&3)*9 + (col>>2))*2 + (half ^ bit 2 of row): the two halves of a pixel are
+// neighbours, fetched by neighbouring DMA lanes - 32 contiguous bytes, one L2 request instead of two (with one 16-byte piece per
+// request the kernel ran at the L2's request rate: 0.6 requests per clock and channel, 94 % hits) - and the swap by the row bit puts
+// the tiles of rows ty and ty+1 on the even and the odd 16-byte slots, so that every 16-lane group of a ds_read_b128 still hits 16
+// different slots.  Weight slot: [half][32 couts][4 channels] = the lane order of the DMA.
 // ---------------------------------------------------------------------------------------------
 constexpr float W4_A = 0.75f, W4_B = 1.5f;
 constexpr float W4_C0 = W4_A * W4_A * W4_B * W4_B, W4_C2 = -(W4_A * W4_A + W4_B * W4_B);
+#ifdef W4_SCALAR_FMA
+__device__ __forceinline__ f32x4 fma4(float c, f32x4 x, f32x4 y) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float t; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "s"(c), "v"(x[i]), "v"(y[i])); r[i] = t; }
+    return r;
+}
+#else
 __device__ __forceinline__ f32x4 fma4(float c, f32x4 x, f32x4 y) { return __builtin_elementwise_fma((f32x4)(c), x, y); }
+#endif
 // three rows of B^T applied to five consecutive window elements: BLK 0 = rows (0, +a, -a) on d0..d4, BLK 1 = rows (+b, -b, inf) on d1..d5
 template <int BLK>
 __device__ __forceinline__ void w4_fwd(const f32x4 (&x)[5], f32x4 (&o)[3]) {
@@ -974,7 +985,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 template <bool UPS>
 __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__   // device pass only (see k_conv_bf3)
-    constexpr int PRW = 38, PROWS = 18, P_REAL = 2 * PROWS * PRW, NP = (P_REAL + 63) / 64, P_F = P_REAL * 4;   // patch: chunks / row, rows, chunks, DMAs, floats
+    constexpr int PRW = 36, PROWS = 18, P_REAL = 2 * PROWS * PRW, NP = (P_REAL + 63) / 64, P_F = P_REAL * 4;   // patch: pixels / row, rows, chunks, DMAs, floats
     constexpr int U_F = 36 * 256;                                                                            // 36 weight slots of 1 KiB
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1012,11 +1023,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
         unsigned pv[NPW];
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
-            const int c = (W + 4 * j) * 64 + lane;                    // patch chunk
-            const int h = c / (PROWS * PRW), rem = c - h * (PROWS * PRW), row = rem / PRW, q = rem - row * PRW;
+            const int c = (W + 4 * j) * 64 + lane;                    // patch chunk: lanes 2i, 2i+1 fetch the two halves of one pixel
+            const int pixp = c >> 1, row = pixp / PRW, q = pixp - row * PRW, h = (c & 1) ^ ((row >> 2) & 1);
             const int col = (q % 9) * 4 + q / 9;
             const int y = y0 - 1 + row, x = x0 - 1 + col;
-            const bool ok = c < P_REAL && q < 36 && col < 34 && y >= 0 && y < Hv && x >= 0 && x < Wv;
+            const bool ok = c < P_REAL && col < 34 && y >= 0 && y < Hv && x >= 0 && x < Wv;
             const int ys = UPS ? y >> 1 : y, xs = UPS ? x >> 1 : x;
             pv[j] = ok ? (unsigned)((img * p.Hin + ys) * p.Win + xs) * pitch4 + h * 16 : OOB;
         }
@@ -1024,7 +1035,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
         int soffU = ((nb * nkt + kt0) * 36 + W * 9) * 1024;           // this wave's first slice of k-tile kt0
         const unsigned uvp = (unsigned)lane * 16u;
         const int T = lane & 31, ty = T >> 3, tx = T & 7;
-        const float *pread = lds + U_F + ((half * PROWS + 4 * ty + FR) * PRW + tx) * 4;   // + stage*P_F + (rr*PRW + coff(c))*4
+        // window row rr of this lane's tile is patch row 4*ty + FR + rr; its pixels' halves are swapped when bit 2 of the row is set
+        const float *pread = lds + U_F + (((4 * ty + FR) * PRW + tx) * 2 + (half ^ (ty & 1))) * 4;   // + stage*P_F + ((rr*PRW + coff(c))*2 +- 1)*4
         const float *uread = lds + W * 9 * 256 + lane * 4;                                // + f*256
 
         auto issue_p = [&](int stage) {
@@ -1048,10 +1060,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
         f32x4 x[5];
         auto load_col = [&](int stage, int k) {
             constexpr int ord0[5] = {4, 2, 0, 3, 1}, ord1[5] = {3, 1, 4, 2, 0};
-            const int c = FC + (FC == 0 ? ord0[k] : ord1[k]), coff = ((c & 3) * 9 + (c >> 2)) * 4;
+            const int c = FC + (FC == 0 ? ord0[k] : ord1[k]), coff = ((c & 3) * 9 + (c >> 2)) * 8;
             const float *pb = pread + stage * P_F + coff;
+            const int flip = (half ^ (ty & 1)) ? -4 : 4;              // rows 4, 5 of the window: the other half-slot of the pixel
 #pragma unroll
-            for (int rr = 0; rr < 5; ++rr) x[rr] = *reinterpret_cast<const f32x4 *>(pb + rr * PRW * 4);
+            for (int rr = 0; rr < 5; ++rr) x[rr] = *reinterpret_cast<const f32x4 *>(pb + rr * PRW * 8 + (((FR + rr) >> 2) & 1) * flip);
         };
         auto transform = [&](int stage) {   // the first column is already on its way (load_col(stage, 0))
             f32x4 P[3][3];
@@ -1118,14 +1131,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
         auto body = [&](auto sc, int t) {
             constexpr int S = decltype(sc)::value;
             const bool more = t + 1 < ntiles, more2 = t + 2 < ntiles;
+#ifndef W4_NO_XFORM
             transform(S);
+#endif
             if (more) {
                 // every wave has read patch t; patch t+1 (issued one k-tile ago, only the nine U(t, .) are younger) is published
                 wait_vmcnt<9>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+#ifndef W4_NO_DMA
                 if (more2) issue_p(S);
+#endif
             }
             // U(t, f) was issued one k-tile ago; younger when slot f+1 is read in unit f: U(t, f+2..8), the NPW of P(t+2), the f refills
             // of this k-tile = 7 + NPW (the first read: 8 + NPW).  Without P: 7 / 8; the last k-tile drains the queue.
@@ -1135,17 +1152,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
             for (int f = 0; f < 9; ++f) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef W4_NO_MFMA
                 acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][0], ub[f & 1][0], acc[f], 0, 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (f < 8) {
                     if (more2) wait_vmcnt<7 + NPW>(); else if (more) wait_vmcnt<7>();
                     ub[(f + 1) & 1] = *reinterpret_cast<const f32x4 *>(uread + (f + 1) * 256);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef W4_NO_MFMA
 #pragma unroll
                 for (int s = 1; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][s], acc[f], 0, 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef W4_NO_DMA
                 if (more) issue_u(f);                                 // the slot just consumed refills for k-tile t+1
+#endif
                 if (f == 6 && more) load_col(S ^ 1, 0);               // first window column of k-tile t+1 (published at the barrier above)
             }
             if (more) soffU += 36 * 1024;
@@ -1162,6 +1185,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
         default: run(std::integral_constant<int, 3>{}); break;
     }
 
+#ifdef W4_NO_EPI
+    if (acc[0][0] == 123.f) p.out[0] = acc[1][2] + acc[2][0] + acc[3][0] + acc[4][0] + acc[5][0] + acc[6][0] + acc[7][0] + acc[8][0];
+    return;
+#endif
     // the 36 frequencies of a (tile, channel) meet in LDS: two rounds of 16 tiles; [freq][tile][cout]
     const int fbase = (3 * (wave >> 1)) * 6 + 3 * (wave & 1);
     const int n = n0 + (lane & 31);
@@ -1234,6 +1261,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) { s2 += v2[k]; q2 += v2[k] * v2[k]; }
             }
+#ifdef W4_NO_STORE
+            if (v[0] == 123.f) p.out[0] = v[1] + v[5] + v2[3];
+            continue;
+#endif
             if (p.out_nchw) {
                 float *op = p.out + ((long)img * p.Cout + n) * hw + (m0 - (long)img * hw);
 #pragma unroll
@@ -2482,7 +2513,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             p.n_nblocks = a.Cout / 32;
             p.n_mtiles = a.out.N * (a.out.H / 16) * (a.out.W / 32);
             const dim3 nblk((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
-            const size_t sh4 = (size_t)(36 * 256 + 2 * 1368 * 4) * sizeof(float);   // 78.75 KB: two workgroups per CU
+            const size_t sh4 = (size_t)(36 * 256 + 2 * 1296 * 4) * sizeof(float);   // 76.5 KB: two workgroups per CU
             if (splits == 1 && a.stats && !a.out_nchw) {   // statistics from the epilogue: slot = (32x16 block, round, wave) = 64 pixels
                 p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
                 a.stat_slots = (a.out.H / 16) * (a.out.W / 32) * 8;
