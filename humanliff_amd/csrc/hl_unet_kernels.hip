@@ -946,16 +946,7 @@ __global__ void k_pack_conv_wino(const float *__restrict__ w, int Cout, int Cin,
 // ---------------------------------------------------------------------------------------------
 constexpr float W4_A = 0.75f, W4_B = 1.5f;
 constexpr float W4_C0 = W4_A * W4_A * W4_B * W4_B, W4_C2 = -(W4_A * W4_A + W4_B * W4_B);
-#ifdef W4_SCALAR_FMA
-__device__ __forceinline__ f32x4 fma4(float c, f32x4 x, f32x4 y) {
-    f32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { float t; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "s"(c), "v"(x[i]), "v"(y[i])); r[i] = t; }
-    return r;
-}
-#else
 __device__ __forceinline__ f32x4 fma4(float c, f32x4 x, f32x4 y) { return __builtin_elementwise_fma((f32x4)(c), x, y); }
-#endif
 // three rows of B^T applied to five consecutive window elements: BLK 0 = rows (0, +a, -a) on d0..d4, BLK 1 = rows (+b, -b, inf) on d1..d5
 template <int BLK>
 __device__ __forceinline__ void w4_fwd(const f32x4 (&x)[5], f32x4 (&o)[3]) {
@@ -972,12 +963,14 @@ __device__ __forceinline__ void w4_fwd(const f32x4 (&x)[5], f32x4 (&o)[3]) {
     }
 }
 // one side of the output transform: four outputs from the six frequencies (0, +a, -a, +b, -b, inf)
-__device__ __forceinline__ void w4_out(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
-    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(float c, f32x2 x, f32x2 y) { return __builtin_elementwise_fma((f32x2)(c), x, y); }
+__device__ __forceinline__ void w4_out(f32x2 m0, f32x2 m1, f32x2 m2, f32x2 m3, f32x2 m4, f32x2 m5, f32x2 (&y)[4]) {   // two channels at once
+    const f32x2 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
     y[0] = (m0 + s1) + s2;
-    y[1] = fmaf(W4_B, d2, W4_A * d1);
-    y[2] = fmaf(W4_B * W4_B, s2, (W4_A * W4_A) * s1);
-    y[3] = fmaf(W4_B * W4_B * W4_B, d2, fmaf(W4_A * W4_A * W4_A, d1, m5));
+    y[1] = fma2(W4_B, d2, W4_A * d1);
+    y[2] = fma2(W4_B * W4_B, s2, (W4_A * W4_A) * s1);
+    y[3] = fma2(W4_B * W4_B * W4_B, d2, fma2(W4_A * W4_A * W4_A, d1, m5));
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -1039,16 +1032,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
         const float *pread = lds + U_F + (((4 * ty + FR) * PRW + tx) * 2 + (half ^ (ty & 1))) * 4;   // + stage*P_F + ((rr*PRW + coff(c))*2 +- 1)*4
         const float *uread = lds + W * 9 * 256 + lane * 4;                                // + f*256
 
-        auto issue_p = [&](int stage) {
-#pragma unroll
-            for (int j = 0; j < NPW; ++j) {
-                // the last instruction is ragged (P_REAL is not a multiple of 64): its tail lanes are switched off, so that a stage
-                // is exactly P_REAL chunks and two workgroups fit a CU's 160 KB
-                if ((W + 4 * j + 1) * 64 <= P_REAL || lane < P_REAL - (W + 4 * j) * 64)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        rsA, (__attribute__((address_space(3))) void *)(lds + U_F + stage * P_F + (W + 4 * j) * 256), 16, pv[j], soffA, 0, 0);
-            }
-            soffA += 32;
+        // one piece (64 chunks) of the patch of the k-tile at soffA; the last one is ragged (P_REAL is not a multiple of 64): its tail
+        // lanes are switched off, so that a stage is exactly P_REAL chunks and two workgroups fit a CU's 160 KB
+        auto issue_piece = [&](int stage, auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if ((W + 4 * j + 1) * 64 <= P_REAL || lane < P_REAL - (W + 4 * j) * 64)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsA, (__attribute__((address_space(3))) void *)(lds + U_F + stage * P_F + (W + 4 * j) * 256), 16, pv[j], soffA, 0, 0);
         };
         auto issue_u = [&](int f) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void *)(lds + (W * 9 + f) * 256), 16, uvp,
@@ -1117,65 +1107,87 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
             // and keeps all 25 window reads live instead (spills)
             asm volatile("" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(V[4]), "+v"(V[5]), "+v"(V[6]), "+v"(V[7]), "+v"(V[8]));
         };
+        // Per-wave DMA queue of a k-tile, issued behind the MFMAs of its units:  U(t+1,0) P0(t+2) U(t+1,1) P1(t+2) ... U(t+1,8)  (NPW patch
+        // pieces behind the first NPW units - one piece per unit instead of a burst of 21 per workgroup behind the barrier).  Every wait
+        // is an exact count of the younger instructions of that fixed sequence:
+        //   slot f+1, read in unit f (issued one k-tile ago): 6 + NPW younger while f < NPW, 7 + NPW after; the first read: 8 + NPW
+        //   the patch of k-tile t+1 at the barrier behind transform(t): the 9 - NPW weight slots issued behind its last piece
+        // MODE 0: steady state; 1: the k-tile before the last (no patch pieces any more: 7 + max(0, NPW - f - 1), first 8 + NPW);
+        // 2: the last one (nothing is issued, the queue drains).
+        auto piece = [&](int stage, int j) {
+            if (j == 0) issue_piece(stage, std::integral_constant<int, 0>{});
+            else if (j == 1) issue_piece(stage, std::integral_constant<int, 1>{});
+            else if (j == 2) issue_piece(stage, std::integral_constant<int, 2>{});
+            else if (j == 3) issue_piece(stage, std::integral_constant<int, 3>{});
+            else if (j == 4) issue_piece(stage, std::integral_constant<int, 4>{});
+            else if (NPW > 5 && j == 5) issue_piece(stage, std::integral_constant<int, (NPW > 5 ? 5 : 0)>{});
+        };
         if (ntiles > 0) {
-            issue_p(0);
-            if (ntiles > 1) issue_p(1);
 #pragma unroll
-            for (int f = 0; f < 9; ++f) issue_u(f);
+            for (int j = 0; j < NPW; ++j) piece(0, j);
+            soffA += 32;
+#pragma unroll
+            for (int f = 0; f < 9; ++f) {
+                issue_u(f);
+                if (ntiles > 1 && f < NPW) piece(1, f);
+            }
+            soffA += 32;
             soffU += 36 * 1024;
-            wait_vmcnt<9>();                                          // the patches have landed
+            if (ntiles > 1) wait_vmcnt<9 + NPW>(); else wait_vmcnt<9>();       // patch 0 has landed
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             load_col(0, 0);
         }
-        auto body = [&](auto sc, int t) {
+        // STEADY: k-tiles t with t + 2 < ntiles (everything known at compile time, no branches in the loop); the last two k-tiles of a
+        // workgroup run the same code with the conditions evaluated at run time
+        auto body = [&](auto sc, auto stc, int t) {
             constexpr int S = decltype(sc)::value;
-            const bool more = t + 1 < ntiles, more2 = t + 2 < ntiles;
-#ifndef W4_NO_XFORM
+            constexpr bool STEADY = decltype(stc)::value;
+            const bool more = STEADY || t + 1 < ntiles, more2 = STEADY || t + 2 < ntiles;
             transform(S);
-#endif
             if (more) {
-                // every wave has read patch t; patch t+1 (issued one k-tile ago, only the nine U(t, .) are younger) is published
-                wait_vmcnt<9>();
+                // every wave has read patch t; patch t+1 is published
+                wait_vmcnt<9 - NPW>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-#ifndef W4_NO_DMA
-                if (more2) issue_p(S);
-#endif
             }
-            // U(t, f) was issued one k-tile ago; younger when slot f+1 is read in unit f: U(t, f+2..8), the NPW of P(t+2), the f refills
-            // of this k-tile = 7 + NPW (the first read: 8 + NPW).  Without P: 7 / 8; the last k-tile drains the queue.
-            if (more2) wait_vmcnt<8 + NPW>(); else if (more) wait_vmcnt<8>(); else wait_vmcnt<0>();
+            if (more) wait_vmcnt<8 + NPW>(); else wait_vmcnt<0>();
             ub[0] = *reinterpret_cast<const f32x4 *>(uread);
 #pragma unroll
             for (int f = 0; f < 9; ++f) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef W4_NO_MFMA
                 acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][0], ub[f & 1][0], acc[f], 0, 0, 0);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (f < 8) {
-                    if (more2) wait_vmcnt<7 + NPW>(); else if (more) wait_vmcnt<7>();
+                    if (more2) { if (f < NPW) wait_vmcnt<6 + NPW>(); else wait_vmcnt<7 + NPW>(); }
+                    else if (more) {
+                        const int k = NPW - f - 1;                    // patch pieces of k-tile t+1 that sit behind slot f+1 in the queue
+                        if (k >= 5) wait_vmcnt<12>(); else if (k == 4) wait_vmcnt<11>(); else if (k == 3) wait_vmcnt<10>();
+                        else if (k == 2) wait_vmcnt<9>(); else if (k == 1) wait_vmcnt<8>(); else wait_vmcnt<7>();
+                    }
                     ub[(f + 1) & 1] = *reinterpret_cast<const f32x4 *>(uread + (f + 1) * 256);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef W4_NO_MFMA
 #pragma unroll
                 for (int s = 1; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[f][s], ub[f & 1][s], acc[f], 0, 0, 0);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef W4_NO_DMA
                 if (more) issue_u(f);                                 // the slot just consumed refills for k-tile t+1
-#endif
+                if (more2 && f < NPW) piece(S, f);                    // a piece of the patch of k-tile t+2 into the stage just released
                 if (f == 6 && more) load_col(S ^ 1, 0);               // first window column of k-tile t+1 (published at the barrier above)
             }
             if (more) soffU += 36 * 1024;
+            if (more2) soffA += 32;
         };
-        for (int t = 0; t < ntiles; t += 2) {
-            body(std::integral_constant<int, 0>{}, t);
-            if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, t + 1);
+        if (ntiles > 0) {
+            using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+            int t = 0;
+            for (; t + 3 < ntiles; t += 2) { body(S0{}, std::true_type{}, t); body(S1{}, std::true_type{}, t + 1); }
+            for (; t < ntiles; t += 2) {
+                body(S0{}, std::false_type{}, t);
+                if (t + 1 < ntiles) body(S1{}, std::false_type{}, t + 1);
+            }
         }
     };
     switch (wave) {
@@ -1185,14 +1197,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
         default: run(std::integral_constant<int, 3>{}); break;
     }
 
-#ifdef W4_NO_EPI
-    if (acc[0][0] == 123.f) p.out[0] = acc[1][2] + acc[2][0] + acc[3][0] + acc[4][0] + acc[5][0] + acc[6][0] + acc[7][0] + acc[8][0];
-    return;
-#endif
-    // the 36 frequencies of a (tile, channel) meet in LDS: two rounds of 16 tiles; [freq][tile][cout]
+    // the 36 frequencies of a (tile, channel) meet in LDS: two rounds of 16 tiles; [freq][tile][cout].  A thread then finishes one tile
+    // for two neighbouring output channels (ds_read_b64, 8-byte stores: 16 lanes cover the 128 bytes of a pixel's 32 channels)
     const int fbase = (3 * (wave >> 1)) * 6 + 3 * (wave & 1);
-    const int n = n0 + (lane & 31);
-    const float bs = (p.bias && !p.partial) ? p.bias[n] : 0.f;
+    const int mloc = tid >> 4, np2 = (tid & 15) * 2, n = n0 + np2;
+    f32x2 bs = {0.f, 0.f};
+    if (p.bias && !p.partial) bs = *reinterpret_cast<const f32x2 *>(p.bias + n);
     const long hw = (long)Hv * Wv;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1202,92 +1212,79 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
             const int F = fbase + (f / 3) * 6 + (f % 3);
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
-                const int r = 8 * q + rr, mloc = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
-                lds[(F * 16 + mloc) * 32 + (lane & 31)] = acc[f][r];
+                const int r = 8 * q + rr, ml = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+                lds[(F * 16 + ml) * 32 + (lane & 31)] = acc[f][r];
             }
         }
         __syncthreads();
-        float s1 = 0.f, q1 = 0.f, s2 = 0.f, q2 = 0.f;                  // GroupNorm statistics of this lane's channel over its two tiles
+        const float *zz = lds + mloc * 32 + np2;
+        f32x2 z[4][6];                                                // rows of A^T applied: z[p][j]
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const int mloc = wave * 4 + half * 2 + pp;
-            const float *zz = lds + mloc * 32 + (lane & 31);
-            float z[4][6];                                            // rows of A^T applied: z[p][j]
+        for (int j = 0; j < 6; ++j) {
+            f32x2 col[4];
+            w4_out(*reinterpret_cast<const f32x2 *>(zz + (0 * 6 + j) * 512), *reinterpret_cast<const f32x2 *>(zz + (1 * 6 + j) * 512),
+                   *reinterpret_cast<const f32x2 *>(zz + (2 * 6 + j) * 512), *reinterpret_cast<const f32x2 *>(zz + (3 * 6 + j) * 512),
+                   *reinterpret_cast<const f32x2 *>(zz + (4 * 6 + j) * 512), *reinterpret_cast<const f32x2 *>(zz + (5 * 6 + j) * 512), col);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                float col[4];
-                w4_out(zz[(0 * 6 + j) * 512], zz[(1 * 6 + j) * 512], zz[(2 * 6 + j) * 512], zz[(3 * 6 + j) * 512], zz[(4 * 6 + j) * 512],
-                       zz[(5 * 6 + j) * 512], col);
+            for (int pr = 0; pr < 4; ++pr) z[pr][j] = col[pr];
+        }
+        const int Tg = q * 16 + mloc, oy = y0 + 4 * (Tg >> 3), ox = x0 + 4 * (Tg & 7);
+        const long m0 = ((long)img * Hv + oy) * Wv + ox;              // pixel (pr, qc) of the tile: m0 + pr*Wv + qc
+        f32x2 v[16];
 #pragma unroll
-                for (int pr = 0; pr < 4; ++pr) z[pr][j] = col[pr];
-            }
-            const int Tg = q * 16 + mloc, oy = y0 + 4 * (Tg >> 3), ox = x0 + 4 * (Tg & 7);
-            const long m0 = ((long)img * Hv + oy) * Wv + ox;          // pixel (pr, qc) of the tile: m0 + pr*Wv + qc
-            float v[16];
+        for (int pr = 0; pr < 4; ++pr) {
+            f32x2 row[4];
+            w4_out(z[pr][0], z[pr][1], z[pr][2], z[pr][3], z[pr][4], z[pr][5], row);
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
-                float row[4];
-                w4_out(z[pr][0], z[pr][1], z[pr][2], z[pr][3], z[pr][4], z[pr][5], row);
+            for (int qc = 0; qc < 4; ++qc) v[pr * 4 + qc] = row[qc] + bs;
+        }
+        if (p.partial) {   // split-K: the output transform is linear, so slabs are summed in the output domain by k_splitk_finish
+            float *dst = p.partial + (long)blockIdx.z * p.M * p.Cout + m0 * p.Cout + n;
 #pragma unroll
-                for (int qc = 0; qc < 4; ++qc) v[pr * 4 + qc] = row[qc] + bs;
-            }
-            if (p.partial) {   // split-K: the output transform is linear, so slabs are summed in the output domain by k_splitk_finish
-                float *dst = p.partial + (long)blockIdx.z * p.M * p.Cout + m0 * p.Cout + n;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) dst[((k >> 2) * Wv + (k & 3)) * p.Cout] = v[k];
-                continue;
-            }
-            if (p.res) {
-                const float *rp = p.res + m0 * p.res_pitch + n;
-                float rr[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) rr[k] = rp[((k >> 2) * Wv + (k & 3)) * p.res_pitch];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] += rr[k];
-            }
-            float v2[16];
-            if (p.out2) {
-                const float *rp = p.res2 + m0 * p.res2_pitch + n;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v2[k] = rp[((k >> 2) * Wv + (k & 3)) * p.res2_pitch];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v2[k] += v[k];
-            }
-            if (p.st1) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) { s1 += v[k]; q1 += v[k] * v[k]; }
-            }
-            if (p.st2) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) { s2 += v2[k]; q2 += v2[k] * v2[k]; }
-            }
-#ifdef W4_NO_STORE
-            if (v[0] == 123.f) p.out[0] = v[1] + v[5] + v2[3];
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x2 *>(dst + (long)((k >> 2) * Wv + (k & 3)) * p.Cout) = v[k];
             continue;
-#endif
-            if (p.out_nchw) {
-                float *op = p.out + ((long)img * p.Cout + n) * hw + (m0 - (long)img * hw);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) op[(k >> 2) * Wv + (k & 3)] = v[k];
-            } else {
-                float *op = p.out + m0 * p.out_pitch + n;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) op[((k >> 2) * Wv + (k & 3)) * p.out_pitch] = v[k];
-            }
-            if (p.out2) {
-                float *op = p.out2 + m0 * p.out2_pitch + n;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) op[((k >> 2) * Wv + (k & 3)) * p.out2_pitch] = v2[k];
-            }
         }
-        // slot = (tile block, round, wave): two lane halves x two tiles = 64 pixels of one image
-        if (!p.partial && p.st1) {
-            s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
-            if (half == 0) *reinterpret_cast<float2 *>(p.st1 + ((((long)tb * 2 + q) * 4 + wave) * p.Cout + n) * 2) = make_float2(s1, q1);
+        if (p.res) {
+            const float *rp = p.res + m0 * p.res_pitch + n;
+            f32x2 rr[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) rr[k] = *reinterpret_cast<const f32x2 *>(rp + (long)((k >> 2) * Wv + (k & 3)) * p.res_pitch);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] += rr[k];
         }
-        if (!p.partial && p.st2) {
-            s2 += __shfl_xor(s2, 32); q2 += __shfl_xor(q2, 32);
-            if (half == 0) *reinterpret_cast<float2 *>(p.st2 + ((((long)tb * 2 + q) * 4 + wave) * p.Cout + n) * 2) = make_float2(s2, q2);
+        f32x2 v2[16];
+        if (p.out2) {
+            const float *rp = p.res2 + m0 * p.res2_pitch + n;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v2[k] = *reinterpret_cast<const f32x2 *>(rp + (long)((k >> 2) * Wv + (k & 3)) * p.res2_pitch);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v2[k] += v[k];
+        }
+        // GroupNorm statistics: slot = (tile block, round, wave): the wave's four tiles = 64 pixels of one image
+        auto stats = [&](float *st, const f32x2(&vv)[16]) {
+            f32x2 sm = {0.f, 0.f}, sq = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { sm += vv[k]; sq += vv[k] * vv[k]; }
+            f32x4 r = {sm[0], sq[0], sm[1], sq[1]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { r[i] += __shfl_xor(r[i], 16); r[i] += __shfl_xor(r[i], 32); }
+            if (lane < 16) *reinterpret_cast<f32x4 *>(st + ((((long)tb * 2 + q) * 4 + wave) * p.Cout + n) * 2) = r;
+        };
+        if (p.st1) stats(p.st1, v);
+        if (p.st2) stats(p.st2, v2);
+        if (p.out_nchw) {
+            float *op = p.out + ((long)img * p.Cout + n) * hw + (m0 - (long)img * hw);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { op[(k >> 2) * Wv + (k & 3)] = v[k][0]; op[hw + (k >> 2) * Wv + (k & 3)] = v[k][1]; }
+        } else {
+            float *op = p.out + m0 * p.out_pitch + n;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x2 *>(op + (long)((k >> 2) * Wv + (k & 3)) * p.out_pitch) = v[k];
+        }
+        if (p.out2) {
+            float *op = p.out2 + m0 * p.out2_pitch + n;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x2 *>(op + (long)((k >> 2) * Wv + (k & 3)) * p.out2_pitch) = v2[k];
         }
     }
 #endif
