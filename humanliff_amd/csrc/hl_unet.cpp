@@ -26,7 +26,7 @@ struct Conv {
     const float *w = nullptr;  // packed
     const void *w_bf3 = nullptr;  // packed split-bf16 copy (layers that take the DMA tile), used when Net::conv_mode == 1
     const float *w_wino = nullptr;  // Winograd-domain copy (3x3 layers), used when Net::conv_mode == 0
-    const float *w_wino4 = nullptr; // Winograd F(4x4,3x3) copy (3x3 layers), used when Net::conv_mode == HL_CONV_FP32_F43
+    const float *w_wino4 = nullptr; // Winograd F(4x4,3x3) copy (3x3 layers up to 64 MB of it), used when Net::conv_mode == HL_CONV_FP32
     const float *bias = nullptr;
     int Cin = 0, Cin_pad = 0, Cout = 0, ks = 1;
 };
@@ -150,7 +150,9 @@ Conv make_conv(Net &n, const std::string &p, int Cin, int Cout, int ks) {
         }
         n.packed_off += (wino / 4 + 63) / 64 * 64;
     }
-    const size_t wino4 = hl::conv_packed_wino4_bytes(Cout, c.Cin_pad, ks);
+    // F(4x4,3x3) weights are 4x the direct ones: kept for the layers that can reach a level wide enough for that kernel (up to 64 MB a layer)
+    size_t wino4 = hl::conv_packed_wino4_bytes(Cout, c.Cin_pad, ks);
+    if (wino4 > ((size_t)64 << 20)) wino4 = 0;
     if (wino4) {
         if (!n.dry && w) {
             float *dst = n.packed + n.packed_off;
@@ -386,8 +388,8 @@ struct Exec {
         ConvArgs a{};
         a.in = in; a.in.C = c.Cin_pad;
         a.w = c.w; a.w_bf3 = n.conv_mode == HL_CONV_BF16X3 ? c.w_bf3 : nullptr;
-        a.w_wino = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_F43) ? c.w_wino : nullptr;
-        a.w_wino4 = n.conv_mode == HL_CONV_FP32_F43 ? c.w_wino4 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
+        a.w_wino = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_F23) ? c.w_wino : nullptr;
+        a.w_wino4 = n.conv_mode == HL_CONV_FP32 ? c.w_wino4 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
         a.coefA = cA; a.coefB = cB; a.act = act;
         a.out = out; a.res = res; a.res_pitch = res_pitch;
         a.out2 = out2; a.out2_pitch = out2_pitch; a.res2 = res2; a.res2_pitch = res2_pitch; a.out_nchw = nchw;
@@ -647,7 +649,7 @@ int hl_unet_set_overlap(void *handle, int enable) {
 
 int hl_unet_set_conv_mode(void *handle, int mode) {
     HL_REQUIRE(handle, "hl_unet_set_conv_mode: null handle");
-    HL_REQUIRE(mode == HL_CONV_FP32 || mode == HL_CONV_BF16X3 || mode == HL_CONV_FP32_DIRECT || mode == HL_CONV_FP32_F43, "hl_unet_set_conv_mode: unknown mode %d", mode);
+    HL_REQUIRE(mode == HL_CONV_FP32 || mode == HL_CONV_BF16X3 || mode == HL_CONV_FP32_DIRECT || mode == HL_CONV_FP32_F23, "hl_unet_set_conv_mode: unknown mode %d", mode);
     static_cast<Net *>(handle)->conv_mode = mode;
     return HL_OK;
 }
@@ -725,8 +727,8 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     HL_REQUIRE(Cin_w <= Cin, "hl_conv2d_nhwc: the weight has more input channels than the tensor");
     const size_t need32 = (hl::conv_packed_floats(Cout, Cin, ks) * sizeof(float) + 255) / 256 * 256;
     const size_t extra = mode == HL_CONV_BF16X3 ? hl::conv_packed_bf3_bytes(Cout, Cin, ks)
-                         : (mode == HL_CONV_FP32 ? hl::conv_packed_wino_bytes(Cout, Cin, ks)
-                            : (mode == HL_CONV_FP32_F43 ? std::max(hl::conv_packed_wino_bytes(Cout, Cin, ks), hl::conv_packed_wino4_bytes(Cout, Cin, ks)) : 0));
+                         : (mode == HL_CONV_FP32_F23 ? hl::conv_packed_wino_bytes(Cout, Cin, ks)
+                            : (mode == HL_CONV_FP32 ? std::max(hl::conv_packed_wino_bytes(Cout, Cin, ks), hl::conv_packed_wino4_bytes(Cout, Cin, ks)) : 0));
     const size_t need = need32 + (extra + 255) / 256 * 256;
     HL_REQUIRE(scratch && scratch_bytes >= need, "hl_conv2d_nhwc: scratch too small (%zu < %zu)", scratch_bytes, need);
     HL_REQUIRE(!tf || mode != HL_CONV_BF16X3, "hl_conv2d_nhwc: the bf16x3 mode has no backward-data weights");
@@ -735,8 +737,8 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     a.in.p = const_cast<float *>(in); a.in.N = N; a.in.H = H; a.in.W = W; a.in.C = Cin; a.in.pitch = Cin;
     a.w = static_cast<float *>(scratch); a.bias = bias; a.Cout = Cout; a.ks = ks; a.stride = stride; a.ups = upsample;
     if (mode == HL_CONV_BF16X3 && need > need32) a.w_bf3 = extra_dst;
-    if ((mode == HL_CONV_FP32 || mode == HL_CONV_FP32_F43) && hl::conv_packed_wino_bytes(Cout, Cin, ks)) a.w_wino = static_cast<float *>(extra_dst);
-    if (mode == HL_CONV_FP32_F43 && hl::conv_packed_wino4_bytes(Cout, Cin, ks)) a.w_wino4 = static_cast<float *>(extra_dst);
+    if ((mode == HL_CONV_FP32 || mode == HL_CONV_FP32_F23) && hl::conv_packed_wino_bytes(Cout, Cin, ks)) a.w_wino = static_cast<float *>(extra_dst);
+    if (mode == HL_CONV_FP32 && hl::conv_packed_wino4_bytes(Cout, Cin, ks)) a.w_wino4 = static_cast<float *>(extra_dst);
     a.coefA = coefA; a.coefB = coefB; a.act = silu;
     const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     a.out.p = out; a.out.N = N; a.out.H = (Hv + 2 * pad - ks) / stride + 1; a.out.W = (Wv + 2 * pad - ks) / stride + 1;
@@ -779,7 +781,7 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
 
 int hl_conv2d_nhwc_bwd_data(int conv_mode, const float *dy, int N, int Ho, int Wo, int Cy, const float *w_oihw, int Cout, int Cin, int ks,
                             int stride, int upsample, float *dx, int Cx, void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F43, "hl_conv2d_nhwc_bwd_data: mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23, "hl_conv2d_nhwc_bwd_data: mode %d", conv_mode);
     HL_REQUIRE(dy && w_oihw && dx && scratch, "hl_conv2d_nhwc_bwd_data: null argument");
     HL_REQUIRE(Cy % 16 == 0 && Cout <= Cy && Cin <= Cx && (ks == 1 || ks == 3) && (stride == 1 || (stride == 2 && !upsample && ks == 3)),
                "hl_conv2d_nhwc_bwd_data: bad argument");
@@ -815,7 +817,7 @@ int hl_conv2d_nhwc_gn(int conv_mode, const float *in, int N, int H, int W, int C
                       int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu, const float *residual,
                       float *out, const float *gamma, const float *beta, float *next_coefA, float *next_coefB, int *h_used_stats,
                       void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F43, "hl_conv2d_nhwc_gn: unknown mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23, "hl_conv2d_nhwc_gn: unknown mode %d", conv_mode);
     HL_REQUIRE(gamma && beta && next_coefA && next_coefB && scratch, "hl_conv2d_nhwc_gn: null argument");
     const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     const int Ho = (Hv + 2 * pad - ks) / stride + 1, Wo = (Wv + 2 * pad - ks) / stride + 1;
@@ -849,7 +851,7 @@ int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w
 int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias,
                         int Cout, int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F43, "hl_conv2d_nhwc_mode: unknown mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23, "hl_conv2d_nhwc_mode: unknown mode %d", conv_mode);
     return conv2d_single(conv_mode, in, N, H, W, Cin, w_oihw, bias, Cout, ks, stride, upsample, coefA, coefB, silu, residual, out,
                          scratch, scratch_bytes, stream);
 }

@@ -282,19 +282,23 @@ int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float 
 int hl_unet_set_overlap(void *handle, int enable);
 
 /* Arithmetic of the large convolutions - all modes keep fp32 tensors and fp32 accumulators.
- * HL_CONV_FP32 (default): fp32 products on v_mfma_f32_32x32x2_f32; 3x3 / stride-1 layers that fill the chip take Winograd
- *   F(2x2,3x3) (16 fp32 multiplies per 2x2 outputs instead of 36), everything else the direct implicit GEMM.
+ * HL_CONV_FP32 (default): fp32 products on v_mfma_f32_32x32x2_f32; 3x3 / stride-1 layers take Winograd F(4x4,3x3) (36 fp32
+ *   multiplies per 4x4 outputs instead of 144; interpolation points 0, +-3/4, +-3/2, inf) where 32x16-pixel x 32-channel
+ *   workgroups fill the chip (the 256- and 128-pixel levels at batch 4), Winograd F(2x2,3x3) (16 per 2x2 instead of 36) on the
+ *   smaller levels, everything else the direct implicit GEMM.
+ * HL_CONV_FP32_F23: the same without F(4x4,3x3) (the arithmetic of the round-2 library).
  * HL_CONV_FP32_DIRECT: the direct implicit GEMM only - every product of the reference's sum is formed exactly once.
  * HL_CONV_BF16X3 (opt-in, direct only): each product a*b is formed on the bf16 matrix pipe from exact three-way splits
  *   a = ah+am+al, b = bh+bm+bl (8 significand bits per bf16 plane) as ah*bh + ah*bm + am*bh + ah*bl + am*bm + al*bh; the three
  *   dropped terms are <= 3*2^-24 |a*b|, the size of one fp32 rounding.
  * The modes are not bit-identical to each other; all meet the same parity bounds (tests/test_unet_gpu.py,
- * tests/test_fullsize_gpu.py: production UNet vs the CPU oracle 4.5e-6 / 5.0e-6 / 5.1e-6 max-abs on O(0.5) outputs).
+ * tests/test_fullsize_gpu.py: production UNet vs the CPU oracle about 5e-6 max-abs on O(0.5) outputs in every mode; against the direct mode the F(4x4) mode differs
+ * by 7.9e-6 max-abs / 1.4e-6 rms, the F(2x2) mode by 6.4e-6 / 1.0e-6).
  * Only layers with Cout a multiple of 96 (the DMA tile) are affected. */
 #define HL_CONV_FP32 0
 #define HL_CONV_BF16X3 1
 #define HL_CONV_FP32_DIRECT 2
-#define HL_CONV_FP32_F43 3
+#define HL_CONV_FP32_F23 3
 int hl_unet_set_conv_mode(void *handle, int mode);
 
 /* Instrumentation for the roofline measurement (bench.py): with profiling enabled every kernel launch

@@ -13,7 +13,7 @@ for (N, H, W, C, Co) in shapes:
     x = torch.randn((N, H, W, C), device=dev); w = torch.randn((Co, C, 3, 3), device=dev) * 0.02; b = torch.randn(Co, device=dev)
     res = torch.randn((N, H, W, Co), device=dev)
     out = torch.empty((N, H, W, Co), device=dev); scratch = torch.empty(Co * C * 9 * 5 + 256 + (64 << 20), device=dev)
-    for mode in (0, 3):
+    for mode in (3, 0):   # HL_CONV_FP32_F23 (F(2x2) only), HL_CONV_FP32 (F(4x4) where it fills the chip)
         for rep in range(3):
             for r in (None, res):
                 _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(x), N, H, W, C, _lib.ptr(w), _lib.ptr(b), Co, 3, 1, 0, None, None, 0,

@@ -13,7 +13,7 @@ for C in (48, 96, 192, 384, 768):
     out = torch.empty((N, H, W, Co), device=dev); scratch = torch.empty(256 * C * 9 * 3 + 256 + (4 << 20), device=dev)
     for rep in range(3):
         for r in (None, res):
-            _lib.check(L.hl_conv2d_nhwc_mode(0, _lib.ptr(x), N, H, W, C, _lib.ptr(w), _lib.ptr(b), Co, 3, 1, 0, None, None, 0, _lib.ptr(r) if r is not None else None,
+            _lib.check(L.hl_conv2d_nhwc_mode(3, _lib.ptr(x), N, H, W, C, _lib.ptr(w), _lib.ptr(b), Co, 3, 1, 0, None, None, 0, _lib.ptr(r) if r is not None else None,
                                              _lib.ptr(out), _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()))
     torch.cuda.synchronize()
 print("done")

@@ -102,7 +102,7 @@ def test_conv_winograd_upsample_matches_torch():
     x = torch.randn((N, C, H, W), generator=g)
     w = torch.randn((Cout, C, 3, 3), generator=g) / (C * 9) ** 0.5
     b = torch.randn((Cout,), generator=g)
-    got = hip_conv(x, w, b, 3, ups=1, mode=_lib.HL_CONV_FP32)
+    got = hip_conv(x, w, b, 3, ups=1, mode=_lib.HL_CONV_FP32_F23)
     direct = hip_conv(x, w, b, 3, ups=1, mode=_lib.HL_CONV_FP32_DIRECT)
     want = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
     assert got.shape == want.shape and not torch.equal(got, direct)
@@ -136,7 +136,7 @@ def test_conv_winograd_matches_torch(N, C, H, W, Cout, with_gn):
         kw = dict(cA=cA, cB=cB, silu=1, res=res)
         hn = x.double() * cA.double()[:, :, None, None] + cB.double()[:, :, None, None]
         xin = hn * torch.sigmoid(hn)
-    got = hip_conv(x, w, b, 3, mode=_lib.HL_CONV_FP32, **kw)
+    got = hip_conv(x, w, b, 3, mode=_lib.HL_CONV_FP32_F23, **kw)
     direct = hip_conv(x, w, b, 3, mode=_lib.HL_CONV_FP32_DIRECT, **kw)
     want = F.conv2d(xin, w.double(), b.double(), padding=1)
     if with_gn:
@@ -157,8 +157,8 @@ def test_conv_winograd_matches_torch(N, C, H, W, Cout, with_gn):
     (4, 96, 64, 48, 192, False, 1),     # nearest x2 upsample in front (the patch DMA reads source pixel (y>>1, x>>1))
 ])
 def test_conv_winograd_f43_matches_torch(N, C, H, W, Cout, with_gn, ups):
-    """HL_CONV_FP32_F43: the same layers by Winograd F(4x4,3x3) with the points (0, +-3/4, +-3/2, inf) - a quarter of the direct
-    multiplies, fp32 throughout; compared with float64 torch and with the direct kernel on the same inputs."""
+    """HL_CONV_FP32 takes Winograd F(4x4,3x3) with the points (0, +-3/4, +-3/2, inf) where it fills the chip - a quarter of the direct
+    multiplies, fp32 throughout; compared with float64 torch, with the F(2x2) kernel and with the direct kernel on the same inputs."""
     from humanliff_amd import _lib
     g = torch.Generator().manual_seed(N * 1000 + C + H + Cout)
     x = torch.randn((N, C, H, W), generator=g)
@@ -174,8 +174,8 @@ def test_conv_winograd_f43_matches_torch(N, C, H, W, Cout, with_gn, ups):
         xin = hn * torch.sigmoid(hn)
     if ups:
         xin = F.interpolate(xin, scale_factor=2, mode="nearest")
-    got = hip_conv(x, w, b, 3, ups=ups, mode=_lib.HL_CONV_FP32_F43, **kw)
-    f23 = hip_conv(x, w, b, 3, ups=ups, mode=_lib.HL_CONV_FP32, **kw)
+    got = hip_conv(x, w, b, 3, ups=ups, mode=_lib.HL_CONV_FP32, **kw)
+    f23 = hip_conv(x, w, b, 3, ups=ups, mode=_lib.HL_CONV_FP32_F23, **kw)
     direct = hip_conv(x, w, b, 3, ups=ups, mode=_lib.HL_CONV_FP32_DIRECT, **kw)
     want = F.conv2d(xin, w.double(), b.double(), padding=1)
     if with_gn:
