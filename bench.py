@@ -170,10 +170,10 @@ def bench_unet(args, rank, world, dev):
     conv_ms, conv_fl, conv_n = ms[0], fl[0], nl[0]
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     executed = xf[0] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    # `achieved` / `frac`: FLOPs the matrix pipe actually EXECUTES (Winograd F(2x2,3x3) issues 16 of the 36 multiplies of a direct 3x3
-    # convolution) over the conv-path time, against the fp32 MFMA peak - a real fraction (<= 1).  The algorithmic figure (direct-convolution
+    # `achieved` / `frac`: FLOPs the matrix pipe actually EXECUTES (Winograd F(4x4,3x3) issues 36 of the 144 multiplies of a direct 3x3
+    # convolution per 4x4 outputs, F(2x2,3x3) 16 of 36 per 2x2) over the conv-path time, against the fp32 MFMA peak - a real fraction (<= 1).  The algorithmic figure (direct-convolution
     # FLOPs of SURVEY 8(d) over the same time) is reported next to it as `algorithmic`; it can exceed the peak.
-    roof = {"bound": "mfma", "kernel": "k_conv_wino (Winograd F(2x2,3x3), large 3x3 layers) + k_conv_dma (direct implicit GEMM, the rest), "
+    roof = {"bound": "mfma", "kernel": "k_conv_wino4 (Winograd F(4x4,3x3), 3x3 layers of the 256- and 128-pixel levels) + k_conv_wino (F(2x2,3x3), 3x3 layers of the smaller levels) + k_conv_dma (direct implicit GEMM, the rest), "
                                        "v_mfma_f32_32x32x2_f32; with their pre/post passes (k_gn_apply, k_splitk_finish); all launches of one denoise step",
             "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),

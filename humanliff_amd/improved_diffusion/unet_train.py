@@ -44,7 +44,7 @@ def _conv_raw(x, w, b, ks, stride=1, ups=0):
     Ho, Wo = (Hv + 2 * (ks // 2) - ks) // stride + 1, (Wv + 2 * (ks // 2) - ks) // stride + 1
     out = th.empty((N, Ho, Wo, Cout), device=x.device, dtype=th.float32)
     rows = (Cout + 63) // 64 * 64
-    scratch = th.empty(rows * Cx * ks * ks * 3 + 256 + (16 << 20) + N * Cx * H * W, device=x.device, dtype=th.float32)
+    scratch = th.empty(rows * Cx * ks * ks * 5 + 256 + (16 << 20) + N * Cx * H * W, device=x.device, dtype=th.float32)
     with _lib.on(x.device):
         _lib.check(L.hl_conv2d_nhwc_mode(_MODE, _lib.ptr(x), N, H, W, Cx, _lib.ptr(w), _lib.ptr(b), Cout, ks, stride, ups, None, None, 0,
                                          None, _lib.ptr(out), _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()), "hl_conv2d_nhwc_mode")
@@ -84,7 +84,7 @@ class _Conv(th.autograd.Function):
             dx = th.empty_like(x) if Cxp == Cin else th.zeros_like(x)
             rows = (Cin + 63) // 64 * 64
             extra = N * 4 * Ho * Wo * Cyp if stride == 2 else (N * Ho * Wo * Cxp if ups else 0)
-            scratch = th.empty(rows * Cyp * ks * ks * 3 + 512 + (16 << 20) + extra, device=dy.device, dtype=th.float32)
+            scratch = th.empty(rows * Cyp * ks * ks * 5 + 512 + (16 << 20) + extra, device=dy.device, dtype=th.float32)
             with _lib.on(dy.device):
                 _lib.check(L.hl_conv2d_nhwc_bwd_data(_MODE, _lib.ptr(dyp), N, Ho, Wo, Cyp, _lib.ptr(w4.contiguous()), Cout, Cin, ks, stride, ups,
                                                      _lib.ptr(dx), Cxp, _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()),

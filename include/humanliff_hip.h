@@ -334,8 +334,10 @@ int hl_diffusion_step(int mode, const float *x, const float *eps, const float *n
 int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,
                    int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                    const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream);
-/* hl_conv2d_nhwc with an explicit arithmetic mode (HL_CONV_*); HL_CONV_BF16X3 needs room for the split weights too:
- * scratch >= 4*Cout_pad*K (rounded up to 256) + 6*Cout_pad*K bytes, Cout_pad = Cout rounded up to 64, K = Cin*ks*ks. */
+/* hl_conv2d_nhwc with an explicit arithmetic mode (HL_CONV_*); the scratch also holds the mode's second weight layout:
+ * scratch >= 4*Cout_pad*K (rounded up to 256) + extra, Cout_pad = Cout rounded up to 64, K = Cin*ks*ks; extra = 6*Cout_pad*K bytes
+ * (HL_CONV_BF16X3), 64*Cout*Cin (HL_CONV_FP32_F23, 3x3 layers) or 144*Cout*Cin (HL_CONV_FP32, 3x3 layers); what is left beyond
+ * that serves the materialised GroupNorm input (N*H*W*Cin floats, when coefA is given) and split-K partial sums. */
 int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias,
                         int Cout, int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream);
@@ -352,7 +354,7 @@ int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int
  * Cy >= Cout a multiple of 16 (zero-padded channels), w the convolution's own (Cout, Cin, ks, ks) weights - read flipped and
  * channel-transposed while they are re-laid for the kernel, no flipped copy is made -, dx (N,H,W,Cx) with Cx >= Cin (channels
  * [Cin, Cx) are not written).  stride 2 (ks 3): H = 2*Ho; upsample: the convolution ran on the nearest-x2 image, (Ho,Wo) = (2H,2W).
- * scratch: the re-laid weights (3 * round_up(Cin,64) * Cy * ks^2 floats) + 16 MiB + the zero-stuffed / upsampled gradient. */
+ * scratch: the re-laid weights (5 * round_up(Cin,64) * Cy * ks^2 floats) + 16 MiB + the zero-stuffed / upsampled gradient. */
 int hl_conv2d_nhwc_bwd_data(int conv_mode, const float *dy, int N, int Ho, int Wo, int Cy, const float *w_oihw, int Cout, int Cin, int ks,
                             int stride, int upsample, float *dx, int Cx, void *scratch, size_t scratch_bytes, void *stream);
 int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,

@@ -8,7 +8,7 @@ L = _lib.lib(); dev = torch.device("cuda:0")
 def run(N, C, H, W, Co, ks, mode=2, reps=4):
     x = torch.randn((N, H, W, C), device=dev); w = torch.randn((Co, C, ks, ks), device=dev) * 0.02; b = torch.randn(Co, device=dev)
     cA = torch.rand((N, C), device=dev) + 0.5; cB = torch.randn((N, C), device=dev) * 0.1
-    out = torch.empty((N, H, W, Co), device=dev); scratch = torch.empty(((Co + 63) // 64 * 64) * C * ks * ks * 3 + 256 + N * H * W * C + (4 << 20), device=dev)
+    out = torch.empty((N, H, W, Co), device=dev); scratch = torch.empty(((Co + 63) // 64 * 64) * C * ks * ks * 5 + 256 + N * H * W * C + (4 << 20), device=dev)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for r in range(reps + 1):
         if r == 1: evs[0].record()

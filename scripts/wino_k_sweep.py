@@ -10,7 +10,7 @@ N, H, W, Co = 4, 256, 256, 192
 for C in (48, 96, 192, 384, 768):
     x = torch.randn((N, H, W, C), device=dev); w = torch.randn((Co, C, 3, 3), device=dev) * 0.02; b = torch.randn(Co, device=dev)
     res = torch.randn((N, H, W, Co), device=dev)
-    out = torch.empty((N, H, W, Co), device=dev); scratch = torch.empty(256 * C * 9 * 3 + 256 + (4 << 20), device=dev)
+    out = torch.empty((N, H, W, Co), device=dev); scratch = torch.empty(256 * C * 9 * 5 + 256 + (4 << 20), device=dev)
     for rep in range(3):
         for r in (None, res):
             _lib.check(L.hl_conv2d_nhwc_mode(3, _lib.ptr(x), N, H, W, C, _lib.ptr(w), _lib.ptr(b), Co, 3, 1, 0, None, None, 0, _lib.ptr(r) if r is not None else None,

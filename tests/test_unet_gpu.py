@@ -447,7 +447,9 @@ def test_training_path_matches_inference_forward_and_twin():
 
 
 @pytest.mark.parametrize("N,C,H,W,Cout,ks,stride,ups,mode,with_gn,expect_stats", [
-    (2, 64, 256, 128, 192, 3, 1, 0, 0, True, True),     # Winograd after the k_gn_apply pass, residual; slot = (16x8 block, parity)
+    (2, 64, 256, 128, 192, 3, 1, 0, 0, True, True),     # Winograd F(4x4) after the k_gn_apply pass, residual; slot = (32x16 block, round, wave)
+    (2, 64, 256, 128, 192, 3, 1, 0, 3, True, True),     # Winograd F(2x2) (HL_CONV_FP32_F23); slot = (16x8 block, parity)
+    (4, 96, 64, 64, 192, 3, 1, 1, 0, False, True),      # nearest x2 + 3x3 (Upsample) through the F(4x4) kernel
     (4, 384, 32, 32, 384, 3, 1, 0, 0, True, True),      # Winograd over 3 input-channel slabs: statistics from k_splitk_finish_st
     (2, 96, 32, 64, 192, 3, 1, 1, 0, False, True),      # nearest x2 + 3x3 (Upsample) through the Winograd kernel
     (2, 192, 64, 64, 384, 1, 1, 0, 2, False, True),     # 1x1 skip / zero-conv on the direct kernel: slot = a wave's 32 rows
