@@ -69,6 +69,9 @@ struct Net {
     Conv out_conv;
     Norm out_norm;
     const float *te0_w = nullptr, *te0_b = nullptr, *te2_w = nullptr, *te2_b = nullptr, *label = nullptr;
+    // cond_type == "AdaGN" (unet.py:519-525, 574-578): x_cond -> conv 3x3 s2 (6) -> conv 3x3 s2 (1) -> Linear(64*64, E), added to emb
+    Conv ada1, ada2;
+    const float *ada_w = nullptr, *ada_b = nullptr;
     const float *emb_w = nullptr, *emb_b = nullptr;  // stacked emb_layers
     long emb_total = 0;
     int E = 0;         // time_embed_dim
@@ -267,6 +270,12 @@ void build(Net &n) {
     n.te2_w = lookup(n, "time_embed.2.weight", (int64_t)n.E * n.E);
     n.te2_b = lookup(n, "time_embed.2.bias", n.E);
     n.label = c.num_classes > 0 ? lookup(n, "label_emb.weight", (int64_t)c.num_classes * n.E) : nullptr;
+    if (c.adagn) {
+        n.ada1 = make_conv(n, "conv_proj_1", c.out_channels, 6, 3);
+        n.ada2 = make_conv(n, "conv_proj_2", 6, 1, 3);
+        n.ada_w = lookup(n, "linear.weight", (int64_t)n.E * 4096);
+        n.ada_b = lookup(n, "linear.bias", n.E);
+    }
 
     std::vector<int> chans;
     build_encoder(n, emb, "input_blocks", n.in_blocks, chans);
@@ -502,11 +511,33 @@ struct Exec {
         xin.p = alloc((size_t)xin.pixels() * n.Cpad0);
         View xsum = xin;
         if (c.controlnet) xsum.p = alloc((size_t)xin.pixels() * n.Cpad0);
+        // AdaGN: the condition is projected to one more summand of emb (unet.py:574-578): two stride-2 convs, then a Linear over the
+        // 64x64 map (so H = W = 256, as in the reference).  emb = (time_embed + label_emb[y]) + projection.
+        View ac, a1, a2;
+        float *emb0 = nullptr;
+        int64_t *iota = nullptr;
+        if (c.adagn) {
+            ac.N = B; ac.H = H; ac.W = W; ac.C = round_up(c.out_channels, 16); ac.pitch = ac.C; ac.p = alloc((size_t)ac.pixels() * ac.C);
+            a1.N = B; a1.H = H / 2; a1.W = W / 2; a1.C = 16; a1.pitch = 16; a1.p = alloc((size_t)a1.pixels() * 16);
+            a2.N = B; a2.H = H / 4; a2.W = W / 4; a2.C = 1; a2.pitch = 1; a2.p = alloc((size_t)a2.pixels());
+            emb0 = alloc((size_t)B * n.E);
+            iota = reinterpret_cast<int64_t *>(alloc(2 * 16));
+            if (run) {
+                static const int64_t h_iota[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+                ok(hipMemcpyAsync(iota, h_iota, sizeof(h_iota), hipMemcpyHostToDevice, st) == hipSuccess ? 0 : hl::fail(HL_ERR_RUNTIME, "hl_unet_forward: memcpy"));
+                ok(hipMemsetAsync(a1.p, 0, (size_t)a1.pixels() * 16 * sizeof(float), st) == hipSuccess ? 0 : hl::fail(HL_ERR_RUNTIME, "hl_unet_forward: memset"));
+                ok(hl::prep_inputs(x_cond, nullptr, B, c.out_channels, H, W, ac.C, ac.p, nullptr, st));
+            }
+            View a1w = a1; a1w.C = 6;                                 // the conv writes 6 of the 16 (zeroed) channels
+            conv(n.ada1, ac, a1w, 2, 0, nullptr, nullptr, 0, nullptr, 0);
+            conv(n.ada2, a1, a2, 2, 0, nullptr, nullptr, 0, nullptr, 0);
+        }
         if (run) {
             const size_t e0 = span_begin();
             ok(hl::timestep_embedding(t, tf, B, c.model_channels, temb, st));
             ok(hl::linear_small(temb, c.model_channels, B, c.model_channels, n.te0_w, n.te0_b, n.E, 0, nullptr, nullptr, e1, n.E, st));
-            ok(hl::linear_small(e1, n.E, B, n.E, n.te2_w, n.te2_b, n.E, 1, c.num_classes > 0 ? n.label : nullptr, y, emb, n.E, st));
+            ok(hl::linear_small(e1, n.E, B, n.E, n.te2_w, n.te2_b, n.E, 1, c.num_classes > 0 ? n.label : nullptr, y, c.adagn ? emb0 : emb, n.E, st));
+            if (c.adagn) ok(hl::linear_small(a2.p, 4096, B, 4096, n.ada_w, n.ada_b, n.E, 0, emb0, iota, emb, n.E, st));
             ok(hl::linear_small(emb, n.E, B, n.E, n.emb_w, n.emb_b, (int)n.emb_total, 1, nullptr, nullptr, emb_all, n.emb_total, st));
             ok(hl::prep_inputs(x, c.controlnet ? x_cond : nullptr, B, c.in_channels, H, W, n.Cpad0, xin.p,
                                c.controlnet ? xsum.p : nullptr, st));
@@ -590,6 +621,7 @@ int validate(const hl_unet_cfg *c) {
     HL_REQUIRE(c->n_levels >= 1 && c->n_levels <= 8 && c->n_attention_ds >= 0 && c->n_attention_ds <= 8, "unet: bad cfg sizes");
     HL_REQUIRE(c->model_channels % 32 == 0, "unet: model_channels must be a multiple of 32 (GroupNorm32)");
     HL_REQUIRE(c->in_channels > 0 && c->out_channels > 0 && c->num_res_blocks > 0 && c->num_heads > 0, "unet: bad cfg");
+    HL_REQUIRE(!(c->controlnet && c->adagn), "unet: cond_type is either controlnet or AdaGN");
     return 0;
 }
 
@@ -672,6 +704,7 @@ int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float 
     HL_REQUIRE(B >= 1 && B <= 16, "hl_unet_forward: batch %d outside [1,16]", B);
     HL_REQUIRE(H % total_ds == 0 && W % total_ds == 0, "hl_unet_forward: H,W must be divisible by %d", total_ds);
     HL_REQUIRE(!n.cfg.controlnet || x_cond, "hl_unet_forward: x_cond is required with cond_type='controlnet'");
+    HL_REQUIRE(!n.cfg.adagn || (x_cond && H == 256 && W == 256), "hl_unet_forward: cond_type='AdaGN' needs x_cond and 256x256 inputs (Linear(64*64, ..))");
     HL_REQUIRE(n.cfg.num_classes == 0 || y, "hl_unet_forward: y is required for a class-conditional model");
     Exec dry{n, false, nullptr, 0, nullptr, B, H, W};   // sizes only (host work, no launches)
     dry.forward(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);

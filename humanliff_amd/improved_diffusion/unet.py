@@ -4,7 +4,7 @@
 The torch modules declared here only own the parameters (so reference checkpoints load with
 load_state_dict and .to(device) works).  forward() hands the parameter pointers to the C ABI
 (hl_unet_create / hl_unet_forward); there is no PyTorch implementation of the math and no CPU path.
-Supported configuration: dims=2, use_scale_shift_norm=True, cond_type in {"controlnet", "concat", ""},
+Supported configuration: dims=2, use_scale_shift_norm=True, cond_type in {"controlnet", "AdaGN", "concat", ""},
 use_3d_aware=False.  Under no_grad / eval() forward() is the fused inference path; with gradients enabled on a model in training
 mode it is the differentiable path of unet_train.py (HIP forward and backward kernels behind autograd.Functions).
 """
@@ -100,10 +100,10 @@ class UNetModel(nn.Module):
         super().__init__()
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
-        if dims != 2 or not conv_resample or use_3d_aware or not use_scale_shift_norm or cond_type not in ("controlnet", "", "concat"):
+        if dims != 2 or not conv_resample or use_3d_aware or not use_scale_shift_norm or cond_type not in ("controlnet", "", "concat", "AdaGN"):
             raise NotImplementedError(
                 "the MI355X build covers dims=2, conv_resample=True, use_scale_shift_norm=True, "
-                "cond_type in {'controlnet', '', 'concat'}, use_3d_aware=False (the shipped HumanLiff configuration is controlnet)")
+                "cond_type in {'controlnet', '', 'concat', 'AdaGN'}, use_3d_aware=False (the shipped HumanLiff configuration is controlnet)")
         if dropout != 0:
             raise NotImplementedError("dropout > 0 is a training feature; inference build only")
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
@@ -146,6 +146,10 @@ class UNetModel(nn.Module):
             self.input_blocks_cond = nn.ModuleList(cenc)
             self.input_blocks_proj_cond = nn.ModuleList(
                 [zero_module(conv_nd(dims, c, c, 1, padding=0)) for c in cchans])
+        elif cond_type == "AdaGN":      # unet.py:519-525: the condition becomes one more summand of the timestep embedding
+            self.conv_proj_1 = conv_nd(dims, self.out_channels, 6, 3, padding=1, stride=2)
+            self.conv_proj_2 = conv_nd(dims, 6, 1, 3, padding=1, stride=2)
+            self.linear = nn.Linear(64 * 64, emb_dim)
         self._hip = None       # (handle, packed buffer, key)
         self._conv_mode = _lib.HL_CONV_FP32
         self._ws = {}          # (B,H,W,device) -> workspace tensor
@@ -175,6 +179,7 @@ class UNetModel(nn.Module):
         c.num_heads, c.num_heads_upsample = self.num_heads, self.num_heads_upsample
         c.num_classes = self.num_classes or 0
         c.controlnet = 1 if self.cond_type == "controlnet" else 0
+        c.adagn = 1 if self.cond_type == "AdaGN" else 0
         return c
 
     def _apply(self, fn, *a, **kw):       # .to() / .cuda() / .float(): parameter objects may be replaced
@@ -258,8 +263,8 @@ class UNetModel(nn.Module):
         """Same contract as the reference: x (N,C,H,W), timesteps (N,), x_cond (N,C,H,W), y (N,) -> (N,C_out,H,W)."""
         if self.num_classes is not None:
             assert y is not None and y.shape == (x.shape[0],)
-        if self.cond_type == "controlnet":
-            assert x_cond is not None, "cond_type='controlnet' needs x_cond (zeros for the first layer)"
+        if self.cond_type in ("controlnet", "AdaGN"):
+            assert x_cond is not None, f"cond_type='{self.cond_type}' needs x_cond (zeros for the first layer)"
         if self.cond_type == "concat":        # unet.py:572-573: the condition rides along as extra input channels (in_channels counts both)
             assert x_cond is not None, "cond_type='concat' needs x_cond"
             x, x_cond = th.cat([x, x_cond], dim=1), None

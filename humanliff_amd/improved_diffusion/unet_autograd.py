@@ -77,6 +77,10 @@ def forward_autograd(model, x, timesteps, x_cond=None, y=None):
     if model.cond_type == "concat":          # unet.py:572-573
         x, x_cond = th.cat([x, x_cond], dim=1), None
     emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
+    if model.cond_type == "AdaGN":           # unet.py:574-578 (like the embedding MLP: three tiny torch modules, autograd's own backward)
+        assert x_cond is not None, "cond_type='AdaGN' needs x_cond"
+        xp = model.conv_proj_2(model.conv_proj_1(x_cond.float()))
+        emb = emb + model.linear(xp.reshape(xp.shape[0], -1))
     if model.num_classes is not None:
         emb = emb + model.label_emb(y)
     hs = []

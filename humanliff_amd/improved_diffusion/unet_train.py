@@ -232,6 +232,10 @@ def forward_train(model, x, timesteps, x_cond=None, y=None):
     if model.cond_type == "concat":          # unet.py:572-573
         x, x_cond = th.cat([x, x_cond], dim=1), None
     emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
+    if model.cond_type == "AdaGN":           # unet.py:574-578 (like the embedding MLP: three tiny torch modules, autograd's own backward)
+        assert x_cond is not None, "cond_type='AdaGN' needs x_cond"
+        xp = model.conv_proj_2(model.conv_proj_1(x_cond.float()))
+        emb = emb + model.linear(xp.reshape(xp.shape[0], -1))
     if model.num_classes is not None:
         emb = emb + model.label_emb(y)
     to_nhwc = lambda t: _pad_c(t.float().permute(0, 2, 3, 1), 16).contiguous()  # noqa: E731   (27 -> 32 channels, zeros)

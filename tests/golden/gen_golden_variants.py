@@ -88,6 +88,27 @@ def unet_concat():
         out[f"{tag}_out"] = y.numpy()
         out[f"{tag}_nkeys"] = len(ks)
         print(tag, "keys", len(ks), "out abs mean", float(y.abs().mean()))
+    # cond_type='AdaGN' (unet.py:519-525, 574-578): Linear(64*64, E) fixes the input at 256x256; a narrow 6-level net, batch 1.  The
+    # output is 27x256x256: every 8th pixel is stored plus the sum and the sum of absolute values of all of them (float64)
+    a = model_and_diffusion_defaults()
+    a.update(dict(in_channels=27, out_channels=27, class_cond=True, learn_sigma=False, num_heads=2, use_scale_shift_norm=True,
+                  cond_type="AdaGN", rescale_timesteps=False, dropout=0.0, image_size=256, num_channels=32, num_res_blocks=1,
+                  attention_resolutions="32,16,8"))
+    model, _ = create_model_and_diffusion(**a)
+    model.eval()
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((1, 27, 256, 256), generator=g)
+    xc = torch.randn((1, 27, 256, 256), generator=g).clamp(-1, 1) * 0.7
+    with torch.no_grad():
+        y = model(x, torch.tensor([412]), xc, y=torch.tensor([731]))
+        y0 = model(x, torch.tensor([412]), torch.zeros_like(xc), y=torch.tensor([731]))
+    out["adagn_out_s8"] = y[:, :, ::8, ::8].numpy()
+    out["adagn_sums"] = np.array([float(y.double().sum()), float(y.double().abs().sum())])
+    out["adagn_nkeys"] = len(ks)
+    out["adagn_cond_effect"] = float((y - y0).abs().max())       # the condition matters (the projection is not a no-op)
+    print("AdaGN keys", len(ks), "out abs mean", float(y.abs().mean()), "effect of x_cond", out["adagn_cond_effect"])
     np.savez_compressed(os.path.join(HERE, "unet_cond_types.npz"), **out)
 
 

@@ -335,6 +335,38 @@ def test_learn_sigma_network_samples_end_to_end():
     assert out.shape == (2, 27, 32, 32) and torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6
 
 
+def test_unet_adagn_matches_reference():
+    """cond_type='AdaGN' (unet.py:519-525, 574-578): x_cond -> conv 3x3 s2 -> conv 3x3 s2 -> Linear(64*64, E) added to the timestep
+    embedding; 1000 classes (script_util.py:130).  A narrow 256x256 net against the reference's forward: every 8th output pixel and
+    the sums over all of them (tests/golden/gen_golden_variants.py)."""
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+    g = np.load(os.path.join(GOLDEN, "unet_cond_types.npz"))
+    a = model_and_diffusion_defaults()
+    a.update(dict(in_channels=27, out_channels=27, class_cond=True, learn_sigma=False, num_heads=2, use_scale_shift_norm=True,
+                  cond_type="AdaGN", rescale_timesteps=False, dropout=0.0, image_size=256, num_channels=32, num_res_blocks=1,
+                  attention_resolutions="32,16,8"))
+    model, _ = create_model_and_diffusion(**a)
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert len(ks) == int(g["adagn_nkeys"]) and model.num_classes == 1000
+    model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+    model = model.to(dev).eval()
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn((1, 27, 256, 256), generator=gen)
+    xc = torch.randn((1, 27, 256, 256), generator=gen).clamp(-1, 1) * 0.7
+    t, yl = torch.tensor([412], device=dev), torch.tensor([731], device=dev)
+    with torch.no_grad():
+        y = model(x.to(dev), t, xc.to(dev), y=yl).cpu()
+        y0 = model(x.to(dev), t, torch.zeros_like(xc).to(dev), y=yl).cpu()
+    assert (y[:, :, ::8, ::8] - torch.from_numpy(g["adagn_out_s8"])).abs().max() < 1e-4
+    n = y.numel()
+    assert abs(float(y.double().sum()) - g["adagn_sums"][0]) < 2e-5 * n and abs(float(y.double().abs().sum()) - g["adagn_sums"][1]) < 2e-5 * n
+    assert abs(float((y - y0).abs().max()) - float(g["adagn_cond_effect"])) < 1e-3          # the condition acts through the embedding
+    # the differentiable twin (and with it the training path's embedding) states the same function
+    with torch.no_grad():
+        tw = model.forward_autograd(x.to(dev), t, xc.to(dev), y=yl).cpu()
+    assert (tw - y).abs().max() < 1e-4
+
+
 @pytest.mark.parametrize("tag,cond,cin", [("concat", "concat", 54), ("plain", "", 27)])
 def test_unet_cond_types_match_reference(tag, cond, cin):
     """cond_type='concat' (x_cond rides along as input channels, unet.py:572-573) and cond_type='' (no conditioning branch) on the tiny
