@@ -38,6 +38,7 @@ struct Res {
     Norm n1, n2;
     Conv c1, c2, skip;
     bool has_skip = false;
+    bool aware = false;   // use_3d_aware: out_layers' conv reads cat[h, two plane means] = 3*Cout channels (unet.py:158-166, 208-214)
     long emb_off = 0;
     int Cin = 0, Cout = 0;
 };
@@ -176,16 +177,16 @@ Norm make_norm(Net &n, const std::string &p, int C) {
 
 struct EmbPiece { std::string name; int O; long off; };
 
-int add_res(Net &n, std::vector<EmbPiece> &emb, const std::string &p, int Cin, int Cout) {
+int add_res(Net &n, std::vector<EmbPiece> &emb, const std::string &p, int Cin, int Cout, bool aware = false) {
     Res r;
-    r.Cin = Cin; r.Cout = Cout;
+    r.Cin = Cin; r.Cout = Cout; r.aware = aware;
     r.n1 = make_norm(n, p + ".in_layers.0", Cin);
     r.c1 = make_conv(n, p + ".in_layers.2", Cin, Cout, 3);
     r.emb_off = n.emb_total;
     emb.push_back({p + ".emb_layers.1", 2 * Cout, n.emb_total});
     n.emb_total += 2 * Cout;
     r.n2 = make_norm(n, p + ".out_layers.0", Cout);
-    r.c2 = make_conv(n, p + ".out_layers.3", Cout, Cout, 3);
+    r.c2 = make_conv(n, p + ".out_layers.3", aware ? 3 * Cout : Cout, Cout, 3);
     r.has_skip = Cin != Cout;
     if (r.has_skip) {
         // the shipped config uses a 1x1 skip (use_conv=False, unet.py:177-184); a 3x3 one is told apart by size
@@ -221,7 +222,7 @@ bool has_ds(const hl_unet_cfg &c, int ds) {
 
 // builds one encoder (main or control) following unet.py:375-415 / 477-518
 void build_encoder(Net &n, std::vector<EmbPiece> &emb, const std::string &root, std::vector<Block> &blocks,
-                   std::vector<int> &chans) {
+                   std::vector<int> &chans, bool aware) {
     const hl_unet_cfg &c = n.cfg;
     Block b0;
     b0.layers.push_back({K_CONV, add_conv(n, root + ".0.0", c.in_channels, c.model_channels, 3)});
@@ -235,7 +236,7 @@ void build_encoder(Net &n, std::vector<EmbPiece> &emb, const std::string &root, 
             Block b;
             const std::string p = root + "." + std::to_string(bi);
             const int co = c.channel_mult[level] * c.model_channels;
-            b.layers.push_back({K_RES, add_res(n, emb, p + ".0", ch, co)});
+            b.layers.push_back({K_RES, add_res(n, emb, p + ".0", ch, co, aware)});
             ch = co;
             if (has_ds(c, ds)) b.layers.push_back({K_ATTN, add_attn(n, p + ".1", ch, c.num_heads)});
             b.Cout = ch; b.ds_out = ds;
@@ -278,14 +279,15 @@ void build(Net &n) {
     }
 
     std::vector<int> chans;
-    build_encoder(n, emb, "input_blocks", n.in_blocks, chans);
+    const bool aware = c.aware3d != 0;
+    build_encoder(n, emb, "input_blocks", n.in_blocks, chans, aware);
     int ch = chans.back();
     int ds = n.in_blocks.back().ds_out;
     {
         Block m;
-        m.layers.push_back({K_RES, add_res(n, emb, "middle_block.0", ch, ch)});
+        m.layers.push_back({K_RES, add_res(n, emb, "middle_block.0", ch, ch, aware)});
         m.layers.push_back({K_ATTN, add_attn(n, "middle_block.1", ch, c.num_heads)});
-        m.layers.push_back({K_RES, add_res(n, emb, "middle_block.2", ch, ch)});
+        m.layers.push_back({K_RES, add_res(n, emb, "middle_block.2", ch, ch, aware)});
         m.Cout = ch; m.ds_out = ds;
         n.middle = m;
     }
@@ -299,7 +301,7 @@ void build(Net &n) {
             stack.pop_back();
             const int co = c.model_channels * c.channel_mult[level];
             int li = 0;
-            b.layers.push_back({K_RES, add_res(n, emb, p + "." + std::to_string(li++), ch + skip, co)});
+            b.layers.push_back({K_RES, add_res(n, emb, p + "." + std::to_string(li++), ch + skip, co, aware)});
             ch = co;
             if (has_ds(c, ds)) b.layers.push_back({K_ATTN, add_attn(n, p + "." + std::to_string(li++), ch, c.num_heads_upsample)});
             if (level && i == c.num_res_blocks) {
@@ -315,7 +317,7 @@ void build(Net &n) {
     n.out_conv = make_conv(n, "out.2", c.model_channels, c.out_channels, 3);
     if (c.controlnet) {
         std::vector<int> cch;
-        build_encoder(n, emb, "input_blocks_cond", n.cond_blocks, cch);
+        build_encoder(n, emb, "input_blocks_cond", n.cond_blocks, cch, false);   // the control tower's ResBlocks are plain (unet.py:477-518)
         for (size_t i = 0; i < n.cond_blocks.size(); ++i)
             n.proj_cond.push_back(add_conv(n, "input_blocks_proj_cond." + std::to_string(i), cch[i], cch[i], 1));
     }
@@ -447,6 +449,26 @@ struct Exec {
         View h = plain(H / dst.H, r.Cout);
         conv(r.c1, x, h, 1, 0, a1, b1, 1, nullptr, 0);
         coef(h, r.n2, run ? emb_all + r.emb_off : nullptr, a2, b2);
+        if (r.aware) {
+            // unet.py:208-214: every plane sees, next to its own normalised features, the other two planes averaged along the axis
+            // it does not share with them; materialised (with the SiLU of out_layers) as a 3C-channel tensor for the convolution
+            View h3 = plain(H / dst.H, 3 * r.Cout);
+            float *sums = alloc((size_t)B * 3 * (h.H + h.W / 3) * r.Cout);
+            if (run) {
+                const size_t e0 = span_begin();
+                ok(hl::gn_apply_3d(h, a2, b2, sums, h3.p, st));
+                span_end(CAT_GN, e0, 0.0);
+            }
+            if (r.has_skip) {
+                want_stats = false;
+                conv(r.skip, x, dst, 1, 0, nullptr, nullptr, 0, nullptr, 0);
+                want_stats = true;
+                conv(r.c2, h3, dst, 1, 0, nullptr, nullptr, 0, dst.p, dst.pitch);
+            } else {
+                conv(r.c2, h3, dst, 1, 0, nullptr, nullptr, 0, x.p, x.pitch);
+            }
+            return;
+        }
         if (r.has_skip) {
             want_stats = false;          // dst is finished by c2 below
             conv(r.skip, x, dst, 1, 0, nullptr, nullptr, 0, nullptr, 0);
@@ -539,8 +561,10 @@ struct Exec {
             ok(hl::linear_small(e1, n.E, B, n.E, n.te2_w, n.te2_b, n.E, 1, c.num_classes > 0 ? n.label : nullptr, y, c.adagn ? emb0 : emb, n.E, st));
             if (c.adagn) ok(hl::linear_small(a2.p, 4096, B, 4096, n.ada_w, n.ada_b, n.E, 0, emb0, iota, emb, n.E, st));
             ok(hl::linear_small(emb, n.E, B, n.E, n.emb_w, n.emb_b, (int)n.emb_total, 1, nullptr, nullptr, emb_all, n.emb_total, st));
-            ok(hl::prep_inputs(x, c.controlnet ? x_cond : nullptr, B, c.in_channels, H, W, n.Cpad0, xin.p,
-                               c.controlnet ? xsum.p : nullptr, st));
+            if (c.aware3d) ok(hl::prep_inputs_3d(x, c.controlnet ? x_cond : nullptr, B, c.in_channels, H, W / 3, n.Cpad0, xin.p,
+                                                 c.controlnet ? xsum.p : nullptr, st));
+            else ok(hl::prep_inputs(x, c.controlnet ? x_cond : nullptr, B, c.in_channels, H, W, n.Cpad0, xin.p,
+                                    c.controlnet ? xsum.p : nullptr, st));
             span_end(CAT_OTHER, e0, 2.0 * B * ((double)n.E * c.model_channels + (double)n.E * n.E + (double)n.emb_total * n.E));
         }
         // decoder "concat" buffers: [h | skip]; sized from the block structure
@@ -612,6 +636,12 @@ struct Exec {
         float *ca, *cb;
         coef(last, n.out_norm, nullptr, ca, cb);
         View o; o.N = B; o.H = H; o.W = W; o.C = c.out_channels; o.pitch = c.out_channels; o.p = out;
+        if (c.aware3d) {   // unet.py:613-614: the planes go back to channels
+            o.p = alloc((size_t)o.pixels() * c.out_channels);
+            conv(n.out_conv, last, o, 1, 0, ca, cb, 1, nullptr, 0, nullptr, 0, nullptr, 0, 1);
+            if (run) ok(hl::unroll_planes(o.p, B, c.out_channels, H, W / 3, out, st));
+            return;
+        }
         conv(n.out_conv, last, o, 1, 0, ca, cb, 1, nullptr, 0, nullptr, 0, nullptr, 0, 1);
     }
 };
@@ -622,6 +652,7 @@ int validate(const hl_unet_cfg *c) {
     HL_REQUIRE(c->model_channels % 32 == 0, "unet: model_channels must be a multiple of 32 (GroupNorm32)");
     HL_REQUIRE(c->in_channels > 0 && c->out_channels > 0 && c->num_res_blocks > 0 && c->num_heads > 0, "unet: bad cfg");
     HL_REQUIRE(!(c->controlnet && c->adagn), "unet: cond_type is either controlnet or AdaGN");
+    HL_REQUIRE(!(c->aware3d && c->adagn), "unet: use_3d_aware with cond_type='AdaGN' is not built");
     return 0;
 }
 
@@ -691,7 +722,7 @@ void hl_unet_destroy(void *handle) { delete static_cast<Net *>(handle); }
 size_t hl_unet_workspace_bytes(void *handle, int B, int H, int W) {
     if (!handle || B <= 0) return 0;
     Net &n = *static_cast<Net *>(handle);
-    Exec e{n, false, nullptr, 0, nullptr, B, H, W};
+    Exec e{n, false, nullptr, 0, nullptr, B, H, n.cfg.aware3d ? 3 * W : W};
     e.forward(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     return e.off + 2 * e.act_need * sizeof(float) + 1024;
 }
@@ -706,6 +737,7 @@ int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float 
     HL_REQUIRE(!n.cfg.controlnet || x_cond, "hl_unet_forward: x_cond is required with cond_type='controlnet'");
     HL_REQUIRE(!n.cfg.adagn || (x_cond && H == 256 && W == 256), "hl_unet_forward: cond_type='AdaGN' needs x_cond and 256x256 inputs (Linear(64*64, ..))");
     HL_REQUIRE(n.cfg.num_classes == 0 || y, "hl_unet_forward: y is required for a class-conditional model");
+    if (n.cfg.aware3d) W *= 3;                           // use_3d_aware: x is (B, 3*in_channels, H, W); the network runs on (B, in_channels, H, 3W)
     Exec dry{n, false, nullptr, 0, nullptr, B, H, W};   // sizes only (host work, no launches)
     dry.forward(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     Exec e{n, true, static_cast<char *>(workspace), 0, (hipStream_t)stream, B, H, W};

@@ -95,4 +95,11 @@ int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipS
 int prep_inputs(const float *x, const float *x_cond, int B, int C, int H, int W, int Cpad, float *x_nhwc, float *xsum_nhwc,
                 hipStream_t st);
 
+// use_3d_aware=True (unet.py:566-570, 613-614): (B, 3C, H, W) NCHW <-> the planes side by side, NHWC (B, H, 3W, Cpad) / NCHW (B, C, H, 3W)
+int prep_inputs_3d(const float *x, const float *x_cond, int B, int C, int H, int W, int Cpad, float *x_nhwc, float *xsum_nhwc,
+                   hipStream_t st);
+int unroll_planes(const float *rolled_nchw, int B, int C, int H, int W, float *out, hipStream_t st);
+// ResBlock step of unet.py:208-214: y (N, H, 3W, 3C dense) = silu(cat[A h + B, two plane means of it]); sums: N*3*(H + W/3)*C floats
+int gn_apply_3d(const View &h, const float *coefA, const float *coefB, float *sums, float *y, hipStream_t st);
+
 }  // namespace hl

@@ -2317,6 +2317,82 @@ __global__ void k_prep_inputs(const float *__restrict__ x, const float *__restri
     }
 }
 
+// ---- use_3d_aware=True (unet.py:566-570, 208-214, 613-614): the three planes of a tri-plane sit side by side, (B, C/3, H, 3W) ----
+// (B, 3C, H, W) NCHW -> rolled NHWC (B, H, 3W, Cpad): pixel (y, p*W + x) channel c <- channel p*C + c; xs = x + x_cond likewise
+__global__ void k_prep_inputs_3d(const float *__restrict__ x, const float *__restrict__ xc, int B, int C, int H, int W, int Cpad,
+                                 float *__restrict__ xo, float *__restrict__ xs) {
+    const long n = (long)B * H * 3 * W * Cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const long pix = i / Cpad;
+        const int X = (int)(pix % (3 * W));
+        const long by = pix / (3 * W);
+        const int yy = (int)(by % H);
+        const long b = by / H;
+        const int pl = X / W, xx = X - pl * W;
+        float v = 0.f, sm = 0.f;
+        if (c < C) {
+            const long src = ((b * 3 * C + pl * C + c) * H + yy) * W + xx;
+            v = x[src];
+            sm = xc ? v + xc[src] : v;
+        }
+        xo[i] = v;
+        if (xs) xs[i] = sm;
+    }
+}
+// rolled NCHW (B, C, H, 3W) -> (B, 3C, H, W)
+__global__ void k_unroll_planes(const float *__restrict__ in, int B, int C, int H, int W, float *__restrict__ out) {
+    const long n = (long)B * 3 * C * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        long r = i / W;
+        const int yy = (int)(r % H); r /= H;
+        const int ch = (int)(r % (3 * C));
+        const long b = r / (3 * C);
+        const int pl = ch / C, c = ch - pl * C;
+        out[i] = in[((b * C + c) * H + yy) * (3L * W) + pl * W + xx];
+    }
+}
+// per plane p: row sums over its W columns -> sums[b][p][y][c] (y < H) and column sums over the H rows -> sums[b][p][H + x][c]
+__global__ __launch_bounds__(256) void k_plane_sums(const float *__restrict__ h, long pitch, int H, int W, int C, float *__restrict__ sums) {
+    const int item = blockIdx.x % (H + W), bp = blockIdx.x / (H + W), pl = bp % 3, b = bp / 3;
+    const float *base = h + ((long)b * H * 3 * W + (long)pl * W) * pitch;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f;
+        if (item < H) for (int xx = 0; xx < W; ++xx) a += base[((long)item * 3 * W + xx) * pitch + c];
+        else for (int yy = 0; yy < H; ++yy) a += base[((long)yy * 3 * W + (item - H)) * pitch + c];
+        sums[((long)bp * (H + W) + item) * C + c] = a;
+    }
+}
+// y (B, H, 3W, 3C) = silu(cat[hn, m1, m2]) with hn = A h + B and, per plane (unet.py:210-213):
+//   plane 0: m1 = mean over W of plane 1 (a function of y), m2 = mean over H of plane 2 (of x)
+//   plane 1: m1 = mean over W of plane 0 (y),               m2 = mean over W of plane 2 (y)
+//   plane 2: m1 = mean over H of plane 0 (x),               m2 = mean over H of plane 1 (x)
+// (means of the normalised tensor = the affine of the raw means)
+__global__ void k_gn_apply_3d(const float *__restrict__ h, long pitch, int B, int H, int W, int C, const float *__restrict__ cA,
+                              const float *__restrict__ cB, const float *__restrict__ sums, float *__restrict__ y) {
+    const long n = (long)B * H * 3 * W * C;
+    const float iw = 1.f / (float)W, ih = 1.f / (float)H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        const int X = (int)(pix % (3 * W));
+        const long by = pix / (3 * W);
+        const int yy = (int)(by % H);
+        const int b = (int)(by / H);
+        const int pl = X / W, xx = X - pl * W;
+        const float a = cA[(long)b * C + c], bb = cB[(long)b * C + c];
+        auto rowm = [&](int q) { return sums[(((long)b * 3 + q) * (H + W) + yy) * C + c] * iw; };
+        auto colm = [&](int q) { return sums[(((long)b * 3 + q) * (H + W) + H + xx) * C + c] * ih; };
+        const float m1 = pl == 0 ? rowm(1) : (pl == 1 ? rowm(0) : colm(0));
+        const float m2 = pl == 0 ? colm(2) : (pl == 1 ? rowm(2) : colm(1));
+        float *o = y + pix * 3 * C + c;
+        o[0] = silu_f(fmaf(h[pix * pitch + c], a, bb));
+        o[C] = silu_f(fmaf(m1, a, bb));
+        o[2 * C] = silu_f(fmaf(m2, a, bb));
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -2698,6 +2774,30 @@ int prep_inputs(const float *x, const float *xc, int B, int C, int H, int W, int
     HL_REQUIRE(x && xo && Cpad >= C, "prep_inputs: bad argument");
     hipLaunchKernelGGL(k_prep_inputs, dim3(2048), dim3(256), 0, st, x, xc, B, C, H * W, Cpad, xo, xs);
     return check_launch("k_prep_inputs");
+}
+
+int prep_inputs_3d(const float *x, const float *xc, int B, int C, int H, int W, int Cpad, float *xo, float *xs, hipStream_t st) {
+    HL_REQUIRE(x && xo && Cpad >= C, "prep_inputs_3d: bad argument");
+    hipLaunchKernelGGL(k_prep_inputs_3d, dim3(2048), dim3(256), 0, st, x, xc, B, C, H, W, Cpad, xo, xs);
+    return check_launch("k_prep_inputs_3d");
+}
+
+int unroll_planes(const float *in, int B, int C, int H, int W, float *out, hipStream_t st) {
+    HL_REQUIRE(in && out, "unroll_planes: null argument");
+    hipLaunchKernelGGL(k_unroll_planes, dim3(2048), dim3(256), 0, st, in, B, C, H, W, out);
+    return check_launch("k_unroll_planes");
+}
+
+int gn_apply_3d(const View &h, const float *coefA, const float *coefB, float *sums, float *y, hipStream_t st) {
+    HL_REQUIRE(h.p && coefA && coefB && sums && y && h.W % 3 == 0, "gn_apply_3d: bad argument");
+    const int W = h.W / 3;
+    hipLaunchKernelGGL(k_plane_sums, dim3((unsigned)(h.N * 3 * (h.H + W))), dim3(256), 0, st, h.p, h.pitch, h.H, W, h.C, sums);
+    int rc = check_launch("k_plane_sums");
+    if (rc) return rc;
+    long g = ((long)h.pixels() * h.C + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_gn_apply_3d, dim3((unsigned)g), dim3(256), 0, st, h.p, h.pitch, h.N, h.H, W, h.C, coefA, coefB, sums, y);
+    return check_launch("k_gn_apply_3d");
 }
 
 }  // namespace hl

@@ -5,7 +5,7 @@ The torch modules declared here only own the parameters (so reference checkpoint
 load_state_dict and .to(device) works).  forward() hands the parameter pointers to the C ABI
 (hl_unet_create / hl_unet_forward); there is no PyTorch implementation of the math and no CPU path.
 Supported configuration: dims=2, use_scale_shift_norm=True, cond_type in {"controlnet", "AdaGN", "concat", ""},
-use_3d_aware=False.  Under no_grad / eval() forward() is the fused inference path; with gradients enabled on a model in training
+use_3d_aware False or True (sampling only; not with AdaGN).  Under no_grad / eval() forward() is the fused inference path; with gradients enabled on a model in training
 mode it is the differentiable path of unet_train.py (HIP forward and backward kernels behind autograd.Functions).
 """
 import ctypes as C
@@ -45,14 +45,16 @@ class ResBlock(TimestepBlock):
     def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
                  use_3d_aware=False, dims=2, use_checkpoint=False):
         super().__init__()
-        if not use_scale_shift_norm or use_3d_aware:
-            raise NotImplementedError("only use_scale_shift_norm=True, use_3d_aware=False is built")
+        if not use_scale_shift_norm:
+            raise NotImplementedError("only use_scale_shift_norm=True is built")
         oc = out_channels or channels
         self.channels, self.emb_channels, self.dropout, self.out_channels = channels, emb_channels, dropout, oc
+        self.use_3d_aware = use_3d_aware
         self.in_layers = nn.Sequential(normalization(channels), SiLU(), conv_nd(dims, channels, oc, 3, padding=1))
         self.emb_layers = nn.Sequential(SiLU(), linear(emb_channels, 2 * oc))
+        # use_3d_aware (unet.py:158-166): the conv reads cat[h, two plane means of h] = 3*oc channels
         self.out_layers = nn.Sequential(normalization(oc), SiLU(), nn.Dropout(p=dropout),
-                                        zero_module(conv_nd(dims, oc, oc, 3, padding=1)))
+                                        zero_module(conv_nd(dims, 3 * oc if use_3d_aware else oc, oc, 3, padding=1)))
         if oc == channels:
             self.skip_connection = nn.Identity()
         else:
@@ -73,13 +75,13 @@ class AttentionBlock(nn.Module):
         self.proj_out = zero_module(conv_nd(1, channels, channels, 1))
 
 
-def _encoder(in_channels, mc, channel_mult, num_res_blocks, attention_resolutions, emb_dim, dropout, dims, heads):
+def _encoder(in_channels, mc, channel_mult, num_res_blocks, attention_resolutions, emb_dim, dropout, dims, heads, aware=False):
     """Block list of one encoder tower + its per-block channel counts (unet.py:375-415 / 477-518)."""
     blocks = [TimestepEmbedSequential(conv_nd(dims, in_channels, mc, 3, padding=1))]
     chans, ch, ds = [mc], mc, 1
     for level, mult in enumerate(channel_mult):
         for _ in range(num_res_blocks):
-            layers = [ResBlock(ch, emb_dim, dropout, out_channels=mult * mc, dims=dims, use_scale_shift_norm=True)]
+            layers = [ResBlock(ch, emb_dim, dropout, out_channels=mult * mc, dims=dims, use_scale_shift_norm=True, use_3d_aware=aware)]
             ch = mult * mc
             if ds in attention_resolutions:
                 layers.append(AttentionBlock(ch, num_heads=heads))
@@ -100,10 +102,11 @@ class UNetModel(nn.Module):
         super().__init__()
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
-        if dims != 2 or not conv_resample or use_3d_aware or not use_scale_shift_norm or cond_type not in ("controlnet", "", "concat", "AdaGN"):
+        if dims != 2 or not conv_resample or not use_scale_shift_norm or cond_type not in ("controlnet", "", "concat", "AdaGN") or \
+                (use_3d_aware and cond_type == "AdaGN"):
             raise NotImplementedError(
-                "the MI355X build covers dims=2, conv_resample=True, use_scale_shift_norm=True, "
-                "cond_type in {'controlnet', '', 'concat', 'AdaGN'}, use_3d_aware=False (the shipped HumanLiff configuration is controlnet)")
+                "the MI355X build covers dims=2, conv_resample=True, use_scale_shift_norm=True, cond_type in {'controlnet', '', 'concat', "
+                "'AdaGN'}, use_3d_aware with every cond_type but 'AdaGN' (the shipped HumanLiff configuration is controlnet, use_3d_aware=False)")
         if dropout != 0:
             raise NotImplementedError("dropout > 0 is a training feature; inference build only")
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
@@ -119,18 +122,18 @@ class UNetModel(nn.Module):
         if num_classes is not None:
             self.label_emb = nn.Embedding(num_classes, emb_dim)
         enc, chans, ch, ds = _encoder(in_channels, model_channels, self.channel_mult, num_res_blocks,
-                                      self.attention_resolutions, emb_dim, dropout, dims, num_heads)
+                                      self.attention_resolutions, emb_dim, dropout, dims, num_heads, aware=use_3d_aware)
         self.input_blocks = nn.ModuleList(enc)
         self.middle_block = TimestepEmbedSequential(
-            ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=True),
+            ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=True, use_3d_aware=use_3d_aware),
             AttentionBlock(ch, num_heads=num_heads),
-            ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=True))
+            ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=True, use_3d_aware=use_3d_aware))
         self.output_blocks = nn.ModuleList([])
         stack = list(chans)
         for level, mult in list(enumerate(self.channel_mult))[::-1]:
             for i in range(num_res_blocks + 1):
                 layers = [ResBlock(ch + stack.pop(), emb_dim, dropout, out_channels=model_channels * mult, dims=dims,
-                                   use_scale_shift_norm=True)]
+                                   use_scale_shift_norm=True, use_3d_aware=use_3d_aware)]
                 ch = model_channels * mult
                 if ds in self.attention_resolutions:
                     layers.append(AttentionBlock(ch, num_heads=num_heads_upsample))
@@ -180,6 +183,7 @@ class UNetModel(nn.Module):
         c.num_classes = self.num_classes or 0
         c.controlnet = 1 if self.cond_type == "controlnet" else 0
         c.adagn = 1 if self.cond_type == "AdaGN" else 0
+        c.aware3d = 1 if self.use_3d_aware else 0
         return c
 
     def _apply(self, fn, *a, **kw):       # .to() / .cuda() / .float(): parameter objects may be replaced
@@ -274,12 +278,15 @@ class UNetModel(nn.Module):
             # training call (train_util.py:236 reaches this through the DDP wrapper): gradients are wanted, take the differentiable path -
             # the same network as a chain of autograd.Functions whose forward and backward are HIP kernels (unet_train.py).
             # Sampling never gets here: the loops run under no_grad and the scripts call model.eval()
+            if self.use_3d_aware:
+                raise NotImplementedError("the HIP training path does not cover use_3d_aware=True (sampling does)")
             from .unet_train import forward_train
             return forward_train(self, x, timesteps, x_cond, y)
         handle = self._bind()
         L = _lib.lib()
         B, Cc, H, W = x.shape
-        assert Cc == self.in_channels
+        planes = 3 if self.use_3d_aware else 1     # use_3d_aware: x / x_cond / the output carry the three planes as 3*in_channels channels
+        assert Cc == planes * self.in_channels, (Cc, self.in_channels, self.use_3d_aware)
         xin = x.detach().to(th.float32).contiguous()
         xc = x_cond.detach().to(th.float32).contiguous() if x_cond is not None else None
         ti = tf = None
@@ -288,7 +295,7 @@ class UNetModel(nn.Module):
         else:
             ti = timesteps.to(th.int64).contiguous()
         yi = y.to(th.int64).contiguous() if y is not None else None
-        out = th.empty((B, self.out_channels, H, W), dtype=th.float32, device=x.device)
+        out = th.empty((B, planes * self.out_channels, H, W), dtype=th.float32, device=x.device)
         wkey = (B, H, W, str(x.device))
         ws = self._ws.get(wkey)
         if ws is None:

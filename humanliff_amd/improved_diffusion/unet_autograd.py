@@ -38,6 +38,12 @@ def _res_block(m, x, emb):
     h = m.in_layers[2](_silu(_norm(m.in_layers[0], x)))
     scale, shift = m.emb_layers[1](_silu(emb)).chunk(2, dim=1)
     h = _norm(m.out_layers[0], h) * (1 + scale[:, :, None, None]) + shift[:, :, None, None]
+    if getattr(m, "use_3d_aware", False):    # unet.py:208-214: each plane + the other two averaged along the axis it does not share
+        w3 = h.shape[-1] // 3
+        p0, p1, p2 = h[..., :w3], h[..., w3:2 * w3], h[..., 2 * w3:]
+        row = lambda p: p.mean(-1, keepdim=True).expand(-1, -1, -1, w3)          # noqa: E731
+        col = lambda p: p.mean(-2, keepdim=True).expand(-1, -1, p.shape[-2], -1)  # noqa: E731
+        h = th.cat([th.cat([p0, row(p1), col(p2)], 1), th.cat([p1, row(p0), row(p2)], 1), th.cat([p2, col(p0), col(p1)], 1)], -1)
     h = m.out_layers[3](_silu(h))
     return m.skip_connection(x) + h
 
@@ -83,6 +89,12 @@ def forward_autograd(model, x, timesteps, x_cond=None, y=None):
         emb = emb + model.linear(xp.reshape(xp.shape[0], -1))
     if model.num_classes is not None:
         emb = emb + model.label_emb(y)
+    aware = getattr(model, "use_3d_aware", False)
+    if aware:                                # unet.py:566-570: the planes side by side
+        c3 = x.shape[1] // 3
+        x = th.cat([x[:, :c3], x[:, c3:2 * c3], x[:, 2 * c3:]], -1)
+        if x_cond is not None:
+            x_cond = th.cat([x_cond[:, :c3], x_cond[:, c3:2 * c3], x_cond[:, 2 * c3:]], -1)
     hs = []
     h = x.float()
     for blk in model.input_blocks:
@@ -101,4 +113,8 @@ def forward_autograd(model, x, timesteps, x_cond=None, y=None):
         if model.cond_type == "controlnet":
             skip = skip + hs_cond.pop()
         h = _run(blk, th.cat([h, skip], dim=1), emb)
-    return model.out[2](_silu(_norm(model.out[0], h))).to(x.dtype)
+    h = model.out[2](_silu(_norm(model.out[0], h)))
+    if aware:                                # unet.py:613-614
+        w3 = h.shape[-1] // 3
+        h = th.cat([h[..., :w3], h[..., w3:2 * w3], h[..., 2 * w3:]], 1)
+    return h.to(x.dtype)

@@ -109,6 +109,25 @@ def unet_concat():
     out["adagn_nkeys"] = len(ks)
     out["adagn_cond_effect"] = float((y - y0).abs().max())       # the condition matters (the projection is not a no-op)
     print("AdaGN keys", len(ks), "out abs mean", float(y.abs().mean()), "effect of x_cond", out["adagn_cond_effect"])
+    # use_3d_aware=True (unet.py:158-166, 208-214, 566-570, 613-614): 27-channel tri-planes, a 9-channel network on the planes side by
+    # side; with the control tower (whose ResBlocks stay plain, :477-518) and without conditioning
+    for tag, cond in (("aware3d_controlnet", "controlnet"), ("aware3d_plain", "")):
+        a = model_and_diffusion_defaults()
+        a.update(dict(in_channels=9, out_channels=9, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=True,
+                      cond_type=cond, use_3d_aware=True, rescale_timesteps=False, dropout=0.0, image_size=32, num_channels=32,
+                      num_res_blocks=1, attention_resolutions="16,8"))
+        model, _ = create_model_and_diffusion(**a)
+        model.eval()
+        ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+        model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+        g = torch.Generator().manual_seed(13)
+        x = torch.randn((2, 27, 32, 32), generator=g)
+        xc = torch.randn((2, 27, 32, 32), generator=g).clamp(-1, 1) * 0.7
+        with torch.no_grad():
+            y = model(x, torch.tensor([999, 17]), xc if cond else None, y=torch.tensor([3, 0]))
+        out[f"{tag}_out"] = y.numpy()
+        out[f"{tag}_nkeys"] = len(ks)
+        print(tag, "keys", len(ks), "out", tuple(y.shape), "abs mean", float(y.abs().mean()))
     np.savez_compressed(os.path.join(HERE, "unet_cond_types.npz"), **out)
 
 

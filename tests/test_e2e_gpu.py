@@ -335,6 +335,36 @@ def test_learn_sigma_network_samples_end_to_end():
     assert out.shape == (2, 27, 32, 32) and torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6
 
 
+@pytest.mark.parametrize("tag,cond", [("aware3d_controlnet", "controlnet"), ("aware3d_plain", "")])
+def test_unet_3d_aware_matches_reference(tag, cond):
+    """use_3d_aware=True (unet.py:158-166, 208-214, 566-570, 613-614): the three planes of a 27-channel tri-plane side by side through a
+    9-channel network whose ResBlocks feed every plane the axis means of the other two; against the reference's forward, plus the
+    differentiable twin and a short sampling loop."""
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+    g = np.load(os.path.join(GOLDEN, "unet_cond_types.npz"))
+    a = model_and_diffusion_defaults()
+    a.update(dict(in_channels=9, out_channels=9, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=True,
+                  cond_type=cond, use_3d_aware=True, rescale_timesteps=False, dropout=0.0, image_size=32, num_channels=32,
+                  num_res_blocks=1, attention_resolutions="16,8", timestep_respacing="ddim4"))
+    model, diffusion = create_model_and_diffusion(**a)
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert len(ks) == int(g[f"{tag}_nkeys"])
+    model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+    model = model.to(dev).eval()
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn((2, 27, 32, 32), generator=gen)
+    xc = torch.randn((2, 27, 32, 32), generator=gen).clamp(-1, 1) * 0.7
+    t, yl = torch.tensor([999, 17], device=dev), torch.tensor([3, 0], device=dev)
+    with torch.no_grad():
+        y = model(x.to(dev), t, xc.to(dev) if cond else None, y=yl).cpu()
+        tw = model.forward_autograd(x.to(dev), t, xc.to(dev) if cond else None, y=yl).cpu()
+    want = torch.from_numpy(g[f"{tag}_out"])
+    assert y.shape == want.shape == (2, 27, 32, 32)
+    assert (y - want).abs().max() < 1e-4 and (tw - want).abs().max() < 1e-4
+    out = diffusion.ddim_sample_loop(model, (2, 27, 32, 32), x_cond=xc.to(dev) if cond else None, noise=x.to(dev), model_kwargs={"y": yl})
+    assert out.shape == (2, 27, 32, 32) and torch.isfinite(out).all()
+
+
 def test_unet_adagn_matches_reference():
     """cond_type='AdaGN' (unet.py:519-525, 574-578): x_cond -> conv 3x3 s2 -> conv 3x3 s2 -> Linear(64*64, E) added to the timestep
     embedding; 1000 classes (script_util.py:130).  A narrow 256x256 net against the reference's forward: every 8th output pixel and
