@@ -33,6 +33,7 @@ struct Conv {
 struct Norm {
     const float *gamma = nullptr, *beta = nullptr;
     int C = 0;
+    float eps = 1e-5f;
 };
 struct Res {
     Norm n1, n2;
@@ -47,7 +48,15 @@ struct Attn {
     Conv qkv, proj;
     int C = 0, heads = 1;
 };
-enum Kind { K_CONV, K_RES, K_ATTN, K_DOWN, K_UP };
+// cond_type='cross_attention': SpatialTransformer (spatial_transformer.py:136-178) in place of AttentionBlock, depth 1
+struct Xf {
+    Norm norm;                                  // GroupNorm(32, C, eps 1e-6)
+    Conv proj_in, proj_out, qkv, out1, ff_in, ff_out;
+    const float *ln1_g = nullptr, *ln1_b = nullptr, *ln3_g = nullptr, *ln3_b = nullptr;
+    const float *v2_w = nullptr, *o2_w = nullptr, *o2_b = nullptr;   // attn2: to_v (C, E), to_out.0 (C, C) + bias
+    int C = 0, heads = 1;
+};
+enum Kind { K_CONV, K_RES, K_ATTN, K_DOWN, K_UP, K_XF };
 struct Layer {
     Kind kind;
     int idx;
@@ -64,6 +73,7 @@ struct Net {
     std::vector<Conv> convs;  // bare convs, down/up convs, proj convs
     std::vector<Res> res;
     std::vector<Attn> attn;
+    std::vector<Xf> xf;
     std::vector<Block> in_blocks, out_blocks, cond_blocks;
     Block middle;
     std::vector<int> proj_cond;  // conv index per control block
@@ -124,12 +134,17 @@ const float *lookup(Net &n, const std::string &name, int64_t expect) {
     return it->second.first;
 }
 
-Conv make_conv(Net &n, const std::string &p, int Cin, int Cout, int ks) {
+Conv make_conv_w(Net &n, const float *w, const float *bias, int Cin, int Cout, int ks);
+Conv make_conv(Net &n, const std::string &p, int Cin, int Cout, int ks, bool has_bias = true) {
+    const float *w = lookup(n, p + ".weight", (int64_t)Cout * Cin * ks * ks);
+    const float *b = has_bias ? lookup(n, p + ".bias", Cout) : nullptr;
+    return make_conv_w(n, w, b, Cin, Cout, ks);
+}
+Conv make_conv_w(Net &n, const float *w, const float *bias, int Cin, int Cout, int ks) {
     Conv c;
     c.Cin = Cin; c.Cin_pad = round_up(Cin, 16); c.Cout = Cout; c.ks = ks;
     const size_t fl = hl::conv_packed_floats(Cout, c.Cin_pad, ks);
-    const float *w = lookup(n, p + ".weight", (int64_t)Cout * Cin * ks * ks);
-    c.bias = lookup(n, p + ".bias", Cout);
+    c.bias = n.dry ? nullptr : bias;
     if (!n.dry && w) {
         float *dst = n.packed + n.packed_off;
         if (hl::conv_pack_weights(w, Cout, Cin, c.Cin_pad, ks, dst, n.st) != 0 && n.err.empty()) n.err = hl_last_error();
@@ -210,6 +225,39 @@ int add_attn(Net &n, const std::string &p, int C, int heads) {
     n.attn.push_back(a);
     return (int)n.attn.size() - 1;
 }
+int add_xf(Net &n, const std::string &p, int C, int heads) {
+    Xf a;
+    a.C = C; a.heads = heads;
+    a.norm = make_norm(n, p + ".norm", C);
+    a.norm.eps = 1e-6f;
+    a.proj_in = make_conv(n, p + ".proj_in", C, C, 1);
+    const std::string t = p + ".transformer_blocks.0";
+    // self-attention: to_q / to_k / to_v (no bias; output channel = head*d + c) stacked into ONE projection in the layout the attention
+    // kernel reads, channel = head*3d + {q,k,v}*d + c
+    const int d = C / heads;
+    const float *wq = lookup(n, t + ".attn1.to_q.weight", (int64_t)C * C), *wk = lookup(n, t + ".attn1.to_k.weight", (int64_t)C * C),
+                *wv = lookup(n, t + ".attn1.to_v.weight", (int64_t)C * C);
+    float *fused = n.dry ? nullptr : n.packed + n.packed_off;
+    n.packed_off += ((size_t)3 * C * C + 63) / 64 * 64;
+    if (!n.dry && wq && wk && wv) {
+        const float *src[3] = {wq, wk, wv};
+        for (int h = 0; h < heads; ++h)
+            for (int q = 0; q < 3; ++q)
+                hipMemcpyAsync(fused + ((size_t)h * 3 + q) * d * C, src[q] + (size_t)h * d * C, (size_t)d * C * sizeof(float), hipMemcpyDeviceToDevice, n.st);
+    }
+    a.qkv = make_conv_w(n, n.dry ? reinterpret_cast<const float *>(16) : fused, nullptr, C, 3 * C, 1);
+    a.out1 = make_conv(n, t + ".attn1.to_out.0", C, C, 1);
+    a.ln1_g = lookup(n, t + ".norm1.weight", C); a.ln1_b = lookup(n, t + ".norm1.bias", C);
+    a.ln3_g = lookup(n, t + ".norm3.weight", C); a.ln3_b = lookup(n, t + ".norm3.bias", C);
+    a.v2_w = lookup(n, t + ".attn2.to_v.weight", (int64_t)C * n.E);
+    a.o2_w = lookup(n, t + ".attn2.to_out.0.weight", (int64_t)C * C);
+    a.o2_b = lookup(n, t + ".attn2.to_out.0.bias", C);
+    a.ff_in = make_conv(n, t + ".ff.net.0.proj", C, 8 * C, 1);
+    a.ff_out = make_conv(n, t + ".ff.net.2", 4 * C, C, 1);
+    a.proj_out = make_conv(n, p + ".proj_out", C, C, 1);
+    n.xf.push_back(a);
+    return (int)n.xf.size() - 1;
+}
 int add_conv(Net &n, const std::string &p, int Cin, int Cout, int ks) {
     n.convs.push_back(make_conv(n, p, Cin, Cout, ks));
     return (int)n.convs.size() - 1;
@@ -238,7 +286,10 @@ void build_encoder(Net &n, std::vector<EmbPiece> &emb, const std::string &root, 
             const int co = c.channel_mult[level] * c.model_channels;
             b.layers.push_back({K_RES, add_res(n, emb, p + ".0", ch, co, aware)});
             ch = co;
-            if (has_ds(c, ds)) b.layers.push_back({K_ATTN, add_attn(n, p + ".1", ch, c.num_heads)});
+            if (has_ds(c, ds)) {
+                if (c.cross_attn) b.layers.push_back({K_XF, add_xf(n, p + ".1", ch, c.num_heads)});
+                else b.layers.push_back({K_ATTN, add_attn(n, p + ".1", ch, c.num_heads)});
+            }
             b.Cout = ch; b.ds_out = ds;
             blocks.push_back(b);
             chans.push_back(ch);
@@ -263,7 +314,7 @@ void build(Net &n) {
     n.Cpad0 = round_up(c.in_channels, 16);
     n.emb_total = 0;
     n.packed_off = 0;
-    n.convs.clear(); n.res.clear(); n.attn.clear();
+    n.convs.clear(); n.res.clear(); n.attn.clear(); n.xf.clear();
     n.in_blocks.clear(); n.out_blocks.clear(); n.cond_blocks.clear(); n.proj_cond.clear();
     std::vector<EmbPiece> emb;
     n.te0_w = lookup(n, "time_embed.0.weight", (int64_t)n.E * c.model_channels);
@@ -271,7 +322,7 @@ void build(Net &n) {
     n.te2_w = lookup(n, "time_embed.2.weight", (int64_t)n.E * n.E);
     n.te2_b = lookup(n, "time_embed.2.bias", n.E);
     n.label = c.num_classes > 0 ? lookup(n, "label_emb.weight", (int64_t)c.num_classes * n.E) : nullptr;
-    if (c.adagn) {
+    if (c.adagn || c.cross_attn) {
         n.ada1 = make_conv(n, "conv_proj_1", c.out_channels, 6, 3);
         n.ada2 = make_conv(n, "conv_proj_2", 6, 1, 3);
         n.ada_w = lookup(n, "linear.weight", (int64_t)n.E * 4096);
@@ -286,7 +337,8 @@ void build(Net &n) {
     {
         Block m;
         m.layers.push_back({K_RES, add_res(n, emb, "middle_block.0", ch, ch, aware)});
-        m.layers.push_back({K_ATTN, add_attn(n, "middle_block.1", ch, c.num_heads)});
+        if (c.cross_attn) m.layers.push_back({K_XF, add_xf(n, "middle_block.1", ch, c.num_heads)});
+        else m.layers.push_back({K_ATTN, add_attn(n, "middle_block.1", ch, c.num_heads)});
         m.layers.push_back({K_RES, add_res(n, emb, "middle_block.2", ch, ch, aware)});
         m.Cout = ch; m.ds_out = ds;
         n.middle = m;
@@ -303,7 +355,10 @@ void build(Net &n) {
             int li = 0;
             b.layers.push_back({K_RES, add_res(n, emb, p + "." + std::to_string(li++), ch + skip, co, aware)});
             ch = co;
-            if (has_ds(c, ds)) b.layers.push_back({K_ATTN, add_attn(n, p + "." + std::to_string(li++), ch, c.num_heads_upsample)});
+            if (has_ds(c, ds)) {
+                if (c.cross_attn) b.layers.push_back({K_XF, add_xf(n, p + "." + std::to_string(li++), ch, c.num_heads)});   // unet.py:463: num_heads
+                else b.layers.push_back({K_ATTN, add_attn(n, p + "." + std::to_string(li++), ch, c.num_heads_upsample)});
+            }
             if (level && i == c.num_res_blocks) {
                 b.layers.push_back({K_UP, add_conv(n, p + "." + std::to_string(li++) + ".conv", ch, ch, 3)});
                 ds /= 2;
@@ -346,6 +401,7 @@ struct Exec {
     hipStream_t st;
     int B, H, W;
     float *emb_all = nullptr;
+    const float *ctx = nullptr;    // cond_type='cross_attention': the context token (B, E)
     float *gn_scratch = nullptr;
     float *splitk_ws = nullptr;
     float *gn_scratch2 = nullptr, *splitk_ws2 = nullptr;   // second set for the side stream
@@ -438,8 +494,8 @@ struct Exec {
                     else nsrc = 0;
                 }
             }
-            if (nsrc) ok(hl::groupnorm_coef_stats(x, src, nsrc, g.gamma, g.beta, emb, n.emb_total, cA, cB, st));
-            else ok(hl::groupnorm_coef(x, g.gamma, g.beta, emb, n.emb_total, cA, cB, gn_scratch, st));
+            if (nsrc) ok(hl::groupnorm_coef_stats(x, src, nsrc, g.gamma, g.beta, emb, n.emb_total, cA, cB, st, g.eps));
+            else ok(hl::groupnorm_coef(x, g.gamma, g.beta, emb, n.emb_total, cA, cB, gn_scratch, st, nullptr, g.eps));
             span_end(CAT_GN, e0, 0.0);
         }
     }
@@ -494,6 +550,40 @@ struct Exec {
         }
         conv(a.proj, o, dst, 1, 0, nullptr, nullptr, 0, x.p, x.pitch);
     }
+    // SpatialTransformer (spatial_transformer.py:136-178, BasicTransformerBlock :115-134), depth 1, context = ONE token per image:
+    //   h = proj_in(GroupNorm(x));  h += to_out(self-attention(LayerNorm1(h)));  h += to_out2(to_v2(context))  [softmax over a single key
+    //   is 1, so norm2 / to_q / to_k of attn2 cannot act];  h += ff_out(GEGLU(ff_in(LayerNorm3(h))));  y = proj_out(h) + x
+    void xf_block(const Xf &a, const View &x, const View &dst) {
+        const int ds = H / x.H;
+        float *ca, *cb;
+        coef(x, a.norm, nullptr, ca, cb);
+        const bool ws_keep = want_stats;
+        want_stats = false;              // nothing in here feeds a GroupNorm
+        View h = plain(ds, a.C), ln = plain(ds, a.C), qkv = plain(ds, 3 * a.C), o = plain(ds, a.C), h1 = plain(ds, a.C);
+        View ln3 = plain(ds, a.C), f8 = plain(ds, 8 * a.C), f4 = plain(ds, 4 * a.C), h2 = plain(ds, a.C);
+        float *v2 = alloc((size_t)B * a.C), *r2 = alloc((size_t)B * a.C);
+        conv(a.proj_in, x, h, 1, 0, ca, cb, 0, nullptr, 0);
+        if (run) ok(hl::layernorm(h, a.ln1_g, a.ln1_b, ln.p, st));
+        conv(a.qkv, ln, qkv, 1, 0, nullptr, nullptr, 0, nullptr, 0);
+        if (run) {
+            const size_t e0 = span_begin();
+            ok(hl::attention(qkv.p, B, x.H * x.W, a.C, a.heads, o.p, st));
+            const double T = (double)x.H * x.W;
+            span_end(CAT_ATTN, e0, 4.0 * B * T * T * a.C);
+        }
+        conv(a.out1, o, h1, 1, 0, nullptr, nullptr, 0, h.p, h.pitch);
+        if (run) {
+            ok(hl::linear_small(ctx, n.E, B, n.E, a.v2_w, nullptr, a.C, 0, nullptr, nullptr, v2, a.C, st));
+            ok(hl::linear_small(v2, a.C, B, a.C, a.o2_w, a.o2_b, a.C, 0, nullptr, nullptr, r2, a.C, st));
+            ok(hl::add_rowvec(h1, r2, st));
+            ok(hl::layernorm(h1, a.ln3_g, a.ln3_b, ln3.p, st));
+        }
+        conv(a.ff_in, ln3, f8, 1, 0, nullptr, nullptr, 0, nullptr, 0);
+        if (run) ok(hl::geglu(f8.p, f8.pixels(), 4 * a.C, f4.p, st));
+        conv(a.ff_out, f4, h2, 1, 0, nullptr, nullptr, 0, h1.p, h1.pitch);
+        want_stats = ws_keep;
+        conv(a.proj_out, h2, dst, 1, 0, nullptr, nullptr, 0, x.p, x.pitch);
+    }
     // run one TimestepEmbedSequential; the last layer writes into dst
     void block(const Block &b, View x, const View &dst) {
         for (size_t i = 0; i < b.layers.size(); ++i) {
@@ -505,6 +595,7 @@ struct Exec {
                 case K_CONV: Cout = n.convs[L.idx].Cout; ds_out = ds_in; break;
                 case K_RES: Cout = n.res[L.idx].Cout; ds_out = ds_in; break;
                 case K_ATTN: Cout = n.attn[L.idx].C; ds_out = ds_in; break;
+                case K_XF: Cout = n.xf[L.idx].C; ds_out = ds_in; break;
                 case K_DOWN: Cout = n.convs[L.idx].Cout; ds_out = ds_in * 2; break;
                 default: Cout = n.convs[L.idx].Cout; ds_out = ds_in / 2; break;
             }
@@ -513,6 +604,7 @@ struct Exec {
                 case K_CONV: conv(n.convs[L.idx], x, y, 1, 0, nullptr, nullptr, 0, nullptr, 0); break;
                 case K_RES: res_block(n.res[L.idx], x, y); break;
                 case K_ATTN: attn_block(n.attn[L.idx], x, y); break;
+                case K_XF: xf_block(n.xf[L.idx], x, y); break;
                 case K_DOWN: conv(n.convs[L.idx], x, y, 2, 0, nullptr, nullptr, 0, nullptr, 0); break;
                 case K_UP: conv(n.convs[L.idx], x, y, 1, 1, nullptr, nullptr, 0, nullptr, 0); break;
             }
@@ -538,7 +630,7 @@ struct Exec {
         View ac, a1, a2;
         float *emb0 = nullptr;
         int64_t *iota = nullptr;
-        if (c.adagn) {
+        if (c.adagn || c.cross_attn) {
             ac.N = B; ac.H = H; ac.W = W; ac.C = round_up(c.out_channels, 16); ac.pitch = ac.C; ac.p = alloc((size_t)ac.pixels() * ac.C);
             a1.N = B; a1.H = H / 2; a1.W = W / 2; a1.C = 16; a1.pitch = 16; a1.p = alloc((size_t)a1.pixels() * 16);
             a2.N = B; a2.H = H / 4; a2.W = W / 4; a2.C = 1; a2.pitch = 1; a2.p = alloc((size_t)a2.pixels());
@@ -559,7 +651,9 @@ struct Exec {
             ok(hl::timestep_embedding(t, tf, B, c.model_channels, temb, st));
             ok(hl::linear_small(temb, c.model_channels, B, c.model_channels, n.te0_w, n.te0_b, n.E, 0, nullptr, nullptr, e1, n.E, st));
             ok(hl::linear_small(e1, n.E, B, n.E, n.te2_w, n.te2_b, n.E, 1, c.num_classes > 0 ? n.label : nullptr, y, c.adagn ? emb0 : emb, n.E, st));
+            ctx = emb0;
             if (c.adagn) ok(hl::linear_small(a2.p, 4096, B, 4096, n.ada_w, n.ada_b, n.E, 0, emb0, iota, emb, n.E, st));
+            if (c.cross_attn) ok(hl::linear_small(a2.p, 4096, B, 4096, n.ada_w, n.ada_b, n.E, 0, nullptr, nullptr, emb0, n.E, st));   // the context token (unet.py:579-582)
             ok(hl::linear_small(emb, n.E, B, n.E, n.emb_w, n.emb_b, (int)n.emb_total, 1, nullptr, nullptr, emb_all, n.emb_total, st));
             if (c.aware3d) ok(hl::prep_inputs_3d(x, c.controlnet ? x_cond : nullptr, B, c.in_channels, H, W / 3, n.Cpad0, xin.p,
                                                  c.controlnet ? xsum.p : nullptr, st));
@@ -652,7 +746,8 @@ int validate(const hl_unet_cfg *c) {
     HL_REQUIRE(c->model_channels % 32 == 0, "unet: model_channels must be a multiple of 32 (GroupNorm32)");
     HL_REQUIRE(c->in_channels > 0 && c->out_channels > 0 && c->num_res_blocks > 0 && c->num_heads > 0, "unet: bad cfg");
     HL_REQUIRE(!(c->controlnet && c->adagn), "unet: cond_type is either controlnet or AdaGN");
-    HL_REQUIRE(!(c->aware3d && c->adagn), "unet: use_3d_aware with cond_type='AdaGN' is not built");
+    HL_REQUIRE(!(c->aware3d && (c->adagn || c->cross_attn)), "unet: use_3d_aware with cond_type='AdaGN' / 'cross_attention' is not built");
+    HL_REQUIRE(c->controlnet + c->adagn + c->cross_attn <= 1, "unet: one cond_type");
     return 0;
 }
 
@@ -735,7 +830,8 @@ int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float 
     HL_REQUIRE(B >= 1 && B <= 16, "hl_unet_forward: batch %d outside [1,16]", B);
     HL_REQUIRE(H % total_ds == 0 && W % total_ds == 0, "hl_unet_forward: H,W must be divisible by %d", total_ds);
     HL_REQUIRE(!n.cfg.controlnet || x_cond, "hl_unet_forward: x_cond is required with cond_type='controlnet'");
-    HL_REQUIRE(!n.cfg.adagn || (x_cond && H == 256 && W == 256), "hl_unet_forward: cond_type='AdaGN' needs x_cond and 256x256 inputs (Linear(64*64, ..))");
+    HL_REQUIRE(!(n.cfg.adagn || n.cfg.cross_attn) || (x_cond && H == 256 && W == 256),
+               "hl_unet_forward: cond_type='AdaGN' / 'cross_attention' need x_cond and 256x256 inputs (Linear(64*64, ..))");
     HL_REQUIRE(n.cfg.num_classes == 0 || y, "hl_unet_forward: y is required for a class-conditional model");
     if (n.cfg.aware3d) W *= 3;                           // use_3d_aware: x is (B, 3*in_channels, H, W); the network runs on (B, in_channels, H, 3W)
     Exec dry{n, false, nullptr, 0, nullptr, B, H, W};   // sizes only (host work, no launches)

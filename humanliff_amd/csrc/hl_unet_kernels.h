@@ -73,10 +73,10 @@ size_t gn_scratch_floats(int N);
 // source 1 (decoder concats: the control branch's half) the rest; `slots` = ConvArgs::stat_slots of the producing launch
 struct StatSrc { const float *p; int Cn, slots; };
 int groupnorm_coef_stats(const View &x, const StatSrc *src, int nsrc, const float *gamma, const float *beta, const float *emb,
-                         long emb_pitch, float *coefA, float *coefB, hipStream_t st);
+                         long emb_pitch, float *coefA, float *coefB, hipStream_t st, float eps = 1e-5f);
 // gstat (optional): (N, 32, 2) = (mean, rstd) of every group, for the backward pass of the training path
 int groupnorm_coef(const View &x, const float *gamma, const float *beta, const float *emb, long emb_pitch, float *coefA,
-                   float *coefB, float *scratch, hipStream_t st, float *gstat = nullptr);
+                   float *coefB, float *scratch, hipStream_t st, float *gstat = nullptr, float eps = 1e-5f);
 
 // y (dense NHWC) = act ? silu(x*A + B) : x*A + B with the per-(n,c) affine of groupnorm_coef (the pre-pass of the DMA convs; the
 // GroupNorm forward of the training path)
@@ -95,6 +95,11 @@ int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipS
 int prep_inputs(const float *x, const float *x_cond, int B, int C, int H, int W, int Cpad, float *x_nhwc, float *xsum_nhwc,
                 hipStream_t st);
 
+// cond_type='cross_attention' (spatial_transformer.py): nn.LayerNorm over the channels of every pixel -> y dense (pixels, C); GEGLU on
+// (pixels, 2F) -> (pixels, F); x (N, HW, C) += v (N, C)
+int layernorm(const View &x, const float *gamma, const float *beta, float *y, hipStream_t st);
+int geglu(const float *in, long npix, int F, float *out, hipStream_t st);
+int add_rowvec(const View &x, const float *v, hipStream_t st);
 // use_3d_aware=True (unet.py:566-570, 613-614): (B, 3C, H, W) NCHW <-> the planes side by side, NHWC (B, H, 3W, Cpad) / NCHW (B, C, H, 3W)
 int prep_inputs_3d(const float *x, const float *x_cond, int B, int C, int H, int W, int Cpad, float *x_nhwc, float *xsum_nhwc,
                    hipStream_t st);

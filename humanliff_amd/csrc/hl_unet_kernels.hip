@@ -1758,7 +1758,7 @@ __global__ void k_pack_conv_bf3(const float *__restrict__ w, int Cout, int Cin, 
 // grid (nchunks, N); blockDim = (C/4) * k threads; thread owns one float4 channel column.
 __global__ void k_gn_partial(const float *__restrict__ x, long pitch, int HW, int C, int nchunks, float *__restrict__ partial,
                              const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ emb,
-                             long emb_pitch, float *__restrict__ cA, float *__restrict__ cB, float *__restrict__ gstat) {
+                             long emb_pitch, float *__restrict__ cA, float *__restrict__ cB, float *__restrict__ gstat, float eps) {
     extern __shared__ float sh[];  // [k][C] sums then [k][C] sumsq
     const int cq = C >> 2;
     const int k = blockDim.x / cq;
@@ -1810,7 +1810,7 @@ __global__ void k_gn_partial(const float *__restrict__ x, long pitch, int HW, in
         const double mean = (double)gs[g] / cnt;
         double var = (double)gs[32 + g] / cnt - mean * mean;
         var = var < 0.0 ? 0.0 : var;
-        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         float a = rstd * gamma[c];
         float b = beta[c] - (float)mean * a;
         if (emb) {
@@ -1831,7 +1831,7 @@ template <int V>
 __global__ __launch_bounds__(256) void k_gn_small(const float *__restrict__ x, long pitch, int HW, int C,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
                                                   const float *__restrict__ emb, long emb_pitch, float *__restrict__ cA,
-                                                  float *__restrict__ cB, float *__restrict__ gstat) {
+                                                  float *__restrict__ cB, float *__restrict__ gstat, float eps) {
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int cg = C / 32, per = cg / V;
     const float *base = x + (long)n * HW * pitch + g * cg;
@@ -1869,7 +1869,7 @@ __global__ __launch_bounds__(256) void k_gn_small(const float *__restrict__ x, l
     const double mean = ds / cnt;
     double var = dss / cnt - mean * mean;
     var = var < 0.0 ? 0.0 : var;
-    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     for (int j = tid; j < cg; j += 256) {
         const int c = g * cg + j;
         float a = rstd * gamma[c];
@@ -1891,7 +1891,7 @@ __global__ __launch_bounds__(256) void k_gn_small(const float *__restrict__ x, l
 __global__ __launch_bounds__(64) void k_gn_coef(const float *__restrict__ partial, int nchunks, int HW, int C,
                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                 const float *__restrict__ emb, long emb_pitch, float *__restrict__ cA,
-                                                float *__restrict__ cB, float *__restrict__ gstat) {
+                                                float *__restrict__ cB, float *__restrict__ gstat, float eps) {
     const int g = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
     const int cg = C / 32;
     double s = 0.0, ss = 0.0;
@@ -1909,7 +1909,7 @@ __global__ __launch_bounds__(64) void k_gn_coef(const float *__restrict__ partia
     const double mean = s / cnt;
     double var = ss / cnt - mean * mean;
     var = var < 0.0 ? 0.0 : var;
-    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     for (int j = lane; j < cg; j += 64) {
         const int c = g * cg + j;
         float a = rstd * gamma[c];
@@ -1932,7 +1932,7 @@ __global__ __launch_bounds__(64) void k_gn_coef(const float *__restrict__ partia
 struct StatSrcK { const float *p; int Cn, slots; };
 __global__ __launch_bounds__(256) void k_gn_coef_st(StatSrcK s0, StatSrcK s1, int HW, int C, const float *__restrict__ gamma,
                                                     const float *__restrict__ beta, const float *__restrict__ emb, long emb_pitch,
-                                                    float *__restrict__ cA, float *__restrict__ cB, float *__restrict__ gstat) {
+                                                    float *__restrict__ cA, float *__restrict__ cB, float *__restrict__ gstat, float eps) {
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int cg = C / 32, c_lo = g * cg, c_hi = c_lo + cg;
     double s = 0.0, ss = 0.0;
@@ -1965,7 +1965,7 @@ __global__ __launch_bounds__(256) void k_gn_coef_st(StatSrcK s0, StatSrcK s1, in
     const double mean = s / cnt;
     double var = ss / cnt - mean * mean;
     var = var < 0.0 ? 0.0 : var;
-    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     for (int j = tid; j < cg; j += 256) {
         const int c = c_lo + j;
         float a = rstd * gamma[c];
@@ -2317,6 +2317,47 @@ __global__ void k_prep_inputs(const float *__restrict__ x, const float *__restri
     }
 }
 
+// ---- cond_type='cross_attention' (spatial_transformer.py): LayerNorm over the channels of every token, GEGLU, a per-image row vector ----
+// y (npix, C dense) = (x - mean) * rstd * gamma + beta per pixel (nn.LayerNorm(C), eps 1e-5); one wave per pixel
+__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, long pitch, long npix, int C, const float *__restrict__ gamma,
+                                                   const float *__restrict__ beta, float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= npix) return;
+    const float *xp = x + pix * pitch;
+    float sm = 0.f;
+    for (int c = lane; c < C; c += 64) sm += xp[c];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sm += __shfl_xor(sm, d);
+    const float mean = sm / (float)C;
+    float sq = 0.f;
+    for (int c = lane; c < C; c += 64) { const float dv = xp[c] - mean; sq = fmaf(dv, dv, sq); }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sq += __shfl_xor(sq, d);
+    const float rstd = 1.f / sqrtf(sq / (float)C + 1e-5f);
+    for (int c = lane; c < C; c += 64) y[pix * C + c] = fmaf((xp[c] - mean) * rstd, gamma[c], beta[c]);
+}
+// GEGLU (spatial_transformer.py:37-44): in (npix, 2F) = [x | gate] -> out (npix, F) = x * gelu(gate), the exact (erf) GELU
+__global__ void k_geglu(const float *__restrict__ in, long npix, int F, float *__restrict__ out) {
+    const long n = npix * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / F;
+        const int f = (int)(i - pix * F);
+        const float a = in[pix * 2 * F + f], g = in[pix * 2 * F + F + f];
+        out[i] = a * (0.5f * g * (1.f + erff(g * 0.70710678118654752f)));
+    }
+}
+// x (N, HW, C pitch) += v (N, C): the cross-attention over ONE context token (softmax over a single key is 1: the output is the same
+// projected value vector at every query)
+__global__ void k_add_rowvec(float *__restrict__ x, long pitch, long HW, long npix, int C, const float *__restrict__ v) {
+    const long n = npix * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C;
+        const int c = (int)(i - pix * C);
+        x[pix * pitch + c] += v[(pix / HW) * C + c];
+    }
+}
+
 // ---- use_3d_aware=True (unet.py:566-570, 208-214, 613-614): the three planes of a tri-plane sit side by side, (B, C/3, H, 3W) ----
 // (B, 3C, H, W) NCHW -> rolled NHWC (B, H, 3W, Cpad): pixel (y, p*W + x) channel c <- channel p*C + c; xs = x + x_cond likewise
 __global__ void k_prep_inputs_3d(const float *__restrict__ x, const float *__restrict__ xc, int B, int C, int H, int W, int Cpad,
@@ -2659,7 +2700,7 @@ static int gn_chunks(int HW, int C) {
 size_t gn_scratch_floats(int N) { return (size_t)N * 128 * 32 * 2; }
 
 int groupnorm_coef(const View &x, const float *gamma, const float *beta, const float *emb, long emb_pitch, float *cA, float *cB,
-                   float *scratch, hipStream_t st, float *gstat) {
+                   float *scratch, hipStream_t st, float *gstat, float eps) {
     HL_REQUIRE(x.p && gamma && beta && cA && cB && scratch, "groupnorm_coef: null argument");
     HL_REQUIRE(x.C % 32 == 0, "GroupNorm32 needs C %% 32 == 0 (C=%d)", x.C);
     const int HW = x.H * x.W, cq = x.C / 4;
@@ -2668,11 +2709,11 @@ int groupnorm_coef(const View &x, const float *gamma, const float *beta, const f
         const int cg = x.C / 32;
         dim3 grid(32, x.N);
         if (cg % 4 == 0 && ((uintptr_t)x.p % 16) == 0 && x.pitch % 4 == 0)
-            hipLaunchKernelGGL(k_gn_small<4>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat);
+            hipLaunchKernelGGL(k_gn_small<4>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat, eps);
         else if (cg % 2 == 0 && ((uintptr_t)x.p % 8) == 0 && x.pitch % 2 == 0)
-            hipLaunchKernelGGL(k_gn_small<2>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat);
+            hipLaunchKernelGGL(k_gn_small<2>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat, eps);
         else
-            hipLaunchKernelGGL(k_gn_small<1>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat);
+            hipLaunchKernelGGL(k_gn_small<1>, grid, dim3(256), 0, st, x.p, x.pitch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat, eps);
         return check_launch("k_gn_small");
     }
     int k = (nch == 1 ? 1024 : 512) / cq;
@@ -2681,10 +2722,10 @@ int groupnorm_coef(const View &x, const float *gamma, const float *beta, const f
     const int threads = cq * k > 64 ? cq * k : 64;
     const size_t shm = (size_t)2 * k * x.C * sizeof(float);
     hipLaunchKernelGGL(k_gn_partial, dim3(nch, x.N), dim3(threads), shm, st, x.p, x.pitch, HW, x.C, nch, scratch, gamma, beta, emb,
-                       emb_pitch, cA, cB, gstat);
+                       emb_pitch, cA, cB, gstat, eps);
     int rc = check_launch("k_gn_partial");
     if (rc || nch == 1) return rc;
-    hipLaunchKernelGGL(k_gn_coef, dim3(32, x.N), dim3(64), 0, st, scratch, nch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat);
+    hipLaunchKernelGGL(k_gn_coef, dim3(32, x.N), dim3(64), 0, st, scratch, nch, HW, x.C, gamma, beta, emb, emb_pitch, cA, cB, gstat, eps);
     return check_launch("k_gn_coef");
 }
 
@@ -2697,14 +2738,14 @@ int gn_apply(const View &x, const float *cA, const float *cB, int act, float *y,
 }
 
 int groupnorm_coef_stats(const View &x, const StatSrc *src, int nsrc, const float *gamma, const float *beta, const float *emb,
-                         long emb_pitch, float *cA, float *cB, hipStream_t st) {
+                         long emb_pitch, float *cA, float *cB, hipStream_t st, float eps) {
     HL_REQUIRE(src && (nsrc == 1 || nsrc == 2) && gamma && beta && cA && cB, "groupnorm_coef_stats: bad argument");
     HL_REQUIRE(x.C % 32 == 0, "GroupNorm32 needs C %% 32 == 0 (C=%d)", x.C);
     HL_REQUIRE(src[0].Cn + (nsrc == 2 ? src[1].Cn : 0) == x.C, "groupnorm_coef_stats: the statistics cover %d of %d channels",
                src[0].Cn + (nsrc == 2 ? src[1].Cn : 0), x.C);
     StatSrcK s0{src[0].p, src[0].Cn, src[0].slots}, s1{nullptr, 0, 0};
     if (nsrc == 2) s1 = StatSrcK{src[1].p, src[1].Cn, src[1].slots};
-    hipLaunchKernelGGL(k_gn_coef_st, dim3(32, x.N), dim3(256), 0, st, s0, s1, x.H * x.W, x.C, gamma, beta, emb, emb_pitch, cA, cB, nullptr);
+    hipLaunchKernelGGL(k_gn_coef_st, dim3(32, x.N), dim3(256), 0, st, s0, s1, x.H * x.W, x.C, gamma, beta, emb, emb_pitch, cA, cB, nullptr, eps);
     return check_launch("k_gn_coef_st");
 }
 
@@ -2774,6 +2815,29 @@ int prep_inputs(const float *x, const float *xc, int B, int C, int H, int W, int
     HL_REQUIRE(x && xo && Cpad >= C, "prep_inputs: bad argument");
     hipLaunchKernelGGL(k_prep_inputs, dim3(2048), dim3(256), 0, st, x, xc, B, C, H * W, Cpad, xo, xs);
     return check_launch("k_prep_inputs");
+}
+
+int layernorm(const View &x, const float *gamma, const float *beta, float *y, hipStream_t st) {
+    HL_REQUIRE(x.p && gamma && beta && y, "layernorm: null argument");
+    const long npix = x.pixels();
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, x.p, x.pitch, npix, x.C, gamma, beta, y);
+    return check_launch("k_layernorm");
+}
+
+int geglu(const float *in, long npix, int F, float *out, hipStream_t st) {
+    HL_REQUIRE(in && out, "geglu: null argument");
+    long g = (npix * F + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_geglu, dim3((unsigned)g), dim3(256), 0, st, in, npix, F, out);
+    return check_launch("k_geglu");
+}
+
+int add_rowvec(const View &x, const float *v, hipStream_t st) {
+    HL_REQUIRE(x.p && v, "add_rowvec: null argument");
+    long g = ((long)x.pixels() * x.C + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_add_rowvec, dim3((unsigned)g), dim3(256), 0, st, x.p, x.pitch, (long)x.H * x.W, (long)x.pixels(), x.C, v);
+    return check_launch("k_add_rowvec");
 }
 
 int prep_inputs_3d(const float *x, const float *xc, int B, int C, int H, int W, int Cpad, float *xo, float *xs, hipStream_t st) {

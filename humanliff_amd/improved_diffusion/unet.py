@@ -4,8 +4,8 @@
 The torch modules declared here only own the parameters (so reference checkpoints load with
 load_state_dict and .to(device) works).  forward() hands the parameter pointers to the C ABI
 (hl_unet_create / hl_unet_forward); there is no PyTorch implementation of the math and no CPU path.
-Supported configuration: dims=2, use_scale_shift_norm=True, cond_type in {"controlnet", "AdaGN", "concat", ""},
-use_3d_aware False or True (sampling only; not with AdaGN).  Under no_grad / eval() forward() is the fused inference path; with gradients enabled on a model in training
+Supported configuration: dims=2, use_scale_shift_norm=True, cond_type in {"controlnet", "AdaGN", "cross_attention", "concat", ""},
+use_3d_aware False or True (sampling only; not with AdaGN / cross_attention).  Under no_grad / eval() forward() is the fused inference path; with gradients enabled on a model in training
 mode it is the differentiable path of unet_train.py (HIP forward and backward kernels behind autograd.Functions).
 """
 import ctypes as C
@@ -75,7 +75,59 @@ class AttentionBlock(nn.Module):
         self.proj_out = zero_module(conv_nd(1, channels, channels, 1))
 
 
-def _encoder(in_channels, mc, channel_mult, num_res_blocks, attention_resolutions, emb_dim, dropout, dims, heads, aware=False):
+class _GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class _FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(_GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim))
+
+
+class _CrossAttention(nn.Module):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        inner = dim_head * heads
+        self.heads, self.scale = heads, dim_head ** -0.5
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim or query_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim or query_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(0.0))
+
+
+class _BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, d_head, context_dim=None):
+        super().__init__()
+        self.attn1 = _CrossAttention(dim, heads=n_heads, dim_head=d_head)
+        self.ff = _FeedForward(dim)
+        self.attn2 = _CrossAttention(dim, context_dim=context_dim, heads=n_heads, dim_head=d_head)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+
+
+class SpatialTransformer(nn.Module):
+    """Parameter holder with the reference's layout (spatial_transformer.py:136-178); the math runs in hl_unet_forward."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None):
+        super().__init__()
+        if depth != 1 or dropout != 0:
+            raise NotImplementedError("SpatialTransformer: depth 1, dropout 0 (the reference's defaults)")
+        self.in_channels, self.n_heads, self.d_head = in_channels, n_heads, d_head
+        inner = n_heads * d_head
+        assert inner == in_channels, "unet.py builds it with d_head = ch // num_heads"
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([_BasicTransformerBlock(inner, n_heads, d_head, context_dim=context_dim)])
+        self.proj_out = zero_module(nn.Conv2d(inner, in_channels, 1))
+
+
+def _attn_layer(ch, heads, xf_ctx):
+    return SpatialTransformer(ch, heads, ch // heads, context_dim=xf_ctx) if xf_ctx else AttentionBlock(ch, num_heads=heads)
+
+
+def _encoder(in_channels, mc, channel_mult, num_res_blocks, attention_resolutions, emb_dim, dropout, dims, heads, aware=False, xf_ctx=None):
     """Block list of one encoder tower + its per-block channel counts (unet.py:375-415 / 477-518)."""
     blocks = [TimestepEmbedSequential(conv_nd(dims, in_channels, mc, 3, padding=1))]
     chans, ch, ds = [mc], mc, 1
@@ -84,7 +136,7 @@ def _encoder(in_channels, mc, channel_mult, num_res_blocks, attention_resolution
             layers = [ResBlock(ch, emb_dim, dropout, out_channels=mult * mc, dims=dims, use_scale_shift_norm=True, use_3d_aware=aware)]
             ch = mult * mc
             if ds in attention_resolutions:
-                layers.append(AttentionBlock(ch, num_heads=heads))
+                layers.append(_attn_layer(ch, heads, xf_ctx))
             blocks.append(TimestepEmbedSequential(*layers))
             chans.append(ch)
         if level != len(channel_mult) - 1:
@@ -102,11 +154,12 @@ class UNetModel(nn.Module):
         super().__init__()
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
-        if dims != 2 or not conv_resample or not use_scale_shift_norm or cond_type not in ("controlnet", "", "concat", "AdaGN") or \
-                (use_3d_aware and cond_type == "AdaGN"):
+        if dims != 2 or not conv_resample or not use_scale_shift_norm or cond_type not in ("controlnet", "", "concat", "AdaGN", "cross_attention") or \
+                (use_3d_aware and cond_type in ("AdaGN", "cross_attention")):
             raise NotImplementedError(
                 "the MI355X build covers dims=2, conv_resample=True, use_scale_shift_norm=True, cond_type in {'controlnet', '', 'concat', "
-                "'AdaGN'}, use_3d_aware with every cond_type but 'AdaGN' (the shipped HumanLiff configuration is controlnet, use_3d_aware=False)")
+                "'AdaGN', 'cross_attention'}, use_3d_aware with 'controlnet' / '' / 'concat' (the shipped HumanLiff configuration is controlnet, "
+                "use_3d_aware=False)")
         if dropout != 0:
             raise NotImplementedError("dropout > 0 is a training feature; inference build only")
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
@@ -121,12 +174,15 @@ class UNetModel(nn.Module):
         self.time_embed = nn.Sequential(linear(model_channels, emb_dim), SiLU(), linear(emb_dim, emb_dim))
         if num_classes is not None:
             self.label_emb = nn.Embedding(num_classes, emb_dim)
+        xf_ctx = emb_dim if cond_type == "cross_attention" else None      # unet.py:364: context_dim = model_channels * 4
+        if transformer_depth != 1:
+            raise NotImplementedError("transformer_depth != 1")
         enc, chans, ch, ds = _encoder(in_channels, model_channels, self.channel_mult, num_res_blocks,
-                                      self.attention_resolutions, emb_dim, dropout, dims, num_heads, aware=use_3d_aware)
+                                      self.attention_resolutions, emb_dim, dropout, dims, num_heads, aware=use_3d_aware, xf_ctx=xf_ctx)
         self.input_blocks = nn.ModuleList(enc)
         self.middle_block = TimestepEmbedSequential(
             ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=True, use_3d_aware=use_3d_aware),
-            AttentionBlock(ch, num_heads=num_heads),
+            _attn_layer(ch, num_heads, xf_ctx),
             ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=True, use_3d_aware=use_3d_aware))
         self.output_blocks = nn.ModuleList([])
         stack = list(chans)
@@ -136,7 +192,7 @@ class UNetModel(nn.Module):
                                    use_scale_shift_norm=True, use_3d_aware=use_3d_aware)]
                 ch = model_channels * mult
                 if ds in self.attention_resolutions:
-                    layers.append(AttentionBlock(ch, num_heads=num_heads_upsample))
+                    layers.append(_attn_layer(ch, num_heads, xf_ctx) if xf_ctx else AttentionBlock(ch, num_heads=num_heads_upsample))
                 if level and i == num_res_blocks:
                     layers.append(Upsample(ch, True, dims=dims))
                     ds //= 2
@@ -149,7 +205,7 @@ class UNetModel(nn.Module):
             self.input_blocks_cond = nn.ModuleList(cenc)
             self.input_blocks_proj_cond = nn.ModuleList(
                 [zero_module(conv_nd(dims, c, c, 1, padding=0)) for c in cchans])
-        elif cond_type == "AdaGN":      # unet.py:519-525: the condition becomes one more summand of the timestep embedding
+        elif cond_type in ("AdaGN", "cross_attention"):   # unet.py:519-525: the condition becomes one more summand of the timestep embedding / the context token
             self.conv_proj_1 = conv_nd(dims, self.out_channels, 6, 3, padding=1, stride=2)
             self.conv_proj_2 = conv_nd(dims, 6, 1, 3, padding=1, stride=2)
             self.linear = nn.Linear(64 * 64, emb_dim)
@@ -183,6 +239,7 @@ class UNetModel(nn.Module):
         c.num_classes = self.num_classes or 0
         c.controlnet = 1 if self.cond_type == "controlnet" else 0
         c.adagn = 1 if self.cond_type == "AdaGN" else 0
+        c.cross_attn = 1 if self.cond_type == "cross_attention" else 0
         c.aware3d = 1 if self.use_3d_aware else 0
         return c
 
@@ -267,7 +324,7 @@ class UNetModel(nn.Module):
         """Same contract as the reference: x (N,C,H,W), timesteps (N,), x_cond (N,C,H,W), y (N,) -> (N,C_out,H,W)."""
         if self.num_classes is not None:
             assert y is not None and y.shape == (x.shape[0],)
-        if self.cond_type in ("controlnet", "AdaGN"):
+        if self.cond_type in ("controlnet", "AdaGN", "cross_attention"):
             assert x_cond is not None, f"cond_type='{self.cond_type}' needs x_cond (zeros for the first layer)"
         if self.cond_type == "concat":        # unet.py:572-573: the condition rides along as extra input channels (in_channels counts both)
             assert x_cond is not None, "cond_type='concat' needs x_cond"
@@ -278,8 +335,8 @@ class UNetModel(nn.Module):
             # training call (train_util.py:236 reaches this through the DDP wrapper): gradients are wanted, take the differentiable path -
             # the same network as a chain of autograd.Functions whose forward and backward are HIP kernels (unet_train.py).
             # Sampling never gets here: the loops run under no_grad and the scripts call model.eval()
-            if self.use_3d_aware:
-                raise NotImplementedError("the HIP training path does not cover use_3d_aware=True (sampling does)")
+            if self.use_3d_aware or self.cond_type == "cross_attention":
+                raise NotImplementedError("the HIP training path does not cover use_3d_aware=True / cond_type='cross_attention' (sampling does)")
             from .unet_train import forward_train
             return forward_train(self, x, timesteps, x_cond, y)
         handle = self._bind()

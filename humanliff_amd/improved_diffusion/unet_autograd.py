@@ -61,10 +61,38 @@ def _attention(m, x):
     return (xf + m.proj_out(a)).reshape(b, c, hh, ww)
 
 
-def _run(seq, h, emb):
+def _xattn(a, x, context):
+    """CrossAttention.forward (spatial_transformer.py:86-112), no mask."""
+    ctx = x if context is None else context
+    q, k, v = a.to_q(x), a.to_k(ctx), a.to_v(ctx)
+    b, nq, _ = q.shape
+    sp = lambda t: t.reshape(b, t.shape[1], a.heads, -1).permute(0, 2, 1, 3).reshape(b * a.heads, t.shape[1], -1)  # noqa: E731
+    q, k, v = sp(q), sp(k), sp(v)
+    w = th.softmax(th.einsum("bid,bjd->bij", q, k) * a.scale, dim=-1)
+    o = th.einsum("bij,bjd->bid", w, v).reshape(b, a.heads, nq, -1).permute(0, 2, 1, 3).reshape(b, nq, -1)
+    return a.to_out[0](o)
+
+
+def _spatial_transformer(m, x, context):
+    """SpatialTransformer.forward (spatial_transformer.py:165-178) with its BasicTransformerBlock (:128-134)."""
+    b, c, hh, ww = x.shape
+    h = m.proj_in(F.group_norm(x.float(), 32, m.norm.weight, m.norm.bias, m.norm.eps))
+    h = h.reshape(b, c, hh * ww).permute(0, 2, 1)
+    for blk in m.transformer_blocks:
+        h = _xattn(blk.attn1, blk.norm1(h), None) + h
+        h = _xattn(blk.attn2, blk.norm2(h), context) + h
+        u, gate = blk.ff.net[0].proj(blk.norm3(h)).chunk(2, dim=-1)
+        h = blk.ff.net[2](u * F.gelu(gate)) + h
+    h = h.permute(0, 2, 1).reshape(b, c, hh, ww)
+    return m.proj_out(h) + x
+
+
+def _run(seq, h, emb, context=None):
     for m in seq:
         if isinstance(m, U.ResBlock):
             h = _res_block(m, h, emb)
+        elif isinstance(m, U.SpatialTransformer):
+            h = _spatial_transformer(m, h, context)
         elif isinstance(m, U.AttentionBlock):
             h = _attention(m, h)
         elif isinstance(m, U.Downsample):
@@ -83,10 +111,15 @@ def forward_autograd(model, x, timesteps, x_cond=None, y=None):
     if model.cond_type == "concat":          # unet.py:572-573
         x, x_cond = th.cat([x, x_cond], dim=1), None
     emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
-    if model.cond_type == "AdaGN":           # unet.py:574-578 (like the embedding MLP: three tiny torch modules, autograd's own backward)
-        assert x_cond is not None, "cond_type='AdaGN' needs x_cond"
+    context = None
+    if model.cond_type in ("AdaGN", "cross_attention"):   # unet.py:574-582
+        assert x_cond is not None, f"cond_type='{model.cond_type}' needs x_cond"
         xp = model.conv_proj_2(model.conv_proj_1(x_cond.float()))
-        emb = emb + model.linear(xp.reshape(xp.shape[0], -1))
+        xp = model.linear(xp.reshape(xp.shape[0], -1))
+        if model.cond_type == "AdaGN":
+            emb = emb + xp
+        else:
+            context = xp.unsqueeze(1)
     if model.num_classes is not None:
         emb = emb + model.label_emb(y)
     aware = getattr(model, "use_3d_aware", False)
@@ -98,9 +131,9 @@ def forward_autograd(model, x, timesteps, x_cond=None, y=None):
     hs = []
     h = x.float()
     for blk in model.input_blocks:
-        h = _run(blk, h, emb)
+        h = _run(blk, h, emb, context)
         hs.append(h)
-    h = _run(model.middle_block, h, emb)
+    h = _run(model.middle_block, h, emb, context)
     if model.cond_type == "controlnet":
         assert x_cond is not None, "cond_type='controlnet' needs x_cond (zeros for the first layer)"
         hs_cond = []
@@ -112,7 +145,7 @@ def forward_autograd(model, x, timesteps, x_cond=None, y=None):
         skip = hs.pop()
         if model.cond_type == "controlnet":
             skip = skip + hs_cond.pop()
-        h = _run(blk, th.cat([h, skip], dim=1), emb)
+        h = _run(blk, th.cat([h, skip], dim=1), emb, context)
     h = model.out[2](_silu(_norm(model.out[0], h)))
     if aware:                                # unet.py:613-614
         w3 = h.shape[-1] // 3

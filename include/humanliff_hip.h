@@ -240,7 +240,7 @@ int hl_render_rays_canonical(const void *mlp_packed, const void *planes_packed, 
 
 /* Architecture hyper-parameters, as UNetModel.__init__ receives them
  * (human_diffusion/improved_diffusion/unet.py:323-343, built by script_util.py:98-150).
- * Supported: dims=2, use_scale_shift_norm=True, cond_type="controlnet", "AdaGN", "concat" (a wider in_channels) or "", dropout=0,
+ * Supported: dims=2, use_scale_shift_norm=True, cond_type="controlnet", "AdaGN", "cross_attention", "concat" (a wider in_channels) or "", dropout=0,
  * conv_resample=True; use_3d_aware False (the shipped configuration) or True (not with AdaGN). */
 typedef struct hl_unet_cfg {
     int in_channels, model_channels, out_channels, num_res_blocks;
@@ -252,6 +252,8 @@ typedef struct hl_unet_cfg {
     int num_classes;            /* 0: not class conditional */
     int controlnet;             /* 1: cond_type == "controlnet" */
     int adagn;                  /* 1: cond_type == "AdaGN" (x_cond projected to one more summand of the timestep embedding) */
+    int cross_attn;             /* 1: cond_type == "cross_attention": SpatialTransformer blocks (spatial_transformer.py, depth 1) in place of the
+                                 * AttentionBlocks, attending to one context token per image = the AdaGN projection of x_cond */
     int aware3d;                /* 1: use_3d_aware: x, x_cond and the output are (B, 3*in_channels, H, W) tri-planes; the network runs on
                                  * the three planes side by side, (B, in_channels, H, 3W), and every ResBlock of the main towers feeds
                                  * each plane the axis means of the other two (unet.py:208-214, 566-570, 613-614) */

@@ -109,6 +109,27 @@ def unet_concat():
     out["adagn_nkeys"] = len(ks)
     out["adagn_cond_effect"] = float((y - y0).abs().max())       # the condition matters (the projection is not a no-op)
     print("AdaGN keys", len(ks), "out abs mean", float(y.abs().mean()), "effect of x_cond", out["adagn_cond_effect"])
+    # cond_type='cross_attention' (unet.py:404-405, 427, 463, 579-582; spatial_transformer.py): SpatialTransformer blocks attending to one
+    # context token = the same projection of x_cond; the narrow 256x256 net again
+    a = model_and_diffusion_defaults()
+    a.update(dict(in_channels=27, out_channels=27, class_cond=True, learn_sigma=False, num_heads=2, use_scale_shift_norm=True,
+                  cond_type="cross_attention", rescale_timesteps=False, dropout=0.0, image_size=256, num_channels=32, num_res_blocks=1,
+                  attention_resolutions="32,16,8"))
+    model, _ = create_model_and_diffusion(**a)
+    model.eval()
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn((1, 27, 256, 256), generator=g)
+    xc = torch.randn((1, 27, 256, 256), generator=g).clamp(-1, 1) * 0.7
+    with torch.no_grad():
+        y = model(x, torch.tensor([412]), xc, y=torch.tensor([2]))
+        y0 = model(x, torch.tensor([412]), torch.zeros_like(xc), y=torch.tensor([2]))
+    out["xattn_out_s8"] = y[:, :, ::8, ::8].numpy()
+    out["xattn_sums"] = np.array([float(y.double().sum()), float(y.double().abs().sum())])
+    out["xattn_nkeys"] = len(ks)
+    out["xattn_cond_effect"] = float((y - y0).abs().max())
+    print("cross_attention keys", len(ks), "out abs mean", float(y.abs().mean()), "effect of x_cond", out["xattn_cond_effect"])
     # use_3d_aware=True (unet.py:158-166, 208-214, 566-570, 613-614): 27-channel tri-planes, a 9-channel network on the planes side by
     # side; with the control tower (whose ResBlocks stay plain, :477-518) and without conditioning
     for tag, cond in (("aware3d_controlnet", "controlnet"), ("aware3d_plain", "")):

@@ -365,6 +365,36 @@ def test_unet_3d_aware_matches_reference(tag, cond):
     assert out.shape == (2, 27, 32, 32) and torch.isfinite(out).all()
 
 
+def test_unet_cross_attention_matches_reference():
+    """cond_type='cross_attention' (unet.py:404-405, 579-582; spatial_transformer.py:136-178): SpatialTransformer blocks (GroupNorm eps
+    1e-6, 1x1 projections, LayerNorm, self-attention, cross-attention to ONE context token = the projection of x_cond, GEGLU feed-forward)
+    in place of the AttentionBlocks.  Narrow 256x256 net against the reference's forward, every 8th pixel + the sums over all."""
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+    g = np.load(os.path.join(GOLDEN, "unet_cond_types.npz"))
+    a = model_and_diffusion_defaults()
+    a.update(dict(in_channels=27, out_channels=27, class_cond=True, learn_sigma=False, num_heads=2, use_scale_shift_norm=True,
+                  cond_type="cross_attention", rescale_timesteps=False, dropout=0.0, image_size=256, num_channels=32, num_res_blocks=1,
+                  attention_resolutions="32,16,8"))
+    model, _ = create_model_and_diffusion(**a)
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert len(ks) == int(g["xattn_nkeys"])
+    model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+    model = model.to(dev).eval()
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn((1, 27, 256, 256), generator=gen)
+    xc = torch.randn((1, 27, 256, 256), generator=gen).clamp(-1, 1) * 0.7
+    t, yl = torch.tensor([412], device=dev), torch.tensor([2], device=dev)
+    with torch.no_grad():
+        y = model(x.to(dev), t, xc.to(dev), y=yl).cpu()
+        y0 = model(x.to(dev), t, torch.zeros_like(xc).to(dev), y=yl).cpu()
+        tw = model.forward_autograd(x.to(dev), t, xc.to(dev), y=yl).cpu()
+    assert (y[:, :, ::8, ::8] - torch.from_numpy(g["xattn_out_s8"])).abs().max() < 1e-4
+    n = y.numel()
+    assert abs(float(y.double().sum()) - g["xattn_sums"][0]) < 2e-5 * n and abs(float(y.double().abs().sum()) - g["xattn_sums"][1]) < 2e-5 * n
+    assert abs(float((y - y0).abs().max()) - float(g["xattn_cond_effect"])) < 1e-3 and float(g["xattn_cond_effect"]) > 1e-3
+    assert (tw - y).abs().max() < 1e-4
+
+
 def test_unet_adagn_matches_reference():
     """cond_type='AdaGN' (unet.py:519-525, 574-578): x_cond -> conv 3x3 s2 -> conv 3x3 s2 -> Linear(64*64, E) added to the timestep
     embedding; 1000 classes (script_util.py:130).  A narrow 256x256 net against the reference's forward: every 8th output pixel and
