@@ -56,11 +56,17 @@ def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("HL_BENCH_BACKEND", "nccl")    # "gloo": rehearsal of the N > 1 code path with all ranks on one GPU (no RCCL there)
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     return rank, local, world
 
 
