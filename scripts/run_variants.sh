@@ -8,6 +8,6 @@ for v in "$@"; do
   cp humanliff_amd/exp/lib_$v.so humanliff_amd/libhumanliff_hip.so
   rm -rf gpurun_out/var_$v
   timeout 90 rocprofv3 --kernel-trace -d gpurun_out/var_$v -o w -- python $probe > gpurun_out/var_$v.log 2>&1
-  echo "$v rc=$? : $(python scripts/rocpd_list.py gpurun_out/var_$v k_conv_wino4 2>/dev/null | grep -v pack | awk '{print $1}' | tr '\n' ' ')"
+  echo "$v rc=$? : $(python scripts/rocpd_list.py gpurun_out/var_$v ${KPAT:-k_conv_wino4} 2>/dev/null | grep -v pack | awk '{print $1}' | tr '\n' ' ')"
 done
 cp /tmp/lib_keep.so humanliff_amd/libhumanliff_hip.so
