@@ -975,7 +975,7 @@ __device__ __forceinline__ void w4_out(f32x2 m0, f32x2 m1, f32x2 m2, f32x2 m3, f
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool UPS>
+template <bool UPS, bool BLK>
 __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__   // device pass only (see k_conv_bf3)
     constexpr int PRW = 36, PROWS = 18, P_REAL = 2 * PROWS * PRW, NP = (P_REAL + 63) / 64, P_F = P_REAL * 4;   // patch: pixels / row, rows, chunks, DMAs, floats
@@ -995,7 +995,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
     const int img = tb / (bw * bh), brem = tb - img * (bw * bh);
     const int y0 = (brem / bw) * 16, x0 = (brem - (brem / bw) * bw) * 32;
     const int nkt = p.Cin >> 3;
-    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+    // BLK: the input is the channel-blocked copy k_gn_apply_blk wrote, [Cin/8][pixel][8]: a k-tile's 8 channels of a pixel are 32 bytes, the
+    // pixels of an image row follow each other, a k-tile is a plane of kstep bytes.  Otherwise NHWC: 32 bytes at a pitch of Cin*4.
+    static_assert(!(UPS && BLK), "the upsampling convolution reads a raw NHWC tensor");
+    const unsigned pitch4 = BLK ? 32u : (unsigned)p.in_pitch * 4u;
+    const int kstep = BLK ? (int)(p.M * 32) : 32;
     const int kt0 = blockIdx.z * p.kt_per;                        // split-K over input channels: this slab's k-tiles
     const int ntiles = min(nkt, kt0 + p.kt_per) - kt0;
 
@@ -1017,19 +1021,34 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
             const int c = (W + 4 * j) * 64 + lane;                    // patch chunk: lanes 2i, 2i+1 fetch the two halves of one pixel
-            const int pixp = c >> 1, row = pixp / PRW, q = pixp - row * PRW, h = (c & 1) ^ ((row >> 2) & 1);
-            const int col = (q % 9) * 4 + q / 9;
+            int row, col, h;
+            if (BLK) {   // eight lanes = the four pixels 4g..4g+3 of a row = 128 contiguous bytes, order inside the group swizzled
+                row = c / 72;
+                const int g = (c - row * 72) >> 3, kk = (c & 7) ^ ((((g >> 1) & 1) << 2) | ((row >> 2) & 3));
+                col = 4 * g + (kk >> 1); h = kk & 1;
+            } else {
+                const int pixp = c >> 1, q = pixp % PRW;
+                row = pixp / PRW; h = (c & 1) ^ ((row >> 2) & 1);
+                col = (q % 9) * 4 + q / 9;
+            }
             const int y = y0 - 1 + row, x = x0 - 1 + col;
             const bool ok = c < P_REAL && col < 34 && y >= 0 && y < Hv && x >= 0 && x < Wv;
             const int ys = UPS ? y >> 1 : y, xs = UPS ? x >> 1 : x;
             pv[j] = ok ? (unsigned)((img * p.Hin + ys) * p.Win + xs) * pitch4 + h * 16 : OOB;
         }
-        int soffA = kt0 * 32;
+        int soffA = kt0 * kstep;
         int soffU = ((nb * nkt + kt0) * 36 + W * 9) * 1024;           // this wave's first slice of k-tile kt0
         const unsigned uvp = (unsigned)lane * 16u;
         const int T = lane & 31, ty = T >> 3, tx = T & 7;
         // window row rr of this lane's tile is patch row 4*ty + FR + rr; its pixels' halves are swapped when bit 2 of the row is set
         const float *pread = lds + U_F + (((4 * ty + FR) * PRW + tx) * 2 + (half ^ (ty & 1))) * 4;   // + stage*P_F + ((rr*PRW + coff(c))*2 +- 1)*4
+        // BLK: byte offset of (row, group g = tx + (c>>2), slot ((c&3)*2 + half) ^ swizzle(row, g)); the swizzle has four per-lane variants
+        int Av[2][2];
+#pragma unroll
+        for (int cq = 0; cq < 2; ++cq)
+#pragma unroll
+            for (int rq = 0; rq < 2; ++rq)
+                Av[cq][rq] = ((4 * ty + FR) * 9 + tx) * 128 + ((half ^ (((((tx + cq) >> 1) & 1) << 2) | ((ty + rq) & 3))) << 4);
         const float *uread = lds + W * 9 * 256 + lane * 4;                                // + f*256
 
         // one piece (64 chunks) of the patch of the k-tile at soffA; the last one is ragged (P_REAL is not a multiple of 64): its tail
@@ -1051,6 +1070,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
         auto load_col = [&](int stage, int k) {
             constexpr int ord0[5] = {4, 2, 0, 3, 1}, ord1[5] = {3, 1, 4, 2, 0};
             const int c = FC + (FC == 0 ? ord0[k] : ord1[k]), coff = ((c & 3) * 9 + (c >> 2)) * 8;
+            if (BLK) {
+                const char *sb = reinterpret_cast<const char *>(lds + U_F + stage * P_F);
+#pragma unroll
+                for (int rr = 0; rr < 5; ++rr)
+                    x[rr] = *reinterpret_cast<const f32x4 *>(sb + ((Av[c >> 2][(FR + rr) >> 2] ^ ((c & 3) << 5)) + (rr * 9 + (c >> 2)) * 128));
+                return;
+            }
             const float *pb = pread + stage * P_F + coff;
             const int flip = (half ^ (ty & 1)) ? -4 : 4;              // rows 4, 5 of the window: the other half-slot of the pixel
 #pragma unroll
@@ -1125,13 +1151,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
         if (ntiles > 0) {
 #pragma unroll
             for (int j = 0; j < NPW; ++j) piece(0, j);
-            soffA += 32;
+            soffA += kstep;
 #pragma unroll
             for (int f = 0; f < 9; ++f) {
                 issue_u(f);
                 if (ntiles > 1 && f < NPW) piece(1, f);
             }
-            soffA += 32;
+            soffA += kstep;
             soffU += 36 * 1024;
             if (ntiles > 1) wait_vmcnt<9 + NPW>(); else wait_vmcnt<9>();       // patch 0 has landed
             __builtin_amdgcn_s_barrier();
@@ -1178,7 +1204,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
                 if (f == 6 && more) load_col(S ^ 1, 0);               // first window column of k-tile t+1 (published at the barrier above)
             }
             if (more) soffU += 36 * 1024;
-            if (more2) soffA += 32;
+            if (more2) soffA += kstep;
         };
         if (ntiles > 0) {
             using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
@@ -2317,6 +2343,33 @@ __global__ void k_prep_inputs(const float *__restrict__ x, const float *__restri
     }
 }
 
+// k_gn_apply into the channel-blocked layout the F(4x4) convolution reads, y[(c/8)][pixel][c%8]: a workgroup normalises tp pixels x C
+// channels with coalesced 16-byte reads, turns them through LDS (row length rs = C + pad, (rs/4) % 16 == 2: the 16-lane groups of
+// the read-back hit 16 different slots) and writes tp x 32 contiguous bytes per 8-channel plane
+__global__ __launch_bounds__(256) void k_gn_apply_blk(const float *__restrict__ x, long pitch, long pixels_per_img, long npix, int C,
+                                                      const float *__restrict__ cA, const float *__restrict__ cB, int act,
+                                                      float *__restrict__ y, int tp, int rs) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int cq = C >> 2, tid = threadIdx.x;
+    const long pix0 = (long)blockIdx.x * tp;
+    for (int idx = tid; idx < tp * cq; idx += 256) {
+        const int px = idx / cq, c = (idx - px * cq) * 4;
+        const long pix = pix0 + px, n = pix / pixels_per_img;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + pix * pitch + c);
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(cA + n * C + c);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(cB + n * C + c);
+        f32x4 o = v * a + b;
+        if (act) { o[0] = silu_f(o[0]); o[1] = silu_f(o[1]); o[2] = silu_f(o[2]); o[3] = silu_f(o[3]); }
+        *reinterpret_cast<f32x4 *>(sh + px * rs + c) = o;
+    }
+    __syncthreads();
+    const int per = tp * 2, nkt = C >> 3;
+    for (int idx = tid; idx < nkt * per; idx += 256) {
+        const int kt = idx / per, rem = idx - kt * per, px = rem >> 1, h = rem & 1;
+        *reinterpret_cast<f32x4 *>(y + ((long)kt * npix + pix0 + px) * 8 + h * 4) = *reinterpret_cast<const f32x4 *>(sh + px * rs + kt * 8 + h * 4);
+    }
+}
+
 // ---- cond_type='cross_attention' (spatial_transformer.py): LayerNorm over the channels of every token, GEGLU, a per-image row vector ----
 // y (npix, C dense) = (x - mean) * rstd * gamma + beta per pixel (nn.LayerNorm(C), eps 1e-5); one wave per pixel
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, long pitch, long npix, int C, const float *__restrict__ gamma,
@@ -2613,6 +2666,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         a.path = (dma && wino4) ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0));
         return HL_OK;
     }
+    bool blk4 = false;
     if (dma) {
         HL_REQUIRE(mode == 0 || !a.ups, "conv2d: upsample with a GroupNorm prologue is not used by the UNet");
         if (mode != 0) {   // materialise GroupNorm(+SiLU) once, then the DMA kernels read it raw
@@ -2620,6 +2674,17 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             const long npix = a.in.pixels();
             long g = (npix * (a.in.C / 4) + 255) / 256;
             if (g > 4096) g = 4096;
+            if (wino4 && npix % 64 == 0) {
+                // for the F(4x4) kernel the normalised copy is channel-blocked, [C/8][pixel][8]: its patch DMA then reads 128 contiguous
+                // bytes per four pixels instead of 32 per pixel (the gather rate of the LDS-DMA path is set by the number of distinct
+                // segments: 33 B/ns/CU at 32 bytes, 148 at 128 - scripts/microbench/dma_bw.hip)
+                blk4 = true;
+                const int tp = 8;   // (8 pixels = 256 contiguous bytes per plane; larger tiles cost occupancy: 64 pixels 93 us, 8 pixels 70 us = the plain pass)
+                const int pad = ((2 - (a.in.C / 4) % 16 + 16) % 16) * 4;
+                const size_t shb = (size_t)tp * (a.in.C + pad) * sizeof(float);
+                hipLaunchKernelGGL(k_gn_apply_blk, dim3((unsigned)(npix / tp)), dim3(256), shb, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix,
+                                   a.in.C, a.coefA, a.coefB, a.act, a.act_ws, tp, a.in.C + pad);
+            } else
             hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix,
                                a.in.C, a.coefA, a.coefB, a.act, a.act_ws);
             p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0;
@@ -2635,8 +2700,9 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
                 p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
                 a.stat_slots = (a.out.H / 16) * (a.out.W / 32) * 8;
             }
-            if (a.ups) hipLaunchKernelGGL((k_conv_wino4<true>), nblk, dim3(256), sh4, st, p);
-            else hipLaunchKernelGGL((k_conv_wino4<false>), nblk, dim3(256), sh4, st, p);
+            if (a.ups) hipLaunchKernelGGL((k_conv_wino4<true, false>), nblk, dim3(256), sh4, st, p);
+            else if (blk4) hipLaunchKernelGGL((k_conv_wino4<false, true>), nblk, dim3(256), sh4, st, p);
+            else hipLaunchKernelGGL((k_conv_wino4<false, false>), nblk, dim3(256), sh4, st, p);
             if (splits > 1) return finish("k_conv_wino4");
             return check_launch("k_conv_wino4");
         }

@@ -19,6 +19,18 @@ __global__ __launch_bounds__(WAVES * 64) void k(const float *src, int bytes_mask
             const unsigned off = (base + j * 1024u) & bytes_mask;
             if (MODE == 0) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(my + j * 256), 16, lane * 16u, off, 0, 0);
+            } else if (MODE >= 7) {
+                // 1 KiB contiguous, but the 16-byte pieces permuted inside every 128-byte group of eight lanes (7: XOR 5, 8: XOR (group & 7)):
+                // does the address coalescing depend on the lane order inside a group?
+                const unsigned grp = lane >> 3, k = (lane & 7) ^ (MODE == 7 ? 5u : (grp & 7u));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(my + j * 256), 16, (grp * 8u + k) * 16u, off, 0, 0);
+            } else if (MODE >= 4) {
+                // gathers shaped like the convolution's patch DMA: 768-byte pixels (192 channels); 4: one 16-byte piece per lane and pixel,
+                // 5: lanes 2i, 2i+1 take 32 contiguous bytes of a pixel, 6: lanes 4i..4i+3 two pixels' 32 bytes twice (nearest-x2 upsample)
+                const unsigned pix = MODE == 4 ? lane : (MODE == 5 ? (lane >> 1) : (lane >> 2));
+                const unsigned sub = MODE == 4 ? 0u : (lane & 1) * 16u;
+                const unsigned voff = (pix * 768u + sub + ((unsigned)it & 3u) * 32u) & (unsigned)bytes_mask;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(my + j * 256), 16, voff, (off & ~1023u) * 48u & (unsigned)bytes_mask, 0, 0);
             } else if (MODE == 1) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -29,7 +41,7 @@ __global__ __launch_bounds__(WAVES * 64) void k(const float *src, int bytes_mask
             }
         }
         base = (base + 65536u * WAVES) & bytes_mask;
-        if (MODE <= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // keep one batch in flight
+        if (MODE <= 1 || MODE >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // keep one batch in flight
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -56,6 +68,11 @@ int main() {
         run<0, 4>("LDS-DMA b128", src, bytes, 1, sink);
         run<0, 8>("LDS-DMA b128", src, bytes, 2, sink);
         run<1, 4>("LDS-DMA b32", src, bytes, 2, sink);
+        run<4, 4>("LDS-DMA b128 gather 16 B / pixel", src, bytes, 2, sink);
+        run<5, 4>("LDS-DMA b128 gather 32 B / pixel", src, bytes, 2, sink);
+        run<6, 4>("LDS-DMA b128 gather 32 B / pixel x2", src, bytes, 2, sink);
+        run<7, 4>("LDS-DMA b128 1 KiB, groups of 8 permuted (^5)", src, bytes, 2, sink);
+        run<8, 4>("LDS-DMA b128 1 KiB, groups of 8 permuted (^g)", src, bytes, 2, sink);
         run<2, 4>("buffer_load b128 + ds_write_b128", src, bytes, 2, sink);
         run<3, 4>("buffer_load b128 to VGPR", src, bytes, 2, sink);
         run<3, 8>("buffer_load b128 to VGPR", src, bytes, 2, sink);
