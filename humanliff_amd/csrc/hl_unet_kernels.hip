@@ -2344,29 +2344,31 @@ __global__ void k_prep_inputs(const float *__restrict__ x, const float *__restri
 }
 
 // k_gn_apply into the channel-blocked layout the F(4x4) convolution reads, y[(c/8)][pixel][c%8]: a workgroup normalises tp pixels x C
-// channels with coalesced 16-byte reads, turns them through LDS (row length rs = C + pad, (rs/4) % 16 == 2: the 16-lane groups of
+// channels with coalesced 16-byte reads, turns them through LDS (row length rs = C + pad, (rs/4) % 16 == 4: the 16-lane groups of
 // the read-back hit 16 different slots) and writes tp x 32 contiguous bytes per 8-channel plane
 __global__ __launch_bounds__(256) void k_gn_apply_blk(const float *__restrict__ x, long pitch, long pixels_per_img, long npix, int C,
                                                       const float *__restrict__ cA, const float *__restrict__ cB, int act,
                                                       float *__restrict__ y, int tp, int rs) {
     extern __shared__ __attribute__((aligned(16))) float sh[];
-    const int cq = C >> 2, tid = threadIdx.x;
+    f32x4 *sh4 = reinterpret_cast<f32x4 *>(sh);                      // (indexed in 16-byte units: the compiler then emits ds_*_b128)
+    f32x4 *y4 = reinterpret_cast<f32x4 *>(y);
+    const int cq = C >> 2, rs4 = rs >> 2, tid = threadIdx.x;
     const long pix0 = (long)blockIdx.x * tp;
     for (int idx = tid; idx < tp * cq; idx += 256) {
-        const int px = idx / cq, c = (idx - px * cq) * 4;
+        const int px = idx / cq, c4 = idx - px * cq;
         const long pix = pix0 + px, n = pix / pixels_per_img;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + pix * pitch + c);
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(cA + n * C + c);
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(cB + n * C + c);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + pix * pitch + c4 * 4);
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(cA + n * C + c4 * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(cB + n * C + c4 * 4);
         f32x4 o = v * a + b;
         if (act) { o[0] = silu_f(o[0]); o[1] = silu_f(o[1]); o[2] = silu_f(o[2]); o[3] = silu_f(o[3]); }
-        *reinterpret_cast<f32x4 *>(sh + px * rs + c) = o;
+        sh4[px * rs4 + c4] = o;
     }
     __syncthreads();
     const int per = tp * 2, nkt = C >> 3;
     for (int idx = tid; idx < nkt * per; idx += 256) {
         const int kt = idx / per, rem = idx - kt * per, px = rem >> 1, h = rem & 1;
-        *reinterpret_cast<f32x4 *>(y + ((long)kt * npix + pix0 + px) * 8 + h * 4) = *reinterpret_cast<const f32x4 *>(sh + px * rs + kt * 8 + h * 4);
+        y4[((long)kt * npix + pix0 + px) * 2 + h] = sh4[px * rs4 + kt * 2 + h];
     }
 }
 
@@ -2680,7 +2682,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
                 // segments: 33 B/ns/CU at 32 bytes, 148 at 128 - scripts/microbench/dma_bw.hip)
                 blk4 = true;
                 const int tp = 8;   // (8 pixels = 256 contiguous bytes per plane; larger tiles cost occupancy: 64 pixels 93 us, 8 pixels 70 us = the plain pass)
-                const int pad = ((2 - (a.in.C / 4) % 16 + 16) % 16) * 4;
+                const int pad = ((4 - (a.in.C / 4) % 16 + 16) % 16) * 4;   // row length / 4 = 4 (mod 16): the read-back groups (8 pixels x 2 halves of two planes) hit 16 different slots
                 const size_t shb = (size_t)tp * (a.in.C + pad) * sizeof(float);
                 hipLaunchKernelGGL(k_gn_apply_blk, dim3((unsigned)(npix / tp)), dim3(256), shb, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix,
                                    a.in.C, a.coefA, a.coefB, a.act, a.act_ws, tp, a.in.C + pad);
