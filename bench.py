@@ -41,8 +41,8 @@ FINE_FLOP_PER_RAY_TOTAL = FINE_FLOP_PER_RAY + COARSE_FLOP_PER_RAY   # the refere
 # Fabric-side bytes per launch of the two dominant kernels from the separate rocprofv3 PMC passes (FETCH_SIZE
 # doubled per the gfx950 calibration, WRITE_SIZE as is): profiles/r02_pmc_hbm_traffic.md.  Not measured by this
 # script - PMC collection needs its own runs.
-PMC_TRAFFIC = {"k_conv_avg_launch_b4": 331e6, "k_march_fine_512x512": 4.1e9, "k_march_eval_512x512": 0.72e9,
-               "source": "profiles/r02_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv path: (381.48 GB read "
+PMC_TRAFFIC = {"k_conv_avg_launch_b4": 329e6, "k_march_fine_512x512": 4.1e9, "k_march_eval_512x512": 0.72e9,
+               "source": "profiles/r02_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv path: (378.06 GB read "
                          "+ 127.54 GB written) / 6 forwards / 256 launches; k_march<true,true>: (1.50 + 4.29 GB) / 8 launches)"}
 
 F4 = dict(image_size=256, in_channels=27, out_channels=27, num_channels=192, num_res_blocks=3, num_heads=4,
