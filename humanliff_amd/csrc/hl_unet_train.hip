@@ -144,6 +144,166 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const WgradK p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward-weights of the 3x3 layers, all nine taps per workgroup (k_conv_wgrad_t + k_wgrad_finish)
+// ---------------------------------------------------------------------------------------------
+// k_conv_wgrad above takes its operands straight from L2 - 1 KiB per four MFMAs and wave - and gives every tap a workgroup of its
+// own, so a 3x3 layer pulls X and dY through the L2 nine times per channel-block pair: the kernel runs at the L2's delivery rate
+// (0.38 of the fp32 matrix peak over the production network).  Here a workgroup owns a (64 co x 64 ci) block of dW for ALL nine taps
+// and walks a slab of 8x8-pixel output tiles (4x8 for stride 2):
+//   * per tile the 64 dY rows and the (8+2)x(8+2) input patch (9x17 for stride 2) of the 64 input channels are staged in LDS ONCE
+//     (42 KB; fetched one tile ahead into registers, written after the barrier that ends the previous tile's reads) - 1.56 patch pixels
+//     per output pixel instead of 9;
+//   * wave (i, j) owns channel quadrant (co half i, ci half j) x 9 taps = nine 32x32 accumulator tiles (144 registers, two workgroups
+//     per CU).  A k-step is one pixel pair: ONE ds_read_b32 of dY (A operand: lane (m, kh) = channel m of pixel 2s + kh) and NINE of
+//     the patch (B operand of tap (ky, kx): the same lane, patch pixel shifted by the tap - a compile-time LDS offset) feed nine MFMAs.
+//     LDS is split by channel half, [half][pixel][32], so each 32-lane group of a read covers 32 consecutive floats (conflict-free;
+//     ds_read_b32 banks over 32 lanes).  10 reads x 2 LDS cycles per 9 x 64 matrix cycles: the LDS array is ~14 % busy.
+//   * zero padding / ragged tiles / the nearest-x2 upsample / stride 2 are per-lane source offsets of the staging loads, out-of-range
+//     ones point outside the buffer (the hardware returns zeros).
+// No atomics: every workgroup writes its block to a partial buffer [slab][co][tap][ci] (caller's scratch) and k_wgrad_finish sums the
+// slabs in a fixed order into the OIHW gradient - the weight gradients of these layers are bit-reproducible run to run.  The bias
+// gradient (row sums of dY, taken by the j = 0 waves of the ci-block-0 workgroups from the A operands they read anyway) goes the
+// same way, as a tenth "tap".
+struct WgradT {
+    const float *x; long x_pitch; int N, Hin, Win, Cx;        // conv input (NHWC, Cx % 4 == 0 channels present)
+    const float *dy; long dy_pitch; int Hout, Wout, Cy;       // output gradient (NHWC, Cy % 4 == 0)
+    int ups;
+    float *part;                                               // [slabs][n_co*64][10][n_ci*64]: taps 0..8, 9 = bias (column 0 of ci block 0)
+    int n_co, n_ci, slabs;
+    int tilesX, tilesY; long tiles, per_slab;                  // output tiles per image row / column, in all, per slab
+    int want_b;
+};
+
+template <int S>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_t(const WgradT p) {
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int TH = 8 / S, TW = 8, NPIX = TH * TW;                          // output pixels of a tile
+    constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, NP = PH * PW;  // input patch: 10x10 (stride 1), 9x17 (stride 2)
+    constexpr int NLB = (NP + 15) / 16, NLA = NPIX / 16;                       // staging loads per thread (16 threads x float4 = 64 channels)
+    __shared__ float ldsB[2][NP][32];
+    __shared__ float ldsA[2][NPIX][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, m = lane & 31;
+    const int wi = wave >> 1, wj = wave & 1;
+    // XCD-aware order: the channel blocks of one slab (same pixels) run on the same XCD, so its L2 serves their common X / dY reads
+    const int blocks = p.n_co * p.n_ci;
+    const int per_xcd = (int)(gridDim.x >> 3);
+    const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (logical >= blocks * p.slabs) return;
+    const int slab = logical / blocks, blk = logical - slab * blocks;
+    const int cob = blk / p.n_ci, cib = blk - cob * p.n_ci;
+    const int co0 = cob * 64, ci0 = cib * 64;
+    const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
+    const __amdgpu_buffer_rsrc_t rsY =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.dy, (short)0, (int)((long)p.N * p.Hout * p.Wout * p.dy_pitch * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.x, (short)0, (int)((long)p.N * p.Hin * p.Win * p.x_pitch * 4), 0x00020000);
+    const int c4 = tid & 15, e0 = tid >> 4;
+    const bool a_ok = co0 + 4 * c4 < p.Cy, b_ok = ci0 + 4 * c4 < p.Cx;
+    const long t0 = (long)slab * p.per_slab, t1 = min(p.tiles, t0 + p.per_slab);
+    const int tpi = p.tilesX * p.tilesY;
+
+    f32x4 rb[NLB], ra[NLA];
+    auto fetch = [&](long tile) {
+        const int n = (int)(tile / tpi), r = (int)(tile - (long)n * tpi);
+        const int tyb = r / p.tilesX, txb = r - tyb * p.tilesX;
+        const int oy0 = tyb * TH, ox0 = txb * TW;
+#pragma unroll
+        for (int u = 0; u < NLB; ++u) {
+            const int pos = e0 + 16 * u, pr = pos / PW, pc = pos - pr * PW;
+            const int yi = oy0 * S + pr - 1, xi = ox0 * S + pc - 1;
+            const bool v = pos < NP && b_ok && yi >= 0 && yi < Hv && xi >= 0 && xi < Wv;
+            const int ys = p.ups ? yi >> 1 : yi, xs = p.ups ? xi >> 1 : xi;
+            const unsigned off = v ? (unsigned)((((long)n * p.Hin + ys) * p.Win + xs) * p.x_pitch + ci0 + 4 * c4) * 4u : OOB;
+            rb[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < NLA; ++u) {
+            const int q = e0 + 16 * u, yo = oy0 + (q >> 3), xo = ox0 + (q & 7);
+            const bool v = a_ok && yo < p.Hout && xo < p.Wout;
+            const unsigned off = v ? (unsigned)((((long)n * p.Hout + yo) * p.Wout + xo) * p.dy_pitch + co0 + 4 * c4) * 4u : OOB;
+            ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
+        }
+    };
+    auto stage = [&]() {
+        const int half = c4 >> 3, cc = (c4 & 7) * 4;
+#pragma unroll
+        for (int u = 0; u < NLB; ++u) {
+            const int pos = e0 + 16 * u;
+            if (pos < NP) *reinterpret_cast<f32x4 *>(&ldsB[half][pos][cc]) = rb[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NLA; ++u) *reinterpret_cast<f32x4 *>(&ldsA[half][e0 + 16 * u][cc]) = ra[u];
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bs = 0.f;
+    const float *la = &ldsA[wi][kh][m];                          // + pixel pair s: 2 s * 32 floats
+    const float *lb = &ldsB[wj][kh * S][m];                      // + patch pixel of (pair s, tap): compile-time offsets
+
+    if (t0 < t1) fetch(t0);
+    for (long tile = t0; tile < t1; ++tile) {
+        if (tile > t0) __syncthreads();                          // the previous tile's reads are done
+        stage();
+        __syncthreads();
+        if (tile + 1 < t1) fetch(tile + 1);                      // in flight during this tile's MFMAs
+#pragma unroll 1
+        for (int row = 0; row < TH; ++row) {                     // a tile row = 4 pixel pairs; only the row offset is a run-time value
+            const float *lar = la + row * (8 * 32), *lbr = lb + row * (S * PW * 32);
+#pragma unroll
+            for (int sc = 0; sc < 4; ++sc) {
+                const float a = lar[(2 * sc) * 32];
+                float b[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) b[t] = lbr[((t / 3) * PW + 2 * sc * S + t % 3) * 32];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+                bs += a;
+            }
+        }
+    }
+    // partial block: accumulator r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5) (co), column l & 31 (ci)
+    const long CoP = (long)p.n_co * 64, CiP = (long)p.n_ci * 64;
+    float *pp = p.part + (long)slab * CoP * 10 * CiP;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            pp[((long)(co0 + 32 * wi + row) * 10 + t) * CiP + ci0 + 32 * wj + m] = acc[t][r];
+        }
+    if (p.want_b && cib == 0 && wj == 0) {
+        bs += __shfl_xor(bs, 32);
+        if (kh == 0) pp[((long)(co0 + 32 * wi + m) * 10 + 9) * CiP] = bs;
+    }
+}
+
+// dW[co][ci][tap] = sum over the slabs, in slab order; db[co] likewise from "tap" 9, column 0
+__global__ void k_wgrad_finish(const float *__restrict__ part, int slabs, long CoP, long CiP, int Cout, int Cin, float *__restrict__ dw,
+                               float *__restrict__ db) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Cout * Cin) return;
+    const int co = (int)(i / Cin), ci = (int)(i - (long)co * Cin);
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = 0.f;
+    float b = 0.f;
+    const long sstride = CoP * 10 * CiP;
+    const float *q = part + (long)co * 10 * CiP + ci;
+    for (int s = 0; s < slabs; ++s, q += sstride) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] += q[t * CiP];
+        if (db && ci == 0) b += q[9 * CiP];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dw[i * 9 + t] = v[t];
+    if (db && ci == 0) db[co] = b;
+}
+
+// ---------------------------------------------------------------------------------------------
 // GroupNorm (+SiLU) backward
 // ---------------------------------------------------------------------------------------------
 // forward: u = A[n,c] * x + B[n,c]  (A, B fold GroupNorm32 statistics, affine and the ResBlock's scale / shift), out = act ? silu(u) : u.
@@ -329,6 +489,59 @@ int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const floa
     slabs = (p.P + p.slab - 1) / p.slab;
     hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)tiles, (unsigned)slabs), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("k_conv_wgrad");
+}
+
+// k_conv_wgrad_t geometry: 8x8 output tiles (4x8 for stride 2), ~512 workgroups (two per CU, one round)
+static void wgrad_t_plan(int N, int Hout, int Wout, int Cout, int Cin, int stride, WgradT &p) {
+    const int TH = 8 / stride;
+    p.tilesX = (Wout + 7) / 8; p.tilesY = (Hout + TH - 1) / TH;
+    p.tiles = (long)N * p.tilesX * p.tilesY;
+    p.n_co = (Cout + 63) / 64; p.n_ci = (Cin + 63) / 64;
+    const long blocks = (long)p.n_co * p.n_ci;
+    long slabs = 512 / blocks;
+    if (slabs < 1) slabs = 1;
+    if (slabs > p.tiles) slabs = p.tiles;
+    p.per_slab = (p.tiles + slabs - 1) / slabs;
+    p.slabs = (int)((p.tiles + p.per_slab - 1) / p.per_slab);
+}
+
+static bool wgrad_t_applies(int Cx, int Cy, int ks) { return ks == 3 && Cx % 4 == 0 && Cy % 4 == 0; }
+
+size_t hl_conv2d_wgrad_scratch_bytes(int N, int H, int W, int Cx, int Cy, int ks, int stride, int upsample, int Cout, int Cin) {
+    if (!wgrad_t_applies(Cx, Cy, ks) || (stride != 1 && stride != 2)) return 0;
+    const int Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
+    WgradT p{};
+    wgrad_t_plan(N, (Hv + 2 - 3) / stride + 1, (Wv + 2 - 3) / stride + 1, Cout, Cin, stride, p);
+    return (size_t)p.slabs * p.n_co * 64 * 10 * p.n_ci * 64 * sizeof(float);
+}
+
+int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
+                            float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream) {
+    if (!wgrad_t_applies(Cx, Cy, ks)) return hl_conv2d_wgrad_nhwc(x, N, H, W, Cx, dy, Cy, ks, stride, upsample, dw, Cout, Cin, db, stream);
+    HL_REQUIRE(x && dy && dw, "hl_conv2d_wgrad_nhwc_ws: null argument");
+    HL_REQUIRE(stride == 1 || (stride == 2 && !upsample), "hl_conv2d_wgrad_nhwc_ws: stride");
+    HL_REQUIRE(Cin <= Cx && Cout <= Cy, "hl_conv2d_wgrad_nhwc_ws: channel counts (x %d, dy %d) must cover the weight (%d, %d)", Cx, Cy, Cout, Cin);
+    const int Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
+    WgradT p{};
+    p.x = x; p.x_pitch = Cx; p.N = N; p.Hin = H; p.Win = W; p.Cx = Cx;
+    p.dy = dy; p.dy_pitch = Cy; p.Hout = (Hv + 2 - 3) / stride + 1; p.Wout = (Wv + 2 - 3) / stride + 1; p.Cy = Cy;
+    p.ups = upsample; p.want_b = db != nullptr;
+    HL_REQUIRE((long)N * p.Hout * p.Wout * Cy * 4 < (1L << 31) && (long)N * H * W * Cx * 4 < (1L << 31),
+               "hl_conv2d_wgrad_nhwc_ws: tensors of 2 GiB and more are not addressed");
+    wgrad_t_plan(N, p.Hout, p.Wout, Cout, Cin, stride, p);
+    const size_t need = (size_t)p.slabs * p.n_co * 64 * 10 * p.n_ci * 64 * sizeof(float);
+    HL_REQUIRE(scratch && scratch_bytes >= need, "hl_conv2d_wgrad_nhwc_ws: scratch too small (%zu bytes, hl_conv2d_wgrad_scratch_bytes says %zu)",
+               scratch_bytes, need);
+    p.part = static_cast<float *>(scratch);
+    const unsigned grid = (unsigned)(((long)p.n_co * p.n_ci * p.slabs + 7) / 8 * 8);
+    if (stride == 1) hipLaunchKernelGGL(k_conv_wgrad_t<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(k_conv_wgrad_t<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    int rc = check_launch("k_conv_wgrad_t");
+    if (rc) return rc;
+    const long n = (long)Cout * Cin;
+    hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.part, p.slabs, (long)p.n_co * 64,
+                       (long)p.n_ci * 64, Cout, Cin, dw, db);
+    return check_launch("k_wgrad_finish");
 }
 
 int hl_gn_apply_nhwc(const float *x, long x_pitch, int N, int HW, int C, const float *coefA, const float *coefB, int silu, float *y,

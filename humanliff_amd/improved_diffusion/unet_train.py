@@ -90,12 +90,17 @@ class _Conv(th.autograd.Function):
                                                      _lib.ptr(dx), Cxp, _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()),
                            "hl_conv2d_nhwc_bwd_data")
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
-            dw = th.zeros(w4.shape, device=dy.device, dtype=th.float32)
-            db = th.zeros((Cout,), device=dy.device, dtype=th.float32) if has_b else None
-            dy2 = _pad_c(dy, 2)
+            dy2 = _pad_c(dy, 4)
+            geom = (N, x.shape[1], x.shape[2], x.shape[3], dy2.shape[-1], ks, stride, ups, Cout, Cin)
+            nbytes = L.hl_conv2d_wgrad_scratch_bytes(*geom)          # per-slab partial blocks of the 3x3 kernel (0: 1x1 layers)
+            part = th.empty(max(1, nbytes // 4), device=dy.device, dtype=th.float32)
+            alloc = th.empty if nbytes else th.zeros                 # the 3x3 kernel stores, the 1x1 kernel adds with atomics
+            dw = alloc(w4.shape, device=dy.device, dtype=th.float32)
+            db = alloc((Cout,), device=dy.device, dtype=th.float32) if has_b else None
             with _lib.on(dy.device):
-                _lib.check(L.hl_conv2d_wgrad_nhwc(_lib.ptr(x), N, x.shape[1], x.shape[2], x.shape[3], _lib.ptr(dy2), dy2.shape[-1], ks, stride, ups,
-                                                  _lib.ptr(dw), Cout, Cin, _lib.ptr(db), _lib.stream_ptr()), "hl_conv2d_wgrad_nhwc")
+                _lib.check(L.hl_conv2d_wgrad_nhwc_ws(_lib.ptr(x), N, x.shape[1], x.shape[2], x.shape[3], _lib.ptr(dy2), dy2.shape[-1], ks, stride,
+                                                     ups, _lib.ptr(dw), Cout, Cin, _lib.ptr(db), _lib.ptr(part), nbytes, _lib.stream_ptr()),
+                           "hl_conv2d_wgrad_nhwc_ws")
             dw = dw.reshape(wshape)
         return dx, dw, db, None, None
 

@@ -365,6 +365,14 @@ int hl_conv2d_nhwc_bwd_data(int conv_mode, const float *dy, int N, int Ho, int W
                             int stride, int upsample, float *dx, int Cx, void *scratch, size_t scratch_bytes, void *stream);
 int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                          float *dw, int Cout, int Cin, float *db, void *stream);
+/* hl_conv2d_wgrad_nhwc_ws: the same gradients, 3x3 layers through k_conv_wgrad_t (a workgroup owns a 64x64 channel block of dW for
+ * all nine taps, dY rows and input patch of an 8x8-pixel tile staged in LDS once; per-slab partial blocks in `scratch`, summed in a
+ * fixed order by k_wgrad_finish - no atomics, dw / db are plainly stored and bit-reproducible).  Needs Cx, Cy multiples of 4 and
+ * `scratch` of hl_conv2d_wgrad_scratch_bytes(...) bytes; 1x1 layers (and odd channel counts) fall through to hl_conv2d_wgrad_nhwc,
+ * so dw / db must still be zeroed by the caller. */
+size_t hl_conv2d_wgrad_scratch_bytes(int N, int H, int W, int Cx, int Cy, int ks, int stride, int upsample, int Cout, int Cin);
+int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
+                            float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream);
 /* y (N,HW,C dense) = silu ? silu(x*A + B) : x*A + B with the per-(n,c) affine of hl_groupnorm_coef; x has a channel pitch. */
 int hl_gn_apply_nhwc(const float *x, long x_pitch, int N, int HW, int C, const float *coefA, const float *coefB, int silu, float *y,
                      void *stream);
