@@ -614,8 +614,10 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_dma(const C
 // After the K walk every wave applies the column half of A^T . A to its accumulators, the four frequency rows meet in
 // LDS, and each wave finishes one (column parity, channel block) of the outputs with the usual epilogue.
 // LDS layouts are chosen so that the 8 lanes a ds_read_b128 serves per cycle read consecutive 16-byte chunks:
-//   patch chunk  ((half*18 + row)*2 + (col&1))*10 + (col>>1)       (4 channels of one pixel; 10, not 9, per half-row so that
-//                                                                    the next row of tiles starts 128 bytes off modulo 256)
+//   patch chunk  (((row*2 + (col&1))*10 + (col>>1))*2 + (half ^ bit 1 of row)   (4 channels of one pixel: the two channel halves of a
+//                pixel are neighbours, fetched by neighbouring DMA lanes - 32 contiguous bytes, one L2 request instead of two, as in
+//                k_conv_wino4; the swap by the row bit puts the tiles of rows ty and ty+1 on the even / odd 16-byte slots, so the
+//                lane groups of a ds_read_b128 still hit 16 different slots - checked by enumeration)
 //   weight chunk ((f*2 + ct)*2 + half)*32 + cout                   (4 channels of one output channel)
 // ---------------------------------------------------------------------------------------------
 template <bool UPS>
@@ -665,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(const ConvK p) {
     for (int j = 0; j < NJ - NU; ++j) {
         const int pi = wave + NW * (NU + j) - 32;
         const int c = pi * 64 + lane;                             // patch chunk
-        const int jc = c % 10, t1 = c / 10, par = t1 & 1, t2 = t1 >> 1, row = t2 % PR, h = t2 / PR;
+        const int hs = c & 1, tq = c >> 1, jc = tq % 10, t1 = tq / 10, par = t1 & 1, row = t1 >> 1, h = hs ^ ((row >> 1) & 1);
         const int y = y0 - 1 + row, x = x0 - 1 + 2 * jc + par;
         const bool ok = pi < NP && c < P_REAL && jc < 9 && y >= 0 && y < Hv && x >= 0 && x < Wv;
         const int ys = UPS ? y >> 1 : y, xs = UPS ? x >> 1 : x;
@@ -680,8 +682,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(const ConvK p) {
     const int T = lane & 31, ty = 4 * g + (T >> 3), tx = T & 7;
     const int rA = (fi == 0) ? 0 : (fi == 2 ? 2 : 1), rB = (fi == 0) ? 2 : (fi == 1 ? 2 : (fi == 2 ? 1 : 3));
     const float sB = (fi == 1) ? 1.f : -1.f;                      // T = d[rA] + sB * d[rB]
-    const int pA = U_F + (((half * PR + 2 * ty + rA) * 2) * 10 + tx) * 4, pB = U_F + (((half * PR + 2 * ty + rB) * 2) * 10 + tx) * 4;
-    // column c of a row: + ((c & 1) * 10 + (c >> 1)) * 4 floats
+    const int pA = U_F + (((((2 * ty + rA) * 2) * 10 + tx) * 2) + (half ^ (((2 * ty + rA) >> 1) & 1))) * 4;
+    const int pB = U_F + (((((2 * ty + rB) * 2) * 10 + tx) * 2) + (half ^ (((2 * ty + rB) >> 1) & 1))) * 4;
+    // column c of a row: + ((c & 1) * 10 + (c >> 1)) * 8 floats
     const int u_off = ((fi * 4 * 2) * 2 + half) * 32 * 4 + (lane & 31) * 4;   // + ((f' * 2 + ct) * 2) * 128 floats
 
     f32x16 acc[4][NCT];
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(const ConvK p) {
     auto read_patch = [&](const float *base, f32x4(&da)[4], f32x4(&db)[4]) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int co = ((c & 1) * 10 + (c >> 1)) * 4;
+            const int co = ((c & 1) * 10 + (c >> 1)) * 8;
             da[c] = *reinterpret_cast<const f32x4 *>(base + pA + co);
             db[c] = *reinterpret_cast<const f32x4 *>(base + pB + co);
         }

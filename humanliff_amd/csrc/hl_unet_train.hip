@@ -5,12 +5,12 @@
 // of the stock ops is replaced, op by op (humanliff_amd/improved_diffusion/unet_train.py holds the autograd.Functions), by
 //   conv forward / backward-data   the FORWARD conv kernels of hl_unet_kernels.hip: backward-data of a 3x3 / 1x1 convolution is the
 //                                  same convolution of the output gradient with the flipped, channel-transposed weights
-//   k_conv_wgrad                   backward-weights + bias:  dW[co][ci][ky][kx] = sum_p dY[p][co] * X[p*stride + (ky,kx) - pad][ci]
-//                                  as a GEMM over the pixels on v_mfma_f32_32x32x2_f32
+//   k_conv_wgrad_t / k_conv_wgrad  backward-weights + bias:  dW[co][ci][ky][kx] = sum_p dY[p][co] * X[p*stride + (ky,kx) - pad][ci]
+//                                  as a GEMM over the pixels on v_mfma_f32_32x32x2_f32 (3x3 layers: _t, all taps per workgroup)
 //   k_gn_apply (hl_unet_kernels)   GroupNorm32 (+scale/shift) (+SiLU) apply, nn.py:100, unet.py:198-219
 //   k_gn_bwd_reduce / _apply       its backward: per-(n,c) reductions, then dx = k1*du + k2*x + k3
-// fp32 atomics accumulate the K-split partial sums (weight gradients, GroupNorm reductions): a training step is not bit-reproducible
-// run to run, like the reference's cuDNN backward.
+// fp32 atomics accumulate the K-split partial sums of the 1x1 weight gradients and the GroupNorm reductions: a training step is not
+// bit-reproducible run to run, like the reference's cuDNN backward (the 3x3 weight gradients are: fixed-order slab sums).
 #include "hl_unet_kernels.h"
 
 namespace hl {

@@ -9,7 +9,8 @@ include/humanliff_hip.h), activations NHWC fp32:
                    d input   hl_conv2d_nhwc_bwd_data: the same forward kernels on the output gradient, the weights read flipped and
                              channel-transposed while they are re-laid (stride 2: zero-stuffed gradient first; nearest-x2 upsample:
                              2x2 block sums afterwards)
-                   d weight  hl_conv2d_wgrad_nhwc (pixels-as-K MFMA GEMM), bias gradient in the same launch
+                   d weight  hl_conv2d_wgrad_nhwc_ws (pixels-as-K MFMA GEMM: 3x3 layers with all nine taps per workgroup from an LDS-staged
+                             tile and a deterministic slab sum, 1x1 layers straight from L2), bias gradient in the same launch
     _GroupNormAct  forward   hl_groupnorm_train_forward (statistics -> affine with scale/shift -> apply + SiLU)
                    backward  hl_groupnorm_train_backward (per-(n,c) reductions, the (N,C) algebra, dx; parameter / scale-shift gradients)
     _Attention     forward   hl_attention_nhwc (fp32 flash-style kernel)
