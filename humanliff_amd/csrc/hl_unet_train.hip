@@ -324,10 +324,7 @@ __global__ void k_gn_bwd_reduce(const float *__restrict__ x, long x_pitch, const
     const int p0 = chunk * per, p1 = min(HW, p0 + per);
     const f32x4 a = *reinterpret_cast<const f32x4 *>(cA + (long)n * C + c4 * 4), b = *reinterpret_cast<const f32x4 *>(cB + (long)n * C + c4 * 4);
     f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int pp = p0 + prow; pp < p1 && prow < k; pp += k) {
-        const long pix = (long)n * HW + pp;
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + pix * x_pitch + c4 * 4);
-        f32x4 dv = *reinterpret_cast<const f32x4 *>(dout + pix * d_pitch + c4 * 4);
+    auto accum = [&](const f32x4 xv, f32x4 dv) {
         if (act) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -337,6 +334,17 @@ __global__ void k_gn_bwd_reduce(const float *__restrict__ x, long x_pitch, const
         }
         s1 += dv;
         s2 += dv * xv;
+    };
+    auto ldx = [&](int pp) { return *reinterpret_cast<const f32x4 *>(x + ((long)n * HW + pp) * x_pitch + c4 * 4); };
+    auto ldd = [&](int pp) { return *reinterpret_cast<const f32x4 *>(dout + ((long)n * HW + pp) * d_pitch + c4 * 4); };
+    if (prow < k) {
+        int pp = p0 + prow;
+        for (; pp + 3 * k < p1; pp += 4 * k) {                     // four pixels (eight 16-byte loads) in flight per thread
+            const f32x4 x0 = ldx(pp), d0 = ldd(pp), x1 = ldx(pp + k), d1 = ldd(pp + k), x2 = ldx(pp + 2 * k), d2 = ldd(pp + 2 * k),
+                        x3 = ldx(pp + 3 * k), d3 = ldd(pp + 3 * k);
+            accum(x0, d0); accum(x1, d1); accum(x2, d2); accum(x3, d3);
+        }
+        for (; pp < p1; pp += k) accum(ldx(pp), ldd(pp));
     }
     // the k pixel rows of the workgroup meet in LDS, then one global atomic per channel and workgroup
 #pragma unroll
@@ -557,7 +565,7 @@ int hl_gn_backward_reduce(const float *x, long x_pitch, const float *dout, int N
     const int cq = C / 4;
     int k = 256 / cq; if (k < 1) k = 1;
     const int threads = cq * k;
-    int chunks = HW / (k * 16); if (chunks < 1) chunks = 1; if (chunks > 256) chunks = 256;
+    int chunks = HW / (k * 16); if (chunks < 1) chunks = 1; if (chunks > 1024) chunks = 1024;
     hipLaunchKernelGGL(k_gn_bwd_reduce, dim3(chunks, N), dim3(threads), (size_t)2 * C * sizeof(float), (hipStream_t)stream, x, x_pitch, dout, (long)C,
                        HW, C, chunks, coefA, coefB, silu, S);
     return check_launch("k_gn_bwd_reduce");
