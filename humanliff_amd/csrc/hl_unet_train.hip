@@ -9,8 +9,8 @@
 //                                  as a GEMM over the pixels on v_mfma_f32_32x32x2_f32 (3x3 layers: _t, all taps per workgroup)
 //   k_gn_apply (hl_unet_kernels)   GroupNorm32 (+scale/shift) (+SiLU) apply, nn.py:100, unet.py:198-219
 //   k_gn_bwd_reduce / _apply       its backward: per-(n,c) reductions, then dx = k1*du + k2*x + k3
-// fp32 atomics accumulate the K-split partial sums of the 1x1 weight gradients and the GroupNorm reductions: a training step is not
-// bit-reproducible run to run, like the reference's cuDNN backward (the 3x3 weight gradients are: fixed-order slab sums).
+// fp32 atomics accumulate the GroupNorm reductions: a training step is not bit-reproducible run to run, like the reference's cuDNN
+// backward (the convolutions' weight / bias gradients are: fixed-order slab sums).
 #include "hl_unet_kernels.h"
 
 namespace hl {
@@ -281,26 +281,137 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_t(const WgradT p) {
     }
 }
 
-// dW[co][ci][tap] = sum over the slabs, in slab order; db[co] likewise from "tap" 9, column 0
-__global__ void k_wgrad_finish(const float *__restrict__ part, int slabs, long CoP, long CiP, int Cout, int Cin, float *__restrict__ dw,
-                               float *__restrict__ db) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)Cout * Cin) return;
-    const int co = (int)(i / Cin), ci = (int)(i - (long)co * Cin);
-    float v[9];
+// 1x1 layers (skip / zero / qkv / proj convolutions): no halo, so a tile is 64 consecutive pixels of the flattened image batch.  With
+// a single tap the only reuse there is sits in the channel block, so a workgroup owns 192 output x 64 input channels (every width of
+// the network is a multiple of 192 and of 64): wave (i, j) holds co tiles 3i..3i+2 x ci tile j - three A reads and one B read per
+// three MFMAs - and a tile moves 64 KB from L2 for 12 x 32 MFMAs, 2/3 more per byte than k_conv_wgrad's 64 x 64 block per wave.
+// Same partial / finish scheme as k_conv_wgrad_t (one "tap" + the bias slot): deterministic.
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_1x1(const WgradT p) {
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NPIX = 64;
+    __shared__ float ldsA[6][NPIX][32];
+    __shared__ float ldsB[2][NPIX][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, m = lane & 31;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int blocks = p.n_co * p.n_ci;
+    const int per_xcd = (int)(gridDim.x >> 3);
+    const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (logical >= blocks * p.slabs) return;
+    const int slab = logical / blocks, blk = logical - slab * blocks;
+    const int cob = blk / p.n_ci, cib = blk - cob * p.n_ci;
+    const int co0 = cob * 192, ci0 = cib * 64;
+    const long P = (long)p.N * p.Hout * p.Wout;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)p.dy, (short)0, (int)(P * p.dy_pitch * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, (short)0, (int)(P * p.x_pitch * 4), 0x00020000);
+    const int c4 = tid & 15, e0 = tid >> 4;
+    const bool b_ok = ci0 + 4 * c4 < p.Cx;
+    const long t0 = (long)slab * p.per_slab, t1 = min(p.tiles, t0 + p.per_slab);
+
+    f32x4 ra[12], rb[4];
+    auto fetch = [&](long tile) {
+        const long px0 = tile * NPIX;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) v[t] = 0.f;
-    float b = 0.f;
-    const long sstride = CoP * 10 * CiP;
-    const float *q = part + (long)co * 10 * CiP + ci;
-    for (int s = 0; s < slabs; ++s, q += sstride) {
+        for (int u = 0; u < 4; ++u) {
+            const long px = px0 + e0 + 16 * u;
+            const bool in = px < P;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) v[t] += q[t * CiP];
-        if (db && ci == 0) b += q[9 * CiP];
+            for (int g = 0; g < 3; ++g) {
+                const bool v = in && co0 + 64 * g + 4 * c4 < p.Cy;
+                ra[g * 4 + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rsY, v ? (unsigned)(px * p.dy_pitch + co0 + 64 * g + 4 * c4) * 4u : OOB, 0, 0));
+            }
+            rb[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rsX, (in && b_ok) ? (unsigned)(px * p.x_pitch + ci0 + 4 * c4) * 4u : OOB, 0, 0));
+        }
+    };
+    auto stage = [&]() {
+        const int half = c4 >> 3, cc = (c4 & 7) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4 *>(&ldsA[2 * g + half][e0 + 16 * u][cc]) = ra[g * 4 + u];
+            *reinterpret_cast<f32x4 *>(&ldsB[half][e0 + 16 * u][cc]) = rb[u];
+        }
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bs[3] = {0.f, 0.f, 0.f};
+    const float *la = &ldsA[3 * wi][kh][m], *lb = &ldsB[wj][kh][m];
+
+    if (t0 < t1) fetch(t0);
+    for (long tile = t0; tile < t1; ++tile) {
+        if (tile > t0) __syncthreads();
+        stage();
+        __syncthreads();
+        if (tile + 1 < t1) fetch(tile + 1);
+#pragma unroll 8
+        for (int s = 0; s < NPIX / 2; ++s) {
+            const float b = lb[(2 * s) * 32];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float a = la[(t * NPIX + 2 * s) * 32];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                bs[t] += a;
+            }
+        }
     }
+    const long CoP = (long)p.n_co * 192, CiP = (long)p.n_ci * 64;
+    float *pp = p.part + (long)slab * CoP * 2 * CiP;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) dw[i * 9 + t] = v[t];
-    if (db && ci == 0) db[co] = b;
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            pp[((long)(co0 + 32 * (3 * wi + t) + row) * 2) * CiP + ci0 + 32 * wj + m] = acc[t][r];
+        }
+    if (p.want_b && cib == 0 && wj == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float v = bs[t] + __shfl_xor(bs[t], 32);
+            if (kh == 0) pp[((long)(co0 + 32 * (3 * wi + t) + m) * 2 + 1) * CiP] = v;
+        }
+    }
+}
+
+// dW[co][ci][tap] = sum over the slabs in a fixed order; db[co] likewise from the extra "tap" (column 0 of ci block 0).
+// A block = 64 (co, ci) pairs x 4 slab groups (group g sums slabs g, g+4, ...; the four meet in LDS in group order): four times the
+// loads in flight of a thread-per-pair walk over all slabs, still a fixed order.
+template <int TAPS>
+__global__ __launch_bounds__(256) void k_wgrad_finish(const float *__restrict__ part, int slabs, long CoP, long CiP, int Cout, int Cin,
+                                                      float *__restrict__ dw, float *__restrict__ db) {
+    __shared__ float red[3][TAPS + 1][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + lane;
+    const bool ok = i < (long)Cout * Cin;
+    const int co = ok ? (int)(i / Cin) : 0, ci = ok ? (int)(i - (long)co * Cin) : 0;
+    float v[TAPS + 1];
+#pragma unroll
+    for (int t = 0; t <= TAPS; ++t) v[t] = 0.f;
+    const long sstride = CoP * (TAPS + 1) * CiP;
+    const bool wb = db && ci == 0;
+    if (ok) {
+        const float *q = part + (long)co * (TAPS + 1) * CiP + ci + grp * sstride;
+        for (int s = grp; s < slabs; s += 4, q += 4 * sstride) {
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) v[t] += q[t * CiP];
+            if (wb) v[TAPS] += q[TAPS * CiP];
+        }
+    }
+    if (grp > 0) {
+#pragma unroll
+        for (int t = 0; t <= TAPS; ++t) red[grp - 1][t][lane] = v[t];
+    }
+    __syncthreads();
+    if (grp == 0 && ok) {
+#pragma unroll
+        for (int t = 0; t <= TAPS; ++t) v[t] = ((v[t] + red[0][t][lane]) + red[1][t][lane]) + red[2][t][lane];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) dw[i * TAPS + t] = v[t];
+        if (wb) db[co] = v[TAPS];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -499,12 +610,19 @@ int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const floa
     return check_launch("k_conv_wgrad");
 }
 
-// k_conv_wgrad_t geometry: 8x8 output tiles (4x8 for stride 2), ~512 workgroups (two per CU, one round)
-static void wgrad_t_plan(int N, int Hout, int Wout, int Cout, int Cin, int stride, WgradT &p) {
-    const int TH = 8 / stride;
-    p.tilesX = (Wout + 7) / 8; p.tilesY = (Hout + TH - 1) / TH;
-    p.tiles = (long)N * p.tilesX * p.tilesY;
-    p.n_co = (Cout + 63) / 64; p.n_ci = (Cin + 63) / 64;
+// k_conv_wgrad_t geometry: 8x8 output tiles (4x8 for stride 2); k_conv_wgrad_1x1: 64 consecutive pixels; ~512 workgroups (two per CU,
+// one round)
+static void wgrad_t_plan(int N, int Hout, int Wout, int Cout, int Cin, int ks, int stride, WgradT &p) {
+    if (ks == 3) {
+        const int TH = 8 / stride;
+        p.tilesX = (Wout + 7) / 8; p.tilesY = (Hout + TH - 1) / TH;
+        p.tiles = (long)N * p.tilesX * p.tilesY;
+        p.n_co = (Cout + 63) / 64; p.n_ci = (Cin + 63) / 64;
+    } else {
+        p.tilesX = p.tilesY = 0;
+        p.tiles = ((long)N * Hout * Wout + 63) / 64;
+        p.n_co = (Cout + 191) / 192; p.n_ci = (Cin + 63) / 64;
+    }
     const long blocks = (long)p.n_co * p.n_ci;
     long slabs = 512 / blocks;
     if (slabs < 1) slabs = 1;
@@ -512,43 +630,54 @@ static void wgrad_t_plan(int N, int Hout, int Wout, int Cout, int Cin, int strid
     p.per_slab = (p.tiles + slabs - 1) / slabs;
     p.slabs = (int)((p.tiles + p.per_slab - 1) / p.per_slab);
 }
+static size_t wgrad_t_scratch(const WgradT &p, int ks) {
+    return (size_t)p.slabs * p.n_co * (ks == 3 ? 64 : 192) * (ks * ks + 1) * p.n_ci * 64 * sizeof(float);
+}
 
-static bool wgrad_t_applies(int Cx, int Cy, int ks) { return ks == 3 && Cx % 4 == 0 && Cy % 4 == 0; }
+static bool wgrad_t_applies(int Cx, int Cy, int ks, int stride, int upsample) {
+    return Cx % 4 == 0 && Cy % 4 == 0 && (ks == 3 || (ks == 1 && stride == 1 && !upsample));
+}
 
 size_t hl_conv2d_wgrad_scratch_bytes(int N, int H, int W, int Cx, int Cy, int ks, int stride, int upsample, int Cout, int Cin) {
-    if (!wgrad_t_applies(Cx, Cy, ks) || (stride != 1 && stride != 2)) return 0;
-    const int Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
+    if (!wgrad_t_applies(Cx, Cy, ks, stride, upsample) || (stride != 1 && stride != 2)) return 0;
+    const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     WgradT p{};
-    wgrad_t_plan(N, (Hv + 2 - 3) / stride + 1, (Wv + 2 - 3) / stride + 1, Cout, Cin, stride, p);
-    return (size_t)p.slabs * p.n_co * 64 * 10 * p.n_ci * 64 * sizeof(float);
+    wgrad_t_plan(N, (Hv + 2 * pad - ks) / stride + 1, (Wv + 2 * pad - ks) / stride + 1, Cout, Cin, ks, stride, p);
+    return wgrad_t_scratch(p, ks);
 }
 
 int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                             float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream) {
-    if (!wgrad_t_applies(Cx, Cy, ks)) return hl_conv2d_wgrad_nhwc(x, N, H, W, Cx, dy, Cy, ks, stride, upsample, dw, Cout, Cin, db, stream);
+    if (!wgrad_t_applies(Cx, Cy, ks, stride, upsample))
+        return hl_conv2d_wgrad_nhwc(x, N, H, W, Cx, dy, Cy, ks, stride, upsample, dw, Cout, Cin, db, stream);
     HL_REQUIRE(x && dy && dw, "hl_conv2d_wgrad_nhwc_ws: null argument");
     HL_REQUIRE(stride == 1 || (stride == 2 && !upsample), "hl_conv2d_wgrad_nhwc_ws: stride");
     HL_REQUIRE(Cin <= Cx && Cout <= Cy, "hl_conv2d_wgrad_nhwc_ws: channel counts (x %d, dy %d) must cover the weight (%d, %d)", Cx, Cy, Cout, Cin);
-    const int Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
+    const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     WgradT p{};
     p.x = x; p.x_pitch = Cx; p.N = N; p.Hin = H; p.Win = W; p.Cx = Cx;
-    p.dy = dy; p.dy_pitch = Cy; p.Hout = (Hv + 2 - 3) / stride + 1; p.Wout = (Wv + 2 - 3) / stride + 1; p.Cy = Cy;
+    p.dy = dy; p.dy_pitch = Cy; p.Hout = (Hv + 2 * pad - ks) / stride + 1; p.Wout = (Wv + 2 * pad - ks) / stride + 1; p.Cy = Cy;
     p.ups = upsample; p.want_b = db != nullptr;
     HL_REQUIRE((long)N * p.Hout * p.Wout * Cy * 4 < (1L << 31) && (long)N * H * W * Cx * 4 < (1L << 31),
                "hl_conv2d_wgrad_nhwc_ws: tensors of 2 GiB and more are not addressed");
-    wgrad_t_plan(N, p.Hout, p.Wout, Cout, Cin, stride, p);
-    const size_t need = (size_t)p.slabs * p.n_co * 64 * 10 * p.n_ci * 64 * sizeof(float);
+    wgrad_t_plan(N, p.Hout, p.Wout, Cout, Cin, ks, stride, p);
+    const size_t need = wgrad_t_scratch(p, ks);
     HL_REQUIRE(scratch && scratch_bytes >= need, "hl_conv2d_wgrad_nhwc_ws: scratch too small (%zu bytes, hl_conv2d_wgrad_scratch_bytes says %zu)",
                scratch_bytes, need);
     p.part = static_cast<float *>(scratch);
     const unsigned grid = (unsigned)(((long)p.n_co * p.n_ci * p.slabs + 7) / 8 * 8);
-    if (stride == 1) hipLaunchKernelGGL(k_conv_wgrad_t<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    if (ks == 1) hipLaunchKernelGGL(k_conv_wgrad_1x1, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (stride == 1) hipLaunchKernelGGL(k_conv_wgrad_t<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(k_conv_wgrad_t<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     int rc = check_launch("k_conv_wgrad_t");
     if (rc) return rc;
     const long n = (long)Cout * Cin;
-    hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.part, p.slabs, (long)p.n_co * 64,
-                       (long)p.n_ci * 64, Cout, Cin, dw, db);
+    if (ks == 1)
+        hipLaunchKernelGGL(k_wgrad_finish<1>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p.part, p.slabs, (long)p.n_co * 192,
+                           (long)p.n_ci * 64, Cout, Cin, dw, db);
+    else
+        hipLaunchKernelGGL(k_wgrad_finish<9>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p.part, p.slabs, (long)p.n_co * 64,
+                           (long)p.n_ci * 64, Cout, Cin, dw, db);
     return check_launch("k_wgrad_finish");
 }
 

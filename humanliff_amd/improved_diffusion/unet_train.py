@@ -10,7 +10,7 @@ include/humanliff_hip.h), activations NHWC fp32:
                              channel-transposed while they are re-laid (stride 2: zero-stuffed gradient first; nearest-x2 upsample:
                              2x2 block sums afterwards)
                    d weight  hl_conv2d_wgrad_nhwc_ws (pixels-as-K MFMA GEMM: 3x3 layers with all nine taps per workgroup from an LDS-staged
-                             tile and a deterministic slab sum, 1x1 layers straight from L2), bias gradient in the same launch
+                             tile, 1x1 layers with 192 x 64 channel blocks; deterministic slab sums), bias gradient in the same launch
     _GroupNormAct  forward   hl_groupnorm_train_forward (statistics -> affine with scale/shift -> apply + SiLU)
                    backward  hl_groupnorm_train_backward (per-(n,c) reductions, the (N,C) algebra, dx; parameter / scale-shift gradients)
     _Attention     forward   hl_attention_nhwc (fp32 flash-style kernel)
@@ -93,9 +93,9 @@ class _Conv(th.autograd.Function):
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dy2 = _pad_c(dy, 4)
             geom = (N, x.shape[1], x.shape[2], x.shape[3], dy2.shape[-1], ks, stride, ups, Cout, Cin)
-            nbytes = L.hl_conv2d_wgrad_scratch_bytes(*geom)          # per-slab partial blocks of the 3x3 kernel (0: 1x1 layers)
+            nbytes = L.hl_conv2d_wgrad_scratch_bytes(*geom)          # per-slab partial blocks (0: odd channel counts, per-tap kernel)
             part = th.empty(max(1, nbytes // 4), device=dy.device, dtype=th.float32)
-            alloc = th.empty if nbytes else th.zeros                 # the 3x3 kernel stores, the 1x1 kernel adds with atomics
+            alloc = th.empty if nbytes else th.zeros                 # the slab kernels store, the per-tap kernel adds with atomics
             dw = alloc(w4.shape, device=dy.device, dtype=th.float32)
             db = alloc((Cout,), device=dy.device, dtype=th.float32) if has_b else None
             with _lib.on(dy.device):

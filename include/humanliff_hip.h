@@ -365,11 +365,12 @@ int hl_conv2d_nhwc_bwd_data(int conv_mode, const float *dy, int N, int Ho, int W
                             int stride, int upsample, float *dx, int Cx, void *scratch, size_t scratch_bytes, void *stream);
 int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                          float *dw, int Cout, int Cin, float *db, void *stream);
-/* hl_conv2d_wgrad_nhwc_ws: the same gradients, 3x3 layers through k_conv_wgrad_t (a workgroup owns a 64x64 channel block of dW for
- * all nine taps, dY rows and input patch of an 8x8-pixel tile staged in LDS once; per-slab partial blocks in `scratch`, summed in a
- * fixed order by k_wgrad_finish - no atomics, dw / db are plainly stored and bit-reproducible).  Needs Cx, Cy multiples of 4 and
- * `scratch` of hl_conv2d_wgrad_scratch_bytes(...) bytes; 1x1 layers (and odd channel counts) fall through to hl_conv2d_wgrad_nhwc,
- * so dw / db must still be zeroed by the caller. */
+/* hl_conv2d_wgrad_nhwc_ws: the same gradients without atomics.  3x3 layers: k_conv_wgrad_t (a workgroup owns a 64x64 channel block of
+ * dW for all nine taps; dY rows and input patch of an 8x8-pixel tile staged in LDS once); 1x1 layers: k_conv_wgrad_1x1 (192 x 64 channel
+ * block, 64-pixel tiles).  Per-slab partial blocks go to `scratch` and k_wgrad_finish sums them in a fixed order: dw / db are plainly
+ * stored (no need to zero them) and bit-reproducible.  Needs Cx, Cy multiples of 4 and `scratch` of
+ * hl_conv2d_wgrad_scratch_bytes(...) bytes; other channel counts fall through to hl_conv2d_wgrad_nhwc (scratch size 0: dw / db must
+ * then be zeroed by the caller). */
 size_t hl_conv2d_wgrad_scratch_bytes(int N, int H, int W, int Cx, int Cy, int ks, int stride, int upsample, int Cout, int Cin);
 int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                             float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream);

@@ -57,32 +57,34 @@ def test_conv_backward_matches_torch_autograd(N, Cin, H, W, Cout, ks, stride, up
     assert (bd.grad.cpu().double() - br.grad).abs().max() < 1e-5 * sb
 
 
-def test_wgrad_3x3_is_bit_reproducible_and_checks_its_scratch():
-    """hl_conv2d_wgrad_nhwc_ws through the C ABI: the 3x3 kernel sums its slabs in a fixed order (no atomics) - two runs agree bit for
-    bit and match float64; a scratch smaller than hl_conv2d_wgrad_scratch_bytes is refused; a 1x1 layer needs none."""
+@pytest.mark.parametrize("ks", [3, 1])
+def test_wgrad_is_bit_reproducible_and_checks_its_scratch(ks):
+    """hl_conv2d_wgrad_nhwc_ws through the C ABI: the 3x3 and the 1x1 kernel sum their slabs in a fixed order (no atomics) - two runs
+    agree bit for bit and match float64; the gradients are stored, not accumulated; a scratch smaller than
+    hl_conv2d_wgrad_scratch_bytes is refused."""
     from humanliff_amd import _lib
     L = _lib.lib()
     g = torch.Generator().manual_seed(5)
     N, H, W, Cin, Cout = 2, 48, 40, 128, 192
     x = torch.randn((N, Cin, H, W), generator=g)
     dy = torch.randn((N, Cout, H, W), generator=g)
-    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), padding=1)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, ks, ks), dy.double(), padding=ks // 2)
     xd, dyd = nhwc(x).to(dev), nhwc(dy).to(dev)
-    nbytes = L.hl_conv2d_wgrad_scratch_bytes(N, H, W, Cin, Cout, 3, 1, 0, Cout, Cin)
-    assert nbytes > 0 and L.hl_conv2d_wgrad_scratch_bytes(N, H, W, Cin, Cout, 1, 1, 0, Cout, Cin) == 0
+    nbytes = L.hl_conv2d_wgrad_scratch_bytes(N, H, W, Cin, Cout, ks, 1, 0, Cout, Cin)
+    assert nbytes > 0
     outs = []
     for _ in range(2):
-        dw, db = torch.full((Cout, Cin, 3, 3), 7.0, device=dev), torch.full((Cout,), 7.0, device=dev)    # stored, not accumulated
+        dw, db = torch.full((Cout, Cin, ks, ks), 7.0, device=dev), torch.full((Cout,), 7.0, device=dev)    # stored, not accumulated
         part = torch.empty(nbytes // 4, device=dev)
         with _lib.on(dev):
-            _lib.check(L.hl_conv2d_wgrad_nhwc_ws(_lib.ptr(xd), N, H, W, Cin, _lib.ptr(dyd), Cout, 3, 1, 0, _lib.ptr(dw), Cout, Cin, _lib.ptr(db),
+            _lib.check(L.hl_conv2d_wgrad_nhwc_ws(_lib.ptr(xd), N, H, W, Cin, _lib.ptr(dyd), Cout, ks, 1, 0, _lib.ptr(dw), Cout, Cin, _lib.ptr(db),
                                                  _lib.ptr(part), nbytes, _lib.stream_ptr()), "hl_conv2d_wgrad_nhwc_ws")
         outs.append((dw.cpu(), db.cpu()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert (outs[0][0].double() - ref).abs().max() < 1e-5 * float(ref.abs().max())
     assert (outs[0][1].double() - dy.double().sum((0, 2, 3))).abs().max() < 1e-5 * float(dy.double().sum((0, 2, 3)).abs().max())
     with _lib.on(dev):
-        rc = L.hl_conv2d_wgrad_nhwc_ws(_lib.ptr(xd), N, H, W, Cin, _lib.ptr(dyd), Cout, 3, 1, 0, _lib.ptr(dw), Cout, Cin, _lib.ptr(db),
+        rc = L.hl_conv2d_wgrad_nhwc_ws(_lib.ptr(xd), N, H, W, Cin, _lib.ptr(dyd), Cout, ks, 1, 0, _lib.ptr(dw), Cout, Cin, _lib.ptr(db),
                                        _lib.ptr(part), nbytes - 4, _lib.stream_ptr())
     assert rc != 0 and b"scratch too small" in L.hl_last_error()
 
