@@ -439,7 +439,8 @@ def bench_fit(args, rank, world, dev, iters=10):
     r.load_state_dict(syn.render_mlp_state(3), strict=False)
     r = r.to(dev)
     tri = torch.nn.Parameter((0.1 * torch.randn((2, 4, 3, 9, 256, 256))).to(dev))
-    opt = torch.optim.Adam([{'params': list(r.parameters()), 'lr': 5e-4}, {'params': [tri], 'lr': 1e-2}], betas=(0.9, 0.999))
+    opt = torch.optim.Adam([{'params': list(r.parameters()), 'lr': 5e-4}, {'params': [tri], 'lr': 1e-2}], betas=(0.9, 0.999),
+                           fused=os.environ.get('HL_ADAMW_FUSED', '1') == '1')
     bs, R, N = 2, 2048, 128
     ro, rd, nr, fr = syn.orbit_rays(2, 8, 128, 128)
     pick = torch.nonzero(fr != 1).flatten()

@@ -66,8 +66,6 @@ class Renderer(nn.Module):
         # (recon_NeRF/lib/renderer.py:288) does not clamp and clears the second flag
         self._depth_flags = _lib.HL_RENDER_NORMALIZE_DEPTH | _lib.HL_RENDER_CLAMP_DEPTH
         self.uniforms_on_device = False      # extension: draw sample_pdf's uniforms with the device generator (see render())
-        self._packed = None
-        self._packed_key = None
         self._ws = None
 
     # ---- packing caches ------------------------------------------------------------------------
@@ -79,21 +77,22 @@ class Renderer(nn.Module):
         return out
 
     def _packed_mlp(self, device):
+        """The MLP re-laid for the kernels (17 chunks in MFMA A-fragment order), rebuilt on EVERY call: a 5 us kernel.  An
+        (address, version) keyed cache served stale weights to a fitting loop whose optimizer is `Adam(..., fused=True)` - the fused
+        optimizers (and any writer that goes through raw pointers) update parameters without touching `Tensor._version`, so the
+        loss simply stopped moving (scripts/adam_check.py; tests/test_render_train_gpu.py pins it)."""
         ts = self._mlp_tensors()
-        key = tuple((t.data_ptr(), t._version) for t in ts) + (str(device),)
-        if self._packed is None or self._packed_key != key:
-            for t in ts:
-                if not t.is_cuda:
-                    raise RuntimeError("Renderer parameters must live on the GPU (call .to('cuda')); "
-                                       "humanliff_amd has no CPU path")
-                if t.dtype != torch.float32 or not t.is_contiguous():
-                    raise RuntimeError("Renderer parameters must be contiguous fp32")
-            L = _lib.lib()
-            params = _lib.RenderMlpParams(*[C.c_void_p(t.data_ptr()) for t in ts])
-            buf = torch.empty(L.hl_render_mlp_packed_bytes() // 4, dtype=torch.float32, device=device)
-            _lib.check(L.hl_render_mlp_pack(C.byref(params), _lib.ptr(buf), _lib.stream_ptr()), "hl_render_mlp_pack")
-            self._packed, self._packed_key = buf, key
-        return self._packed
+        for t in ts:
+            if not t.is_cuda:
+                raise RuntimeError("Renderer parameters must live on the GPU (call .to('cuda')); "
+                                   "humanliff_amd has no CPU path")
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("Renderer parameters must be contiguous fp32")
+        L = _lib.lib()
+        params = _lib.RenderMlpParams(*[C.c_void_p(t.data_ptr()) for t in ts])
+        buf = torch.empty(L.hl_render_mlp_packed_bytes() // 4, dtype=torch.float32, device=device)
+        _lib.check(L.hl_render_mlp_pack(C.byref(params), _lib.ptr(buf), _lib.stream_ptr()), "hl_render_mlp_pack")
+        return buf
 
     def _packed_planes(self, planes):
         """planes (3,9,H,W) fp32 device view of one subject -> packed texel-major copy.

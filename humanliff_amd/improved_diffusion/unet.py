@@ -256,9 +256,13 @@ class UNetModel(nn.Module):
         sd = getattr(self, "_sd_cache", None)
         if sd is None:
             sd = self._sd_cache = dict(self.state_dict(keep_vars=True))
+        # The packed copy (1.9 GB, tens of ms to build) is kept while nothing can have changed the parameters: same tensors, same
+        # versions, and no training-mode forward since it was built - `torch.optim.AdamW(fused=True)` (and any raw-pointer writer)
+        # updates parameters WITHOUT bumping Tensor._version, so after a training forward the next sampling call re-lays the weights.
         key = [(v.data_ptr(), v._version) for v in sd.values()]
-        if self._hip is not None and self._hip[2] == key:
+        if self._hip is not None and self._hip[2] == key and not getattr(self, "_hip_stale", False):
             return self._hip[0]
+        self._hip_stale = False
         L = _lib.lib()
         if self._hip is not None:
             L.hl_unet_destroy(self._hip[0])
@@ -338,6 +342,7 @@ class UNetModel(nn.Module):
             if self.use_3d_aware or self.cond_type == "cross_attention":
                 raise NotImplementedError("the HIP training path does not cover use_3d_aware=True / cond_type='cross_attention' (sampling does)")
             from .unet_train import forward_train
+            self._hip_stale = True     # an optimizer step follows; fused optimizers do not bump Tensor._version (see _bind)
             return forward_train(self, x, timesteps, x_cond, y)
         handle = self._bind()
         L = _lib.lib()

@@ -1,0 +1,51 @@
+"""Developer check: torch.optim.Adam(fused=True) against the default implementation inside the tri-plane fitting loop (gradients come
+from the HIP backward as views of one flat buffer, at offsets that are not 16-byte aligned)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from humanliff_amd import synthetic as syn
+from humanliff_amd.NeRF import Renderer
+dev = torch.device("cuda:0")
+
+
+def run(fused, iters=6):
+    torch.manual_seed(0)
+    r = Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, test=False)
+    r.load_state_dict(syn.render_mlp_state(3), strict=False)
+    r = r.to(dev)
+    r.uniforms_on_device = True
+    tri = torch.nn.Parameter((0.1 * torch.randn((2, 4, 3, 9, 256, 256))).to(dev))
+    opt = torch.optim.Adam([{'params': list(r.parameters()), 'lr': 5e-4}, {'params': [tri], 'lr': 1e-2}], betas=(0.9, 0.999), fused=fused)
+    bs, R, N = 2, 2048, 128
+    ro, rd, nr, fr = syn.orbit_rays(2, 8, 128, 128)
+    pick = torch.nonzero(fr != 1).flatten()[:R]
+    ro, rd, nr, fr = (t[pick].to(dev) for t in (ro, rd, nr, fr))
+    target = torch.rand((bs, R, 3), device=dev)
+    tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].expand(bs, 2, 3).to(dev)}
+    ids, layer = torch.tensor([0, 1]), torch.tensor([1, 3])
+    t = torch.linspace(0., 1., steps=N, device=dev)
+    torch.manual_seed(1)
+    losses = []
+    for it in range(iters):
+        z = (nr[:, None] * (1. - t) + fr[:, None] * t)[None].expand(bs, R, N).contiguous()
+        out = r.render(tp, None, z, ro[None].expand(bs, R, 3), rd[None].expand(bs, R, 3), nr[None, :, None].expand(bs, R, 1),
+                       fr[None, :, None].expand(bs, R, 1), tri[ids, layer], N, False)
+        loss = ((out["rgb_map"] - target) ** 2).mean() + 0.1 * ((out["acc_map"] - 1.0) ** 2).mean()
+        loss.backward()
+        if it == 0:
+            info = [(n, tuple(p.grad.shape), p.grad.is_contiguous(), p.grad.data_ptr() % 16) for n, p in r.named_parameters() if p.grad is not None]
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss.detach()))
+    return losses, [p.detach().clone() for p in r.parameters()] + [tri.detach().clone()], info
+
+
+la, pa, info = run(False)
+lb, pb, _ = run(False)
+lf, pf, _ = run(True)
+print("grad layout (name, shape, contiguous, address % 16):", info)
+print("losses default:", [round(v, 6) for v in la])
+print("losses default again:", [round(v, 6) for v in lb])
+print("losses fused:  ", [round(v, 6) for v in lf])
+print("param max-abs default vs default:", [float((a - b).abs().max()) for a, b in zip(pa, pb)])
+print("param max-abs fused vs default:  ", [float((a - b).abs().max()) for a, b in zip(pa, pf)])

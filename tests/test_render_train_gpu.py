@@ -108,14 +108,16 @@ def test_gradients_match_oracle_larger(dev):
         close(d_mlp[k], o_mlp[k], k)
 
 
-def test_fitting_loop_two_subjects(dev):
+@pytest.mark.parametrize("fused", [False, True])
+def test_fitting_loop_two_subjects(dev, fused):
     """The shape of recon_NeRF/run_nerf_batch.py:236-265: tri_planes is a Parameter indexed per subject, batch of two subjects, MSE on
-    rgb and acc, Adam on both parameter groups; the loss must go down and only the rendered subjects receive tri-plane gradient."""
+    rgb and acc, Adam on both parameter groups; the loss must go down and only the rendered subjects receive tri-plane gradient.
+    fused=True: the fused optimizers do not bump Tensor._version; a version-keyed cache of the re-laid MLP once froze this loop."""
     from humanliff_amd import synthetic as syn
     torch.manual_seed(0)
     r = make_renderer(syn.render_mlp_state(3), dev)
     tri = torch.nn.Parameter((0.1 * torch.randn((3, 4, 3, 9, 32, 32))).to(dev))
-    opt = torch.optim.Adam([{'params': list(r.parameters()), 'lr': 5e-4}, {'params': [tri], 'lr': 1e-2}], betas=(0.9, 0.999))
+    opt = torch.optim.Adam([{'params': list(r.parameters()), 'lr': 5e-4}, {'params': [tri], 'lr': 1e-2}], betas=(0.9, 0.999), fused=fused)
     ro, rd, nr, fr = syn.orbit_rays(2, 8, 32, 32)
     pick = torch.nonzero(fr != 1).flatten()[:256]
     ro, rd, nr, fr = (t[pick].to(dev) for t in (ro, rd, nr, fr))

@@ -177,8 +177,11 @@ def test_training_losses_backward_matches_reference_on_hip():
           f"worst relative gradient error over {len(g['keys'])} reference tensors {worst:.2e}, sum|grad| rel {abs(tot - float(g['grad_abs_sum'])) / float(g['grad_abs_sum']):.2e}")
 
 
-def test_ddp_style_wrapper_trains_on_hip():
-    """train_util.py:236 hands training_losses the DDP-wrapped model: a wrapper whose forward calls the module must work and step."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_ddp_style_wrapper_trains_on_hip(fused):
+    """train_util.py:236 hands training_losses the DDP-wrapped model: a wrapper whose forward calls the module must work and step.
+    fused=True: torch's fused optimizers update parameters without bumping Tensor._version - the sampling path must still see the
+    new weights (its packed copy is re-laid after a training forward)."""
     from tests.test_train_loss_cpu import inputs, tiny_model
 
     class Wrapper(torch.nn.Module):          # the call pattern of DistributedDataParallel: forward(*a, **k) -> self.module(*a, **k)
@@ -192,10 +195,14 @@ def test_ddp_style_wrapper_trains_on_hip():
             return self.module(*a, **k)
 
     model, diffusion = tiny_model()
-    wrapped = Wrapper(model.to(dev).train())
+    model.to(dev)
     x0, xc = (t.to(dev) for t in inputs())
     t, y = torch.tensor([999, 17], device=dev), torch.tensor([3, 0], device=dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    model.eval()
+    with torch.no_grad():                    # a sampling call BEFORE training: the packed copy of the initial weights exists
+        out_before = model(x0, t, xc, y=y)
+    wrapped = Wrapper(model.train())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=fused)
     noise = torch.randn(x0.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
     vals = []
     for _ in range(5):
@@ -206,6 +213,9 @@ def test_ddp_style_wrapper_trains_on_hip():
         vals.append(float(loss.detach()))
     assert wrapped.calls == 5 and vals[-1] < vals[0]
     model.eval()
-    with torch.no_grad():                    # the updated weights are picked up by the inference path (re-bound by parameter version)
+    with torch.no_grad():                    # the updated weights are picked up by the inference path
         out = model(x0, t, xc, y=y)
+        twin = model.forward_autograd(x0, t, xc, y=y)        # PyTorch ops on the parameters as they are now
     assert torch.isfinite(out).all()
+    assert (out - twin).abs().max() < 1e-4 * max(1.0, float(twin.abs().max())), float((out - twin).abs().max())
+    assert (out - out_before).abs().max() > 1e-3             # ... and they did move
