@@ -243,6 +243,11 @@ class UNetModel(nn.Module):
         c.aware3d = 1 if self.use_3d_aware else 0
         return c
 
+    def train(self, mode=True):           # entering training mode: optimizer steps are coming (fused ones do not bump Tensor._version)
+        if mode and not self.training:
+            self._hip_stale = True
+        return super().train(mode)
+
     def _apply(self, fn, *a, **kw):       # .to() / .cuda() / .float(): parameter objects may be replaced
         self._sd_cache = None
         return super()._apply(fn, *a, **kw)
@@ -322,6 +327,8 @@ class UNetModel(nn.Module):
         the gradient tests compare with the reference's vectors and with the HIP training path.  Nothing in the product calls it:
         training goes through forward() -> unet_train.forward_train (HIP forward and backward), sampling through the HIP forward."""
         from .unet_autograd import forward_autograd
+        if th.is_grad_enabled():
+            self._hip_stale = True     # a differentiable call: parameters may be updated behind Tensor._version (see _bind)
         return forward_autograd(self, x, timesteps, x_cond, y)
 
     def forward(self, x, timesteps, x_cond=None, y=None):
