@@ -301,6 +301,157 @@ def e2e_chain(model, dev, golden=None):
             "workload": "F4 net, DDIM-10, B=1, 2 cloth layers chained through x_cond -> reshape(1,3,9,256,256) -> one 128x128 view @32+32"}
 
 
+def ddim50_parity(model, dev, golden=None):
+    """The sampler at the length the shipped scripts use, against the REFERENCE's own outputs (tests/golden/f4_ddim50.npz, made by
+    tests/golden/gen_golden_ddim50.py from /root/reference): production network, `timestep_respacing="ddim50"`, B = 1, cloth layer 1
+    conditioned on a seeded x_cond, all 50 steps of ddim_sample_loop_progressive on injected noise; compared after steps 1, 10, 25, 40
+    and 50 (every 8th pixel + whole-tensor checksums).  Used by tests/test_fullsize_gpu.py and the `parity` object of the bench line."""
+    import numpy as np
+    from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
+    g = np.load(golden or os.path.join(ROOT, "tests", "golden", "f4_ddim50.npz"))
+    diffusion = create_gaussian_diffusion(steps=1000, learn_sigma=False, noise_schedule="linear", timestep_respacing="ddim50")
+    stride, keep, layer = int(g["stride"]), [int(k) for k in g["keep"]], int(g["layer"])
+    n = {"i": 0}
+
+    def draw(shape):
+        gg = torch.Generator().manual_seed(9100 + n["i"])
+        n["i"] += 1
+        return torch.randn(tuple(shape), generator=gg)
+
+    shape = (1, 27, 256, 256)
+    x_cond = (torch.randn(shape, generator=torch.Generator().manual_seed(77)) * 0.3).clamp_(-1, 1)
+    assert abs(float(x_cond.double().abs().sum()) - float(g["x_cond_ck"][1])) < 1e-6 * float(g["x_cond_ck"][1])
+    y = torch.full((1,), layer, dtype=torch.int64, device=dev)
+    steps = []
+    orig = torch.randn_like
+    torch.randn_like = lambda ref: draw(ref.shape).to(ref.device)
+    try:
+        x_T = draw(shape).to(dev)
+        for k, out in enumerate(diffusion.ddim_sample_loop_progressive(model, shape, x_cond=x_cond.to(dev), noise=x_T, clip_denoised=True,
+                                                                       model_kwargs={"y": y}, device=dev), 1):
+            if k in keep:
+                s_ = out["sample"].cpu()
+                want = torch.from_numpy(g[f"step{k}_sub"])
+                got = s_[:, :, ::stride, ::stride]
+                ck = float(g[f"step{k}_ck"][1])
+                steps.append({"step": k, "max_abs": float((got - want).abs().max()), "psnr_db": round(_psnr(got, want), 2),
+                              "abs_sum_rel": abs(float(s_.double().abs().sum()) - ck) / ck, "value_abs_max": float(want.abs().max())})
+    finally:
+        torch.randn_like = orig
+    final_row = float((s_[0, :, 100, :] - torch.from_numpy(g["final_row100"])).abs().max())
+    chmean = float(np.abs(s_.double().mean(dim=(0, 2, 3)).numpy() - g["final_chmean"]).max())
+    return {"steps": steps, "final_row100_max_abs": final_row, "final_channel_mean_max_abs": chmean, "ndraws": n["i"], "ndraws_reference": int(g["ndraws"]),
+            "max_abs": max(s["max_abs"] for s in steps), "psnr_db": min(s["psnr_db"] for s in steps),
+            "against": "the reference's outputs on identical noise (tests/golden/f4_ddim50.npz <- tests/golden/gen_golden_ddim50.py)",
+            "workload": "F4 net, DDIM-50 (ddim_sample_loop_progressive), B=1, cloth layer 1 with a seeded x_cond"}
+
+
+def e2e_slice(model, dev, rank, world, n_layers=4, ddim=50, n_views=185, res=512, n_check_views=3, n_check_rays=1024, oracle=True):
+    """The real per-GPU slice of BASELINE configs[3] / [4] (scripts/triplane_sample_layered.py:112-213): per rank ONE subject x
+    `n_layers` cloth layers chained through x_cond x DDIM-`ddim` on the production network (B = 1, like the shipped sampling script),
+    the finished tri-plane reshaped to (1,3,9,256,256) and rendered into `n_views` orbit views of res x res at 128 + 128 samples, the
+    samples and the uint8 images gathered over the ranks - humanliff_amd.distributed.sample_and_render, the code the multi-GPU script
+    runs.  Timed as a whole and per stage (HIP events around the sampling and the render part); with `oracle`, `n_check_rays` rays of
+    each of `n_check_views` views are rendered again by the CPU oracle from the SAME generated tri-plane, rays and uniforms (renderer
+    parity decoupled from sampler drift) and compared (PSNR, colours in [0,1])."""
+    import numpy as np
+    from humanliff_amd import distributed as hd, synthetic as syn
+    from humanliff_amd.NeRF import Renderer, render_view
+    from humanliff_amd.SynBodyView_datasets import camera_rays
+    from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
+    diffusion = create_gaussian_diffusion(steps=1000, learn_sigma=False, noise_schedule="linear", timestep_respacing=f"ddim{ddim}")
+    rend = Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, smpl_type="smpl", test=True)
+    mlp = syn.render_mlp_state(3)
+    rend.load_state_dict(mlp, strict=False)
+    rend = rend.to(dev)
+    shape = (27, 256, 256)
+    tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].to(dev)}
+    bounds_np = np.asarray(syn.WORLD_BOUNDS, dtype=np.float64)
+    u = torch.rand((res * res, 128), device=dev, generator=torch.Generator(device=dev).manual_seed(5 + rank))
+    ev = {k: torch.cuda.Event(enable_timing=True) for k in ("s0", "s1", "r1")}
+    state = {"first_render": True, "calls": 0}
+
+    def sample_fn(x_cond, layer, ids):
+        if state["calls"] == 0:
+            ev["s0"].record()
+        state["calls"] += 1
+        g = torch.Generator().manual_seed(4000 + 100 * ids[0] + layer)
+        noise = torch.randn((len(ids),) + shape, generator=g).to(dev)
+        y = torch.full((len(ids),), layer, dtype=torch.int64, device=dev)
+        return diffusion.ddim_sample_loop(model, (len(ids),) + shape, x_cond=x_cond, noise=noise, clip_denoised=True, model_kwargs={"y": y}, device=dev)
+
+    def cam(v):
+        K, c2w, c = syn.orbit_camera(v, n_views, res, res)
+        R = c2w.T.copy()
+        return K, R, (-R @ c).reshape(3, 1)
+
+    def render_fn(sid, sample, v):
+        if state["first_render"]:
+            ev["s1"].record()
+            state["first_render"] = False
+        planes = sample.reshape(1, 3, 9, 256, 256)                                  # triplane_sample_layered.py:158
+        K, R, T = cam(v)
+        return render_view(res, res, K, R, T, planes, tp, rend, n_samples=128, n_importance=128, u=u)[0]
+
+    # warm-up outside the timed region: one B=1 forward (binds the B=1 workspace) and one small view (packs the MLP)
+    with torch.no_grad():
+        model(torch.zeros((1,) + shape, device=dev), torch.zeros((1,), dtype=torch.int64, device=dev), torch.zeros((1,) + shape, device=dev),
+              y=torch.zeros((1,), dtype=torch.int64, device=dev))
+    render_view(*syn_cam64(syn), torch.zeros((1, 3, 9, 256, 256), device=dev), tp, rend, n_samples=128, n_importance=128)
+    barrier(world)
+    t0 = time.perf_counter()
+    samples, images = hd.sample_and_render(sample_fn, render_fn, world, n_layers, shape, 1, n_views, (res, res, 3), dev, as_uint8=True)
+    ev["r1"].record()
+    barrier(world)
+    secs = max_over_ranks(time.perf_counter() - t0, world, dev)
+    t_sample, t_render = ev["s0"].elapsed_time(ev["s1"]) * 1e-3, ev["s1"].elapsed_time(ev["r1"]) * 1e-3
+    steps, rays = world * n_layers * ddim, world * n_views * res * res
+    assert samples.shape == (world, n_layers) + shape and images.shape == (world, n_views, res, res, 3) and images.dtype == torch.uint8
+    assert torch.isfinite(samples).all()
+    out = {"workload": f"configs[3]/[4] per-GPU slice: 1 subject per GPU x {n_layers} cloth layers x DDIM-{ddim} (production F4 net, B=1, layers chained "
+                       f"through x_cond) -> reshape(1,3,9,256,256) -> {n_views} orbit views {res}x{res} @128+128 -> gather of samples (fp32) and "
+                       "images (uint8); humanliff_amd.distributed.sample_and_render",
+           "seconds": round(secs, 3), "subjects": world, "denoise_steps": steps, "rays": rays,
+           "sampling": {"seconds_rank0": round(t_sample, 3), "denoise_steps_per_sec_per_gpu": round(n_layers * ddim / t_sample, 2), "batch": 1},
+           "rendering": {"seconds_rank0": round(t_render, 3), "mrays_per_sec_per_gpu": round(n_views * res * res / t_render / 1e6, 4),
+                         "ms_per_view": round(t_render * 1e3 / n_views, 3),
+                         "note": "includes device ray generation (hl_camera_rays), the uint8 conversion and the per-subject image gather"},
+           "subjects_per_hour_per_gpu": round(3600.0 / secs, 1), "image_mean": float(images.float().mean()) / 255.0,
+           "sample_abs_max": float(samples.abs().max())}
+    if oracle and rank == 0:
+        from oracle import render_oracle as ro
+        planes = samples[0, -1].reshape(3, 9, 256, 256)
+        checks, psnrs = [], []
+        for i in range(n_check_views):
+            v = (i * n_views) // n_check_views
+            K, R, T = cam(v)
+            rays_o, rays_d, near, far, _ = camera_rays(res, res, K, R, T, bounds_np, dev, return_mask=False)
+            hit = torch.nonzero(far != 1).flatten()                                  # rays that meet the box (the others see the far plane only)
+            pick = hit[torch.randperm(hit.numel(), generator=torch.Generator().manual_seed(v))[:n_check_rays].to(dev)]
+            got = rend.render(tp, None, None, rays_o[pick][None], rays_d[pick][None], near[pick][None, :, None], far[pick][None, :, None],
+                              planes[None], 128, False, n_samples=128, u=u[pick][None])
+            with torch.no_grad():
+                rgb, acc, depth = ro.render_rays(mlp, planes.cpu(), torch.tensor(syn.WORLD_BOUNDS), rays_o[pick].cpu(), rays_d[pick].cpu(),
+                                                 near[pick].cpu(), far[pick].cpu(), 128, 128, u=u[pick].cpu())
+            # the same rays inside the full-view launch: the image the slice produced (uint8, truncated like the reference's writer)
+            full = images[0, v].reshape(-1, 3)[pick].cpu().float() / 255.0
+            assert float((full - (rgb.clamp(0, 1) * 255).to(torch.uint8).float() / 255.0).abs().max()) <= 1.0 / 255.0 + 1e-6
+            p_ = _psnr(got["rgb_map"][0].cpu(), rgb)
+            psnrs.append(p_)
+            checks.append({"view": v, "rays": int(pick.numel()), "psnr_db": round(p_, 2), "max_abs": float((got["rgb_map"][0].cpu() - rgb).abs().max()),
+                           "acc_max_abs": float((got["acc_map"][0].cpu() - acc).abs().max()), "depth_max_abs": float((got["depth_map"][0].cpu() - depth).abs().max())})
+        out["parity"] = {"psnr_db": round(min(psnrs), 2), "views": checks,
+                         "what": f"{n_check_rays} box-hitting rays of each of {n_check_views} views of the GENERATED tri-plane: HIP render vs the CPU oracle on identical "
+                                 "rays / uniforms (north-star bar: PSNR >= 45 dB); the uint8 pixels of the slice's own images equal the oracle's within one grey level"}
+    return out
+
+
+def syn_cam64(syn):
+    K, c2w, c = syn.orbit_camera(0, 4, 64, 64)
+    R = c2w.T.copy()
+    return 64, 64, K, R, (-R @ c).reshape(3, 1)
+
+
 def bench_train(model, diffusion, dev, rank, world, iters=3, B=2):
     """SURVEY 8(f) rank 4, UNet half (not a BASELINE metric): one training step of the production network at the reference's
     microbatch (README.md:104 `--microbatch 2`): GaussianDiffusion.training_losses -> backward through the HIP kernels
@@ -620,6 +771,15 @@ def cpu_baseline_unet(sd, threads, model=None, dev=None):
            "batch4": {"value": round(4 / dt4, 4), "unit": "denoise-steps/sec", "sample": "same, batch 4 (the configuration `value` is quoted on), 1 timed step"}}
     parity = None
     if model is not None:
+        # the headline dispatch: the B=4 forward of the oracle above against the HIP forward on the same inputs (kernel selection depends
+        # on the batch size - at B=4 the 128-pixel level runs k_conv_wino4, at B=1 it does not; the census says which kernels ran)
+        with torch.no_grad():
+            got4 = model(x4.to(dev), torch.full((4,), 500, device=dev), torch.zeros_like(x4).to(dev), y=torch.zeros((4,), dtype=torch.int64, device=dev)).cpu()
+        census = model.dispatch_census()
+        b4 = {"max_abs": float((got4 - eps4).abs().max()), "psnr_db": round(_psnr(got4, eps4), 2), "output_abs_mean": float(eps4.abs().mean()),
+              "dispatch": {k: v[:6] for k, v in census.items() if any(v)},
+              "what": "one forward of the production net at B=4 (t=500), HIP vs the oracle; dispatch = conv launches per kernel family and "
+                      "resolution level (256, 128, 64, 32, 16, 8 pixels)"}
         from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
         d = create_gaussian_diffusion(steps=1000, timestep_respacing="")
         k = {"i": 0}
@@ -638,7 +798,8 @@ def cpu_baseline_unet(sd, threads, model=None, dev=None):
             torch.randn_like = orig
         parity = {"steps": 1 + n_timed, "max_abs": float((xg.cpu() - x).abs().max()), "psnr_db": round(_psnr(xg.cpu(), x), 2),
                   "value_scale": float(x.abs().max()),
-                  "what": "x after 4 recurrent p_sample steps (t = 999..996) of the production net, B=1, HIP vs the oracle on identical x_T / noise"}
+                  "what": "x after 4 recurrent p_sample steps (t = 999..996) of the production net, B=1, HIP vs the oracle on identical x_T / noise",
+                  "forward_b4": b4}
     return out, parity
 
 
@@ -691,6 +852,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity legs (end-to-end chain vs the reference's vectors, HIP vs oracle samples)")
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the per-GPU slice of configs[3]/[4] (4 layers x DDIM-50 -> 185 views 512x512)")
+    ap.add_argument("--e2e-views", type=int, default=185)
+    ap.add_argument("--e2e-ddim", type=int, default=50)
+    ap.add_argument("--e2e-layers", type=int, default=4)
     ap.add_argument("--no-train", action="store_true", help="skip the UNet training-step leg (SURVEY 8(f) rank 4)")
     ap.add_argument("--no-fit", action="store_true", help="skip the tri-plane fitting leg (SURVEY 8(f) rank 4)")
     ap.add_argument("--no-bf16x3-leg", action="store_true", help="skip the extra measurement of the opt-in bf16x3 conv mode")
@@ -712,7 +877,8 @@ def main():
         chain = e2e_chain(model, dev)
         parity = {"psnr_db": min(l["image_psnr_db"] for l in chain["layers"]), "max_abs": max(l["image_max_abs"] for l in chain["layers"]),
                   "triplane_psnr_db": min(l["triplane_psnr_db"] for l in chain["layers"]),
-                  "triplane_max_abs": max(l["triplane_max_abs"] for l in chain["layers"]), "end_to_end": chain}
+                  "triplane_max_abs": max(l["triplane_max_abs"] for l in chain["layers"]), "end_to_end": chain,
+                  "ddim50_vs_reference": ddim50_parity(model, dev)}
     cpu = step_parity = None
     threads = min(len(os.sched_getaffinity(0)), 32)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -721,6 +887,10 @@ def main():
         cpu, step_parity = cpu_baseline_unet(sd, threads, None if args.no_parity else model, dev)
         if parity is not None:
             parity["denoise_steps_vs_oracle"] = step_parity
+    e2e = None
+    if not args.no_e2e:
+        e2e = e2e_slice(model, dev, rank, world, n_layers=args.e2e_layers, ddim=args.e2e_ddim, n_views=args.e2e_views,
+                        oracle=(world == 1 and not args.no_parity))
     train = None
     if not args.no_train:
         from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
@@ -753,7 +923,7 @@ def main():
                        "parallelism": f"replicas x{world} (subjects sharded, final all-gather only)",
                        "gflop_per_sample_step": UNET_GFLOP_PER_SAMPLE_STEP},
             "step_tflops": round(world * args.batch * args.steps * UNET_GFLOP_PER_SAMPLE_STEP / secs / 1e3, 2),
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "render": render, "fit": fit, "train": train,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "render": render, "fit": fit, "train": train,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -105,6 +105,9 @@ struct Net {
     struct Span { int cat; size_t a, b; double flops, exec; };   // algorithmic FLOPs and the FLOPs the kernel actually issued
     std::vector<Span> spans;
     size_t ev_used = 0;
+    // which kernel family each convolution of the LAST forward took, per resolution level (hl_unet_dispatch_census):
+    // [path 0 direct / 1 Winograd F(2x2) / 2 bf16x3 / 3 Winograd F(4x4)][log2(H / H_out)]
+    int64_t census[4][8] = {};
     ~Net() {
         for (auto e : ev_pool) if (e) hipEventDestroy(e);
         for (auto e : ev_block) if (e) hipEventDestroy(e);
@@ -465,6 +468,11 @@ struct Exec {
         a.stats = st1; a.stats2 = st2;
         const size_t e0 = span_begin();
         ok(hl::conv2d(a, st));
+        {
+            int lvl = 0;
+            while (lvl < 7 && (out.H << lvl) < H) ++lvl;
+            n.census[a.path & 3][lvl] += 1;
+        }
         const double fl = 2.0 * (double)out.pixels() * c.Cout * c.Cin * c.ks * c.ks;
         // Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36; bf16x3: six bf16 MFMA products per fp32 product
         span_end(CAT_CONV, e0, fl, a.path == 1 ? fl * (16.0 / 36.0) : (a.path == 3 ? fl * 0.25 : (a.path == 2 ? fl * 6.0 : fl)));
@@ -840,8 +848,16 @@ int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float 
     e.act_need = dry.act_need;
     e.act_ws = reinterpret_cast<float *>(static_cast<char *>(workspace) + (dry.off + 255) / 256 * 256);
     e.act_ws2 = e.act_ws + dry.act_need;
+    for (auto &row : n.census) for (auto &v : row) v = 0;
     e.forward(x, t, t_float, x_cond, y, out);
     return e.rc;
+}
+
+int hl_unet_dispatch_census(void *handle, int64_t *h_counts) {
+    HL_REQUIRE(handle && h_counts, "hl_unet_dispatch_census: null argument");
+    const Net &n = *static_cast<Net *>(handle);
+    for (int p = 0; p < 4; ++p) for (int l = 0; l < 8; ++l) h_counts[p * 8 + l] = n.census[p][l];
+    return HL_OK;
 }
 
 int hl_unet_profile(void *handle, int enable) {

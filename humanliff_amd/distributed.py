@@ -100,10 +100,15 @@ class ImageGather:
         dst = self.buf[k].view((-1,) + tuple(item.shape[1:])) if item.dim() > 0 else self.buf[k]
         self.pending.append((dist.all_gather_into_tensor(dst, item, async_op=True), item))   # keep `item` alive until the wait
 
-    def result(self):
+    def result(self, root=None):
+        """Waits for the gathers; returns the global (n_items, ...) tensor.  root: only that rank materialises it (the transposed copy
+        of the whole buffer - 9 GB of uint8 for 64 subjects x 185 views x 512^2 - is what only the rank that writes the images needs,
+        rank 0 in the reference, triplane_sample_layered.py:214-219); the other ranks get None."""
         for w, _ in self.pending:
             w.wait()
         self.pending = []
+        if root is not None and self.rank != root:
+            return None
         if self.world == 1:
             return self.buf[:, 0][:self.n]
         return self.buf.transpose(0, 1).reshape((self.world * self.per,) + tuple(self.buf.shape[2:]))[:self.n]
@@ -136,12 +141,13 @@ def render_views_sharded(render_fn, n_views, image_shape, device, as_uint8=False
     return gather_shards(imgs, n_views, as_uint8=as_uint8)
 
 
-def sample_and_render(sample_fn, render_fn, n_subjects, n_layers, shape, batch, n_views, image_shape, device, as_uint8=True):
+def sample_and_render(sample_fn, render_fn, n_subjects, n_layers, shape, batch, n_views, image_shape, device, as_uint8=True, images_root=None):
     """The end-to-end flow of BASELINE configs[3] / [4] (scripts/triplane_sample_layered.py:112-213) over the ranks it runs on:
     every rank samples the layers of its block of subjects (sample_fn as in sample_layered_sharded), renders all views of each of its
     finished subjects - render_fn(subject_id, final_sample (C,H,W), view) -> image_shape tensor in [0,1] - and hands each subject's
     views to an asynchronous gather that overlaps the next subject's renders.  One gather of the samples, per-subject gathers of the
-    images (uint8 by default).  Returns (samples (n_subjects, n_layers, C, H, W), images (n_subjects, n_views, *image_shape))."""
+    images (uint8 by default).  Returns (samples (n_subjects, n_layers, C, H, W), images (n_subjects, n_views, *image_shape));
+    images_root = r: only rank r assembles the image tensor, the others return None for it (ImageGather.result)."""
     idx, _ = shard_indices(n_subjects)
     local = torch.empty((len(idx), n_layers) + tuple(shape), dtype=torch.float32, device=device)
     for s0 in range(0, len(idx), batch):
@@ -155,4 +161,4 @@ def sample_and_render(sample_fn, render_fn, n_subjects, n_layers, shape, batch, 
         views = torch.stack([render_fn(sid, local[k, -1], v) for v in range(n_views)])
         gather.put(k, views)
     samples = gather_shards(local, n_subjects)
-    return samples, gather.result()
+    return samples, gather.result(root=images_root)

@@ -185,8 +185,11 @@ class GaussianDiffusion:
         """Direct callers of p_sample / ddim_sample / p_mean_variance: a timestep outside this (possibly respaced) schedule - e.g. an
         ORIGINAL-schedule index handed to a respaced diffusion - raises IndexError before anything is launched, like the reference's
         table lookups (gaussian_diffusion.py:859; on a GPU the reference dies with a device-side assert in respace.py:119 instead).
-        One device read-back; the sampling loops generate their own indices and skip it.  The update kernel never reads outside its
-        table either way (it writes NaN for such a row)."""
+        One device read-back (a host sync per call); the sampling loops generate their own indices and skip it, and callers that drive
+        p_sample / ddim_sample themselves in a tight loop can switch it off with `diffusion.check_timesteps = False`.  The update
+        kernel never reads outside its table either way (it writes NaN for such a row)."""
+        if not getattr(self, "check_timesteps", True):
+            return
         lo, hi = int(t.min()), int(t.max())
         if lo < 0 or hi >= self.num_timesteps:
             raise IndexError(f"timestep {hi if hi >= self.num_timesteps else lo} is out of range for a {self.num_timesteps}-step schedule")

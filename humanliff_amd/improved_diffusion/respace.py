@@ -4,6 +4,8 @@ space_timesteps (:7-60) -> kept original-schedule steps; SpacedDiffusion (:63-11
 the kept steps; _WrappedModel (:113-122) maps loop indices back to ORIGINAL timesteps before the UNet
 sees them.  Here the map lives on the device once (the reference rebuilds the tensor every call).
 """
+import weakref
+
 import numpy as np
 import torch as th
 
@@ -66,28 +68,45 @@ class SpacedDiffusion(GaussianDiffusion):
         return self._wrap_model(model)
 
     def _wrap_model(self, model):
-        """One wrapper per model object, kept on the diffusion (the reference builds a new one - and a new device tensor of the
-        timestep map - on every call, respace.py:97-122).  The entry holds the model itself, so its id cannot be recycled."""
+        """One wrapper per model object (the reference builds a new one - and a new device tensor of the timestep map - on every call,
+        respace.py:97-122).  The cache holds the model WEAKLY: a model carries its parameters plus the packed HIP copy and workspaces
+        (several GB on the device), and deleting it must free them while the diffusion object lives on.  Callables that cannot be weakly
+        referenced (a bare function object can, a bound C callable cannot) get a throwaway wrapper like in the reference."""
         if isinstance(model, _WrappedModel):
             return model
         hit = self._wrapped.get(id(model))
-        if hit is None or hit.model is not model:
-            if len(self._wrapped) >= 4:
-                self._wrapped.clear()
-            hit = self._wrapped[id(model)] = _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
-        return hit
+        if hit is not None and hit[0]() is model:
+            return hit[1]
+        wrapper = _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps, weak=True)
+        if wrapper._ref is None:
+            return wrapper
+        key = id(model)
+        self._wrapped[key] = (weakref.ref(model, lambda _, k=key, d=self._wrapped: d.pop(k, None)), wrapper)
+        return wrapper
 
     def _scale_timesteps(self, t):
         return t  # scaling is done by the wrapped model
 
 
 class _WrappedModel:
-    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps):
-        self.model = model
+    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps, weak=False):
+        # weak=True (the cached wrappers of SpacedDiffusion): the wrapper must not keep the model alive
+        self._ref = self._strong = None
+        if weak:
+            try:
+                self._ref = weakref.ref(model)
+            except TypeError:
+                self._strong = model
+        else:
+            self._strong = model
         self.timestep_map = timestep_map
         self.rescale_timesteps = rescale_timesteps
         self.original_num_steps = original_num_steps
         self._maps = {}
+
+    @property
+    def model(self):
+        return self._strong if self._ref is None else self._ref()
 
     def parameters(self):
         return self.model.parameters()

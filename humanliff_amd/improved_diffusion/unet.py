@@ -312,6 +312,16 @@ class UNetModel(nn.Module):
             _lib.check(_lib.lib().hl_unet_set_conv_mode(self._hip[0], self._conv_mode), "hl_unet_set_conv_mode")
         return self
 
+    def dispatch_census(self):
+        """Which kernel family every convolution of the LAST inference forward took (hl_unet_dispatch_census):
+        {"direct" | "wino2" | "bf16x3" | "wino4": [launches per resolution level, level = log2(H / H_out)]}.  Kernel selection depends
+        on the batch size, so parity tests state with this which dispatch they covered."""
+        if self._hip is None:
+            raise RuntimeError("dispatch_census: no forward has run yet")
+        counts = (C.c_int64 * 32)()
+        _lib.check(_lib.lib().hl_unet_dispatch_census(self._hip[0], counts), "hl_unet_dispatch_census")
+        return {name: [int(counts[p * 8 + l]) for l in range(8)] for p, name in enumerate(("direct", "wino2", "bf16x3", "wino4"))}
+
     def __del__(self):
         try:
             if self._hip is not None:
@@ -339,10 +349,23 @@ class UNetModel(nn.Module):
             assert x_cond is not None, f"cond_type='{self.cond_type}' needs x_cond (zeros for the first layer)"
         if self.cond_type == "concat":        # unet.py:572-573: the condition rides along as extra input channels (in_channels counts both)
             assert x_cond is not None, "cond_type='concat' needs x_cond"
-            x, x_cond = th.cat([x, x_cond], dim=1), None
+            if self.use_3d_aware:
+                # unet.py:566-573 rolls the planes of x and of x_cond out separately, (B, C/3, H, 3W) each, and only then joins the
+                # channels: plane p of the network input is [x_p | cond_p].  The kernels cut the joined tensor into three equal channel
+                # ranges, so the join is made per plane here.
+                B_, Cx, H_, W_ = x.shape
+                Cc_ = x_cond.shape[1]
+                assert Cx % 3 == 0 and Cc_ % 3 == 0, (Cx, Cc_)
+                x = th.cat([x.reshape(B_, 3, Cx // 3, H_, W_), x_cond.reshape(B_, 3, Cc_ // 3, H_, W_)], dim=2).reshape(B_, Cx + Cc_, H_, W_)
+                x_cond = None
+            else:
+                x, x_cond = th.cat([x, x_cond], dim=1), None
         if not x.is_cuda:
             raise RuntimeError("UNetModel.forward needs CUDA(HIP) tensors; there is no CPU path")
-        if th.is_grad_enabled() and self.training and (x.requires_grad or self._any_param_requires_grad()):
+        # Which path: parameter gradients are wanted in training mode only (a sampling call on a model whose parameters merely have
+        # requires_grad=True - the default of a fresh module - stays on the inference kernels); a gradient with respect to x (guidance /
+        # cond_fn callers) is honoured in eval mode too instead of being dropped silently.
+        if th.is_grad_enabled() and (x.requires_grad or (self.training and self._any_param_requires_grad())):
             # training call (train_util.py:236 reaches this through the DDP wrapper): gradients are wanted, take the differentiable path -
             # the same network as a chain of autograd.Functions whose forward and backward are HIP kernels (unet_train.py).
             # Sampling never gets here: the loops run under no_grad and the scripts call model.eval()

@@ -108,7 +108,13 @@ def forward_autograd(model, x, timesteps, x_cond=None, y=None):
     """UNetModel.forward's contract (x (N,C,H,W), timesteps (N,), x_cond, y) with autograd; fp32."""
     if model.num_classes is not None:
         assert y is not None and y.shape == (x.shape[0],)
-    if model.cond_type == "concat":          # unet.py:572-573
+    aware = getattr(model, "use_3d_aware", False)
+    if aware:                                # unet.py:566-570: the planes side by side - x and x_cond each, BEFORE a 'concat' joins them
+        roll = lambda v: th.cat(v.chunk(3, dim=1), -1)  # noqa: E731
+        x = roll(x)
+        if x_cond is not None:
+            x_cond = roll(x_cond)
+    if model.cond_type == "concat" and x_cond is not None:   # unet.py:572-573
         x, x_cond = th.cat([x, x_cond], dim=1), None
     emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
     context = None
@@ -122,12 +128,6 @@ def forward_autograd(model, x, timesteps, x_cond=None, y=None):
             context = xp.unsqueeze(1)
     if model.num_classes is not None:
         emb = emb + model.label_emb(y)
-    aware = getattr(model, "use_3d_aware", False)
-    if aware:                                # unet.py:566-570: the planes side by side
-        c3 = x.shape[1] // 3
-        x = th.cat([x[:, :c3], x[:, c3:2 * c3], x[:, 2 * c3:]], -1)
-        if x_cond is not None:
-            x_cond = th.cat([x_cond[:, :c3], x_cond[:, c3:2 * c3], x_cond[:, 2 * c3:]], -1)
     hs = []
     h = x.float()
     for blk in model.input_blocks:

@@ -26,6 +26,8 @@ both against the reference's vectors.
 import ctypes as C
 import math
 
+import weakref
+
 import torch as th
 import torch.nn.functional as F
 
@@ -235,7 +237,7 @@ def forward_train(model, x, timesteps, x_cond=None, y=None):
         raise RuntimeError("the HIP training path needs CUDA(HIP) tensors; there is no CPU path")
     if model.num_classes is not None:
         assert y is not None and y.shape == (x.shape[0],)
-    if model.cond_type == "concat":          # unet.py:572-573
+    if model.cond_type == "concat" and x_cond is not None:   # unet.py:572-573 (UNetModel.forward has already joined them when it is the caller)
         x, x_cond = th.cat([x, x_cond], dim=1), None
     emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
     if model.cond_type == "AdaGN":           # unet.py:574-578 (like the embedding MLP: three tiny torch modules, autograd's own backward)
@@ -264,4 +266,9 @@ def forward_train(model, x, timesteps, x_cond=None, y=None):
             skip = skip + hs_cond.pop()
         h = _run(blk, th.cat([h, skip], dim=-1), emb)
     out = conv(gn_act(h, model.out[0]), model.out[2])                       # (N, H, W, C_out)
-    return out.permute(0, 3, 1, 2).contiguous().to(x.dtype)
+    out = out.permute(0, 3, 1, 2).contiguous().to(x.dtype)
+    if out.requires_grad:
+        # backward is what precedes an optimizer step: from here on the packed inference weights count as stale, also when a sampling
+        # call between this forward and the step has re-packed them meanwhile (fused optimizers do not bump Tensor._version)
+        out.register_hook(lambda g, m=weakref.ref(model): (setattr(m(), "_hip_stale", True) if m() is not None else None, g)[1])
+    return out

@@ -318,6 +318,12 @@ int hl_unet_profile_read(void *handle, double *h_ms, double *h_flops, int64_t *h
  * 16/36 of their algorithmic multiplies, HL_CONV_BF16X3 layers six bf16 products per fp32 product. */
 int hl_unet_profile_read_ex(void *handle, double *h_ms, double *h_flops, double *h_exec_flops, int64_t *h_launches);
 
+/* Which kernel family every convolution of the LAST hl_unet_forward took: h_counts[path * 8 + level] launches, path 0 = direct
+ * implicit GEMM (k_conv_dma / k_conv), 1 = Winograd F(2x2,3x3) (k_conv_wino), 2 = bf16x3 emulation (k_conv_bf3), 3 = Winograd F(4x4,3x3)
+ * (k_conv_wino4); level = log2(H / H_out) of the layer's output.  Kernel selection depends on the batch size (a layer takes a Winograd
+ * kernel only where its workgroups fill the chip), so parity tests use this to state WHICH dispatch they covered. */
+int hl_unet_dispatch_census(void *handle, int64_t *h_counts);
+
 /* Fused sampler update (everything after the model call in p_sample / ddim_sample,
  * gaussian_diffusion.py:293-333, 356-388, 484-529) for EPSILON prediction with a fixed
  * variance.  coef: (T, 8) fp32 per-kept-timestep table built by the host mirror from the

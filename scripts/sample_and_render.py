@@ -60,7 +60,7 @@ def main():
     # sampling, rendering and the gathers (samples: one all-gather; images: per subject, uint8, asynchronous behind the next
     # subject's renders) - humanliff_amd.distributed.sample_and_render, the same code the world-size-2 CPU test drives
     samples, images = hd.sample_and_render(sample_fn, render_fn, args.subjects, args.layers, shape, args.batch, args.views, (H, W, 3), dev,
-                                           as_uint8=not args.float_images)
+                                           as_uint8=not args.float_images, images_root=0)   # only rank 0 writes images (:214-219)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     t1 = t0
     if rank == 0:

@@ -132,9 +132,11 @@ def unet_concat():
     print("cross_attention keys", len(ks), "out abs mean", float(y.abs().mean()), "effect of x_cond", out["xattn_cond_effect"])
     # use_3d_aware=True (unet.py:158-166, 208-214, 566-570, 613-614): 27-channel tri-planes, a 9-channel network on the planes side by
     # side; with the control tower (whose ResBlocks stay plain, :477-518) and without conditioning
-    for tag, cond in (("aware3d_controlnet", "controlnet"), ("aware3d_plain", "")):
+    # ... and with cond_type='concat' (:566-573: x and x_cond are rolled out plane by plane FIRST and joined after, so plane p of the
+    # 18-channel network input is [x_p | cond_p])
+    for tag, cond in (("aware3d_controlnet", "controlnet"), ("aware3d_plain", ""), ("aware3d_concat", "concat")):
         a = model_and_diffusion_defaults()
-        a.update(dict(in_channels=9, out_channels=9, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=True,
+        a.update(dict(in_channels=18 if cond == "concat" else 9, out_channels=9, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=True,
                       cond_type=cond, use_3d_aware=True, rescale_timesteps=False, dropout=0.0, image_size=32, num_channels=32,
                       num_res_blocks=1, attention_resolutions="16,8"))
         model, _ = create_model_and_diffusion(**a)

@@ -71,9 +71,12 @@ def _worker(rank, world, port, q):
     ok7 = all(min(s, 4) // per5 == rank for s, _ in rendered)          # every rank renders only the subjects it sampled
     smp_f, img_f = hd.sample_and_render(sample_fn, render_fn, 5, 2, (2, 4, 4), 2, 3, (2, 2, 3), dev, as_uint8=False)
     ok8 = img_f.dtype == torch.float32 and torch.allclose(img_f[:, :, 0, 0, 0], torch.tensor([[(s * 10 + v) / 100.0 for v in range(3)] for s in range(5)]))
+    # 6) images assembled on rank 0 only (the other ranks skip the transposed copy of the gathered buffer)
+    _, img_r = hd.sample_and_render(sample_fn, render_fn, 5, 2, (2, 4, 4), 2, 3, (2, 2, 3), dev, as_uint8=True, images_root=0)
+    ok9 = (img_r is None) if rank != 0 else torch.equal(img_r, img)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, ok1, ok2, ok3, ok4, ok5, ok6, ok7, ok8))
+    q.put((rank, ok1, ok2, ok3, ok4, ok5, ok6, ok7, ok8, ok9))
 
 
 @pytest.mark.timeout(120)

@@ -335,7 +335,7 @@ def test_learn_sigma_network_samples_end_to_end():
     assert out.shape == (2, 27, 32, 32) and torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6
 
 
-@pytest.mark.parametrize("tag,cond", [("aware3d_controlnet", "controlnet"), ("aware3d_plain", "")])
+@pytest.mark.parametrize("tag,cond", [("aware3d_controlnet", "controlnet"), ("aware3d_plain", ""), ("aware3d_concat", "concat")])
 def test_unet_3d_aware_matches_reference(tag, cond):
     """use_3d_aware=True (unet.py:158-166, 208-214, 566-570, 613-614): the three planes of a 27-channel tri-plane side by side through a
     9-channel network whose ResBlocks feed every plane the axis means of the other two; against the reference's forward, plus the
@@ -343,7 +343,9 @@ def test_unet_3d_aware_matches_reference(tag, cond):
     from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
     g = np.load(os.path.join(GOLDEN, "unet_cond_types.npz"))
     a = model_and_diffusion_defaults()
-    a.update(dict(in_channels=9, out_channels=9, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=True,
+    # ('concat': the reference rolls the planes of x and x_cond out separately and joins them after, unet.py:566-573 - plane p of the
+    # 18-channel network input is [x_p | cond_p])
+    a.update(dict(in_channels=18 if cond == "concat" else 9, out_channels=9, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=True,
                   cond_type=cond, use_3d_aware=True, rescale_timesteps=False, dropout=0.0, image_size=32, num_channels=32,
                   num_res_blocks=1, attention_resolutions="16,8", timestep_respacing="ddim4"))
     model, diffusion = create_model_and_diffusion(**a)

@@ -65,3 +65,26 @@ def test_samplers_never_use_the_torch_twin(monkeypatch):
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             diffusion.training_losses(model, x0, xc, torch.tensor([5, 6]), model_kwargs={"y": torch.tensor([0, 1])})
+
+
+@pytest.mark.parametrize("tag,cond", [("aware3d_controlnet", "controlnet"), ("aware3d_plain", ""), ("aware3d_concat", "concat")])
+def test_twin_3d_aware_matches_reference_on_cpu(tag, cond):
+    """The PyTorch-op statement of the network (the CPU-checkable twin the gradient tests lean on) against the reference's forward for
+    use_3d_aware=True, including cond_type='concat': the reference rolls the planes of x and of x_cond out SEPARATELY and joins the
+    channels after (unet.py:566-573), so plane p of the network input is [x_p | cond_p]."""
+    g = np.load(os.path.join(GOLDEN, "unet_cond_types.npz"))
+    a = model_and_diffusion_defaults()
+    a.update(dict(in_channels=18 if cond == "concat" else 9, out_channels=9, class_cond=True, learn_sigma=False, num_heads=4,
+                  use_scale_shift_norm=True, cond_type=cond, use_3d_aware=True, rescale_timesteps=False, dropout=0.0, image_size=32,
+                  num_channels=32, num_res_blocks=1, attention_resolutions="16,8"))
+    model, _ = create_model_and_diffusion(**a)
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert len(ks) == int(g[f"{tag}_nkeys"])
+    model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn((2, 27, 32, 32), generator=gen)
+    xc = torch.randn((2, 27, 32, 32), generator=gen).clamp(-1, 1) * 0.7
+    with torch.no_grad():
+        y = model.forward_autograd(x, torch.tensor([999, 17]), xc if cond else None, y=torch.tensor([3, 0]))
+    want = torch.from_numpy(g[f"{tag}_out"])
+    assert y.shape == want.shape and (y - want).abs().max() < 2e-5

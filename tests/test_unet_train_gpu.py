@@ -219,3 +219,90 @@ def test_ddp_style_wrapper_trains_on_hip(fused):
     assert torch.isfinite(out).all()
     assert (out - twin).abs().max() < 1e-4 * max(1.0, float(twin.abs().max())), float((out - twin).abs().max())
     assert (out - out_before).abs().max() > 1e-3             # ... and they did move
+
+
+@pytest.mark.parametrize("cond,cin", [("concat", 54), ("AdaGN", 27)])
+def test_training_other_cond_types_on_hip(cond, cin):
+    """cond_type='concat' / 'AdaGN' through the product training path (training_losses -> model(...) -> forward_train): UNetModel.forward
+    joins x and x_cond for 'concat' BEFORE handing over (unet.py:572-573) - forward_train must not join them again - and 'AdaGN' adds the
+    projected condition to the embedding.  Loss and every parameter gradient against the PyTorch-op statement of the same network
+    (forward_autograd, pinned to the reference's forward by tests/test_e2e_gpu.py::test_unet_cond_types_match_reference / _adagn_)."""
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+    from humanliff_amd import synthetic as syn
+    a = model_and_diffusion_defaults()
+    size = 256 if cond == "AdaGN" else 32                 # AdaGN's Linear(64*64, E) fixes the input at 256x256 (narrow net there)
+    a.update(dict(in_channels=cin, out_channels=27, class_cond=True, learn_sigma=False, num_heads=2, use_scale_shift_norm=True,
+                  cond_type=cond, rescale_timesteps=False, dropout=0.0, image_size=size, num_channels=32, num_res_blocks=1,
+                  attention_resolutions="16,8" if size == 32 else "32,16,8"))
+    model, diffusion = create_model_and_diffusion(**a)
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+    model = model.to(dev).train()
+    g = torch.Generator().manual_seed(21)
+    B = 1 if size == 256 else 2
+    x0 = torch.randn((B, 27, size, size), generator=g).clamp(-1, 1).to(dev)
+    xc = (torch.randn((B, 27, size, size), generator=g).clamp(-1, 1) * 0.7).to(dev)
+    noise = torch.randn((B, 27, size, size), generator=g).to(dev)
+    t, y = torch.tensor([999, 17][:B], device=dev), torch.tensor([3, 0][:B], device=dev)
+    loss = diffusion.training_losses(model, x0, xc, t, model_kwargs={"y": y}, noise=noise)["loss"]
+    assert loss.requires_grad
+    loss.mean().backward()
+    got = {k: p.grad.clone() for k, p in model.named_parameters()}
+    assert all(v is not None for v in got.values())
+    model.zero_grad(set_to_none=True)
+    twin = lambda x, ts, x_cond=None, y=None: model.forward_autograd(x, ts, x_cond, y)  # noqa: E731
+    loss_t = diffusion.training_losses(twin, x0, xc, t, model_kwargs={"y": y}, noise=noise)["loss"]
+    loss_t.mean().backward()
+    assert (loss.detach() - loss_t.detach()).abs().max() < 1e-5 * max(1.0, float(loss_t.abs().max()))
+    worst = 0.0
+    for k, p in model.named_parameters():
+        ref = p.grad
+        scale = float(ref.abs().max())
+        if scale == 0.0:
+            assert float(got[k].abs().max()) == 0.0, k
+            continue
+        err = float((got[k] - ref).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 5e-4, (k, err)
+    print(f"cond_type={cond}: HIP training path vs PyTorch-op twin, worst relative gradient error {worst:.2e}")
+
+
+def test_sampling_between_forward_and_fused_step_sees_new_weights():
+    """A preview sample drawn BETWEEN the training forward and the optimizer step re-packs the inference weights (and clears the stale
+    mark); the backward pass that follows marks them stale again, so sampling after a fused optimizer step (which does not bump
+    Tensor._version) still sees the new parameters."""
+    from tests.test_train_loss_cpu import inputs, tiny_model
+    model, diffusion = tiny_model()
+    model.to(dev).train()
+    x0, xc = (t.to(dev) for t in inputs())
+    t, y = torch.tensor([999, 17], device=dev), torch.tensor([3, 0], device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+    loss = diffusion.training_losses(model, x0.clamp(-1, 1), xc, t, model_kwargs={"y": y})["loss"].mean()
+    with torch.no_grad():
+        preview = model(x0, t, xc, y=y)          # inference kernels; packs the CURRENT weights
+    loss.backward()
+    opt.step()
+    with torch.no_grad():
+        after = model(x0, t, xc, y=y)
+        twin = model.forward_autograd(x0, t, xc, y=y)
+    assert (after - preview).abs().max() > 1e-3               # the step moved the weights and sampling sees it
+    assert (after - twin).abs().max() < 1e-4 * max(1.0, float(twin.abs().max()))
+
+
+def test_eval_mode_input_gradient_is_not_dropped():
+    """Guidance / cond_fn style callers ask for d out / d x on an eval() model: the differentiable HIP path answers (the inference
+    kernels would return a tensor without grad_fn)."""
+    from tests.test_train_loss_cpu import inputs, tiny_model
+    model, _ = tiny_model()
+    model.to(dev).eval()
+    x0, xc = (t.to(dev) for t in inputs())
+    t, y = torch.tensor([999, 17], device=dev), torch.tensor([3, 0], device=dev)
+    x = x0.clone().requires_grad_(True)
+    out = model(x, t, xc, y=y)
+    assert out.requires_grad
+    (gx,) = torch.autograd.grad(out.square().sum(), x)
+    xt = x0.clone().requires_grad_(True)
+    (gt,) = torch.autograd.grad(model.forward_autograd(xt, t, xc, y=y).square().sum(), xt)
+    assert (gx - gt).abs().max() < 5e-4 * float(gt.abs().max())
+    with torch.no_grad():                                     # and a plain sampling call on the same model still takes the inference kernels
+        assert not model(x0, t, xc, y=y).requires_grad
