@@ -125,10 +125,11 @@ def test_production_ddim50_matches_reference(production):
     for s in res["steps"]:
         print(s)
         # DDIM with eta = 0 re-injects nothing, so differences accumulate over the 50 network evaluations; values reach 5.3 mid-loop and
-        # [-1, 1] at the end.  DDIM-10 of the chain test measures 8e-5; bounds here ~10x the first measurement on MI355X.
-        assert s["max_abs"] < 2e-3, s
-        assert s["psnr_db"] > 95.0 and s["abs_sum_rel"] < 2e-6, s
-    assert res["final_row100_max_abs"] < 2e-3 and res["final_channel_mean_max_abs"] < 2e-6
+        # [-1, 1] at the end.  Measured on MI355X: max-abs 7.7e-7 / 1.8e-6 / 9.0e-6 / 2.6e-5 / 3.0e-5 after steps 1 / 10 / 25 / 40 / 50
+        # (PSNR 142 ... 118.7 dB), |sum| relative 2e-8 ... 1.6e-7.  Bounds ~10x that.
+        assert s["max_abs"] < 3e-4, s
+        assert s["psnr_db"] > 105.0 and s["abs_sum_rel"] < 2e-6, s
+    assert res["final_row100_max_abs"] < 3e-4 and res["final_channel_mean_max_abs"] < 1e-6
 
 
 def test_production_batch_independence(production):

@@ -253,14 +253,14 @@ def test_training_other_cond_types_on_hip(cond, cin):
     twin = lambda x, ts, x_cond=None, y=None: model.forward_autograd(x, ts, x_cond, y)  # noqa: E731
     loss_t = diffusion.training_losses(twin, x0, xc, t, model_kwargs={"y": y}, noise=noise)["loss"]
     loss_t.mean().backward()
-    assert (loss.detach() - loss_t.detach()).abs().max() < 1e-5 * max(1.0, float(loss_t.abs().max()))
+    assert float((loss.detach() - loss_t.detach()).abs().max()) < 1e-5 * max(1.0, float(loss_t.detach().abs().max()))
     worst = 0.0
+    gscale = max(float(p.grad.abs().max()) for p in model.parameters())
     for k, p in model.named_parameters():
         ref = p.grad
-        scale = float(ref.abs().max())
-        if scale == 0.0:
-            assert float(got[k].abs().max()) == 0.0, k
-            continue
+        # relative to the tensor's own largest entry, with a floor: the bias of a convolution that feeds a GroupNorm has a gradient of
+        # exactly zero in exact arithmetic (the mean subtraction removes it) - both sides hold rounding noise there
+        scale = max(float(ref.abs().max()), 1e-4 * gscale)
         err = float((got[k] - ref).abs().max()) / scale
         worst = max(worst, err)
         assert err < 5e-4, (k, err)
