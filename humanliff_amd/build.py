@@ -11,6 +11,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhumanliff_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+# per-file overrides (the last -std wins): k_conv_wino4w's compile-time slot schedule uses templated lambdas
+FILE_FLAGS = {"hl_conv_wino4w.hip": ["-std=c++20"] + os.environ.get("HL_W4W_FLAGS", "").split()}   # HL_W4W_FLAGS: developer variants (-D...)
 
 
 def _sources():
@@ -40,7 +42,7 @@ def build(force=False, verbose=False):
     for src in _sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -48,6 +48,30 @@ struct ConvArgs {
     mutable int stat_slots;
     int plan_only;       // 1: no launch, only set `path` (w / w_wino / w_bf3 are then just non-null markers of what could be packed)
 };
+// kernel-side argument block of the convolution kernels (filled by conv2d)
+struct ConvK {
+    const float *in; long in_pitch; int N, Hin, Win, Cin;
+    int Hout, Wout, ks, stride, ups, taps;
+    const float *w; const void *w_bf3; const float *w_wino; long Ktot; const float *bias; int Cout;
+    const float *cA; const float *cB; int act;
+    float *out; long out_pitch; const float *res; long res_pitch;
+    float *out2; long out2_pitch; const float *res2; long res2_pitch;
+    int out_nchw; long M; int wrows;
+    int kt_per;        // k-tiles per split (blockIdx.z); gridDim.z == 1 -> whole K
+    int n_mtiles, n_nblocks;
+    float *partial;    // split-K: raw accumulators [z][M][Cout]
+    // GroupNorm statistics of the OUTPUT, emitted by the epilogue for the layer that will normalise it (nn.py:17-19): per slot of
+    // consecutive output pixels (32 rows of M; a Winograd workgroup: one column parity of its 16x8 block = 64 pixels) and per
+    // output channel (sum, sum of squares) of the stored value (after bias / residual), [slot][Cout][2]; null = not wanted.
+    // st2: the same for out2.  Deterministic (no atomics); k_gn_coef_st folds the slots of an image.
+    float *st1, *st2;
+};
+
+// k_conv_wino4w (hl_conv_wino4w.hip): Winograd F(4x4,3x3) with 64 output channels per workgroup, one wave per SIMD, 18 accumulator
+// tiles per wave in the accumulator registers; reads the weights conv_pack_weights_wino4 laid out.  LDS: conv_wino4w_lds_bytes().
+size_t conv_wino4w_lds_bytes();
+int conv_wino4w_launch(const ConvK &p, int ups, int blk, int splits, hipStream_t st);
+
 inline size_t conv_stats_floats(long out_pixels, int Cout) { return (size_t)(out_pixels / 32 + 1) * Cout * 2; }
 size_t conv_splitk_ws_bytes();
 int conv2d(const ConvArgs &a, hipStream_t st);

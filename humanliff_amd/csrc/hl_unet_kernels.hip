@@ -44,23 +44,7 @@ __host__ __device__ inline void kt_decode(int kt, int ncc, int taps, int &cc, in
     cc = cg * KG + (r - tap * g);
 }
 
-struct ConvK {
-    const float *in; long in_pitch; int N, Hin, Win, Cin;
-    int Hout, Wout, ks, stride, ups, taps;
-    const float *w; const void *w_bf3; const float *w_wino; long Ktot; const float *bias; int Cout;
-    const float *cA; const float *cB; int act;
-    float *out; long out_pitch; const float *res; long res_pitch;
-    float *out2; long out2_pitch; const float *res2; long res2_pitch;
-    int out_nchw; long M; int wrows;
-    int kt_per;        // k-tiles per split (blockIdx.z); gridDim.z == 1 -> whole K
-    int n_mtiles, n_nblocks;
-    float *partial;    // split-K: raw accumulators [z][M][Cout]
-    // GroupNorm statistics of the OUTPUT, emitted by the epilogue for the layer that will normalise it (nn.py:17-19): per slot of
-    // consecutive output pixels (32 rows of M; a Winograd workgroup: one column parity of its 16x8 block = 64 pixels) and per
-    // output channel (sum, sum of squares) of the stored value (after bias / residual), [slot][Cout][2]; null = not wanted.
-    // st2: the same for out2.  Deterministic (no atomics); k_gn_coef_st folds the slots of an image.
-    float *st1, *st2;
-};
+// (struct ConvK - the kernel-side argument block of every convolution kernel - lives in hl_unet_kernels.h: k_conv_wino4w has its own file)
 
 // (sum, sumsq) of a lane's values -> combined over the two lane halves (same channel, other pixels) -> [slot][Cout][2]
 template <int NV>
@@ -2679,6 +2663,10 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     const long wino4_blocks = (long)a.out.N * (a.out.H / 16) * (a.out.W / 32) * (a.Cout / 32);
     const bool wino4 = dma && a.w_wino4 && !a.w_bf3 && a.ks == 3 && a.stride == 1 && a.out.H % 16 == 0 && a.out.W % 32 == 0 &&
                        a.Cout % 32 == 0 && (long)a.Cout * a.in.C * 144 < (1L << 31) && wino4_blocks >= wino4_thr;
+    // ... and among those, the 64-channel one-wave-per-SIMD variant where 32x16-pixel x 64-channel workgroups still give every CU one
+    const char *w4w_env = getenv("HL_WINO4W");   // developer switch while the kernel is being tuned: 0 = k_conv_wino4 only
+    const int w4w_mode = w4w_env ? atoi(w4w_env) : 1;
+    const bool wino4w = wino4 && w4w_mode != 0 && a.Cout % 64 == 0 && wino4_blocks / 2 >= (w4w_mode == 2 ? 1024 : 256);
     if (wino4) {
         wino = false;
         splits = 1;
@@ -2711,6 +2699,21 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix,
                                a.in.C, a.coefA, a.coefB, a.act, a.act_ws);
             p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0;
+        }
+        if (wino4 && wino4w) {
+            // 64 output channels per workgroup, one wave per SIMD, accumulators in the accumulator registers (hl_conv_wino4w.hip)
+            a.path = 3;
+            p.w_wino = a.w_wino4;
+            p.n_nblocks = a.Cout / 64;
+            p.n_mtiles = a.out.N * (a.out.H / 16) * (a.out.W / 32);
+            if (splits == 1 && a.stats && !a.out_nchw) {   // statistics from the epilogue: slot = (32x16 block, round, wave) = 32 pixels
+                p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
+                a.stat_slots = (a.out.H / 16) * (a.out.W / 32) * 16;
+            }
+            int rc = conv_wino4w_launch(p, a.ups, blk4 ? 1 : 0, splits, st);
+            if (rc) return rc;
+            if (splits > 1) return finish("k_conv_wino4w");
+            return HL_OK;
         }
         if (wino4) {
             a.path = 3;
