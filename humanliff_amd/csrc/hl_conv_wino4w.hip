@@ -340,8 +340,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
         auto body = [&](auto sc, f32x4 (&Vc)[9], f32x4 (&Vn)[9], int t) {
             constexpr int S = decltype(sc)::value;                    // = t & 1: stage of patch t
             const int tl1 = min(t + 1, ntiles - 1), tl2 = min(t + 2, ntiles - 1);
-            const int soffU0 = ubase + t * (36 * 1024), soffU1 = ubase + tl1 * (36 * 1024);
-            const int soffA2 = (kt0 + tl2) * kstep;
+            const int soffU0 = (HL_W4W_ABL & 64) ? ubase : ubase + t * (36 * 1024), soffU1 = (HL_W4W_ABL & 64) ? ubase : ubase + tl1 * (36 * 1024);   // (64: hot weights)
+            const int soffA2 = (HL_W4W_ABL & 128) ? kt0 * kstep : (kt0 + tl2) * kstep;                                                                 // (128: hot patch)
             [&]<int... J>(std::integer_sequence<int, J...>) {
                 ([&] {
                     constexpr int Jc = J, f = J >> 3, idx = J & 7, s = idx >> 1, cb = idx & 1;
@@ -399,97 +399,109 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
     // stray patch pieces must not land in the exchange buffer; the last MFMAs have left the pipe before their results are read
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
 
-    // ---- output transform: the 36 frequencies of a (tile, channel) meet in LDS, four rounds of 8 tiles x 64 channels: [freq][tile][cout].
-    // A thread finishes one tile for two neighbouring channels (ds_read_b64; 8-byte stores: 32 lanes cover the 256 bytes of a pixel).
+    // ---- output transform: the 36 frequencies of a (tile, channel) meet in LDS, two rounds of 16 tiles x 64 channels: [freq][tile][cout]
+    // (144 KB - the workgroup has the CU's LDS to itself).  A thread finishes one tile for FOUR neighbouring channels (ds_read_b128, 16-byte
+    // stores: 16 lanes cover the 256 bytes of a pixel) - the epilogue is bound by the number of store instructions, not by their bytes.
     const int fbase = (3 * (wave >> 1)) * 6 + 3 * (wave & 1);
-    const int mloc = tid >> 5, np2 = (tid & 31) * 2, n = n0 + np2;
-    f32x2 bs = {0.f, 0.f};
-    if (p.bias && !p.partial) bs = *reinterpret_cast<const f32x2 *>(p.bias + n);
+    const int mloc = tid >> 4, nq = (tid & 15) * 4, n = n0 + nq;
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && !p.partial) bs = *reinterpret_cast<const f32x4 *>(p.bias + n);
     const long hw = (long)Hv * Wv;
+    auto w4_out4 = [](f32x4 m0, f32x4 m1, f32x4 m2, f32x4 m3, f32x4 m4, f32x4 m5, f32x4 (&y)[4]) {
+        const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+        y[0] = (m0 + s1) + s2;
+        y[1] = __builtin_elementwise_fma((f32x4)(W4_B), d2, W4_A * d1);
+        y[2] = __builtin_elementwise_fma((f32x4)(W4_B * W4_B), s2, (W4_A * W4_A) * s1);
+        y[3] = __builtin_elementwise_fma((f32x4)(W4_B * W4_B * W4_B), d2, __builtin_elementwise_fma((f32x4)(W4_A * W4_A * W4_A), d1, m5));
+    };
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 2; ++q) {
         __syncthreads();
-        [&]<int... I>(std::integer_sequence<int, I...>) {   // I = (f, cb, rr): accumulator register 4q + rr of tile f*2+cb holds tile 8q + rr + 4 half
+        [&]<int... I>(std::integer_sequence<int, I...>) {   // I = (f, cb, rr): accumulator register 8q + rr of tile f*2+cb holds tile 16q + (rr&3) + 8(rr>>2) + 4 half
             ([&] {
-                constexpr int f = I / 8, cb = (I >> 2) & 1, rr = I & 3;
+                constexpr int f = I / 16, cb = (I >> 3) & 1, rr = I & 7;
                 const int F = fbase + (f / 3) * 6 + (f % 3);
-                float v;
-                if (q == 0) v = acc_get<f * 2 + cb, rr>(accv);
-                else if (q == 1) v = acc_get<f * 2 + cb, 4 + rr>(accv);
-                else if (q == 2) v = acc_get<f * 2 + cb, 8 + rr>(accv);
-                else v = acc_get<f * 2 + cb, 12 + rr>(accv);
-                lds[(F * 8 + rr + 4 * half) * 64 + cb * 32 + (lane & 31)] = v;
+                const float v = q == 0 ? acc_get<f * 2 + cb, rr>(accv) : acc_get<f * 2 + cb, 8 + rr>(accv);
+                lds[(F * 16 + (rr & 3) + 8 * (rr >> 2) + 4 * half) * 64 + cb * 32 + (lane & 31)] = v;
             }(), ...);
-        }(std::make_integer_sequence<int, 72>{});
+        }(std::make_integer_sequence<int, 144>{});
         __syncthreads();
-        const float *zz = lds + mloc * 64 + np2;
-        f32x2 z[4][6];                                                // rows of A^T applied: z[p][j]
+        const float *zz = lds + mloc * 64 + nq;
+        f32x4 z[4][6];                                                // rows of A^T applied: z[p][j]
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            f32x2 col[4];
-            w4_out(*reinterpret_cast<const f32x2 *>(zz + (0 * 6 + j) * 512), *reinterpret_cast<const f32x2 *>(zz + (1 * 6 + j) * 512),
-                   *reinterpret_cast<const f32x2 *>(zz + (2 * 6 + j) * 512), *reinterpret_cast<const f32x2 *>(zz + (3 * 6 + j) * 512),
-                   *reinterpret_cast<const f32x2 *>(zz + (4 * 6 + j) * 512), *reinterpret_cast<const f32x2 *>(zz + (5 * 6 + j) * 512), col);
+            f32x4 col[4];
+            w4_out4(*reinterpret_cast<const f32x4 *>(zz + (0 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(zz + (1 * 6 + j) * 1024),
+                    *reinterpret_cast<const f32x4 *>(zz + (2 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(zz + (3 * 6 + j) * 1024),
+                    *reinterpret_cast<const f32x4 *>(zz + (4 * 6 + j) * 1024), *reinterpret_cast<const f32x4 *>(zz + (5 * 6 + j) * 1024), col);
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) z[pr][j] = col[pr];
         }
-        const int Tg = q * 8 + mloc, oy = y0 + 4 * (Tg >> 3), ox = x0 + 4 * (Tg & 7);
+        const int Tg = q * 16 + mloc, oy = y0 + 4 * (Tg >> 3), ox = x0 + 4 * (Tg & 7);
         const long m0 = ((long)img * Hv + oy) * Wv + ox;              // pixel (pr, qc) of the tile: m0 + pr*Wv + qc
-        f32x2 v[16];
+        f32x4 v[16];
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
-            f32x2 row[4];
-            w4_out(z[pr][0], z[pr][1], z[pr][2], z[pr][3], z[pr][4], z[pr][5], row);
+            f32x4 row[4];
+            w4_out4(z[pr][0], z[pr][1], z[pr][2], z[pr][3], z[pr][4], z[pr][5], row);
 #pragma unroll
             for (int qc = 0; qc < 4; ++qc) v[pr * 4 + qc] = row[qc] + bs;
         }
         if (p.partial) {   // split-K: the output transform is linear, so slabs are summed in the output domain by k_splitk_finish
             float *dst = p.partial + (long)blockIdx.z * p.M * p.Cout + m0 * p.Cout + n;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x2 *>(dst + (long)((k >> 2) * Wv + (k & 3)) * p.Cout) = v[k];
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4 *>(dst + (long)((k >> 2) * Wv + (k & 3)) * p.Cout) = v[k];
             continue;
         }
         if (p.res) {
             const float *rp = p.res + m0 * p.res_pitch + n;
-            f32x2 rr[16];
+            f32x4 rr[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) rr[k] = *reinterpret_cast<const f32x2 *>(rp + (long)((k >> 2) * Wv + (k & 3)) * p.res_pitch);
+            for (int k = 0; k < 16; ++k) rr[k] = *reinterpret_cast<const f32x4 *>(rp + (long)((k >> 2) * Wv + (k & 3)) * p.res_pitch);
 #pragma unroll
             for (int k = 0; k < 16; ++k) v[k] += rr[k];
         }
-        f32x2 v2[16];
+        f32x4 v2[16];
         if (p.out2) {
             const float *rp = p.res2 + m0 * p.res2_pitch + n;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v2[k] = *reinterpret_cast<const f32x2 *>(rp + (long)((k >> 2) * Wv + (k & 3)) * p.res2_pitch);
+            for (int k = 0; k < 16; ++k) v2[k] = *reinterpret_cast<const f32x4 *>(rp + (long)((k >> 2) * Wv + (k & 3)) * p.res2_pitch);
 #pragma unroll
             for (int k = 0; k < 16; ++k) v2[k] += v[k];
         }
-        // GroupNorm statistics: slot = (tile block, round, wave): the wave's two tiles of the round = 32 pixels of one image
-        auto stats = [&](float *st, const f32x2(&vv)[16]) {
-            f32x2 sm = {0.f, 0.f}, sq = {0.f, 0.f};
+        // GroupNorm statistics: slot = (tile block, round, wave): the wave's four tiles of the round = 64 pixels of one image
+        auto stats = [&](float *st, const f32x4(&vv)[16]) {
+            f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 16; ++k) { sm += vv[k]; sq += vv[k] * vv[k]; }
-            f32x4 r = {sm[0], sq[0], sm[1], sq[1]};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] += __shfl_xor(r[i], 32);
-            if (lane < 32) *reinterpret_cast<f32x4 *>(st + ((((long)tb * 4 + q) * 4 + wave) * p.Cout + n) * 2) = r;
+            for (int i = 0; i < 4; ++i) {
+                sm[i] += __shfl_xor(sm[i], 16); sm[i] += __shfl_xor(sm[i], 32);
+                sq[i] += __shfl_xor(sq[i], 16); sq[i] += __shfl_xor(sq[i], 32);
+            }
+            if (lane < 16) {
+                float *d = st + ((((long)tb * 2 + q) * 4 + wave) * p.Cout + n) * 2;
+                *reinterpret_cast<f32x4 *>(d) = f32x4{sm[0], sq[0], sm[1], sq[1]};
+                *reinterpret_cast<f32x4 *>(d + 4) = f32x4{sm[2], sq[2], sm[3], sq[3]};
+            }
         };
         if (p.st1) stats(p.st1, v);
         if (p.st2) stats(p.st2, v2);
         if (p.out_nchw) {
             float *op = p.out + ((long)img * p.Cout + n) * hw + (m0 - (long)img * hw);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { op[(k >> 2) * Wv + (k & 3)] = v[k][0]; op[hw + (k >> 2) * Wv + (k & 3)] = v[k][1]; }
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) op[c * hw + (k >> 2) * Wv + (k & 3)] = v[k][c];
         } else {
             float *op = p.out + m0 * p.out_pitch + n;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x2 *>(op + (long)((k >> 2) * Wv + (k & 3)) * p.out_pitch) = v[k];
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4 *>(op + (long)((k >> 2) * Wv + (k & 3)) * p.out_pitch) = v[k];
         }
         if (p.out2) {
             float *op = p.out2 + m0 * p.out2_pitch + n;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x2 *>(op + (long)((k >> 2) * Wv + (k & 3)) * p.out2_pitch) = v2[k];
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4 *>(op + (long)((k >> 2) * Wv + (k & 3)) * p.out2_pitch) = v2[k];
         }
     }
 #endif
@@ -497,13 +509,20 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
 
 }  // namespace
 
-size_t conv_wino4w_lds_bytes() { return (size_t)36 * 8 * 64 * sizeof(float); }   // 72 KB: the output exchange; the two patch stages need 40.5 KB
+size_t conv_wino4w_lds_bytes() { return (size_t)36 * 16 * 64 * sizeof(float); }   // 144 KB: the output exchange (the two patch stages + the dump slot need 41.5 KB)
 
 int conv_wino4w_launch(const ConvK &p, int ups, int blk, int splits, hipStream_t st) {
     HL_REQUIRE(p.Cout % 64 == 0 && p.Cin % 8 == 0 && p.w_wino, "k_conv_wino4w: bad layer");
     HL_REQUIRE(!(ups && blk), "k_conv_wino4w: the upsampling convolution reads a raw NHWC tensor");
     const dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, (unsigned)splits);
     const size_t sh = conv_wino4w_lds_bytes();
+    static const bool attr_ok = [] {   // 144 KB of dynamic LDS: above the default cap
+        const int b = (int)conv_wino4w_lds_bytes();
+        return hipFuncSetAttribute((const void *)k_conv_wino4w<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess &&
+               hipFuncSetAttribute((const void *)k_conv_wino4w<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess &&
+               hipFuncSetAttribute((const void *)k_conv_wino4w<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess;
+    }();
+    HL_REQUIRE(attr_ok, "k_conv_wino4w: cannot raise the dynamic LDS limit to %zu bytes", sh);
     if (ups) hipLaunchKernelGGL((k_conv_wino4w<true, false>), grid, dim3(256), sh, st, p);
     else if (blk) hipLaunchKernelGGL((k_conv_wino4w<false, true>), grid, dim3(256), sh, st, p);
     else hipLaunchKernelGGL((k_conv_wino4w<false, false>), grid, dim3(256), sh, st, p);

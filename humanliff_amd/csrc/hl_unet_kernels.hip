@@ -2666,7 +2666,9 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     // ... and among those, the 64-channel one-wave-per-SIMD variant where 32x16-pixel x 64-channel workgroups still give every CU one
     const char *w4w_env = getenv("HL_WINO4W");   // developer switch while the kernel is being tuned: 0 = k_conv_wino4 only
     const int w4w_mode = w4w_env ? atoi(w4w_env) : 1;
-    const bool wino4w = wino4 && w4w_mode != 0 && a.Cout % 64 == 0 && wino4_blocks / 2 >= (w4w_mode == 2 ? 1024 : 256);
+    // (one workgroup per CU there: below three rounds of the 256 CUs the two-workgroups-per-CU kernel with its finer grain wins -
+    //  128x128 at batch 4 is 384 workgroups = 1.5 rounds: 151 us against 131 us)
+    const bool wino4w = wino4 && w4w_mode != 0 && a.Cout % 64 == 0 && wino4_blocks / 2 >= (w4w_mode == 2 ? 256 : 768);
     if (wino4) {
         wino = false;
         splits = 1;
@@ -2706,9 +2708,9 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             p.w_wino = a.w_wino4;
             p.n_nblocks = a.Cout / 64;
             p.n_mtiles = a.out.N * (a.out.H / 16) * (a.out.W / 32);
-            if (splits == 1 && a.stats && !a.out_nchw) {   // statistics from the epilogue: slot = (32x16 block, round, wave) = 32 pixels
+            if (splits == 1 && a.stats && !a.out_nchw) {   // statistics from the epilogue: slot = (32x16 block, round, wave) = 64 pixels
                 p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
-                a.stat_slots = (a.out.H / 16) * (a.out.W / 32) * 16;
+                a.stat_slots = (a.out.H / 16) * (a.out.W / 32) * 8;
             }
             int rc = conv_wino4w_launch(p, a.ups, blk4 ? 1 : 0, splits, st);
             if (rc) return rc;
