@@ -172,7 +172,18 @@ def bench_unet(args, rank, world, dev):
     next(it)
     ms, fl, xf, nl = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int64 * 4)()
     _lib.check(L.hl_unet_profile_read_ex(handle, ms, fl, xf, nl))
+    dv, dk = (C.c_double * 4)(), (C.c_int * 5)()
+    _lib.check(L.hl_unet_profile_dominant(handle, dv, dk))
     _lib.check(L.hl_unet_profile(handle, 0))
+    fam = ("k_conv_dma / k_conv (direct implicit GEMM)", "k_conv_wino (Winograd F(2x2,3x3))", "k_conv_bf3 (bf16x3)", "k_conv_wino4w / k_conv_wino4 (Winograd F(4x4,3x3))")[dk[0] & 3]
+    dom_ms = dv[0] / max(dv[3], 1.0)
+    dominant = {"kernel": fam, "layer": f"{dk[2]}->{dk[3]} {dk[4]}x{dk[4]} @{256 >> dk[1]}x{256 >> dk[1]}, batch {B}", "launches_per_step": int(dv[3]),
+                "avg_launch_ms": round(dom_ms, 4), "total_ms_per_step": round(dv[0], 3),
+                "executed_tflops": round(dv[2] / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None,
+                "frac": round(dv[2] / (dom_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if dom_ms > 0 else None,
+                "algorithmic_tflops": round(dv[1] / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None,
+                "what": "the convolution shape with the largest share of the step; kernel time alone (HIP events behind the GroupNorm pre-pass), "
+                        "FLOPs the matrix pipe executes (a quarter of the direct-convolution count for F(4x4,3x3)) against the fp32 MFMA peak"}
     conv_ms, conv_fl, conv_n = ms[0], fl[0], nl[0]
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     executed = xf[0] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -187,7 +198,7 @@ def bench_unet(args, rank, world, dev):
                             "x_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                             "note": "direct-convolution FLOPs (SURVEY 8(d): 2*M*Cout*Cin*taps) over the same time; not a roofline fraction"},
             "traffic": PMC_TRAFFIC["k_conv_avg_launch_b4"] if B == 4 else None, "traffic_source": PMC_TRAFFIC["source"],
-            "launches_per_step": int(conv_n), "gflop_per_step": round(conv_fl / 1e9, 1), "executed_gflop_per_step": round(xf[0] / 1e9, 1),
+            "dominant": dominant, "launches_per_step": int(conv_n), "gflop_per_step": round(conv_fl / 1e9, 1), "executed_gflop_per_step": round(xf[0] / 1e9, 1),
             "ms_per_step": round(conv_ms, 3), "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4),
             "other_ms": {"groupnorm": round(ms[1], 3), "attention": round(ms[2], 3), "emb_prep": round(ms[3], 3)}}
     # ---- sustained leg: the loop keeps running for >= 200 more steps; steps/s and the shader clock sampled meanwhile ----
@@ -205,6 +216,7 @@ def bench_unet(args, rank, world, dev):
                              "ms_per_step": round(dt * 1e3 / args.sustained_steps, 3), "seconds": round(dt, 2), **clk.stop()}
         assert torch.isfinite(out["sample"]).all()
     del it
+    roof["batch_sweep"] = bench_batches(model, dev) if (world == 1 and not args.no_batch_sweep) else None
     # ---- opt-in arithmetic mode (not the headline): fp32 products emulated with three bf16 planes per operand ----
     roof["bf16x3_mode"] = None
     if world == 1 and not args.no_bf16x3_leg:
@@ -233,6 +245,39 @@ def bench_unet(args, rank, world, dev):
             "value": round(B * k3 / s3, 3), "unit": "denoise-steps/s", "steps": k3, "ms_per_step": round(s3 * 1e3 / k3, 3),
             "max_abs_diff_vs_fp32_forward": float((alt - ref).abs().max()), "forward_output_mean_abs": float(ref.abs().mean())}
     return secs, roof, sd, model
+
+
+def bench_batches(model, dev, batches=(1, 8, 4), steps=12, warm=3):
+    """denoise-steps/s of the same 1000-step DDPM loop at other batch sizes (the shipped sampling script runs --batch_size 1), eager and in
+    graph mode (`diffusion.use_hip_graph`: one step captured into a HIP graph and replayed - the per-launch host cost is what bounds small
+    batches).  Not used for `value`."""
+    from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
+    out = {}
+    for B in batches:
+        row = {}
+        for graph in (False, True):
+            d = create_gaussian_diffusion(steps=1000, timestep_respacing="")
+            d.use_hip_graph = graph
+            g = torch.Generator().manual_seed(70 + B)
+            x_T = torch.randn((B, 27, 256, 256), generator=g).to(dev)
+            xc = torch.zeros_like(x_T)
+            y = torch.zeros((B,), dtype=torch.int64, device=dev)
+            it = d.p_sample_loop_progressive(model, (B, 27, 256, 256), x_cond=xc, noise=x_T, clip_denoised=True, model_kwargs={"y": y}, device=dev)
+            for _ in range(warm):
+                o = next(it)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                o = next(it)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert torch.isfinite(o["sample"]).all()
+            del it
+            row["graph" if graph else "eager"] = {"value": round(B * steps / dt, 2), "ms_per_step": round(dt * 1e3 / steps, 3)}
+        out[f"batch{B}"] = row
+    out["unit"] = "denoise-steps/s"
+    out["what"] = f"p_sample_loop of the production net, {steps} timed steps after {warm} warm-up steps per point; graph = diffusion.use_hip_graph (HIP graph replay of one step)"
+    return out
 
 
 def _psnr(a, b):
@@ -851,6 +896,7 @@ def main():
                     help="extra untimed-for-`value` steps of the same loop after the timed region: sustained steps/s + shader clock (N=1 only; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity legs (end-to-end chain vs the reference's vectors, HIP vs oracle samples)")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the B = 1 / 8 / 4 eager-vs-graph legs of the denoise loop")
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the per-GPU slice of configs[3]/[4] (4 layers x DDIM-50 -> 185 views 512x512)")
     ap.add_argument("--e2e-views", type=int, default=185)

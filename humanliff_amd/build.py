@@ -50,11 +50,38 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+    audit_accumulator_file()
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
     return LIB
+
+
+def audit_accumulator_file():
+    """k_conv_wino4w keeps 16 accumulator tiles in the accumulator registers a[0:255] by NAME, inside inline asm (hl_conv_wino4w.hip).
+    The compiler only knows them as clobbers; if register pressure ever makes it place a value of its own there (a load into a[..], a
+    v_accvgpr_write, a spill) the kernel computes garbage without any diagnostic.  So the ISA of that file is checked after every build:
+    outside the ;;#ASMSTART / ;;#ASMEND brackets no instruction may name an accumulator register."""
+    import re
+    import tempfile
+    src = os.path.join(CSRC, "hl_conv_wino4w.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get("hl_conv_wino4w.hip", []) + ["--cuda-device-only", "-S", src, "-o", os.path.join(tmp, "w4w.s")]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc -S failed on {src}:\n{r.stdout.decode()}")
+        inasm, bad = False, []
+        for n, line in enumerate(open(os.path.join(tmp, "w4w.s")), 1):
+            if "ASMSTART" in line:
+                inasm = True
+            elif "ASMEND" in line:
+                inasm = False
+            elif not inasm and not line.lstrip().startswith((";", ".")) and re.search(r"\ba\[?\d", line.split(";")[0]):
+                bad.append(f"{n}: {line.strip()}")
+    if bad:
+        raise RuntimeError("k_conv_wino4w: the compiler touched the accumulator file outside the kernel's inline asm "
+                           f"({len(bad)} instructions, e.g. {bad[:3]}): reduce the register pressure of the kernel")
 
 
 if __name__ == "__main__":

@@ -102,7 +102,9 @@ struct Net {
     // optional per-category HIP-event timing of one forward (bench.py roofline leg)
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;
-    struct Span { int cat; size_t a, b; double flops, exec; };   // algorithmic FLOPs and the FLOPs the kernel actually issued
+    struct Span { int cat; size_t a, b; double flops, exec; int key[5]; long mid; };   // mid: event between pre-pass and kernel (-1: none)   // algorithmic FLOPs and the FLOPs the kernel actually issued; conv launches: {path, level, Cin, Cout, ks}
+    double dom[4] = {0, 0, 0, 0};   // dominant convolution shape of the last profile read: total ms, algorithmic / executed FLOPs per launch, launches
+    int dom_key[5] = {0, 0, 0, 0, 0};
     std::vector<Span> spans;
     size_t ev_used = 0;
     // which kernel family each convolution of the LAST forward took, per resolution level (hl_unet_dispatch_census):
@@ -440,8 +442,11 @@ struct Exec {
         if (!n.err.empty() && !rc) rc = hl::fail(HL_ERR_RUNTIME, "hl_unet_forward: %s", n.err.c_str());
         const size_t b = n.next_event();
         if (n.ev_pool[b]) hipEventRecord(n.ev_pool[b], st);
-        n.spans.push_back({cat, a, b, flops, exec < 0 ? flops : exec});
+        n.spans.push_back({cat, a, b, flops, exec < 0 ? flops : exec, {span_key[0], span_key[1], span_key[2], span_key[3], span_key[4]}, span_mid});
+        span_key[0] = -1; span_mid = -1;
     }
+    int span_key[5] = {-1, 0, 0, 0, 0};
+    long span_mid = -1;
 
     void conv(const Conv &c, const View &in, const View &out, int stride, int ups, const float *cA, const float *cB, int act,
               const float *res, long res_pitch, float *out2 = nullptr, long out2_pitch = 0, const float *res2 = nullptr,
@@ -467,11 +472,15 @@ struct Exec {
         a.act_ws = act_ws; a.act_ws_bytes = act_need * sizeof(float);
         a.stats = st1; a.stats2 = st2;
         const size_t e0 = span_begin();
+        size_t emid = 0;
+        if (n.prof) { emid = n.next_event(); a.ev_mid = n.ev_pool[emid]; }
         ok(hl::conv2d(a, st));
+        if (n.prof && a.ev_mid_used) span_mid = (long)emid;
         {
             int lvl = 0;
             while (lvl < 7 && (out.H << lvl) < H) ++lvl;
             n.census[a.path & 3][lvl] += 1;
+            span_key[0] = a.path; span_key[1] = lvl; span_key[2] = c.Cin; span_key[3] = c.Cout; span_key[4] = c.ks;
         }
         const double fl = 2.0 * (double)out.pixels() * c.Cout * c.Cin * c.ks * c.ks;
         // Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36; bf16x3: six bf16 MFMA products per fp32 product
@@ -879,14 +888,38 @@ int hl_unet_profile_read_ex(void *handle, double *h_ms, double *h_flops, double 
     for (int i = 0; i < CAT_N; ++i) { h_ms[i] = 0; h_flops[i] = 0; h_launches[i] = 0; if (h_exec_flops) h_exec_flops[i] = 0; }
     if (n.spans.empty()) return HL_OK;
     HL_HIP(hipEventSynchronize(n.ev_pool[n.spans.back().b]));
+    struct Agg { double ms = 0, fl = 0, ex = 0; long calls = 0; int key[5]; };
+    std::vector<Agg> aggs;
     for (auto &sp : n.spans) {
         float ms = 0.f;
         HL_HIP(hipEventElapsedTime(&ms, n.ev_pool[sp.a], n.ev_pool[sp.b]));
         h_ms[sp.cat] += ms; h_flops[sp.cat] += sp.flops; h_launches[sp.cat] += 1;
         if (h_exec_flops) h_exec_flops[sp.cat] += sp.exec;
+        if (sp.cat == CAT_CONV && sp.key[0] >= 0) {   // per convolution shape (kernel family, level, channels): which one dominates the step?
+            Agg *hit = nullptr;
+            for (auto &g : aggs) if (std::equal(g.key, g.key + 5, sp.key)) { hit = &g; break; }
+            if (!hit) { aggs.emplace_back(); hit = &aggs.back(); std::copy(sp.key, sp.key + 5, hit->key); }
+            float kms = ms;                                   // the kernel alone: from the event behind the GroupNorm pre-pass, if there was one
+            if (sp.mid >= 0 && n.ev_pool[sp.mid]) HL_HIP(hipEventElapsedTime(&kms, n.ev_pool[sp.mid], n.ev_pool[sp.b]));
+            hit->ms += kms; hit->fl += sp.flops; hit->ex += sp.exec; hit->calls += 1;
+        }
     }
+    n.dom[0] = n.dom[1] = n.dom[2] = n.dom[3] = 0;
+    for (auto &g : aggs)
+        if (g.ms > n.dom[0]) {
+            n.dom[0] = g.ms; n.dom[1] = g.fl / g.calls; n.dom[2] = g.ex / g.calls; n.dom[3] = (double)g.calls;
+            std::copy(g.key, g.key + 5, n.dom_key);
+        }
     n.spans.clear();
     n.ev_used = 0;
+    return HL_OK;
+}
+
+int hl_unet_profile_dominant(void *handle, double *h_vals, int *h_key) {
+    HL_REQUIRE(handle && h_vals && h_key, "hl_unet_profile_dominant: null argument");
+    const Net &n = *static_cast<Net *>(handle);
+    for (int i = 0; i < 4; ++i) h_vals[i] = n.dom[i];
+    for (int i = 0; i < 5; ++i) h_key[i] = n.dom_key[i];
     return HL_OK;
 }
 

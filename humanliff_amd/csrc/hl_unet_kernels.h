@@ -46,6 +46,8 @@ struct ConvArgs {
     // computes the statistics from the tensor (groupnorm_coef).
     float *stats, *stats2;
     mutable int stat_slots;
+    hipEvent_t ev_mid;   // optional (profiling): recorded between the GroupNorm pre-pass and the convolution kernel, when there is a pre-pass
+    mutable int ev_mid_used;
     int plan_only;       // 1: no launch, only set `path` (w / w_wino / w_bf3 are then just non-null markers of what could be packed)
 };
 // kernel-side argument block of the convolution kernels (filled by conv2d)

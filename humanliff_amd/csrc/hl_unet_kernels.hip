@@ -2661,19 +2661,39 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     // alone fills the chip
     constexpr long wino4_thr = 512;
     const long wino4_blocks = (long)a.out.N * (a.out.H / 16) * (a.out.W / 32) * (a.Cout / 32);
-    const bool wino4 = dma && a.w_wino4 && !a.w_bf3 && a.ks == 3 && a.stride == 1 && a.out.H % 16 == 0 && a.out.W % 32 == 0 &&
-                       a.Cout % 32 == 0 && (long)a.Cout * a.in.C * 144 < (1L << 31) && wino4_blocks >= wino4_thr;
-    // ... and among those, the 64-channel one-wave-per-SIMD variant where 32x16-pixel x 64-channel workgroups still give every CU one
-    const char *w4w_env = getenv("HL_WINO4W");   // developer switch while the kernel is being tuned: 0 = k_conv_wino4 only
+    const bool wino4_ok = dma && a.w_wino4 && !a.w_bf3 && a.ks == 3 && a.stride == 1 && a.out.H % 16 == 0 && a.out.W % 32 == 0 &&
+                          a.Cout % 32 == 0 && (long)a.Cout * a.in.C * 144 < (1L << 31);
+    bool wino4 = wino4_ok && wino4_blocks >= wino4_thr;
+    // k_conv_wino4w: the same arithmetic with 64 output channels per workgroup at ONE workgroup per CU (hl_conv_wino4w.hip).  With W
+    // = 32x16-pixel x 64-channel workgroups it is taken
+    //   * from three rounds of the 256 CUs on (W >= 768: the 256-pixel level at batch >= 2),
+    //   * where one round nearly fills the chip (160 <= W <= 256: the 64-pixel level at batch 4 - 192 workgroups run 140 us where the
+    //     768 smaller workgroups of the F(2x2) kernel take 188 us),
+    //   * below that with the input channels split into slabs until W x slabs reaches one round (k_splitk_finish sums them).
+    // In between (1.5 rounds: 128x128 at batch 4, 384 workgroups, 151 us against 131 us) the two-workgroups-per-CU kernels keep the layer.
+    const char *w4w_env = getenv("HL_WINO4W");   // developer switch while the kernel is being tuned: 0 = off, 2 = wherever it can run
     const int w4w_mode = w4w_env ? atoi(w4w_env) : 1;
-    // (one workgroup per CU there: below three rounds of the 256 CUs the two-workgroups-per-CU kernel with its finer grain wins -
-    //  128x128 at batch 4 is 384 workgroups = 1.5 rounds: 151 us against 131 us)
-    const bool wino4w = wino4 && w4w_mode != 0 && a.Cout % 64 == 0 && wino4_blocks / 2 >= (w4w_mode == 2 ? 256 : 768);
+    const long w4w_blocks = wino4_blocks / 2;
+    bool wino4w = false;
+    int w4w_splits = 1;
+    if (wino4_ok && w4w_mode != 0 && a.Cout % 64 == 0 && w4w_blocks > 0) {
+        const int nkt8 = a.in.C / 8;
+        if (w4w_blocks >= 768 || (w4w_blocks >= 160 && w4w_blocks <= 256) || (w4w_mode == 2 && w4w_blocks >= 160)) wino4w = true;
+        else if (w4w_blocks < 160 && a.splitk_ws) {
+            w4w_splits = (int)(256 / w4w_blocks);
+            if (w4w_splits > nkt8 / 8) w4w_splits = nkt8 / 8;            // at least 8 k-tiles (64 channels) per slab
+            while (w4w_splits > 1 && (size_t)w4w_splits * M * a.Cout * sizeof(float) > a.splitk_ws_bytes) --w4w_splits;
+            wino4w = w4w_splits >= 2 && w4w_blocks * w4w_splits >= 128;
+            if (!wino4w) w4w_splits = 1;
+        }
+    }
+    if (wino4w) wino4 = true;
     if (wino4) {
         wino = false;
-        splits = 1;
-        p.kt_per = a.in.C / 8;
-        p.partial = nullptr;
+        splits = wino4w ? w4w_splits : 1;
+        p.kt_per = (a.in.C / 8 + splits - 1) / splits;
+        splits = (a.in.C / 8 + p.kt_per - 1) / p.kt_per;
+        p.partial = splits > 1 ? a.splitk_ws : nullptr;
     }
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
         a.path = (dma && wino4) ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0));
@@ -2701,6 +2721,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix,
                                a.in.C, a.coefA, a.coefB, a.act, a.act_ws);
             p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0;
+            if (a.ev_mid) { hipEventRecord(a.ev_mid, st); a.ev_mid_used = 1; }
         }
         if (wino4 && wino4w) {
             // 64 output channels per workgroup, one wave per SIMD, accumulators in the accumulator registers (hl_conv_wino4w.hip)

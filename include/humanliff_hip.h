@@ -318,6 +318,12 @@ int hl_unet_profile_read(void *handle, double *h_ms, double *h_flops, int64_t *h
  * 16/36 of their algorithmic multiplies, HL_CONV_BF16X3 layers six bf16 products per fp32 product. */
 int hl_unet_profile_read_ex(void *handle, double *h_ms, double *h_flops, double *h_exec_flops, int64_t *h_launches);
 
+/* The convolution shape that took the most time in the spans of the last hl_unet_profile_read(_ex): h_vals = {total ms over its launches,
+ * algorithmic FLOPs per launch, FLOPs issued to the matrix pipe per launch, number of launches}, h_key = {kernel family (as in
+ * hl_unet_dispatch_census), resolution level, Cin, Cout, kernel size}.  The time is the convolution kernel's own (an event behind the
+ * GroupNorm pre-pass k_gn_apply(_blk) separates the two; a split-K finish pass, where there is one, is included). */
+int hl_unet_profile_dominant(void *handle, double *h_vals, int *h_key);
+
 /* Which kernel family every convolution of the LAST hl_unet_forward took: h_counts[path * 8 + level] launches, path 0 = direct
  * implicit GEMM (k_conv_dma / k_conv), 1 = Winograd F(2x2,3x3) (k_conv_wino), 2 = bf16x3 emulation (k_conv_bf3), 3 = Winograd F(4x4,3x3)
  * (k_conv_wino4); level = log2(H / H_out) of the layer's output.  Kernel selection depends on the batch size (a layer takes a Winograd

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from humanliff_amd import _lib
 L = _lib.lib(); dev = torch.device("cuda:0")
-shapes = [(4, 256, 256, 192, 192, 0), (4, 256, 256, 384, 192, 0), (4, 128, 128, 192, 192, 0), (4, 128, 128, 384, 384, 1), (1, 256, 256, 192, 192, 0), (8, 128, 128, 48, 64, 0)]
+shapes = [(4, 256, 256, 192, 192, 0), (4, 128, 128, 192, 192, 0), (4, 64, 64, 384, 384, 0), (4, 64, 64, 768, 384, 0), (4, 64, 64, 384, 384, 1), (4, 32, 32, 384, 384, 0), (4, 32, 32, 768, 384, 0), (1, 256, 256, 192, 192, 0), (1, 128, 128, 192, 192, 0), (1, 64, 64, 384, 384, 0), (2, 256, 256, 192, 192, 0), (2, 64, 64, 384, 384, 0), (8, 64, 64, 384, 384, 0)]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 for (N, H, W, C, Co, ups) in shapes:
     g = torch.Generator(device=dev).manual_seed(1)

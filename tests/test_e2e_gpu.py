@@ -450,3 +450,31 @@ def test_unet_cond_types_match_reference(tag, cond, cin):
     with torch.no_grad():
         y = model(x.to(dev), torch.tensor([999, 17], device=dev), xc.to(dev) if cond else None, y=torch.tensor([3, 0], device=dev)).cpu()
     assert (y - torch.from_numpy(g[f"{tag}_out"])).abs().max() < 1e-4
+
+
+def test_graph_mode_of_the_sampling_loop_equals_the_eager_loop():
+    """`diffusion.use_hip_graph = True`: one step (UNet forward with its side stream, noise draw, fused update) captured into a HIP graph
+    and replayed.  DDIM with eta = 0 multiplies the noise by exactly zero, so the two loops must agree bit for bit whatever the RNG
+    offsets; a DDPM loop is checked for being finite and for consuming the generator."""
+    from tests.test_train_loss_cpu import tiny_model
+    from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
+    model, _ = tiny_model()
+    model = model.to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    shape = (2, 27, 32, 32)
+    x_T = torch.randn(shape, generator=g).to(dev)
+    xc = (torch.randn(shape, generator=g).clamp(-1, 1) * 0.7).to(dev)
+    y = torch.tensor([3, 0], device=dev)
+    d = create_gaussian_diffusion(steps=1000, timestep_respacing="ddim20")
+    eager = d.ddim_sample_loop(model, shape, x_cond=xc, noise=x_T, model_kwargs={"y": y}).clone()
+    d.use_hip_graph = True
+    graphed = d.ddim_sample_loop(model, shape, x_cond=xc, noise=x_T, model_kwargs={"y": y}).clone()
+    assert torch.equal(eager, graphed)
+    steps = [o["sample"].clone() for o in d.ddim_sample_loop_progressive(model, shape, x_cond=xc, noise=x_T, model_kwargs={"y": y})]
+    assert len(steps) == 20 and torch.equal(steps[-1], eager) and not torch.equal(steps[0], steps[1])
+    d2 = create_gaussian_diffusion(steps=1000, timestep_respacing="25")
+    d2.use_hip_graph = True
+    torch.manual_seed(0)
+    a = d2.p_sample_loop(model, shape, x_cond=xc, noise=x_T, model_kwargs={"y": y}).clone()
+    b = d2.p_sample_loop(model, shape, x_cond=xc, noise=x_T, model_kwargs={"y": y}).clone()
+    assert torch.isfinite(a).all() and not torch.equal(a, b)        # fresh noise every step, also on replay
