@@ -525,12 +525,30 @@ def bench_train(model, diffusion, dev, rank, world, iters=3, B=2):
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, dev) / iters
     assert torch.isfinite(loss.detach()).all()
+    # the opt-in 16-bit MFMA arithmetic of the convolutions (forward and backward-data on the direct DMA-tile layers; HL_CONV_BF16)
+    from humanliff_amd.improved_diffusion import unet_train as ut
+    ut.set_train_arithmetic("bf16")
+    try:
+        step()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(iters):
+            loss16 = step()
+        torch.cuda.synchronize()
+        dt16 = (time.perf_counter() - tb) / iters
+    finally:
+        ut.set_train_arithmetic(None)
+    assert torch.isfinite(loss16.detach()).all()
     model.train(was_training)
     del opt
     for p in model.parameters():
         p.grad = None
     return {"metric": "UNet training samples/sec", "value": round(world * B / dt, 3), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 2),
             "batch_per_gpu": B, "iterations": iters,
+            "bf16_arithmetic": {"ms_per_step": round(dt16 * 1e3, 2), "value": round(B / dt16, 3), "unit": "samples/s (this rank)",
+                                "what": "unet_train.set_train_arithmetic('bf16'): activations rounded to bf16 x 16-bit weights on v_mfma_f32_32x32x16_bf16 for forward and "
+                                        "backward-data of the direct-tile layers (weight gradients fp32); opt-in, NOT tied to autocast - its direct kernel is bound by "
+                                        "LDS-DMA issue and loses to the fp32 Winograd kernels on the 3x3 layers"},
             "algorithmic_tflops": round(world * 3 * UNET_GFLOP_PER_SAMPLE_STEP * B / dt / 1e3, 2),
             "config": {"workload": "production F4 UNet, training_losses (MSE) + backward on the HIP kernels + AdamW (torch, fused=True), microbatch 2 (README.md:104)",
                        "flop_count": "3 x 2015.4 GFLOP per sample (forward, backward-data, backward-weights; direct-convolution FLOPs)"}}

@@ -462,7 +462,7 @@ struct Exec {
         if (!run) return;
         ConvArgs a{};
         a.in = in; a.in.C = c.Cin_pad;
-        a.w = c.w; a.w_bf3 = n.conv_mode == HL_CONV_BF16X3 ? c.w_bf3 : nullptr;
+        a.w = c.w; a.w_bf3 = (n.conv_mode == HL_CONV_BF16X3 || n.conv_mode == HL_CONV_BF16) ? c.w_bf3 : nullptr; a.bf16_single = n.conv_mode == HL_CONV_BF16;
         a.w_wino = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_F23) ? c.w_wino : nullptr;
         a.w_wino4 = n.conv_mode == HL_CONV_FP32 ? c.w_wino4 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
         a.coefA = cA; a.coefB = cB; a.act = act;
@@ -824,7 +824,7 @@ int hl_unet_set_overlap(void *handle, int enable) {
 
 int hl_unet_set_conv_mode(void *handle, int mode) {
     HL_REQUIRE(handle, "hl_unet_set_conv_mode: null handle");
-    HL_REQUIRE(mode == HL_CONV_FP32 || mode == HL_CONV_BF16X3 || mode == HL_CONV_FP32_DIRECT || mode == HL_CONV_FP32_F23, "hl_unet_set_conv_mode: unknown mode %d", mode);
+    HL_REQUIRE(mode == HL_CONV_FP32 || mode == HL_CONV_BF16X3 || mode == HL_CONV_FP32_DIRECT || mode == HL_CONV_FP32_F23 || mode == HL_CONV_BF16, "hl_unet_set_conv_mode: unknown mode %d", mode);
     static_cast<Net *>(handle)->conv_mode = mode;
     return HL_OK;
 }
@@ -936,17 +936,17 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     if (Cin_w < 0) Cin_w = Cin;
     HL_REQUIRE(Cin_w <= Cin, "hl_conv2d_nhwc: the weight has more input channels than the tensor");
     const size_t need32 = (hl::conv_packed_floats(Cout, Cin, ks) * sizeof(float) + 255) / 256 * 256;
-    const size_t extra = mode == HL_CONV_BF16X3 ? hl::conv_packed_bf3_bytes(Cout, Cin, ks)
+    const bool bf = mode == HL_CONV_BF16X3 || mode == HL_CONV_BF16;
+    const size_t extra = bf ? hl::conv_packed_bf3_bytes(Cout, Cin, ks)
                          : (mode == HL_CONV_FP32_F23 ? hl::conv_packed_wino_bytes(Cout, Cin, ks)
                             : (mode == HL_CONV_FP32 ? std::max(hl::conv_packed_wino_bytes(Cout, Cin, ks), hl::conv_packed_wino4_bytes(Cout, Cin, ks)) : 0));
     const size_t need = need32 + (extra + 255) / 256 * 256;
     HL_REQUIRE(scratch && scratch_bytes >= need, "hl_conv2d_nhwc: scratch too small (%zu < %zu)", scratch_bytes, need);
-    HL_REQUIRE(!tf || mode != HL_CONV_BF16X3, "hl_conv2d_nhwc: the bf16x3 mode has no backward-data weights");
     ConvArgs a{};
     void *extra_dst = static_cast<char *>(scratch) + need32;
     a.in.p = const_cast<float *>(in); a.in.N = N; a.in.H = H; a.in.W = W; a.in.C = Cin; a.in.pitch = Cin;
     a.w = static_cast<float *>(scratch); a.bias = bias; a.Cout = Cout; a.ks = ks; a.stride = stride; a.ups = upsample;
-    if (mode == HL_CONV_BF16X3 && need > need32) a.w_bf3 = extra_dst;
+    if (bf && need > need32) { a.w_bf3 = extra_dst; a.bf16_single = mode == HL_CONV_BF16; }
     if ((mode == HL_CONV_FP32 || mode == HL_CONV_FP32_F23) && hl::conv_packed_wino_bytes(Cout, Cin, ks)) a.w_wino = static_cast<float *>(extra_dst);
     if (mode == HL_CONV_FP32 && hl::conv_packed_wino4_bytes(Cout, Cin, ks)) a.w_wino4 = static_cast<float *>(extra_dst);
     a.coefA = coefA; a.coefB = coefB; a.act = silu;
@@ -979,7 +979,7 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
         a.w_wino4 = nullptr;
     } else {
         rc = hl::conv_pack_weights(w_oihw, Cout, Cin_w, Cin, ks, static_cast<float *>(scratch), (hipStream_t)stream, tf);
-        if (!rc && a.path == 2) rc = hl::conv_pack_weights_bf3(w_oihw, Cout, Cin_w, Cin, ks, extra_dst, (hipStream_t)stream);
+        if (!rc && a.path == 2) rc = hl::conv_pack_weights_bf3(w_oihw, Cout, Cin_w, Cin, ks, extra_dst, (hipStream_t)stream, tf);
         a.w_wino = nullptr;
         a.w_wino4 = nullptr;
     }
@@ -991,7 +991,7 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
 
 int hl_conv2d_nhwc_bwd_data(int conv_mode, const float *dy, int N, int Ho, int Wo, int Cy, const float *w_oihw, int Cout, int Cin, int ks,
                             int stride, int upsample, float *dx, int Cx, void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23, "hl_conv2d_nhwc_bwd_data: mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16, "hl_conv2d_nhwc_bwd_data: mode %d", conv_mode);
     HL_REQUIRE(dy && w_oihw && dx && scratch, "hl_conv2d_nhwc_bwd_data: null argument");
     HL_REQUIRE(Cy % 16 == 0 && Cout <= Cy && Cin <= Cx && (ks == 1 || ks == 3) && (stride == 1 || (stride == 2 && !upsample && ks == 3)),
                "hl_conv2d_nhwc_bwd_data: bad argument");
@@ -1027,7 +1027,7 @@ int hl_conv2d_nhwc_gn(int conv_mode, const float *in, int N, int H, int W, int C
                       int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu, const float *residual,
                       float *out, const float *gamma, const float *beta, float *next_coefA, float *next_coefB, int *h_used_stats,
                       void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23, "hl_conv2d_nhwc_gn: unknown mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16, "hl_conv2d_nhwc_gn: unknown mode %d", conv_mode);
     HL_REQUIRE(gamma && beta && next_coefA && next_coefB && scratch, "hl_conv2d_nhwc_gn: null argument");
     const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     const int Ho = (Hv + 2 * pad - ks) / stride + 1, Wo = (Wv + 2 * pad - ks) / stride + 1;
@@ -1061,7 +1061,7 @@ int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w
 int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias,
                         int Cout, int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23, "hl_conv2d_nhwc_mode: unknown mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16, "hl_conv2d_nhwc_mode: unknown mode %d", conv_mode);
     return conv2d_single(conv_mode, in, N, H, W, Cin, w_oihw, bias, Cout, ks, stride, upsample, coefA, coefB, silu, residual, out,
                          scratch, scratch_bytes, stream);
 }

@@ -16,6 +16,7 @@ struct ConvArgs {
     View in;             // C must be a multiple of 16 (pad channels are zero and have zero weights)
     const float *w;      // packed [Cout_pad][Ktot], K order = kt_decode() in hl_unet_kernels.hip (groups of two 16-channel chunks, taps inside)
     const void *w_bf3;   // optional: the same weights split into three bf16 planes (conv_pack_weights_bf3); selects k_conv_bf3
+    int bf16_single;     // with w_bf3: 1 = HL_CONV_BF16 (activations rounded to bf16 x the weights' two leading bf16 planes), 0 = bf16x3 emulation
     const float *w_wino; // optional: Winograd-domain weights (conv_pack_weights_wino); selects k_conv_wino for large 3x3 layers
     const float *w_wino4;// optional: Winograd F(4x4,3x3) weights (conv_pack_weights_wino4); selects k_conv_wino4 where it fills the chip
     const float *bias;   // [Cout] or null
@@ -89,7 +90,7 @@ int conv_pack_weights_wino(const float *w_oihw, int Cout, int Cin, int Cin_pad, 
 size_t conv_packed_wino4_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_wino4(const float *w_oihw, int Cout, int Cin, int Cin_pad, float *packed, hipStream_t st, int tf = 0);
 size_t conv_packed_bf3_bytes(int Cout, int Cin_pad, int ks);
-int conv_pack_weights_bf3(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st);
+int conv_pack_weights_bf3(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st, int tf = 0);
 
 // GroupNorm(32 groups, eps 1e-5) statistics -> per-(n,c) affine  y = x*A + B   (nn.py:17-19,100)
 // optional scale/shift (ResBlock use_scale_shift_norm, unet.py:203-206): y = GN(x)*(1+scale)+shift,

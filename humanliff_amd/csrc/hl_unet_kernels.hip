@@ -1351,7 +1351,10 @@ __global__ __launch_bounds__(256) void k_pack_conv_wino4(const float *__restrict
 }
 
 // k_conv_bf3: k_conv_dma with the fp32 products emulated on the bf16 matrix pipe (opt-in, see hl_unet_set_conv_mode).
-template <int WM, bool UPS>
+// NPL = 3: the emulation above.  NPL = 1: the 16-bit training arithmetic (hl_unet_set_conv_mode HL_CONV_BF16, what the reference's
+// autocast selects, train_util.py:214): every activation is rounded to bf16 (nearest-even) and multiplied with the weight's two leading
+// bf16 planes (16 significand bits - the packed planes are already there), fp32 accumulation: two bf16 MFMAs per k-tile instead of six.
+template <int WM, bool UPS, int NPL = 3>
 __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_bf3(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__   // device pass only: the host pass of this clang drops the launch stub when it parses the body
     constexpr int NS = 3;
@@ -1485,6 +1488,17 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_bf3(const C
     // Weights are split once at pack time; the activation fragment is split here, after the LDS read.
     const int ntiles = nk - kt0;
     auto split3 = [&](const f32x4 x0, const f32x4 x1, bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
+        if constexpr (NPL == 1) {   // round to nearest even: u + 0x7fff + lsb, upper half (no NaN / overflow care needed beyond what fp32 gives)
+            u32x4 ph;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned a = __float_as_uint(2 * i < 4 ? x0[2 * i] : x1[2 * i - 4]), b = __float_as_uint(2 * i + 1 < 4 ? x0[2 * i + 1] : x1[2 * i + 1 - 4]);
+                const unsigned ra = a + 0x7fffu + ((a >> 16) & 1u), rb = b + 0x7fffu + ((b >> 16) & 1u);
+                ph[i] = __builtin_amdgcn_perm(rb, ra, 0x07060302);
+            }
+            hi = __builtin_bit_cast(bf16x8, ph);
+            return;
+        }
         unsigned u[8], m[8], l[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1514,13 +1528,15 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_bf3(const C
     auto readB = [&](const float *base, int j, bf16x8 &h, bf16x8 &m, bf16x8 &l) {
         h = *reinterpret_cast<const bf16x8 *>(base + b_off + (0 * BN + j * 32) * 4);
         m = *reinterpret_cast<const bf16x8 *>(base + b_off + (2 * BN + j * 32) * 4);
-        l = *reinterpret_cast<const bf16x8 *>(base + b_off + (4 * BN + j * 32) * 4);
+        if constexpr (NPL == 3) l = *reinterpret_cast<const bf16x8 *>(base + b_off + (4 * BN + j * 32) * 4);
     };
     auto mma6 = [&](f32x16 &c, const bf16x8 ah, const bf16x8 am, const bf16x8 al, const bf16x8 bh, const bf16x8 bm, const bf16x8 bl) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);   // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+        if constexpr (NPL == 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);   // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+        }
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
     };
@@ -1557,7 +1573,8 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_bf3(const C
         }
         // unit (t,2): its weight planes are in b0*, so first park them, then start the reads of tile t+1
         const bf16x8 ch = b0h, cm = b0m, cl = b0l;
-        f32x16 c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch, acc[2], 0, 0, 0);
+        f32x16 c2 = acc[2];
+        if constexpr (NPL == 3) c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch, c2, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
             if (t + NS < ntiles) issue(U);
@@ -1566,9 +1583,11 @@ __global__ __launch_bounds__(WM * 64, (WM == 8) ? 4 : 3) void k_conv_bf3(const C
             readB(nbase, 0, b0h, b0m, b0l);
         }
         __builtin_amdgcn_sched_barrier(0);
-        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cm, c2, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cl, c2, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, ch, c2, 0, 0, 0);
+        if constexpr (NPL == 3) {
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cm, c2, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cl, c2, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, ch, c2, 0, 0, 0);
+        }
         c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cm, c2, 0, 0, 0);
         acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ch, c2, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -1757,7 +1776,7 @@ __global__ void k_pack_conv(const float *__restrict__ w, int Cout, int Cin, int 
 
 // weights -> three truncated-bf16 planes (w = hi + mid + lo exactly), laid out as k_conv_bf3 stages them
 __global__ void k_pack_conv_bf3(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, int ks, int rows,
-                                unsigned short *__restrict__ dst) {
+                                unsigned short *__restrict__ dst, int tf) {
     const int taps = ks * ks;
     const long Ktot = (long)Cin_pad * taps;
     const long n = (long)rows * Ktot;
@@ -1770,7 +1789,7 @@ __global__ void k_pack_conv_bf3(const float *__restrict__ w, int Cout, int Cin, 
         kt_decode((int)t, Cin_pad >> 4, taps, cc, tap);
         const int cin = cc * 16 + c16;
         float v = 0.f;
-        if (o < Cout && cin < Cin) v = w[((long)o * Cin + cin) * taps + tap];
+        if (o < Cout && cin < Cin) v = tf ? w[((long)cin * Cout + o) * taps + (taps - 1 - tap)] : w[((long)o * Cin + cin) * taps + tap];
         const unsigned uh = __float_as_uint(v) & 0xffff0000u;
         const float r1 = v - __uint_as_float(uh);
         const unsigned um = __float_as_uint(r1) & 0xffff0000u;
@@ -2517,10 +2536,10 @@ size_t conv_packed_bf3_bytes(int Cout, int Cin_pad, int ks) {
     return rows % 96 == 0 ? (size_t)rows * Cin_pad * ks * ks * 6 : 0;
 }
 
-int conv_pack_weights_bf3(const float *w, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st) {
+int conv_pack_weights_bf3(const float *w, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st, int tf) {
     HL_REQUIRE(w && packed && Cin_pad % 16 == 0 && Cin <= Cin_pad && (ks == 1 || ks == 3), "conv_pack_weights_bf3: bad argument");
     const int rows = round_up(Cout, 64);
-    hipLaunchKernelGGL(k_pack_conv_bf3, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, ks, rows, static_cast<unsigned short *>(packed));
+    hipLaunchKernelGGL(k_pack_conv_bf3, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, ks, rows, static_cast<unsigned short *>(packed), tf);
     return check_launch("k_pack_conv_bf3");
 }
 
@@ -2781,7 +2800,12 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         if (a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) {   // fp32 emulated on the bf16 matrix pipe (opt-in)
             a.path = 2;
             const size_t s8 = (size_t)3 * (256 * 16 + 6 * 96 * 4) * sizeof(float), s4 = (size_t)3 * (128 * 16 + 6 * 96 * 4) * sizeof(float);
-            if (tile8 && a.ups) hipLaunchKernelGGL((k_conv_bf3<8, true>), grid, dim3(512), s8, st, p);
+            if (a.bf16_single) {   // HL_CONV_BF16: bf16 activations x 16-bit weights
+                if (tile8 && a.ups) hipLaunchKernelGGL((k_conv_bf3<8, true, 1>), grid, dim3(512), s8, st, p);
+                else if (tile8) hipLaunchKernelGGL((k_conv_bf3<8, false, 1>), grid, dim3(512), s8, st, p);
+                else if (a.ups) hipLaunchKernelGGL((k_conv_bf3<4, true, 1>), grid, dim3(256), s4, st, p);
+                else hipLaunchKernelGGL((k_conv_bf3<4, false, 1>), grid, dim3(256), s4, st, p);
+            } else if (tile8 && a.ups) hipLaunchKernelGGL((k_conv_bf3<8, true>), grid, dim3(512), s8, st, p);
             else if (tile8) hipLaunchKernelGGL((k_conv_bf3<8, false>), grid, dim3(512), s8, st, p);
             else if (a.ups) hipLaunchKernelGGL((k_conv_bf3<4, true>), grid, dim3(256), s4, st, p);
             else hipLaunchKernelGGL((k_conv_bf3<4, false>), grid, dim3(256), s4, st, p);

@@ -35,10 +35,28 @@ from .. import _lib
 from . import unet as U
 
 _MODE = _lib.HL_CONV_FP32
+_ARITH = {"mode": None}       # None / "fp32": exact kernels; "bf16": HL_CONV_BF16 (set_train_arithmetic)
 
 
-def _conv_raw(x, w, b, ks, stride=1, ups=0):
+def set_train_arithmetic(kind=None):
+    """Arithmetic of the convolutions of the training path (forward and backward-data): None / "fp32" (default) = the exact fp32 kernels
+    (Winograd where it applies); "bf16" = HL_CONV_BF16 (activations rounded to bf16 x 16-bit weights on the bf16 matrix pipe, fp32
+    accumulation, fp32 tensors and master weights) on the layers that take the direct DMA tile.  Weight gradients, GroupNorm and attention
+    stay fp32 either way.  Opt-in and not tied to torch.autocast: measured SLOWER than the fp32 Winograd path on the 3x3 layers."""
+    assert kind in (None, "fp32", "bf16")
+    _ARITH["mode"] = kind
+
+
+def _conv_mode():
+    kind = _ARITH["mode"]
+    if kind is None:
+        kind = "fp32"
+    return _lib.HL_CONV_BF16 if kind == "bf16" else _MODE
+
+
+def _conv_raw(x, w, b, ks, stride=1, ups=0, mode=None):
     """x (N,H,W,Cx) NHWC dense, Cx % 16 == 0; w (Cout, Cx, ks, ks) contiguous; -> (N,Ho,Wo,Cout)."""
+    mode = _MODE if mode is None else mode
     L = _lib.lib()
     N, H, W, Cx = x.shape
     Cout = w.shape[0]
@@ -49,7 +67,7 @@ def _conv_raw(x, w, b, ks, stride=1, ups=0):
     rows = (Cout + 63) // 64 * 64
     scratch = th.empty(rows * Cx * ks * ks * 5 + 256 + (16 << 20) + N * Cx * H * W, device=x.device, dtype=th.float32)
     with _lib.on(x.device):
-        _lib.check(L.hl_conv2d_nhwc_mode(_MODE, _lib.ptr(x), N, H, W, Cx, _lib.ptr(w), _lib.ptr(b), Cout, ks, stride, ups, None, None, 0,
+        _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(x), N, H, W, Cx, _lib.ptr(w), _lib.ptr(b), Cout, ks, stride, ups, None, None, 0,
                                          None, _lib.ptr(out), _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()), "hl_conv2d_nhwc_mode")
     return out
 
@@ -66,9 +84,11 @@ class _Conv(th.autograd.Function):
         ks = w4.shape[2]
         Cin = w4.shape[1]
         wp = w4 if x.shape[-1] == Cin else F.pad(w4, (0, 0, 0, 0, 0, x.shape[-1] - Cin))    # zero weights for the padded input channels
-        y = _conv_raw(x, wp.contiguous(), b, ks, stride, ups)
+        mode = _conv_mode()
+        y = _conv_raw(x, wp.contiguous(), b, ks, stride, ups, mode)
         ctx.save_for_backward(x, w4)
         ctx.meta = (ks, stride, ups, w.shape, b is not None)
+        ctx.mode = mode                                          # backward-data in the arithmetic of the forward (autocast is off in backward)
         return y
 
     @staticmethod
@@ -89,7 +109,7 @@ class _Conv(th.autograd.Function):
             extra = N * 4 * Ho * Wo * Cyp if stride == 2 else (N * Ho * Wo * Cxp if ups else 0)
             scratch = th.empty(rows * Cyp * ks * ks * 5 + 512 + (16 << 20) + extra, device=dy.device, dtype=th.float32)
             with _lib.on(dy.device):
-                _lib.check(L.hl_conv2d_nhwc_bwd_data(_MODE, _lib.ptr(dyp), N, Ho, Wo, Cyp, _lib.ptr(w4.contiguous()), Cout, Cin, ks, stride, ups,
+                _lib.check(L.hl_conv2d_nhwc_bwd_data(ctx.mode, _lib.ptr(dyp), N, Ho, Wo, Cyp, _lib.ptr(w4.contiguous()), Cout, Cin, ks, stride, ups,
                                                      _lib.ptr(dx), Cxp, _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()),
                            "hl_conv2d_nhwc_bwd_data")
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
@@ -239,6 +259,13 @@ def forward_train(model, x, timesteps, x_cond=None, y=None):
         assert y is not None and y.shape == (x.shape[0],)
     if model.cond_type == "concat" and x_cond is not None:   # unet.py:572-573 (UNetModel.forward has already joined them when it is the caller)
         x, x_cond = th.cat([x, x_cond], dim=1), None
+    if th.is_autocast_enabled():
+        # The caller trains under autocast (train_util.py:214, --use_amp True).  The kernels in here take fp32 tensors, so torch's own
+        # autocasting of the few tensor ops of this function is switched off.  The convolutions stay on the fp32 Winograd kernels: they are
+        # faster than the 16-bit direct kernel of this library (HL_CONV_BF16, measured 290 us against 242 us on 192->192 @256x256 at
+        # microbatch 2 - it is bound by LDS-DMA issue, not by the matrix pipe), which therefore is opt-in (set_train_arithmetic("bf16")).
+        with th.autocast(device_type="cuda", enabled=False):
+            return forward_train(model, x.float(), timesteps, None if x_cond is None else x_cond.float(), y)
     emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
     if model.cond_type == "AdaGN":           # unet.py:574-578 (like the embedding MLP: three tiny torch modules, autograd's own backward)
         assert x_cond is not None, "cond_type='AdaGN' needs x_cond"

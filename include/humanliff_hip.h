@@ -305,6 +305,12 @@ int hl_unet_set_overlap(void *handle, int enable);
 #define HL_CONV_BF16X3 1
 #define HL_CONV_FP32_DIRECT 2
 #define HL_CONV_FP32_F23 3
+/* HL_CONV_BF16 (opt-in, direct only): 16-bit MFMA arithmetic for the TRAINING path - what the reference's train scripts select with
+ *   --use_amp True (train_util.py:214 autocast): every activation is rounded to bf16 (nearest even) and multiplied with the weight's two
+ *   leading bf16 planes (16 significand bits), fp32 accumulation on v_mfma_f32_32x32x16_bf16; tensors stay fp32 in HBM, master weights
+ *   fp32.  Relative error per product <= 2^-9; NOT an inference default.  Forward (hl_conv2d_nhwc_mode) and backward-data
+ *   (hl_conv2d_nhwc_bwd_data) take it; weight gradients stay fp32. */
+#define HL_CONV_BF16 4
 int hl_unet_set_conv_mode(void *handle, int mode);
 
 /* Instrumentation for the roofline measurement (bench.py): with profiling enabled every kernel launch

@@ -308,3 +308,98 @@ def test_eval_mode_input_gradient_is_not_dropped():
     assert (gx - gt).abs().max() < 5e-4 * float(gt.abs().max())
     with torch.no_grad():                                     # and a plain sampling call on the same model still takes the inference kernels
         assert not model(x0, t, xc, y=y).requires_grad
+
+
+def test_bf16_conv_mode_forward_and_backward_data():
+    """HL_CONV_BF16 (opt-in 16-bit MFMA arithmetic of the training path): activations rounded to bf16 x 16-bit weights, fp32 accumulation.  A 3x3
+    and a 1x1 layer, forward and backward-data, against float64: relative error of a few 2^-9 per product, averaged down over K."""
+    from humanliff_amd.improved_diffusion import unet_train as ut
+    g = torch.Generator().manual_seed(4)
+    for (N, H, W, C, Co, ks) in ((2, 64, 64, 96, 192, 3), (2, 64, 64, 384, 192, 1)):   # (only layers that take the direct DMA tile - Cout a multiple of 96, enough rows - take the mode)
+        x = torch.randn((N, C, H, W), generator=g)
+        w = torch.randn((Co, C, ks, ks), generator=g) / (C * ks * ks) ** 0.5
+        b = torch.randn((Co,), generator=g) * 0.1
+        cot = torch.randn((N, Co, H, W), generator=g)
+        xr = x.double().requires_grad_(True)
+        yr = F.conv2d(xr, w.double(), b.double(), padding=ks // 2)
+        (yr * cot.double()).sum().backward()
+        xd = nhwc(x).to(dev).requires_grad_(True)
+        wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        ut.set_train_arithmetic("bf16")
+        try:
+            y = ut._Conv.apply(xd, wd, bd, 1, 0)
+            (y * nhwc(cot).to(dev)).sum().backward()
+        finally:
+            ut.set_train_arithmetic(None)
+        rel = lambda a, r: float((a.double() - r).norm() / r.norm())  # noqa: E731
+        e_y, e_dx = rel(nchw(y.detach().cpu()), yr.detach()), rel(nchw(xd.grad.cpu()), xr.grad)
+        ut.set_train_arithmetic("fp32")
+        try:
+            y32 = ut._Conv.apply(xd.detach(), wd.detach(), bd.detach(), 1, 0)
+        finally:
+            ut.set_train_arithmetic(None)
+        e32 = rel(nchw(y32.cpu()), yr.detach())
+        print(f"{C}->{Co} {ks}x{ks}: bf16 mode rel-L2 forward {e_y:.2e}, backward-data {e_dx:.2e} (fp32 mode forward {e32:.1e})")
+        assert 1e-5 < e_y < 4e-3 and e_dx < 4e-3 and e32 < 1e-5      # bf16 rounding of one operand: ~2^-9 / sqrt(3) per product
+        assert not torch.equal(y.detach(), y32)                      # the mode really switched arithmetic
+
+
+def test_training_under_autocast_and_in_bf16_arithmetic_tracks_fp32():
+    """The reference trains under torch.autocast (train_util.py:214, --use_amp True).  The HIP training path accepts the autocast context
+    (its kernels take fp32 tensors, so torch's own autocasting is switched off inside); the convolutions stay on the fp32 Winograd kernels
+    there - they are FASTER than the 16-bit direct kernel this library has (242 us against 290 us on 192->192 @256x256, batch 2) - and
+    `set_train_arithmetic("bf16")` opts into HL_CONV_BF16.  Loss, gradients and a 20-step loss curve of the three runs agree."""
+    from tests.test_train_loss_cpu import inputs, tiny_model
+    from humanliff_amd.improved_diffusion import unet_train as ut
+    x0, xc = (t.to(dev) for t in inputs())
+    t, y = torch.tensor([999, 17], device=dev), torch.tensor([3, 0], device=dev)
+    noise = torch.randn(x0.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+
+    def wide_model():       # 192 base channels: layers wide enough for the direct DMA tile, which is where HL_CONV_BF16 applies
+        from humanliff_amd import synthetic as syn
+        from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+        a = model_and_diffusion_defaults()
+        a.update(dict(in_channels=27, out_channels=27, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=True,
+                      cond_type="controlnet", rescale_timesteps=False, dropout=0.0, diffusion_steps=1000, noise_schedule="linear",
+                      timestep_respacing="", image_size=32, num_channels=192, num_res_blocks=1, attention_resolutions="16"))
+        model, diffusion = create_model_and_diffusion(**a)
+        ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+        model.load_state_dict(syn.state_from_shapes(ks, 1), strict=True)
+        return model, diffusion
+
+    def run(amp, arith, steps):
+        model, diffusion = wide_model()
+        model.to(dev).train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.02)    # (plain SGD: Adam's per-parameter normalisation turns rounding noise on tiny gradients into full-size steps)
+        losses, first_grads = [], None
+        ut.set_train_arithmetic(arith)
+        try:
+            for i in range(steps):
+                with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=amp):
+                    loss = diffusion.training_losses(model, x0.clamp(-1, 1), xc, t, model_kwargs={"y": y}, noise=noise)["loss"].mean()
+                assert loss.dtype == torch.float32
+                loss.backward()
+                if i == 0:
+                    first_grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+                opt.step()
+                opt.zero_grad()
+                losses.append(float(loss.detach()))
+        finally:
+            ut.set_train_arithmetic(None)
+        return losses, first_grads
+
+    l32, g32 = run(False, None, 20)
+    lam, gam = run(True, None, 20)            # under autocast: same arithmetic as without (fp32 kernels), same numbers
+    l16, g16 = run(False, "bf16", 20)         # opt-in 16-bit MFMA arithmetic
+    assert abs(lam[0] - l32[0]) < 1e-6 * abs(l32[0]) and abs(lam[-1] - l32[-1]) < 5e-3 * abs(l32[-1])   # (GroupNorm backward sums with float atomics: runs differ in the last bits)
+    assert l32[0] != l16[0]                                          # different arithmetic ...
+    assert abs(l16[0] - l32[0]) < 2e-3 * abs(l32[0])                 # ... same loss to bf16 accuracy
+    num = sum(float(((g16[k] - g32[k]).double() ** 2).sum()) for k in g32)
+    den = sum(float((g32[k].double() ** 2).sum()) for k in g32)
+    print(f"bf16 arithmetic: first loss {l16[0]:.6f} vs fp32 {l32[0]:.6f}; gradient rel-L2 over all parameters {(num / den) ** 0.5:.2e}; "
+          f"loss after 20 steps {l16[-1]:.5f} vs {l32[-1]:.5f}")
+    assert (num / den) ** 0.5 < 3e-2
+    assert l32[-1] < l32[0] and l16[-1] < l16[0]
+    print("loss curves fp32 / bf16:", [round(v, 4) for v in l32[::4]], [round(v, 4) for v in l16[::4]])
+    worst = max(abs(a - b) / abs(b) for a, b in zip(l16, l32))
+    assert worst < 0.05, worst
