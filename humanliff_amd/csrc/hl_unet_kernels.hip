@@ -1994,7 +1994,19 @@ __global__ __launch_bounds__(256) void k_gn_coef_st(StatSrcK s0, StatSrcK s1, in
         if (src.p == nullptr || hi <= lo) continue;
         const int nch = hi - lo, items = nch * src.slots;
         const float *q = src.p + (long)n * src.slots * src.Cn * 2;
-        for (int i = tid; i < items; i += 256) {
+        // (eight loads in flight per thread: the walk over up to 1024 slots is latency-bound - 7.9 us per launch, 156 launches per step)
+        int i = tid;
+        for (; i + 7 * 256 < items; i += 8 * 256) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = i + u * 256, slot = j / nch, c = lo + (j - slot * nch);
+                v[u] = *reinterpret_cast<const float2 *>(q + ((long)slot * src.Cn + c) * 2);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += (double)v[u].x; ss += (double)v[u].y; }
+        }
+        for (; i < items; i += 256) {
             const int slot = i / nch, c = lo + (i - slot * nch);
             const float2 v = *reinterpret_cast<const float2 *>(q + ((long)slot * src.Cn + c) * 2);
             s += (double)v.x;

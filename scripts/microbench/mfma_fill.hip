@@ -17,7 +17,7 @@ __device__ __forceinline__ void mfma_lit(float a, float b) {
 #undef M
 }
 // KIND 0 none, 1 v_pk_fma_f32 (f32x2 fma), 2 v_fma_f32 (asm), 3 ds_read_b128, 4 buffer_load_dwordx4 -> VGPR (L2-hot), 5 LDS-DMA 1 KiB piece,
-// 6 v_fma_f32 (compiler), 7 s_add (SALU), 8 v_pk_fma with a VGPR constant (no SGPR operand)
+// 6 v_fma_f32 (compiler), 7 s_add (SALU), 8 v_pk_fma with a VGPR constant (no SGPR operand), 9 v_exp_f32 (transcendental), 10 v_mov_b32
 template <int KIND, int NF, int ORDER>
 __global__ __launch_bounds__(256, 1) void k(const float *src, int iters, float *sink, long long *cyc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -56,6 +56,8 @@ __global__ __launch_bounds__(256, 1) void k(const float *src, int iters, float *
                     else if constexpr (KIND == 6) s[(J * NF + f) & 15] = __builtin_fmaf(s[(J * NF + f) & 15], c1, a);
                     else if constexpr (KIND == 7) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sacc));
                     else if constexpr (KIND == 8) p[r] = __builtin_elementwise_fma(q[(r + 1) & 7], p[r], q[r]);
+                    else if constexpr (KIND == 9) s[(J * NF + f) & 15] = __builtin_amdgcn_exp2f(s[(J * NF + f) & 15]);
+                    else if constexpr (KIND == 10) asm volatile("v_mov_b32 %0, %1" : "=v"(s[(J * NF + f) & 15]) : "v"(a));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }(), ...);
@@ -103,6 +105,8 @@ int main() {
     run<3, 1>("ds_read_b128", src, sink, cyc); run<3, 2>("ds_read_b128", src, sink, cyc); run<3, 4>("ds_read_b128", src, sink, cyc);
     run<4, 1>("buffer_load_dwordx4", src, sink, cyc); run<4, 2>("buffer_load_dwordx4", src, sink, cyc);
     run<5, 1>("LDS-DMA piece", src, sink, cyc);
+    run<9, 1>("v_exp_f32", src, sink, cyc); run<9, 2>("v_exp_f32", src, sink, cyc); run<9, 4>("v_exp_f32", src, sink, cyc); run<9, 8>("v_exp_f32", src, sink, cyc);
+    run<10, 4>("v_mov_b32", src, sink, cyc); run<10, 8>("v_mov_b32", src, sink, cyc);
     run<7, 2>("s_add_i32", src, sink, cyc); run<7, 8>("s_add_i32", src, sink, cyc);
     run<1, 2, 1>("v_pk_fma_f32, same-tile runs", src, sink, cyc); run<1, 4, 1>("v_pk_fma_f32, same-tile runs", src, sink, cyc);
     return 0;
