@@ -39,11 +39,11 @@ FINE_FLOP_PER_RAY = 256 * 132608
 COARSE_FLOP_PER_RAY = 128 * 79616
 FINE_FLOP_PER_RAY_TOTAL = FINE_FLOP_PER_RAY + COARSE_FLOP_PER_RAY   # the reference's schedule: 44 138 496 FLOP per ray
 # Fabric-side bytes per launch of the two dominant kernels from the separate rocprofv3 PMC passes (FETCH_SIZE
-# doubled per the gfx950 calibration, WRITE_SIZE as is): profiles/r02_pmc_hbm_traffic.md.  Not measured by this
+# doubled per the gfx950 calibration, WRITE_SIZE as is): profiles/r03_pmc_hbm_traffic.md.  Not measured by this
 # script - PMC collection needs its own runs.
-PMC_TRAFFIC = {"k_conv_avg_launch_b4": 329e6, "k_march_fine_512x512": 4.1e9, "k_march_eval_512x512": 0.72e9,
-               "source": "profiles/r02_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv path: (378.06 GB read "
-                         "+ 127.54 GB written) / 6 forwards / 256 launches; k_march<true,true>: (1.50 + 4.29 GB) / 8 launches)"}
+PMC_TRAFFIC = {"k_conv_avg_launch_b4": 308e6, "k_march_fine_512x512": 4.1e9, "k_march_eval_512x512": 0.72e9,
+               "source": "profiles/r03_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv path: (343.78 GB read "
+                         "+ 129.81 GB written) / 6 forwards / 256 launches) and profiles/r02_pmc_hbm_traffic.md (k_march<true,true>: (1.50 + 4.29 GB) / 8 launches)"}
 
 F4 = dict(image_size=256, in_channels=27, out_channels=27, num_channels=192, num_res_blocks=3, num_heads=4,
           num_heads_upsample=-1, attention_resolutions="32,16,8", dropout=0.0, learn_sigma=False, sigma_small=False,
@@ -190,7 +190,7 @@ def bench_unet(args, rank, world, dev):
     # `achieved` / `frac`: FLOPs the matrix pipe actually EXECUTES (Winograd F(4x4,3x3) issues 36 of the 144 multiplies of a direct 3x3
     # convolution per 4x4 outputs, F(2x2,3x3) 16 of 36 per 2x2) over the conv-path time, against the fp32 MFMA peak - a real fraction (<= 1).  The algorithmic figure (direct-convolution
     # FLOPs of SURVEY 8(d) over the same time) is reported next to it as `algorithmic`; it can exceed the peak.
-    roof = {"bound": "mfma", "kernel": "k_conv_wino4 (Winograd F(4x4,3x3), 3x3 layers of the 256- and 128-pixel levels) + k_conv_wino (F(2x2,3x3), 3x3 layers of the smaller levels) + k_conv_dma (direct implicit GEMM, the rest), "
+    roof = {"bound": "mfma", "kernel": "k_conv_wino4w / k_conv_wino4 (Winograd F(4x4,3x3), 3x3 layers of the 256- to 32-pixel levels) + k_conv_wino (F(2x2,3x3), the 16-pixel level) + k_conv_dma (direct implicit GEMM, the rest), "
                                        "v_mfma_f32_32x32x2_f32; with their pre/post passes (k_gn_apply, k_splitk_finish); all launches of one denoise step",
             "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),

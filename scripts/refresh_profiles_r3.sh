@@ -20,3 +20,10 @@ done < scripts/pmc_wino.txt
 python scripts/pmc_sq_summary.py $O/pmc_sq_conv.md $O/sq1 $O/sq2 $O/sq3 > /dev/null
 rm -rf $O/tr_a $O/tr_b $O/pmc_f $O/pmc_w $O/sq1 $O/sq2 $O/sq3
 ls -la $O
+scripts/microbench/mfma_fill > $O/microbench_mfma_fill.txt 2>&1
+HL_WINO4W=1 rocprofv3 --kernel-trace -d $O/ks1 -- python scripts/wino4_ksweep.py > /dev/null 2>&1; python scripts/rocpd_list.py $O/ks1 k_conv_wino4w > $O/ksweep_wino4w.txt
+HL_WINO4W=0 rocprofv3 --kernel-trace -d $O/ks0 -- python scripts/wino4_ksweep.py > /dev/null 2>&1; python scripts/rocpd_list.py $O/ks0 k_conv_wino4 > $O/ksweep_wino4.txt
+python scripts/wino4w_probe.py 10 > $O/wino4w_probe.txt 2>&1
+python scripts/bf16_probe.py > $O/bf16_probe.txt 2>&1
+rm -rf $O/ks0 $O/ks1
+ls $O
