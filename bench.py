@@ -177,29 +177,35 @@ def bench_unet(args, rank, world, dev):
     _lib.check(L.hl_unet_profile(handle, 0))
     fam = ("k_conv_dma / k_conv (direct implicit GEMM)", "k_conv_wino (Winograd F(2x2,3x3))", "k_conv_bf3 (bf16x3)", "k_conv_wino4w / k_conv_wino4 (Winograd F(4x4,3x3))")[dk[0] & 3]
     dom_ms = dv[0] / max(dv[3], 1.0)
-    dominant = {"kernel": fam, "layer": f"{dk[2]}->{dk[3]} {dk[4]}x{dk[4]} @{256 >> dk[1]}x{256 >> dk[1]}, batch {B}", "launches_per_step": int(dv[3]),
-                "avg_launch_ms": round(dom_ms, 4), "total_ms_per_step": round(dv[0], 3),
-                "executed_tflops": round(dv[2] / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None,
-                "frac": round(dv[2] / (dom_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if dom_ms > 0 else None,
-                "algorithmic_tflops": round(dv[1] / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None,
-                "what": "the convolution shape with the largest share of the step; kernel time alone (HIP events behind the GroupNorm pre-pass), "
-                        "FLOPs the matrix pipe executes (a quarter of the direct-convolution count for F(4x4,3x3)) against the fp32 MFMA peak"}
+    dom_exec = dv[2] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    dominant = {"kernel": fam, "layers": f"{dk[4]}x{dk[4]} convolutions with {dk[3]} output channels @{256 >> dk[1]}x{256 >> dk[1]}, batch {B}"
+                                         + (" behind a nearest-x2 upsample" if dk[2] else "") + " (all input channel counts: one rocprofv3 kernel / grid row)",
+                "launches_per_step": int(dv[3]), "avg_launch_ms": round(dom_ms, 4), "total_ms_per_step": round(dv[0], 3),
+                "executed_gflop_per_launch": round(dv[2] / 1e9, 2), "algorithmic_gflop_per_launch": round(dv[1] / 1e9, 2),
+                "executed_tflops": round(dom_exec, 2), "algorithmic_tflops": round(dv[1] / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None}
     conv_ms, conv_fl, conv_n = ms[0], fl[0], nl[0]
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     executed = xf[0] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     # `achieved` / `frac`: FLOPs the matrix pipe actually EXECUTES (Winograd F(4x4,3x3) issues 36 of the 144 multiplies of a direct 3x3
     # convolution per 4x4 outputs, F(2x2,3x3) 16 of 36 per 2x2) over the conv-path time, against the fp32 MFMA peak - a real fraction (<= 1).  The algorithmic figure (direct-convolution
     # FLOPs of SURVEY 8(d) over the same time) is reported next to it as `algorithmic`; it can exceed the peak.
-    roof = {"bound": "mfma", "kernel": "k_conv_wino4w / k_conv_wino4 (Winograd F(4x4,3x3), 3x3 layers of the 256- to 32-pixel levels) + k_conv_wino (F(2x2,3x3), the 16-pixel level) + k_conv_dma (direct implicit GEMM, the rest), "
-                                       "v_mfma_f32_32x32x2_f32; with their pre/post passes (k_gn_apply, k_splitk_finish); all launches of one denoise step",
-            "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
-            "algorithmic": {"tflops": round(achieved, 2), "speedup_vs_executed": round(achieved / executed, 3) if executed > 0 else None,
-                            "x_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                            "note": "direct-convolution FLOPs (SURVEY 8(d): 2*M*Cout*Cin*taps) over the same time; not a roofline fraction"},
+    # `roofline` is the DOMINANT KERNEL's: FLOPs its launches issue to the matrix pipe (Winograd F(4x4,3x3) issues 36 of the 144 multiplies of
+    # a direct 3x3 convolution per 4x4 outputs) / its own launch time (HIP events inside hl_unet_forward, behind the GroupNorm pre-pass) /
+    # the fp32 MFMA peak - a real fraction.  `algorithmic` is the same launch priced in direct-convolution FLOPs (exceeds the
+    # peak); `conv_path` the same two figures for ALL convolution launches of the step with their pre / post passes (round 2's `frac`).
+    roof = {"bound": "mfma", "kernel": dominant["kernel"] + ": " + dominant["layers"],
+            "achieved": round(dom_exec, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dom_exec / PEAK_F32_MFMA_TFLOPS, 4),
+            "avg_launch_ms": dominant["avg_launch_ms"], "launches_per_step": dominant["launches_per_step"], "ms_per_step_in_this_kernel": dominant["total_ms_per_step"],
+            "algorithmic": {"tflops": dominant["algorithmic_tflops"], "x_peak": round((dominant["algorithmic_tflops"] or 0.0) / PEAK_F32_MFMA_TFLOPS, 4),
+                            "note": "direct-convolution FLOPs (SURVEY 8(d): 2*M*Cout*Cin*taps) of the same launches over the same time; not a roofline fraction"},
+            "note": "fp32 MFMA and the vector ALU share the SIMD's fp32 lanes (scripts/microbench/mfma_fill.hip): the kernel's own input transform (VALU) is "
+                    "added to its MFMA time, so 1.0 is not reachable for a Winograd kernel - MFMAs alone run this launch shape at 0.70 (profiles/r03_wino4w_ablations.md)",
+            "conv_path": {"what": "all convolution launches of one denoise step (k_conv_wino4w / k_conv_wino4 / k_conv_wino / k_conv_dma / k_conv) with their pre / post "
+                                  "passes (k_gn_apply, k_splitk_finish)", "executed_tflops": round(executed, 2), "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+                          "algorithmic_tflops": round(achieved, 2), "algorithmic_x_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                          "launches_per_step": int(conv_n), "gflop_per_step": round(conv_fl / 1e9, 1), "executed_gflop_per_step": round(xf[0] / 1e9, 1),
+                          "ms_per_step": round(conv_ms, 3), "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4)},
             "traffic": PMC_TRAFFIC["k_conv_avg_launch_b4"] if B == 4 else None, "traffic_source": PMC_TRAFFIC["source"],
-            "dominant": dominant, "launches_per_step": int(conv_n), "gflop_per_step": round(conv_fl / 1e9, 1), "executed_gflop_per_step": round(xf[0] / 1e9, 1),
-            "ms_per_step": round(conv_ms, 3), "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4),
             "other_ms": {"groupnorm": round(ms[1], 3), "attention": round(ms[2], 3), "emb_prep": round(ms[3], 3)}}
     # ---- sustained leg: the loop keeps running for >= 200 more steps; steps/s and the shader clock sampled meanwhile ----
     roof["sustained"] = None

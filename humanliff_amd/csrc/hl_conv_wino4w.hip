@@ -304,7 +304,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
         const unsigned uvp = (unsigned)lane * 16u;
         const int cbstep = nkt * 36 * 1024;                           // second 32-channel half of the workgroup's 64: the next packed block
         const int ubase = ((2 * nb * nkt + kt0) * 36 + W * 9) * 1024; // (k-tile kt0, frequency 0, half 0) of this wave
-        f32x4 U[6];                                                   // frequency pair f lives in U[(f % 3) * 2 + cb] (9 pairs per k-tile: no phase)
+#ifndef HL_W4W_RING
+#define HL_W4W_RING 3   // frequency pairs in the weight ring (3 or 6): prefetch distance 24 or 48 MFMAs (measured equal: 120.8 vs 120.2 denoise-steps/s)
+#endif
+        constexpr int RING = HL_W4W_RING;
+        static_assert(RING == 3 || RING == 6, "weight ring");
+        f32x4 U[2 * RING];                                            // global pair g = 9 t + f lives in U[(g % RING) * 2 + cb] (RING 6: the phase alternates with t & 1)
         auto load_u = [&](int soffU, auto fc, auto slotc) {           // frequency pair f of the k-tile at soffU -> ring slot
             constexpr int f = decltype(fc)::value, sl = decltype(slotc)::value;
 #pragma unroll
@@ -312,14 +317,23 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
                 U[sl * 2 + cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, uvp, soffU + f * 1024 + cb * cbstep, 0));
         };
 
+#ifndef HL_W4W_ROTATE
+#define HL_W4W_ROTATE 0
+#endif
+        // HL_W4W_ROTATE = 1 (tried, measured, off): every workgroup walks K from its own starting k-tile and wraps, so that the 32 CUs of
+        // an XCD - which run in step - do not ask the L2 for the SAME weight fragments at the same time (the SQ counters show 10 % of the
+        // wave cycles parked at s_waitcnt although the loads are issued 24 MFMAs ahead).  Result: 15 % SLOWER (1 712 -> 1 970 us at 768
+        // input channels, 519 -> 564 us at 192): the lock-step is what makes one CU's miss everybody else's hit.
+        const int rot = HL_W4W_ROTATE ? (int)(((unsigned)tb * 7u + (unsigned)nb * 3u) % (unsigned)max(ntiles, 1)) : 0;
+        auto tmap = [&](int t) { const int x = min(t, ntiles - 1) + rot; return x >= ntiles ? x - ntiles : x; };   // t-th k-tile this workgroup takes
         f32x4 V0[9], V1[9];
         if (ntiles > 0) {
             // prologue: patches 0 and 1 into the two stages, the first six weight pairs, the transform of patch 0 (nothing to overlap it with)
-            load_pieces(kt0 * kstep);
+            load_pieces((kt0 + tmap(0)) * kstep);
             [&]<int... J>(std::integer_sequence<int, J...>) { (store_piece(0, std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, 6>{});
-            load_pieces((kt0 + (ntiles > 1 ? 1 : 0)) * kstep);
+            load_pieces((kt0 + tmap(1)) * kstep);
             [&]<int... J>(std::integer_sequence<int, J...>) { (store_piece(1, std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, 6>{});
-            [&]<int... F>(std::integer_sequence<int, F...>) { (load_u(ubase, std::integral_constant<int, F>{}, std::integral_constant<int, F>{}), ...); }(std::make_integer_sequence<int, 3>{});
+            [&]<int... F>(std::integer_sequence<int, F...>) { (load_u(ubase + tmap(0) * (36 * 1024), std::integral_constant<int, F>{}, std::integral_constant<int, F>{}), ...); }(std::make_integer_sequence<int, RING>{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -339,13 +353,14 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
         // past the end the loads re-read the last k-tile and the transform chews on a stale stage.
         auto body = [&](auto sc, f32x4 (&Vc)[9], f32x4 (&Vn)[9], int t) {
             constexpr int S = decltype(sc)::value;                    // = t & 1: stage of patch t
-            const int tl1 = min(t + 1, ntiles - 1), tl2 = min(t + 2, ntiles - 1);
-            const int soffU0 = (HL_W4W_ABL & 64) ? ubase : ubase + t * (36 * 1024), soffU1 = (HL_W4W_ABL & 64) ? ubase : ubase + tl1 * (36 * 1024);   // (64: hot weights)
-            const int soffA2 = (HL_W4W_ABL & 128) ? kt0 * kstep : (kt0 + tl2) * kstep;                                                                 // (128: hot patch)
+            const int tl0 = tmap(t), tl1 = tmap(t + 1), tl2 = tmap(t + 2);
+            const int soffU0 = (HL_W4W_ABL & 64) ? ubase : ubase + tl0 * (36 * 1024), soffU1 = (HL_W4W_ABL & 64) ? ubase : ubase + tl1 * (36 * 1024);   // (64: hot weights)
+            const int soffA2 = (HL_W4W_ABL & 128) ? kt0 * kstep : (kt0 + tl2) * kstep;                                                                   // (128: hot patch)
             [&]<int... J>(std::integer_sequence<int, J...>) {
                 ([&] {
                     constexpr int Jc = J, f = J >> 3, idx = J & 7, s = idx >> 1, cb = idx & 1;
-                    if constexpr (!(HL_W4W_ABL & 16)) mfma_tile<f * 2 + cb>(accv[(f * 2 + cb) & 1], Vc[f][s], U[(f % 3) * 2 + cb][s]);
+                    constexpr int g = 9 * S + f, us = (g % RING) * 2;     // global pair index (mod 18), its ring slot
+                    if constexpr (!(HL_W4W_ABL & 16)) mfma_tile<f * 2 + cb>(accv[(f * 2 + cb) & 1], Vc[f][s], U[us + cb][s]);
                     if constexpr ((HL_W4W_ABL & 32) != 0) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (!(HL_W4W_ABL & 2)) {
@@ -362,13 +377,15 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
                     // registers that die at an MFMA to the instructions right behind it (a burst overwrote the weight fragment of the MFMA in
                     // front of it: wrong sums).  The operands of this gap's MFMA and of the one before stay alive to the end of the gap.
                     if constexpr (idx >= 1) {   // (idx 0: the previous MFMA's fragment has already been handed to a load that lands much later)
-                        asm volatile("" ::"v"(Vc[f]), "v"(U[(f % 3) * 2 + ((idx - 1) & 1)]));
+                        asm volatile("" ::"v"(Vc[f]), "v"(U[us + ((idx - 1) & 1)]));
                     } else if constexpr (J >= 1) asm volatile("" ::"v"(Vc[f - 1]));
-                    asm volatile("" ::"v"(Vc[f]), "v"(U[(f % 3) * 2 + cb]));
+                    asm volatile("" ::"v"(Vc[f]), "v"(U[us + cb]));
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (idx == 7 && !(HL_W4W_ABL & 4)) {   // pair f is consumed: its ring slot takes pair f+3 (of this k-tile or the next)
-                        if constexpr (f + 3 < 9) load_u(soffU0, std::integral_constant<int, f + 3>{}, std::integral_constant<int, f % 3>{});
-                        else load_u(soffU1, std::integral_constant<int, f + 3 - 9>{}, std::integral_constant<int, f % 3>{});
+                        // (its slot takes pair g + RING: RING pairs = 8 RING MFMAs ahead; patch loads that sit in front of it in the in-order
+                        //  return queue then have that long to land before they can stall a weight wait)
+                        if constexpr (f + RING < 9) load_u(soffU0, std::integral_constant<int, f + RING>{}, std::integral_constant<int, g % RING>{});
+                        else load_u(soffU1, std::integral_constant<int, f + RING - 9>{}, std::integral_constant<int, g % RING>{});
                     }
                     if constexpr (!(HL_W4W_ABL & 8)) {
                         if constexpr (Jc == GAP_PATCH_LOAD) load_pieces(soffA2);

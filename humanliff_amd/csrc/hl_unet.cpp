@@ -480,7 +480,8 @@ struct Exec {
             int lvl = 0;
             while (lvl < 7 && (out.H << lvl) < H) ++lvl;
             n.census[a.path & 3][lvl] += 1;
-            span_key[0] = a.path; span_key[1] = lvl; span_key[2] = c.Cin; span_key[3] = c.Cout; span_key[4] = c.ks;
+            // (keyed like a rocprofv3 per-kernel, per-grid row: kernel family, level, Cout, kernel size - the input channel counts of a level share a row)
+            span_key[0] = a.path; span_key[1] = lvl; span_key[2] = ups ? 1 : 0; span_key[3] = c.Cout; span_key[4] = c.ks;
         }
         const double fl = 2.0 * (double)out.pixels() * c.Cout * c.Cin * c.ks * c.ks;
         // Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36; bf16x3: six bf16 MFMA products per fp32 product

@@ -325,8 +325,9 @@ int hl_unet_profile_read(void *handle, double *h_ms, double *h_flops, int64_t *h
 int hl_unet_profile_read_ex(void *handle, double *h_ms, double *h_flops, double *h_exec_flops, int64_t *h_launches);
 
 /* The convolution shape that took the most time in the spans of the last hl_unet_profile_read(_ex): h_vals = {total ms over its launches,
- * algorithmic FLOPs per launch, FLOPs issued to the matrix pipe per launch, number of launches}, h_key = {kernel family (as in
- * hl_unet_dispatch_census), resolution level, Cin, Cout, kernel size}.  The time is the convolution kernel's own (an event behind the
+ * algorithmic FLOPs per launch, FLOPs issued to the matrix pipe per launch, number of launches} (averages over the launches of the shape),
+ * h_key = {kernel family (as in hl_unet_dispatch_census), resolution level, 1 if behind a nearest-x2 upsample, Cout, kernel size} - the grouping
+ * of a rocprofv3 per-kernel, per-grid row (layers that differ only in the input channel count share it).  The time is the convolution kernel's own (an event behind the
  * GroupNorm pre-pass k_gn_apply(_blk) separates the two; a split-K finish pass, where there is one, is included). */
 int hl_unet_profile_dominant(void *handle, double *h_vals, int *h_key);
 
