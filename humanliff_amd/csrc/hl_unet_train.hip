@@ -9,8 +9,9 @@
 //                                  as a GEMM over the pixels on v_mfma_f32_32x32x2_f32 (3x3 layers: _t, all taps per workgroup)
 //   k_gn_apply (hl_unet_kernels)   GroupNorm32 (+scale/shift) (+SiLU) apply, nn.py:100, unet.py:198-219
 //   k_gn_bwd_reduce / _apply       its backward: per-(n,c) reductions, then dx = k1*du + k2*x + k3
-// fp32 atomics accumulate the GroupNorm reductions: a training step is not bit-reproducible run to run, like the reference's cuDNN
-// backward (the convolutions' weight / bias gradients are: fixed-order slab sums).
+// No float atomics on this path: the GroupNorm reductions and the convolutions' weight / bias gradients are partial sums added in a fixed
+// order (k_gn_bwd_fin, k_wgrad_finish), so the kernels of a training step give the same bits run to run.  (Only the fallback k_conv_wgrad
+// for channel counts that are not multiples of 4 - no layer of the network - still ends in atomics.)
 #include "hl_unet_kernels.h"
 
 namespace hl {
@@ -421,16 +422,16 @@ __global__ __launch_bounds__(256) void k_wgrad_finish(const float *__restrict__ 
 // With du = dout * (act ? silu'(u) : 1) the two reductions everything else follows from are, per (n, c):
 //     S1 = sum_p du,    S2 = sum_p du * x
 // (parameter gradients, the scale / shift gradients and the three per-(n,c) coefficients of dx = k1*du + k2*x + k3 are small (N,C)
-// tensor algebra done by the caller).  grid (chunks, N); a thread owns a float4 of channels; float atomics into S (N, C, 2), zeroed.
+// tensor algebra done by the caller).  grid (chunks, N); a thread owns a float4 of channels.  No atomics: the k pixel rows of a workgroup
+// meet in LDS and are added in row order, every workgroup stores its 2C sums to part[n][chunk][2C], and k_gn_bwd_fin adds the chunks
+// in chunk order - the same bits on every run.
 __global__ void k_gn_bwd_reduce(const float *__restrict__ x, long x_pitch, const float *__restrict__ dout, long d_pitch, int HW, int C,
-                                int nchunks, const float *__restrict__ cA, const float *__restrict__ cB, int act, float *__restrict__ S) {
+                                int nchunks, const float *__restrict__ cA, const float *__restrict__ cB, int act, float *__restrict__ part) {
     const int cq = C >> 2;
     const int k = blockDim.x / cq;
     const int c4 = threadIdx.x % cq, prow = threadIdx.x / cq;
     const int n = blockIdx.y, chunk = blockIdx.x;
-    extern __shared__ float sh[];                                 // [C][2]
-    for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) sh[e] = 0.f;
-    __syncthreads();
+    extern __shared__ float sh[];                                 // [k][2C]: row r, channel c -> (S1, S2) at r*2C + 2c
     const int per = (HW + nchunks - 1) / nchunks;
     const int p0 = chunk * per, p1 = min(HW, p0 + per);
     const f32x4 a = *reinterpret_cast<const f32x4 *>(cA + (long)n * C + c4 * 4), b = *reinterpret_cast<const f32x4 *>(cB + (long)n * C + c4 * 4);
@@ -448,23 +449,37 @@ __global__ void k_gn_bwd_reduce(const float *__restrict__ x, long x_pitch, const
     };
     auto ldx = [&](int pp) { return *reinterpret_cast<const f32x4 *>(x + ((long)n * HW + pp) * x_pitch + c4 * 4); };
     auto ldd = [&](int pp) { return *reinterpret_cast<const f32x4 *>(dout + ((long)n * HW + pp) * d_pitch + c4 * 4); };
-    if (prow < k) {
-        int pp = p0 + prow;
-        for (; pp + 3 * k < p1; pp += 4 * k) {                     // four pixels (eight 16-byte loads) in flight per thread
-            const f32x4 x0 = ldx(pp), d0 = ldd(pp), x1 = ldx(pp + k), d1 = ldd(pp + k), x2 = ldx(pp + 2 * k), d2 = ldd(pp + 2 * k),
-                        x3 = ldx(pp + 3 * k), d3 = ldd(pp + 3 * k);
-            accum(x0, d0); accum(x1, d1); accum(x2, d2); accum(x3, d3);
-        }
-        for (; pp < p1; pp += k) accum(ldx(pp), ldd(pp));
+    int pp = p0 + prow;
+    for (; pp + 3 * k < p1; pp += 4 * k) {                         // four pixels (eight 16-byte loads) in flight per thread
+        const f32x4 x0 = ldx(pp), d0 = ldd(pp), x1 = ldx(pp + k), d1 = ldd(pp + k), x2 = ldx(pp + 2 * k), d2 = ldd(pp + 2 * k),
+                    x3 = ldx(pp + 3 * k), d3 = ldd(pp + 3 * k);
+        accum(x0, d0); accum(x1, d1); accum(x2, d2); accum(x3, d3);
     }
-    // the k pixel rows of the workgroup meet in LDS, then one global atomic per channel and workgroup
+    for (; pp < p1; pp += k) accum(ldx(pp), ldd(pp));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        atomicAdd(sh + (c4 * 4 + i) * 2, s1[i]);
-        atomicAdd(sh + (c4 * 4 + i) * 2 + 1, s2[i]);
+        sh[prow * 2 * C + (c4 * 4 + i) * 2] = s1[i];
+        sh[prow * 2 * C + (c4 * 4 + i) * 2 + 1] = s2[i];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) atomicAdd(S + (long)n * C * 2 + e, sh[e]);
+    for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) {
+        float v = sh[e];
+        for (int r = 1; r < k; ++r) v += sh[r * 2 * C + e];
+        part[((long)n * nchunks + chunk) * 2 * C + e] = v;
+    }
+}
+
+// S[n][e] = sum over chunks of part[n][chunk][e], e < 2C: workgroup = 64 entries x 4 chunk quarters, the quarters added in order
+__global__ __launch_bounds__(256) void k_gn_bwd_fin(const float *__restrict__ part, int nchunks, int C2, float *__restrict__ S) {
+    __shared__ float sh[4][64];
+    const int n = blockIdx.y, e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int per = (nchunks + 3) / 4, c0 = q * per, c1 = min(nchunks, c0 + per);
+    float v = 0.f;
+    if (e < C2)
+        for (int c = c0; c < c1; ++c) v += part[((long)n * nchunks + c) * C2 + e];
+    sh[q][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (q == 0 && e < C2) S[(long)n * C2 + e] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 // dx = k1[n,c] * du + k2[n,c] * x + k3[n,c]  (+ dx_add: the gradient arriving over the residual branch), du as above
@@ -688,16 +703,31 @@ int hl_gn_apply_nhwc(const float *x, long x_pitch, int N, int HW, int C, const f
     return gn_apply(v, coefA, coefB, silu, y, (hipStream_t)stream);
 }
 
-int hl_gn_backward_reduce(const float *x, long x_pitch, const float *dout, int N, int HW, int C, const float *coefA, const float *coefB,
-                          int silu, float *S, void *stream) {
-    HL_REQUIRE(x && dout && coefA && coefB && S && C % 4 == 0 && x_pitch % 4 == 0 && C <= 4096, "hl_gn_backward_reduce: bad argument");
+static int gn_bwd_chunks(int HW, int C) {
     const int cq = C / 4;
     int k = 256 / cq; if (k < 1) k = 1;
-    const int threads = cq * k;
-    int chunks = HW / (k * 16); if (chunks < 1) chunks = 1; if (chunks > 1024) chunks = 1024;
-    hipLaunchKernelGGL(k_gn_bwd_reduce, dim3(chunks, N), dim3(threads), (size_t)2 * C * sizeof(float), (hipStream_t)stream, x, x_pitch, dout, (long)C,
-                       HW, C, chunks, coefA, coefB, silu, S);
-    return check_launch("k_gn_bwd_reduce");
+    int chunks = HW / (k * 16); if (chunks < 1) chunks = 1; if (chunks > 256) chunks = 256;
+    return chunks;
+}
+
+size_t hl_gn_backward_scratch_bytes(int N, int HW, int C) { return (size_t)N * gn_bwd_chunks(HW, C) * 2 * C * sizeof(float); }
+
+int hl_gn_backward_reduce(const float *x, long x_pitch, const float *dout, int N, int HW, int C, const float *coefA, const float *coefB,
+                          int silu, float *S, void *scratch, size_t scratch_bytes, void *stream) {
+    HL_REQUIRE(x && dout && coefA && coefB && S && C % 4 == 0 && x_pitch % 4 == 0 && C <= 4096, "hl_gn_backward_reduce: bad argument");
+    HL_REQUIRE(scratch && scratch_bytes >= hl_gn_backward_scratch_bytes(N, HW, C),
+               "hl_gn_backward_reduce: scratch too small (%zu bytes, hl_gn_backward_scratch_bytes says %zu)", scratch_bytes,
+               hl_gn_backward_scratch_bytes(N, HW, C));
+    const int cq = C / 4;
+    int k = 256 / cq; if (k < 1) k = 1;
+    const int threads = cq * k, chunks = gn_bwd_chunks(HW, C);
+    float *part = static_cast<float *>(scratch);
+    hipLaunchKernelGGL(k_gn_bwd_reduce, dim3(chunks, N), dim3(threads), (size_t)k * 2 * C * sizeof(float), (hipStream_t)stream, x, x_pitch, dout,
+                       (long)C, HW, C, chunks, coefA, coefB, silu, part);
+    int rc = check_launch("k_gn_bwd_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gn_bwd_fin, dim3((2 * C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, part, chunks, 2 * C, S);
+    return check_launch("k_gn_bwd_fin");
 }
 
 int hl_gn_backward_apply(const float *x, long x_pitch, const float *dout, int N, int HW, int C, const float *coefA, const float *coefB,
@@ -725,10 +755,12 @@ int hl_groupnorm_train_backward(const float *x, const float *dout, int N, int H,
                                 float *dgamma, float *dbeta, float *dscale_shift, void *scratch, size_t scratch_bytes, void *stream) {
     HL_REQUIRE(x && dout && coefA && coefB && gstat && gamma && beta && dgamma && dbeta, "hl_groupnorm_train_backward: null argument");
     HL_REQUIRE(C % 32 == 0 && (scale_shift == nullptr) == (dscale_shift == nullptr), "hl_groupnorm_train_backward: bad argument");
-    HL_REQUIRE(scratch && scratch_bytes >= (size_t)N * C * 5 * sizeof(float), "hl_groupnorm_train_backward: scratch too small (N*C*5 floats)");
+    const size_t part_bytes = hl_gn_backward_scratch_bytes(N, H * W, C);
+    HL_REQUIRE(scratch && scratch_bytes >= (size_t)N * C * 5 * sizeof(float) + part_bytes,
+               "hl_groupnorm_train_backward: scratch too small (%zu bytes; N*C*5 floats + hl_gn_backward_scratch_bytes = %zu)", scratch_bytes,
+               (size_t)N * C * 5 * sizeof(float) + part_bytes);
     float *S = static_cast<float *>(scratch), *k1 = S + (size_t)N * C * 2, *k2 = k1 + (size_t)N * C, *k3 = k2 + (size_t)N * C;
-    HL_HIP(hipMemsetAsync(S, 0, (size_t)N * C * 2 * sizeof(float), (hipStream_t)stream));
-    int rc = hl_gn_backward_reduce(x, C, dout, N, H * W, C, coefA, coefB, silu, S, stream);
+    int rc = hl_gn_backward_reduce(x, C, dout, N, H * W, C, coefA, coefB, silu, S, k3 + (size_t)N * C, part_bytes, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gn_bwd_coef, dim3(32), dim3(64), 0, (hipStream_t)stream, S, gstat, gamma, beta, scale_shift, N, H * W, C, k1, k2, k3, dgamma,
                        dbeta, dscale_shift);

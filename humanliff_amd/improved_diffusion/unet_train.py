@@ -164,7 +164,7 @@ class _GroupNormAct(th.autograd.Function):
         dx = th.empty_like(x) if ctx.needs_input_grad[0] else None
         dgamma, dbeta = th.empty(Cc, device=dev), th.empty(Cc, device=dev)
         dss = th.empty((N, 2 * Cc), device=dev) if has_ss else None
-        scr = th.empty(N * Cc * 5, device=dev)
+        scr = th.empty(N * Cc * 5 + L.hl_gn_backward_scratch_bytes(N, H * W, Cc) // 4, device=dev)
         with _lib.on(dev):
             _lib.check(L.hl_groupnorm_train_backward(_lib.ptr(x), _lib.ptr(dy), N, H, W, Cc, _lib.ptr(A), _lib.ptr(B), 1 if ctx.silu else 0,
                                                      _lib.ptr(gstat), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(ss) if has_ss else None, _lib.ptr(dx),

@@ -396,18 +396,21 @@ int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const f
 /* y (N,HW,C dense) = silu ? silu(x*A + B) : x*A + B with the per-(n,c) affine of hl_groupnorm_coef; x has a channel pitch. */
 int hl_gn_apply_nhwc(const float *x, long x_pitch, int N, int HW, int C, const float *coefA, const float *coefB, int silu, float *y,
                      void *stream);
-/* backward of y = silu?(x*A + B): with du = dout * silu'(x*A + B) (or dout), S[n][c] = (sum_p du, sum_p du*x) - float atomics into
- * the zeroed S (N,C,2); then dx = k1[n,c]*du + k2[n,c]*x + k3[n,c] (+ dx_add), the (N,C) coefficients being the caller's small
+/* backward of y = silu?(x*A + B): with du = dout * silu'(x*A + B) (or dout), S[n][c] = (sum_p du, sum_p du*x), written (N,C,2);
+ * per-workgroup partial sums in the caller's scratch (hl_gn_backward_scratch_bytes) added in a fixed order - no atomics, the same
+ * bits on every run; then dx = k1[n,c]*du + k2[n,c]*x + k3[n,c] (+ dx_add), the (N,C) coefficients being the caller's small
  * tensor algebra on S, the group statistics and the affine parameters (unet_train.py). */
+size_t hl_gn_backward_scratch_bytes(int N, int HW, int C);
 int hl_gn_backward_reduce(const float *x, long x_pitch, const float *dout, int N, int HW, int C, const float *coefA, const float *coefB,
-                          int silu, float *S, void *stream);
+                          int silu, float *S, void *scratch, size_t scratch_bytes, void *stream);
 int hl_gn_backward_apply(const float *x, long x_pitch, const float *dout, int N, int HW, int C, const float *coefA, const float *coefB,
                          int silu, const float *k1, const float *k2, const float *k3, const float *dx_add, float *dx, void *stream);
 /* The two as the training path uses them (unet_train.py), the (N,C) algebra between the passes in a kernel of its own:
  * forward   y = silu?( GroupNorm32(x) [* (1 + scale) + shift] ), x / y dense (N,H,W,C); scale_shift (N,2C) = [scale | shift] or NULL
  *           (unet.py:203-206); also returns the affine coefA / coefB (N,C) and gstat (N,32,2) = (mean, rstd) per group for the backward.
  *           scratch: N * 32 KiB.
- * backward  dx (may be NULL), dgamma / dbeta (C) (written, not accumulated), dscale_shift (N,2C) (iff scale_shift); scratch: N*C*5 floats. */
+ * backward  dx (may be NULL), dgamma / dbeta (C) (written, not accumulated), dscale_shift (N,2C) (iff scale_shift); scratch: N*C*5 floats
+ *           + hl_gn_backward_scratch_bytes(N, H*W, C).  Deterministic (fixed-order sums). */
 int hl_groupnorm_train_forward(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta, const float *scale_shift,
                                int silu, float *coefA, float *coefB, float *gstat, float *y, void *scratch, size_t scratch_bytes, void *stream);
 int hl_groupnorm_train_backward(const float *x, const float *dout, int N, int H, int W, int C, const float *coefA, const float *coefB, int silu,

@@ -119,6 +119,42 @@ def test_groupnorm_backward_matches_torch_autograd(N, C, H, W, use_ss, silu):
         assert rel(sd_.grad, sr.grad) < 2e-5
 
 
+def test_groupnorm_backward_is_bit_reproducible():
+    """k_gn_bwd_reduce / k_gn_bwd_fin add their partial sums in a fixed order (no float atomics): the same bits on every run, also at the
+    256 x 256 production level where 256 workgroups per image contribute to every (n, c) sum."""
+    from humanliff_amd.improved_diffusion import unet_train as ut
+    for N, C, H, W in [(2, 192, 256, 256), (3, 96, 20, 12), (1, 576, 32, 32)]:
+        g = torch.Generator().manual_seed(C)
+        x = (torch.randn((N, H, W, C), generator=g) * 1.5 + 0.3).to(dev)
+        gamma, beta = (torch.randn(C, generator=g) * 0.2 + 1).to(dev), (torch.randn(C, generator=g) * 0.2).to(dev)
+        ss, cot = (torch.randn((N, 2 * C), generator=g) * 0.3).to(dev), torch.randn((N, H, W, C), generator=g).to(dev)
+        runs = []
+        for _ in range(3):
+            leaves = [t.clone().requires_grad_(True) for t in (x, gamma, beta, ss)]
+            (ut._GroupNormAct.apply(*leaves, True) * cot).sum().backward()
+            runs.append([t.grad.clone() for t in leaves])
+        for r in runs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(runs[0], r)), (N, C, H, W)
+
+
+def test_training_step_gradients_are_bit_reproducible():
+    """Every kernel of the training step sums in a fixed order: two backward passes over the same batch give identical parameter gradients."""
+    from tests.test_train_loss_cpu import inputs, tiny_model
+    model, diffusion = tiny_model()
+    model = model.to(dev).train()
+    x0, xc = (t.to(dev) for t in inputs())
+    noise = torch.randn(x0.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+    grads = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        losses = diffusion.training_losses(model, x0.clamp(-1, 1), xc, torch.tensor([999, 17], device=dev),
+                                           model_kwargs={"y": torch.tensor([3, 0], device=dev)}, noise=noise)
+        losses["loss"].mean().backward()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    diff = [k for k in grads[0] if not torch.equal(grads[0][k], grads[1][k])]
+    assert not diff, diff
+
+
 def test_attention_backward_matches_torch_autograd():
     from humanliff_amd.improved_diffusion import unet_train as ut
     g = torch.Generator().manual_seed(9)
