@@ -33,7 +33,7 @@ constexpr float W4_C0 = W4_A * W4_A * W4_B * W4_B, W4_C2 = -(W4_A * W4_A + W4_B 
 #ifndef HL_W4W_SCALAR_FMA
 #define HL_W4W_SCALAR_FMA 0
 #endif
-#ifndef HL_W4W_ABL   // timing ablations (wrong results): 1 no per-tile barrier, 2 no transform, 4 no weight loads, 8 no patch DMA, 16 no MFMA
+#ifndef HL_W4W_ABL   // timing ablations (wrong results; 256 no epilogue global traffic, 512 no epilogue LDS exchange): 1 no per-tile barrier, 2 no transform, 4 no weight loads, 8 no patch DMA, 16 no MFMA
 #define HL_W4W_ABL 0
 #endif
 // d = c * x + y on four channels.  Packed (v_pk_fma_f32 x2) or four plain v_fma_f32 (HL_W4W_SCALAR_FMA: the instruction selector would
@@ -219,6 +219,15 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
     const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.w_wino, (short)0, (int)((long)(p.Cout >> 5) * nkt * 36 * 1024), 0x00020000);
 
+#ifndef HL_W4W_STAGGER
+#define HL_W4W_STAGGER 0
+#endif
+    // HL_W4W_STAGGER = n (experiment): the first workgroup of every CU starts (its index / 8 mod 4) * n * 0.9 us late, so that the CUs of an XCD
+    // are not all in their epilogues (256 KB of HBM traffic per workgroup) at the same moment.
+    if (HL_W4W_STAGGER > 0 && blockIdx.x < 256 && gridDim.x >= 512) {
+        const int ph = (blockIdx.x >> 3) & 3;
+        for (int i = 0; i < ph * HL_W4W_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     // accumulators [frequency f of the wave's 3x3 block][32-channel half cb]: tile f*2+cb; tiles 0..15 = the accumulator file, 16 / 17 here
     f32x16 accv[2];
 #pragma unroll
@@ -434,6 +443,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         __syncthreads();
+        if (!((HL_W4W_ABL & 512) && p.Hin != 12345))
         [&]<int... I>(std::integer_sequence<int, I...>) {   // I = (f, cb, rr): accumulator register 8q + rr of tile f*2+cb holds tile 16q + (rr&3) + 8(rr>>2) + 4 half
             ([&] {
                 constexpr int f = I / 16, cb = (I >> 3) & 1, rr = I & 7;
@@ -470,6 +480,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
             for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4 *>(dst + (long)((k >> 2) * Wv + (k & 3)) * p.Cout) = v[k];
             continue;
         }
+        if ((HL_W4W_ABL & 256) && p.Hin != 12345) continue;
         if (p.res) {
             const float *rp = p.res + m0 * p.res_pitch + n;
             f32x4 rr[16];
