@@ -1,0 +1,324 @@
+// k_conv_h16: the 3x3 / stride-1 convolutions of the UNet with 16-bit operands (fp16 or bf16) and fp32 accumulation on
+// v_mfma_f32_32x32x16_{f16,bf16} - the arithmetic the reference's training scripts select (train_util.py:214 torch.autocast under
+// --use_amp True; fp16 there) and, for fp16, the operand precision the reference's own convolutions have on its hardware (TF32: the
+// same 10 explicit significand bits).  Opt-in (HL_CONV_BF16 / HL_CONV_FP16), never the default: the fp32 kernels stay the product path.
+//
+// Direct implicit GEMM, one workgroup = 16x16 output pixels x 192 output channels, ONE wave per SIMD (the 512-entry register budget):
+//   * wave (wm, wn) owns 128 pixels (rows 8wm..8wm+7 of the tile) x 96 channels = 4 x 3 accumulator tiles of 32x32 (192 registers,
+//     which the compiler keeps in the accumulator file);
+//   * K is walked in chunks of 32 input channels: the chunk's 18x18 input patch (zero padding = out-of-range buffer loads) is fetched
+//     as fp32 into registers one chunk ahead, rounded to 16 bits (nearest even) and written to LDS as [pixel][32 channels] (64 bytes per
+//     pixel, rows of 20 pixels, the 16-byte quarter index XORed with bits 2-3 of the pixel's x: the slot (address / 16 mod 16) of a
+//     quarter is then a bijection of x mod 16, and each of the four 16-lane groups a ds_read_b128 is served in holds 16 consecutive x
+//     - conflict-free for every tap), two stages; the nine taps of the chunk read the SAME patch at shifted pixel addresses;
+//   * the weights never touch LDS: they are packed in MFMA-fragment order (one 16-byte load per lane and fragment) and go from L2 into a
+//     register ring of six k-steps (3 fragments each) - the CUs of an XCD walk K in step, so every line is one miss and 31 hits;
+//   * per k-step (16 channels of one tap): 4 ds_read_b128 + 3 buffer_load_dwordx4 for 12 MFMAs of 32 cycles.
+// Epilogue: two rounds of 128 pixels x 192 channels through LDS (padded rows), then bias + residual and 16-byte NHWC stores.
+#include "hl_unet_kernels.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace hl {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <bool F16>
+__device__ __forceinline__ unsigned pack2(float a, float b) {   // two 16-bit values (round to nearest even), a in the low half
+    if constexpr (F16) {
+        const f16x2 h = {(_Float16)a, (_Float16)b};
+        return __builtin_bit_cast(unsigned, h);
+    } else {
+        const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+        const unsigned ra = ua + 0x7fffu + ((ua >> 16) & 1u), rb = ub + 0x7fffu + ((ub >> 16) & 1u);
+        return __builtin_amdgcn_perm(rb, ra, 0x07060302);
+    }
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int H16_PW = 18, H16_NPIX = H16_PW * H16_PW;       // patch of a 16x16 tile
+constexpr int H16_LP = 20;                                    // LDS row pitch of the patch in pixels (multiple of 4: the slot of a pixel depends on its x only)
+constexpr int H16_STAGE = H16_PW * H16_LP * 64;              // bytes per patch stage
+#ifndef H16_RING
+#define H16_RING 6                                         // k-steps of weights in flight (divides 18)
+#endif
+#ifndef H16_ABL   // timing ablations (wrong results): 1 no weight loads in the loop, 2 no patch loads / staging in the loop, 4 no A-fragment reads, 8 no MFMA
+#define H16_ABL 0
+#endif
+#ifndef H16_ROT
+#define H16_ROT 0
+#endif
+#ifndef H16_ST0
+#define H16_ST0 12                                        // k-step behind which the next chunk's patch goes to LDS (6 units, one per step)
+#endif
+constexpr int H16_EP = 196;                                  // epilogue row pitch in floats (192 + 4: rows 4 apart are 16 banks apart)
+
+template <bool F16>
+__global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NU = H16_NPIX * 4, NUT = (NU + 255) / 256;      // staging units (pixel, 8-channel group) and units per thread
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int total = p.n_mtiles * p.n_nblocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;       // contiguous runs of (tile, channel block) per XCD
+    const int tb = __builtin_amdgcn_readfirstlane(wi / p.n_nblocks), nb = wi - tb * p.n_nblocks;   // (wave-uniform: the weight loads take them as scalar offsets)
+    const int bw = p.Wout >> 4, bh = p.Hout >> 4;
+    const int img = tb / (bw * bh), brem = tb - img * (bw * bh);
+    const int y0 = (brem / bw) * 16, x0 = (brem - (brem / bw) * bw) * 16;
+    const int nch = p.Cin >> 5;
+    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * p.in_pitch * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * nch * 18 * 6144), 0x00020000);
+
+    // ---- patch staging: unit u = (pixel of the 18x18 patch, group of 8 channels) -> two 16-byte fp32 loads, one 16-byte LDS write ----
+    unsigned sv[NUT], sl[NUT];
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) {
+        const int u = tid + 256 * j, pix = u >> 2, grp = u & 3;
+        const int py = pix / H16_PW, px = pix - py * H16_PW;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        const bool ok = u < NU && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+        sv[j] = ok ? (unsigned)((img * p.Hin + y) * p.Win + x) * pitch4 + grp * 32 : OOB;
+        sl[j] = u < NU ? (unsigned)((py * H16_LP + px) * 64 + ((grp ^ ((px >> 2) & 3)) << 4)) : (unsigned)(2 * H16_STAGE + (tid & 63) * 16);   // (no unit: a dump slot behind the stages)
+    }
+    u32x4 ar[NUT][2];
+    auto a_load = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NUT; ++j) {
+            const int so = (H16_ABL & 16) ? 0 : chunk * 128;      // (16: the patch from L2-hot addresses)
+            ar[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j], so, 0);
+            ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] == OOB ? OOB : sv[j] + 16, so, 0);
+        }
+    };
+    auto a_store = [&](int stage, int j) {
+        const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
+        const u32x4 h = {pack2<F16>(v0[0], v0[1]), pack2<F16>(v0[2], v0[3]), pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3])};
+        *reinterpret_cast<u32x4 *>(lds + (sl[j] >= 2u * H16_STAGE ? 0 : stage * H16_STAGE) + sl[j]) = h;
+    };
+
+    // ---- A fragments: row r of fragment mf = pixel (8wm + 2mf + (r >> 4), r & 15) of the tile; lane half g holds channels 8g..8g+7 of the k-step
+    unsigned aoff[4][3];                                           // per tap column kx (the swizzle depends on x); tap row ky is an immediate offset
+    {
+        const int r = lane & 31, g = lane >> 5;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int py = 8 * wm + 2 * mf + (r >> 4), px = (r & 15) + kx;
+                aoff[mf][kx] = (unsigned)((py * H16_LP + px) * 64 + ((g ^ ((px >> 2) & 3)) << 4));
+            }
+    }
+    // ---- weights: packed [channel block][chunk][tap][k-half][wn][fragment][lane][8] -> one 16-byte load per lane and fragment
+    const unsigned wv = (unsigned)lane * 16u;
+    const int wbase = nb * nch * 18 * 6144 + wn * 3072;
+    u32x4 ring[H16_RING][3];
+    // every workgroup walks the chunks from its own start (rot) and wraps: the 32 CUs of an XCD run in step, and reading the SAME weight
+    // lines at the same moment queues them all on the few L2 channels those lines live in (the 16-bit weights of a layer fit the L2)
+    const int rot = H16_ROT ? __builtin_amdgcn_readfirstlane(wi % nch) : 0;
+    auto w_load = [&](int slot_, int chunk, int s18) {
+        const int so = wbase + (chunk * 18 + s18) * 6144;
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf) ring[slot_][nf] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wv, so + nf * 1024, 0);
+    };
+
+    f32x16 acc[4][3];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+
+    // ---- prologue: the first chunk staged, the first H16_RING k-steps of weights in flight
+    a_load(rot);
+#pragma unroll
+    for (int s = 0; s < H16_RING; ++s) w_load(s, rot, s);
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) a_store(0, j);
+    __syncthreads();
+
+    u32x4 af[2][4];                                                // A fragments of the current / next k-step
+    auto a_read = [&](const char *st, int tap, int k2, u32x4 (&dst)[4]) {
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) dst[mf] = *reinterpret_cast<const u32x4 *>(st + (tap / 3) * (H16_LP * 64) + (aoff[mf][tap % 3] ^ (k2 ? 32u : 0u)));
+    };
+    for (int c = 0; c < nch; ++c) {
+        const char *st = lds + (c & 1) * H16_STAGE;
+        const int cc = c + rot < nch ? c + rot : c + rot - nch;          // this chunk / the next one (past the end: a valid chunk, never used)
+        const int ccn = cc + 1 < nch ? cc + 1 : 0;
+        if (!(H16_ABL & 2) && !(H16_ABL & 64)) a_load(ccn);              // (last chunk: a valid chunk again, staged and never read)
+        a_read(st, 0, 0, af[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ([&] {
+                constexpr int rs = S % H16_RING, cur = S & 1;
+                if constexpr (S + 1 < 18 && !(H16_ABL & 4)) a_read(st, (S + 1) >> 1, (S + 1) & 1, af[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);                 // the next step's fragments are on their way before this step's MFMAs
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf)
+                        if constexpr (!(H16_ABL & 8)) acc[mf][nf] = mma<F16>(af[(H16_ABL & 4) ? 0 : cur][mf], ring[rs][nf], acc[mf][nf]);
+                if constexpr (!(H16_ABL & 1)) w_load(rs, S + H16_RING < 18 ? cc : ccn, (S + H16_RING) % 18);
+                if constexpr (S >= H16_ST0 && S < H16_ST0 + NUT) {
+                    if (!(H16_ABL & 2) && !(H16_ABL & 32)) a_store((c + 1) & 1, S - H16_ST0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, 18>{});
+        __syncthreads();
+    }
+
+    // ---- epilogue: two rounds of (fragments 2q, 2q+1 of every wave) = 128 pixels x 192 channels through LDS
+    const int n0 = nb * 192;
+    float *ep = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (q) __syncthreads();
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = (i >> 2) * 8 + (lane >> 5) * 4 + (i & 3);            // row of the 32x32 tile held by acc[..][i]
+                    const int prow = wm * 64 + m2 * 32 + r;                            // pixel slot of the round: wave-major, fragment, row
+                    ep[prow * H16_EP + wn * 96 + nf * 32 + (lane & 31)] = acc[2 * q + m2][nf][i];
+                }
+        __syncthreads();
+        // thread (pr0 = tid / 48 < 5, cq = tid % 48) finishes channels 4cq..4cq+3 of pixel slots pr0, pr0 + 5, ... (<= 26 of the round's 128),
+        // in batches of 9 / 9 / 8: the residual loads of a batch are all in flight before its first store (on this ISA stores count on
+        // vmcnt too: a load waited for behind a store waits for the store).  One channel quad per thread = GroupNorm sums without shuffles.
+        const int pr0 = tid / 48, cq = (tid - pr0 * 48) * 4;
+        f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && pr0 < 5) bs = *reinterpret_cast<const f32x4 *>(p.bias + n0 + cq);
+        auto finish = [&](auto kc0, auto nbc) {   // pixel slots pr0 + 5 (K0 .. K0 + NB - 1): every load of the batch in flight before its first store
+            constexpr int K0 = decltype(kc0)::value, NB = decltype(nbc)::value;
+            long mm[NB];
+            f32x4 v[NB], rr[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int pc = pr0 + 5 * (K0 + k);
+                const int wmm = pc >> 6, m2 = (pc >> 5) & 1, r = pc & 31;
+                const int oy = y0 + 8 * wmm + 2 * (2 * q + m2) + (r >> 4), ox = x0 + (r & 15);
+                mm[k] = ((long)img * p.Hout + oy) * p.Wout + ox;
+                if (p.res) rr[k] = *reinterpret_cast<const f32x4 *>(p.res + mm[k] * p.res_pitch + n0 + cq);
+                v[k] = *reinterpret_cast<const f32x4 *>(ep + pc * H16_EP + cq);
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                v[k] += bs;
+                if (p.res) v[k] += rr[k];
+                sm += v[k]; sq += v[k] * v[k];
+                *reinterpret_cast<f32x4 *>(p.out + mm[k] * p.out_pitch + n0 + cq) = v[k];
+            }
+        };
+        if (pr0 < 5) {
+            finish(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+            finish(std::integral_constant<int, 9>{}, std::integral_constant<int, 8>{});
+            finish(std::integral_constant<int, 17>{}, std::integral_constant<int, 8>{});
+            if (pr0 < 3) finish(std::integral_constant<int, 25>{}, std::integral_constant<int, 1>{});      // slots 125, 126, 127
+        }
+        if (p.st1) {   // GroupNorm statistics of the stored tensor: slot = (tile, round) = 128 pixels; the five pixel groups meet in LDS
+            __syncthreads();
+            if (pr0 < 5) {
+                *reinterpret_cast<f32x4 *>(ep + (pr0 * 48 * 2 + (cq >> 2) * 2) * 4) = sm;
+                *reinterpret_cast<f32x4 *>(ep + (pr0 * 48 * 2 + (cq >> 2) * 2 + 1) * 4) = sq;
+            }
+            __syncthreads();
+            if (tid < 48) {
+                f32x4 a = *reinterpret_cast<const f32x4 *>(ep + (tid * 2) * 4), b = *reinterpret_cast<const f32x4 *>(ep + (tid * 2 + 1) * 4);
+#pragma unroll
+                for (int g = 1; g < 5; ++g) {
+                    a += *reinterpret_cast<const f32x4 *>(ep + (g * 48 * 2 + tid * 2) * 4);
+                    b += *reinterpret_cast<const f32x4 *>(ep + (g * 48 * 2 + tid * 2 + 1) * 4);
+                }
+                float *d = p.st1 + (((long)tb * 2 + q) * p.Cout + n0 + tid * 4) * 2;
+                *reinterpret_cast<f32x4 *>(d) = f32x4{a[0], b[0], a[1], b[1]};
+                *reinterpret_cast<f32x4 *>(d + 4) = f32x4{a[2], b[2], a[3], b[3]};
+            }
+        }
+    }
+#endif
+}
+
+// weights -> 16-bit values in fragment order: [channel block of 192][chunk of 32 inputs][tap][k-half][wn][fragment nf][lane][8]
+// lane l of fragment (wn, nf) holds output channel 192 nb + 96 wn + 32 nf + (l & 31), inputs 32 chunk + 16 k-half + 8 (l >> 5) + 0..7
+__global__ void k_pack_conv_h16(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, unsigned short *__restrict__ dst, int f16, int tf) {
+    const int nch = Cin_pad >> 5;
+    const long n = (long)(Cout / 192) * nch * 18 * 3072;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+        long t = i >> 9;
+        const int nf = (int)(t % 3); t /= 3;
+        const int wn = (int)(t & 1); t >>= 1;
+        const int k2 = (int)(t & 1); t >>= 1;
+        const int tap = (int)(t % 9); t /= 9;
+        const int chunk = (int)(t % nch);
+        const int nb = (int)(t / nch);
+        const int o = nb * 192 + wn * 96 + nf * 32 + (l & 31), cin = chunk * 32 + k2 * 16 + (l >> 5) * 8 + j;
+        float v = 0.f;
+        if (cin < Cin) v = tf ? w[((long)cin * Cout + o) * 9 + (8 - tap)] : w[((long)o * Cin + cin) * 9 + tap];
+        unsigned short h;
+        if (f16) {
+            const _Float16 hh = (_Float16)v;
+            h = __builtin_bit_cast(unsigned short, hh);
+        } else {
+            const unsigned u = __float_as_uint(v);
+            h = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+        dst[i] = h;
+    }
+}
+
+}  // namespace
+
+bool conv_h16_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int ups) {
+    return ks == 3 && stride == 1 && !ups && Hout % 16 == 0 && Wout % 16 == 0 && Cin % 32 == 0 && Cout % 192 == 0 &&
+           (long)Cout * Cin * 18 < (1L << 31);
+}
+
+size_t conv_packed_h16_bytes(int Cout, int Cin_pad, int ks) {
+    return (ks == 3 && Cout % 192 == 0 && Cin_pad % 32 == 0) ? (size_t)Cout * Cin_pad * 9 * 2 : 0;
+}
+
+int conv_pack_weights_h16(const float *w, int Cout, int Cin, int Cin_pad, void *packed, int f16, hipStream_t st, int tf) {
+    HL_REQUIRE(w && packed && Cout % 192 == 0 && Cin_pad % 32 == 0 && Cin <= Cin_pad, "conv_pack_weights_h16: bad argument");
+    hipLaunchKernelGGL(k_pack_conv_h16, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), f16, tf);
+    return check_launch("k_pack_conv_h16");
+}
+
+size_t conv_h16_lds_bytes() { return (size_t)128 * H16_EP * sizeof(float); }   // the epilogue exchange (98 KB); the two patch stages need 40.5 KB
+
+int conv_h16_launch(const ConvK &p, int f16, hipStream_t st) {
+    HL_REQUIRE(p.w_bf3 && p.Cout % 192 == 0 && p.Cin % 32 == 0 && p.Hout % 16 == 0 && p.Wout % 16 == 0, "k_conv_h16: bad layer");
+    const dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks));
+    const size_t sh = conv_h16_lds_bytes();
+    static const bool attr_ok = [] {
+        const int b = (int)conv_h16_lds_bytes();
+        return hipFuncSetAttribute((const void *)k_conv_h16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess &&
+               hipFuncSetAttribute((const void *)k_conv_h16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess;
+    }();
+    HL_REQUIRE(attr_ok, "k_conv_h16: cannot raise the dynamic LDS limit to %zu bytes", sh);
+    if (f16) hipLaunchKernelGGL((k_conv_h16<true>), grid, dim3(256), sh, st, p);
+    else hipLaunchKernelGGL((k_conv_h16<false>), grid, dim3(256), sh, st, p);
+    return check_launch("k_conv_h16");
+}
+
+}  // namespace hl

@@ -26,6 +26,7 @@ struct Conv {
     const float *w = nullptr;  // packed
     const void *w_bf3 = nullptr;  // packed split-bf16 copy (layers that take the DMA tile), used when Net::conv_mode == 1
     const float *w_wino = nullptr;  // Winograd-domain copy (3x3 layers), used when Net::conv_mode == 0
+    const void *w_h16 = nullptr;    // fp16 copy in MFMA-fragment order (3x3 layers k_conv_h16 covers), used when Net::conv_mode == HL_CONV_FP16
     const float *w_wino4 = nullptr; // Winograd F(4x4,3x3) copy (3x3 layers up to 64 MB of it), used when Net::conv_mode == HL_CONV_FP32
     const float *bias = nullptr;
     int Cin = 0, Cin_pad = 0, Cout = 0, ks = 1;
@@ -184,6 +185,15 @@ Conv make_conv_w(Net &n, const float *w, const float *bias, int Cin, int Cout, i
             c.w_wino4 = dst;
         }
         n.packed_off += (wino4 / 4 + 63) / 64 * 64;
+    }
+    const size_t h16 = hl::conv_packed_h16_bytes(Cout, c.Cin_pad, ks);
+    if (h16) {
+        if (!n.dry && w) {
+            void *dst = n.packed + n.packed_off;
+            if (hl::conv_pack_weights_h16(w, Cout, Cin, c.Cin_pad, dst, 1, n.st) != 0 && n.err.empty()) n.err = hl_last_error();
+            c.w_h16 = dst;
+        }
+        n.packed_off += (h16 / 4 + 63) / 64 * 64;
     }
     return c;
 }
@@ -463,8 +473,9 @@ struct Exec {
         ConvArgs a{};
         a.in = in; a.in.C = c.Cin_pad;
         a.w = c.w; a.w_bf3 = (n.conv_mode == HL_CONV_BF16X3 || n.conv_mode == HL_CONV_BF16) ? c.w_bf3 : nullptr; a.bf16_single = n.conv_mode == HL_CONV_BF16;
-        a.w_wino = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_F23) ? c.w_wino : nullptr;
-        a.w_wino4 = n.conv_mode == HL_CONV_FP32 ? c.w_wino4 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
+        a.w_wino = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_F23 || n.conv_mode == HL_CONV_FP16) ? c.w_wino : nullptr;
+        a.w_h16 = n.conv_mode == HL_CONV_FP16 ? c.w_h16 : nullptr; a.h16_fp16 = 1;
+        a.w_wino4 = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP16) ? c.w_wino4 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
         a.coefA = cA; a.coefB = cB; a.act = act;
         a.out = out; a.res = res; a.res_pitch = res_pitch;
         a.out2 = out2; a.out2_pitch = out2_pitch; a.res2 = res2; a.res2_pitch = res2_pitch; a.out_nchw = nchw;
@@ -479,7 +490,7 @@ struct Exec {
         {
             int lvl = 0;
             while (lvl < 7 && (out.H << lvl) < H) ++lvl;
-            n.census[a.path & 3][lvl] += 1;
+            n.census[a.path == 5 ? 2 : (a.path & 3)][lvl] += 1;   // (k_conv_h16 counts with the other kernels of the 16-bit matrix pipe)
             // (keyed like a rocprofv3 per-kernel, per-grid row: kernel family, level, Cout, kernel size - the input channel counts of a level share a row)
             span_key[0] = a.path; span_key[1] = lvl; span_key[2] = ups ? 1 : 0; span_key[3] = c.Cout; span_key[4] = c.ks;
         }
@@ -825,7 +836,7 @@ int hl_unet_set_overlap(void *handle, int enable) {
 
 int hl_unet_set_conv_mode(void *handle, int mode) {
     HL_REQUIRE(handle, "hl_unet_set_conv_mode: null handle");
-    HL_REQUIRE(mode == HL_CONV_FP32 || mode == HL_CONV_BF16X3 || mode == HL_CONV_FP32_DIRECT || mode == HL_CONV_FP32_F23 || mode == HL_CONV_BF16, "hl_unet_set_conv_mode: unknown mode %d", mode);
+    HL_REQUIRE(mode == HL_CONV_FP32 || mode == HL_CONV_BF16X3 || mode == HL_CONV_FP32_DIRECT || mode == HL_CONV_FP32_F23 || mode == HL_CONV_BF16 || mode == HL_CONV_FP16, "hl_unet_set_conv_mode: unknown mode %d", mode);
     static_cast<Net *>(handle)->conv_mode = mode;
     return HL_OK;
 }
@@ -938,9 +949,12 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     HL_REQUIRE(Cin_w <= Cin, "hl_conv2d_nhwc: the weight has more input channels than the tensor");
     const size_t need32 = (hl::conv_packed_floats(Cout, Cin, ks) * sizeof(float) + 255) / 256 * 256;
     const bool bf = mode == HL_CONV_BF16X3 || mode == HL_CONV_BF16;
-    const size_t extra = bf ? hl::conv_packed_bf3_bytes(Cout, Cin, ks)
-                         : (mode == HL_CONV_FP32_F23 ? hl::conv_packed_wino_bytes(Cout, Cin, ks)
-                            : (mode == HL_CONV_FP32 ? std::max(hl::conv_packed_wino_bytes(Cout, Cin, ks), hl::conv_packed_wino4_bytes(Cout, Cin, ks)) : 0));
+    const bool h16m = mode == HL_CONV_BF16 || mode == HL_CONV_FP16;      // 16-bit operands where k_conv_h16 applies
+    const bool f32m = mode == HL_CONV_FP32 || mode == HL_CONV_FP16;      // (HL_CONV_FP16: the other layers as HL_CONV_FP32)
+    size_t extra = bf ? hl::conv_packed_bf3_bytes(Cout, Cin, ks)
+                      : (mode == HL_CONV_FP32_F23 ? hl::conv_packed_wino_bytes(Cout, Cin, ks)
+                         : (f32m ? std::max(hl::conv_packed_wino_bytes(Cout, Cin, ks), hl::conv_packed_wino4_bytes(Cout, Cin, ks)) : 0));
+    if (h16m) extra = std::max(extra, hl::conv_packed_h16_bytes(Cout, Cin, ks));
     const size_t need = need32 + (extra + 255) / 256 * 256;
     HL_REQUIRE(scratch && scratch_bytes >= need, "hl_conv2d_nhwc: scratch too small (%zu < %zu)", scratch_bytes, need);
     ConvArgs a{};
@@ -948,8 +962,9 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     a.in.p = const_cast<float *>(in); a.in.N = N; a.in.H = H; a.in.W = W; a.in.C = Cin; a.in.pitch = Cin;
     a.w = static_cast<float *>(scratch); a.bias = bias; a.Cout = Cout; a.ks = ks; a.stride = stride; a.ups = upsample;
     if (bf && need > need32) { a.w_bf3 = extra_dst; a.bf16_single = mode == HL_CONV_BF16; }
-    if ((mode == HL_CONV_FP32 || mode == HL_CONV_FP32_F23) && hl::conv_packed_wino_bytes(Cout, Cin, ks)) a.w_wino = static_cast<float *>(extra_dst);
-    if (mode == HL_CONV_FP32 && hl::conv_packed_wino4_bytes(Cout, Cin, ks)) a.w_wino4 = static_cast<float *>(extra_dst);
+    if ((f32m || mode == HL_CONV_FP32_F23) && hl::conv_packed_wino_bytes(Cout, Cin, ks)) a.w_wino = static_cast<float *>(extra_dst);
+    if (f32m && hl::conv_packed_wino4_bytes(Cout, Cin, ks)) a.w_wino4 = static_cast<float *>(extra_dst);
+    if (h16m && hl::conv_packed_h16_bytes(Cout, Cin, ks)) { a.w_h16 = extra_dst; a.h16_fp16 = mode == HL_CONV_FP16; }
     a.coefA = coefA; a.coefB = coefB; a.act = silu;
     const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     a.out.p = out; a.out.N = N; a.out.H = (Hv + 2 * pad - ks) / stride + 1; a.out.W = (Wv + 2 * pad - ks) / stride + 1;
@@ -972,7 +987,10 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     int rc = hl::conv2d(a, (hipStream_t)stream);
     if (rc) return rc;
     a.plan_only = 0;
-    if (a.path == 3) {
+    if (a.path == 5) {
+        rc = hl::conv_pack_weights_h16(w_oihw, Cout, Cin_w, Cin, extra_dst, a.h16_fp16, (hipStream_t)stream, tf);
+        a.w_wino = nullptr; a.w_wino4 = nullptr; a.w_bf3 = nullptr;
+    } else if (a.path == 3) {
         rc = hl::conv_pack_weights_wino4(w_oihw, Cout, Cin_w, Cin, static_cast<float *>(extra_dst), (hipStream_t)stream, tf);
         a.w_wino = nullptr;
     } else if (a.path == 1) {
@@ -985,6 +1003,7 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
         a.w_wino4 = nullptr;
     }
     if (rc) return rc;
+    if (a.path != 5) a.w_h16 = nullptr;
     rc = hl::conv2d(a, (hipStream_t)stream);
     if (stat_slots) *stat_slots = a.stat_slots;
     return rc;
@@ -992,7 +1011,7 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
 
 int hl_conv2d_nhwc_bwd_data(int conv_mode, const float *dy, int N, int Ho, int Wo, int Cy, const float *w_oihw, int Cout, int Cin, int ks,
                             int stride, int upsample, float *dx, int Cx, void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16, "hl_conv2d_nhwc_bwd_data: mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16 || conv_mode == HL_CONV_FP16, "hl_conv2d_nhwc_bwd_data: mode %d", conv_mode);
     HL_REQUIRE(dy && w_oihw && dx && scratch, "hl_conv2d_nhwc_bwd_data: null argument");
     HL_REQUIRE(Cy % 16 == 0 && Cout <= Cy && Cin <= Cx && (ks == 1 || ks == 3) && (stride == 1 || (stride == 2 && !upsample && ks == 3)),
                "hl_conv2d_nhwc_bwd_data: bad argument");
@@ -1028,7 +1047,7 @@ int hl_conv2d_nhwc_gn(int conv_mode, const float *in, int N, int H, int W, int C
                       int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu, const float *residual,
                       float *out, const float *gamma, const float *beta, float *next_coefA, float *next_coefB, int *h_used_stats,
                       void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16, "hl_conv2d_nhwc_gn: unknown mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16 || conv_mode == HL_CONV_FP16, "hl_conv2d_nhwc_gn: unknown mode %d", conv_mode);
     HL_REQUIRE(gamma && beta && next_coefA && next_coefB && scratch, "hl_conv2d_nhwc_gn: null argument");
     const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     const int Ho = (Hv + 2 * pad - ks) / stride + 1, Wo = (Wv + 2 * pad - ks) / stride + 1;
@@ -1062,7 +1081,7 @@ int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w
 int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias,
                         int Cout, int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16, "hl_conv2d_nhwc_mode: unknown mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16 || conv_mode == HL_CONV_FP16, "hl_conv2d_nhwc_mode: unknown mode %d", conv_mode);
     return conv2d_single(conv_mode, in, N, H, W, Cin, w_oihw, bias, Cout, ks, stride, upsample, coefA, coefB, silu, residual, out,
                          scratch, scratch_bytes, stream);
 }

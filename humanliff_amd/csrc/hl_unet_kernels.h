@@ -17,6 +17,8 @@ struct ConvArgs {
     const float *w;      // packed [Cout_pad][Ktot], K order = kt_decode() in hl_unet_kernels.hip (groups of two 16-channel chunks, taps inside)
     const void *w_bf3;   // optional: the same weights split into three bf16 planes (conv_pack_weights_bf3); selects k_conv_bf3
     int bf16_single;     // with w_bf3: 1 = HL_CONV_BF16 (activations rounded to bf16 x the weights' two leading bf16 planes), 0 = bf16x3 emulation
+    const void *w_h16;   // optional: 16-bit weights in MFMA-fragment order (conv_pack_weights_h16); selects k_conv_h16 where conv_h16_applies
+    int h16_fp16;        // with w_h16: 1 = fp16 operands (HL_CONV_FP16), 0 = bf16 (HL_CONV_BF16)
     const float *w_wino; // optional: Winograd-domain weights (conv_pack_weights_wino); selects k_conv_wino for large 3x3 layers
     const float *w_wino4;// optional: Winograd F(4x4,3x3) weights (conv_pack_weights_wino4); selects k_conv_wino4 where it fills the chip
     const float *bias;   // [Cout] or null
@@ -37,7 +39,7 @@ struct ConvArgs {
     int out_nchw;        // write (N, Cout, H, W) instead of NHWC
     float *act_ws;       // optional scratch (pixels*Cin floats) for the materialised GroupNorm(+SiLU) input of k_conv_dma
     size_t act_ws_bytes;
-    mutable int path;    // set by conv2d: 0 direct implicit GEMM, 1 Winograd F(2x2,3x3), 2 bf16x3 emulation, 3 Winograd F(4x4,3x3)
+    mutable int path;    // set by conv2d: 0 direct implicit GEMM, 1 Winograd F(2x2,3x3), 2 bf16x3 emulation, 3 Winograd F(4x4,3x3), 5 k_conv_h16
     float *splitk_ws;    // optional scratch for split-K partial sums (small-M layers); null disables split-K
     size_t splitk_ws_bytes;
     // GroupNorm statistics of the OUTPUT for the layer that will normalise it, emitted by the epilogue of whichever kernel stores
@@ -74,6 +76,13 @@ struct ConvK {
 // tiles per wave in the accumulator registers; reads the weights conv_pack_weights_wino4 laid out.  LDS: conv_wino4w_lds_bytes().
 size_t conv_wino4w_lds_bytes();
 int conv_wino4w_launch(const ConvK &p, int ups, int blk, int splits, hipStream_t st);
+
+// k_conv_h16 (hl_conv_h16.hip): 3x3 / stride-1 convolution with 16-bit operands (fp16 / bf16) and fp32 accumulation, 16x16 pixels x 192
+// channels per workgroup; reads ConvK::w_bf3 = the weights conv_pack_weights_h16 laid out (ConvK::n_mtiles = N (H/16)(W/16), n_nblocks = Cout/192).
+bool conv_h16_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int ups);
+size_t conv_packed_h16_bytes(int Cout, int Cin_pad, int ks);
+int conv_pack_weights_h16(const float *w_oihw, int Cout, int Cin, int Cin_pad, void *packed, int f16, hipStream_t st, int tf = 0);
+int conv_h16_launch(const ConvK &p, int f16, hipStream_t st);
 
 inline size_t conv_stats_floats(long out_pixels, int Cout) { return (size_t)(out_pixels / 32 + 1) * Cout * 2; }
 size_t conv_splitk_ws_bytes();

@@ -2726,9 +2726,35 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         splits = (a.in.C / 8 + p.kt_per - 1) / p.kt_per;
         p.partial = splits > 1 ? a.splitk_ws : nullptr;
     }
+    // 16-bit operands (opt-in modes): the 3x3 / stride-1 layers k_conv_h16 covers; the rest of the mode stays on k_conv_bf3 / fp32
+    const bool h16 = a.w_h16 && (a.coefA == nullptr || a.act_ws) && !a.out_nchw && !a.out2 &&
+                     conv_h16_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
+                     (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0;
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
-        a.path = (dma && wino4) ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0));
+        a.path = h16 ? 5 : ((dma && wino4) ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
         return HL_OK;
+    }
+    if (h16) {
+        a.path = 5;
+        if (mode != 0) {   // GroupNorm(+SiLU) materialised once (fp32), the kernel rounds it to 16 bits while staging
+            HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
+            const long npix = a.in.pixels();
+            long g = (npix * (a.in.C / 4) + 255) / 256;
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix, a.in.C, a.coefA,
+                               a.coefB, a.act, a.act_ws);
+            p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0;
+            if (a.ev_mid) { hipEventRecord(a.ev_mid, st); a.ev_mid_used = 1; }
+        }
+        p.w_bf3 = a.w_h16;
+        p.partial = nullptr;
+        p.n_nblocks = a.Cout / 192;
+        p.n_mtiles = a.out.N * (a.out.H / 16) * (a.out.W / 16);
+        if (a.stats) {   // statistics from the epilogue: slot = (16x16 tile, round) = 128 pixels
+            p.st1 = a.stats; p.st2 = nullptr;
+            a.stat_slots = (a.out.H / 16) * (a.out.W / 16) * 2;
+        }
+        return conv_h16_launch(p, a.h16_fp16, st);
     }
     bool blk4 = false;
     if (dma) {

@@ -35,23 +35,28 @@ from .. import _lib
 from . import unet as U
 
 _MODE = _lib.HL_CONV_FP32
-_ARITH = {"mode": None}       # None / "fp32": exact kernels; "bf16": HL_CONV_BF16 (set_train_arithmetic)
+_ARITH = {"mode": None, "autocast": None}   # set_train_arithmetic's choice; the dtype of the caller's autocast region (forward_train)
+_KIND_MODE = {"fp32": _lib.HL_CONV_FP32, "bf16": _lib.HL_CONV_BF16, "fp16": _lib.HL_CONV_FP16}
 
 
 def set_train_arithmetic(kind=None):
-    """Arithmetic of the convolutions of the training path (forward and backward-data): None / "fp32" (default) = the exact fp32 kernels
-    (Winograd where it applies); "bf16" = HL_CONV_BF16 (activations rounded to bf16 x 16-bit weights on the bf16 matrix pipe, fp32
-    accumulation, fp32 tensors and master weights) on the layers that take the direct DMA tile.  Weight gradients, GroupNorm and attention
-    stay fp32 either way.  Opt-in and not tied to torch.autocast: measured SLOWER than the fp32 Winograd path on the 3x3 layers."""
-    assert kind in (None, "fp32", "bf16")
+    """Arithmetic of the convolutions of the training path (forward and backward-data).
+      "fp32"          the exact fp32 kernels (Winograd where it applies);
+      "fp16" / "bf16" 16-bit operands, fp32 accumulation (HL_CONV_FP16 / HL_CONV_BF16): k_conv_h16 on the 3x3 / stride-1 layers it covers
+                      (2.2-2.6x the fp32 Winograd kernel on the 256x256 layers), the other layers on k_conv_bf3 (bf16) or the fp32 kernels
+                      (fp16); fp32 tensors and master weights;
+      None (default)  "fp32", unless the caller trains under torch.autocast (train_util.py:214, --use_amp True): then the autocast dtype -
+                      what the reference's AMP computes its convolutions in.
+    Weight gradients, GroupNorm and attention stay fp32 either way."""
+    assert kind in (None, "fp32", "bf16", "fp16")
     _ARITH["mode"] = kind
 
 
 def _conv_mode():
     kind = _ARITH["mode"]
     if kind is None:
-        kind = "fp32"
-    return _lib.HL_CONV_BF16 if kind == "bf16" else _MODE
+        kind = _ARITH["autocast"] or "fp32"
+    return _MODE if kind == "fp32" else _KIND_MODE[kind]
 
 
 def _conv_raw(x, w, b, ks, stride=1, ups=0, mode=None):
@@ -261,11 +266,16 @@ def forward_train(model, x, timesteps, x_cond=None, y=None):
         x, x_cond = th.cat([x, x_cond], dim=1), None
     if th.is_autocast_enabled():
         # The caller trains under autocast (train_util.py:214, --use_amp True).  The kernels in here take fp32 tensors, so torch's own
-        # autocasting of the few tensor ops of this function is switched off.  The convolutions stay on the fp32 Winograd kernels: they are
-        # faster than the 16-bit direct kernel of this library (HL_CONV_BF16, measured 290 us against 242 us on 192->192 @256x256 at
-        # microbatch 2 - it is bound by LDS-DMA issue, not by the matrix pipe), which therefore is opt-in (set_train_arithmetic("bf16")).
-        with th.autocast(device_type="cuda", enabled=False):
-            return forward_train(model, x.float(), timesteps, None if x_cond is None else x_cond.float(), y)
+        # autocasting of the few tensor ops of this function is switched off; the convolutions take the autocast dtype as their operand
+        # precision (k_conv_h16: 16-bit operands, fp32 accumulation) unless set_train_arithmetic pinned another arithmetic.
+        dt = th.get_autocast_dtype("cuda") if hasattr(th, "get_autocast_dtype") else th.get_autocast_gpu_dtype()
+        prev = _ARITH["autocast"]
+        _ARITH["autocast"] = "bf16" if dt == th.bfloat16 else "fp16"
+        try:
+            with th.autocast(device_type="cuda", enabled=False):
+                return forward_train(model, x.float(), timesteps, None if x_cond is None else x_cond.float(), y)
+        finally:
+            _ARITH["autocast"] = prev
     emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
     if model.cond_type == "AdaGN":           # unet.py:574-578 (like the embedding MLP: three tiny torch modules, autograd's own backward)
         assert x_cond is not None, "cond_type='AdaGN' needs x_cond"

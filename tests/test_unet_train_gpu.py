@@ -346,12 +346,15 @@ def test_eval_mode_input_gradient_is_not_dropped():
         assert not model(x0, t, xc, y=y).requires_grad
 
 
-def test_bf16_conv_mode_forward_and_backward_data():
-    """HL_CONV_BF16 (opt-in 16-bit MFMA arithmetic of the training path): activations rounded to bf16 x 16-bit weights, fp32 accumulation.  A 3x3
-    and a 1x1 layer, forward and backward-data, against float64: relative error of a few 2^-9 per product, averaged down over K."""
+@pytest.mark.parametrize("kind", ["bf16", "fp16"])
+def test_16bit_conv_modes_forward_and_backward_data(kind):
+    """HL_CONV_BF16 / HL_CONV_FP16 (16-bit MFMA arithmetic of the training path): operands rounded to 16 bits, fp32 accumulation.  3x3 layers
+    (k_conv_h16: 16x16-pixel x 192-channel workgroups) and a 1x1 layer (k_conv_bf3 in the bf16 mode, the fp32 kernel in the fp16 mode), forward
+    and backward-data, against float64: the relative error of one rounding per operand (2^-9 bf16, 2^-12 fp16), averaged down over K."""
     from humanliff_amd.improved_diffusion import unet_train as ut
     g = torch.Generator().manual_seed(4)
-    for (N, H, W, C, Co, ks) in ((2, 64, 64, 96, 192, 3), (2, 64, 64, 384, 192, 1)):   # (only layers that take the direct DMA tile - Cout a multiple of 96, enough rows - take the mode)
+    lo, hi = (1e-5, 4e-3) if kind == "bf16" else (2e-6, 5e-4)
+    for (N, H, W, C, Co, ks) in ((2, 64, 64, 96, 192, 3), (1, 32, 48, 64, 384, 3), (2, 64, 64, 384, 192, 1)):
         x = torch.randn((N, C, H, W), generator=g)
         w = torch.randn((Co, C, ks, ks), generator=g) / (C * ks * ks) ** 0.5
         b = torch.randn((Co,), generator=g) * 0.1
@@ -361,7 +364,7 @@ def test_bf16_conv_mode_forward_and_backward_data():
         (yr * cot.double()).sum().backward()
         xd = nhwc(x).to(dev).requires_grad_(True)
         wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
-        ut.set_train_arithmetic("bf16")
+        ut.set_train_arithmetic(kind)
         try:
             y = ut._Conv.apply(xd, wd, bd, 1, 0)
             (y * nhwc(cot).to(dev)).sum().backward()
@@ -375,16 +378,51 @@ def test_bf16_conv_mode_forward_and_backward_data():
         finally:
             ut.set_train_arithmetic(None)
         e32 = rel(nchw(y32.cpu()), yr.detach())
-        print(f"{C}->{Co} {ks}x{ks}: bf16 mode rel-L2 forward {e_y:.2e}, backward-data {e_dx:.2e} (fp32 mode forward {e32:.1e})")
-        assert 1e-5 < e_y < 4e-3 and e_dx < 4e-3 and e32 < 1e-5      # bf16 rounding of one operand: ~2^-9 / sqrt(3) per product
+        print(f"{C}->{Co} {ks}x{ks}: {kind} mode rel-L2 forward {e_y:.2e}, backward-data {e_dx:.2e} (fp32 mode forward {e32:.1e})")
+        assert e32 < 1e-5
+        if ks == 1 and kind == "fp16":                               # no fp16 kernel for the 1x1 layers: the fp32 one
+            assert e_y < 1e-5 and e_dx < 1e-5
+            continue
+        assert lo < e_y < hi and e_dx < hi
         assert not torch.equal(y.detach(), y32)                      # the mode really switched arithmetic
+
+
+@pytest.mark.parametrize("f16", [0, 1])
+def test_conv_h16_equals_the_convolution_of_the_rounded_operands(f16):
+    """k_conv_h16 through the C ABI (hl_conv2d_nhwc_mode / hl_conv2d_nhwc_gn): the kernel's result is the float64 convolution of the operands
+    rounded to 16 bits, up to fp32 summation - ragged tile counts, a residual, the GroupNorm + SiLU pre-pass, the emitted GroupNorm statistics."""
+    from humanliff_amd import _lib
+    L = _lib.lib()
+    mode, dt = (_lib.HL_CONV_FP16, torch.float16) if f16 else (_lib.HL_CONV_BF16, torch.bfloat16)
+    for (N, H, W, C, Co, use_res, gn) in ((1, 16, 16, 32, 192, 0, 0), (2, 48, 80, 64, 384, 1, 0), (3, 32, 16, 96, 192, 1, 1)):
+        g = torch.Generator().manual_seed(N + C)
+        x = torch.randn((N, H, W, C), generator=g); w = torch.randn((Co, C, 3, 3), generator=g) / (C * 9) ** 0.5; b = torch.randn(Co, generator=g)
+        res = torch.randn((N, H, W, Co), generator=g)
+        cA, cB = torch.rand((N, C), generator=g) + 0.5, torch.randn((N, C), generator=g) * 0.1
+        xin = x
+        if gn:
+            u = x * cA[:, None, None, :] + cB[:, None, None, :]
+            xin = (u * torch.sigmoid(u)).to(dev).cpu()               # (the pre-pass runs in fp32 on the GPU; its rounding is inside the tolerance)
+        ref = F.conv2d(xin.to(dt).double().permute(0, 3, 1, 2), w.to(dt).double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        if use_res:
+            ref = ref + res.double()
+        xd, wd, bd, rd, ad, bd2 = (t.to(dev) for t in (x, w, b, res, cA, cB))
+        out = torch.zeros((N, H, W, Co), device=dev)
+        scratch = torch.empty(Co * C * 9 * 6 + 256 + (8 << 20) + N * H * W * C, device=dev)
+        with _lib.on(dev):
+            _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(xd), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Co, 3, 1, 0, _lib.ptr(ad) if gn else None,
+                                             _lib.ptr(bd2) if gn else None, gn, _lib.ptr(rd) if use_res else None, _lib.ptr(out), _lib.ptr(scratch),
+                                             scratch.numel() * 4, _lib.stream_ptr()), "hl_conv2d_nhwc_mode")
+        err = float((out.cpu().double() - ref).abs().max())
+        assert err < (2e-5 if not gn else 2e-3), (N, H, W, C, Co, err)       # (with the pre-pass: a value next to a rounding boundary may round the other way)
+        assert float((out.cpu().double() - ref).norm() / ref.norm()) < (1e-6 if not gn else 1e-4)
 
 
 def test_training_under_autocast_and_in_bf16_arithmetic_tracks_fp32():
     """The reference trains under torch.autocast (train_util.py:214, --use_amp True).  The HIP training path accepts the autocast context
-    (its kernels take fp32 tensors, so torch's own autocasting is switched off inside); the convolutions stay on the fp32 Winograd kernels
-    there - they are FASTER than the 16-bit direct kernel this library has (242 us against 290 us on 192->192 @256x256, batch 2) - and
-    `set_train_arithmetic("bf16")` opts into HL_CONV_BF16.  Loss, gradients and a 20-step loss curve of the three runs agree."""
+    (its kernels take fp32 tensors, so torch's own autocasting is switched off inside) and computes its convolutions with operands of the
+    autocast dtype (k_conv_h16 where it applies), exactly as `set_train_arithmetic("bf16")` does by hand; `set_train_arithmetic("fp32")`
+    pins the exact kernels.  Loss, gradients and a 20-step loss curve of the 16-bit runs track the fp32 run."""
     from tests.test_train_loss_cpu import inputs, tiny_model
     from humanliff_amd.improved_diffusion import unet_train as ut
     x0, xc = (t.to(dev) for t in inputs())
@@ -425,9 +463,11 @@ def test_training_under_autocast_and_in_bf16_arithmetic_tracks_fp32():
         return losses, first_grads
 
     l32, g32 = run(False, None, 20)
-    lam, gam = run(True, None, 20)            # under autocast: same arithmetic as without (fp32 kernels), same numbers
-    l16, g16 = run(False, "bf16", 20)         # opt-in 16-bit MFMA arithmetic
-    assert abs(lam[0] - l32[0]) < 1e-6 * abs(l32[0]) and abs(lam[-1] - l32[-1]) < 5e-3 * abs(l32[-1])   # (GroupNorm backward sums with float atomics: runs differ in the last bits)
+    lam, gam = run(True, None, 20)            # under autocast(bfloat16): the convolutions take the autocast dtype = the "bf16" arithmetic
+    l16, g16 = run(False, "bf16", 20)         # the same arithmetic chosen by hand
+    assert lam == l16 and all(torch.equal(gam[k], g16[k]) for k in g16)     # (every kernel of the step sums in a fixed order: identical runs)
+    lpin, _ = run(True, "fp32", 3)            # a pinned arithmetic wins over the autocast context
+    assert lpin == l32[:3]
     assert l32[0] != l16[0]                                          # different arithmetic ...
     assert abs(l16[0] - l32[0]) < 2e-3 * abs(l32[0])                 # ... same loss to bf16 accuracy
     num = sum(float(((g16[k] - g32[k]).double() ** 2).sum()) for k in g32)
