@@ -250,7 +250,44 @@ def bench_unet(args, rank, world, dev):
                     "opt-in, NOT used for `value`",
             "value": round(B * k3 / s3, 3), "unit": "denoise-steps/s", "steps": k3, "ms_per_step": round(s3 * 1e3 / k3, 3),
             "max_abs_diff_vs_fp32_forward": float((alt - ref).abs().max()), "forward_output_mean_abs": float(ref.abs().mean())}
+    # ---- opt-in arithmetic mode (not the headline): fp16 operands / fp32 accumulation on the 3x3 layers (k_conv_h16) ----
+    roof["fp16_mode"] = None
+    if world == 1 and not args.no_bf16x3_leg:
+        xx = torch.randn((B, 27, 256, 256), generator=torch.Generator().manual_seed(99)).to(dev)
+        tt = torch.full((B,), 500, dtype=torch.int64, device=dev)
+        d50 = create_gaussian_diffusion_for_bench("ddim50")
+        with torch.no_grad():
+            ref = model(xx, tt, x_cond, y=y)
+            ref50 = d50.ddim_sample_loop(model, (1, 27, 256, 256), x_cond=x_cond[:1], noise=x_T[:1], clip_denoised=True, model_kwargs={"y": y[:1]}, device=dev)
+            model.set_conv_mode("fp16")
+            alt = model(xx, tt, x_cond, y=y)
+            alt50 = d50.ddim_sample_loop(model, (1, 27, 256, 256), x_cond=x_cond[:1], noise=x_T[:1], clip_denoised=True, model_kwargs={"y": y[:1]}, device=dev)
+        it3 = diffusion.p_sample_loop_progressive(model, (B, 27, 256, 256), x_cond=x_cond, noise=x_T, clip_denoised=True,
+                                                  model_kwargs={"y": y}, device=dev)
+        next(it3); next(it3)
+        torch.cuda.synchronize()
+        k3 = max(2, min(args.steps, 10))
+        t3 = time.perf_counter()
+        for _ in range(k3):
+            next(it3)
+        torch.cuda.synchronize()
+        s3 = time.perf_counter() - t3
+        del it3
+        model.set_conv_mode("fp32")
+        psnr = lambda a, b: float(10 * torch.log10(b.abs().max() ** 2 / ((a - b) ** 2).mean()))  # noqa: E731
+        roof["fp16_mode"] = {
+            "what": "UNetModel.set_conv_mode('fp16') / HL_CONV_FP16: fp16 operands, fp32 accumulation (v_mfma_f32_32x32x16_f16, k_conv_h16) on "
+                    "the 3x3 / stride-1 layers, everything else as the fp32 mode - the operand precision of the reference's own TF32 "
+                    "convolutions; opt-in, NOT used for `value`, not an fp32-tolerance mode",
+            "value": round(B * k3 / s3, 3), "unit": "denoise-steps/s", "steps": k3, "ms_per_step": round(s3 * 1e3 / k3, 3),
+            "psnr_db_forward_vs_fp32": round(psnr(alt, ref), 1), "max_abs_diff_vs_fp32_forward": float((alt - ref).abs().max()),
+            "psnr_db_ddim50_sample_vs_fp32": round(psnr(alt50, ref50), 1), "max_abs_diff_ddim50_sample": float((alt50 - ref50).abs().max())}
     return secs, roof, sd, model
+
+
+def create_gaussian_diffusion_for_bench(respacing):
+    from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
+    return create_gaussian_diffusion(steps=1000, timestep_respacing=respacing)
 
 
 def bench_batches(model, dev, batches=(1, 8, 4), steps=12, warm=3):

@@ -1,6 +1,7 @@
 """UNet training step at the reference's configuration (README.md:104: production F4 network, microbatch 2, MSE loss):
 GaussianDiffusion.training_losses -> backward through the HIP kernels (unet_train.py) -> AdamW step.
-    python scripts/unet_train_bench.py [iters] [batch] [twin]      (twin: the same step through the PyTorch-op twin on MIOpen / rocBLAS)"""
+    python scripts/unet_train_bench.py [iters] [batch] [twin]      (twin: the same step through the PyTorch-op twin on MIOpen / rocBLAS)
+HL_TRAIN_ARITH=fp32|bf16|fp16 selects the arithmetic of the convolutions (unet_train.set_train_arithmetic)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,6 +13,9 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 twin = len(sys.argv) > 3 and sys.argv[3] == "twin"
 model, diffusion, _ = bench.build_unet(dev)
 model.train()
+if os.environ.get('HL_TRAIN_ARITH'):
+    from humanliff_amd.improved_diffusion import unet_train as _ut
+    _ut.set_train_arithmetic(os.environ['HL_TRAIN_ARITH'])
 opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.0, fused=os.environ.get('HL_ADAMW_FUSED', '1') == '1')   # one pass over the 497 M parameters instead of PyTorch's ~8 foreach passes
 g = torch.Generator(device=dev).manual_seed(0)
 x0 = torch.randn((B, 27, 256, 256), device=dev, generator=g).clamp(-1, 1)
@@ -35,5 +39,5 @@ for _ in range(iters):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / iters
 fl = 3 * 2015.4e9 * B          # forward + backward-data + backward-weights, direct-convolution FLOPs
-print(f"UNet training step ({'PyTorch-op twin, MIOpen' if twin else 'HIP kernels'}), batch {B}: {dt * 1e3:.1f} ms/step = {B / dt:.2f} samples/s = {fl / dt / 1e12:.1f} TFLOP/s algorithmic "
+print(f"UNet training step ({'PyTorch-op twin, MIOpen' if twin else 'HIP kernels, ' + os.environ.get('HL_TRAIN_ARITH', 'fp32')}), batch {B}: {dt * 1e3:.1f} ms/step = {B / dt:.2f} samples/s = {fl / dt / 1e12:.1f} TFLOP/s algorithmic "
       f"(3 x 2015.4 GFLOP per sample); loss {float(loss):.4f}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")

@@ -1,6 +1,7 @@
 """GPU tests at BASELINE.json's full sizes: the production 497M-parameter UNet against the oracle, and
 size-independent properties of the renderer / sampler at 512x512 x (128+128) and 4x27x256x256."""
 import pytest
+import numpy as np
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -49,6 +50,20 @@ def test_production_unet_matches_oracle(production):
         assert errs[mode] < 5e-5 * max(1.0, scale), (mode, errs, scale)      # measured 5.0e-6 / 5.1e-6
         assert float(((alt - want) ** 2).mean()) < 1e-9 * max(1.0, scale ** 2)
     print("production UNet max-abs vs oracle: " + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()) + f" (output scale {scale:.3f})")
+    # the opt-in fp16-operand mode (k_conv_h16 on the 3x3 / stride-1 layers, fp32 accumulation, everything else fp32): the operand precision
+    # of the reference's own TF32 convolutions - not an fp32-tolerance mode, so its bound is a PSNR
+    model.set_conv_mode("fp16")
+    try:
+        with torch.no_grad():
+            alt = model(x.to(dev), t.to(dev), xc.to(dev), y=y.to(dev)).cpu()
+        census = model.dispatch_census()
+    finally:
+        model.set_conv_mode("fp32")
+    assert sum(census["bf16x3"]) > 20, census                  # (the census counts k_conv_h16 with the kernels of the 16-bit matrix pipe)
+    peak = float(want.abs().max())
+    psnr = 10 * np.log10(peak ** 2 / float(((alt - want) ** 2).mean()))
+    print(f"fp16-operand mode: max-abs {float((alt - want).abs().max()):.3e}, PSNR vs oracle {psnr:.1f} dB, 16-bit launches per level {census['bf16x3'][:6]}")
+    assert psnr > 60, psnr                                      # measured ~75 dB
 
 
 def test_production_b4_dispatch_matches_oracle(production):
