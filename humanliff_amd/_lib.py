@@ -103,6 +103,7 @@ SIGNATURES = {
     "hl_conv2d_wgrad_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p]),
     "hl_conv2d_wgrad_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "hl_conv2d_wgrad_nhwc_ws": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _sz, _p]),
+    "hl_conv2d_wgrad_nhwc_ws_mode": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _sz, _p]),
     "hl_gn_apply_nhwc": (_i, [_p, _i64, _i, _i, _i, _p, _p, _i, _p, _p]),
     "hl_gn_backward_scratch_bytes": (_sz, [_i, _i, _i]),
     "hl_gn_backward_reduce": (_i, [_p, _i64, _p, _i, _i, _i, _p, _p, _i, _p, _p, _sz, _p]),

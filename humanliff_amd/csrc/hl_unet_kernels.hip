@@ -2577,6 +2577,12 @@ int conv_pack_weights_wino4(const float *w, int Cout, int Cin, int Cin_pad, floa
 
 static inline long hw_o_early(const ConvArgs &a) { return (long)a.out.H * a.out.W; }
 
+// k_conv_h16 is taken from this many workgroups on (HL_H16_MIN_BLOCKS overrides: the unit tests run it on single tiles)
+static long h16_min_blocks() {
+    const char *e = getenv("HL_H16_MIN_BLOCKS");
+    return e ? atol(e) : 48;
+}
+
 int conv2d(const ConvArgs &a, hipStream_t st) {
     a.path = 0;
     HL_REQUIRE(a.in.p && a.w && a.out.p, "conv2d: null tensor");
@@ -2729,7 +2735,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     // 16-bit operands (opt-in modes): the 3x3 / stride-1 layers k_conv_h16 covers; the rest of the mode stays on k_conv_bf3 / fp32
     const bool h16 = a.w_h16 && (a.coefA == nullptr || a.act_ws) && !a.out_nchw && !a.out2 &&
                      conv_h16_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
-                     (long)a.out.N * (a.out.H / 16) * (a.out.W / 16) * (a.Cout / 192) >= 48 &&   // (fewer workgroups: the split-K fp32 kernels fill the chip better)
+                     (long)a.out.N * (a.out.H / 16) * (a.out.W / 16) * (a.Cout / 192) >= h16_min_blocks() &&   // (fewer workgroups: the split-K fp32 kernels fill the chip better)
                      (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0;
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
         a.path = h16 ? 5 : ((dma && wino4) ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));

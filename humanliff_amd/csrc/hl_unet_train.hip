@@ -282,6 +282,158 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_t(const WgradT p) {
     }
 }
 
+// k_conv_wgrad_h16: k_conv_wgrad_t (stride 1, no upsample) with 16-bit operands and fp32 accumulation on v_mfma_f32_32x32x16_{f16,bf16} -
+// the arithmetic of the 16-bit training modes (HL_CONV_FP16 / HL_CONV_BF16).  Same work split, same partial buffer and finish kernel.
+// The contraction runs over PIXELS, and a 16-bit MFMA fragment wants 8 consecutive k values per lane, so both operands sit in LDS
+// pixel-contiguous, [channel][pixel]: the transposition happens in registers while staging (a thread fetches a few pixels x 4 channels
+// as fp32, rounds them and writes one run of pixels per channel), never in memory.
+//   * dY: [co 64][8 rows][8 px], 16 bytes per tile row; a k-step of 16 pixels = two tile rows = the two lane halves of a fragment;
+//   * the input patch three times, one copy per tap column kx: [kx][ci 64][10 rows][8 px] holds columns kx..kx+7 of every patch row,
+//     so the fragment of tap (ky, kx) for tile row y is the aligned 16 bytes of row y + ky in copy kx;
+//   * channel rows are padded by 16 bytes (144 / 176 bytes): the 16 lanes a ds_read_b128 is served in hit 16 different slots.
+// Per k-step and wave: 1 + 9 ds_read_b128 for 9 MFMAs.  The kernel is bound by what it pulls through L2 (41.6 KB of fp32 per 64 pixels
+// and workgroup), not by the matrix pipe - two workgroups per CU keep loads in flight behind the other's MFMAs.
+template <bool F16>
+__device__ __forceinline__ unsigned wg_pack2(float a, float b) {
+    if constexpr (F16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 h = {(_Float16)a, (_Float16)b};
+        return __builtin_bit_cast(unsigned, h);
+    } else {
+        const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+        const unsigned ra = ua + 0x7fffu + ((ua >> 16) & 1u), rb = ub + 0x7fffu + ((ub >> 16) & 1u);
+        return __builtin_amdgcn_perm(rb, ra, 0x07060302);
+    }
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 wg_mma(const u32x4 a, const u32x4 b, const f32x16 c) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_h16(const WgradT p) {
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int AP = 144, BP = 176, A_BYTES = 64 * AP, B_COPY = 64 * BP;      // channel-row pitches (bytes), operand images
+    __shared__ __attribute__((aligned(16))) char lds[A_BYTES + 3 * B_COPY];     // 42 KB: two workgroups per CU
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, m = lane & 31;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int blocks = p.n_co * p.n_ci;
+    const int per_xcd = (int)(gridDim.x >> 3);
+    const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (logical >= blocks * p.slabs) return;
+    const int slab = logical / blocks, blk = logical - slab * blocks;
+    const int cob = blk / p.n_ci, cib = blk - cob * p.n_ci;
+    const int co0 = cob * 64, ci0 = cib * 64;
+    const __amdgpu_buffer_rsrc_t rsY =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.dy, (short)0, (int)((long)p.N * p.Hout * p.Wout * p.dy_pitch * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.x, (short)0, (int)((long)p.N * p.Hin * p.Win * p.x_pitch * 4), 0x00020000);
+    const int c4 = tid & 15;
+    const int ar = (tid >> 4) & 7, ah = tid >> 7;              // dY: tile row, half row (4 pixels) of this thread
+    const int br = tid >> 4;                                   // patch: row of this thread (threads 0..159)
+    const bool a_ok = co0 + 4 * c4 < p.Cy, b_ok = ci0 + 4 * c4 < p.Cx && br < 10;
+    const long t0 = (long)slab * p.per_slab, t1 = min(p.tiles, t0 + p.per_slab);
+    const int tpi = p.tilesX * p.tilesY;
+
+    f32x4 ra[4], rb[10];
+    auto fetch = [&](long tile) {
+        const int n = (int)(tile / tpi), r = (int)(tile - (long)n * tpi);
+        const int tyb = r / p.tilesX, txb = r - tyb * p.tilesX;
+        const int oy0 = tyb * 8, ox0 = txb * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int yo = oy0 + ar, xo = ox0 + 4 * ah + j;
+            const bool v = a_ok && yo < p.Hout && xo < p.Wout;
+            const unsigned off = v ? (unsigned)((((long)n * p.Hout + yo) * p.Wout + xo) * p.dy_pitch + co0 + 4 * c4) * 4u : OOB;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
+        }
+        if (tid < 160) {
+#pragma unroll
+            for (int c = 0; c < 10; ++c) {
+                const int yi = oy0 + br - 1, xi = ox0 + c - 1;
+                const bool v = b_ok && yi >= 0 && yi < p.Hin && xi >= 0 && xi < p.Win;
+                const unsigned off = v ? (unsigned)((((long)n * p.Hin + yi) * p.Win + xi) * p.x_pitch + ci0 + 4 * c4) * 4u : OOB;
+                rb[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
+            }
+        }
+    };
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                          // bias gradient: fp32 sums of this thread's dY values
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                           // channel 4 c4 + i: four pixels of tile row ar -> 8 bytes
+            const unsigned lo = wg_pack2<F16>(ra[0][i], ra[1][i]), hi = wg_pack2<F16>(ra[2][i], ra[3][i]);
+            *reinterpret_cast<uint2 *>(lds + (4 * c4 + i) * AP + ar * 16 + ah * 8) = uint2{lo, hi};
+            bsum[i] += (ra[0][i] + ra[1][i]) + (ra[2][i] + ra[3][i]);
+        }
+        if (tid < 160) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                       // channel 4 c4 + i: patch row br, columns 0..9 -> the three shifted 8-pixel runs
+                unsigned e[5], o[4];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) e[k] = wg_pack2<F16>(rb[2 * k][i], rb[2 * k + 1][i]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = __builtin_amdgcn_perm(e[k + 1], e[k], 0x05040302);      // (h[2k+1], h[2k+2])
+                char *q = lds + A_BYTES + (4 * c4 + i) * BP + br * 16;
+                *reinterpret_cast<u32x4 *>(q) = u32x4{e[0], e[1], e[2], e[3]};
+                *reinterpret_cast<u32x4 *>(q + B_COPY) = u32x4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<u32x4 *>(q + 2 * B_COPY) = u32x4{e[1], e[2], e[3], e[4]};
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const char *la = lds + (32 * wi + m) * AP + g * 16;                      // + k-step s: 32 bytes (two tile rows)
+    const char *lb = lds + A_BYTES + (32 * wj + m) * BP + g * 16;            // + copy kx, + (2 s + ky) * 16
+
+    if (t0 < t1) fetch(t0);
+    for (long tile = t0; tile < t1; ++tile) {
+        if (tile > t0) __syncthreads();                          // the previous tile's reads are done
+        stage();
+        __syncthreads();
+        if (tile + 1 < t1) fetch(tile + 1);                      // in flight during this tile's MFMAs
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const u32x4 a = *reinterpret_cast<const u32x4 *>(la + s * 32);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                u32x4 b[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) b[kx] = *reinterpret_cast<const u32x4 *>(lb + kx * B_COPY + (2 * s + ky) * 16);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = wg_mma<F16>(a, b[kx], acc[ky * 3 + kx]);
+            }
+        }
+    }
+    // partial block: accumulator r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5) (co), column l & 31 (ci)
+    const long CoP = (long)p.n_co * 64, CiP = (long)p.n_ci * 64;
+    float *pp = p.part + (long)slab * CoP * 10 * CiP;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+            pp[((long)(co0 + 32 * wi + row) * 10 + t) * CiP + ci0 + 32 * wj + m] = acc[t][r];
+        }
+    if (p.want_b && cib == 0) {                                  // bias slot: the 16 threads that share a channel quad meet in LDS, fixed order
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(lds);
+        *reinterpret_cast<f32x4 *>(red + ((tid >> 4) * 16 + c4) * 4) = bsum;
+        __syncthreads();
+        if (tid < 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v += red[(k * 16 + (tid >> 2)) * 4 + (tid & 3)];
+            pp[((long)(co0 + tid) * 10 + 9) * CiP] = v;
+        }
+    }
+}
+
 // 1x1 layers (skip / zero / qkv / proj convolutions): no halo, so a tile is 64 consecutive pixels of the flattened image batch.  With
 // a single tap the only reuse there is sits in the channel block, so a workgroup owns 192 output x 64 input channels (every width of
 // the network is a multiple of 192 and of 64): wave (i, j) holds co tiles 3i..3i+2 x ci tile j - three A reads and one B read per
@@ -663,6 +815,12 @@ size_t hl_conv2d_wgrad_scratch_bytes(int N, int H, int W, int Cx, int Cy, int ks
 
 int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                             float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream) {
+    return hl_conv2d_wgrad_nhwc_ws_mode(HL_CONV_FP32, x, N, H, W, Cx, dy, Cy, ks, stride, upsample, dw, Cout, Cin, db, scratch, scratch_bytes, stream);
+}
+
+int hl_conv2d_wgrad_nhwc_ws_mode(int conv_mode, const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
+                                 float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream) {
+    const bool h16 = (conv_mode == HL_CONV_FP16 || conv_mode == HL_CONV_BF16) && ks == 3 && stride == 1 && !upsample;
     if (!wgrad_t_applies(Cx, Cy, ks, stride, upsample))
         return hl_conv2d_wgrad_nhwc(x, N, H, W, Cx, dy, Cy, ks, stride, upsample, dw, Cout, Cin, db, stream);
     HL_REQUIRE(x && dy && dw, "hl_conv2d_wgrad_nhwc_ws: null argument");
@@ -682,6 +840,8 @@ int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const f
     p.part = static_cast<float *>(scratch);
     const unsigned grid = (unsigned)(((long)p.n_co * p.n_ci * p.slabs + 7) / 8 * 8);
     if (ks == 1) hipLaunchKernelGGL(k_conv_wgrad_1x1, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (h16 && conv_mode == HL_CONV_FP16) hipLaunchKernelGGL(k_conv_wgrad_h16<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (h16) hipLaunchKernelGGL(k_conv_wgrad_h16<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else if (stride == 1) hipLaunchKernelGGL(k_conv_wgrad_t<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(k_conv_wgrad_t<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     int rc = check_launch("k_conv_wgrad_t");

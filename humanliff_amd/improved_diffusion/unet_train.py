@@ -47,7 +47,8 @@ def set_train_arithmetic(kind=None):
                       (fp16); fp32 tensors and master weights;
       None (default)  "fp32", unless the caller trains under torch.autocast (train_util.py:214, --use_amp True): then the autocast dtype -
                       what the reference's AMP computes its convolutions in.
-    Weight gradients, GroupNorm and attention stay fp32 either way."""
+    The weight gradients of the 3x3 / stride-1 layers take the same arithmetic (k_conv_wgrad_h16); the other weight gradients, GroupNorm
+    and attention stay fp32."""
     assert kind in (None, "fp32", "bf16", "fp16")
     _ARITH["mode"] = kind
 
@@ -126,9 +127,9 @@ class _Conv(th.autograd.Function):
             dw = alloc(w4.shape, device=dy.device, dtype=th.float32)
             db = alloc((Cout,), device=dy.device, dtype=th.float32) if has_b else None
             with _lib.on(dy.device):
-                _lib.check(L.hl_conv2d_wgrad_nhwc_ws(_lib.ptr(x), N, x.shape[1], x.shape[2], x.shape[3], _lib.ptr(dy2), dy2.shape[-1], ks, stride,
-                                                     ups, _lib.ptr(dw), Cout, Cin, _lib.ptr(db), _lib.ptr(part), nbytes, _lib.stream_ptr()),
-                           "hl_conv2d_wgrad_nhwc_ws")
+                _lib.check(L.hl_conv2d_wgrad_nhwc_ws_mode(ctx.mode, _lib.ptr(x), N, x.shape[1], x.shape[2], x.shape[3], _lib.ptr(dy2), dy2.shape[-1], ks,
+                                                          stride, ups, _lib.ptr(dw), Cout, Cin, _lib.ptr(db), _lib.ptr(part), nbytes, _lib.stream_ptr()),
+                           "hl_conv2d_wgrad_nhwc_ws_mode")
             dw = dw.reshape(wshape)
         return dx, dw, db, None, None
 

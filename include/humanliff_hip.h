@@ -397,6 +397,10 @@ int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const floa
 size_t hl_conv2d_wgrad_scratch_bytes(int N, int H, int W, int Cx, int Cy, int ks, int stride, int upsample, int Cout, int Cin);
 int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                             float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream);
+/* The same with an arithmetic mode: HL_CONV_FP16 / HL_CONV_BF16 round both operands to 16 bits and accumulate in fp32
+ * (v_mfma_f32_32x32x16, k_conv_wgrad_h16) on the 3x3 / stride-1 layers; every other layer and mode as hl_conv2d_wgrad_nhwc_ws. */
+int hl_conv2d_wgrad_nhwc_ws_mode(int conv_mode, const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride,
+                                 int upsample, float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream);
 /* y (N,HW,C dense) = silu ? silu(x*A + B) : x*A + B with the per-(n,c) affine of hl_groupnorm_coef; x has a channel pitch. */
 int hl_gn_apply_nhwc(const float *x, long x_pitch, int N, int HW, int C, const float *coefA, const float *coefB, int silu, float *y,
                      void *stream);

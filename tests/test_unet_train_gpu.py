@@ -354,7 +354,7 @@ def test_16bit_conv_modes_forward_and_backward_data(kind):
     from humanliff_amd.improved_diffusion import unet_train as ut
     g = torch.Generator().manual_seed(4)
     lo, hi = (1e-5, 4e-3) if kind == "bf16" else (2e-6, 5e-4)
-    for (N, H, W, C, Co, ks) in ((2, 64, 64, 96, 192, 3), (1, 32, 48, 64, 384, 3), (2, 64, 64, 384, 192, 1)):
+    for (N, H, W, C, Co, ks) in ((3, 64, 64, 96, 192, 3), (4, 32, 48, 64, 384, 3), (2, 64, 64, 384, 192, 1)):     # (3x3: 48 workgroups, where the dispatch starts to take k_conv_h16)
         x = torch.randn((N, C, H, W), generator=g)
         w = torch.randn((Co, C, ks, ks), generator=g) / (C * ks * ks) ** 0.5
         b = torch.randn((Co,), generator=g) * 0.1
@@ -387,12 +387,47 @@ def test_16bit_conv_modes_forward_and_backward_data(kind):
         assert not torch.equal(y.detach(), y32)                      # the mode really switched arithmetic
 
 
+@pytest.mark.parametrize("kind", ["bf16", "fp16"])
+def test_16bit_weight_gradient_equals_the_gradient_of_the_rounded_operands(kind):
+    """k_conv_wgrad_h16 (3x3 / stride-1 layers in the 16-bit training modes): dW is the float64 weight gradient of the input and the output
+    gradient rounded to 16 bits, up to fp32 summation; db is the fp32 row sum of the unrounded output gradient.  Ragged tiles (sizes that
+    are not multiples of 8), ragged channel blocks, several images, K slabs; bit-reproducible."""
+    from humanliff_amd.improved_diffusion import unet_train as ut
+    dt = torch.bfloat16 if kind == "bf16" else torch.float16
+    for (N, H, W, C, Co) in ((2, 32, 32, 64, 64), (1, 20, 12, 96, 160), (2, 64, 64, 192, 192), (3, 8, 8, 32, 32)):
+        g = torch.Generator().manual_seed(H + C)
+        x = torch.randn((N, C, H, W), generator=g)
+        w = torch.randn((Co, C, 3, 3), generator=g) / (C * 9) ** 0.5
+        b = torch.randn((Co,), generator=g)
+        cot = torch.randn((N, Co, H, W), generator=g)
+        wr = w.double().requires_grad_(True)
+        (F.conv2d(x.to(dt).double(), wr, None, padding=1) * cot.to(dt).double()).sum().backward()
+        dw_ref, db_ref = wr.grad, cot.double().sum(dim=(0, 2, 3))
+        runs = []
+        for _ in range(2):
+            xd = nhwc(x).to(dev).requires_grad_(True)
+            wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+            ut.set_train_arithmetic(kind)
+            try:
+                (ut._Conv.apply(xd, wd, bd, 1, 0) * nhwc(cot).to(dev)).sum().backward()
+            finally:
+                ut.set_train_arithmetic(None)
+            runs.append((wd.grad.clone(), bd.grad.clone()))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+        dw, db = runs[0]
+        ew = float((dw.cpu().double() - dw_ref).abs().max() / dw_ref.abs().max())
+        eb = float((db.cpu().double() - db_ref).abs().max() / db_ref.abs().max())
+        print(f"{kind} N{N} {H}x{W} {C}->{Co}: dW max-abs / max {ew:.2e}, db {eb:.2e}")
+        assert ew < 2e-5 and eb < 1e-5, (N, H, W, C, Co, ew, eb)
+
+
 @pytest.mark.parametrize("f16", [0, 1])
-def test_conv_h16_equals_the_convolution_of_the_rounded_operands(f16):
+def test_conv_h16_equals_the_convolution_of_the_rounded_operands(f16, monkeypatch):
     """k_conv_h16 through the C ABI (hl_conv2d_nhwc_mode / hl_conv2d_nhwc_gn): the kernel's result is the float64 convolution of the operands
     rounded to 16 bits, up to fp32 summation - ragged tile counts, a residual, the GroupNorm + SiLU pre-pass, the emitted GroupNorm statistics."""
     from humanliff_amd import _lib
     L = _lib.lib()
+    monkeypatch.setenv("HL_H16_MIN_BLOCKS", "1")             # (the dispatch takes the kernel from 48 workgroups on; here also single tiles)
     mode, dt = (_lib.HL_CONV_FP16, torch.float16) if f16 else (_lib.HL_CONV_BF16, torch.bfloat16)
     for (N, H, W, C, Co, use_res, gn) in ((1, 16, 16, 32, 192, 0, 0), (2, 48, 80, 64, 384, 1, 0), (3, 32, 16, 96, 192, 1, 1)):
         g = torch.Generator().manual_seed(N + C)
