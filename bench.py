@@ -568,19 +568,21 @@ def bench_train(model, diffusion, dev, rank, world, iters=3, B=2):
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, dev) / iters
     assert torch.isfinite(loss.detach()).all()
-    # the opt-in 16-bit MFMA arithmetic of the convolutions (forward and backward-data on the direct DMA-tile layers; HL_CONV_BF16)
+    # the 16-bit MFMA arithmetic of the convolutions (what the reference's --use_amp True selects; taken automatically under torch.autocast)
     from humanliff_amd.improved_diffusion import unet_train as ut
-    ut.set_train_arithmetic("bf16")
-    try:
-        step()
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        for _ in range(iters):
-            loss16 = step()
-        torch.cuda.synchronize()
-        dt16 = (time.perf_counter() - tb) / iters
-    finally:
-        ut.set_train_arithmetic(None)
+    dt16 = {}
+    for kind in ("bf16", "fp16"):
+        ut.set_train_arithmetic(kind)
+        try:
+            step()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(iters):
+                loss16 = step()
+            torch.cuda.synchronize()
+            dt16[kind] = (time.perf_counter() - tb) / iters
+        finally:
+            ut.set_train_arithmetic(None)
     assert torch.isfinite(loss16.detach()).all()
     model.train(was_training)
     del opt
@@ -588,10 +590,11 @@ def bench_train(model, diffusion, dev, rank, world, iters=3, B=2):
         p.grad = None
     return {"metric": "UNet training samples/sec", "value": round(world * B / dt, 3), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 2),
             "batch_per_gpu": B, "iterations": iters,
-            "bf16_arithmetic": {"ms_per_step": round(dt16 * 1e3, 2), "value": round(B / dt16, 3), "unit": "samples/s (this rank)",
-                                "what": "unet_train.set_train_arithmetic('bf16'): activations rounded to bf16 x 16-bit weights on v_mfma_f32_32x32x16_bf16 for forward and "
-                                        "backward-data of the direct-tile layers (weight gradients fp32); opt-in, NOT tied to autocast - its direct kernel is bound by "
-                                        "LDS-DMA issue and loses to the fp32 Winograd kernels on the 3x3 layers"},
+            "bf16_arithmetic": {"ms_per_step": round(dt16["bf16"] * 1e3, 2), "value": round(B / dt16["bf16"], 3), "unit": "samples/s (this rank)"},
+            "fp16_arithmetic": {"ms_per_step": round(dt16["fp16"] * 1e3, 2), "value": round(B / dt16["fp16"], 3), "unit": "samples/s (this rank)",
+                                "what": "unet_train.set_train_arithmetic('fp16' / 'bf16'), chosen automatically under torch.autocast (train_util.py:214): 16-bit "
+                                        "operands / fp32 accumulation on v_mfma_f32_32x32x16 for forward, backward-data (k_conv_h16) and the weight gradients "
+                                        "(k_conv_wgrad_h16) of the 3x3 / stride-1 layers; fp32 tensors and master weights; `value` above is the fp32 arithmetic"},
             "algorithmic_tflops": round(world * 3 * UNET_GFLOP_PER_SAMPLE_STEP * B / dt / 1e3, 2),
             "config": {"workload": "production F4 UNet, training_losses (MSE) + backward on the HIP kernels + AdamW (torch, fused=True), microbatch 2 (README.md:104)",
                        "flop_count": "3 x 2015.4 GFLOP per sample (forward, backward-data, backward-weights; direct-convolution FLOPs)"}}

@@ -997,8 +997,8 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
         rc = hl::conv_pack_weights_wino(w_oihw, Cout, Cin_w, Cin, static_cast<float *>(extra_dst), (hipStream_t)stream, tf);
         a.w_wino4 = nullptr;
     } else {
-        rc = hl::conv_pack_weights(w_oihw, Cout, Cin_w, Cin, ks, static_cast<float *>(scratch), (hipStream_t)stream, tf);
-        if (!rc && a.path == 2) rc = hl::conv_pack_weights_bf3(w_oihw, Cout, Cin_w, Cin, ks, extra_dst, (hipStream_t)stream, tf);
+        if (a.path == 2) rc = hl::conv_pack_weights_bf3(w_oihw, Cout, Cin_w, Cin, ks, extra_dst, (hipStream_t)stream, tf);   // (k_conv_bf3 reads only these planes)
+        else rc = hl::conv_pack_weights(w_oihw, Cout, Cin_w, Cin, ks, static_cast<float *>(scratch), (hipStream_t)stream, tf);
         a.w_wino = nullptr;
         a.w_wino4 = nullptr;
     }
