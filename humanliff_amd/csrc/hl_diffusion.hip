@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ x, const
                                               const float *__restrict__ noise, const float *__restrict__ coef,
                                               const int64_t *__restrict__ t, float *__restrict__ sample,
                                               float *__restrict__ x0_out, long n, int T, int clip, int has_noise, int x0_given,
-                                              const float *__restrict__ logvar) {
+                                              const float *__restrict__ logvar, int xprev_given) {
     const int b = blockIdx.y;
     const int64_t tb = t[b];
     // a timestep outside the (T,8) table (the reference's numpy indexing raises IndexError, gaussian_diffusion.py:859) never
@@ -25,17 +25,19 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ x, const
     const bool in_range = tb >= 0 && tb < (int64_t)T;
     const float *c = coef + (in_range ? tb : 0) * 8;
     const float poison = in_range ? 0.f : __builtin_nanf("");
-    const float r = c[0] + poison, rm1 = c[1], c0 = c[2], c1 = c[3];
+    const float r = c[0] + poison, rm1 = c[1], c0 = c[2], c1 = c[3], q0 = c[5], q1 = c[6];
     const float nz = has_noise ? (tb != 0 ? 1.f : 0.f) * c[4] : 0.f;
     const long base = (long)b * n;
     // logvar (learned variances, gaussian_diffusion.py:262-276): per-element model_log_variance replaces the table's sigma
     auto one = [&](float xv, float ev, float nv, float lv, float &sv, float &x0v) {
         // x0_given: `eps` holds pred_xstart already processed by the caller (denoised_fn + clamp, gaussian_diffusion.py:293-299)
-        float x0 = x0_given ? ev + poison : r * xv - rm1 * ev;
+        // xprev_given: `eps` holds the model's x_{t-1} prediction (gaussian_diffusion.py:300-304): x0 = xprev / coef1 - coef2 / coef1 * x_t
+        // (:335-343) and the model mean of the ancestral step is the prediction itself
+        float x0 = x0_given ? ev + poison : (xprev_given ? q0 * ev - q1 * xv + poison : r * xv - rm1 * ev);
         if (clip && !x0_given) x0 = fminf(fmaxf(x0, -1.f), 1.f);
         float mean;
         if (MODE == 0) {
-            mean = c0 * x0 + c1 * xv;
+            mean = xprev_given ? ev + poison : c0 * x0 + c1 * xv;
         } else {
             const float e2 = (r * xv - x0) / rm1;
             mean = x0 * c0 + c1 * e2;
@@ -75,8 +77,8 @@ extern "C" int hl_diffusion_step(int mode, const float *x, const float *eps, con
     HL_REQUIRE(x && eps && coef && t && sample, "hl_diffusion_step: null argument");
     const int has_noise = noise != nullptr;
     if (!noise) noise = x;  // never contributes (factor 0); keeps the loads in bounds
-    HL_REQUIRE(mode >= 0 && mode <= 3, "hl_diffusion_step: mode %d", mode);
-    const int x0_given = mode >> 1;
+    HL_REQUIRE(mode >= 0 && mode <= 5, "hl_diffusion_step: mode %d", mode);
+    const int x0_given = (mode >> 1) & 1, xprev_given = mode >> 2;
     mode &= 1;
     HL_REQUIRE(n_per_sample > 0 && B > 0 && T > 0, "hl_diffusion_step: bad sizes");
     const bool vec = (n_per_sample % 4 == 0) && (((uintptr_t)x | (uintptr_t)eps | (uintptr_t)noise | (uintptr_t)sample |
@@ -86,7 +88,7 @@ extern "C" int hl_diffusion_step(int mode, const float *x, const float *eps, con
     if (gx > 1024) gx = 1024;
     dim3 grid((unsigned)gx, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-#define HL_GO(M, V) hipLaunchKernelGGL((k_step<M, V>), grid, dim3(256), 0, st, x, eps, noise, coef, t, sample, pred_xstart, (long)n_per_sample, T, clip, has_noise, x0_given, log_variance)
+#define HL_GO(M, V) hipLaunchKernelGGL((k_step<M, V>), grid, dim3(256), 0, st, x, eps, noise, coef, t, sample, pred_xstart, (long)n_per_sample, T, clip, has_noise, x0_given, log_variance, xprev_given)
     if (mode == 0) { if (vec) HL_GO(0, true); else HL_GO(0, false); }
     else { if (vec) HL_GO(1, true); else HL_GO(1, false); }
 #undef HL_GO

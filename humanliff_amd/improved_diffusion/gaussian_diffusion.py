@@ -9,8 +9,9 @@ six times per step, :850-863); timesteps come from a device-resident table (the 
 from a Python list every step, :474); everything after the model call is ONE kernel.
 
 Sampling covers EPSILON and START_X prediction with fixed (FIXED_LARGE - the shipped configuration - / FIXED_SMALL) or learned
-(LEARNED / LEARNED_RANGE, learn_sigma=True) variances and an optional denoised_fn; x_{t-1} prediction and the VLB training losses
-raise NotImplementedError.
+(LEARNED / LEARNED_RANGE, learn_sigma=True) variances, x_{t-1} prediction (PREVIOUS_X) and an optional denoised_fn - all through the
+same fused kernel.  training_losses covers every LossType of the reference (MSE / RESCALED_MSE incl. the hybrid variational-bound term of
+learned variances, KL / RESCALED_KL) as differentiable tensor algebra around the model call.
 """
 import enum
 import math
@@ -19,6 +20,7 @@ import numpy as np
 import torch as th
 
 from .. import _lib
+from .losses import discretized_gaussian_log_likelihood, normal_kl
 from .nn import mean_flat
 
 
@@ -114,6 +116,8 @@ class GaussianDiffusion:
         tab = th.zeros((T, 8), dtype=th.float32)
         tab[:, 0] = f32(self.sqrt_recip_alphas_cumprod)
         tab[:, 1] = f32(self.sqrt_recipm1_alphas_cumprod)
+        tab[:, 5] = f32(1.0 / self.posterior_mean_coef1)                       # x_{t-1} prediction (:335-343): x0 = xprev / coef1 - coef2 / coef1 * x_t
+        tab[:, 6] = f32(self.posterior_mean_coef2 / self.posterior_mean_coef1)
         if kind == "ddpm":
             tab[:, 2] = f32(self.posterior_mean_coef1)
             tab[:, 3] = f32(self.posterior_mean_coef2)
@@ -129,7 +133,7 @@ class GaussianDiffusion:
         self._tables[key] = hit
         return hit
 
-    def _step(self, mode, x, eps, noise, t, clip, eta=0.0, want_x0=True, x0_given=False, logvar=None):
+    def _step(self, mode, x, eps, noise, t, clip, eta=0.0, want_x0=True, x0_given=False, logvar=None, xprev_given=False):
         if not x.is_cuda:
             raise RuntimeError("sampling needs CUDA(HIP) tensors; there is no CPU path")
         tab = self._table("ddpm" if mode == 0 else "ddim", x.device, eta)
@@ -141,7 +145,7 @@ class GaussianDiffusion:
         B = x.shape[0]
         tt = t.to(device=x.device, dtype=th.int64).contiguous()
         with _lib.on(x.device):
-            _lib.check(_lib.lib().hl_diffusion_step(mode + (2 if x0_given else 0), _lib.ptr(xf), _lib.ptr(ef), _lib.ptr(nf), _lib.ptr(tab), _lib.ptr(tt),
+            _lib.check(_lib.lib().hl_diffusion_step(mode + (2 if x0_given else 0) + (4 if xprev_given else 0), _lib.ptr(xf), _lib.ptr(ef), _lib.ptr(nf), _lib.ptr(tab), _lib.ptr(tt),
                                                     _lib.ptr(out), _lib.ptr(x0), xf.numel() // B, B, self.num_timesteps,
                                                     1 if clip else 0, _lib.ptr(lvf), _lib.stream_ptr()), "hl_diffusion_step")
         return out, x0
@@ -172,6 +176,11 @@ class GaussianDiffusion:
         assert x_t.shape == eps.shape
         return (_extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
                 - _extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * eps)
+
+    def _predict_xstart_from_xprev(self, x_t, t, xprev):
+        assert x_t.shape == xprev.shape
+        return (_extract_into_tensor(1.0 / self.posterior_mean_coef1, t, x_t.shape) * xprev
+                - _extract_into_tensor(self.posterior_mean_coef2 / self.posterior_mean_coef1, t, x_t.shape) * x_t)
 
     def _predict_eps_from_xstart(self, x_t, t, pred_xstart):
         return ((_extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - pred_xstart)
@@ -217,7 +226,17 @@ class GaussianDiffusion:
         """Everything after the model call, one fused kernel: EPSILON prediction goes in as eps; START_X prediction, or any
         denoised_fn, as the processed pred_xstart (process_xstart, :293-299)."""
         if self.model_mean_type == ModelMeanType.PREVIOUS_X:
-            raise NotImplementedError("model_mean_type PREVIOUS_X is not built (no script of the reference selects it)")
+            # x_{t-1} prediction (:300-304): the model output IS the mean of p_sample / p_mean_variance; pred_xstart (what ddim_sample
+            # continues from) = process_xstart(xprev / coef1 - coef2 / coef1 * x_t).  Mode bit 4 of the fused kernel does both.
+            if denoised_fn is None:
+                return self._step(mode, x, out, noise, t, clip_denoised, eta=eta, logvar=logvar, xprev_given=True)
+            x0 = denoised_fn(self._predict_xstart_from_xprev(x, t, out))
+            if clip_denoised:
+                x0 = x0.clamp(-1, 1)
+            if mode == 1:
+                return self._step(mode, x, x0, noise, t, False, eta=eta, x0_given=True, logvar=logvar)
+            sample, _ = self._step(mode, x, out, noise, t, False, eta=eta, logvar=logvar, xprev_given=True, want_x0=False)
+            return sample, x0
         if self.model_mean_type == ModelMeanType.START_X or denoised_fn is not None:
             x0 = out if self.model_mean_type == ModelMeanType.START_X else self._predict_xstart_from_eps(x, t, out)
             if denoised_fn is not None:
@@ -325,18 +344,68 @@ class GaussianDiffusion:
             pass
         return final["sample"]
 
-    # ---- training loss (tensor algebra around a differentiable `model`; the HIP UNet is inference-only) ----
+    # ---- training losses: differentiable tensor algebra around a differentiable `model` (UNetModel.forward picks its HIP training path) ----
+    def _pmv_autograd(self, out, x, t, clip_denoised):
+        """p_mean_variance (:239-333) as differentiable tensor algebra on an already computed model output - the variational-bound terms
+        need gradients through mean and log-variance, which the fused sampling kernel does not give."""
+        B, Cc = x.shape[:2]
+        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
+            assert out.shape == (B, Cc * 2, *x.shape[2:])
+            out, v = th.split(out, Cc, dim=1)
+            if self.model_var_type == ModelVarType.LEARNED:
+                logvar = v
+            else:
+                min_log = _extract_into_tensor(self.posterior_log_variance_clipped, t, x.shape)
+                max_log = _extract_into_tensor(np.log(self.betas), t, x.shape)
+                frac = (v + 1) / 2
+                logvar = frac * max_log + (1 - frac) * min_log
+        else:
+            logvar = _extract_into_tensor(self._fixed_variance()[1], t, x.shape)
+        clip = (lambda z: z.clamp(-1, 1)) if clip_denoised else (lambda z: z)
+        if self.model_mean_type == ModelMeanType.PREVIOUS_X:
+            x0, mean = clip(self._predict_xstart_from_xprev(x, t, out)), out
+        else:
+            x0 = clip(out if self.model_mean_type == ModelMeanType.START_X else self._predict_xstart_from_eps(x, t, out))
+            mean = self.q_posterior_mean_variance(x_start=x0, x_t=x, t=t)[0]
+        return mean, logvar, x0
+
+    def _vb_terms_bpd(self, model, x_start, x_t, t, clip_denoised=True, model_kwargs=None):
+        """One term of the variational bound in bits per dimension (:653-687): KL(q(x_{t-1} | x_t, x_0) || p(x_{t-1} | x_t)), and at t = 0
+        the decoder's negative log-likelihood.  Like the reference's, the model is called WITHOUT x_cond here (:668-670 pass none)."""
+        true_mean, _, true_logvar = self.q_posterior_mean_variance(x_start=x_start, x_t=x_t, t=t)
+        out = model(x_t, self._scale_timesteps(t), None, **(model_kwargs or {}))
+        mean, logvar, x0 = self._pmv_autograd(out, x_t, t, clip_denoised)
+        kl = mean_flat(normal_kl(true_mean, true_logvar, mean, logvar)) / np.log(2.0)
+        nll = -discretized_gaussian_log_likelihood(x_start, means=mean, log_scales=0.5 * logvar)
+        assert nll.shape == x_start.shape
+        nll = mean_flat(nll) / np.log(2.0)
+        return {"output": th.where(t == 0, nll, kl), "pred_xstart": x0}
+
     def training_losses(self, model, x_start, x_cond, t, model_kwargs=None, noise=None):
-        if self.loss_type.is_vb() or self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
-            raise NotImplementedError("variational-bound losses / learned variances are not built")
         if noise is None:
             noise = th.randn_like(x_start)
         x_t = self.q_sample(x_start, t, noise=noise)
+        terms = {}
+        if self.loss_type.is_vb():                                    # KL / RESCALED_KL (:715-726)
+            terms["loss"] = self._vb_terms_bpd(model, x_start, x_t, t, clip_denoised=False, model_kwargs=model_kwargs)["output"]
+            if self.loss_type == LossType.RESCALED_KL:
+                terms["loss"] = terms["loss"] * self.num_timesteps
+            return terms
         # `model` may be the bare UNetModel, a DDP / DataParallel wrapper around it (train_util.py:236 passes ddp_model) or any
         # callable: it is simply called.  UNetModel.forward itself picks its differentiable path when gradients are enabled
         out = model(x_t, self._scale_timesteps(t), x_cond, **(model_kwargs or {}))
+        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
+            # hybrid loss (:730-748): the variance learns from the variational bound with the mean prediction frozen
+            B, Cc = x_t.shape[:2]
+            assert out.shape == (B, Cc * 2, *x_t.shape[2:])
+            out, var_values = th.split(out, Cc, dim=1)
+            frozen = th.cat([out.detach(), var_values], dim=1)
+            terms["vb"] = self._vb_terms_bpd(lambda *a, r=frozen, **k: r, x_start, x_t, t, clip_denoised=False)["output"]
+            if self.loss_type == LossType.RESCALED_MSE:
+                terms["vb"] = terms["vb"] * (self.num_timesteps / 1000.0)
         target = {ModelMeanType.PREVIOUS_X: self.q_posterior_mean_variance(x_start=x_start, x_t=x_t, t=t)[0],
                   ModelMeanType.START_X: x_start, ModelMeanType.EPSILON: noise}[self.model_mean_type]
         assert out.shape == target.shape == x_start.shape
-        mse = mean_flat((target - out) ** 2)
-        return {"mse": mse, "loss": mse}
+        terms["mse"] = mean_flat((target - out) ** 2)
+        terms["loss"] = terms["mse"] + terms["vb"] if "vb" in terms else terms["mse"]
+        return terms

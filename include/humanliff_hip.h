@@ -344,12 +344,14 @@ int hl_unet_dispatch_census(void *handle, int64_t *h_counts);
 /* Fused sampler update (everything after the model call in p_sample / ddim_sample,
  * gaussian_diffusion.py:293-333, 356-388, 484-529) for EPSILON prediction with a fixed
  * variance.  coef: (T, 8) fp32 per-kept-timestep table built by the host mirror from the
- * float64 schedule: [sqrt_recip_acp, sqrt_recipm1_acp, c0, c1, c2, 0, 0, 0] where
+ * float64 schedule: [sqrt_recip_acp, sqrt_recipm1_acp, c0, c1, c2, 1/coef1, coef2/coef1, 0] (coef1/2 = posterior_mean_coef1/2) where
  *   mode 0 (p_sample):  x0 = clip(r*x - rm1*eps); sample = (c0*x0 + c1*x) + (t!=0) * c2 * noise
  *   mode 1 (ddim):      x0 = clip(r*x - rm1*eps); e = (r*x - x0)/rm1;
  *                       sample = (x0*c0 + c1*e) + (t!=0) * c2 * noise
  *   mode 2 / 3:         as 0 / 1 with `eps` holding the already processed pred_xstart (the caller applied denoised_fn and the
  *                       clamp, gaussian_diffusion.py:293-299); `clip` is ignored
+ *   mode 4 / 5:         x_{t-1} prediction (ModelMeanType.PREVIOUS_X, :300-304, 335-343): `eps` holds the model's x_{t-1}; x0 = clip(eps/coef1 -
+ *                       coef2/coef1 * x); mode 4: sample = eps + noise term (the prediction is the mean); mode 5: the ddim update from x0
  *   log_variance:       NULL = fixed variance (c2 of the table); else the per-element model_log_variance of a learned-variance model
  *                       (gaussian_diffusion.py:262-276), same shape as x: the noise term of mode 0 / 2 becomes (t!=0)*exp(lv/2)*noise
  * t: (B) int64 indices into the table of T rows (a t outside [0, T) reads nothing out of bounds and turns that

@@ -42,7 +42,9 @@ def main():
         for tag, mean_t, var_t, two in [("range", gd.ModelMeanType.EPSILON, gd.ModelVarType.LEARNED_RANGE, True),
                                         ("learned", gd.ModelMeanType.EPSILON, gd.ModelVarType.LEARNED, True),
                                         ("x0", gd.ModelMeanType.START_X, gd.ModelVarType.FIXED_LARGE, False),
-                                        ("x0range", gd.ModelMeanType.START_X, gd.ModelVarType.LEARNED_RANGE, True)]:
+                                        ("x0range", gd.ModelMeanType.START_X, gd.ModelVarType.LEARNED_RANGE, True),
+                                        ("xprev", gd.ModelMeanType.PREVIOUS_X, gd.ModelVarType.FIXED_SMALL, False),
+                                        ("xprevrange", gd.ModelMeanType.PREVIOUS_X, gd.ModelVarType.LEARNED_RANGE, True)]:
             d = SpacedDiffusion(use_timesteps=space_timesteps(1000, "ddim50"), betas=betas, model_mean_type=mean_t, model_var_type=var_t,
                                 loss_type=gd.LossType.MSE, rescale_timesteps=False)
             t = torch.tensor([49, 0, 17])
@@ -62,6 +64,29 @@ def main():
             out[f"{tag}_t"] = t.numpy()
     finally:
         torch.randn_like = orig
+    # ---- training_losses of every LossType / mean type / variance type (:688-772), with the gradient with respect to a scalar the stub
+    # model multiplies its conditioning by (the variational-bound terms must be differentiable through mean and log-variance)
+    x0 = (torch.randn((3, 27, 8, 8), generator=g) * 0.6).clamp(-1, 1)
+    x0[0, :, :2] = -1.0                                      # (the decoder likelihood's open-ended border bins)
+    x0[1, :, :2] = 1.0
+    tl = torch.tensor([0, 49, 17])
+    for tag, loss_t, mean_t, var_t, two in [("kl", gd.LossType.KL, gd.ModelMeanType.EPSILON, gd.ModelVarType.LEARNED_RANGE, True),
+                                            ("rkl", gd.LossType.RESCALED_KL, gd.ModelMeanType.START_X, gd.ModelVarType.FIXED_LARGE, False),
+                                            ("hyb", gd.LossType.MSE, gd.ModelMeanType.EPSILON, gd.ModelVarType.LEARNED_RANGE, True),
+                                            ("rhyb", gd.LossType.RESCALED_MSE, gd.ModelMeanType.EPSILON, gd.ModelVarType.LEARNED, True),
+                                            ("msexp", gd.LossType.MSE, gd.ModelMeanType.PREVIOUS_X, gd.ModelVarType.FIXED_SMALL, False),
+                                            ("klxp", gd.LossType.KL, gd.ModelMeanType.PREVIOUS_X, gd.ModelVarType.LEARNED, True)]:
+        d = SpacedDiffusion(use_timesteps=space_timesteps(1000, "ddim50"), betas=betas, model_mean_type=mean_t, model_var_type=var_t,
+                            loss_type=loss_t, rescale_timesteps=False)
+        p = torch.tensor(0.8, requires_grad=True)
+        model = lambda a, b, c, **k: stub(a, b, (xc if c is None else c) * p, two=two)  # noqa: E731   (the KL losses call the model without x_cond)
+        terms = d.training_losses(model, x0, xc, tl, noise=noise)
+        terms["loss"].sum().backward()
+        for k, v in terms.items():
+            out[f"loss_{tag}_{k}"] = v.detach().numpy()
+        out[f"loss_{tag}_dp"] = p.grad.numpy()
+    out["loss_x0"] = x0.numpy()
+    out["loss_t"] = tl.numpy()
     np.savez_compressed(os.path.join(HERE, "diffusion_variants.npz"), **out)
     print("ok", len(out), "arrays", os.path.getsize(os.path.join(HERE, "diffusion_variants.npz")) // 1024, "KiB")
 

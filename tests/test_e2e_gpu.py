@@ -276,11 +276,13 @@ def _variant_stub(x, t, x_cond, two=False):
 
 
 @pytest.mark.parametrize("tag,mean_t,var_t,two", [("range", "EPSILON", "LEARNED_RANGE", True), ("learned", "EPSILON", "LEARNED", True),
-                                                  ("x0", "START_X", "FIXED_LARGE", False), ("x0range", "START_X", "LEARNED_RANGE", True)])
+                                                  ("x0", "START_X", "FIXED_LARGE", False), ("x0range", "START_X", "LEARNED_RANGE", True),
+                                                  ("xprev", "PREVIOUS_X", "FIXED_SMALL", False), ("xprevrange", "PREVIOUS_X", "LEARNED_RANGE", True)])
 @pytest.mark.parametrize("clip", [True, False])
 def test_sampler_variants_match_reference(tag, mean_t, var_t, two, clip):
-    """Learned variances (learn_sigma=True), START_X prediction and denoised_fn: the fused update (x0-given modes, per-element
-    log-variance) against the reference's p_sample / ddim_sample / p_mean_variance (tests/golden/gen_golden_variants.py)."""
+    """Learned variances (learn_sigma=True), START_X and x_{t-1} (PREVIOUS_X) prediction and denoised_fn: the fused update (x0-given /
+    xprev-given modes, per-element log-variance) against the reference's p_sample / ddim_sample / p_mean_variance
+    (tests/golden/gen_golden_variants.py)."""
     from humanliff_amd.improved_diffusion import gaussian_diffusion as gd
     from humanliff_amd.improved_diffusion.respace import SpacedDiffusion, space_timesteps
     g = np.load(os.path.join(GOLDEN, "diffusion_variants.npz"))
