@@ -40,7 +40,8 @@ class UNetCfg(C.Structure):
     _fields_ = [("in_channels", C.c_int), ("model_channels", C.c_int), ("out_channels", C.c_int),
                 ("num_res_blocks", C.c_int), ("n_levels", C.c_int), ("channel_mult", C.c_int * 8),
                 ("n_attention_ds", C.c_int), ("attention_ds", C.c_int * 8), ("num_heads", C.c_int),
-                ("num_heads_upsample", C.c_int), ("num_classes", C.c_int), ("controlnet", C.c_int), ("adagn", C.c_int), ("cross_attn", C.c_int), ("aware3d", C.c_int)]
+                ("num_heads_upsample", C.c_int), ("num_classes", C.c_int), ("controlnet", C.c_int), ("adagn", C.c_int), ("cross_attn", C.c_int), ("aware3d", C.c_int),
+                ("no_scale_shift", C.c_int)]
 
 
 _lib = None

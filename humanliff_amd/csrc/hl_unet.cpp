@@ -213,8 +213,9 @@ int add_res(Net &n, std::vector<EmbPiece> &emb, const std::string &p, int Cin, i
     r.n1 = make_norm(n, p + ".in_layers.0", Cin);
     r.c1 = make_conv(n, p + ".in_layers.2", Cin, Cout, 3);
     r.emb_off = n.emb_total;
-    emb.push_back({p + ".emb_layers.1", 2 * Cout, n.emb_total});
-    n.emb_total += 2 * Cout;
+    const int emb_o = n.cfg.no_scale_shift ? Cout : 2 * Cout;      // unet.py:186-191
+    emb.push_back({p + ".emb_layers.1", emb_o, n.emb_total});
+    n.emb_total += emb_o;
     r.n2 = make_norm(n, p + ".out_layers.0", Cout);
     r.c2 = make_conv(n, p + ".out_layers.3", aware ? 3 * Cout : Cout, Cout, 3);
     r.has_skip = Cin != Cout;
@@ -532,8 +533,18 @@ struct Exec {
         float *a1, *b1, *a2, *b2;
         coef(x, r.n1, nullptr, a1, b1);
         View h = plain(H / dst.H, r.Cout);
-        conv(r.c1, x, h, 1, 0, a1, b1, 1, nullptr, 0);
-        coef(h, r.n2, run ? emb_all + r.emb_off : nullptr, a2, b2);
+        if (n.cfg.no_scale_shift) {
+            // use_scale_shift_norm=False (unet.py:216-218): h = h + emb_out[..., None, None]; h = out_layers(h).  The sum is materialised in
+            // place and its GroupNorm statistics come from a pass over the tensor (the producer's epilogue saw h without the embedding)
+            want_stats = false;
+            conv(r.c1, x, h, 1, 0, a1, b1, 1, nullptr, 0);
+            want_stats = true;
+            if (run) ok(hl::add_rowvec(h, emb_all + r.emb_off, st, n.emb_total));
+            coef(h, r.n2, nullptr, a2, b2);
+        } else {
+            conv(r.c1, x, h, 1, 0, a1, b1, 1, nullptr, 0);
+            coef(h, r.n2, run ? emb_all + r.emb_off : nullptr, a2, b2);
+        }
         if (r.aware) {
             // unet.py:208-214: every plane sees, next to its own normalised features, the other two planes averaged along the axis
             // it does not share with them; materialised (with the SiLU of out_layers) as a 3C-channel tensor for the convolution

@@ -135,7 +135,7 @@ int prep_inputs(const float *x, const float *x_cond, int B, int C, int H, int W,
 // (pixels, 2F) -> (pixels, F); x (N, HW, C) += v (N, C)
 int layernorm(const View &x, const float *gamma, const float *beta, float *y, hipStream_t st);
 int geglu(const float *in, long npix, int F, float *out, hipStream_t st);
-int add_rowvec(const View &x, const float *v, hipStream_t st);
+int add_rowvec(const View &x, const float *v, hipStream_t st, long vpitch = 0);   // x[n, p, c] += v[n * vpitch + c] (vpitch 0: C)
 // use_3d_aware=True (unet.py:566-570, 613-614): (B, 3C, H, W) NCHW <-> the planes side by side, NHWC (B, H, 3W, Cpad) / NCHW (B, C, H, 3W)
 int prep_inputs_3d(const float *x, const float *x_cond, int B, int C, int H, int W, int Cpad, float *x_nhwc, float *xsum_nhwc,
                    hipStream_t st);

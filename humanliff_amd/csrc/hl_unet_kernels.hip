@@ -2440,12 +2440,12 @@ __global__ void k_geglu(const float *__restrict__ in, long npix, int F, float *_
 }
 // x (N, HW, C pitch) += v (N, C): the cross-attention over ONE context token (softmax over a single key is 1: the output is the same
 // projected value vector at every query)
-__global__ void k_add_rowvec(float *__restrict__ x, long pitch, long HW, long npix, int C, const float *__restrict__ v) {
+__global__ void k_add_rowvec(float *__restrict__ x, long pitch, long HW, long npix, int C, const float *__restrict__ v, long vpitch) {
     const long n = npix * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const long pix = i / C;
         const int c = (int)(i - pix * C);
-        x[pix * pitch + c] += v[(pix / HW) * C + c];
+        x[pix * pitch + c] += v[(pix / HW) * vpitch + c];
     }
 }
 
@@ -3019,11 +3019,11 @@ int geglu(const float *in, long npix, int F, float *out, hipStream_t st) {
     return check_launch("k_geglu");
 }
 
-int add_rowvec(const View &x, const float *v, hipStream_t st) {
+int add_rowvec(const View &x, const float *v, hipStream_t st, long vpitch) {
     HL_REQUIRE(x.p && v, "add_rowvec: null argument");
     long g = ((long)x.pixels() * x.C + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_add_rowvec, dim3((unsigned)g), dim3(256), 0, st, x.p, x.pitch, (long)x.H * x.W, (long)x.pixels(), x.C, v);
+    hipLaunchKernelGGL(k_add_rowvec, dim3((unsigned)g), dim3(256), 0, st, x.p, x.pitch, (long)x.H * x.W, (long)x.pixels(), x.C, v, vpitch ? vpitch : (long)x.C);
     return check_launch("k_add_rowvec");
 }
 

@@ -4,7 +4,7 @@
 The torch modules declared here only own the parameters (so reference checkpoints load with
 load_state_dict and .to(device) works).  forward() hands the parameter pointers to the C ABI
 (hl_unet_create / hl_unet_forward); there is no PyTorch implementation of the math and no CPU path.
-Supported configuration: dims=2, use_scale_shift_norm=True, cond_type in {"controlnet", "AdaGN", "cross_attention", "concat", ""},
+Supported configuration: dims=2, use_scale_shift_norm True / False, cond_type in {"controlnet", "AdaGN", "cross_attention", "concat", ""},
 use_3d_aware False or True (sampling only; not with AdaGN / cross_attention).  Under no_grad / eval() forward() is the fused inference path; with gradients enabled on a model in training
 mode it is the differentiable path of unet_train.py (HIP forward and backward kernels behind autograd.Functions).
 """
@@ -45,13 +45,11 @@ class ResBlock(TimestepBlock):
     def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
                  use_3d_aware=False, dims=2, use_checkpoint=False):
         super().__init__()
-        if not use_scale_shift_norm:
-            raise NotImplementedError("only use_scale_shift_norm=True is built")
         oc = out_channels or channels
         self.channels, self.emb_channels, self.dropout, self.out_channels = channels, emb_channels, dropout, oc
-        self.use_3d_aware = use_3d_aware
+        self.use_3d_aware, self.use_scale_shift_norm = use_3d_aware, use_scale_shift_norm
         self.in_layers = nn.Sequential(normalization(channels), SiLU(), conv_nd(dims, channels, oc, 3, padding=1))
-        self.emb_layers = nn.Sequential(SiLU(), linear(emb_channels, 2 * oc))
+        self.emb_layers = nn.Sequential(SiLU(), linear(emb_channels, 2 * oc if use_scale_shift_norm else oc))      # unet.py:186-191
         # use_3d_aware (unet.py:158-166): the conv reads cat[h, two plane means of h] = 3*oc channels
         self.out_layers = nn.Sequential(normalization(oc), SiLU(), nn.Dropout(p=dropout),
                                         zero_module(conv_nd(dims, 3 * oc if use_3d_aware else oc, oc, 3, padding=1)))
@@ -127,13 +125,13 @@ def _attn_layer(ch, heads, xf_ctx):
     return SpatialTransformer(ch, heads, ch // heads, context_dim=xf_ctx) if xf_ctx else AttentionBlock(ch, num_heads=heads)
 
 
-def _encoder(in_channels, mc, channel_mult, num_res_blocks, attention_resolutions, emb_dim, dropout, dims, heads, aware=False, xf_ctx=None):
+def _encoder(in_channels, mc, channel_mult, num_res_blocks, attention_resolutions, emb_dim, dropout, dims, heads, aware=False, xf_ctx=None, ssn=True):
     """Block list of one encoder tower + its per-block channel counts (unet.py:375-415 / 477-518)."""
     blocks = [TimestepEmbedSequential(conv_nd(dims, in_channels, mc, 3, padding=1))]
     chans, ch, ds = [mc], mc, 1
     for level, mult in enumerate(channel_mult):
         for _ in range(num_res_blocks):
-            layers = [ResBlock(ch, emb_dim, dropout, out_channels=mult * mc, dims=dims, use_scale_shift_norm=True, use_3d_aware=aware)]
+            layers = [ResBlock(ch, emb_dim, dropout, out_channels=mult * mc, dims=dims, use_scale_shift_norm=ssn, use_3d_aware=aware)]
             ch = mult * mc
             if ds in attention_resolutions:
                 layers.append(_attn_layer(ch, heads, xf_ctx))
@@ -154,21 +152,20 @@ class UNetModel(nn.Module):
         super().__init__()
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
-        if dims != 2 or not conv_resample or not use_scale_shift_norm or cond_type not in ("controlnet", "", "concat", "AdaGN", "cross_attention") or \
+        if dims != 2 or not conv_resample or cond_type not in ("controlnet", "", "concat", "AdaGN", "cross_attention") or \
                 (use_3d_aware and cond_type in ("AdaGN", "cross_attention")):
             raise NotImplementedError(
-                "the MI355X build covers dims=2, conv_resample=True, use_scale_shift_norm=True, cond_type in {'controlnet', '', 'concat', "
+                "the MI355X build covers dims=2, conv_resample=True, cond_type in {'controlnet', '', 'concat', "
                 "'AdaGN', 'cross_attention'}, use_3d_aware with 'controlnet' / '' / 'concat' (the shipped HumanLiff configuration is controlnet, "
                 "use_3d_aware=False)")
-        if dropout != 0:
-            raise NotImplementedError("dropout > 0 is a training feature; inference build only")
+        # dropout (unet.py:196: nn.Dropout in out_layers) acts in the training path only (unet_train.py); sampling is eval-mode = identity
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
         self.num_res_blocks = num_res_blocks
         self.attention_resolutions = tuple(attention_resolutions)
         self.dropout, self.channel_mult, self.conv_resample = dropout, tuple(channel_mult), conv_resample
         self.num_classes, self.use_checkpoint = num_classes, use_checkpoint
         self.num_heads, self.num_heads_upsample = num_heads, num_heads_upsample
-        self.cond_type, self.use_3d_aware = cond_type, use_3d_aware
+        self.cond_type, self.use_3d_aware, self.use_scale_shift_norm = cond_type, use_3d_aware, use_scale_shift_norm
 
         emb_dim = model_channels * 4
         self.time_embed = nn.Sequential(linear(model_channels, emb_dim), SiLU(), linear(emb_dim, emb_dim))
@@ -178,18 +175,18 @@ class UNetModel(nn.Module):
         if transformer_depth != 1:
             raise NotImplementedError("transformer_depth != 1")
         enc, chans, ch, ds = _encoder(in_channels, model_channels, self.channel_mult, num_res_blocks,
-                                      self.attention_resolutions, emb_dim, dropout, dims, num_heads, aware=use_3d_aware, xf_ctx=xf_ctx)
+                                      self.attention_resolutions, emb_dim, dropout, dims, num_heads, aware=use_3d_aware, xf_ctx=xf_ctx, ssn=use_scale_shift_norm)
         self.input_blocks = nn.ModuleList(enc)
         self.middle_block = TimestepEmbedSequential(
-            ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=True, use_3d_aware=use_3d_aware),
+            ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=use_scale_shift_norm, use_3d_aware=use_3d_aware),
             _attn_layer(ch, num_heads, xf_ctx),
-            ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=True, use_3d_aware=use_3d_aware))
+            ResBlock(ch, emb_dim, dropout, dims=dims, use_scale_shift_norm=use_scale_shift_norm, use_3d_aware=use_3d_aware))
         self.output_blocks = nn.ModuleList([])
         stack = list(chans)
         for level, mult in list(enumerate(self.channel_mult))[::-1]:
             for i in range(num_res_blocks + 1):
                 layers = [ResBlock(ch + stack.pop(), emb_dim, dropout, out_channels=model_channels * mult, dims=dims,
-                                   use_scale_shift_norm=True, use_3d_aware=use_3d_aware)]
+                                   use_scale_shift_norm=use_scale_shift_norm, use_3d_aware=use_3d_aware)]
                 ch = model_channels * mult
                 if ds in self.attention_resolutions:
                     layers.append(_attn_layer(ch, num_heads, xf_ctx) if xf_ctx else AttentionBlock(ch, num_heads=num_heads_upsample))
@@ -201,7 +198,7 @@ class UNetModel(nn.Module):
                                  zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
         if cond_type == "controlnet":
             cenc, cchans, _, _ = _encoder(in_channels, model_channels, self.channel_mult, num_res_blocks,
-                                          self.attention_resolutions, emb_dim, dropout, dims, num_heads)
+                                          self.attention_resolutions, emb_dim, dropout, dims, num_heads, ssn=use_scale_shift_norm)
             self.input_blocks_cond = nn.ModuleList(cenc)
             self.input_blocks_proj_cond = nn.ModuleList(
                 [zero_module(conv_nd(dims, c, c, 1, padding=0)) for c in cchans])
@@ -239,6 +236,7 @@ class UNetModel(nn.Module):
         c.num_classes = self.num_classes or 0
         c.controlnet = 1 if self.cond_type == "controlnet" else 0
         c.adagn = 1 if self.cond_type == "AdaGN" else 0
+        c.no_scale_shift = 0 if self.use_scale_shift_norm else 1
         c.cross_attn = 1 if self.cond_type == "cross_attention" else 0
         c.aware3d = 1 if self.use_3d_aware else 0
         return c

@@ -36,15 +36,19 @@ def _norm(m, x):
 
 def _res_block(m, x, emb):
     h = m.in_layers[2](_silu(_norm(m.in_layers[0], x)))
-    scale, shift = m.emb_layers[1](_silu(emb)).chunk(2, dim=1)
-    h = _norm(m.out_layers[0], h) * (1 + scale[:, :, None, None]) + shift[:, :, None, None]
+    e = m.emb_layers[1](_silu(emb))
+    if getattr(m, "use_scale_shift_norm", True):
+        scale, shift = e.chunk(2, dim=1)
+        h = _norm(m.out_layers[0], h) * (1 + scale[:, :, None, None]) + shift[:, :, None, None]
+    else:
+        h = _norm(m.out_layers[0], h + e[:, :, None, None])
     if getattr(m, "use_3d_aware", False):    # unet.py:208-214: each plane + the other two averaged along the axis it does not share
         w3 = h.shape[-1] // 3
         p0, p1, p2 = h[..., :w3], h[..., w3:2 * w3], h[..., 2 * w3:]
         row = lambda p: p.mean(-1, keepdim=True).expand(-1, -1, -1, w3)          # noqa: E731
         col = lambda p: p.mean(-2, keepdim=True).expand(-1, -1, p.shape[-2], -1)  # noqa: E731
         h = th.cat([th.cat([p0, row(p1), col(p2)], 1), th.cat([p1, row(p0), row(p2)], 1), th.cat([p2, col(p0), col(p1)], 1)], -1)
-    h = m.out_layers[3](_silu(h))
+    h = m.out_layers[3](m.out_layers[2](_silu(h)))                             # (out_layers[2]: nn.Dropout)
     return m.skip_connection(x) + h
 
 

@@ -230,7 +230,13 @@ def _silu(x):
 def _res_block(m, x, emb):
     h = conv(gn_act(x, m.in_layers[0]), m.in_layers[2])
     ss = m.emb_layers[1](_silu(emb))                                        # (N, 2*Cout): [scale | shift] (unet.py:203-206)
-    h = conv(gn_act(h, m.out_layers[0], ss), m.out_layers[3])
+    if getattr(m, "use_scale_shift_norm", True):
+        h = gn_act(h, m.out_layers[0], ss)
+    else:                                                                   # (N, Cout) added before the GroupNorm (unet.py:216-218)
+        h = gn_act(h + ss[:, None, None, :], m.out_layers[0], None)
+    if m.dropout > 0:                                                       # out_layers[2] = nn.Dropout (unet.py:196): identity in eval mode
+        h = F.dropout(h, p=m.dropout, training=m.training)
+    h = conv(h, m.out_layers[3])
     skip = x if isinstance(m.skip_connection, th.nn.Identity) else conv(x, m.skip_connection)
     return skip + h
 

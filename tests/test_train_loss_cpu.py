@@ -12,10 +12,10 @@ from humanliff_amd import synthetic as syn
 from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
 
 
-def tiny_model():
+def tiny_model(use_scale_shift_norm=True, dropout=0.0):
     a = model_and_diffusion_defaults()
-    a.update(dict(in_channels=27, out_channels=27, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=True,
-                  cond_type="controlnet", rescale_timesteps=False, dropout=0.0, diffusion_steps=1000, noise_schedule="linear",
+    a.update(dict(in_channels=27, out_channels=27, class_cond=True, learn_sigma=False, num_heads=4, use_scale_shift_norm=use_scale_shift_norm,
+                  cond_type="controlnet", rescale_timesteps=False, dropout=dropout, diffusion_steps=1000, noise_schedule="linear",
                   timestep_respacing="", image_size=32, num_channels=32, num_res_blocks=1, attention_resolutions="16,8"))
     model, diffusion = create_model_and_diffusion(**a)
     ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
@@ -42,6 +42,30 @@ def test_training_losses_and_gradients_match_reference():
     losses["loss"].mean().backward()
     sd = dict(model.named_parameters())
     assert all(p.grad is not None for p in sd.values())
+    tot = sum(float(p.grad.double().abs().sum()) for p in sd.values())
+    assert abs(tot - float(g["grad_abs_sum"])) < 1e-4 * float(g["grad_abs_sum"])
+    for k in g["keys"]:
+        ref = torch.from_numpy(g["g_" + str(k)])
+        assert (sd[str(k)].grad - ref).abs().max() < 1e-6 + 1e-4 * ref.abs().max(), k
+
+
+def test_no_scale_shift_norm_twin_and_oracle_match_reference():
+    """use_scale_shift_norm=False (unet.py:186-191, 216-218; tests/golden/gen_golden_noss.py): the oracle's forward and the twin's
+    training_losses + gradients against the reference's."""
+    from oracle import unet_oracle as uo
+    g = np.load(os.path.join(GOLDEN, "unet_noss.npz"))
+    model, diffusion = tiny_model(use_scale_shift_norm=False)
+    assert len(model.state_dict()) == int(g["nkeys"]) and model.input_blocks[1][0].emb_layers[1].weight.shape[0] == 32
+    x0, xc = inputs()
+    t, y = torch.tensor([999, 17]), torch.tensor([3, 0])
+    with torch.no_grad():
+        want = uo.unet_forward({k: v for k, v in model.state_dict().items()}, x0, t, xc, y, num_heads=4)
+    assert (want - torch.from_numpy(g["out"])).abs().max() < 2e-5
+    model.train()
+    losses = diffusion.training_losses(model.forward_autograd, x0.clamp(-1, 1), xc, t, model_kwargs={"y": y}, noise=torch.from_numpy(g["noise"]))
+    assert np.abs(losses["loss"].detach().numpy() - g["loss"]).max() < 1e-5
+    losses["loss"].mean().backward()
+    sd = dict(model.named_parameters())
     tot = sum(float(p.grad.double().abs().sum()) for p in sd.values())
     assert abs(tot - float(g["grad_abs_sum"])) < 1e-4 * float(g["grad_abs_sum"])
     for k in g["keys"]:

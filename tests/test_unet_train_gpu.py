@@ -514,3 +514,49 @@ def test_training_under_autocast_and_in_bf16_arithmetic_tracks_fp32():
     print("loss curves fp32 / bf16:", [round(v, 4) for v in l32[::4]], [round(v, 4) for v in l16[::4]])
     worst = max(abs(a - b) / abs(b) for a, b in zip(l16, l32))
     assert worst < 0.05, worst
+
+
+def test_no_scale_shift_norm_and_dropout_on_hip():
+    """use_scale_shift_norm=False (the embedding is added before out_layers' GroupNorm, unet.py:216-218) on the HIP inference AND training
+    paths against the reference's forward, loss and gradients (tests/golden/gen_golden_noss.py); dropout > 0 (unet.py:196) acts in the
+    training path only."""
+    from tests.test_train_loss_cpu import inputs, tiny_model
+    from humanliff_amd.improved_diffusion import unet_autograd
+    g = np.load(os.path.join(GOLDEN, "unet_noss.npz"))
+    model, diffusion = tiny_model(use_scale_shift_norm=False)
+    model = model.to(dev).eval()
+    x0, xc = (t.to(dev) for t in inputs())
+    t, y = torch.tensor([999, 17], device=dev), torch.tensor([3, 0], device=dev)
+    with torch.no_grad():
+        out = model(x0, t, xc, y=y).cpu()
+    assert (out - torch.from_numpy(g["out"])).abs().max() < 2e-5
+    model.train()
+
+    def boom(*a, **k):
+        raise AssertionError("the PyTorch-op twin must not run on the GPU training path")
+    orig = unet_autograd.forward_autograd
+    unet_autograd.forward_autograd = boom
+    try:
+        losses = diffusion.training_losses(model, x0.clamp(-1, 1), xc, t, model_kwargs={"y": y}, noise=torch.from_numpy(g["noise"]).to(dev))
+        assert np.abs(losses["loss"].detach().cpu().numpy() - g["loss"]).max() < 1e-5
+        losses["loss"].mean().backward()
+    finally:
+        unet_autograd.forward_autograd = orig
+    sd = dict(model.named_parameters())
+    tot = sum(float(p.grad.double().abs().sum()) for p in sd.values())
+    assert abs(tot - float(g["grad_abs_sum"])) < 2e-4 * float(g["grad_abs_sum"])
+    for k in g["keys"]:
+        ref = torch.from_numpy(g["g_" + str(k)])
+        assert float((sd[str(k)].grad.cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max()) + 1e-8, str(k)     # (floor: some gradients of this net are ~1e-10)
+    # dropout: eval-mode sampling ignores it; the training path draws a new mask per call
+    md, _ = tiny_model(dropout=0.5)
+    md = md.to(dev)
+    m0, _ = tiny_model(dropout=0.0)
+    m0 = m0.to(dev).eval()
+    with torch.no_grad():
+        assert torch.equal(md.eval()(x0, t, xc, y=y), m0(x0, t, xc, y=y))
+    md.train()
+    torch.manual_seed(0)
+    a = md(x0.requires_grad_(False), t, xc, y=y)
+    b = md(x0, t, xc, y=y)
+    assert a.requires_grad and not torch.equal(a, b)
