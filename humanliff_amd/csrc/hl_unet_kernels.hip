@@ -1227,7 +1227,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
     const int fbase = (3 * (wave >> 1)) * 6 + 3 * (wave & 1);
     const int mloc = tid >> 4, np2 = (tid & 15) * 2, n = n0 + np2;
     f32x2 bs = {0.f, 0.f};
-    if (p.bias && !p.partial) bs = *reinterpret_cast<const f32x2 *>(p.bias + n);
+    if (p.bias && !p.partial) {   // (ragged Cout - only the NCHW output convolution: channels past Cout are computed from zero weights and not stored)
+        if (n + 1 < p.Cout) bs = *reinterpret_cast<const f32x2 *>(p.bias + n);
+        else if (n < p.Cout) bs[0] = p.bias[n];
+    }
     const long hw = (long)Hv * Wv;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1300,7 +1303,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino4(const ConvK p) {
         if (p.out_nchw) {
             float *op = p.out + ((long)img * p.Cout + n) * hw + (m0 - (long)img * hw);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { op[(k >> 2) * Wv + (k & 3)] = v[k][0]; op[hw + (k >> 2) * Wv + (k & 3)] = v[k][1]; }
+            for (int k = 0; k < 16; ++k) {
+                if (n < p.Cout) op[(k >> 2) * Wv + (k & 3)] = v[k][0];
+                if (n + 1 < p.Cout) op[hw + (k >> 2) * Wv + (k & 3)] = v[k][1];
+            }
         } else {
             float *op = p.out + m0 * p.out_pitch + n;
 #pragma unroll
@@ -1324,7 +1330,7 @@ __global__ __launch_bounds__(256) void k_pack_conv_wino4(const float *__restrict
     const double G[6][3] = {{1 / n0, 0, 0}, {1 / na, a / na, a * a / na}, {1 / na, -a / na, a * a / na},
                             {1 / nb_, b / nb_, b * b / nb_}, {1 / nb_, -b / nb_, b * b / nb_}, {0, 0, 1}};
     const int t = threadIdx.x, s = t & 3, nn = (t >> 2) & 31, hf = t >> 7;
-    const long nblk = (long)(Cout >> 5) * nkt;
+    const long nblk = (long)((Cout + 31) >> 5) * nkt;          // (output channels past Cout: zero rows)
     for (long bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
         const int kt = (int)(bi % nkt), nb = (int)(bi / nkt);
         const int co = nb * 32 + nn, ci = kt * 8 + hf * 4 + s;
@@ -2565,13 +2571,13 @@ int conv_pack_weights_wino(const float *w, int Cout, int Cin, int Cin_pad, float
     return check_launch("k_pack_conv_wino");
 }
 
-size_t conv_packed_wino4_bytes(int Cout, int Cin_pad, int ks) {
-    return (ks == 3 && Cout % 32 == 0 && Cin_pad % 8 == 0) ? (size_t)Cout * Cin_pad * 36 * sizeof(float) : 0;
+size_t conv_packed_wino4_bytes(int Cout, int Cin_pad, int ks) {   // (a ragged Cout - the 27-channel output convolution - is padded with zero rows to 32)
+    return (ks == 3 && (Cout % 32 == 0 || Cout < 32) && Cin_pad % 8 == 0) ? (size_t)round_up(Cout, 32) * Cin_pad * 36 * sizeof(float) : 0;
 }
 
 int conv_pack_weights_wino4(const float *w, int Cout, int Cin, int Cin_pad, float *packed, hipStream_t st, int tf) {
-    HL_REQUIRE(w && packed && Cout % 32 == 0 && Cin_pad % 8 == 0 && Cin <= Cin_pad, "conv_pack_weights_wino4: bad argument");
-    hipLaunchKernelGGL(k_pack_conv_wino4, dim3((unsigned)std::min<long>(8192, (long)(Cout >> 5) * (Cin_pad >> 3))), dim3(256), 0, st, w, Cout, Cin, Cin_pad, packed, tf);
+    HL_REQUIRE(w && packed && (Cout % 32 == 0 || Cout < 32) && Cin_pad % 8 == 0 && Cin <= Cin_pad, "conv_pack_weights_wino4: bad argument");
+    hipLaunchKernelGGL(k_pack_conv_wino4, dim3((unsigned)std::min<long>(8192, (long)(round_up(Cout, 32) >> 5) * (Cin_pad >> 3))), dim3(256), 0, st, w, Cout, Cin, Cin_pad, packed, tf);
     return check_launch("k_pack_conv_wino4");
 }
 
@@ -2697,9 +2703,12 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     // the same layers by Winograd F(4x4,3x3) (32x16-pixel x 32-channel workgroups, a quarter of the direct multiplies) where that
     // alone fills the chip
     constexpr long wino4_thr = 512;
-    const long wino4_blocks = (long)a.out.N * (a.out.H / 16) * (a.out.W / 32) * (a.Cout / 32);
-    const bool wino4_ok = dma && a.w_wino4 && !a.w_bf3 && a.ks == 3 && a.stride == 1 && a.out.H % 16 == 0 && a.out.W % 32 == 0 &&
-                          a.Cout % 32 == 0 && (long)a.Cout * a.in.C * 144 < (1L << 31);
+    // (the 27-channel NCHW output convolution takes the F(4x4) kernel too: its weights are padded to 32 rows, the epilogue stores 27)
+    const bool small_nchw = a.out_nchw && a.Cout < 32 && !a.res && !a.out2 && !a.stats && (a.coefA == nullptr || a.act_ws) &&
+                            (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31);
+    const long wino4_blocks = (long)a.out.N * (a.out.H / 16) * (a.out.W / 32) * ((a.Cout + 31) / 32);
+    const bool wino4_ok = (dma || small_nchw) && a.w_wino4 && !a.w_bf3 && a.ks == 3 && a.stride == 1 && a.out.H % 16 == 0 && a.out.W % 32 == 0 &&
+                          (a.Cout % 32 == 0 || small_nchw) && (long)round_up(a.Cout, 32) * a.in.C * 144 < (1L << 31);
     bool wino4 = wino4_ok && wino4_blocks >= wino4_thr;
     // k_conv_wino4w: the same arithmetic with 64 output channels per workgroup at ONE workgroup per CU (hl_conv_wino4w.hip).  With W
     // = 32x16-pixel x 64-channel workgroups it is taken
@@ -2738,7 +2747,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
                      (long)a.out.N * (a.out.H / 16) * (a.out.W / 16) * (a.Cout / 192) >= h16_min_blocks() &&   // (fewer workgroups: the split-K fp32 kernels fill the chip better)
                      (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0;
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
-        a.path = h16 ? 5 : ((dma && wino4) ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
+        a.path = h16 ? 5 : (wino4 ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
         return HL_OK;
     }
     if (h16) {
@@ -2764,7 +2773,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         return conv_h16_launch(p, a.h16_fp16, st);
     }
     bool blk4 = false;
-    if (dma) {
+    if (dma || wino4) {
         HL_REQUIRE(mode == 0 || !a.ups, "conv2d: upsample with a GroupNorm prologue is not used by the UNet");
         if (mode != 0) {   // materialise GroupNorm(+SiLU) once, then the DMA kernels read it raw
             HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
@@ -2805,7 +2814,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         if (wino4) {
             a.path = 3;
             p.w_wino = a.w_wino4;
-            p.n_nblocks = a.Cout / 32;
+            p.n_nblocks = (a.Cout + 31) / 32;
             p.n_mtiles = a.out.N * (a.out.H / 16) * (a.out.W / 32);
             const dim3 nblk((unsigned)(p.n_mtiles * p.n_nblocks), 1, splits);
             const size_t sh4 = (size_t)(36 * 256 + 2 * 1296 * 4) * sizeof(float);   // 76.5 KB: two workgroups per CU

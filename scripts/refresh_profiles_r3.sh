@@ -27,3 +27,14 @@ python scripts/wino4w_probe.py 10 > $O/wino4w_probe.txt 2>&1
 python scripts/bf16_probe.py > $O/bf16_probe.txt 2>&1
 rm -rf $O/ks0 $O/ks1
 ls $O
+# late round 3: the 16-bit kernels (probe, SQ counters), the fp16-operand inference mode and the training step in fp32 / bf16
+python scripts/h16_probe.py 2>&1 | grep -v amdgpu.ids > $O/h16_probe.txt
+bash scripts/pmc_h16.sh 2>&1 | grep "^[abc] waves" > $O/pmc_h16.txt
+rocprofv3 --kernel-trace --stats -d $O/f16t -- python scripts/fp16_mode_trace.py > /dev/null 2>&1
+python scripts/rocpd_summary.py $(ls $O/f16t/*/*results.db | head -1) $O/trace_fp16_mode.md > /dev/null; rm -rf $O/f16t
+for a in fp32 bf16 fp16; do HL_TRAIN_ARITH=$a python scripts/unet_train_bench.py 5 2 2>&1 | grep "UNet training"; done > $O/unet_train_wall.txt
+HL_TRAIN_ARITH=fp32 rocprofv3 --kernel-trace --stats -d $O/trf -- python scripts/unet_train_bench.py 2 2 > /dev/null 2>&1
+python scripts/rocpd_summary.py $(ls $O/trf/*/*results.db | head -1) $O/trace_unet_train_fp32.md > /dev/null; rm -rf $O/trf
+HL_TRAIN_ARITH=bf16 rocprofv3 --kernel-trace --stats -d $O/trb -- python scripts/unet_train_bench.py 2 2 > /dev/null 2>&1
+python scripts/rocpd_summary.py $(ls $O/trb/*/*results.db | head -1) $O/trace_unet_train_bf16.md > /dev/null; rm -rf $O/trb
+ls $O
