@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
     for (int j = 0; j < NUT; ++j) {
         const int u = tid + 256 * j, pix = u >> 2, grp = u & 3;
         const int py = pix / H16_PW, px = pix - py * H16_PW;
-        const int y = y0 - 1 + py, x = x0 - 1 + px;
-        const bool ok = u < NU && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
-        sv[j] = ok ? (unsigned)((img * p.Hin + y) * p.Win + x) * pitch4 + grp * 32 : OOB;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;                 // (p.ups: coordinates in the nearest-x2 image, unet.py:77 - source pixel (y >> 1, x >> 1))
+        const bool ok = u < NU && y >= 0 && y < p.Hout && x >= 0 && x < p.Wout;
+        const int ys = p.ups ? y >> 1 : y, xs = p.ups ? x >> 1 : x;
+        sv[j] = ok ? (unsigned)((img * p.Hin + ys) * p.Win + xs) * pitch4 + grp * 32 : OOB;
         sl[j] = u < NU ? (unsigned)((py * H16_LP + px) * 64 + ((grp ^ ((px >> 2) & 3)) << 4)) : (unsigned)(2 * H16_STAGE + (tid & 63) * 16);   // (no unit: a dump slot behind the stages)
     }
     u32x4 ar[NUT][2];
@@ -290,7 +291,8 @@ __global__ void k_pack_conv_h16(const float *__restrict__ w, int Cout, int Cin, 
 }  // namespace
 
 bool conv_h16_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int ups) {
-    return ks == 3 && stride == 1 && !ups && Hout % 16 == 0 && Wout % 16 == 0 && Cin % 32 == 0 && Cout % 192 == 0 &&
+    (void)ups;   // the nearest-x2 upsample in front of the convolution is a source-address shift of the patch loads
+    return ks == 3 && stride == 1 && Hout % 16 == 0 && Wout % 16 == 0 && Cin % 32 == 0 && Cout % 192 == 0 &&
            (long)Cout * Cin * 18 < (1L << 31);
 }
 

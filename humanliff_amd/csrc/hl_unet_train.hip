@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_t(const WgradT p) {
     }
 }
 
-// k_conv_wgrad_h16: k_conv_wgrad_t (stride 1, no upsample) with 16-bit operands and fp32 accumulation on v_mfma_f32_32x32x16_{f16,bf16} -
+// k_conv_wgrad_h16: k_conv_wgrad_t (stride 1, with or without the nearest-x2 upsample) with 16-bit operands and fp32 accumulation on v_mfma_f32_32x32x16_{f16,bf16} -
 // the arithmetic of the 16-bit training modes (HL_CONV_FP16 / HL_CONV_BF16).  Same work split, same partial buffer and finish kernel.
 // The contraction runs over PIXELS, and a 16-bit MFMA fragment wants 8 consecutive k values per lane, so both operands sit in LDS
 // pixel-contiguous, [channel][pixel]: the transposition happens in registers while staging (a thread fetches a few pixels x 4 channels
@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_h16(const WgradT p) {
         __builtin_amdgcn_make_buffer_rsrc((void *)p.dy, (short)0, (int)((long)p.N * p.Hout * p.Wout * p.dy_pitch * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX =
         __builtin_amdgcn_make_buffer_rsrc((void *)p.x, (short)0, (int)((long)p.N * p.Hin * p.Win * p.x_pitch * 4), 0x00020000);
+    const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
     const int c4 = tid & 15;
     const int ar = (tid >> 4) & 7, ah = tid >> 7;              // dY: tile row, half row (4 pixels) of this thread
     const int br = tid >> 4;                                   // patch: row of this thread (threads 0..159)
@@ -352,9 +353,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_h16(const WgradT p) {
         if (tid < 160) {
 #pragma unroll
             for (int c = 0; c < 10; ++c) {
-                const int yi = oy0 + br - 1, xi = ox0 + c - 1;
-                const bool v = b_ok && yi >= 0 && yi < p.Hin && xi >= 0 && xi < p.Win;
-                const unsigned off = v ? (unsigned)((((long)n * p.Hin + yi) * p.Win + xi) * p.x_pitch + ci0 + 4 * c4) * 4u : OOB;
+                const int yi = oy0 + br - 1, xi = ox0 + c - 1;          // (p.ups: coordinates in the nearest-x2 image)
+                const bool v = b_ok && yi >= 0 && yi < Hv && xi >= 0 && xi < Wv;
+                const int ys = p.ups ? yi >> 1 : yi, xs = p.ups ? xi >> 1 : xi;
+                const unsigned off = v ? (unsigned)((((long)n * p.Hin + ys) * p.Win + xs) * p.x_pitch + ci0 + 4 * c4) * 4u : OOB;
                 rb[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
             }
         }
@@ -820,7 +822,7 @@ int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const f
 
 int hl_conv2d_wgrad_nhwc_ws_mode(int conv_mode, const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                                  float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream) {
-    const bool h16 = (conv_mode == HL_CONV_FP16 || conv_mode == HL_CONV_BF16) && ks == 3 && stride == 1 && !upsample;
+    const bool h16 = (conv_mode == HL_CONV_FP16 || conv_mode == HL_CONV_BF16) && ks == 3 && stride == 1;
     if (!wgrad_t_applies(Cx, Cy, ks, stride, upsample))
         return hl_conv2d_wgrad_nhwc(x, N, H, W, Cx, dy, Cy, ks, stride, upsample, dw, Cout, Cin, db, stream);
     HL_REQUIRE(x && dy && dw, "hl_conv2d_wgrad_nhwc_ws: null argument");

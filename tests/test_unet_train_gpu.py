@@ -394,14 +394,15 @@ def test_16bit_weight_gradient_equals_the_gradient_of_the_rounded_operands(kind)
     are not multiples of 8), ragged channel blocks, several images, K slabs; bit-reproducible."""
     from humanliff_amd.improved_diffusion import unet_train as ut
     dt = torch.bfloat16 if kind == "bf16" else torch.float16
-    for (N, H, W, C, Co) in ((2, 32, 32, 64, 64), (1, 20, 12, 96, 160), (2, 64, 64, 192, 192), (3, 8, 8, 32, 32)):
+    for (N, H, W, C, Co, ups) in ((2, 32, 32, 64, 64, 0), (1, 20, 12, 96, 160, 0), (2, 64, 64, 192, 192, 0), (3, 8, 8, 32, 32, 0), (2, 16, 24, 64, 96, 1)):
         g = torch.Generator().manual_seed(H + C)
         x = torch.randn((N, C, H, W), generator=g)
         w = torch.randn((Co, C, 3, 3), generator=g) / (C * 9) ** 0.5
         b = torch.randn((Co,), generator=g)
-        cot = torch.randn((N, Co, H, W), generator=g)
+        cot = torch.randn((N, Co, H * (2 if ups else 1), W * (2 if ups else 1)), generator=g)
         wr = w.double().requires_grad_(True)
-        (F.conv2d(x.to(dt).double(), wr, None, padding=1) * cot.to(dt).double()).sum().backward()
+        xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+        (F.conv2d(xin.to(dt).double(), wr, None, padding=1) * cot.to(dt).double()).sum().backward()
         dw_ref, db_ref = wr.grad, cot.double().sum(dim=(0, 2, 3))
         runs = []
         for _ in range(2):
@@ -409,7 +410,7 @@ def test_16bit_weight_gradient_equals_the_gradient_of_the_rounded_operands(kind)
             wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
             ut.set_train_arithmetic(kind)
             try:
-                (ut._Conv.apply(xd, wd, bd, 1, 0) * nhwc(cot).to(dev)).sum().backward()
+                (ut._Conv.apply(xd, wd, bd, 1, ups) * nhwc(cot).to(dev)).sum().backward()
             finally:
                 ut.set_train_arithmetic(None)
             runs.append((wd.grad.clone(), bd.grad.clone()))
@@ -417,7 +418,7 @@ def test_16bit_weight_gradient_equals_the_gradient_of_the_rounded_operands(kind)
         dw, db = runs[0]
         ew = float((dw.cpu().double() - dw_ref).abs().max() / dw_ref.abs().max())
         eb = float((db.cpu().double() - db_ref).abs().max() / db_ref.abs().max())
-        print(f"{kind} N{N} {H}x{W} {C}->{Co}: dW max-abs / max {ew:.2e}, db {eb:.2e}")
+        print(f"{kind} N{N} {H}x{W} {C}->{Co} ups{ups}: dW max-abs / max {ew:.2e}, db {eb:.2e}")
         assert ew < 2e-5 and eb < 1e-5, (N, H, W, C, Co, ew, eb)
 
 
@@ -429,23 +430,27 @@ def test_conv_h16_equals_the_convolution_of_the_rounded_operands(f16, monkeypatc
     L = _lib.lib()
     monkeypatch.setenv("HL_H16_MIN_BLOCKS", "1")             # (the dispatch takes the kernel from 48 workgroups on; here also single tiles)
     mode, dt = (_lib.HL_CONV_FP16, torch.float16) if f16 else (_lib.HL_CONV_BF16, torch.bfloat16)
-    for (N, H, W, C, Co, use_res, gn) in ((1, 16, 16, 32, 192, 0, 0), (2, 48, 80, 64, 384, 1, 0), (3, 32, 16, 96, 192, 1, 1)):
+    for (N, H, W, C, Co, use_res, gn, ups) in ((1, 16, 16, 32, 192, 0, 0, 0), (2, 48, 80, 64, 384, 1, 0, 0), (3, 32, 16, 96, 192, 1, 1, 0), (2, 16, 24, 64, 192, 1, 0, 1)):
         g = torch.Generator().manual_seed(N + C)
         x = torch.randn((N, H, W, C), generator=g); w = torch.randn((Co, C, 3, 3), generator=g) / (C * 9) ** 0.5; b = torch.randn(Co, generator=g)
-        res = torch.randn((N, H, W, Co), generator=g)
+        Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+        res = torch.randn((N, Ho, Wo, Co), generator=g)
         cA, cB = torch.rand((N, C), generator=g) + 0.5, torch.randn((N, C), generator=g) * 0.1
         xin = x
         if gn:
             u = x * cA[:, None, None, :] + cB[:, None, None, :]
             xin = (u * torch.sigmoid(u)).to(dev).cpu()               # (the pre-pass runs in fp32 on the GPU; its rounding is inside the tolerance)
-        ref = F.conv2d(xin.to(dt).double().permute(0, 3, 1, 2), w.to(dt).double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        xr = xin.to(dt).double().permute(0, 3, 1, 2)
+        if ups:
+            xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+        ref = F.conv2d(xr, w.to(dt).double(), b.double(), padding=1).permute(0, 2, 3, 1)
         if use_res:
             ref = ref + res.double()
         xd, wd, bd, rd, ad, bd2 = (t.to(dev) for t in (x, w, b, res, cA, cB))
-        out = torch.zeros((N, H, W, Co), device=dev)
+        out = torch.zeros((N, Ho, Wo, Co), device=dev)
         scratch = torch.empty(Co * C * 9 * 6 + 256 + (8 << 20) + N * H * W * C, device=dev)
         with _lib.on(dev):
-            _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(xd), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Co, 3, 1, 0, _lib.ptr(ad) if gn else None,
+            _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(xd), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Co, 3, 1, ups, _lib.ptr(ad) if gn else None,
                                              _lib.ptr(bd2) if gn else None, gn, _lib.ptr(rd) if use_res else None, _lib.ptr(out), _lib.ptr(scratch),
                                              scratch.numel() * 4, _lib.stream_ptr()), "hl_conv2d_nhwc_mode")
         err = float((out.cpu().double() - ref).abs().max())
