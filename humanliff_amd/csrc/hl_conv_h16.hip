@@ -61,6 +61,82 @@ constexpr int H16_STAGE = H16_PW * H16_LP * 64;              // bytes per patch 
 #endif
 constexpr int H16_EP = 196;                                  // epilogue row pitch in floats (192 + 4: rows 4 apart are 16 banks apart)
 
+// Epilogue shared by the 3x3 and the 1x1 kernel: the wave tiles (128 pixel slots x 96 channels per wave) go through LDS in two rounds of
+// (fragments 2q, 2q+1 of every wave) = 128 pixel slots x 192 channels; pix(q, slot) = the output pixel of slot (wave half wm = slot >> 6,
+// fragment 2q + ((slot >> 5) & 1), row slot & 31); bias, residual, 16-byte NHWC stores, GroupNorm statistics per (tile, round).
+template <class PixFn>
+__device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f32x16 (&acc)[4][3], int tid, int lane, int wm, int wn, int n0, long tile,
+                                             PixFn pix) {
+    // ---- epilogue: two rounds of (fragments 2q, 2q+1 of every wave) = 128 pixels x 192 channels through LDS
+    float *ep = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (q) __syncthreads();
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = (i >> 2) * 8 + (lane >> 5) * 4 + (i & 3);            // row of the 32x32 tile held by acc[..][i]
+                    const int prow = wm * 64 + m2 * 32 + r;                            // pixel slot of the round: wave-major, fragment, row
+                    ep[prow * H16_EP + wn * 96 + nf * 32 + (lane & 31)] = acc[2 * q + m2][nf][i];
+                }
+        __syncthreads();
+        // thread (pr0 = tid / 48 < 5, cq = tid % 48) finishes channels 4cq..4cq+3 of pixel slots pr0, pr0 + 5, ... (<= 26 of the round's 128),
+        // in batches of 9 / 9 / 8: the residual loads of a batch are all in flight before its first store (on this ISA stores count on
+        // vmcnt too: a load waited for behind a store waits for the store).  One channel quad per thread = GroupNorm sums without shuffles.
+        const int pr0 = tid / 48, cq = (tid - pr0 * 48) * 4;
+        f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && pr0 < 5) bs = *reinterpret_cast<const f32x4 *>(p.bias + n0 + cq);
+        auto finish = [&](auto kc0, auto nbc) {   // pixel slots pr0 + 5 (K0 .. K0 + NB - 1): every load of the batch in flight before its first store
+            constexpr int K0 = decltype(kc0)::value, NB = decltype(nbc)::value;
+            long mm[NB];
+            f32x4 v[NB], rr[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int pc = pr0 + 5 * (K0 + k);
+                mm[k] = pix(q, pc);
+                if (p.res) rr[k] = *reinterpret_cast<const f32x4 *>(p.res + mm[k] * p.res_pitch + n0 + cq);
+                v[k] = *reinterpret_cast<const f32x4 *>(ep + pc * H16_EP + cq);
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                v[k] += bs;
+                if (p.res) v[k] += rr[k];
+                sm += v[k]; sq += v[k] * v[k];
+                *reinterpret_cast<f32x4 *>(p.out + mm[k] * p.out_pitch + n0 + cq) = v[k];
+            }
+        };
+        if (pr0 < 5) {
+            finish(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+            finish(std::integral_constant<int, 9>{}, std::integral_constant<int, 8>{});
+            finish(std::integral_constant<int, 17>{}, std::integral_constant<int, 8>{});
+            if (pr0 < 3) finish(std::integral_constant<int, 25>{}, std::integral_constant<int, 1>{});      // slots 125, 126, 127
+        }
+        if (p.st1) {   // GroupNorm statistics of the stored tensor: slot = (tile, round) = 128 pixels; the five pixel groups meet in LDS
+            __syncthreads();
+            if (pr0 < 5) {
+                *reinterpret_cast<f32x4 *>(ep + (pr0 * 48 * 2 + (cq >> 2) * 2) * 4) = sm;
+                *reinterpret_cast<f32x4 *>(ep + (pr0 * 48 * 2 + (cq >> 2) * 2 + 1) * 4) = sq;
+            }
+            __syncthreads();
+            if (tid < 48) {
+                f32x4 a = *reinterpret_cast<const f32x4 *>(ep + (tid * 2) * 4), b = *reinterpret_cast<const f32x4 *>(ep + (tid * 2 + 1) * 4);
+#pragma unroll
+                for (int g = 1; g < 5; ++g) {
+                    a += *reinterpret_cast<const f32x4 *>(ep + (g * 48 * 2 + tid * 2) * 4);
+                    b += *reinterpret_cast<const f32x4 *>(ep + (g * 48 * 2 + tid * 2 + 1) * 4);
+                }
+                float *d = p.st1 + ((tile * 2 + q) * p.Cout + n0 + tid * 4) * 2;
+                *reinterpret_cast<f32x4 *>(d) = f32x4{a[0], b[0], a[1], b[1]};
+                *reinterpret_cast<f32x4 *>(d + 4) = f32x4{a[2], b[2], a[3], b[3]};
+            }
+        }
+    }
+}
+
 template <bool F16>
 __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__
@@ -185,77 +261,117 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
         __syncthreads();
     }
 
-    // ---- epilogue: two rounds of (fragments 2q, 2q+1 of every wave) = 128 pixels x 192 channels through LDS
-    const int n0 = nb * 192;
-    float *ep = reinterpret_cast<float *>(lds);
+    h16_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, [&](int q, int pc) {
+        const int wmm = pc >> 6, m2 = (pc >> 5) & 1, r = pc & 31;
+        const int oy = y0 + 8 * wmm + 2 * (2 * q + m2) + (r >> 4), ox = x0 + (r & 15);
+        return ((long)img * p.Hout + oy) * p.Wout + ox;
+    });
+#endif
+}
+
+// k_conv1_h16: the 1x1 convolutions (skip / qkv / proj) in the same arithmetic.  A workgroup = 256 consecutive pixels x 192 output channels,
+// the same 2x2 wave split, weight ring and epilogue; K in chunks of 96 input channels = six k-steps: the chunk's [256 px][96 ch] slab is fetched
+// as fp32 one chunk ahead, rounded and written to LDS with a pixel pitch of 208 bytes (13 quarters: 13 is odd, so the 16 lanes a ds_read_b128
+// is served in - 16 different pixels, one quarter - hit 16 different slots).  These layers are bound by HBM (a 384→192 layer at 256x256 moves
+// 600 MB for 39 GFLOP), not by the matrix pipe.
+constexpr int H1_PITCH = 208, H1_STAGE = 256 * H1_PITCH;
+
+template <bool F16>
+__global__ __launch_bounds__(256, 1) void k_conv1_h16(const ConvK p) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int NUT = 12;                                        // staging units per thread: 256 px x 12 groups of 8 channels / 256 threads
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int total = p.n_mtiles * p.n_nblocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int tb = __builtin_amdgcn_readfirstlane(wi / p.n_nblocks), nb = wi - tb * p.n_nblocks;
+    const long m0 = (long)tb * 256;
+    const int nch = p.Cin / 96;
+    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * p.in_pitch * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * nch * 6 * 6144), 0x00020000);
+
+    unsigned sv[NUT], sl[NUT];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (q) __syncthreads();
-#pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-            for (int nf = 0; nf < 3; ++nf)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int r = (i >> 2) * 8 + (lane >> 5) * 4 + (i & 3);            // row of the 32x32 tile held by acc[..][i]
-                    const int prow = wm * 64 + m2 * 32 + r;                            // pixel slot of the round: wave-major, fragment, row
-                    ep[prow * H16_EP + wn * 96 + nf * 32 + (lane & 31)] = acc[2 * q + m2][nf][i];
-                }
-        __syncthreads();
-        // thread (pr0 = tid / 48 < 5, cq = tid % 48) finishes channels 4cq..4cq+3 of pixel slots pr0, pr0 + 5, ... (<= 26 of the round's 128),
-        // in batches of 9 / 9 / 8: the residual loads of a batch are all in flight before its first store (on this ISA stores count on
-        // vmcnt too: a load waited for behind a store waits for the store).  One channel quad per thread = GroupNorm sums without shuffles.
-        const int pr0 = tid / 48, cq = (tid - pr0 * 48) * 4;
-        f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
-        f32x4 bs = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && pr0 < 5) bs = *reinterpret_cast<const f32x4 *>(p.bias + n0 + cq);
-        auto finish = [&](auto kc0, auto nbc) {   // pixel slots pr0 + 5 (K0 .. K0 + NB - 1): every load of the batch in flight before its first store
-            constexpr int K0 = decltype(kc0)::value, NB = decltype(nbc)::value;
-            long mm[NB];
-            f32x4 v[NB], rr[NB];
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const int pc = pr0 + 5 * (K0 + k);
-                const int wmm = pc >> 6, m2 = (pc >> 5) & 1, r = pc & 31;
-                const int oy = y0 + 8 * wmm + 2 * (2 * q + m2) + (r >> 4), ox = x0 + (r & 15);
-                mm[k] = ((long)img * p.Hout + oy) * p.Wout + ox;
-                if (p.res) rr[k] = *reinterpret_cast<const f32x4 *>(p.res + mm[k] * p.res_pitch + n0 + cq);
-                v[k] = *reinterpret_cast<const f32x4 *>(ep + pc * H16_EP + cq);
-            }
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                v[k] += bs;
-                if (p.res) v[k] += rr[k];
-                sm += v[k]; sq += v[k] * v[k];
-                *reinterpret_cast<f32x4 *>(p.out + mm[k] * p.out_pitch + n0 + cq) = v[k];
-            }
-        };
-        if (pr0 < 5) {
-            finish(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
-            finish(std::integral_constant<int, 9>{}, std::integral_constant<int, 8>{});
-            finish(std::integral_constant<int, 17>{}, std::integral_constant<int, 8>{});
-            if (pr0 < 3) finish(std::integral_constant<int, 25>{}, std::integral_constant<int, 1>{});      // slots 125, 126, 127
-        }
-        if (p.st1) {   // GroupNorm statistics of the stored tensor: slot = (tile, round) = 128 pixels; the five pixel groups meet in LDS
-            __syncthreads();
-            if (pr0 < 5) {
-                *reinterpret_cast<f32x4 *>(ep + (pr0 * 48 * 2 + (cq >> 2) * 2) * 4) = sm;
-                *reinterpret_cast<f32x4 *>(ep + (pr0 * 48 * 2 + (cq >> 2) * 2 + 1) * 4) = sq;
-            }
-            __syncthreads();
-            if (tid < 48) {
-                f32x4 a = *reinterpret_cast<const f32x4 *>(ep + (tid * 2) * 4), b = *reinterpret_cast<const f32x4 *>(ep + (tid * 2 + 1) * 4);
-#pragma unroll
-                for (int g = 1; g < 5; ++g) {
-                    a += *reinterpret_cast<const f32x4 *>(ep + (g * 48 * 2 + tid * 2) * 4);
-                    b += *reinterpret_cast<const f32x4 *>(ep + (g * 48 * 2 + tid * 2 + 1) * 4);
-                }
-                float *d = p.st1 + (((long)tb * 2 + q) * p.Cout + n0 + tid * 4) * 2;
-                *reinterpret_cast<f32x4 *>(d) = f32x4{a[0], b[0], a[1], b[1]};
-                *reinterpret_cast<f32x4 *>(d + 4) = f32x4{a[2], b[2], a[3], b[3]};
-            }
-        }
+    for (int j = 0; j < NUT; ++j) {
+        const int u = tid + 256 * j, pix = u / 12, grp = u - pix * 12;
+        sv[j] = (unsigned)(m0 + pix) * pitch4 + grp * 32;
+        sl[j] = (unsigned)(pix * H1_PITCH + grp * 16);
     }
+    u32x4 ar[NUT][2];
+    auto a_load = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NUT; ++j) {
+            ar[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j], chunk * 384, 0);
+            ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] + 16, chunk * 384, 0);
+        }
+    };
+    auto a_store = [&](int stage, int j) {
+        const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
+        const u32x4 h = {pack2<F16>(v0[0], v0[1]), pack2<F16>(v0[2], v0[3]), pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3])};
+        *reinterpret_cast<u32x4 *>(lds + stage * H1_STAGE + sl[j]) = h;
+    };
+    unsigned aoff[4];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) aoff[mf] = (unsigned)((128 * wm + 32 * mf + (lane & 31)) * H1_PITCH + (lane >> 5) * 16);
+    const unsigned wv = (unsigned)lane * 16u;
+    const int wbase = nb * nch * 6 * 6144 + wn * 3072;
+    u32x4 ring[6][3];
+    auto w_load = [&](int slot_, int step) {
+        const int so = wbase + min(step, nch * 6 - 1) * 6144;        // (past the end: the last step again, never used)
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf) ring[slot_][nf] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wv, so + nf * 1024, 0);
+    };
+    f32x16 acc[4][3];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+
+    a_load(0);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) w_load(s, s);
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) a_store(0, j);
+    __syncthreads();
+
+    u32x4 af[2][4];
+    auto a_read = [&](const char *st, int k2, u32x4 (&dst)[4]) {
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) dst[mf] = *reinterpret_cast<const u32x4 *>(st + aoff[mf] + k2 * 32);
+    };
+    for (int c = 0; c < nch; ++c) {
+        const char *st = lds + (c & 1) * H1_STAGE;
+        a_load(c + 1 < nch ? c + 1 : c);                             // (last chunk: staged again, never read)
+        a_read(st, 0, af[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ([&] {
+                constexpr int cur = S & 1;
+                if constexpr (S + 1 < 6) a_read(st, S + 1, af[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf) acc[mf][nf] = mma<F16>(af[cur][mf], ring[S][nf], acc[mf][nf]);
+                w_load(S, c * 6 + S + 6);
+                a_store((c + 1) & 1, 2 * S);
+                a_store((c + 1) & 1, 2 * S + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, 6>{});
+        __syncthreads();
+    }
+    h16_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, [&](int q, int pc) {
+        return m0 + 128 * (pc >> 6) + 32 * (2 * q + ((pc >> 5) & 1)) + (pc & 31);
+    });
 #endif
 }
 
@@ -288,36 +404,72 @@ __global__ void k_pack_conv_h16(const float *__restrict__ w, int Cout, int Cin, 
     }
 }
 
+// 1x1 layers: [channel block of 192][chunk of 96 inputs][k-step 6][wn][fragment nf][lane][8]
+__global__ void k_pack_conv1_h16(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, unsigned short *__restrict__ dst, int f16, int tf) {
+    const int nch = Cin_pad / 96;
+    const long n = (long)(Cout / 192) * nch * 6 * 3072;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+        long t = i >> 9;
+        const int nf = (int)(t % 3); t /= 3;
+        const int wn = (int)(t & 1); t >>= 1;
+        const int k2 = (int)(t % 6); t /= 6;
+        const int chunk = (int)(t % nch);
+        const int nb = (int)(t / nch);
+        const int o = nb * 192 + wn * 96 + nf * 32 + (l & 31), cin = chunk * 96 + k2 * 16 + (l >> 5) * 8 + j;
+        float v = 0.f;
+        if (cin < Cin) v = tf ? w[(long)cin * Cout + o] : w[(long)o * Cin + cin];
+        unsigned short h;
+        if (f16) {
+            const _Float16 hh = (_Float16)v;
+            h = __builtin_bit_cast(unsigned short, hh);
+        } else {
+            const unsigned u = __float_as_uint(v);
+            h = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+        dst[i] = h;
+    }
+}
+
 }  // namespace
 
 bool conv_h16_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int ups) {
-    (void)ups;   // the nearest-x2 upsample in front of the convolution is a source-address shift of the patch loads
-    return ks == 3 && stride == 1 && Hout % 16 == 0 && Wout % 16 == 0 && Cin % 32 == 0 && Cout % 192 == 0 &&
-           (long)Cout * Cin * 18 < (1L << 31);
+    // 3x3: the nearest-x2 upsample in front of the convolution is a source-address shift of the patch loads; 1x1: 256 consecutive pixels per tile
+    if (ks == 3) return stride == 1 && Hout % 16 == 0 && Wout % 16 == 0 && Cin % 32 == 0 && Cout % 192 == 0 && (long)Cout * Cin * 18 < (1L << 31);
+    return ks == 1 && stride == 1 && !ups && ((long)Hout * Wout) % 256 == 0 && Cin % 96 == 0 && Cout % 192 == 0 && (long)Cout * Cin * 2 < (1L << 31);
 }
 
 size_t conv_packed_h16_bytes(int Cout, int Cin_pad, int ks) {
-    return (ks == 3 && Cout % 192 == 0 && Cin_pad % 32 == 0) ? (size_t)Cout * Cin_pad * 9 * 2 : 0;
+    if (ks == 3) return (Cout % 192 == 0 && Cin_pad % 32 == 0) ? (size_t)Cout * Cin_pad * 9 * 2 : 0;
+    return (ks == 1 && Cout % 192 == 0 && Cin_pad % 96 == 0) ? (size_t)Cout * Cin_pad * 2 : 0;
 }
 
-int conv_pack_weights_h16(const float *w, int Cout, int Cin, int Cin_pad, void *packed, int f16, hipStream_t st, int tf) {
-    HL_REQUIRE(w && packed && Cout % 192 == 0 && Cin_pad % 32 == 0 && Cin <= Cin_pad, "conv_pack_weights_h16: bad argument");
-    hipLaunchKernelGGL(k_pack_conv_h16, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), f16, tf);
+int conv_pack_weights_h16(const float *w, int Cout, int Cin, int Cin_pad, int ks, void *packed, int f16, hipStream_t st, int tf) {
+    HL_REQUIRE(w && packed && conv_packed_h16_bytes(Cout, Cin_pad, ks) && Cin <= Cin_pad, "conv_pack_weights_h16: bad argument");
+    if (ks == 3) hipLaunchKernelGGL(k_pack_conv_h16, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), f16, tf);
+    else hipLaunchKernelGGL(k_pack_conv1_h16, dim3(512), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), f16, tf);
     return check_launch("k_pack_conv_h16");
 }
 
-size_t conv_h16_lds_bytes() { return (size_t)128 * H16_EP * sizeof(float); }   // the epilogue exchange (98 KB); the two patch stages need 40.5 KB
+size_t conv_h16_lds_bytes() { return (size_t)2 * H1_STAGE; }   // 104 KB: the two 1x1 stages (the epilogue exchange needs 98 KB, the 3x3 patch stages 45 KB)
 
 int conv_h16_launch(const ConvK &p, int f16, hipStream_t st) {
-    HL_REQUIRE(p.w_bf3 && p.Cout % 192 == 0 && p.Cin % 32 == 0 && p.Hout % 16 == 0 && p.Wout % 16 == 0, "k_conv_h16: bad layer");
+    HL_REQUIRE(p.w_bf3 && conv_h16_applies(p.Hout, p.Wout, p.Cin, p.Cout, p.ks, p.stride, p.ups), "k_conv_h16: bad layer");
     const dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks));
     const size_t sh = conv_h16_lds_bytes();
     static const bool attr_ok = [] {
         const int b = (int)conv_h16_lds_bytes();
         return hipFuncSetAttribute((const void *)k_conv_h16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess &&
-               hipFuncSetAttribute((const void *)k_conv_h16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess;
+               hipFuncSetAttribute((const void *)k_conv_h16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess &&
+               hipFuncSetAttribute((const void *)k_conv1_h16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess &&
+               hipFuncSetAttribute((const void *)k_conv1_h16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess;
     }();
     HL_REQUIRE(attr_ok, "k_conv_h16: cannot raise the dynamic LDS limit to %zu bytes", sh);
+    if (p.ks == 1) {
+        if (f16) hipLaunchKernelGGL((k_conv1_h16<true>), grid, dim3(256), sh, st, p);
+        else hipLaunchKernelGGL((k_conv1_h16<false>), grid, dim3(256), sh, st, p);
+        return check_launch("k_conv1_h16");
+    }
     if (f16) hipLaunchKernelGGL((k_conv_h16<true>), grid, dim3(256), sh, st, p);
     else hipLaunchKernelGGL((k_conv_h16<false>), grid, dim3(256), sh, st, p);
     return check_launch("k_conv_h16");

@@ -313,7 +313,7 @@ int hl_unet_set_overlap(void *handle, int enable);
  *   fp32.  Relative error per product <= 2^-9; NOT an inference default.  Forward (hl_conv2d_nhwc_mode) and backward-data
  *   (hl_conv2d_nhwc_bwd_data) take it; weight gradients stay fp32. */
 #define HL_CONV_BF16 4
-/* HL_CONV_FP16 (opt-in): fp16 operands / fp32 accumulation (v_mfma_f32_32x32x16_f16) on the 3x3 / stride-1 layers k_conv_h16 covers - the
+/* HL_CONV_FP16 (opt-in): fp16 operands / fp32 accumulation (v_mfma_f32_32x32x16_f16) on the 3x3 / stride-1 layers (k_conv_h16, also behind a nearest-x2 upsample) and the 1x1 layers (k_conv1_h16) - the
  * operand precision of the reference's own convolutions on its hardware (TF32: 10 explicit significand bits) and of its autocast training;
  * every other layer as HL_CONV_FP32.  HL_CONV_BF16 takes the same kernel with bf16 operands on those layers. */
 #define HL_CONV_FP16 5

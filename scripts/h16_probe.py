@@ -34,3 +34,22 @@ for (N, H, W, C, Co, use_res) in shapes:
     ref = outs[0][0].double()
     fl = 2.0 * N * H * W * Co * C * 9
     print(f"N{N} {H}x{W} {C}->{Co} res{use_res}: " + "; ".join(f"mode {m}: {t:.0f} us ({fl / t / 1e6:.0f} TF/s), rel-L2 vs fp32 {float((o.double() - ref).norm() / ref.norm()):.2e}" for m, (o, t) in outs.items()) + " | " + "; ".join(msg), flush=True)
+
+for (N, H, W, C, Co) in [(4, 256, 256, 384, 192), (4, 64, 64, 384, 1152), (4, 128, 128, 576, 192), (4, 64, 64, 384, 384)]:
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn((N, H, W, C), device=dev, generator=g); w = torch.randn((Co, C, 1, 1), device=dev, generator=g) / C ** 0.5; b = torch.randn(Co, device=dev, generator=g)
+    scratch = torch.empty(Co * C * 6 + 256 + (64 << 20), device=dev)
+    msg = []
+    for mode in (0, 4, 5):
+        out = torch.zeros((N, H, W, Co), device=dev)
+        def call():
+            _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(x), N, H, W, C, _lib.ptr(w), _lib.ptr(b), Co, 1, 1, 0, None, None, 0, None, _lib.ptr(out), _lib.ptr(scratch),
+                                             scratch.numel() * 4, _lib.stream_ptr()))
+        call(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): call()
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 10 * 1e3
+        msg.append(f"mode {mode}: {t:.0f} us ({2.0 * N * H * W * C * Co / t / 1e6:.0f} TF/s, {(N * H * W * (C + Co) * 4) / t / 1e6:.2f} TB/s)")
+    print(f"1x1 N{N} {H}x{W} {C}->{Co}: " + "; ".join(msg), flush=True)
