@@ -42,7 +42,8 @@ _KIND_MODE = {"fp32": _lib.HL_CONV_FP32, "bf16": _lib.HL_CONV_BF16, "fp16": _lib
 def set_train_arithmetic(kind=None):
     """Arithmetic of the convolutions of the training path (forward and backward-data).
       "fp32"          the exact fp32 kernels (Winograd where it applies);
-      "fp16" / "bf16" 16-bit operands, fp32 accumulation (HL_CONV_FP16 / HL_CONV_BF16): k_conv_h16 on the 3x3 / stride-1 layers it covers
+      "fp16" / "bf16" 16-bit operands, fp32 accumulation (HL_CONV_FP16 / HL_CONV_BF16; the BACKWARD of "fp16" runs in bf16: gradients need
+                      fp32's exponent range unless the loss is scaled): k_conv_h16 on the 3x3 / stride-1 layers it covers
                       (2.2-2.6x the fp32 Winograd kernel on the 256x256 layers), the other layers on k_conv_bf3 (bf16) or the fp32 kernels
                       (fp16); fp32 tensors and master weights;
       None (default)  "fp32", unless the caller trains under torch.autocast (train_util.py:214, --use_amp True): then the autocast dtype -
@@ -103,6 +104,9 @@ class _Conv(th.autograd.Function):
         ks, stride, ups, wshape, has_b = ctx.meta
         L = _lib.lib()
         dy = dy.contiguous()
+        # gradients do not fit fp16's range without loss scaling (values below 6e-8 vanish, 6e-5 and below lose bits): the backward of the
+        # fp16 mode runs in bf16 - same kernels, fp32's exponent range - whether or not the caller wraps the step in a GradScaler
+        bmode = _lib.HL_CONV_BF16 if ctx.mode == _lib.HL_CONV_FP16 else ctx.mode
         N, Ho, Wo, Cout = dy.shape
         Cin = w4.shape[1]
         dyp = _pad_c(dy, 16)                                      # (the 27-channel output conv: pad the gradient's channels with zeros)
@@ -115,7 +119,7 @@ class _Conv(th.autograd.Function):
             extra = N * 4 * Ho * Wo * Cyp if stride == 2 else (N * Ho * Wo * Cxp if ups else 0)
             scratch = th.empty(rows * Cyp * ks * ks * 5 + 512 + (16 << 20) + extra, device=dy.device, dtype=th.float32)
             with _lib.on(dy.device):
-                _lib.check(L.hl_conv2d_nhwc_bwd_data(ctx.mode, _lib.ptr(dyp), N, Ho, Wo, Cyp, _lib.ptr(w4.contiguous()), Cout, Cin, ks, stride, ups,
+                _lib.check(L.hl_conv2d_nhwc_bwd_data(bmode, _lib.ptr(dyp), N, Ho, Wo, Cyp, _lib.ptr(w4.contiguous()), Cout, Cin, ks, stride, ups,
                                                      _lib.ptr(dx), Cxp, _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()),
                            "hl_conv2d_nhwc_bwd_data")
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
@@ -127,7 +131,7 @@ class _Conv(th.autograd.Function):
             dw = alloc(w4.shape, device=dy.device, dtype=th.float32)
             db = alloc((Cout,), device=dy.device, dtype=th.float32) if has_b else None
             with _lib.on(dy.device):
-                _lib.check(L.hl_conv2d_wgrad_nhwc_ws_mode(ctx.mode, _lib.ptr(x), N, x.shape[1], x.shape[2], x.shape[3], _lib.ptr(dy2), dy2.shape[-1], ks,
+                _lib.check(L.hl_conv2d_wgrad_nhwc_ws_mode(bmode, _lib.ptr(x), N, x.shape[1], x.shape[2], x.shape[3], _lib.ptr(dy2), dy2.shape[-1], ks,
                                                           stride, ups, _lib.ptr(dw), Cout, Cin, _lib.ptr(db), _lib.ptr(part), nbytes, _lib.stream_ptr()),
                            "hl_conv2d_wgrad_nhwc_ws_mode")
             dw = dw.reshape(wshape)
