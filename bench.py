@@ -22,6 +22,7 @@ restatement of the reference's algorithm, kind "port") on this box's host cores 
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -531,6 +532,38 @@ def e2e_slice(model, dev, rank, world, n_layers=4, ddim=50, n_views=185, res=512
         out["parity"] = {"psnr_db": round(min(psnrs), 2), "views": checks,
                          "what": f"{n_check_rays} box-hitting rays of each of {n_check_views} views of the GENERATED tri-plane: HIP render vs the CPU oracle on identical "
                                  "rays / uniforms (north-star bar: PSNR >= 45 dB); the uint8 pixels of the slice's own images equal the oracle's within one grey level"}
+    if world == 1 and hasattr(model, "set_conv_mode"):
+        # the same subject sampled again in the opt-in fp16-operand mode (same noise, same chaining), and what that does to the IMAGES:
+        # the views of the parity check rendered from both tri-planes, compared as the uint8 pixels the script would write
+        model.set_conv_mode("fp16")
+        try:
+            with torch.no_grad():
+                model(torch.zeros((1,) + shape, device=dev), torch.zeros((1,), dtype=torch.int64, device=dev), torch.zeros((1,) + shape, device=dev),
+                      y=torch.zeros((1,), dtype=torch.int64, device=dev))
+            torch.cuda.synchronize()
+            t16 = time.perf_counter()
+            xc, last = torch.zeros((1,) + shape, device=dev), None
+            for layer in range(n_layers):
+                xc = sample_fn(xc, layer, [0])
+            last = xc
+            torch.cuda.synchronize()
+            t16 = time.perf_counter() - t16
+        finally:
+            model.set_conv_mode("fp32")
+        ps = []
+        for i in range(n_check_views):
+            v = (i * n_views) // n_check_views
+            img16 = render_fn(0, last, v)
+            a = (img16.clamp(0, 1) * 255).to(torch.uint8).float().reshape(-1, 3).cpu() if img16.dtype != torch.uint8 else img16.float().reshape(-1, 3).cpu()
+            b = images[0, v].reshape(-1, 3).cpu().float()
+            mse = float(((a - b) ** 2).mean())
+            ps.append(99.0 if mse == 0 else 10 * math.log10(255.0 ** 2 / mse))
+        tp_mse = float(((last[0] - samples[0, -1]) ** 2).mean())
+        out["fp16_mode"] = {"what": "the same subject sampled in UNetModel.set_conv_mode('fp16') (opt-in; same noise, layers chained the same way) and rendered (fp32 "
+                                    "renderer): sampling time, and the PSNR of the uint8 images / of the last layer's tri-plane against the fp32 slice above",
+                            "sampling_seconds": round(t16, 3), "denoise_steps_per_sec": round(n_layers * ddim / t16, 2),
+                            "image_psnr_db_min": round(min(ps), 2), "image_psnr_db_views": [round(v, 2) for v in ps],
+                            "triplane_psnr_db": round(10 * math.log10(float(samples[0, -1].abs().max()) ** 2 / tp_mse), 2) if tp_mse > 0 else 99.0}
     return out
 
 
