@@ -154,10 +154,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
     const int img = tb / (bw * bh), brem = tb - img * (bw * bh);
     const int y0 = (brem / bw) * 16, x0 = (brem - (brem / bw) * bw) * 16;
     const int nch = p.Cin >> 5;
-    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+    const unsigned pitch4 = (unsigned)p.in_pitch * (p.in16 ? 2u : 4u);      // bytes per pixel (16-bit image from the GroupNorm pass, or fp32)
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * p.in_pitch * 4), 0x00020000);
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * pitch4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * nch * 18 * 6144), 0x00020000);
 
@@ -170,21 +170,22 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
         const int y = y0 - 1 + py, x = x0 - 1 + px;                 // (p.ups: coordinates in the nearest-x2 image, unet.py:77 - source pixel (y >> 1, x >> 1))
         const bool ok = u < NU && y >= 0 && y < p.Hout && x >= 0 && x < p.Wout;
         const int ys = p.ups ? y >> 1 : y, xs = p.ups ? x >> 1 : x;
-        sv[j] = ok ? (unsigned)((img * p.Hin + ys) * p.Win + xs) * pitch4 + grp * 32 : OOB;
+        sv[j] = ok ? (unsigned)((img * p.Hin + ys) * p.Win + xs) * pitch4 + grp * (p.in16 ? 16 : 32) : OOB;
         sl[j] = u < NU ? (unsigned)((py * H16_LP + px) * 64 + ((grp ^ ((px >> 2) & 3)) << 4)) : (unsigned)(2 * H16_STAGE + (tid & 63) * 16);   // (no unit: a dump slot behind the stages)
     }
     u32x4 ar[NUT][2];
     auto a_load = [&](int chunk) {
 #pragma unroll
         for (int j = 0; j < NUT; ++j) {
-            const int so = (H16_ABL & 16) ? 0 : chunk * 128;      // (16: the patch from L2-hot addresses)
+            const int so = (H16_ABL & 16) ? 0 : chunk * (p.in16 ? 64 : 128);      // (16: the patch from L2-hot addresses)
             ar[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j], so, 0);
-            ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] == OOB ? OOB : sv[j] + 16, so, 0);
+            if (!p.in16) ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] == OOB ? OOB : sv[j] + 16, so, 0);
         }
     };
     auto a_store = [&](int stage, int j) {
         const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
-        const u32x4 h = {pack2<F16>(v0[0], v0[1]), pack2<F16>(v0[2], v0[3]), pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3])};
+        const u32x4 h = p.in16 ? ar[j][0]
+                               : u32x4{pack2<F16>(v0[0], v0[1]), pack2<F16>(v0[2], v0[3]), pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3])};
         *reinterpret_cast<u32x4 *>(lds + (sl[j] >= 2u * H16_STAGE ? 0 : stage * H16_STAGE) + sl[j]) = h;
     };
 
@@ -290,9 +291,9 @@ __global__ __launch_bounds__(256, 1) void k_conv1_h16(const ConvK p) {
     const int tb = __builtin_amdgcn_readfirstlane(wi / p.n_nblocks), nb = wi - tb * p.n_nblocks;
     const long m0 = (long)tb * 256;
     const int nch = p.Cin / 96;
-    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+    const unsigned pitch4 = (unsigned)p.in_pitch * (p.in16 ? 2u : 4u);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * p.in_pitch * 4), 0x00020000);
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * pitch4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * nch * 6 * 6144), 0x00020000);
 
@@ -300,20 +301,21 @@ __global__ __launch_bounds__(256, 1) void k_conv1_h16(const ConvK p) {
 #pragma unroll
     for (int j = 0; j < NUT; ++j) {
         const int u = tid + 256 * j, pix = u / 12, grp = u - pix * 12;
-        sv[j] = (unsigned)(m0 + pix) * pitch4 + grp * 32;
+        sv[j] = (unsigned)(m0 + pix) * pitch4 + grp * (p.in16 ? 16 : 32);
         sl[j] = (unsigned)(pix * H1_PITCH + grp * 16);
     }
     u32x4 ar[NUT][2];
     auto a_load = [&](int chunk) {
 #pragma unroll
         for (int j = 0; j < NUT; ++j) {
-            ar[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j], chunk * 384, 0);
-            ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] + 16, chunk * 384, 0);
+            ar[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j], chunk * (p.in16 ? 192 : 384), 0);
+            if (!p.in16) ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] + 16, chunk * 384, 0);
         }
     };
     auto a_store = [&](int stage, int j) {
         const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
-        const u32x4 h = {pack2<F16>(v0[0], v0[1]), pack2<F16>(v0[2], v0[3]), pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3])};
+        const u32x4 h = p.in16 ? ar[j][0]
+                               : u32x4{pack2<F16>(v0[0], v0[1]), pack2<F16>(v0[2], v0[3]), pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3])};
         *reinterpret_cast<u32x4 *>(lds + stage * H1_STAGE + sl[j]) = h;
     };
     unsigned aoff[4];

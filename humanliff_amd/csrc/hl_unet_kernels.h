@@ -70,6 +70,7 @@ struct ConvK {
     // output channel (sum, sum of squares) of the stored value (after bias / residual), [slot][Cout][2]; null = not wanted.
     // st2: the same for out2.  Deterministic (no atomics); k_gn_coef_st folds the slots of an image.
     float *st1, *st2;
+    int in16;          // k_conv_h16 / k_conv1_h16: `in` holds 16-bit values (the GroupNorm pass wrote them), in_pitch counts them
 };
 
 // k_conv_wino4w (hl_conv_wino4w.hip): Winograd F(4x4,3x3) with 64 output channels per workgroup, one wave per SIMD, 18 accumulator

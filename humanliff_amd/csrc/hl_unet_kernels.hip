@@ -1693,6 +1693,36 @@ __global__ void k_gn_apply(const float *__restrict__ x, long pitch, long pixels_
     }
 }
 
+// the same pass writing 16-bit values (fp16 / bf16, nearest even): the activation image of the k_conv_h16 / k_conv1_h16 layers behind a
+// GroupNorm - half the bytes written here and read there, no rounding in the convolution's staging
+__global__ void k_gn_apply_h16(const float *__restrict__ x, long pitch, long pixels_per_img, long npix, int C, const float *__restrict__ cA,
+                               const float *__restrict__ cB, int act, unsigned short *__restrict__ y, int f16) {
+    const int cq = C >> 2;
+    const long n4 = npix * cq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cq;
+        const int c = (int)(i - pix * cq) * 4;
+        const long n = pix / pixels_per_img;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + pix * pitch + c);
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(cA + n * C + c);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(cB + n * C + c);
+        f32x4 o = v * a + b;
+        if (act) { o[0] = silu_f(o[0]); o[1] = silu_f(o[1]); o[2] = silu_f(o[2]); o[3] = silu_f(o[3]); }
+        unsigned short h[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (f16) {
+                const _Float16 hh = (_Float16)o[k];
+                h[k] = __builtin_bit_cast(unsigned short, hh);
+            } else {
+                const unsigned u = __float_as_uint(o[k]);
+                h[k] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            }
+        }
+        *reinterpret_cast<uint2 *>(y + pix * C + c) = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+    }
+}
+
 // split-K epilogue: sum the slabs in a fixed order (deterministic), then bias / residual / second output
 __global__ void k_splitk_finish(const ConvK p, int splits) {
     const long total = p.M * p.Cout;
@@ -2752,14 +2782,15 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     }
     if (h16) {
         a.path = 5;
-        if (mode != 0) {   // GroupNorm(+SiLU) materialised once (fp32), the kernel rounds it to 16 bits while staging
+        if (mode != 0) {   // GroupNorm(+SiLU) materialised once, as the 16-bit image the kernel stages without conversion
             HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
             const long npix = a.in.pixels();
             long g = (npix * (a.in.C / 4) + 255) / 256;
             if (g > 4096) g = 4096;
-            hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix, a.in.C, a.coefA,
-                               a.coefB, a.act, a.act_ws);
+            hipLaunchKernelGGL(k_gn_apply_h16, dim3((unsigned)g), dim3(256), 0, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix, a.in.C, a.coefA,
+                               a.coefB, a.act, reinterpret_cast<unsigned short *>(a.act_ws), a.h16_fp16);
             p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0;
+            p.in16 = 1;                                  // in_pitch counts 16-bit elements now
             if (a.ev_mid) { hipEventRecord(a.ev_mid, st); a.ev_mid_used = 1; }
         }
         p.w_bf3 = a.w_h16;
