@@ -87,18 +87,19 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
         // in batches of 9 / 9 / 8: the residual loads of a batch are all in flight before its first store (on this ISA stores count on
         // vmcnt too: a load waited for behind a store waits for the store).  One channel quad per thread = GroupNorm sums without shuffles.
         const int pr0 = tid / 48, cq = (tid - pr0 * 48) * 4;
-        f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f}, sm2 = {0.f, 0.f, 0.f, 0.f}, sq2 = {0.f, 0.f, 0.f, 0.f};
         f32x4 bs = {0.f, 0.f, 0.f, 0.f};
         if (p.bias && pr0 < 5) bs = *reinterpret_cast<const f32x4 *>(p.bias + n0 + cq);
         auto finish = [&](auto kc0, auto nbc) {   // pixel slots pr0 + 5 (K0 .. K0 + NB - 1): every load of the batch in flight before its first store
             constexpr int K0 = decltype(kc0)::value, NB = decltype(nbc)::value;
             long mm[NB];
-            f32x4 v[NB], rr[NB];
+            f32x4 v[NB], rr[NB], r2[NB];
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const int pc = pr0 + 5 * (K0 + k);
                 mm[k] = pix(q, pc);
                 if (p.res) rr[k] = *reinterpret_cast<const f32x4 *>(p.res + mm[k] * p.res_pitch + n0 + cq);
+                if (p.out2) r2[k] = *reinterpret_cast<const f32x4 *>(p.res2 + mm[k] * p.res2_pitch + n0 + cq);
                 v[k] = *reinterpret_cast<const f32x4 *>(ep + pc * H16_EP + cq);
             }
 #pragma unroll
@@ -107,6 +108,11 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
                 if (p.res) v[k] += rr[k];
                 sm += v[k]; sq += v[k] * v[k];
                 *reinterpret_cast<f32x4 *>(p.out + mm[k] * p.out_pitch + n0 + cq) = v[k];
+                if (p.out2) {                                   // second output out2 = out + res2 (the control tower's zero convolution: unet.py:598-602)
+                    r2[k] += v[k];
+                    sm2 += r2[k]; sq2 += r2[k] * r2[k];
+                    *reinterpret_cast<f32x4 *>(p.out2 + mm[k] * p.out2_pitch + n0 + cq) = r2[k];
+                }
             }
         };
         if (pr0 < 5) {
@@ -115,11 +121,11 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
             finish(std::integral_constant<int, 17>{}, std::integral_constant<int, 8>{});
             if (pr0 < 3) finish(std::integral_constant<int, 25>{}, std::integral_constant<int, 1>{});      // slots 125, 126, 127
         }
-        if (p.st1) {   // GroupNorm statistics of the stored tensor: slot = (tile, round) = 128 pixels; the five pixel groups meet in LDS
+        auto put_stats = [&](float *st, const f32x4 a_sm, const f32x4 a_sq) {   // slot = (tile, round) = 128 pixels; the five pixel groups meet in LDS
             __syncthreads();
             if (pr0 < 5) {
-                *reinterpret_cast<f32x4 *>(ep + (pr0 * 48 * 2 + (cq >> 2) * 2) * 4) = sm;
-                *reinterpret_cast<f32x4 *>(ep + (pr0 * 48 * 2 + (cq >> 2) * 2 + 1) * 4) = sq;
+                *reinterpret_cast<f32x4 *>(ep + (pr0 * 48 * 2 + (cq >> 2) * 2) * 4) = a_sm;
+                *reinterpret_cast<f32x4 *>(ep + (pr0 * 48 * 2 + (cq >> 2) * 2 + 1) * 4) = a_sq;
             }
             __syncthreads();
             if (tid < 48) {
@@ -129,11 +135,13 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
                     a += *reinterpret_cast<const f32x4 *>(ep + (g * 48 * 2 + tid * 2) * 4);
                     b += *reinterpret_cast<const f32x4 *>(ep + (g * 48 * 2 + tid * 2 + 1) * 4);
                 }
-                float *d = p.st1 + ((tile * 2 + q) * p.Cout + n0 + tid * 4) * 2;
+                float *d = st + ((tile * 2 + q) * p.Cout + n0 + tid * 4) * 2;
                 *reinterpret_cast<f32x4 *>(d) = f32x4{a[0], b[0], a[1], b[1]};
                 *reinterpret_cast<f32x4 *>(d + 4) = f32x4{a[2], b[2], a[3], b[3]};
             }
-        }
+        };
+        if (p.st1) put_stats(p.st1, sm, sq);      // GroupNorm statistics of the stored tensor(s)
+        if (p.st2) put_stats(p.st2, sm2, sq2);
     }
 }
 

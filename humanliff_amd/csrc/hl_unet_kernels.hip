@@ -2772,7 +2772,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         p.partial = splits > 1 ? a.splitk_ws : nullptr;
     }
     // 16-bit operands (opt-in modes): the 3x3 / stride-1 layers k_conv_h16 covers; the rest of the mode stays on k_conv_bf3 / fp32
-    const bool h16 = a.w_h16 && (a.coefA == nullptr || (a.act_ws && !a.ups)) && !a.out_nchw && !a.out2 &&
+    const bool h16 = a.w_h16 && (a.coefA == nullptr || (a.act_ws && !a.ups)) && !a.out_nchw &&
                      conv_h16_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
                      ((long)a.out.N * a.out.H * a.out.W / 256) * (a.Cout / 192) >= h16_min_blocks() &&   // (fewer workgroups: the split-K fp32 kernels fill the chip better)
                      (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0;
@@ -2798,7 +2798,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         p.n_nblocks = a.Cout / 192;
         p.n_mtiles = (int)((long)a.out.N * a.out.H * a.out.W / 256);   // 16x16-pixel tiles (3x3) / runs of 256 pixels (1x1)
         if (a.stats) {   // statistics from the epilogue: slot = (tile, round) = 128 pixels
-            p.st1 = a.stats; p.st2 = nullptr;
+            p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
             a.stat_slots = a.out.H * a.out.W / 128;
         }
         return conv_h16_launch(p, a.h16_fp16, st);
