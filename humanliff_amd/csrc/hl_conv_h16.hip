@@ -98,9 +98,14 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
             for (int k = 0; k < NB; ++k) {
                 const int pc = pr0 + 5 * (K0 + k);
                 mm[k] = pix(q, pc);
-                if (p.res) rr[k] = *reinterpret_cast<const f32x4 *>(p.res + mm[k] * p.res_pitch + n0 + cq);
-                if (p.out2) r2[k] = *reinterpret_cast<const f32x4 *>(p.res2 + mm[k] * p.res2_pitch + n0 + cq);
+                if (p.res && !p.partial) rr[k] = *reinterpret_cast<const f32x4 *>(p.res + mm[k] * p.res_pitch + n0 + cq);
+                if (p.out2 && !p.partial) r2[k] = *reinterpret_cast<const f32x4 *>(p.res2 + mm[k] * p.res2_pitch + n0 + cq);
                 v[k] = *reinterpret_cast<const f32x4 *>(ep + pc * H16_EP + cq);
+            }
+            if (p.partial) {   // split-K slab: raw sums, [z][pixel][Cout]
+#pragma unroll
+                for (int k = 0; k < NB; ++k) *reinterpret_cast<f32x4 *>(p.partial + ((long)blockIdx.z * p.M + mm[k]) * p.Cout + n0 + cq) = v[k];
+                return;
             }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
@@ -140,8 +145,8 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
                 *reinterpret_cast<f32x4 *>(d + 4) = f32x4{a[2], b[2], a[3], b[3]};
             }
         };
-        if (p.st1) put_stats(p.st1, sm, sq);      // GroupNorm statistics of the stored tensor(s)
-        if (p.st2) put_stats(p.st2, sm2, sq2);
+        if (p.st1 && !p.partial) put_stats(p.st1, sm, sq);      // GroupNorm statistics of the stored tensor(s)
+        if (p.st2 && !p.partial) put_stats(p.st2, sm2, sq2);
     }
 }
 
@@ -213,9 +218,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
     const unsigned wv = (unsigned)lane * 16u;
     const int wbase = nb * nch * 18 * 6144 + wn * 3072;
     u32x4 ring[H16_RING][3];
-    // every workgroup walks the chunks from its own start (rot) and wraps: the 32 CUs of an XCD run in step, and reading the SAME weight
-    // lines at the same moment queues them all on the few L2 channels those lines live in (the 16-bit weights of a layer fit the L2)
-    const int rot = H16_ROT ? __builtin_amdgcn_readfirstlane(wi % nch) : 0;
+    // split-K (layers with few tiles): blockIdx.z owns the chunks [c0, c1) and stores raw accumulators to p.partial (k_splitk_finish sums
+    // the slabs in a fixed order and applies bias / residual / statistics).  (A per-workgroup rotation of the chunk order - H16_ROT,
+    // tried against L2-channel hot spots - changed nothing and is gone.)
+    const int c0 = (int)blockIdx.z * p.kt_per, c1 = min(nch, c0 + p.kt_per);
     auto w_load = [&](int slot_, int chunk, int s18) {
         const int so = wbase + (chunk * 18 + s18) * 6144;
 #pragma unroll
@@ -231,9 +237,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
             for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
 
     // ---- prologue: the first chunk staged, the first H16_RING k-steps of weights in flight
-    a_load(rot);
+    a_load(c0);
 #pragma unroll
-    for (int s = 0; s < H16_RING; ++s) w_load(s, rot, s);
+    for (int s = 0; s < H16_RING; ++s) w_load(s, c0 + s / 18 < nch ? c0 + s / 18 : c0, s % 18);
 #pragma unroll
     for (int j = 0; j < NUT; ++j) a_store(0, j);
     __syncthreads();
@@ -243,9 +249,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) dst[mf] = *reinterpret_cast<const u32x4 *>(st + (tap / 3) * (H16_LP * 64) + (aoff[mf][tap % 3] ^ (k2 ? 32u : 0u)));
     };
-    for (int c = 0; c < nch; ++c) {
-        const char *st = lds + (c & 1) * H16_STAGE;
-        const int cc = c + rot < nch ? c + rot : c + rot - nch;          // this chunk / the next one (past the end: a valid chunk, never used)
+    for (int c = c0; c < c1; ++c) {
+        const char *st = lds + ((c - c0) & 1) * H16_STAGE;
+        const int cc = c;                                                // this chunk / the next one (past the end: a valid chunk, never used)
         const int ccn = cc + 1 < nch ? cc + 1 : 0;
         if (!(H16_ABL & 2) && !(H16_ABL & 64)) a_load(ccn);              // (last chunk: a valid chunk again, staged and never read)
         a_read(st, 0, 0, af[0]);
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
                         if constexpr (!(H16_ABL & 8)) acc[mf][nf] = mma<F16>(af[(H16_ABL & 4) ? 0 : cur][mf], ring[rs][nf], acc[mf][nf]);
                 if constexpr (!(H16_ABL & 1)) w_load(rs, S + H16_RING < 18 ? cc : ccn, (S + H16_RING) % 18);
                 if constexpr (S >= H16_ST0 && S < H16_ST0 + NUT) {
-                    if (!(H16_ABL & 2) && !(H16_ABL & 32)) a_store((c + 1) & 1, S - H16_ST0);
+                    if (!(H16_ABL & 2) && !(H16_ABL & 32)) a_store((c - c0 + 1) & 1, S - H16_ST0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }(), ...);
@@ -463,9 +469,10 @@ int conv_pack_weights_h16(const float *w, int Cout, int Cin, int Cin_pad, int ks
 
 size_t conv_h16_lds_bytes() { return (size_t)2 * H1_STAGE; }   // 104 KB: the two 1x1 stages (the epilogue exchange needs 98 KB, the 3x3 patch stages 45 KB)
 
-int conv_h16_launch(const ConvK &p, int f16, hipStream_t st) {
+int conv_h16_launch(const ConvK &p, int f16, hipStream_t st, int splits) {
     HL_REQUIRE(p.w_bf3 && conv_h16_applies(p.Hout, p.Wout, p.Cin, p.Cout, p.ks, p.stride, p.ups), "k_conv_h16: bad layer");
-    const dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks));
+    HL_REQUIRE(splits == 1 || (p.ks == 3 && p.partial), "k_conv_h16: split-K is the 3x3 kernel's");
+    const dim3 grid((unsigned)(p.n_mtiles * p.n_nblocks), 1, (unsigned)splits);
     const size_t sh = conv_h16_lds_bytes();
     static const bool attr_ok = [] {
         const int b = (int)conv_h16_lds_bytes();

@@ -83,7 +83,7 @@ int conv_wino4w_launch(const ConvK &p, int ups, int blk, int splits, hipStream_t
 bool conv_h16_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int ups);
 size_t conv_packed_h16_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_h16(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, int f16, hipStream_t st, int tf = 0);
-int conv_h16_launch(const ConvK &p, int f16, hipStream_t st);
+int conv_h16_launch(const ConvK &p, int f16, hipStream_t st, int splits = 1);
 
 inline size_t conv_stats_floats(long out_pixels, int Cout) { return (size_t)(out_pixels / 32 + 1) * Cout * 2; }
 size_t conv_splitk_ws_bytes();

@@ -2772,10 +2772,21 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         p.partial = splits > 1 ? a.splitk_ws : nullptr;
     }
     // 16-bit operands (opt-in modes): the 3x3 / stride-1 layers k_conv_h16 covers; the rest of the mode stays on k_conv_bf3 / fp32
-    const bool h16 = a.w_h16 && (a.coefA == nullptr || (a.act_ws && !a.ups)) && !a.out_nchw &&
-                     conv_h16_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
-                     ((long)a.out.N * a.out.H * a.out.W / 256) * (a.Cout / 192) >= h16_min_blocks() &&   // (fewer workgroups: the split-K fp32 kernels fill the chip better)
-                     (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0;
+    // 16-bit operands (opt-in modes): the 3x3 / 1x1 stride-1 layers k_conv_h16 / k_conv1_h16 cover, from h16_min_blocks() workgroups on; a 3x3
+    // layer with fewer tiles splits its input channels into slabs of >= 2 chunks (k_splitk_finish sums them) until ~128 workgroups run
+    const long h16_blocks = ((long)a.out.N * a.out.H * a.out.W / 256) * (a.Cout / 192);
+    bool h16 = a.w_h16 && (a.coefA == nullptr || (a.act_ws && !a.ups)) && !a.out_nchw &&
+               conv_h16_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
+               (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0 && h16_blocks > 0;
+    int h16_splits = 1;
+    if (h16 && h16_blocks < h16_min_blocks()) {
+        const int nch32 = a.in.C / 32;
+        if (a.ks == 3 && a.splitk_ws && !a.out2 && h16_blocks >= 4) {
+            h16_splits = (int)std::min<long>(std::min<long>(128 / h16_blocks, nch32 / 2), 16);
+            while (h16_splits > 1 && (size_t)h16_splits * M * a.Cout * sizeof(float) > a.splitk_ws_bytes) --h16_splits;
+        }
+        if (h16_splits < 2 || h16_blocks * h16_splits < h16_min_blocks()) { h16 = false; h16_splits = 1; }
+    }
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
         a.path = h16 ? 5 : (wino4 ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
         return HL_OK;
@@ -2794,12 +2805,22 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             if (a.ev_mid) { hipEventRecord(a.ev_mid, st); a.ev_mid_used = 1; }
         }
         p.w_bf3 = a.w_h16;
-        p.partial = nullptr;
+        splits = h16_splits;
+        p.kt_per = (a.in.C / 32 + splits - 1) / splits;                  // chunks of 32 input channels per slab
+        splits = (a.in.C / 32 + p.kt_per - 1) / p.kt_per;
+        p.partial = splits > 1 ? a.splitk_ws : nullptr;
         p.n_nblocks = a.Cout / 192;
         p.n_mtiles = (int)((long)a.out.N * a.out.H * a.out.W / 256);   // 16x16-pixel tiles (3x3) / runs of 256 pixels (1x1)
         if (a.stats) {   // statistics from the epilogue: slot = (tile, round) = 128 pixels
             p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
             a.stat_slots = a.out.H * a.out.W / 128;
+        }
+        if (splits > 1) {   // the finish kernel emits the statistics
+            p.st1 = p.st2 = nullptr;
+            a.stat_slots = 0;
+            int rc = conv_h16_launch(p, a.h16_fp16, st, splits);
+            if (rc) return rc;
+            return finish("k_conv_h16");
         }
         return conv_h16_launch(p, a.h16_fp16, st);
     }

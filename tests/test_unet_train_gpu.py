@@ -619,3 +619,33 @@ def test_fp16_mode_keeps_tiny_gradients():
     e_dx, e_dw = rel(nchw(xd.grad.cpu()), xr.grad), rel(wd.grad.cpu(), wr.grad)
     print(f"output gradient ~1e-8: backward-data rel-L2 {e_dx:.2e}, weight gradient rel-L2 {e_dw:.2e}")
     assert e_dx < 5e-3 and e_dw < 5e-3
+
+
+@pytest.mark.parametrize("f16", [0, 1])
+def test_conv_h16_split_k_on_small_layers(f16):
+    """3x3 layers with fewer than 48 tiles x channel blocks split their input channels into slabs (k_conv_h16 with blockIdx.z, raw sums to the
+    split-K workspace, k_splitk_finish adds them in a fixed order with bias / residual): still the convolution of the rounded operands."""
+    from humanliff_amd import _lib
+    L = _lib.lib()
+    mode, dt = (_lib.HL_CONV_FP16, torch.float16) if f16 else (_lib.HL_CONV_BF16, torch.bfloat16)
+    for (N, H, W, C, Co, use_res) in ((2, 32, 32, 576, 576, 1), (4, 16, 16, 768, 768, 0), (1, 32, 32, 1152, 192, 1)):
+        g = torch.Generator().manual_seed(N + C)
+        x = torch.randn((N, H, W, C), generator=g); w = torch.randn((Co, C, 3, 3), generator=g) / (C * 9) ** 0.5; b = torch.randn(Co, generator=g)
+        res = torch.randn((N, H, W, Co), generator=g)
+        ref = F.conv2d(x.to(dt).double().permute(0, 3, 1, 2), w.to(dt).double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        if use_res:
+            ref = ref + res.double()
+        xd, wd, bd, rd = (t.to(dev) for t in (x, w, b, res))
+        outs = []
+        for _ in range(2):
+            out = torch.zeros((N, H, W, Co), device=dev)
+            scratch = torch.empty(Co * C * 9 * 6 + 256 + (16 << 20), device=dev)
+            with _lib.on(dev):
+                _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(xd), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Co, 3, 1, 0, None, None, 0,
+                                                 _lib.ptr(rd) if use_res else None, _lib.ptr(out), _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()),
+                           "hl_conv2d_nhwc_mode")
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+        err = float((outs[0].cpu().double() - ref).abs().max())
+        rel = float((outs[0].cpu().double() - ref).norm() / ref.norm())
+        assert err < 5e-5 and rel < 2e-6, (N, H, W, C, Co, err, rel)      # (the fp32 kernels would sit at the operand rounding: rel 2e-4 / 2e-3)
