@@ -53,9 +53,6 @@ constexpr int H16_STAGE = H16_PW * H16_LP * 64;              // bytes per patch 
 #ifndef H16_ABL   // timing ablations (wrong results): 1 no weight loads in the loop, 2 no patch loads / staging in the loop, 4 no A-fragment reads, 8 no MFMA
 #define H16_ABL 0
 #endif
-#ifndef H16_ROT
-#define H16_ROT 0
-#endif
 #ifndef H16_ST0
 #define H16_ST0 12                                        // k-step behind which the next chunk's patch goes to LDS (6 units, one per step)
 #endif
@@ -219,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
     const int wbase = nb * nch * 18 * 6144 + wn * 3072;
     u32x4 ring[H16_RING][3];
     // split-K (layers with few tiles): blockIdx.z owns the chunks [c0, c1) and stores raw accumulators to p.partial (k_splitk_finish sums
-    // the slabs in a fixed order and applies bias / residual / statistics).  (A per-workgroup rotation of the chunk order - H16_ROT,
+    // the slabs in a fixed order and applies bias / residual / statistics).  (A per-workgroup rotation of the chunk order,
     // tried against L2-channel hot spots - changed nothing and is gone.)
     const int c0 = (int)blockIdx.z * p.kt_per, c1 = min(nch, c0 + p.kt_per);
     auto w_load = [&](int slot_, int chunk, int s18) {
