@@ -66,6 +66,7 @@ class Renderer(nn.Module):
         # (recon_NeRF/lib/renderer.py:288) does not clamp and clears the second flag
         self._depth_flags = _lib.HL_RENDER_NORMALIZE_DEPTH | _lib.HL_RENDER_CLAMP_DEPTH
         self.uniforms_on_device = False      # extension: draw sample_pdf's uniforms with the device generator (see render())
+        self.mlp_fp16 = False                # extension, opt-in: the MLP with fp16 operands / fp32 accumulation (HL_RENDER_MLP_FP16, k_march16)
         self._ws = None
 
     # ---- packing caches ------------------------------------------------------------------------
@@ -183,7 +184,7 @@ class Renderer(nn.Module):
         acc = torch.empty((bs, R), dtype=torch.float32, device=dev)
         depth = torch.empty((bs, R), dtype=torch.float32, device=dev)
         flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0) | \
-            (_lib.HL_RENDER_REEVALUATE if reevaluate else 0)
+            (_lib.HL_RENDER_REEVALUATE if reevaluate else 0) | (_lib.HL_RENDER_MLP_FP16 if getattr(self, "mlp_fp16", False) else 0)
         f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
         for b in range(bs):
             pp = self._packed_planes(tri_planes[b])

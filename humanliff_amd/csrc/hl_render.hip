@@ -572,6 +572,221 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_march16: the evaluate pass (FULL + STORE) with fp16 operands / fp32 accumulation on v_mfma_f32_32x32x16_f16 - OPT-IN
+// (HL_RENDER_MLP_FP16), never the default.  The accumulator-is-the-next-B-operand identity survives the wider k-step with a permuted k
+// order: a 16-wide k-step takes, from each lane half, EIGHT of the accumulator registers that half already holds (registers 8jj..8jj+7 of
+// input tile tin: units unit_of(tin, r, half)) - the weights are packed in that order (k_pack_mlp16), so a layer's input is its
+// producer's accumulators rounded to fp16 in place, no cross-lane traffic.  128 -> 128 is 32 MFMAs of 32 cycles instead of 256 of 64, and
+// all 132 KB of 16-bit weights sit in LDS for the whole launch: no weight ring, no barrier in the sample loop.
+// Fragment f of the packed image = [lane 64][8 halfs]; parts in consumption order, fragment (part, j, t) at part_base + j * nt + t:
+constexpr int P16_L0 = 0, P16_L1 = 8, P16_L2F = 40, P16_L2H = 48, P16_FEAT = 80, P16_VH = 112, P16_VE = 128, P16_FRAGS = 132;
+struct Part16 { int w, ld, col0, kind, nt, nj, base; };
+__constant__ Part16 c_parts16[7] = {{0, 27, 0, 0, 4, 2, P16_L0},   {1, 128, 0, 1, 4, 8, P16_L1},   {2, 155, 0, 0, 4, 2, P16_L2F}, {2, 155, 27, 1, 4, 8, P16_L2H},
+                                    {3, 128, 0, 1, 4, 8, P16_FEAT}, {4, 155, 0, 1, 2, 8, P16_VH},   {4, 155, 128, 2, 2, 2, P16_VE}};
+
+__global__ void k_pack_mlp16(PackArgs a, unsigned short *out16) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P16_FRAGS * 512) return;
+    const int i = idx & 7, lane = (idx >> 3) & 63, f = idx >> 9;
+    int pi = 6;
+    while (pi > 0 && f < c_parts16[pi].base) --pi;
+    const Part16 d = c_parts16[pi];
+    const int rel = f - d.base, j = rel / d.nt, t = rel - j * d.nt;
+    const int g = lane >> 5, outu = 32 * t + (lane & 31);
+    int in = -1;
+    if (d.kind == 1) {
+        in = unit_of(j >> 1, (j & 1) * 8 + i, g);
+    } else {
+        const int sidx = j * 8 + i, per = d.kind == 0 ? 15 : 14, k = sidx + per * g;
+        if (sidx < per && k < 27) in = k;
+    }
+    const float v = in >= 0 ? a.w[d.w][outu * d.ld + d.col0 + in] : 0.f;
+    const _Float16 h = (_Float16)v;
+    out16[idx] = __builtin_bit_cast(unsigned short, h);
+}
+
+__device__ __forceinline__ u32x4 cvt_h8(const f32x16 &v, int hi) {   // registers 8hi..8hi+7 -> 8 fp16 (nearest even)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const h2 h = {(_Float16)v[8 * hi + 2 * q], (_Float16)v[8 * hi + 2 * q + 1]};
+        o[q] = __builtin_bit_cast(unsigned, h);
+    }
+    return o;
+}
+template <int NT>
+__device__ __forceinline__ void mma_h(f32x16 (&acc)[NT], const u32x4 b, const u32x4 *__restrict__ frags, int lane) {   // frags: NT consecutive fragments
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, frags[t * 64 + lane]), __builtin_bit_cast(h8, b), acc[t], 0, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void k_march16(const MarchArgs a, const unsigned short *__restrict__ packed16) {
+    extern __shared__ __attribute__((aligned(16))) float lds16[];
+    constexpr int NT = 512;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const long long wg = (long long)xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
+    const long long tile = wg * 8 + (tid >> 6);
+    const long long ray = tile * 32 + (lane & 31);
+    const bool valid = ray < a.R;
+    const long long rc = valid ? ray : a.R - 1;
+    const long long tiles_n = (a.R + 31) / 32;
+    const long long zt_base = (tile < tiles_n ? tile : tiles_n - 1) * 32 * (long long)a.S + (lane & 31);
+
+    // LDS: [P16_FRAGS fragments of 1 KB][small parameter block, fp32, as k_march's]
+    u32x4 *fr = reinterpret_cast<u32x4 *>(lds16);
+    const u32x4 *g16 = reinterpret_cast<const u32x4 *>(packed16);
+    for (int i = tid; i < P16_FRAGS * 64; i += NT) fr[i] = g16[i];
+    float *small = lds16 + P16_FRAGS * 256;
+    for (int i = tid; i < SMALL_FLOATS; i += NT) small[i] = a.packed[NCH_FULL * CHUNK_FLOATS + i];
+
+    const float ox = a.rays_o[rc * 3 + 0], oy = a.rays_o[rc * 3 + 1], oz = a.rays_o[rc * 3 + 2];
+    const float dx = a.rays_d[rc * 3 + 0], dy = a.rays_d[rc * 3 + 1], dz = a.rays_d[rc * 3 + 2];
+    const float nr = a.near[rc], fr_ = a.far[rc];
+    const int S = a.S;
+    const float offH = (float)(1.0 / (double)a.H);
+    const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
+    const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
+
+    // view-direction encoding, this half's 14 of the 27 (+1 pad) entries (as k_march)
+    f32x16 ev;
+    {
+        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float vd[3] = {dx / nrm, dy / nrm, dz / nrm};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float val = 0.f;
+            if (s < 14) {
+                const int kl = s, kh = s + 14;
+                const int jl = (kl - 3) / 3, cl = (kl - 3) % 3, jh = (kh - 3) / 3, ch = (kh - 3) % 3;
+                const float argl = kl < 3 ? 0.f : ((jl & 1) ? 1.57079632679489661923f : 0.f) + vd[kl < 3 ? 0 : cl] * (float)(1 << (jl >> 1));
+                const float argh = ((jh & 1) ? 1.57079632679489661923f : 0.f) + vd[ch] * (float)(1 << (jh >> 1));
+                if (kl < 3) {
+                    const float sh = sinf(argh);
+                    val = half ? sh : vd[kl];
+                } else if (kh >= 27) {
+                    const float sl = sinf(argl);
+                    val = half ? 0.f : sl;
+                } else {
+                    val = sinf(half ? argh : argl);
+                }
+            }
+            ev[s] = val;
+        }
+    }
+    const u32x4 bev0 = cvt_h8(ev, 0), bev1 = cvt_h8(ev, 1);
+
+    float zc;
+    if (a.z) zc = a.z_tiled ? a.z[zt_base] : a.z[rc * S];
+    else zc = nr * (1.f - linspace01(0, S)) + fr_ * linspace01(0, S);
+    __syncthreads();
+
+    for (int s = 0; s < S; ++s) {
+        float zn = 0.f;
+        if (s + 1 < S) {
+            if (a.z) zn = a.z_tiled ? a.z[zt_base + 32LL * (s + 1)] : a.z[rc * S + s + 1];
+            else { const float t = linspace01(s + 1, S); zn = nr * (1.f - t) + fr_ * t; }
+        }
+        // ---- tri-plane features of this half (fp32, exactly as k_march)  [renderer.py:502-531] ----
+        const float px = ox + dx * zc, py = oy + dy * zc, pz = oz + dz * zc;
+        const float nx = 2.f * (px - bmin0) / bext0 - 1.f;
+        const float ny = 2.f * (py - bmin1) / bext1 - 1.f;
+        const float nz = 2.f * (pz - bmin2) / bext2 - 1.f;
+        f32x16 f;
+        f[15] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int qlo = i, qhi = (i + 5 > 8) ? 8 : i + 5;
+            const int q = half ? qhi : qlo;
+            const int p = half ? qhi / 3 : qlo / 3, g = half ? qhi % 3 : qlo % 3;
+            float gu = (p == 2) ? nz : nx;
+            float gv = (p == 1) ? nz : ny;
+            gu = (g == 1) ? gu + offH : gu;
+            gv = (g == 2) ? gv + offH : gv;
+            const float ix = ((gu + 1.f) * (float)a.W - 1.f) / 2.f;
+            const float iy = ((gv + 1.f) * (float)a.H - 1.f) / 2.f;
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+            float w_nw = (x1f - ix) * (y1f - iy), w_ne = (ix - x0f) * (y1f - iy);
+            float w_sw = (x1f - ix) * (iy - y0f), w_se = (ix - x0f) * (iy - y0f);
+            const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+            const bool vx0 = (x0 >= 0) & (x0 < a.W), vx1 = (x1 >= 0) & (x1 < a.W);
+            const bool vy0 = (y0 >= 0) & (y0 < a.H), vy1 = (y1 >= 0) & (y1 < a.H);
+            w_nw = (vx0 & vy0) ? w_nw : 0.f;
+            w_ne = (vx1 & vy0) ? w_ne : 0.f;
+            w_sw = (vx0 & vy1) ? w_sw : 0.f;
+            w_se = (vx1 & vy1) ? w_se : 0.f;
+            const int cx0 = min(max(x0, 0), a.W - 1), cx1 = min(max(x1, 0), a.W - 1);
+            const int cy0 = min(max(y0, 0), a.H - 1), cy1 = min(max(y1, 0), a.H - 1);
+            const float4 *pl = a.planes + (long long)q * a.H * a.W;
+            const float4 t_nw = pl[cy0 * a.W + cx0], t_ne = pl[cy0 * a.W + cx1];
+            const float4 t_sw = pl[cy1 * a.W + cx0], t_se = pl[cy1 * a.W + cx1];
+            const bool live = half ? (i + 5 <= 8) : true;
+            const float r0 = t_nw.x * w_nw + t_ne.x * w_ne + t_sw.x * w_sw + t_se.x * w_se;
+            const float r1 = t_nw.y * w_nw + t_ne.y * w_ne + t_sw.y * w_sw + t_se.y * w_se;
+            const float r2 = t_nw.z * w_nw + t_ne.z * w_ne + t_sw.z * w_sw + t_se.z * w_se;
+            f[3 * i + 0] = live ? r0 : 0.f;
+            f[3 * i + 1] = live ? r1 : 0.f;
+            f[3 * i + 2] = live ? r2 : 0.f;
+        }
+        const u32x4 bf0 = cvt_h8(f, 0), bf1 = cvt_h8(f, 1);
+        // ---- MLP  [renderer.py:134-156] ----
+        f32x16 X[4], Y[4];
+        load_bias<4>(X, small + SM_B0, half);
+        mma_h<4>(X, bf0, fr + (P16_L0 + 0) * 64, lane);
+        mma_h<4>(X, bf1, fr + (P16_L0 + 4) * 64, lane);
+        load_bias<4>(Y, small + SM_B1, half);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            X[k] = softplus16(X[k]);
+            mma_h<4>(Y, cvt_h8(X[k], 0), fr + (P16_L1 + (2 * k) * 4) * 64, lane);
+            mma_h<4>(Y, cvt_h8(X[k], 1), fr + (P16_L1 + (2 * k + 1) * 4) * 64, lane);
+        }
+        load_bias<4>(X, small + SM_B2, half);
+        mma_h<4>(X, bf0, fr + (P16_L2F + 0) * 64, lane);
+        mma_h<4>(X, bf1, fr + (P16_L2F + 4) * 64, lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            Y[k] = softplus16(Y[k]);
+            mma_h<4>(X, cvt_h8(Y[k], 0), fr + (P16_L2H + (2 * k) * 4) * 64, lane);
+            mma_h<4>(X, cvt_h8(Y[k], 1), fr + (P16_L2H + (2 * k + 1) * 4) * 64, lane);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = softplus16(X[k]);
+        const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];
+        load_bias<4>(Y, small + SM_BF, half);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mma_h<4>(Y, cvt_h8(X[k], 0), fr + (P16_FEAT + (2 * k) * 4) * 64, lane);
+            mma_h<4>(Y, cvt_h8(X[k], 1), fr + (P16_FEAT + (2 * k + 1) * 4) * 64, lane);
+        }
+        f32x16 V[2];
+        load_bias<2>(V, small + SM_BV, half);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mma_h<2>(V, cvt_h8(Y[k], 0), fr + (P16_VH + (2 * k) * 2) * 64, lane);
+            mma_h<2>(V, cvt_h8(Y[k], 1), fr + (P16_VH + (2 * k + 1) * 2) * 64, lane);
+        }
+        mma_h<2>(V, bev0, fr + (P16_VE + 0) * 64, lane);
+        mma_h<2>(V, bev1, fr + (P16_VE + 2) * 64, lane);
+        V[0] = softplus16(V[0]);
+        V[1] = softplus16(V[1]);
+        const float cr = dot_lane<2>(V, small + SM_RW, half) + small[SM_RB + 0];
+        const float cg = dot_lane<2>(V, small + SM_RW + 64, half) + small[SM_RB + 1];
+        const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
+        if (tile * 32 < a.R) {   // lanes 0-31 store (sigma, r), lanes 32-63 (g, b)
+            const float2 rec = half ? make_float2(cg, cb) : make_float2(sigma_raw, cr);
+            float *dst = reinterpret_cast<float *>(a.vals_out + (zt_base + 32LL * s)) + 2 * half;
+            asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst), "v"(rec) : "memory");
+        }
+        zc = zn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // importance sampling + merge: one wave per ray   [renderer.py:158-170, 533-563, 252-253]
 // ---------------------------------------------------------------------------------------------
 constexpr int IMP_MAX_N = 512;
@@ -2120,7 +2335,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 
 extern "C" {
 
-size_t hl_render_mlp_packed_bytes(void) { return (size_t)PACKED_FLOATS * sizeof(float); }
+size_t hl_render_mlp_packed_bytes(void) { return (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024; }   // fp32 image + the fp16 fragments of k_march16
 
 int hl_render_mlp_pack(const hl_render_mlp_params *p, void *packed, void *stream) {
     HL_REQUIRE(p && packed, "hl_render_mlp_pack: null argument");
@@ -2132,7 +2347,11 @@ int hl_render_mlp_pack(const hl_render_mlp_params *p, void *packed, void *stream
     HL_REQUIRE(a.alpha_w && a.alpha_b && a.rgb_w && a.rgb_b, "hl_render_mlp_pack: null head weight");
     a.out = (float *)packed;
     hipLaunchKernelGGL(k_pack_mlp, dim3((PACKED_FLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
-    return hl::check_launch("k_pack_mlp");
+    int rc = hl::check_launch("k_pack_mlp");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pack_mlp16, dim3(P16_FRAGS * 2), dim3(256), 0, (hipStream_t)stream, a,
+                       reinterpret_cast<unsigned short *>(static_cast<float *>(packed) + PACKED_FLOATS));
+    return hl::check_launch("k_pack_mlp16");
 }
 
 size_t hl_planes_packed_bytes(int H, int W) { return (size_t)9 * H * W * sizeof(float4); }
@@ -2221,18 +2440,34 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
                             n_total_samples, flags, rgb, acc, depth, stream);
 }
 
-int hl_render_eval(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
-                   const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
-                   int n_samples, float *records_out, void *stream) {
+static int render_eval_impl(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
+                            const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
+                            int n_samples, float *records_out, int mlp_fp16, void *stream) {
     HL_REQUIRE(n_rays > 0 && n_samples >= 1 && records_out, "hl_render_eval: bad argument");
     MarchArgs a{};
     int rcode = fill_march(a, mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far);
     if (rcode) return rcode;
     a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
+    if (mlp_fp16) {   // HL_RENDER_MLP_FP16 (opt-in): fp16 operands, all weights LDS-resident
+        const size_t sh = (size_t)P16_FRAGS * 1024 + SMALL_FLOATS * sizeof(float);
+        static const bool attr_ok = hipFuncSetAttribute((const void *)k_march16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)((size_t)P16_FRAGS * 1024 + SMALL_FLOATS * sizeof(float))) == hipSuccess;
+        HL_REQUIRE(attr_ok, "k_march16: cannot raise the dynamic LDS limit to %zu bytes", sh);
+        hipLaunchKernelGGL(k_march16, dim3((unsigned)((n_rays + 255) / 256)), dim3(512), sh, (hipStream_t)stream, a,
+                           reinterpret_cast<const unsigned short *>(static_cast<const float *>(mlp_packed) + PACKED_FLOATS));
+        return hl::check_launch("k_march16");
+    }
     // (4-wave workgroups, two per CU with independent barriers, measured equal - 74.5 vs 74.7 ms per view - at twice the weight
     //  traffic: 8 waves it is)
     hipLaunchKernelGGL((k_march<true, true, 8>), dim3((unsigned)((n_rays + 255) / 256)), dim3(512), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_march<eval>");
+}
+
+int hl_render_eval(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
+                   const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
+                   int n_samples, float *records_out, void *stream) {
+    return render_eval_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z, z_tiled, n_rays, n_samples, records_out, 0,
+                            stream);
 }
 
 int hl_render_importance_new(const float *records, const float *rays_d, const float *near, const float *far, const float *z_vals,
@@ -2471,13 +2706,14 @@ int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int
             const size_t T32 = (size_t)tiles32(n_rays) * 32;
             float *vc = (float *)workspace, *vn = vc + T32 * n_samples * 4;
             float *zn = vn + T32 * n_importance * 4;
-            int rcode = hl_render_eval(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, 0, n_rays, n_samples,
-                                       vc, stream);
+            const int h16 = (flags & HL_RENDER_MLP_FP16) ? 1 : 0;
+            int rcode = render_eval_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, 0, n_rays, n_samples,
+                                         vc, h16, stream);
             if (rcode) return rcode;
             rcode = hl_render_importance_new(vc, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, zn, stream);
             if (rcode) return rcode;
-            rcode = hl_render_eval(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, zn, 1, n_rays, n_importance, vn,
-                                   stream);
+            rcode = render_eval_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, zn, 1, n_rays, n_importance, vn,
+                                     h16, stream);
             if (rcode) return rcode;
             return hl_render_composite(near, far, z_vals, zn, vc, vn, n_rays, n_samples, n_importance, flags, rgb, acc, depth, stream);
         }

@@ -71,6 +71,9 @@ int hl_planes_pack(const float *planes, int H, int W, void *packed, void *stream
 #define HL_RENDER_CLAMP_DEPTH 8u     /* clamp the normalised depth to [0,1]: NeRF/renderer.py:272-274 - the human_diffusion twin only,
                                         recon_NeRF/lib/renderer.py leaves it unclamped */
 
+#define HL_RENDER_MLP_FP16 16u       /* opt-in (hl_render_rays, evaluate-once pipeline): the MLP with fp16 operands / fp32 accumulation
+                                        (k_march16, all weights LDS-resident); features, encodings, softplus, compositing stay fp32 */
+
 size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
 
 /* Replaces Renderer.render (human_diffusion/NeRF/renderer.py:234-281,
