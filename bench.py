@@ -551,6 +551,14 @@ def e2e_slice(model, dev, rank, world, n_layers=4, ddim=50, n_views=185, res=512
         finally:
             model.set_conv_mode("fp32")
         ps = []
+        rend.mlp_fp16 = True                                      # ... and rendered by the fp16-operand MLP (Renderer.mlp_fp16)
+        render_fn(0, last, 0)
+        torch.cuda.synchronize()
+        tr16 = time.perf_counter()
+        for v in range(n_views):
+            render_fn(0, last, v)
+        torch.cuda.synchronize()
+        tr16 = time.perf_counter() - tr16
         for i in range(n_check_views):
             v = (i * n_views) // n_check_views
             img16 = render_fn(0, last, v)
@@ -558,10 +566,14 @@ def e2e_slice(model, dev, rank, world, n_layers=4, ddim=50, n_views=185, res=512
             b = images[0, v].reshape(-1, 3).cpu().float()
             mse = float(((a - b) ** 2).mean())
             ps.append(99.0 if mse == 0 else 10 * math.log10(255.0 ** 2 / mse))
+        rend.mlp_fp16 = False
         tp_mse = float(((last[0] - samples[0, -1]) ** 2).mean())
-        out["fp16_mode"] = {"what": "the same subject sampled in UNetModel.set_conv_mode('fp16') (opt-in; same noise, layers chained the same way) and rendered (fp32 "
-                                    "renderer): sampling time, and the PSNR of the uint8 images / of the last layer's tri-plane against the fp32 slice above",
+        out["fp16_mode"] = {"what": "the same subject sampled in UNetModel.set_conv_mode('fp16') and rendered with Renderer.mlp_fp16 (both opt-in; same noise, layers "
+                                    "chained the same way): sampling and rendering time (rendering without the uint8 conversion / gather of the slice), and the "
+                                    "PSNR of the uint8 images / of the last layer's tri-plane against the fp32 slice above",
                             "sampling_seconds": round(t16, 3), "denoise_steps_per_sec": round(n_layers * ddim / t16, 2),
+                            "rendering_seconds": round(tr16, 3), "mrays_per_sec": round(n_views * res * res / tr16 / 1e6, 3),
+                            "seconds_per_subject": round(t16 + tr16, 3),
                             "image_psnr_db_min": round(min(ps), 2), "image_psnr_db_views": [round(v, 2) for v in ps],
                             "triplane_psnr_db": round(10 * math.log10(float(samples[0, -1].abs().max()) ** 2 / tp_mse), 2) if tp_mse > 0 else 99.0}
     return out
@@ -718,6 +730,27 @@ def bench_render(args, rank, world, dev):
                                 "what": "Renderer.density_grid(resolution=512): the field extract_geometry hands to marching cubes, on k_march<false> "
                                         "(coarse density pass), including the host-side launch loop and the untile copies"}
         del grid
+        # ---- opt-in: the MLP with fp16 operands / fp32 accumulation (Renderer.mlp_fp16, k_march16); not `value` ----
+        ref_imgs = [mine[v].clone() for v in range(min(views, 3))]
+        r.mlp_fp16 = True
+        try:
+            one(views)
+            torch.cuda.synchronize()
+            th_ = time.perf_counter()
+            imgs16 = [one(v)["rgb_map"] for v in range(views)]
+            torch.cuda.synchronize()
+            d16 = time.perf_counter() - th_
+        finally:
+            r.mlp_fp16 = False
+        ps = []
+        for v in range(len(ref_imgs)):
+            mse = float(((imgs16[v] - ref_imgs[v]) ** 2).mean())
+            ps.append(99.0 if mse == 0 else 10 * math.log10(1.0 / mse))
+        roof["fp16_mode"] = {"what": "Renderer.mlp_fp16 / HL_RENDER_MLP_FP16 (opt-in): the MLP on v_mfma_f32_32x32x16_f16 - fp16 operands, fp32 accumulation, "
+                                     "all weights LDS-resident (k_march16); tri-plane gather, encodings, softplus, importance sampling and compositing "
+                                     "stay fp32.  NOT used for `value`",
+                             "value": round(views * R / d16 / 1e6, 4), "unit": "Mrays/s", "ms_per_view": round(d16 * 1e3 / views, 3),
+                             "psnr_db_vs_fp32_views": [round(x, 1) for x in ps], "finite": bool(torch.isfinite(imgs16[0]).all())}
     return secs, roof, views * R
 
 

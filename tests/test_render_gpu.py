@@ -28,8 +28,9 @@ def make_renderer(mlp, dev):
     return r.to(dev)
 
 
-def hip_render(i, dev, z_vals=None):
+def hip_render(i, dev, z_vals=None, mlp_fp16=False):
     r = make_renderer(i["mlp"], dev)
+    r.mlp_fp16 = mlp_fp16
     tp = {"world_bounds": i["bounds"][None].to(dev)}
     out = r.render(tp, None, z_vals, i["rays_o"][None].to(dev), i["rays_d"][None].to(dev), i["near"][None, :, None].to(dev),
                    i["far"][None, :, None].to(dev), i["planes"].to(dev), i["n_importance"], i["white_bkgd"],
@@ -53,6 +54,21 @@ def test_render_matches_reference_golden(name, dev):
     assert (out["depth_map"] - e["depth"]).abs().max() < 5e-5
     assert psnr(out["rgb_map"], e["rgb"]) > 90.0                   # north-star bar is 45 dB
     assert out["normal_map"].data_ptr() == out["rgb_map"].data_ptr() or torch.equal(out["normal_map"], out["rgb_map"])
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_fp16_mlp_mode_meets_the_north_star_bar_against_the_reference(name, dev):
+    """Renderer.mlp_fp16 (opt-in; k_march16: fp16 operands, fp32 accumulation, everything around the MLP fp32) against the REFERENCE's golden
+    renders: the north-star bar is PSNR >= 45 dB; ragged ray counts included (the fixtures are not multiples of 32)."""
+    i, e = load_render_case(name)
+    _, ref32 = hip_render(i, dev)
+    _, out = hip_render(i, dev, mlp_fp16=True)
+    assert torch.isfinite(out["rgb_map"]).all() and not torch.equal(out["rgb_map"], ref32["rgb_map"])     # the mode really switched arithmetic
+    p_ref, p_32 = psnr(out["rgb_map"], e["rgb"]), psnr(out["rgb_map"], ref32["rgb_map"])
+    print(f"fp16 MLP, case {name}: PSNR {p_ref:.1f} dB against the reference's render, {p_32:.1f} dB against the fp32 mode; "
+          f"max-abs rgb {float((out['rgb_map'] - e['rgb']).abs().max()):.2e}, acc {float((out['acc_map'] - e['acc']).abs().max()):.2e}")
+    assert p_ref > 60.0 and p_32 > 60.0
+    assert (out["acc_map"] - e["acc"]).abs().max() < 5e-3 and (out["depth_map"] - e["depth"]).abs().max() < 5e-3
 
 
 def test_importance_stage_matches_oracle(dev):
