@@ -623,13 +623,14 @@ __device__ __forceinline__ void mma_h(f32x16 (&acc)[NT], const u32x4 b, const u3
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, frags[t * 64 + lane]), __builtin_bit_cast(h8, b), acc[t], 0, 0, 0);
 }
 
-__global__ __launch_bounds__(512, 2) void k_march16(const MarchArgs a, const unsigned short *__restrict__ packed16) {
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void k_march16(const MarchArgs a, const unsigned short *__restrict__ packed16) {
     extern __shared__ __attribute__((aligned(16))) float lds16[];
-    constexpr int NT = 512;
+    constexpr int NT = NWV * 64;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const long long wg = (long long)xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
-    const long long tile = wg * 8 + (tid >> 6);
+    const long long tile = wg * NWV + (tid >> 6);
     const long long ray = tile * 32 + (lane & 31);
     const bool valid = ray < a.R;
     const long long rc = valid ? ray : a.R - 1;
@@ -2450,11 +2451,15 @@ static int render_eval_impl(const void *mlp_packed, const void *planes_packed, i
     a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
     if (mlp_fp16) {   // HL_RENDER_MLP_FP16 (opt-in): fp16 operands, all weights LDS-resident
         const size_t sh = (size_t)P16_FRAGS * 1024 + SMALL_FLOATS * sizeof(float);
-        static const bool attr_ok = hipFuncSetAttribute((const void *)k_march16, hipFuncAttributeMaxDynamicSharedMemorySize,
+        static const bool attr_ok = hipFuncSetAttribute((const void *)k_march16<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)((size_t)P16_FRAGS * 1024 + SMALL_FLOATS * sizeof(float))) == hipSuccess &&
+                                    hipFuncSetAttribute((const void *)k_march16<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)((size_t)P16_FRAGS * 1024 + SMALL_FLOATS * sizeof(float))) == hipSuccess;
         HL_REQUIRE(attr_ok, "k_march16: cannot raise the dynamic LDS limit to %zu bytes", sh);
-        hipLaunchKernelGGL(k_march16, dim3((unsigned)((n_rays + 255) / 256)), dim3(512), sh, (hipStream_t)stream, a,
-                           reinterpret_cast<const unsigned short *>(static_cast<const float *>(mlp_packed) + PACKED_FLOATS));
+        const unsigned short *p16 = reinterpret_cast<const unsigned short *>(static_cast<const float *>(mlp_packed) + PACKED_FLOATS);
+        static const int nwv = getenv("HL_MARCH16_WAVES") ? atoi(getenv("HL_MARCH16_WAVES")) : 4;      // 4 = one wave per SIMD (512 registers, no spills: 20.1 against 21.9 ms per view); 8: developer switch
+        if (nwv == 4) hipLaunchKernelGGL(k_march16<4>, dim3((unsigned)((n_rays + 127) / 128)), dim3(256), sh, (hipStream_t)stream, a, p16);
+        else hipLaunchKernelGGL(k_march16<8>, dim3((unsigned)((n_rays + 255) / 256)), dim3(512), sh, (hipStream_t)stream, a, p16);
         return hl::check_launch("k_march16");
     }
     // (4-wave workgroups, two per CU with independent barriers, measured equal - 74.5 vs 74.7 ms per view - at twice the weight
