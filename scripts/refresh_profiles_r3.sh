@@ -38,3 +38,8 @@ python scripts/rocpd_summary.py $(ls $O/trf/*/*results.db | head -1) $O/trace_un
 HL_TRAIN_ARITH=bf16 rocprofv3 --kernel-trace --stats -d $O/trb -- python scripts/unet_train_bench.py 2 2 > /dev/null 2>&1
 python scripts/rocpd_summary.py $(ls $O/trb/*/*results.db | head -1) $O/trace_unet_train_bf16.md > /dev/null; rm -rf $O/trb
 ls $O
+# the renderer's stages in fp32 and in the opt-in fp16-operand mode (two views each)
+rocprofv3 --kernel-trace --stats -d $O/rs -- python scripts/render_stage_probe.py > /dev/null 2>&1
+python scripts/rocpd_summary.py $(ls $O/rs/*/*results.db | head -1) $O/trace_render_fp32_fp16.md > /dev/null; rm -rf $O/rs
+python scripts/render_fp16_probe.py 2>&1 | grep -v amdgpu.ids > $O/render_fp16_probe.txt
+ls $O
