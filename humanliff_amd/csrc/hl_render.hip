@@ -605,6 +605,23 @@ __global__ void k_pack_mlp16(PackArgs a, unsigned short *out16) {
     out16[idx] = __builtin_bit_cast(unsigned short, h);
 }
 
+// softplus of the fp16-operand mode: ln2 * log2(1 + 2^(x log2e)) - no |x| / max split (for x >> 0 the sum rounds to 2^y and the logarithm
+// returns y; for x << 0 it returns 0 where the exact value is e^x < 6e-8 - both far below the fp16 rounding the result meets as an MFMA
+// operand), the exponent capped at 2^126.  Three packed fp32 operations + v_min + two transcendentals per value instead of four + two.
+__device__ __forceinline__ f32x16 softplus16_h(f32x16 v) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        f32x2_ y = f32x2_{v[i], v[i + 1]} * 1.44269504088896341f;
+        y[0] = fminf(y[0], 126.f); y[1] = fminf(y[1], 126.f);
+        const f32x2_ e = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+        const f32x2_ s1 = e + 1.f;
+        const f32x2_ l = f32x2_{__builtin_amdgcn_logf(s1[0]), __builtin_amdgcn_logf(s1[1])} * 0.693147180559945309f;
+        o[i] = l[0]; o[i + 1] = l[1];
+    }
+    return o;
+}
 __device__ __forceinline__ u32x4 cvt_h8(const f32x16 &v, int hi) {   // registers 8hi..8hi+7 -> 8 fp16 (nearest even)
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     u32x4 o;
@@ -742,7 +759,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_march16(const MarchArgs a
         load_bias<4>(Y, small + SM_B1, half);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            X[k] = softplus16(X[k]);
+            X[k] = softplus16_h(X[k]);
             mma_h<4>(Y, cvt_h8(X[k], 0), fr + (P16_L1 + (2 * k) * 4) * 64, lane);
             mma_h<4>(Y, cvt_h8(X[k], 1), fr + (P16_L1 + (2 * k + 1) * 4) * 64, lane);
         }
@@ -751,12 +768,12 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_march16(const MarchArgs a
         mma_h<4>(X, bf1, fr + (P16_L2F + 4) * 64, lane);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            Y[k] = softplus16(Y[k]);
+            Y[k] = softplus16_h(Y[k]);
             mma_h<4>(X, cvt_h8(Y[k], 0), fr + (P16_L2H + (2 * k) * 4) * 64, lane);
             mma_h<4>(X, cvt_h8(Y[k], 1), fr + (P16_L2H + (2 * k + 1) * 4) * 64, lane);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) X[k] = softplus16(X[k]);
+        for (int k = 0; k < 4; ++k) X[k] = softplus16_h(X[k]);
         const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];
         load_bias<4>(Y, small + SM_BF, half);
 #pragma unroll
@@ -773,8 +790,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_march16(const MarchArgs a
         }
         mma_h<2>(V, bev0, fr + (P16_VE + 0) * 64, lane);
         mma_h<2>(V, bev1, fr + (P16_VE + 2) * 64, lane);
-        V[0] = softplus16(V[0]);
-        V[1] = softplus16(V[1]);
+        V[0] = softplus16_h(V[0]);
+        V[1] = softplus16_h(V[1]);
         const float cr = dot_lane<2>(V, small + SM_RW, half) + small[SM_RB + 0];
         const float cg = dot_lane<2>(V, small + SM_RW + 64, half) + small[SM_RB + 1];
         const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
