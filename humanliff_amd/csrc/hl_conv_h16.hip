@@ -14,7 +14,12 @@
 //   * the weights never touch LDS: they are packed in MFMA-fragment order (one 16-byte load per lane and fragment) and go from L2 into a
 //     register ring of six k-steps (3 fragments each) - the CUs of an XCD walk K in step, so every line is one miss and 31 hits;
 //   * per k-step (16 channels of one tap): 4 ds_read_b128 + 3 buffer_load_dwordx4 for 12 MFMAs of 32 cycles.
-// Epilogue: two rounds of 128 pixels x 192 channels through LDS (padded rows), then bias + residual and 16-byte NHWC stores.
+// Epilogue: two rounds of 128 pixels x 192 channels through LDS (padded rows), then bias + residual (+ the control tower's second output) and
+// 16-byte NHWC stores, GroupNorm statistics per (tile, round).
+// Variants in this file: the nearest-x2 upsample in front of the convolution (a source-address shift of the patch loads); a 16-bit activation
+// image written by k_gn_apply_h16 for layers behind a GroupNorm (ConvK::in16: no rounding in the staging); split-K over chunk slabs for
+// layers with few tiles (blockIdx.z, raw sums to the split-K workspace, k_splitk_finish adds them in a fixed order); k_conv1_h16 for the 1x1
+// layers (256 consecutive pixels per workgroup, chunks of 96 channels).  The weight gradients live in hl_unet_train.hip (k_conv_wgrad_h16).
 #include "hl_unet_kernels.h"
 
 #include <type_traits>
