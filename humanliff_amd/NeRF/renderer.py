@@ -66,7 +66,8 @@ class Renderer(nn.Module):
         # (recon_NeRF/lib/renderer.py:288) does not clamp and clears the second flag
         self._depth_flags = _lib.HL_RENDER_NORMALIZE_DEPTH | _lib.HL_RENDER_CLAMP_DEPTH
         self.uniforms_on_device = False      # extension: draw sample_pdf's uniforms with the device generator (see render())
-        self.mlp_fp16 = False                # extension, opt-in: the MLP with fp16 operands / fp32 accumulation (HL_RENDER_MLP_FP16, k_march16)
+        self.mlp_fp16 = False                # extension, opt-in: the MLP with fp16 operands / fp32 accumulation (HL_RENDER_MLP_FP16, k_march16) in
+                                             # render() without canonical space; canonical-space rendering, density_grid() and training stay fp32
         self._ws = None
 
     # ---- packing caches ------------------------------------------------------------------------
