@@ -68,6 +68,9 @@ class Renderer(nn.Module):
         self.uniforms_on_device = False      # extension: draw sample_pdf's uniforms with the device generator (see render())
         self.mlp_fp16 = False                # extension, opt-in: the MLP with fp16 operands / fp32 accumulation (HL_RENDER_MLP_FP16, k_march16) in
                                              # render() without canonical space; canonical-space rendering, density_grid() and training stay fp32
+        self.mlp_products = "fp32"           # how render() forms the fp32 products of the MLP in the evaluate-once pipeline: "fp32" =
+                                             # v_mfma_f32_32x32x2_f32 (k_march); "bf16x3" = exact three-way bf16 split of both operands, six
+                                             # partial products, fp32 accumulation (HL_RENDER_MLP_BF16X3, k_march_b3) - same tolerance, 16-bit pipe
         self._ws = None
 
     # ---- packing caches ------------------------------------------------------------------------
@@ -185,7 +188,8 @@ class Renderer(nn.Module):
         acc = torch.empty((bs, R), dtype=torch.float32, device=dev)
         depth = torch.empty((bs, R), dtype=torch.float32, device=dev)
         flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0) | \
-            (_lib.HL_RENDER_REEVALUATE if reevaluate else 0) | (_lib.HL_RENDER_MLP_FP16 if getattr(self, "mlp_fp16", False) else 0)
+            (_lib.HL_RENDER_REEVALUATE if reevaluate else 0) | (_lib.HL_RENDER_MLP_FP16 if getattr(self, "mlp_fp16", False) else 0) | \
+            (_lib.HL_RENDER_MLP_BF16X3 if getattr(self, "mlp_products", "fp32") == "bf16x3" else 0)
         f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
         for b in range(bs):
             pp = self._packed_planes(tri_planes[b])

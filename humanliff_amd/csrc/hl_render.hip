@@ -805,6 +805,280 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_march16(const MarchArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_march_b3 (round 4): the evaluate pass (FULL + STORE) with the fp32 products formed on the 16-bit matrix pipe WITHOUT leaving fp32
+// tolerance - both operands of every product are split EXACTLY into three bf16 planes (x = x0 + x1 + x2, nearest-even at every level:
+// 3 x 8 significand bits hold all 24 of an fp32 value; the weights once at pack time, an activation fragment in registers right where
+// k_march16 rounds it to fp16) and the six partial products of weight >= 2^-16 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16; the
+// three dropped terms are below 2^-24 |a b|, i.e. less than the rounding of one fp32 fma.  Same fragment order as k_march16 (the
+// accumulator-is-the-next-B-operand identity under the permuted k order), same fp32 gather / softplus / heads as k_march.
+//   fp32 kernel : 1 044 MFMAs of 64 cycles per sample and wave, and every VALU instruction is ADDED to them (the fp32 MFMA runs on the
+//                 SIMD's fp32 lanes: profiles/r03_microbench_mfma_fill.txt)                                  -> 84k cycles, 0.78 of the peak
+//   this kernel :   792 MFMAs of 32 cycles, and ~5 VALU issues hide behind each (profiles/r04_microbench_mfma16_mix.txt)
+// The three planes are 396 KB: they stream from L2 through a two-slot LDS ring in 33 chunks of 12 KB (= 4 fragment positions x 3
+// planes = the weights of one 8-wide k-group for four output tiles), one barrier per chunk, the chunk after next staged in registers -
+// the scheme of k_march.  4 waves per workgroup = one per SIMD (the 512-entry register budget).
+constexpr int B3_POS = 4, B3_NCH = P16_FRAGS / B3_POS, B3_CH_U4 = B3_POS * 3 * 64;   // positions per chunk, chunks, u32x4 per chunk (12 KB)
+static_assert(P16_FRAGS % B3_POS == 0, "chunking");
+constexpr size_t B3_BYTES = (size_t)P16_FRAGS * 3 * 1024;
+
+__device__ __forceinline__ unsigned short bf16_rne(float v) {   // nearest even (the values here are finite)
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__global__ void k_pack_mlp_b3(PackArgs a, unsigned short *out) {   // [position][plane][lane 64][8 bf16]
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P16_FRAGS * 3 * 512) return;
+    const int i = idx & 7, lane = (idx >> 3) & 63, rest = idx >> 9, plane = rest % 3, f = rest / 3;
+    int pi = 6;
+    while (pi > 0 && f < c_parts16[pi].base) --pi;
+    const Part16 d = c_parts16[pi];
+    const int rel = f - d.base, j = rel / d.nt, t = rel - j * d.nt;
+    const int g = lane >> 5, outu = 32 * t + (lane & 31);
+    int in = -1;
+    if (d.kind == 1) {
+        in = unit_of(j >> 1, (j & 1) * 8 + i, g);
+    } else {
+        const int sidx = j * 8 + i, per = d.kind == 0 ? 15 : 14, k = sidx + per * g;
+        if (sidx < per && k < 27) in = k;
+    }
+    float v = in >= 0 ? a.w[d.w][outu * d.ld + d.col0 + in] : 0.f;
+    unsigned short h = 0;
+    for (int p = 0; p <= plane; ++p) {
+        h = bf16_rne(v);
+        v -= __builtin_bit_cast(float, (unsigned)h << 16);       // exact
+    }
+    out[idx] = h;
+}
+
+// registers 8hi..8hi+7 of an accumulator tile -> three planes of 8 bf16 (v = p0 + p1 + p2 exactly)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void split_b3(const f32x16 &v, int hi, u32x4 (&pl)[3]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x = v[8 * hi + 2 * q], y = v[8 * hi + 2 * q + 1];
+        const unsigned p0 = cvt_pk_bf16(x, y);
+        x -= __builtin_bit_cast(float, p0 << 16); y -= __builtin_bit_cast(float, p0 & 0xffff0000u);
+        const unsigned p1 = cvt_pk_bf16(x, y);
+        x -= __builtin_bit_cast(float, p1 << 16); y -= __builtin_bit_cast(float, p1 & 0xffff0000u);
+        pl[0][q] = p0; pl[1][q] = p1; pl[2][q] = cvt_pk_bf16(x, y);
+    }
+}
+// NT output tiles x one 8-wide k-group: positions q0 .. q0+NT-1 of the chunk at `ch`; the six products, smallest first, tiles interleaved
+template <int NT>
+__device__ __forceinline__ void mma_b3(f32x16 (&acc)[NT], const u32x4 (&b)[3], const u32x4 *__restrict__ ch, int q0, int lane) {
+    u32x4 w[NT][3];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w[t][p] = ch[((q0 + t) * 3 + p) * 64 + lane];
+    constexpr int PW[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][PW[i]]), __builtin_bit_cast(bf16x8, b[PB[i]]), acc[t], 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const unsigned short *__restrict__ packed_b3) {
+    __shared__ __attribute__((aligned(16))) float ldsb[2 * B3_CH_U4 * 4 + SMALL_FLOATS];
+    constexpr int NT = 256, NST = B3_CH_U4 / NT;   // threads; u32x4 per thread and chunk
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const long long wg = (long long)xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
+    const long long tile = wg * 4 + (tid >> 6);
+    const long long ray = tile * 32 + (lane & 31);
+    const bool valid = ray < a.R;
+    const long long rc = valid ? ray : a.R - 1;
+    const long long tiles_n = (a.R + 31) / 32;
+    const long long zt_base = (tile < tiles_n ? tile : tiles_n - 1) * 32 * (long long)a.S + (lane & 31);
+
+    u32x4 *ring = reinterpret_cast<u32x4 *>(ldsb);
+    float *small = ldsb + 2 * B3_CH_U4 * 4;
+    for (int i = tid; i < SMALL_FLOATS; i += NT) small[i] = a.packed[NCH_FULL * CHUNK_FLOATS + i];
+    const u32x4 *gb3 = reinterpret_cast<const u32x4 *>(packed_b3);
+#pragma unroll
+    for (int q = 0; q < 2 * NST; ++q) ring[q * NT + tid] = gb3[q * NT + tid];                  // chunks 0, 1 -> slots 0, 1
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)packed_b3, (short)0, (int)B3_BYTES, 0x00020000);
+    const int wv = tid * 16;
+    auto ldw = [&](int u4_index) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rsw, wv, u4_index * 16, 0); };
+    u32x4 st[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) st[q] = ldw(2 * B3_CH_U4 + q * NT);                        // chunk 2 staged
+    int cur = 0;
+
+    const float ox = a.rays_o[rc * 3 + 0], oy = a.rays_o[rc * 3 + 1], oz = a.rays_o[rc * 3 + 2];
+    const float dx = a.rays_d[rc * 3 + 0], dy = a.rays_d[rc * 3 + 1], dz = a.rays_d[rc * 3 + 2];
+    const float nr = a.near[rc], fr_ = a.far[rc];
+    const int S = a.S;
+    const float offH = (float)(1.0 / (double)a.H);
+    const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
+    const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
+
+    // view-direction encoding, this half's 14 of the 27 (+1 pad) entries (as k_march), split once per ray
+    u32x4 bev0[3], bev1[3];
+    {
+        f32x16 ev;
+        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float vd[3] = {dx / nrm, dy / nrm, dz / nrm};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float val = 0.f;
+            if (s < 14) {
+                const int kl = s, kh = s + 14;
+                const int jl = (kl - 3) / 3, cl = (kl - 3) % 3, jh = (kh - 3) / 3, ch = (kh - 3) % 3;
+                const float argl = kl < 3 ? 0.f : ((jl & 1) ? 1.57079632679489661923f : 0.f) + vd[kl < 3 ? 0 : cl] * (float)(1 << (jl >> 1));
+                const float argh = ((jh & 1) ? 1.57079632679489661923f : 0.f) + vd[ch] * (float)(1 << (jh >> 1));
+                if (kl < 3) {
+                    const float sh = sinf(argh);
+                    val = half ? sh : vd[kl];
+                } else if (kh >= 27) {
+                    const float sl = sinf(argl);
+                    val = half ? 0.f : sl;
+                } else {
+                    val = sinf(half ? argh : argl);
+                }
+            }
+            ev[s] = val;
+        }
+        split_b3(ev, 0, bev0);
+        split_b3(ev, 1, bev1);
+    }
+
+    float zc;
+    if (a.z) zc = a.z_tiled ? a.z[zt_base] : a.z[rc * S];
+    else zc = nr * (1.f - linspace01(0, S)) + fr_ * linspace01(0, S);
+    __syncthreads();
+
+    // Ring invariant while chunk g is consumed: slot `cur` holds g, the other slot holds (or is being filled with) g+1, the staging
+    // registers hold (or are receiving) g+2.  B3_ADV(g), executed when moving on to chunk g: barrier (everybody is done with g-1, the
+    // writes of g are visible), flip, write the staged g+1 into the slot g-1 released, start loading g+2.
+#define B3_ADV(g)                                                                                                   \
+    __syncthreads();                                                                                                \
+    cur ^= B3_CH_U4;                                                                                                \
+    _Pragma("unroll") for (int q_ = 0; q_ < NST; ++q_) ring[(cur ^ B3_CH_U4) + q_ * NT + tid] = st[q_];             \
+    _Pragma("unroll") for (int q_ = 0; q_ < NST; ++q_) st[q_] = ldw((((g) + 2) % B3_NCH) * B3_CH_U4 + q_ * NT);
+
+    for (int s = 0; s < S; ++s) {
+        float zn = 0.f;
+        if (s + 1 < S) {
+            if (a.z) zn = a.z_tiled ? a.z[zt_base + 32LL * (s + 1)] : a.z[rc * S + s + 1];
+            else { const float t = linspace01(s + 1, S); zn = nr * (1.f - t) + fr_ * t; }
+        }
+        // ---- tri-plane features of this half (fp32, exactly as k_march)  [renderer.py:502-531] ----
+        const float px = ox + dx * zc, py = oy + dy * zc, pz = oz + dz * zc;
+        const float nx = 2.f * (px - bmin0) / bext0 - 1.f;
+        const float ny = 2.f * (py - bmin1) / bext1 - 1.f;
+        const float nz = 2.f * (pz - bmin2) / bext2 - 1.f;
+        f32x16 f;
+        f[15] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int qlo = i, qhi = (i + 5 > 8) ? 8 : i + 5;
+            const int q = half ? qhi : qlo;
+            const int p = half ? qhi / 3 : qlo / 3, g = half ? qhi % 3 : qlo % 3;
+            float gu = (p == 2) ? nz : nx;
+            float gv = (p == 1) ? nz : ny;
+            gu = (g == 1) ? gu + offH : gu;
+            gv = (g == 2) ? gv + offH : gv;
+            const float ix = ((gu + 1.f) * (float)a.W - 1.f) / 2.f;
+            const float iy = ((gv + 1.f) * (float)a.H - 1.f) / 2.f;
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+            float w_nw = (x1f - ix) * (y1f - iy), w_ne = (ix - x0f) * (y1f - iy);
+            float w_sw = (x1f - ix) * (iy - y0f), w_se = (ix - x0f) * (iy - y0f);
+            const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+            const bool vx0 = (x0 >= 0) & (x0 < a.W), vx1 = (x1 >= 0) & (x1 < a.W);
+            const bool vy0 = (y0 >= 0) & (y0 < a.H), vy1 = (y1 >= 0) & (y1 < a.H);
+            w_nw = (vx0 & vy0) ? w_nw : 0.f;
+            w_ne = (vx1 & vy0) ? w_ne : 0.f;
+            w_sw = (vx0 & vy1) ? w_sw : 0.f;
+            w_se = (vx1 & vy1) ? w_se : 0.f;
+            const int cx0 = min(max(x0, 0), a.W - 1), cx1 = min(max(x1, 0), a.W - 1);
+            const int cy0 = min(max(y0, 0), a.H - 1), cy1 = min(max(y1, 0), a.H - 1);
+            const float4 *pl = a.planes + (long long)q * a.H * a.W;
+            const float4 t_nw = pl[cy0 * a.W + cx0], t_ne = pl[cy0 * a.W + cx1];
+            const float4 t_sw = pl[cy1 * a.W + cx0], t_se = pl[cy1 * a.W + cx1];
+            const bool live = half ? (i + 5 <= 8) : true;
+            const float r0 = t_nw.x * w_nw + t_ne.x * w_ne + t_sw.x * w_sw + t_se.x * w_se;
+            const float r1 = t_nw.y * w_nw + t_ne.y * w_ne + t_sw.y * w_sw + t_se.y * w_se;
+            const float r2 = t_nw.z * w_nw + t_ne.z * w_ne + t_sw.z * w_sw + t_se.z * w_se;
+            f[3 * i + 0] = live ? r0 : 0.f;
+            f[3 * i + 1] = live ? r1 : 0.f;
+            f[3 * i + 2] = live ? r2 : 0.f;
+        }
+        u32x4 bf0[3], bf1[3], bb[3];
+        split_b3(f, 0, bf0);
+        split_b3(f, 1, bf1);
+        // ---- MLP  [renderer.py:134-156]: chunk g = fragment positions 4g .. 4g+3 ----
+        f32x16 X[4], Y[4];
+        load_bias<4>(X, small + SM_B0, half);
+        mma_b3<4>(X, bf0, ring + cur, 0, lane);                                     // chunk 0 (current at loop entry)
+        B3_ADV(1) mma_b3<4>(X, bf1, ring + cur, 0, lane);
+        load_bias<4>(Y, small + SM_B1, half);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                               // L1: chunks 2..9
+            X[k] = softplus16(X[k]);
+            split_b3(X[k], 0, bb);
+            B3_ADV(2 + 2 * k) mma_b3<4>(Y, bb, ring + cur, 0, lane);
+            split_b3(X[k], 1, bb);
+            B3_ADV(3 + 2 * k) mma_b3<4>(Y, bb, ring + cur, 0, lane);
+        }
+        load_bias<4>(X, small + SM_B2, half);
+        B3_ADV(10) mma_b3<4>(X, bf0, ring + cur, 0, lane);                          // L2 (features): chunks 10, 11
+        B3_ADV(11) mma_b3<4>(X, bf1, ring + cur, 0, lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                               // L2 (hidden): chunks 12..19
+            Y[k] = softplus16(Y[k]);
+            split_b3(Y[k], 0, bb);
+            B3_ADV(12 + 2 * k) mma_b3<4>(X, bb, ring + cur, 0, lane);
+            split_b3(Y[k], 1, bb);
+            B3_ADV(13 + 2 * k) mma_b3<4>(X, bb, ring + cur, 0, lane);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = softplus16(X[k]);
+        const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];
+        load_bias<4>(Y, small + SM_BF, half);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                               // feature_linear: chunks 20..27
+            split_b3(X[k], 0, bb);
+            B3_ADV(20 + 2 * k) mma_b3<4>(Y, bb, ring + cur, 0, lane);
+            split_b3(X[k], 1, bb);
+            B3_ADV(21 + 2 * k) mma_b3<4>(Y, bb, ring + cur, 0, lane);
+        }
+        f32x16 V[2];
+        load_bias<2>(V, small + SM_BV, half);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                               // views_linear (feature part): chunks 28..31, two k-groups each
+            B3_ADV(28 + k)
+            split_b3(Y[k], 0, bb);
+            mma_b3<2>(V, bb, ring + cur, 0, lane);
+            split_b3(Y[k], 1, bb);
+            mma_b3<2>(V, bb, ring + cur, 2, lane);
+        }
+        B3_ADV(32)                                                                  // views_linear (direction encoding)
+        mma_b3<2>(V, bev0, ring + cur, 0, lane);
+        mma_b3<2>(V, bev1, ring + cur, 2, lane);
+        V[0] = softplus16(V[0]);
+        V[1] = softplus16(V[1]);
+        const float cr = dot_lane<2>(V, small + SM_RW, half) + small[SM_RB + 0];
+        const float cg = dot_lane<2>(V, small + SM_RW + 64, half) + small[SM_RB + 1];
+        const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
+        B3_ADV(B3_NCH)                                                              // chunk 0 of the next sample
+        if (tile * 32 < a.R) {   // lanes 0-31 store (sigma, r), lanes 32-63 (g, b); hidden store: see k_march
+            const float2 rec = half ? make_float2(cg, cb) : make_float2(sigma_raw, cr);
+            float *dst = reinterpret_cast<float *>(a.vals_out + (zt_base + 32LL * s)) + 2 * half;
+            asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst), "v"(rec) : "memory");
+        }
+        zc = zn;
+    }
+#undef B3_ADV
+}
+
+// ---------------------------------------------------------------------------------------------
 // importance sampling + merge: one wave per ray   [renderer.py:158-170, 533-563, 252-253]
 // ---------------------------------------------------------------------------------------------
 constexpr int IMP_MAX_N = 512;
@@ -2353,7 +2627,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 
 extern "C" {
 
-size_t hl_render_mlp_packed_bytes(void) { return (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024; }   // fp32 image + the fp16 fragments of k_march16
+// fp32 image + the fp16 fragments of k_march16 + the three bf16 planes of k_march_b3
+size_t hl_render_mlp_packed_bytes(void) { return (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024 + B3_BYTES; }
 
 int hl_render_mlp_pack(const hl_render_mlp_params *p, void *packed, void *stream) {
     HL_REQUIRE(p && packed, "hl_render_mlp_pack: null argument");
@@ -2369,7 +2644,11 @@ int hl_render_mlp_pack(const hl_render_mlp_params *p, void *packed, void *stream
     if (rc) return rc;
     hipLaunchKernelGGL(k_pack_mlp16, dim3(P16_FRAGS * 2), dim3(256), 0, (hipStream_t)stream, a,
                        reinterpret_cast<unsigned short *>(static_cast<float *>(packed) + PACKED_FLOATS));
-    return hl::check_launch("k_pack_mlp16");
+    rc = hl::check_launch("k_pack_mlp16");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pack_mlp_b3, dim3(P16_FRAGS * 3 * 2), dim3(256), 0, (hipStream_t)stream, a,
+                       reinterpret_cast<unsigned short *>(static_cast<char *>(packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024));
+    return hl::check_launch("k_pack_mlp_b3");
 }
 
 size_t hl_planes_packed_bytes(int H, int W) { return (size_t)9 * H * W * sizeof(float4); }
@@ -2460,13 +2739,18 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
 
 static int render_eval_impl(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
                             const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
-                            int n_samples, float *records_out, int mlp_fp16, void *stream) {
+                            int n_samples, float *records_out, int mlp_mode, void *stream) {   // mlp_mode: 0 fp32 MFMA, 1 fp16 operands (opt-in), 2 bf16x3 split products
     HL_REQUIRE(n_rays > 0 && n_samples >= 1 && records_out, "hl_render_eval: bad argument");
     MarchArgs a{};
     int rcode = fill_march(a, mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far);
     if (rcode) return rcode;
     a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
-    if (mlp_fp16) {   // HL_RENDER_MLP_FP16 (opt-in): fp16 operands, all weights LDS-resident
+    if (mlp_mode == 2) {   // HL_RENDER_MLP_BF16X3: exact three-way bf16 split of both operands, six partial products, fp32 accumulation
+        const unsigned short *pb3 = reinterpret_cast<const unsigned short *>(static_cast<const char *>(mlp_packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024);
+        hipLaunchKernelGGL(k_march_b3, dim3((unsigned)((n_rays + 127) / 128)), dim3(256), 0, (hipStream_t)stream, a, pb3);
+        return hl::check_launch("k_march_b3");
+    }
+    if (mlp_mode == 1) {   // HL_RENDER_MLP_FP16 (opt-in): fp16 operands, all weights LDS-resident
         const size_t sh = (size_t)P16_FRAGS * 1024 + SMALL_FLOATS * sizeof(float);
         static const bool attr_ok = hipFuncSetAttribute((const void *)k_march16<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)((size_t)P16_FRAGS * 1024 + SMALL_FLOATS * sizeof(float))) == hipSuccess &&
@@ -2728,7 +3012,7 @@ int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int
             const size_t T32 = (size_t)tiles32(n_rays) * 32;
             float *vc = (float *)workspace, *vn = vc + T32 * n_samples * 4;
             float *zn = vn + T32 * n_importance * 4;
-            const int h16 = (flags & HL_RENDER_MLP_FP16) ? 1 : 0;
+            const int h16 = (flags & HL_RENDER_MLP_FP16) ? 1 : ((flags & HL_RENDER_MLP_BF16X3) ? 2 : 0);
             int rcode = render_eval_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, 0, n_rays, n_samples,
                                          vc, h16, stream);
             if (rcode) return rcode;

@@ -73,6 +73,9 @@ int hl_planes_pack(const float *planes, int H, int W, void *packed, void *stream
 
 #define HL_RENDER_MLP_FP16 16u       /* opt-in (hl_render_rays, evaluate-once pipeline): the MLP with fp16 operands / fp32 accumulation
                                         (k_march16, all weights LDS-resident); features, encodings, softplus, compositing stay fp32 */
+#define HL_RENDER_MLP_BF16X3 32u     /* hl_render_rays, evaluate-once pipeline: every fp32 product of the MLP (renderer.py:134-156) formed from an
+                                        EXACT three-way bf16 split of both operands - six partial products on v_mfma_f32_32x32x16_bf16, fp32
+                                        accumulation, dropped terms < 2^-24 |a b| (k_march_b3); an fp32-tolerance mode, not a reduced-precision one */
 
 size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
 

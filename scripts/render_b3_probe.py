@@ -1,0 +1,48 @@
+"""Developer probe: the bf16x3 split-product MLP of the renderer (Renderer.mlp_products = "bf16x3", k_march_b3) against the fp32-MFMA path:
+max-abs / PSNR of 512x512 views of a random tri-plane, time per view; and both against the reference's golden renders."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from humanliff_amd import synthetic as syn
+from humanliff_amd.NeRF import Renderer, render_view
+from tests.golden_util import load_render_case, psnr
+dev = torch.device("cuda:0")
+rend = Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, smpl_type="smpl", test=True)
+rend.load_state_dict(syn.render_mlp_state(3), strict=False)
+rend = rend.to(dev)
+planes = (0.3 * torch.randn((1, 3, 9, 256, 256), generator=torch.Generator().manual_seed(11))).clamp(-1, 1).to(dev)
+tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].to(dev)}
+res = 512
+u = torch.rand((res * res, 128), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+def cam(v):
+    K, c2w, c = syn.orbit_camera(v, 36, res, res)
+    R = c2w.T.copy()
+    return K, R, (-R @ c).reshape(3, 1)
+out = {}
+for mode in ("fp32", "bf16x3"):
+    rend.mlp_products = mode
+    imgs = []
+    render_view(res, res, *cam(0), planes, tp, rend, n_samples=128, n_importance=128, u=u)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for v in (0, 7, 19):
+        imgs.append(render_view(res, res, *cam(v), planes, tp, rend, n_samples=128, n_importance=128, u=u))
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    out[mode] = (imgs, dt)
+    print(f"mlp_products={mode}: {dt * 1e3:.1f} ms per view = {res * res / dt / 1e6:.2f} Mrays/s", flush=True)
+for i in range(3):
+    a, b = out["bf16x3"][0][i], out["fp32"][0][i]
+    mse = float(((a[0] - b[0]) ** 2).mean())
+    print(f"view {i}: rgb PSNR {10 * np.log10(1.0 / max(mse, 1e-30)):.1f} dB (max-abs {float((a[0] - b[0]).abs().max()):.2e}), acc max-abs {float((a[1] - b[1]).abs().max()):.2e}, "
+          f"finite {bool(torch.isfinite(a[0]).all())}, rgb mean {float(b[0].mean()):.3f}")
+for name in "abc":
+    i, e = load_render_case(name)
+    for mode in ("fp32", "bf16x3"):
+        r = Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, smpl_type='smpl', test=True)
+        r.load_state_dict(i["mlp"], strict=False)
+        r = r.to(dev)
+        r.mlp_products = mode
+        o = r.render({"world_bounds": i["bounds"][None].to(dev)}, None, None, i["rays_o"][None].to(dev), i["rays_d"][None].to(dev), i["near"][None, :, None].to(dev),
+                     i["far"][None, :, None].to(dev), i["planes"].to(dev), i["n_importance"], i["white_bkgd"], n_samples=i["n_samples"], u=i["u"].to(dev))
+        o = {k: v[0].cpu() for k, v in o.items()}
+        print(f"golden {name} {mode:7s}: rgb max-abs {float((o['rgb_map'] - e['rgb']).abs().max()):.2e} PSNR {psnr(o['rgb_map'], e['rgb']):.1f} dB, acc {float((o['acc_map'] - e['acc']).abs().max()):.2e}, "
+              f"depth {float((o['depth_map'] - e['depth']).abs().max()):.2e}")
