@@ -68,9 +68,10 @@ class Renderer(nn.Module):
         self.uniforms_on_device = False      # extension: draw sample_pdf's uniforms with the device generator (see render())
         self.mlp_fp16 = False                # extension, opt-in: the MLP with fp16 operands / fp32 accumulation (HL_RENDER_MLP_FP16, k_march16) in
                                              # render() without canonical space; canonical-space rendering, density_grid() and training stay fp32
-        self.mlp_products = "fp32"           # how render() forms the fp32 products of the MLP in the evaluate-once pipeline: "fp32" =
-                                             # v_mfma_f32_32x32x2_f32 (k_march); "bf16x3" = exact three-way bf16 split of both operands, six
-                                             # partial products, fp32 accumulation (HL_RENDER_MLP_BF16X3, k_march_b3) - same tolerance, 16-bit pipe
+        self.mlp_products = "bf16x3"         # how render() forms the fp32 products of the MLP in the evaluate-once pipeline (test mode, world space):
+                                             # "bf16x3" (default) = both operands split EXACTLY into three bf16 planes, six partial products on
+                                             # v_mfma_f32_32x32x16_bf16, fp32 accumulation - dropped terms below one fp32 rounding (k_march_b3,
+                                             # HL_RENDER_MLP_BF16X3); "fp32" = v_mfma_f32_32x32x2_f32 (k_march).  Same tolerances, tested on both.
         self._ws = None
 
     # ---- packing caches ------------------------------------------------------------------------

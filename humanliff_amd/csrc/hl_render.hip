@@ -28,6 +28,8 @@
 #include "hl_common.h"
 
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -806,17 +808,18 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_march16(const MarchArgs a
 
 // ---------------------------------------------------------------------------------------------
 // k_march_b3 (round 4): the evaluate pass (FULL + STORE) with the fp32 products formed on the 16-bit matrix pipe WITHOUT leaving fp32
-// tolerance - both operands of every product are split EXACTLY into three bf16 planes (x = x0 + x1 + x2, nearest-even at every level:
-// 3 x 8 significand bits hold all 24 of an fp32 value; the weights once at pack time, an activation fragment in registers right where
-// k_march16 rounds it to fp16) and the six partial products of weight >= 2^-16 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16; the
-// three dropped terms are below 2^-24 |a b|, i.e. less than the rounding of one fp32 fma.  Same fragment order as k_march16 (the
-// accumulator-is-the-next-B-operand identity under the permuted k order), same fp32 gather / softplus / heads as k_march.
+// tolerance - both operands of every product are split EXACTLY into three bf16 planes (x = x0 + x1 + x2: 3 x 8 significand bits hold all
+// 24 of an fp32 value; the weights once at pack time, an activation fragment in registers right where k_march16 rounds it to fp16) and
+// the six partial products of weight >= 2^-16 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16; the three dropped terms are below
+// 2^-22 |a b| in the worst case (truncated activation planes against nearest-even weight planes), far less on average - the order of
+// the rounding of one fp32 fma.  Same fragment order as k_march16 (the accumulator-is-the-next-B-operand identity under the permuted k
+// order), same fp32 gather / softplus / heads as k_march.
 //   fp32 kernel : 1 044 MFMAs of 64 cycles per sample and wave, and every VALU instruction is ADDED to them (the fp32 MFMA runs on the
 //                 SIMD's fp32 lanes: profiles/r03_microbench_mfma_fill.txt)                                  -> 84k cycles, 0.78 of the peak
 //   this kernel :   792 MFMAs of 32 cycles, and ~5 VALU issues hide behind each (profiles/r04_microbench_mfma16_mix.txt)
-// The three planes are 396 KB: they stream from L2 through a two-slot LDS ring in 33 chunks of 12 KB (= 4 fragment positions x 3
-// planes = the weights of one 8-wide k-group for four output tiles), one barrier per chunk, the chunk after next staged in registers -
-// the scheme of k_march.  4 waves per workgroup = one per SIMD (the 512-entry register budget).
+// The three planes are 396 KB: they stream from L2 through an LDS ring, the chunk pair after next staged in registers - the scheme of
+// k_march.  Chunk = 4 fragment positions x 3 planes = the weights of one 8-wide k-group for four output tiles (12 KB).  4 waves per
+// workgroup = one per SIMD (the 512-entry register budget).
 constexpr int B3_POS = 4, B3_NCH = P16_FRAGS / B3_POS, B3_CH_U4 = B3_POS * 3 * 64;   // positions per chunk, chunks, u32x4 per chunk (12 KB)
 static_assert(P16_FRAGS % B3_POS == 0, "chunking");
 constexpr size_t B3_BYTES = (size_t)P16_FRAGS * 3 * 1024;
@@ -867,25 +870,93 @@ __device__ __forceinline__ void split_b3(const f32x16 &v, int hi, u32x4 (&pl)[3]
         pl[0][q] = p0; pl[1][q] = p1; pl[2][q] = cvt_pk_bf16(x, y);
     }
 }
-// NT output tiles x one 8-wide k-group: positions q0 .. q0+NT-1 of the chunk at `ch`; the six products, smallest first, tiles interleaved
-template <int NT>
-__device__ __forceinline__ void mma_b3(f32x16 (&acc)[NT], const u32x4 (&b)[3], const u32x4 *__restrict__ ch, int q0, int lane) {
-    u32x4 w[NT][3];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) w[t][p] = ch[((q0 + t) * 3 + p) * 64 + lane];
-    constexpr int PW[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][PW[i]]), __builtin_bit_cast(bf16x8, b[PB[i]]), acc[t], 0, 0, 0);
+// ---------------------------------------------------------------------------------------------
+// The instruction stream of k_march_b3 is laid out by hand.  Left to itself the compiler keeps the VALU work of a layer (softplus, the three-way
+// split) outside the MFMA groups, where nothing overlaps it (ablations in profiles/r04_render_b3_ablations.md: everything adds up).  Measured
+// with one wave per SIMD (profiles/r04_microbench_mfma16_mix.txt): behind a v_mfma_f32_32x32x16_bf16 five plain VALU issues are free, a gap
+// then costs ~8 + 4.8 cycles per plain instruction, and v_exp / v_log / v_cvt_pk_bf16_f32 / v_accvgpr_read count double.  Hence:
+//   * every MFMA of a chunk is followed by a fixed slice (~5 plain-instruction equivalents) of the work that prepares the NEXT chunk's B
+//     operand: softplus + split of a pair of values = six slices, a raw split = three;
+//   * the split truncates instead of rounding (v_and + v_perm, plain rate; still exact: 3 x 8 bits) and max(x, 0) is a v_max_i32;
+//   * the next chunk's weight fragments are read from LDS one chunk ahead (one ds_read_b128 behind each of the first twelve MFMAs);
+//   * where a chunk's operand depends on the layer that is just finishing, that layer's last chunk runs tile 0 first and prepares the
+//     operand behind the MFMAs of tiles 1..3;
+//   * the ring holds three slots of two chunks (24 KB): one barrier per 48 MFMAs.
+struct B3Op { u32x4 p[3]; };
+struct B3Tmp { float x, y, ex, ey; unsigned hx, hy; };
+template <int N, class F, int... I>
+__device__ __forceinline__ void b3_seq_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void b3_seq(F &&f) { b3_seq_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+__device__ __forceinline__ float b3_max0(float x) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }   // v_max_i32: max(x, +0) for every non-NaN x
+__device__ __forceinline__ unsigned b3_hi(float x) { return __builtin_bit_cast(unsigned, x) & 0xffff0000u; }
+__device__ __forceinline__ unsigned b3_pack(float x, float y) { return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, y), __builtin_bit_cast(unsigned, x), 0x07060302u); }
+// Preparation of pair Q (registers 8H + 2Q, +1 of `src`) of operand `o`, slice T.  KIND 0: raw split, T = 0..2; KIND 1: softplus, then
+// split, T = 0..5; KIND 2: as 1, and the softplus values also feed the density head (asum += value * aw[register]).
+template <int KIND, int H, int Q, int T>
+__device__ __forceinline__ void b3_prep(const f32x16 &src, B3Op &o, B3Tmp &t, float &asum, const float *__restrict__ aw) {
+    constexpr int r = 8 * H + 2 * Q;
+    if constexpr (KIND == 0) {
+        if constexpr (T == 0) { t.x = src[r]; t.y = src[r + 1]; t.hx = b3_hi(t.x); }
+        else if constexpr (T == 1) {
+            t.hy = b3_hi(t.y); o.p[0][Q] = b3_pack(t.x, t.y);
+            t.x -= __builtin_bit_cast(float, t.hx); t.y -= __builtin_bit_cast(float, t.hy); t.hx = b3_hi(t.x);
+        } else {
+            t.hy = b3_hi(t.y); o.p[1][Q] = b3_pack(t.x, t.y);
+            t.x -= __builtin_bit_cast(float, t.hx); t.y -= __builtin_bit_cast(float, t.hy); o.p[2][Q] = b3_pack(t.x, t.y);
+        }
+    } else {
+        if constexpr (T == 0) {
+            t.x = src[r]; t.y = src[r + 1];
+            t.ex = -1.44269504088896341f * fabsf(t.x); t.ey = -1.44269504088896341f * fabsf(t.y);
+        } else if constexpr (T == 1) {
+            t.ex = __builtin_amdgcn_exp2f(t.ex); t.ey = __builtin_amdgcn_exp2f(t.ey); t.ex = 1.f + t.ex;
+        } else if constexpr (T == 2) {
+            t.ey = 1.f + t.ey; t.ex = __builtin_amdgcn_logf(t.ex); t.ey = __builtin_amdgcn_logf(t.ey);
+        } else if constexpr (T == 3) {
+            t.x = fmaf(0.693147180559945309f, t.ex, b3_max0(t.x));
+            t.y = fmaf(0.693147180559945309f, t.ey, b3_max0(t.y));
+            if constexpr (KIND == 2) { const float2 w2 = *reinterpret_cast<const float2 *>(aw + r); asum = fmaf(t.x, w2.x, asum); asum = fmaf(t.y, w2.y, asum); }
+            t.hx = b3_hi(t.x);
+        } else if constexpr (T == 4) {
+            t.hy = b3_hi(t.y); o.p[0][Q] = b3_pack(t.x, t.y);
+            t.x -= __builtin_bit_cast(float, t.hx); t.y -= __builtin_bit_cast(float, t.hy); t.hx = b3_hi(t.x);
+        } else {
+            t.hy = b3_hi(t.y); o.p[1][Q] = b3_pack(t.x, t.y);
+            t.x -= __builtin_bit_cast(float, t.hx); t.y -= __builtin_bit_cast(float, t.hy); o.p[2][Q] = b3_pack(t.x, t.y);
+        }
+    }
 }
+// slice ST of one operand: 4 pairs x (3 | 6) slices
+template <int KIND, int H, int ST>
+__device__ __forceinline__ void b3_prep_step(const f32x16 &src, B3Op &o, B3Tmp &t, float &asum, const float *__restrict__ aw) {
+    constexpr int NS = KIND == 0 ? 3 : 6;
+    if constexpr (ST < 4 * NS) b3_prep<KIND, H, ST / NS, ST % NS>(src, o, t, asum, aw);
+}
+// The 24 MFMAs of a chunk.  NT2 == 4: one k-group (operand oa) x four output tiles (positions 0..3); NT2 == 2: two k-groups (oa, ob) x two
+// tiles (positions 0,1 | 2,3).  TM (tile-major, NT2 == 4): tile 0 completes before tile 1 starts, ...  after(idx) runs behind MFMA idx.
+template <int NT2, bool TM, class ACC, class F>
+__device__ __forceinline__ void b3_chunk(ACC &acc, const B3Op &oa, const B3Op &ob, const u32x4 (&w)[12], F &&after) {
+    constexpr int PW[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    b3_seq<24>([&](auto ic) {
+        constexpr int idx = decltype(ic)::value;
+        constexpr int i = NT2 == 4 ? (TM ? idx % 6 : idx / 4) : (idx % 12) / 2;
+        constexpr int t = NT2 == 4 ? (TM ? idx / 6 : idx % 4) : (idx & 1);
+        constexpr int q = NT2 == 4 ? t : 2 * (idx / 12) + t;
+        const B3Op &b = (NT2 == 2 && idx >= 12) ? ob : oa;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[q * 3 + PW[i]]), __builtin_bit_cast(bf16x8, b.p[PB[i]]), acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        after(ic);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+constexpr int B3R_NPAIR = (B3_NCH + 1) / 2, B3R_SLOT_U4 = 2 * B3_CH_U4;                     // 17 chunk pairs per sample; 1536 u32x4 = 24 KB per ring slot
+constexpr size_t B3R_LDS = (size_t)3 * B3R_SLOT_U4 * 16 + SMALL_FLOATS * sizeof(float);
 
+template <int ABL>
 __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const unsigned short *__restrict__ packed_b3) {
-    __shared__ __attribute__((aligned(16))) float ldsb[2 * B3_CH_U4 * 4 + SMALL_FLOATS];
-    constexpr int NT = 256, NST = B3_CH_U4 / NT;   // threads; u32x4 per thread and chunk
+    extern __shared__ __attribute__((aligned(16))) float ldsb[];
+    constexpr int NT = 256, NST = B3R_SLOT_U4 / NT;   // threads; u32x4 per thread and chunk pair (6)
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const long long wg = (long long)xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
@@ -897,18 +968,18 @@ __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const un
     const long long zt_base = (tile < tiles_n ? tile : tiles_n - 1) * 32 * (long long)a.S + (lane & 31);
 
     u32x4 *ring = reinterpret_cast<u32x4 *>(ldsb);
-    float *small = ldsb + 2 * B3_CH_U4 * 4;
+    float *small = ldsb + 3 * B3R_SLOT_U4 * 4;
     for (int i = tid; i < SMALL_FLOATS; i += NT) small[i] = a.packed[NCH_FULL * CHUNK_FLOATS + i];
-    const u32x4 *gb3 = reinterpret_cast<const u32x4 *>(packed_b3);
-#pragma unroll
-    for (int q = 0; q < 2 * NST; ++q) ring[q * NT + tid] = gb3[q * NT + tid];                  // chunks 0, 1 -> slots 0, 1
+    // the image is 33 chunks; the 34th (second half of the last pair) lies beyond the buffer's range and loads as zeros - it is never multiplied
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)packed_b3, (short)0, (int)B3_BYTES, 0x00020000);
     const int wv = tid * 16;
     auto ldw = [&](int u4_index) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rsw, wv, u4_index * 16, 0); };
+#pragma unroll
+    for (int q = 0; q < 2 * NST; ++q) ring[q * NT + tid] = ldw(q * NT);                       // pairs 0, 1 -> slots 0, 1
     u32x4 st[NST];
 #pragma unroll
-    for (int q = 0; q < NST; ++q) st[q] = ldw(2 * B3_CH_U4 + q * NT);                        // chunk 2 staged
-    int cur = 0;
+    for (int q = 0; q < NST; ++q) st[q] = ldw(2 * B3R_SLOT_U4 + q * NT);                      // pair 2 staged
+    int pslot = 0;                                                                            // ring slot (0..2) of the pair being multiplied
 
     const float ox = a.rays_o[rc * 3 + 0], oy = a.rays_o[rc * 3 + 1], oz = a.rays_o[rc * 3 + 2];
     const float dx = a.rays_d[rc * 3 + 0], dy = a.rays_d[rc * 3 + 1], dz = a.rays_d[rc * 3 + 2];
@@ -918,8 +989,7 @@ __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const un
     const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
     const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
 
-    // view-direction encoding, this half's 14 of the 27 (+1 pad) entries (as k_march), split once per ray
-    u32x4 bev0[3], bev1[3];
+    B3Op bev0, bev1;
     {
         f32x16 ev;
         const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -944,23 +1014,54 @@ __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const un
             }
             ev[s] = val;
         }
-        split_b3(ev, 0, bev0);
-        split_b3(ev, 1, bev1);
+        split_b3(ev, 0, bev0.p);
+        split_b3(ev, 1, bev1.p);
     }
 
     float zc;
     if (a.z) zc = a.z_tiled ? a.z[zt_base] : a.z[rc * S];
     else zc = nr * (1.f - linspace01(0, S)) + fr_ * linspace01(0, S);
     __syncthreads();
+    u32x4 w[12];                                                                              // fragments of the current chunk
+#pragma unroll
+    for (int i = 0; i < 12; ++i) w[i] = ring[i * 64 + lane];
 
-    // Ring invariant while chunk g is consumed: slot `cur` holds g, the other slot holds (or is being filled with) g+1, the staging
-    // registers hold (or are receiving) g+2.  B3_ADV(g), executed when moving on to chunk g: barrier (everybody is done with g-1, the
-    // writes of g are visible), flip, write the staged g+1 into the slot g-1 released, start loading g+2.
-#define B3_ADV(g)                                                                                                   \
-    __syncthreads();                                                                                                \
-    cur ^= B3_CH_U4;                                                                                                \
-    _Pragma("unroll") for (int q_ = 0; q_ < NST; ++q_) ring[(cur ^ B3_CH_U4) + q_ * NT + tid] = st[q_];             \
-    _Pragma("unroll") for (int q_ = 0; q_ < NST; ++q_) st[q_] = ldw((((g) + 2) % B3_NCH) * B3_CH_U4 + q_ * NT);
+    // Ring while pair P (chunks 2P, 2P+1) is multiplied: its slot and the next pair's are complete and visible; the slot of pair P-1 takes
+    // the staged pair P+2 right after the barrier that opens P, the staging registers then receive pair P+3.  A chunk's fragments are read
+    // into registers behind the MFMAs of the chunk before it.
+    // run(g, ...): [g even: barrier, ring write, loads] the 24 MFMAs of chunk g with their slices and the fragment reads of chunk g+1.
+    const float *aw = small + SM_AW;
+    auto run = [&](auto gc, auto nt2c, auto tmc, auto &acc, const B3Op &oa, const B3Op &ob, auto &&slice) {
+        constexpr int g = decltype(gc)::value, NT2 = decltype(nt2c)::value;
+        constexpr bool TM = decltype(tmc)::value;
+        constexpr bool last_of_pair = (g & 1) || g == B3_NCH - 1;
+        const int s_cur = pslot * B3R_SLOT_U4, s_nxt = (pslot == 2 ? 0 : pslot + 1) * B3R_SLOT_U4, s_old = (pslot == 0 ? 2 : pslot - 1) * B3R_SLOT_U4;
+        constexpr bool ring_here = !(ABL & 4) && (g & 1) == 0;       // the first chunk of a pair carries the ring traffic
+        if constexpr (ring_here && !(ABL & 64)) __syncthreads();      // (64: timing only - no barrier; 128: no ring traffic; 512: no LDS writes; 1024: no loads)
+        const u32x4 *nxt = ring + ((ABL & 4) ? 0 : (last_of_pair ? s_nxt : s_cur + B3_CH_U4));
+        u32x4 wn[12];
+        b3_chunk<NT2, TM>(acc, oa, ob, w, [&](auto ic) {
+            constexpr int idx = decltype(ic)::value;
+            if constexpr (idx < 12) wn[idx] = nxt[idx * 64 + lane];
+            // ring traffic one instruction per gap (in a burst behind the barrier each ds_write_b128 cost ~100 cycles: profiles/r04_render_b3_ablations.md)
+            if constexpr (ring_here && !(ABL & 128) && idx >= 12 && idx < 12 + NST) {
+                if constexpr (!(ABL & 512)) ring[s_old + (idx - 12) * NT + tid] = st[idx - 12];
+                else asm volatile("" ::"v"(st[idx - 12]));
+            }
+            if constexpr (ring_here && !(ABL & 128) && !(ABL & 1024) && idx >= 12 + NST && idx < 12 + 2 * NST)
+                st[idx - 12 - NST] = ldw(((g / 2 + 3) % B3R_NPAIR) * B3R_SLOT_U4 + (idx - 12 - NST) * NT);
+            if constexpr (!(ABL & 256)) slice(ic);                   // (256: timing only - no operand preparation behind the MFMAs)
+        });
+#pragma unroll
+        for (int i = 0; i < 12; ++i) w[i] = wn[i];
+        if constexpr (last_of_pair) pslot = pslot == 2 ? 0 : pslot + 1;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    auto none = [](auto) {};
+    using C4 = std::integral_constant<int, 4>;
+    using C2 = std::integral_constant<int, 2>;
+    using TMy = std::true_type;
+    using TMn = std::false_type;
 
     for (int s = 0; s < S; ++s) {
         float zn = 0.f;
@@ -975,6 +1076,10 @@ __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const un
         const float nz = 2.f * (pz - bmin2) / bext2 - 1.f;
         f32x16 f;
         f[15] = 0.f;
+        if constexpr (ABL & 1) {
+#pragma unroll
+            for (int i = 0; i < 15; ++i) f[i] = nx * (float)i + ny;
+        } else
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int qlo = i, qhi = (i + 5 > 8) ? 8 : i + 5;
@@ -1010,64 +1115,95 @@ __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const un
             f[3 * i + 1] = live ? r1 : 0.f;
             f[3 * i + 2] = live ? r2 : 0.f;
         }
-        u32x4 bf0[3], bf1[3], bb[3];
-        split_b3(f, 0, bf0);
-        split_b3(f, 1, bf1);
+        B3Op bf0, bf1, oa, ob;                                     // feature operands; the operands in flight
+        if constexpr (ABL & 256) { oa = bev0; ob = bev1; bf1 = bev0; }
+        B3Tmp tm;
+        float asum = 0.f, dummy = 0.f;
+        b3_seq<12>([&](auto ic) { b3_prep_step<0, 0, decltype(ic)::value>(f, bf0, tm, dummy, aw); });
         // ---- MLP  [renderer.py:134-156]: chunk g = fragment positions 4g .. 4g+3 ----
         f32x16 X[4], Y[4];
         load_bias<4>(X, small + SM_B0, half);
-        mma_b3<4>(X, bf0, ring + cur, 0, lane);                                     // chunk 0 (current at loop entry)
-        B3_ADV(1) mma_b3<4>(X, bf1, ring + cur, 0, lane);
+        // L0 (chunks 0, 1).  Behind chunk 0: the split of the features' second half; chunk 1 tile-major, behind tiles 1..3: X[0] half 0
+        run(I0{}, C4{}, TMn{}, X, bf0, bf0, [&](auto ic) { b3_prep_step<0, 1, decltype(ic)::value>(f, bf1, tm, dummy, aw); });
+        run(std::integral_constant<int, 1>{}, C4{}, TMy{}, X, bf1, bf1, [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i >= 6) {   // 24 slices behind 18 MFMAs: 4 slices per 3 gaps
+                constexpr int lo = (4 * (i - 6)) / 3, hi = (4 * (i - 5)) / 3;
+                b3_seq<hi - lo>([&](auto uc) { b3_prep_step<1, 0, lo + decltype(uc)::value>(X[0], oa, tm, dummy, aw); });
+            }
+        });
         load_bias<4>(Y, small + SM_B1, half);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {                                               // L1: chunks 2..9
-            X[k] = softplus16(X[k]);
-            split_b3(X[k], 0, bb);
-            B3_ADV(2 + 2 * k) mma_b3<4>(Y, bb, ring + cur, 0, lane);
-            split_b3(X[k], 1, bb);
-            B3_ADV(3 + 2 * k) mma_b3<4>(Y, bb, ring + cur, 0, lane);
-        }
+        // L1 (chunks 2..9): chunk 2 + 2k + h takes softplus(X[k]) half h; the operand of the next chunk is prepared behind this one's MFMAs
+        b3_seq<8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value, k = j >> 1, h = j & 1;      // this chunk: (k, h); next: (k + h, h ^ 1)
+            constexpr int kn = k + h, hn = h ^ 1;
+            if constexpr (h == 0) run(std::integral_constant<int, 2 + j>{}, C4{}, TMn{}, Y, oa, oa, [&](auto ic) { b3_prep_step<1, hn, decltype(ic)::value>(X[kn < 4 ? kn : 3], ob, tm, dummy, aw); });
+            else if constexpr (kn < 4) run(std::integral_constant<int, 2 + j>{}, C4{}, TMn{}, Y, ob, ob, [&](auto ic) { b3_prep_step<1, hn, decltype(ic)::value>(X[kn < 4 ? kn : 3], oa, tm, dummy, aw); });
+            else run(std::integral_constant<int, 2 + j>{}, C4{}, TMn{}, Y, ob, ob, none);
+        });
+        // L2, feature part (chunks 10, 11); behind chunk 11: softplus(Y[0]) half 0
         load_bias<4>(X, small + SM_B2, half);
-        B3_ADV(10) mma_b3<4>(X, bf0, ring + cur, 0, lane);                          // L2 (features): chunks 10, 11
-        B3_ADV(11) mma_b3<4>(X, bf1, ring + cur, 0, lane);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {                                               // L2 (hidden): chunks 12..19
-            Y[k] = softplus16(Y[k]);
-            split_b3(Y[k], 0, bb);
-            B3_ADV(12 + 2 * k) mma_b3<4>(X, bb, ring + cur, 0, lane);
-            split_b3(Y[k], 1, bb);
-            B3_ADV(13 + 2 * k) mma_b3<4>(X, bb, ring + cur, 0, lane);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) X[k] = softplus16(X[k]);
-        const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];
+        run(std::integral_constant<int, 10>{}, C4{}, TMn{}, X, bf0, bf0, none);
+        run(std::integral_constant<int, 11>{}, C4{}, TMn{}, X, bf1, bf1, [&](auto ic) { b3_prep_step<1, 0, decltype(ic)::value>(Y[0], oa, tm, dummy, aw); });
+        // L2, hidden part (chunks 12..19); the last chunk tile-major with softplus(X[0]) half 0 (-> density head + feature_linear) behind tiles 1..3
+        b3_seq<8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value, k = j >> 1, h = j & 1;
+            constexpr int kn = k + h, hn = h ^ 1;
+            if constexpr (h == 0) run(std::integral_constant<int, 12 + j>{}, C4{}, TMn{}, X, oa, oa, [&](auto ic) { b3_prep_step<1, hn, decltype(ic)::value>(Y[kn < 4 ? kn : 3], ob, tm, dummy, aw); });
+            else if constexpr (kn < 4) run(std::integral_constant<int, 12 + j>{}, C4{}, TMn{}, X, ob, ob, [&](auto ic) { b3_prep_step<1, hn, decltype(ic)::value>(Y[kn < 4 ? kn : 3], oa, tm, dummy, aw); });
+            else run(std::integral_constant<int, 12 + j>{}, C4{}, TMy{}, X, ob, ob, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i >= 6) {
+                    constexpr int lo = (4 * (i - 6)) / 3, hi = (4 * (i - 5)) / 3;
+                    b3_seq<hi - lo>([&](auto uc) { b3_prep_step<2, 0, lo + decltype(uc)::value>(X[0], oa, tm, asum, aw + (0 * 2 + half) * 16); });
+                }
+            });
+        });
+        // feature_linear (chunks 20..27): softplus(X[k]) half h (the density head rides along); the last chunk tile-major with the raw split of
+        // Y[0] (both halves: the two k-groups of chunk 28) behind tiles 1..3
         load_bias<4>(Y, small + SM_BF, half);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {                                               // feature_linear: chunks 20..27
-            split_b3(X[k], 0, bb);
-            B3_ADV(20 + 2 * k) mma_b3<4>(Y, bb, ring + cur, 0, lane);
-            split_b3(X[k], 1, bb);
-            B3_ADV(21 + 2 * k) mma_b3<4>(Y, bb, ring + cur, 0, lane);
-        }
+        B3Op oc, od;
+        if constexpr (ABL & 256) { oc = bev0; od = bev1; }
+        b3_seq<8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value, k = j >> 1, h = j & 1;
+            constexpr int kn = k + h, hn = h ^ 1;
+            if constexpr (h == 0) run(std::integral_constant<int, 20 + j>{}, C4{}, TMn{}, Y, oa, oa, [&](auto ic) { b3_prep_step<2, hn, decltype(ic)::value>(X[kn < 4 ? kn : 3], ob, tm, asum, aw + ((kn < 4 ? kn : 3) * 2 + half) * 16); });
+            else if constexpr (kn < 4) run(std::integral_constant<int, 20 + j>{}, C4{}, TMn{}, Y, ob, ob, [&](auto ic) { b3_prep_step<2, hn, decltype(ic)::value>(X[kn < 4 ? kn : 3], oa, tm, asum, aw + ((kn < 4 ? kn : 3) * 2 + half) * 16); });
+            else run(std::integral_constant<int, 20 + j>{}, C4{}, TMy{}, Y, ob, ob, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i >= 6) {   // 2 x 12 slices behind 18 MFMAs
+                    constexpr int lo = (4 * (i - 6)) / 3, hi = (4 * (i - 5)) / 3;
+                    b3_seq<hi - lo>([&](auto uc) {
+                        constexpr int st_ = lo + decltype(uc)::value;
+                        if constexpr (st_ < 12) b3_prep_step<0, 0, st_>(Y[0], oc, tm, dummy, aw);
+                        else b3_prep_step<0, 1, st_ - 12>(Y[0], od, tm, dummy, aw);
+                    });
+                }
+            });
+        });
+        const float sigma_raw = (asum + __shfl_xor(asum, 32)) + small[SM_AB];
+        // views_linear, feature part (chunks 28..31: two k-groups x two tiles each), then the direction encoding (chunk 32)
         f32x16 V[2];
         load_bias<2>(V, small + SM_BV, half);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {                                               // views_linear (feature part): chunks 28..31, two k-groups each
-            B3_ADV(28 + k)
-            split_b3(Y[k], 0, bb);
-            mma_b3<2>(V, bb, ring + cur, 0, lane);
-            split_b3(Y[k], 1, bb);
-            mma_b3<2>(V, bb, ring + cur, 2, lane);
-        }
-        B3_ADV(32)                                                                  // views_linear (direction encoding)
-        mma_b3<2>(V, bev0, ring + cur, 0, lane);
-        mma_b3<2>(V, bev1, ring + cur, 2, lane);
+        b3_seq<4>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            auto prep2 = [&](auto ic) {   // the two operands of chunk 28 + k + 1: 2 x 12 slices behind 24 MFMAs
+                constexpr int i = decltype(ic)::value;
+                if constexpr (k < 3) {
+                    B3Op &na = (k & 1) ? oc : oa, &nb = (k & 1) ? od : ob;
+                    if constexpr (i < 12) b3_prep_step<0, 0, i>(Y[k + 1 < 4 ? k + 1 : 3], na, tm, dummy, aw);
+                    else b3_prep_step<0, 1, i - 12>(Y[k + 1 < 4 ? k + 1 : 3], nb, tm, dummy, aw);
+                }
+            };
+            if constexpr ((k & 1) == 0) run(std::integral_constant<int, 28 + k>{}, C2{}, TMn{}, V, oc, od, prep2);
+            else run(std::integral_constant<int, 28 + k>{}, C2{}, TMn{}, V, oa, ob, prep2);
+        });
+        run(std::integral_constant<int, 32>{}, C2{}, TMn{}, V, bev0, bev1, none);
         V[0] = softplus16(V[0]);
         V[1] = softplus16(V[1]);
         const float cr = dot_lane<2>(V, small + SM_RW, half) + small[SM_RB + 0];
         const float cg = dot_lane<2>(V, small + SM_RW + 64, half) + small[SM_RB + 1];
         const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
-        B3_ADV(B3_NCH)                                                              // chunk 0 of the next sample
         if (tile * 32 < a.R) {   // lanes 0-31 store (sigma, r), lanes 32-63 (g, b); hidden store: see k_march
             const float2 rec = half ? make_float2(cg, cb) : make_float2(sigma_raw, cr);
             float *dst = reinterpret_cast<float *>(a.vals_out + (zt_base + 32LL * s)) + 2 * half;
@@ -1075,7 +1211,6 @@ __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const un
         }
         zc = zn;
     }
-#undef B3_ADV
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2747,7 +2882,24 @@ static int render_eval_impl(const void *mlp_packed, const void *planes_packed, i
     a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
     if (mlp_mode == 2) {   // HL_RENDER_MLP_BF16X3: exact three-way bf16 split of both operands, six partial products, fp32 accumulation
         const unsigned short *pb3 = reinterpret_cast<const unsigned short *>(static_cast<const char *>(mlp_packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024);
-        hipLaunchKernelGGL(k_march_b3, dim3((unsigned)((n_rays + 127) / 128)), dim3(256), 0, (hipStream_t)stream, a, pb3);
+        const dim3 grid((unsigned)((n_rays + 127) / 128));
+#define HL_B3_LAUNCH(A)                                                                                                                    \
+    case A: {                                                                                                                              \
+        static const bool ok_ = hipFuncSetAttribute((const void *)k_march_b3<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3R_LDS) == hipSuccess; \
+        HL_REQUIRE(ok_, "k_march_b3: cannot raise the dynamic LDS limit to %zu bytes", B3R_LDS);                                           \
+        hipLaunchKernelGGL(k_march_b3<A>, grid, dim3(256), B3R_LDS, (hipStream_t)stream, a, pb3);                                          \
+        break;                                                                                                                             \
+    }
+#ifdef HL_B3_ABLATIONS   // developer builds (HL_RENDER_FLAGS=-DHL_B3_ABLATIONS): timing ablations selected by the environment, wrong images
+        static const int abl = getenv("HL_B3_ABL") ? atoi(getenv("HL_B3_ABL")) : 0;
+        switch (abl) {
+            HL_B3_LAUNCH(4) HL_B3_LAUNCH(64) HL_B3_LAUNCH(128) HL_B3_LAUNCH(256) HL_B3_LAUNCH(512) HL_B3_LAUNCH(1024)
+            default: HL_B3_LAUNCH(0)
+        }
+#else
+        switch (0) { default: HL_B3_LAUNCH(0) }
+#endif
+#undef HL_B3_LAUNCH
         return hl::check_launch("k_march_b3");
     }
     if (mlp_mode == 1) {   // HL_RENDER_MLP_FP16 (opt-in): fp16 operands, all weights LDS-resident

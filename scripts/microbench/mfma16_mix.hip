@@ -60,6 +60,11 @@ __global__ __launch_bounds__(256, 1) void k(const float *src, const float *wimg,
                 for (int f = 0; f < NV; ++f) {
                     constexpr int dummy = 0;
                     const int q = J * NV + f;
+                    if constexpr (IND == 2) { asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s[q & 15]) : "v"(m[q & 7]), "v"(m[(q + 3) & 7])); continue; }
+                    if constexpr (IND == 3) { asm volatile("v_exp_f32 %0, %1" : "=v"(s[q & 15]) : "v"(s[(q + 5) & 15])); continue; }
+                    if constexpr (IND == 4) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m[q & 7]) : "v"(s[(q + 5) & 15]), "v"(s[(q + 9) & 15])); continue; }
+                    if constexpr (IND == 5) { asm volatile("v_accvgpr_read_b32 %0, a[7]" : "=v"(s[q & 15])); continue; }
+                    if constexpr (IND == 6) { asm volatile("v_max_i32 %0, 0, %1" : "=v"(m[q & 7]) : "v"(m[(q + 3) & 7])); continue; }
                     switch (IND ? 0 : (q & 3)) {
                         case 0: asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s[q & 15]) : "v"(a), "s"(c1)); break;
                         case 1: asm volatile("v_and_b32 %0, %1, %2" : "=v"(m[q & 7]) : "s"(msk), "v"(s[(q + 5) & 15])); break;
@@ -109,7 +114,7 @@ void run(const float *src, const float *wimg, float *sink, long long *cyc, int s
     double avg = 0; for (int i = 0; i < 1024; ++i) avg += (double)h[i]; avg /= 1024;
     const double per = avg / (iters * 108.0), ns_per = ms * 1e6 / (iters * 108.0);
     printf("[span %4d KB rot %d] %s%s VALU/gap=%2d ds_read/gap=%d weight load every %d gaps : %6.2f ns per MFMA, counter %6.2f cycles per MFMA -> %5.0f cycles per 108-MFMA k-tile, eff clock %.2f GHz\n",
-           span >> 10, rotate, F16 ? "f16 " : "bf16", IND ? " (independent v_fma)" : "", NV, LDS, LD_EVERY, ns_per, per, per * 108.0, per / ns_per);
+           span >> 10, rotate, F16 ? "f16 " : "bf16", IND == 1 ? " (independent v_fma)" : IND == 2 ? " (v_dot2c_f32_bf16)" : IND == 3 ? " (v_exp_f32)" : IND == 4 ? " (v_cvt_pk_bf16_f32)" : IND == 5 ? " (v_accvgpr_read)" : IND == 6 ? " (v_max_i32)" : "", NV, LDS, LD_EVERY, ns_per, per, per * 108.0, per / ns_per);
 }
 
 // do f16 MFMAs honour subnormal inputs?  A = 2^-20 (f16 subnormal) in every k slot of row m, B = 1: D = 16 * 2^-20 if honoured, 0 if flushed
@@ -140,8 +145,11 @@ int main() {
     run<0, 1, 0>(src, wimg, sink, cyc); run<0, 0, 2>(src, wimg, sink, cyc); run<0, 0, 1>(src, wimg, sink, cyc);
     run<4, 1, 2>(src, wimg, sink, cyc); run<6, 1, 2>(src, wimg, sink, cyc); run<7, 1, 2>(src, wimg, sink, cyc); run<8, 1, 2>(src, wimg, sink, cyc);
     run<10, 1, 2>(src, wimg, sink, cyc);
-    for (int span : {144 << 10, 576 << 10, 1152 << 10, 2592 << 10})
-        for (int rot = 0; rot < 2; ++rot) { run<0, 0, 2>(src, wimg, sink, cyc, span, rot); run<0, 0, 1>(src, wimg, sink, cyc, span, rot); run<6, 1, 2>(src, wimg, sink, cyc, span, rot); }
+    run<4, 0, 0, 0, 2>(src, wimg, sink, cyc); run<8, 0, 0, 0, 2>(src, wimg, sink, cyc); run<12, 0, 0, 0, 2>(src, wimg, sink, cyc);
+    run<2, 0, 0, 0, 3>(src, wimg, sink, cyc); run<4, 0, 0, 0, 3>(src, wimg, sink, cyc); run<8, 0, 0, 0, 3>(src, wimg, sink, cyc);
+    run<8, 0, 0, 0, 4>(src, wimg, sink, cyc); run<12, 0, 0, 0, 4>(src, wimg, sink, cyc);
+    run<8, 0, 0, 0, 5>(src, wimg, sink, cyc); run<12, 0, 0, 0, 5>(src, wimg, sink, cyc);
+    run<8, 0, 0, 0, 6>(src, wimg, sink, cyc); run<12, 0, 0, 0, 6>(src, wimg, sink, cyc);
     run<6, 0, 0, 0, 1>(src, wimg, sink, cyc); run<8, 0, 0, 0, 1>(src, wimg, sink, cyc); run<12, 0, 0, 0, 1>(src, wimg, sink, cyc);
     // the f16 two-plane variant: 54 MFMAs per k-tile carry the same transform and a cheaper split -> ~10 VALU per gap, a weight load every 1.5 gaps
     run<0, 0, 0, 1>(src, wimg, sink, cyc); run<8, 1, 2, 1>(src, wimg, sink, cyc); run<10, 1, 1, 1>(src, wimg, sink, cyc); run<12, 1, 1, 1>(src, wimg, sink, cyc);

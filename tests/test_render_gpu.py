@@ -28,9 +28,14 @@ def make_renderer(mlp, dev):
     return r.to(dev)
 
 
-def hip_render(i, dev, z_vals=None, mlp_fp16=False):
+PRODUCTS = ["bf16x3", "fp32"]   # Renderer.mlp_products: the default (exact three-way bf16 splits on the 16-bit pipe, k_march_b3) and the fp32-MFMA kernel
+
+
+def hip_render(i, dev, z_vals=None, mlp_fp16=False, products=None):
     r = make_renderer(i["mlp"], dev)
     r.mlp_fp16 = mlp_fp16
+    if products is not None:
+        r.mlp_products = products
     tp = {"world_bounds": i["bounds"][None].to(dev)}
     out = r.render(tp, None, z_vals, i["rays_o"][None].to(dev), i["rays_d"][None].to(dev), i["near"][None, :, None].to(dev),
                    i["far"][None, :, None].to(dev), i["planes"].to(dev), i["n_importance"], i["white_bkgd"],
@@ -39,10 +44,13 @@ def hip_render(i, dev, z_vals=None, mlp_fp16=False):
     return r, {k: v[0].cpu() for k, v in out.items()}
 
 
+@pytest.mark.parametrize("products", PRODUCTS)
 @pytest.mark.parametrize("name", ["a", "b", "c"])
-def test_render_matches_reference_golden(name, dev):
+def test_render_matches_reference_golden(name, products, dev):
+    """Both product modes against the REFERENCE's renders with the same bounds (the bf16x3 mode drops terms below one fp32 rounding)."""
     i, e = load_render_case(name)
-    r, out = hip_render(i, dev)
+    r, out = hip_render(i, dev, products=products)
+    assert r.mlp_products == products
     # intermediates kept in the workspace: the raw (sigma, r, g, b) records of the coarse points come first, tile-major
     R, N = i["rays_o"].shape[0], i["n_samples"]
     tiles = (R + 31) // 32
@@ -61,7 +69,7 @@ def test_fp16_mlp_mode_meets_the_north_star_bar_against_the_reference(name, dev)
     """Renderer.mlp_fp16 (opt-in; k_march16: fp16 operands, fp32 accumulation, everything around the MLP fp32) against the REFERENCE's golden
     renders: the north-star bar is PSNR >= 45 dB."""
     i, e = load_render_case(name)
-    _, ref32 = hip_render(i, dev)
+    _, ref32 = hip_render(i, dev, products="fp32")
     _, out = hip_render(i, dev, mlp_fp16=True)
     assert torch.isfinite(out["rgb_map"]).all() and not torch.equal(out["rgb_map"], ref32["rgb_map"])     # the mode really switched arithmetic
     p_ref, p_32 = psnr(out["rgb_map"], e["rgb"]), psnr(out["rgb_map"], ref32["rgb_map"])
@@ -200,8 +208,9 @@ def test_density_grid_matches_oracle(dev):
         r.extract_geometry({"world_bounds": bounds[None].to(dev)}, planes.to(dev), resolution=8)
 
 
-@pytest.mark.parametrize("R", [1, 31, 33, 64, 255, 257])
-def test_ragged_ray_counts(R, dev):
+@pytest.mark.parametrize("products", PRODUCTS)
+@pytest.mark.parametrize("R", [1, 31, 33, 64, 127, 129, 255, 257])
+def test_ragged_ray_counts(R, products, dev):
     """Ray counts that leave most of the last 256-ray workgroup / 32-ray tile empty (workspace is sized for
     ceil(R/32) tiles only; idle waves must not touch memory beyond it)."""
     from oracle import render_oracle as ro
@@ -209,7 +218,7 @@ def test_ragged_ray_counts(R, dev):
     i = dict(i)
     for k in ("rays_o", "rays_d", "near", "far", "u"):
         i[k] = i[k][:R] if R <= 256 else torch.cat([i[k], i[k][:R - 256]])
-    _, out = hip_render(i, dev)
+    _, out = hip_render(i, dev, products=products)
     rgb, acc, depth = ro.render_rays(i["mlp"], i["planes"][0], i["bounds"], i["rays_o"], i["rays_d"], i["near"], i["far"],
                                      i["n_samples"], i["n_importance"], u=i["u"])
     assert out["rgb_map"].shape == (R, 3)
@@ -311,6 +320,7 @@ def test_evaluate_once_pipeline_is_bit_identical_to_reevaluation(dev, R, N, whit
     merges; HL_RENDER_REEVALUATE runs the fine pass over all points like the reference.  Same values, same order: equal bits."""
     from humanliff_amd import synthetic as syn
     r = make_renderer(syn.render_mlp_state(3), dev)
+    r.mlp_products = "fp32"                      # the reference's schedule exists on the fp32-MFMA kernel only: the identity is a statement about that kernel
     planes = syn.triplane(seed=11).to(dev)
     ro, rd, nr, fr = [t[:R].to(dev) for t in syn.orbit_rays(5, 36, 64, 64)] if R <= 4096 else None
     tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].to(dev)}
@@ -321,6 +331,12 @@ def test_evaluate_once_pipeline_is_bit_identical_to_reevaluation(dev, R, N, whit
     for k in ("rgb_map", "acc_map", "depth_map"):
         assert torch.equal(a[k], b[k]), k
     assert float(a["acc_map"].max()) > 0.05      # not a vacuous all-empty render
+    # the default product mode against the same schedule: not the same bits (six bf16 partial products per fp32 product), the same image
+    r.mlp_products = "bf16x3"
+    c = r.render(tp, None, None, ro[None], rd[None], nr[None], fr[None], planes, N, white, n_samples=N, u=u[None])
+    assert not torch.equal(c["rgb_map"], b["rgb_map"])
+    assert (c["rgb_map"] - b["rgb_map"]).abs().max() < 5e-6 and (c["acc_map"] - b["acc_map"]).abs().max() < 5e-6
+    assert (c["depth_map"] - b["depth_map"]).abs().max() < 2e-5
 
 
 # ---- canonical-space deformation ----------------------------------------------------------------
