@@ -976,9 +976,15 @@ __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const un
     auto ldw = [&](int u4_index) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rsw, wv, u4_index * 16, 0); };
 #pragma unroll
     for (int q = 0; q < 2 * NST; ++q) ring[q * NT + tid] = ldw(q * NT);                       // pairs 0, 1 -> slots 0, 1
+    constexpr bool DMA = (ABL & 2048) != 0;   // developer A/B: the ring filled by LDS-DMA (buffer_load ... lds) instead of loads + ds_write_b128
     u32x4 st[NST];
+    if constexpr (DMA) {
 #pragma unroll
-    for (int q = 0; q < NST; ++q) st[q] = ldw(2 * B3R_SLOT_U4 + q * NT);                      // pair 2 staged
+        for (int q = 0; q < NST; ++q) ring[2 * B3R_SLOT_U4 + q * NT + tid] = ldw(2 * B3R_SLOT_U4 + q * NT);   // pair 2 -> slot 2
+    } else {
+#pragma unroll
+        for (int q = 0; q < NST; ++q) st[q] = ldw(2 * B3R_SLOT_U4 + q * NT);                  // pair 2 staged
+    }
     int pslot = 0;                                                                            // ring slot (0..2) of the pair being multiplied
 
     const float ox = a.rays_o[rc * 3 + 0], oy = a.rays_o[rc * 3 + 1], oz = a.rays_o[rc * 3 + 2];
@@ -1037,6 +1043,7 @@ __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const un
         constexpr bool last_of_pair = (g & 1) || g == B3_NCH - 1;
         const int s_cur = pslot * B3R_SLOT_U4, s_nxt = (pslot == 2 ? 0 : pslot + 1) * B3R_SLOT_U4, s_old = (pslot == 0 ? 2 : pslot - 1) * B3R_SLOT_U4;
         constexpr bool ring_here = !(ABL & 4) && (g & 1) == 0;       // the first chunk of a pair carries the ring traffic
+        if constexpr (ring_here && DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the pair requested one pair ago have landed
         if constexpr (ring_here && !(ABL & 64)) __syncthreads();      // (64: timing only - no barrier; 128: no ring traffic; 512: no LDS writes; 1024: no loads)
         const u32x4 *nxt = ring + ((ABL & 4) ? 0 : (last_of_pair ? s_nxt : s_cur + B3_CH_U4));
         u32x4 wn[12];
@@ -1044,12 +1051,18 @@ __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const un
             constexpr int idx = decltype(ic)::value;
             if constexpr (idx < 12) wn[idx] = nxt[idx * 64 + lane];
             // ring traffic one instruction per gap (in a burst behind the barrier each ds_write_b128 cost ~100 cycles: profiles/r04_render_b3_ablations.md)
-            if constexpr (ring_here && !(ABL & 128) && idx >= 12 && idx < 12 + NST) {
-                if constexpr (!(ABL & 512)) ring[s_old + (idx - 12) * NT + tid] = st[idx - 12];
-                else asm volatile("" ::"v"(st[idx - 12]));
+            if constexpr (DMA) {
+                if constexpr (ring_here && !(ABL & 128) && idx >= 12 && idx < 12 + NST)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void *)(ring + s_old + (idx - 12) * NT + (tid & ~63)), 16, lane * 16,
+                                                             (((g / 2 + 2) % B3R_NPAIR) * B3R_SLOT_U4 + (idx - 12) * NT) * 16 + (tid & ~63) * 16, 0, 0);
+            } else {
+                if constexpr (ring_here && !(ABL & 128) && idx >= 12 && idx < 12 + NST) {
+                    if constexpr (!(ABL & 512)) ring[s_old + (idx - 12) * NT + tid] = st[idx - 12];
+                    else asm volatile("" ::"v"(st[idx - 12]));
+                }
+                if constexpr (ring_here && !(ABL & 128) && !(ABL & 1024) && idx >= 12 + NST && idx < 12 + 2 * NST)
+                    st[idx - 12 - NST] = ldw(((g / 2 + 3) % B3R_NPAIR) * B3R_SLOT_U4 + (idx - 12 - NST) * NT);
             }
-            if constexpr (ring_here && !(ABL & 128) && !(ABL & 1024) && idx >= 12 + NST && idx < 12 + 2 * NST)
-                st[idx - 12 - NST] = ldw(((g / 2 + 3) % B3R_NPAIR) * B3R_SLOT_U4 + (idx - 12 - NST) * NT);
             if constexpr (!(ABL & 256)) slice(ic);                   // (256: timing only - no operand preparation behind the MFMAs)
         });
 #pragma unroll
@@ -1211,6 +1224,285 @@ __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const un
         }
         zc = zn;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_march_b3w: the same arithmetic with EIGHT waves per workgroup (two per SIMD, 256 registers each), compiler-scheduled.  The partner wave
+// covers what one wave per SIMD has to schedule by hand (LDS and L2 latencies, the VALU phases between MFMA groups), and 256 rays share every
+// weight chunk that goes through LDS - half the ring traffic per ray, which is what bounds k_march_b3 (profiles/r04_render_b3_ablations.md).
+constexpr int B3W_NPAIR = (B3_NCH - 1) / 2;                                               // 16 chunk pairs per sample: chunk 32 (direction encoding) runs once per ray
+constexpr size_t B3W_LDS = (size_t)2 * B3R_SLOT_U4 * 16 + SMALL_FLOATS * sizeof(float) + (size_t)8 * 512 * 16;
+template <int NT>
+__device__ __forceinline__ void load_bias_global(f32x16 (&acc)[NT], const float *__restrict__ tbl, int half) {   // load_bias from the packed image in global memory
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = tbl[(t * 2 + half) * 16 + r];
+}
+__device__ __forceinline__ void split_b3t(const f32x16 &v, int hi, u32x4 (&pl)[3]) {   // exact three-way split by truncation: v_and / v_perm / v_sub, all plain rate
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x = v[8 * hi + 2 * q], y = v[8 * hi + 2 * q + 1];
+        pl[0][q] = b3_pack(x, y);
+        x -= __builtin_bit_cast(float, b3_hi(x)); y -= __builtin_bit_cast(float, b3_hi(y));
+        pl[1][q] = b3_pack(x, y);
+        x -= __builtin_bit_cast(float, b3_hi(x)); y -= __builtin_bit_cast(float, b3_hi(y));
+        pl[2][q] = b3_pack(x, y);
+    }
+}
+__device__ __forceinline__ f32x16 softplus16_b3(f32x16 v) {   // softplus_hidden with max(x, 0) as v_max_i32 (no canonicalising v_max in front)
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(v[i]));
+        o[i] = fmaf(0.693147180559945309f, __builtin_amdgcn_logf(1.f + e), b3_max0(v[i]));
+    }
+    return o;
+}
+// NT output tiles x one 8-wide k-group: positions q0 .. q0+NT-1 of the chunk at `ch`; the six products, smallest first, two tiles at a time
+// (24 fragment registers in flight; the partner wave covers the LDS latency)
+template <int NT>
+__device__ __forceinline__ void mma_b3(f32x16 (&acc)[NT], const u32x4 (&b)[3], const u32x4 *__restrict__ ch, int q0, int lane) {
+    constexpr int PW[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += 2) {
+        u32x4 w[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) w[t][p] = ch[((q0 + t0 + t) * 3 + p) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][PW[i]]), __builtin_bit_cast(bf16x8, b[PB[i]]), acc[t0 + t], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const unsigned short *__restrict__ packed_b3) {
+    extern __shared__ __attribute__((aligned(16))) float ldsb[];   // [ring: 2 x 24 KB][small 4 KB][per wave: the 2 x 16 x 64 accumulator image of views_linear's bias + direction part, 8 KB]
+    constexpr int NT = 512, NST = B3R_SLOT_U4 / NT;   // threads; u32x4 per thread and chunk pair (3)
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const long long wg = (long long)xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
+    const long long tile = wg * 8 + (tid >> 6);
+    const long long ray = tile * 32 + (lane & 31);
+    const bool valid = ray < a.R;
+    const long long rc = valid ? ray : a.R - 1;
+    const long long tiles_n = (a.R + 31) / 32;
+    const long long zt_base = (tile < tiles_n ? tile : tiles_n - 1) * 32 * (long long)a.S + (lane & 31);
+
+    u32x4 *ring = reinterpret_cast<u32x4 *>(ldsb);
+    float *small = ldsb + 2 * B3R_SLOT_U4 * 4;
+    f32x4 *vinit = reinterpret_cast<f32x4 *>(small + SMALL_FLOATS) + (tid >> 6) * 512;
+    for (int i = tid; i < SMALL_FLOATS; i += NT) small[i] = a.packed[NCH_FULL * CHUNK_FLOATS + i];
+    const u32x4 *gb3 = reinterpret_cast<const u32x4 *>(packed_b3);
+#pragma unroll
+    for (int q = 0; q < 2 * NST; ++q) ring[q * NT + tid] = gb3[q * NT + tid];                  // chunk pairs 0, 1 -> slots 0, 1
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)packed_b3, (short)0, (int)B3_BYTES, 0x00020000);
+    const int wv = tid * 16;
+    auto ldw = [&](int u4_index) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rsw, wv, u4_index * 16, 0); };
+    u32x4 st[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) st[q] = ldw(2 * B3R_SLOT_U4 + q * NT);                     // pair 2 staged
+    int cur = 0;
+
+    const float ox = a.rays_o[rc * 3 + 0], oy = a.rays_o[rc * 3 + 1], oz = a.rays_o[rc * 3 + 2];
+    const float dx = a.rays_d[rc * 3 + 0], dy = a.rays_d[rc * 3 + 1], dz = a.rays_d[rc * 3 + 2];
+    const float nr = a.near[rc], fr_ = a.far[rc];
+    const int S = a.S;
+    const float offH = (float)(1.0 / (double)a.H);
+    const float bmin0 = a.bounds[0], bmin1 = a.bounds[1], bmin2 = a.bounds[2];
+    const float bext0 = a.bounds[3] - bmin0, bext1 = a.bounds[4] - bmin1, bext2 = a.bounds[5] - bmin2;
+
+    // view-direction encoding, this half's 14 of the 27 (+1 pad) entries (as k_march), split once per ray
+    {
+        u32x4 bev0[3], bev1[3];
+        f32x16 ev;
+        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float vd[3] = {dx / nrm, dy / nrm, dz / nrm};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float val = 0.f;
+            if (s < 14) {
+                const int kl = s, kh = s + 14;
+                const int jl = (kl - 3) / 3, cl = (kl - 3) % 3, jh = (kh - 3) / 3, ch = (kh - 3) % 3;
+                const float argl = kl < 3 ? 0.f : ((jl & 1) ? 1.57079632679489661923f : 0.f) + vd[kl < 3 ? 0 : cl] * (float)(1 << (jl >> 1));
+                const float argh = ((jh & 1) ? 1.57079632679489661923f : 0.f) + vd[ch] * (float)(1 << (jh >> 1));
+                if (kl < 3) {
+                    const float sh = sinf(argh);
+                    val = half ? sh : vd[kl];
+                } else if (kh >= 27) {
+                    const float sl = sinf(argl);
+                    val = half ? 0.f : sl;
+                } else {
+                    val = sinf(half ? argh : argl);
+                }
+            }
+            ev[s] = val;
+        }
+        split_b3t(ev, 0, bev0);
+        split_b3t(ev, 1, bev1);
+    // views_linear's direction part does not depend on the sample: bias + W_dir enc(dir) is formed once per ray (chunk 32, fragments straight
+    // from global memory) and parked in LDS as the accumulator image every sample starts views_linear from
+        f32x16 V0[2];
+        load_bias_global<2>(V0, a.packed + NCH_FULL * CHUNK_FLOATS + SM_BV, half);
+        mma_b3<2>(V0, bev0, gb3 + (B3_NCH - 1) * B3_CH_U4, 0, lane);
+        mma_b3<2>(V0, bev1, gb3 + (B3_NCH - 1) * B3_CH_U4, 2, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vinit[(t * 4 + q) * 64 + lane] = f32x4{V0[t][4 * q], V0[t][4 * q + 1], V0[t][4 * q + 2], V0[t][4 * q + 3]};
+    }
+
+    float zc;
+    if (a.z) zc = a.z_tiled ? a.z[zt_base] : a.z[rc * S];
+    else zc = nr * (1.f - linspace01(0, S)) + fr_ * linspace01(0, S);
+    __syncthreads();
+
+    // Ring of two 24 KB slots, each a PAIR of chunks (8 fragment positions x 3 planes).  While pair P is multiplied: slot `cur` holds P, the other
+    // slot holds (or is being filled with) P+1, the staging registers hold (or are receiving) P+2.  B3_ADV(g) in front of chunk g: nothing for
+    // the second chunk of a pair; for the first: barrier (everybody is done with pair P-1, the writes of P are visible), flip, write the staged
+    // pair P+1 into the slot P-1 released, start loading pair P+2.  One barrier per 48 MFMAs.
+#define B3_ADV(g)                                                                                                            \
+    if (((g) & 1) == 0) {                                                                                                    \
+        __syncthreads();                                                                                                     \
+        cur ^= B3R_SLOT_U4;                                                                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < NST; ++q_) ring[(cur ^ B3R_SLOT_U4) + q_ * NT + tid] = st[q_];               \
+        _Pragma("unroll") for (int q_ = 0; q_ < NST; ++q_) st[q_] = ldw(((((g) >> 1) + 2) % B3W_NPAIR) * B3R_SLOT_U4 + q_ * NT); \
+    }
+#define B3_AT(g) (ring + cur + ((g) & 1) * B3_CH_U4)
+
+    for (int s = 0; s < S; ++s) {
+        float zn = 0.f;
+        if (s + 1 < S) {
+            if (a.z) zn = a.z_tiled ? a.z[zt_base + 32LL * (s + 1)] : a.z[rc * S + s + 1];
+            else { const float t = linspace01(s + 1, S); zn = nr * (1.f - t) + fr_ * t; }
+        }
+        // ---- tri-plane features of this half (fp32, exactly as k_march)  [renderer.py:502-531] ----
+        const float px = ox + dx * zc, py = oy + dy * zc, pz = oz + dz * zc;
+        const float nx = 2.f * (px - bmin0) / bext0 - 1.f;
+        const float ny = 2.f * (py - bmin1) / bext1 - 1.f;
+        const float nz = 2.f * (pz - bmin2) / bext2 - 1.f;
+        f32x16 f;
+        f[15] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int qlo = i, qhi = (i + 5 > 8) ? 8 : i + 5;
+            const int q = half ? qhi : qlo;
+            const int p = half ? qhi / 3 : qlo / 3, g = half ? qhi % 3 : qlo % 3;
+            float gu = (p == 2) ? nz : nx;
+            float gv = (p == 1) ? nz : ny;
+            gu = (g == 1) ? gu + offH : gu;
+            gv = (g == 2) ? gv + offH : gv;
+            const float ix = ((gu + 1.f) * (float)a.W - 1.f) / 2.f;
+            const float iy = ((gv + 1.f) * (float)a.H - 1.f) / 2.f;
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+            float w_nw = (x1f - ix) * (y1f - iy), w_ne = (ix - x0f) * (y1f - iy);
+            float w_sw = (x1f - ix) * (iy - y0f), w_se = (ix - x0f) * (iy - y0f);
+            const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+            const bool vx0 = (x0 >= 0) & (x0 < a.W), vx1 = (x1 >= 0) & (x1 < a.W);
+            const bool vy0 = (y0 >= 0) & (y0 < a.H), vy1 = (y1 >= 0) & (y1 < a.H);
+            w_nw = (vx0 & vy0) ? w_nw : 0.f;
+            w_ne = (vx1 & vy0) ? w_ne : 0.f;
+            w_sw = (vx0 & vy1) ? w_sw : 0.f;
+            w_se = (vx1 & vy1) ? w_se : 0.f;
+            const int cx0 = min(max(x0, 0), a.W - 1), cx1 = min(max(x1, 0), a.W - 1);
+            const int cy0 = min(max(y0, 0), a.H - 1), cy1 = min(max(y1, 0), a.H - 1);
+            const float4 *pl = a.planes + (long long)q * a.H * a.W;
+            const float4 t_nw = pl[cy0 * a.W + cx0], t_ne = pl[cy0 * a.W + cx1];
+            const float4 t_sw = pl[cy1 * a.W + cx0], t_se = pl[cy1 * a.W + cx1];
+            const bool live = half ? (i + 5 <= 8) : true;
+            const float r0 = t_nw.x * w_nw + t_ne.x * w_ne + t_sw.x * w_sw + t_se.x * w_se;
+            const float r1 = t_nw.y * w_nw + t_ne.y * w_ne + t_sw.y * w_sw + t_se.y * w_se;
+            const float r2 = t_nw.z * w_nw + t_ne.z * w_ne + t_sw.z * w_sw + t_se.z * w_se;
+            f[3 * i + 0] = live ? r0 : 0.f;
+            f[3 * i + 1] = live ? r1 : 0.f;
+            f[3 * i + 2] = live ? r2 : 0.f;
+        }
+        u32x4 bf0[3], bf1[3], ba[3], bb[3];
+        split_b3t(f, 0, bf0);
+        split_b3t(f, 1, bf1);
+        // ---- MLP  [renderer.py:134-156]: chunk g = fragment positions 4g .. 4g+3.  Software-pipelined: the operand of chunk g+1 is prepared
+        // (softplus of a tile at its first use, three-way split of one half) in the same scheduling region as the MFMAs of chunk g, and the
+        // (__builtin_amdgcn_sched_group_barrier patterns over regions of this size do not finish compiling) ----
+        f32x16 X[4], Y[4];
+        load_bias<4>(X, small + SM_B0, half);
+        mma_b3<4>(X, bf0, B3_AT(0), 0, lane);                                       // L0: chunks 0, 1
+        B3_ADV(1) mma_b3<4>(X, bf1, B3_AT(1), 0, lane);
+        load_bias<4>(Y, small + SM_B1, half);
+        X[0] = softplus16_b3(X[0]);
+        split_b3t(X[0], 0, ba);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                               // L1: chunks 2..9 = (tile k of X, half 0 | 1)
+            B3_ADV(2 + 2 * k)
+            split_b3t(X[k], 1, bb);
+            mma_b3<4>(Y, ba, B3_AT(2 + 2 * k), 0, lane);
+            B3_ADV(3 + 2 * k)
+            if (k < 3) { X[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); }
+            mma_b3<4>(Y, bb, B3_AT(3 + 2 * k), 0, lane);
+        }
+        load_bias<4>(X, small + SM_B2, half);
+        B3_ADV(10) mma_b3<4>(X, bf0, B3_AT(10), 0, lane);                          // L2 (features): chunks 10, 11; the first hidden operand rides along
+        B3_ADV(11)
+        Y[0] = softplus16_b3(Y[0]);
+        split_b3t(Y[0], 0, ba);
+        mma_b3<4>(X, bf1, B3_AT(11), 0, lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                               // L2 (hidden): chunks 12..19
+            B3_ADV(12 + 2 * k)
+            split_b3t(Y[k], 1, bb);
+            mma_b3<4>(X, ba, B3_AT(12 + 2 * k), 0, lane);
+            B3_ADV(13 + 2 * k)
+            if (k < 3) { Y[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(Y[k + 1 < 4 ? k + 1 : 3]); split_b3t(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); }
+            mma_b3<4>(X, bb, B3_AT(13 + 2 * k), 0, lane);
+        }
+        load_bias<4>(Y, small + SM_BF, half);
+        X[0] = softplus16_b3(X[0]);
+        split_b3t(X[0], 0, ba);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                               // feature_linear: chunks 20..27
+            B3_ADV(20 + 2 * k)
+            split_b3t(X[k], 1, bb);
+            mma_b3<4>(Y, ba, B3_AT(20 + 2 * k), 0, lane);
+            B3_ADV(21 + 2 * k)
+            if (k < 3) { X[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); }
+            mma_b3<4>(Y, bb, B3_AT(21 + 2 * k), 0, lane);
+        }
+        const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];   // X holds softplus(pts_linears.2) by now
+        f32x16 V[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v4 = vinit[(t * 4 + q) * 64 + lane];
+                V[t][4 * q] = v4[0]; V[t][4 * q + 1] = v4[1]; V[t][4 * q + 2] = v4[2]; V[t][4 * q + 3] = v4[3];
+            }
+        split_b3t(Y[0], 0, ba);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                               // views_linear (feature part): chunks 28..31, two k-groups each
+            B3_ADV(28 + k)
+            split_b3t(Y[k], 1, bb);
+            mma_b3<2>(V, ba, B3_AT(28 + k), 0, lane);
+            if (k < 3) split_b3t(Y[k + 1 < 4 ? k + 1 : 3], 0, ba);
+            mma_b3<2>(V, bb, B3_AT(28 + k), 2, lane);
+        }
+        V[0] = softplus16_b3(V[0]);
+        V[1] = softplus16_b3(V[1]);
+        const float cr = dot_lane<2>(V, small + SM_RW, half) + small[SM_RB + 0];
+        const float cg = dot_lane<2>(V, small + SM_RW + 64, half) + small[SM_RB + 1];
+        const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
+        B3_ADV(B3_NCH - 1)                                                          // pair 0 of the next sample (the stream of a sample is chunks 0..31)
+        if (tile * 32 < a.R) {   // lanes 0-31 store (sigma, r), lanes 32-63 (g, b); hidden store: see k_march
+            const float2 rec = half ? make_float2(cg, cb) : make_float2(sigma_raw, cr);
+            float *dst = reinterpret_cast<float *>(a.vals_out + (zt_base + 32LL * s)) + 2 * half;
+            asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst), "v"(rec) : "memory");
+        }
+        zc = zn;
+    }
+#undef B3_ADV
+#undef B3_AT
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2882,6 +3174,13 @@ static int render_eval_impl(const void *mlp_packed, const void *planes_packed, i
     a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
     if (mlp_mode == 2) {   // HL_RENDER_MLP_BF16X3: exact three-way bf16 split of both operands, six partial products, fp32 accumulation
         const unsigned short *pb3 = reinterpret_cast<const unsigned short *>(static_cast<const char *>(mlp_packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024);
+        static const int b3_waves = getenv("HL_B3_WAVES") ? atoi(getenv("HL_B3_WAVES")) : 8;   // developer switch: 4 = k_march_b3 (one wave per SIMD, hand-scheduled)
+        if (b3_waves == 8) {
+            static const bool okw = hipFuncSetAttribute((const void *)k_march_b3w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3W_LDS) == hipSuccess;
+            HL_REQUIRE(okw, "k_march_b3w: cannot raise the dynamic LDS limit to %zu bytes", B3W_LDS);
+            hipLaunchKernelGGL(k_march_b3w, dim3((unsigned)((n_rays + 255) / 256)), dim3(512), B3W_LDS, (hipStream_t)stream, a, pb3);
+            return hl::check_launch("k_march_b3w");
+        }
         const dim3 grid((unsigned)((n_rays + 127) / 128));
 #define HL_B3_LAUNCH(A)                                                                                                                    \
     case A: {                                                                                                                              \
@@ -2893,7 +3192,7 @@ static int render_eval_impl(const void *mlp_packed, const void *planes_packed, i
 #ifdef HL_B3_ABLATIONS   // developer builds (HL_RENDER_FLAGS=-DHL_B3_ABLATIONS): timing ablations selected by the environment, wrong images
         static const int abl = getenv("HL_B3_ABL") ? atoi(getenv("HL_B3_ABL")) : 0;
         switch (abl) {
-            HL_B3_LAUNCH(4) HL_B3_LAUNCH(64) HL_B3_LAUNCH(128) HL_B3_LAUNCH(256) HL_B3_LAUNCH(512) HL_B3_LAUNCH(1024)
+            HL_B3_LAUNCH(4) HL_B3_LAUNCH(64) HL_B3_LAUNCH(128) HL_B3_LAUNCH(256) HL_B3_LAUNCH(512) HL_B3_LAUNCH(1024) HL_B3_LAUNCH(2048)
             default: HL_B3_LAUNCH(0)
         }
 #else
