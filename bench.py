@@ -435,9 +435,10 @@ def ddim50_parity(model, dev, golden=None):
             "workload": "F4 net, DDIM-50 (ddim_sample_loop_progressive), B=1, cloth layer 1 with a seeded x_cond"}
 
 
-def e2e_slice(model, dev, rank, world, n_layers=4, ddim=50, n_views=185, res=512, n_check_views=3, n_check_rays=1024, oracle=True):
-    """The real per-GPU slice of BASELINE configs[3] / [4] (scripts/triplane_sample_layered.py:112-213): per rank ONE subject x
-    `n_layers` cloth layers chained through x_cond x DDIM-`ddim` on the production network (B = 1, like the shipped sampling script),
+def e2e_slice(model, dev, rank, world, n_layers=4, ddim=50, n_views=185, res=512, n_check_views=3, n_check_rays=1024, oracle=True, subjects_per_gpu=8, batch=8):
+    """The real per-GPU slice of BASELINE configs[3] / [4] (scripts/triplane_sample_layered.py:112-213) AT ITS REAL SIZE: per rank
+    `subjects_per_gpu` subjects (64 subjects over 8 GPUs = 8 each), sampled `batch` at a time x
+    `n_layers` cloth layers chained through x_cond x DDIM-`ddim` on the production network,
     the finished tri-plane reshaped to (1,3,9,256,256) and rendered into `n_views` orbit views of res x res at 128 + 128 samples, the
     samples and the uint8 images gathered over the ranks - humanliff_amd.distributed.sample_and_render, the code the multi-GPU script
     runs.  Timed as a whole and per stage (HIP events around the sampling and the render part); with `oracle`, `n_check_rays` rays of
@@ -464,8 +465,7 @@ def e2e_slice(model, dev, rank, world, n_layers=4, ddim=50, n_views=185, res=512
         if state["calls"] == 0:
             ev["s0"].record()
         state["calls"] += 1
-        g = torch.Generator().manual_seed(4000 + 100 * ids[0] + layer)
-        noise = torch.randn((len(ids),) + shape, generator=g).to(dev)
+        noise = torch.stack([torch.randn(shape, generator=torch.Generator().manual_seed(4000 + 100 * i + layer)) for i in ids]).to(dev)   # per subject: independent of the batching
         y = torch.full((len(ids),), layer, dtype=torch.int64, device=dev)
         return diffusion.ddim_sample_loop(model, (len(ids),) + shape, x_cond=x_cond, noise=noise, clip_denoised=True, model_kwargs={"y": y}, device=dev)
 
@@ -482,30 +482,34 @@ def e2e_slice(model, dev, rank, world, n_layers=4, ddim=50, n_views=185, res=512
         K, R, T = cam(v)
         return render_view(res, res, K, R, T, planes, tp, rend, n_samples=128, n_importance=128, u=u)[0]
 
-    # warm-up outside the timed region: one B=1 forward (binds the B=1 workspace) and one small view (packs the MLP)
+    # warm-up outside the timed region: one forward at the sampling batch (binds that workspace) and one small view (packs the MLP)
+    spg, nsub = subjects_per_gpu, world * subjects_per_gpu
     with torch.no_grad():
-        model(torch.zeros((1,) + shape, device=dev), torch.zeros((1,), dtype=torch.int64, device=dev), torch.zeros((1,) + shape, device=dev),
-              y=torch.zeros((1,), dtype=torch.int64, device=dev))
+        model(torch.zeros((batch,) + shape, device=dev), torch.zeros((batch,), dtype=torch.int64, device=dev), torch.zeros((batch,) + shape, device=dev),
+              y=torch.zeros((batch,), dtype=torch.int64, device=dev))
     render_view(*syn_cam64(syn), torch.zeros((1, 3, 9, 256, 256), device=dev), tp, rend, n_samples=128, n_importance=128)
     barrier(world)
+    torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
-    samples, images = hd.sample_and_render(sample_fn, render_fn, world, n_layers, shape, 1, n_views, (res, res, 3), dev, as_uint8=True)
+    samples, images = hd.sample_and_render(sample_fn, render_fn, nsub, n_layers, shape, batch, n_views, (res, res, 3), dev, as_uint8=True)
     ev["r1"].record()
     barrier(world)
     secs = max_over_ranks(time.perf_counter() - t0, world, dev)
     t_sample, t_render = ev["s0"].elapsed_time(ev["s1"]) * 1e-3, ev["s1"].elapsed_time(ev["r1"]) * 1e-3
-    steps, rays = world * n_layers * ddim, world * n_views * res * res
-    assert samples.shape == (world, n_layers) + shape and images.shape == (world, n_views, res, res, 3) and images.dtype == torch.uint8
+    steps, rays = nsub * n_layers * ddim, nsub * n_views * res * res
+    assert samples.shape == (nsub, n_layers) + shape and images.shape == (nsub, n_views, res, res, 3) and images.dtype == torch.uint8
     assert torch.isfinite(samples).all()
-    out = {"workload": f"configs[3]/[4] per-GPU slice: 1 subject per GPU x {n_layers} cloth layers x DDIM-{ddim} (production F4 net, B=1, layers chained "
-                       f"through x_cond) -> reshape(1,3,9,256,256) -> {n_views} orbit views {res}x{res} @128+128 -> gather of samples (fp32) and "
-                       "images (uint8); humanliff_amd.distributed.sample_and_render",
-           "seconds": round(secs, 3), "subjects": world, "denoise_steps": steps, "rays": rays,
-           "sampling": {"seconds_rank0": round(t_sample, 3), "denoise_steps_per_sec_per_gpu": round(n_layers * ddim / t_sample, 2), "batch": 1},
-           "rendering": {"seconds_rank0": round(t_render, 3), "mrays_per_sec_per_gpu": round(n_views * res * res / t_render / 1e6, 4),
-                         "ms_per_view": round(t_render * 1e3 / n_views, 3),
+    out = {"workload": f"configs[3]/[4] per-GPU slice at its real size: {spg} subjects per GPU (sampled {batch} at a time) x {n_layers} cloth layers x DDIM-{ddim} "
+                       f"(production F4 net, layers chained through x_cond) -> reshape(1,3,9,256,256) -> {n_views} orbit views {res}x{res} @128+128 per subject "
+                       "(Renderer.mlp_products = bf16x3) -> gather of samples (fp32) and, per subject and asynchronously, images (uint8); "
+                       "humanliff_amd.distributed.sample_and_render",
+           "seconds": round(secs, 3), "subjects": nsub, "subjects_per_gpu": spg, "seconds_per_subject": round(secs / spg, 3), "denoise_steps": steps, "rays": rays,
+           "sampling": {"seconds_rank0": round(t_sample, 3), "denoise_steps_per_sec_per_gpu": round(spg * n_layers * ddim / t_sample, 2), "batch": batch},
+           "rendering": {"seconds_rank0": round(t_render, 3), "mrays_per_sec_per_gpu": round(spg * n_views * res * res / t_render / 1e6, 4),
+                         "ms_per_view": round(t_render * 1e3 / (spg * n_views), 3), "views_per_gpu": spg * n_views, "mlp_products": rend.mlp_products,
                          "note": "includes device ray generation (hl_camera_rays), the uint8 conversion and the per-subject image gather"},
-           "subjects_per_hour_per_gpu": round(3600.0 / secs, 1), "image_mean": float(images.float().mean()) / 255.0,
+           "peak_device_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2), "image_gather_buffer_gb": round(images.numel() / 1e9, 3),
+           "subjects_per_hour_per_gpu": round(3600.0 * spg / secs, 1), "image_mean": float(images.float().mean()) / 255.0,
            "sample_abs_max": float(samples.abs().max())}
     if oracle and rank == 0:
         from oracle import render_oracle as ro
@@ -690,32 +694,61 @@ def bench_render(args, rank, world, dev):
     z_new = torch.empty(T32 * N, device=dev)
     rgb, acc, dep = torch.empty((R, 3), device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
     bd = tp["world_bounds"][0].contiguous()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     p, s = _lib.ptr, _lib.stream_ptr
-    ev[0].record()
-    _lib.check(L.hl_render_eval(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), None, 0, R, N, p(rec_c), s()))
-    ev[1].record()
-    _lib.check(L.hl_render_importance_new(p(rec_c), p(rd), p(nr), p(fr), None, p(u), R, N, N, p(z_new), s()))
-    ev[2].record()
-    _lib.check(L.hl_render_eval(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), p(z_new), 1, R, N, p(rec_n), s()))
-    ev[3].record()
-    _lib.check(L.hl_render_composite(p(nr), p(fr), None, p(z_new), p(rec_c), p(rec_n), R, N, N, 2, p(rgb), p(acc), p(dep), s()))
-    ev[4].record()
-    torch.cuda.synchronize()
-    t_a, t_i, t_b, t_c = [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
-    eval_flop = R * N * FULL_FLOP_PER_POINT                     # one k_march<eval> launch: full MLP at 128 points per ray
-    achieved = eval_flop / (t_b * 1e-3) / 1e12
+
+    def stages(flags):   # the four launches of one view with HIP events on the launch stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        for _ in range(2):   # (first pass: warm-up of this mode)
+            ev[0].record()
+            _lib.check(L.hl_render_eval_products(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), None, 0, R, N, flags, p(rec_c), s()))
+            ev[1].record()
+            _lib.check(L.hl_render_importance_new(p(rec_c), p(rd), p(nr), p(fr), None, p(u), R, N, N, p(z_new), s()))
+            ev[2].record()
+            _lib.check(L.hl_render_eval_products(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), p(z_new), 1, R, N, flags, p(rec_n), s()))
+            ev[3].record()
+            _lib.check(L.hl_render_composite(p(nr), p(fr), None, p(z_new), p(rec_c), p(rec_n), R, N, N, 2, p(rgb), p(acc), p(dep), s()))
+            ev[4].record()
+            torch.cuda.synchronize()
+        return [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
+
+    eval_flop = R * N * FULL_FLOP_PER_POINT                     # one evaluate launch: full MLP at 128 points per ray
+    # default product mode (Renderer.mlp_products = "bf16x3"): k_march_b3w.  Its MFMAs: 768 v_mfma_f32_32x32x16_bf16 per 32 points and
+    # sample (32 chunks x 4 positions x 6 partial products) = 786 432 FLOP per point issued on the 16-bit pipe (dense peak 2.5 PFLOP/s)
+    t_a, t_i, t_b, t_c = stages(_lib.HL_RENDER_MLP_BF16X3)
+    issued = R * N * 786432.0
     view_ms = t_a + t_i + t_b + t_c
-    roof = {"bound": "mfma", "kernel": "k_march<true,true> (evaluate pass: tri-plane gather + full MLP at 128 depths per ray, raw records "
-                                       "out), two launches per 512x512 view (coarse depths, importance depths)",
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": PMC_TRAFFIC["k_march_eval_512x512"],
-            "traffic_source": PMC_TRAFFIC["source"], "launch_ms": round(t_b, 3),
+    roof = {"bound": "mfma", "kernel": "k_march_b3w (evaluate pass: tri-plane gather + full MLP at 128 depths per ray, every fp32 product as six bf16 partial products "
+                                       "of exact three-way splits, fp32 accumulation, raw records out), two launches per 512x512 view (coarse depths, importance depths)",
+            "products": "bf16x3 (exact three-way bf16 split of both operands, six partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; dropped terms "
+                        "below one fp32 rounding) - an fp32-tolerance mode: same test bounds as the fp32-MFMA kernel",
+            "achieved": round(issued / (t_b * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(issued / (t_b * 1e-3) / 1e12 / 2500.0, 4),
+            "peak_note": "dense bf16 MFMA peak (MI355X_MICROARCH.md); `achieved` = bf16 FLOPs issued.  In the path's own unit: "
+                         f"{eval_flop / (t_b * 1e-3) / 1e12:.1f} TFLOP/s of algorithmic fp32 work = {eval_flop / (t_b * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS:.2f} x the fp32 matrix peak",
+            "fp32_equivalent_tflops": round(eval_flop / (t_b * 1e-3) / 1e12, 2), "traffic": None, "launch_ms": round(t_b, 3),
             "view": {"ms": round(view_ms, 3), "eval_coarse_ms": round(t_a, 3), "importance_ms": round(t_i, 3),
                      "eval_importance_ms": round(t_b, 3), "composite_ms": round(t_c, 3),
                      "algorithmic_tflops": round(R * FINE_FLOP_PER_RAY_TOTAL / (view_ms * 1e-3) / 1e12, 2),
                      "note": "algorithmic = the reference's schedule, 128 x 79 616 + 256 x 132 608 FLOP per ray (SURVEY 8(d)); this "
-                             "schedule evaluates every point once (256 x 132 608) with bit-identical images"}}
+                             "schedule evaluates every point once (256 x 132 608)"}}
+    # the native-fp32 figure beside it: Renderer.mlp_products = "fp32" (k_march<true,true,8> on v_mfma_f32_32x32x2_f32)
+    f_a, f_i, f_b, f_c = stages(0)
+    r.mlp_products = "fp32"
+    try:
+        one(views)
+        torch.cuda.synchronize()
+        tf_ = time.perf_counter()
+        imgs32 = [one(v)["rgb_map"] for v in range(views)]
+        torch.cuda.synchronize()
+        d32 = time.perf_counter() - tf_
+    finally:
+        r.mlp_products = "bf16x3"
+    diff = max(float((imgs32[v][0] - mine[v][0]).abs().max()) for v in range(min(views, 3)))
+    roof["fp32_products"] = {"what": "the same views with Renderer.mlp_products = 'fp32' (k_march<true,true,8>, v_mfma_f32_32x32x2_f32): the native-fp32 figure",
+                             "value": round(views * R / d32 / 1e6, 4), "unit": "Mrays/s", "ms_per_view": round(d32 * 1e3 / views, 3),
+                             "launch_ms": round(f_b, 3), "achieved_tflops": round(eval_flop / (f_b * 1e-3) / 1e12, 2),
+                             "frac_of_fp32_matrix_peak": round(eval_flop / (f_b * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                             "traffic": PMC_TRAFFIC["k_march_eval_512x512"], "traffic_source": PMC_TRAFFIC["source"],
+                             "rgb_max_abs_between_the_two_modes": diff}
     # ---- extract_geometry's density field at the reference's resolution (renderer.py:290-321): 512^3 lattice points
     #      through the tri-plane lookup + density MLP (79 616 FLOP per point), the input of marching cubes ----
     if world == 1:
@@ -731,7 +764,7 @@ def bench_render(args, rank, world, dev):
                                         "(coarse density pass), including the host-side launch loop and the untile copies"}
         del grid
         # ---- opt-in: the MLP with fp16 operands / fp32 accumulation (Renderer.mlp_fp16, k_march16); not `value` ----
-        ref_imgs = [mine[v].clone() for v in range(min(views, 3))]
+        ref_imgs = [imgs32[v].clone() for v in range(min(views, 3))]
         r.mlp_fp16 = True
         try:
             one(views)
@@ -1021,7 +1054,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="subjects per GPU in the denoise loop (configs[1]: 4)")
-    ap.add_argument("--views", type=int, default=2, help="512x512 views per GPU in the render leg")
+    ap.add_argument("--views", type=int, default=36, help="512x512 views per GPU in the render leg (configs[2]: the whole 36-view orbit)")
     ap.add_argument("--sustained-steps", type=int, default=200,
                     help="extra untimed-for-`value` steps of the same loop after the timed region: sustained steps/s + shader clock (N=1 only; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1032,6 +1065,8 @@ def main():
     ap.add_argument("--e2e-views", type=int, default=185)
     ap.add_argument("--e2e-ddim", type=int, default=50)
     ap.add_argument("--e2e-layers", type=int, default=4)
+    ap.add_argument("--e2e-subjects", type=int, default=8, help="subjects per GPU in the e2e slice (configs[3]/[4]: 64 subjects over 8 GPUs)")
+    ap.add_argument("--e2e-batch", type=int, default=8, help="subjects sampled at a time in the e2e slice")
     ap.add_argument("--no-train", action="store_true", help="skip the UNet training-step leg (SURVEY 8(f) rank 4)")
     ap.add_argument("--no-fit", action="store_true", help="skip the tri-plane fitting leg (SURVEY 8(f) rank 4)")
     ap.add_argument("--no-bf16x3-leg", action="store_true", help="skip the extra measurement of the opt-in bf16x3 conv mode")
@@ -1066,7 +1101,7 @@ def main():
     e2e = None
     if not args.no_e2e:
         e2e = e2e_slice(model, dev, rank, world, n_layers=args.e2e_layers, ddim=args.e2e_ddim, n_views=args.e2e_views,
-                        oracle=(world == 1 and not args.no_parity))
+                        oracle=(world == 1 and not args.no_parity), subjects_per_gpu=args.e2e_subjects, batch=min(args.e2e_batch, args.e2e_subjects))
     train = None
     if not args.no_train:
         from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
@@ -1077,6 +1112,8 @@ def main():
     if not args.no_render:
         rsecs, rroof, rays_per_rank = bench_render(args, rank, world, dev)
         render = {"metric": "Mrays/sec@256spp", "value": round(world * rays_per_rank / rsecs / 1e6, 4), "unit": "Mrays/s",
+                  "dtype": "f32 results; MLP products = bf16x3 (exact three-way bf16 splits, six partial products, fp32 accumulation - fp32 tolerance, same test "
+                           "bounds as the fp32-MFMA kernel whose figure is roofline.fp32_products)",
                   "views_per_gpu": args.views, "ms_per_view": round(rsecs * 1e3 / args.views, 3), "roofline": rroof,
                   "config": {"workload": "configs[2]: tri-plane NeRF render 512x512, n_samples=128 + n_importance=128, "
                                          "views of a 36-view orbit, random 256x256x27 tri-plane", "rays_per_view": 512 * 512}}

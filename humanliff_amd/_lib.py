@@ -69,6 +69,7 @@ SIGNATURES = {
     "hl_render_rays_canonical": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _u, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "hl_camera_rays": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
     "hl_render_eval": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _p, _p]),
+    "hl_render_eval_products": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _u, _p, _p]),
     "hl_render_importance_new": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _p, _p]),
     "hl_render_composite": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _u, _p, _p, _p, _p]),
     "hl_render_composite_noise": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _u, _p, _p, _p, _p]),

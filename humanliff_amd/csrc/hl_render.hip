@@ -3227,6 +3227,13 @@ int hl_render_eval(const void *mlp_packed, const void *planes_packed, int H, int
                             stream);
 }
 
+int hl_render_eval_products(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
+                            const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
+                            int n_samples, unsigned flags, float *records_out, void *stream) {
+    return render_eval_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z, z_tiled, n_rays, n_samples, records_out,
+                            (flags & HL_RENDER_MLP_FP16) ? 1 : ((flags & HL_RENDER_MLP_BF16X3) ? 2 : 0), stream);
+}
+
 int hl_render_importance_new(const float *records, const float *rays_d, const float *near, const float *far, const float *z_vals,
                              const float *u, int64_t n_rays, int n_samples, int n_importance, float *z_new_out, void *stream) {
     HL_REQUIRE(records && rays_d && near && far && u && z_new_out, "hl_render_importance_new: null argument");

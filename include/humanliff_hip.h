@@ -120,6 +120,10 @@ int hl_render_importance(const float *sigma, const float *rays_d, const float *n
 int hl_render_eval(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
                    const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
                    int n_samples, float *records_out, void *stream);
+/* hl_render_eval with the product mode of hl_render_rays: flags = 0 (fp32 MFMA), HL_RENDER_MLP_BF16X3 or HL_RENDER_MLP_FP16 */
+int hl_render_eval_products(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
+                            const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
+                            int n_samples, unsigned flags, float *records_out, void *stream);
 int hl_render_importance_new(const float *records, const float *rays_d, const float *near, const float *far, const float *z_vals,
                              const float *u, int64_t n_rays, int n_samples, int n_importance, float *z_new_out, void *stream);
 int hl_render_composite(const float *near, const float *far, const float *z_vals /* coarse rows or NULL */, const float *z_new,
