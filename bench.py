@@ -330,7 +330,7 @@ def _psnr(a, b):
     return 200.0 if mse == 0 else -10.0 * math.log10(mse)
 
 
-def e2e_chain(model, dev, golden=None):
+def e2e_chain(model, dev, golden=None, mlp_fp16=False, mlp_products=None):
     """BASELINE configs[0] / [3] / [4] at one-GPU scale, against the REFERENCE's own outputs (tests/golden/chain_f4_ddim10.npz, made by
     tests/golden/gen_golden_chain.py from /root/reference): the flow of scripts/triplane_sample_layered.py:112-177 on the production
     network - per cloth layer y = layer, x_cond = the previous layer's sample, ddim_sample_loop (DDIM-10, B = 1) on injected noise,
@@ -345,6 +345,9 @@ def e2e_chain(model, dev, golden=None):
     rend = Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, smpl_type="smpl", test=True)
     rend.load_state_dict(syn.render_mlp_state(3), strict=False)
     rend = rend.to(dev)
+    rend.mlp_fp16 = mlp_fp16                      # opt-in mode of the renderer (tests pin it to the reference's images through this flow)
+    if mlp_products is not None:
+        rend.mlp_products = mlp_products
     IMG, NS, stride = int(g["img"]), int(g["n_samples"]), int(g["stride"])
     rays_o, rays_d, near, far = syn.orbit_rays(int(g["view"]), int(g["n_views"]), IMG, IMG)
     assert np.allclose([float(rays_d.double().sum()), float(rays_d.double().abs().sum())], g["rays_ck"], rtol=0, atol=1e-6)
@@ -390,15 +393,18 @@ def e2e_chain(model, dev, golden=None):
             "workload": "F4 net, DDIM-10, B=1, 2 cloth layers chained through x_cond -> reshape(1,3,9,256,256) -> one 128x128 view @32+32"}
 
 
-def ddim50_parity(model, dev, golden=None):
+def ddim50_parity(model, dev, golden=None, kind="ddim50"):
     """The sampler at the length the shipped scripts use, against the REFERENCE's own outputs (tests/golden/f4_ddim50.npz, made by
     tests/golden/gen_golden_ddim50.py from /root/reference): production network, `timestep_respacing="ddim50"`, B = 1, cloth layer 1
     conditioned on a seeded x_cond, all 50 steps of ddim_sample_loop_progressive on injected noise; compared after steps 1, 10, 25, 40
     and 50 (every 8th pixel + whole-tensor checksums).  Used by tests/test_fullsize_gpu.py and the `parity` object of the bench line."""
     import numpy as np
     from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
-    g = np.load(golden or os.path.join(ROOT, "tests", "golden", "f4_ddim50.npz"))
-    diffusion = create_gaussian_diffusion(steps=1000, learn_sigma=False, noise_schedule="linear", timestep_respacing="ddim50")
+    # kind "p250": the SHIPPED configuration (triplane_scripts/SynBody_triplane_sample_layered_*.sh:24-26: --timestep_respacing 250, p_sample_loop,
+    # batch 1) against tests/golden/f4_p250.npz (gen_golden_p250.py); states after steps 1, 50, 125, 200, 250
+    g = np.load(golden or os.path.join(ROOT, "tests", "golden", "f4_ddim50.npz" if kind == "ddim50" else "f4_p250.npz"))
+    diffusion = create_gaussian_diffusion(steps=1000, learn_sigma=False, noise_schedule="linear", timestep_respacing="ddim50" if kind == "ddim50" else "250")
+    loop = diffusion.ddim_sample_loop_progressive if kind == "ddim50" else diffusion.p_sample_loop_progressive
     stride, keep, layer = int(g["stride"]), [int(k) for k in g["keep"]], int(g["layer"])
     n = {"i": 0}
 
@@ -416,8 +422,7 @@ def ddim50_parity(model, dev, golden=None):
     torch.randn_like = lambda ref: draw(ref.shape).to(ref.device)
     try:
         x_T = draw(shape).to(dev)
-        for k, out in enumerate(diffusion.ddim_sample_loop_progressive(model, shape, x_cond=x_cond.to(dev), noise=x_T, clip_denoised=True,
-                                                                       model_kwargs={"y": y}, device=dev), 1):
+        for k, out in enumerate(loop(model, shape, x_cond=x_cond.to(dev), noise=x_T, clip_denoised=True, model_kwargs={"y": y}, device=dev), 1):
             if k in keep:
                 s_ = out["sample"].cpu()
                 want = torch.from_numpy(g[f"step{k}_sub"])
@@ -431,8 +436,10 @@ def ddim50_parity(model, dev, golden=None):
     chmean = float(np.abs(s_.double().mean(dim=(0, 2, 3)).numpy() - g["final_chmean"]).max())
     return {"steps": steps, "final_row100_max_abs": final_row, "final_channel_mean_max_abs": chmean, "ndraws": n["i"], "ndraws_reference": int(g["ndraws"]),
             "max_abs": max(s["max_abs"] for s in steps), "psnr_db": min(s["psnr_db"] for s in steps),
-            "against": "the reference's outputs on identical noise (tests/golden/f4_ddim50.npz <- tests/golden/gen_golden_ddim50.py)",
-            "workload": "F4 net, DDIM-50 (ddim_sample_loop_progressive), B=1, cloth layer 1 with a seeded x_cond"}
+            "against": "the reference's outputs on identical noise (tests/golden/f4_ddim50.npz <- tests/golden/gen_golden_ddim50.py)" if kind == "ddim50" else
+                       "the reference's outputs on identical noise (tests/golden/f4_p250.npz <- tests/golden/gen_golden_p250.py)",
+            "workload": "F4 net, DDIM-50 (ddim_sample_loop_progressive), B=1, cloth layer 1 with a seeded x_cond" if kind == "ddim50" else
+                        "F4 net, the shipped sampler: timestep_respacing=250, p_sample_loop_progressive, B=1, cloth layer 1 with a seeded x_cond"}
 
 
 def e2e_slice(model, dev, rank, world, n_layers=4, ddim=50, n_views=185, res=512, n_check_views=3, n_check_rays=1024, oracle=True, subjects_per_gpu=8, batch=8):

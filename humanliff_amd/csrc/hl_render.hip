@@ -1372,7 +1372,15 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
         _Pragma("unroll") for (int q_ = 0; q_ < NST; ++q_) st[q_] = ldw(((((g) >> 1) + 2) % B3W_NPAIR) * B3R_SLOT_U4 + q_ * NT); \
     }
 #define B3_AT(g) (ring + cur + ((g) & 1) * B3_CH_U4)
+    // The two waves of a SIMD (w and w + 4) run the same chunks between the same barriers; left alone they prepare operands (VALU) at the same
+    // time and multiply (MFMA) at the same time and the two pipes take turns.  B3_VM orders every chunk as [prepare the next operand, multiply]
+    // in waves 0-3 and as [multiply, prepare] in waves 4-7 (ROT): one wave's VALU phase meets the other's MFMA phase.
+#define B3_VM(V_, M_)                                                                      \
+    if constexpr (ROT) { M_; __builtin_amdgcn_sched_barrier(0); V_; __builtin_amdgcn_sched_barrier(0); } \
+    else { V_; __builtin_amdgcn_sched_barrier(0); M_; __builtin_amdgcn_sched_barrier(0); }
 
+    auto body = [&](auto rotc) {
+    constexpr bool ROT = decltype(rotc)::value;
     for (int s = 0; s < S; ++s) {
         float zn = 0.f;
         if (s + 1 < S) {
@@ -1437,26 +1445,22 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L1: chunks 2..9 = (tile k of X, half 0 | 1)
             B3_ADV(2 + 2 * k)
-            split_b3t(X[k], 1, bb);
-            mma_b3<4>(Y, ba, B3_AT(2 + 2 * k), 0, lane);
+            B3_VM(split_b3t(X[k], 1, bb), mma_b3<4>(Y, ba, B3_AT(2 + 2 * k), 0, lane))
             B3_ADV(3 + 2 * k)
-            if (k < 3) { X[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); }
-            mma_b3<4>(Y, bb, B3_AT(3 + 2 * k), 0, lane);
+            B3_VM(if (k < 3) { X[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); },
+                  mma_b3<4>(Y, bb, B3_AT(3 + 2 * k), 0, lane))
         }
         load_bias<4>(X, small + SM_B2, half);
         B3_ADV(10) mma_b3<4>(X, bf0, B3_AT(10), 0, lane);                          // L2 (features): chunks 10, 11; the first hidden operand rides along
         B3_ADV(11)
-        Y[0] = softplus16_b3(Y[0]);
-        split_b3t(Y[0], 0, ba);
-        mma_b3<4>(X, bf1, B3_AT(11), 0, lane);
+        B3_VM({ Y[0] = softplus16_b3(Y[0]); split_b3t(Y[0], 0, ba); }, mma_b3<4>(X, bf1, B3_AT(11), 0, lane))
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L2 (hidden): chunks 12..19
             B3_ADV(12 + 2 * k)
-            split_b3t(Y[k], 1, bb);
-            mma_b3<4>(X, ba, B3_AT(12 + 2 * k), 0, lane);
+            B3_VM(split_b3t(Y[k], 1, bb), mma_b3<4>(X, ba, B3_AT(12 + 2 * k), 0, lane))
             B3_ADV(13 + 2 * k)
-            if (k < 3) { Y[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(Y[k + 1 < 4 ? k + 1 : 3]); split_b3t(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); }
-            mma_b3<4>(X, bb, B3_AT(13 + 2 * k), 0, lane);
+            B3_VM(if (k < 3) { Y[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(Y[k + 1 < 4 ? k + 1 : 3]); split_b3t(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); },
+                  mma_b3<4>(X, bb, B3_AT(13 + 2 * k), 0, lane))
         }
         load_bias<4>(Y, small + SM_BF, half);
         X[0] = softplus16_b3(X[0]);
@@ -1464,11 +1468,10 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // feature_linear: chunks 20..27
             B3_ADV(20 + 2 * k)
-            split_b3t(X[k], 1, bb);
-            mma_b3<4>(Y, ba, B3_AT(20 + 2 * k), 0, lane);
+            B3_VM(split_b3t(X[k], 1, bb), mma_b3<4>(Y, ba, B3_AT(20 + 2 * k), 0, lane))
             B3_ADV(21 + 2 * k)
-            if (k < 3) { X[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); }
-            mma_b3<4>(Y, bb, B3_AT(21 + 2 * k), 0, lane);
+            B3_VM(if (k < 3) { X[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); },
+                  mma_b3<4>(Y, bb, B3_AT(21 + 2 * k), 0, lane))
         }
         const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];   // X holds softplus(pts_linears.2) by now
         f32x16 V[2];
@@ -1483,10 +1486,8 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // views_linear (feature part): chunks 28..31, two k-groups each
             B3_ADV(28 + k)
-            split_b3t(Y[k], 1, bb);
-            mma_b3<2>(V, ba, B3_AT(28 + k), 0, lane);
-            if (k < 3) split_b3t(Y[k + 1 < 4 ? k + 1 : 3], 0, ba);
-            mma_b3<2>(V, bb, B3_AT(28 + k), 2, lane);
+            B3_VM(split_b3t(Y[k], 1, bb), mma_b3<2>(V, ba, B3_AT(28 + k), 0, lane))
+            B3_VM(if (k < 3) split_b3t(Y[k + 1 < 4 ? k + 1 : 3], 0, ba), mma_b3<2>(V, bb, B3_AT(28 + k), 2, lane))
         }
         V[0] = softplus16_b3(V[0]);
         V[1] = softplus16_b3(V[1]);
@@ -1501,6 +1502,10 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
         }
         zc = zn;
     }
+    };
+    if ((tid >> 6) < 4) body(std::false_type{});
+    else body(std::true_type{});
+#undef B3_VM
 #undef B3_ADV
 #undef B3_AT
 }
