@@ -2747,8 +2747,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     //     768 smaller workgroups of the F(2x2) kernel take 188 us),
     //   * below that with the input channels split into slabs until W x slabs reaches one round (k_splitk_finish sums them).
     // In between (1.5 rounds: 128x128 at batch 4, 384 workgroups, 151 us against 131 us) the two-workgroups-per-CU kernels keep the layer.
-    const char *w4w_env = getenv("HL_WINO4W");   // developer switch while the kernel is being tuned: 0 = off, 2 = wherever it can run
-    const int w4w_mode = w4w_env ? atoi(w4w_env) : 1;
+    static const int w4w_mode = [] { const char *e_ = getenv("HL_WINO4W"); return e_ ? atoi(e_) : 1; }();   // developer switch, read once: 0 = off, 2 = wherever it can run
     const long w4w_blocks = wino4_blocks / 2;
     bool wino4w = false;
     int w4w_splits = 1;

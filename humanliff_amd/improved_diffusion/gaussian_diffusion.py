@@ -294,7 +294,11 @@ class GaussianDiffusion:
         # of GPU time per step behind ~13 ms of enqueueing.  The yielded tensors are then the graph's output buffers: the next
         # step overwrites them (the reference's callers read them at once or keep the last only).  Learned variances (host tables per
         # step) and patched noise sources are not captured - those loops stay eager.
-        graphed = bool(getattr(self, "use_hip_graph", False)) and img.is_cuda and \
+        # A `denoised_fn` (user code: host syncs, data-dependent branches) is never captured; a capture that fails for any other reason
+        # falls back to the eager loop with a warning; the yielded dictionaries hold CLONES of the graph's output buffers, so a progressive
+        # consumer that keeps intermediates is not overwritten by the next replay.  `model_kwargs` tensors are captured by address: replace
+        # their contents in place between steps, not the tensors.
+        graphed = bool(getattr(self, "use_hip_graph", False)) and img.is_cuda and denoised_fn is None and \
             self.model_var_type in (ModelVarType.FIXED_LARGE, ModelVarType.FIXED_SMALL) and T > 2
         graph = x_buf = t_buf = gout = None
         for n_done, i in enumerate(order):
@@ -307,14 +311,25 @@ class GaussianDiffusion:
                         x_buf, t_buf = img.clone(), t_all[i].clone()
                         th.cuda.synchronize(img.device)
                         graph = th.cuda.CUDAGraph()
-                        with th.cuda.graph(graph):
-                            gout = GaussianDiffusion._sample(self, mode, model, x_buf, t_buf, x_cond, clip_denoised, denoised_fn, model_kwargs,
-                                                             eta=eta, trusted=True)
+                        try:
+                            with th.cuda.graph(graph):
+                                gout = GaussianDiffusion._sample(self, mode, model, x_buf, t_buf, x_cond, clip_denoised, denoised_fn, model_kwargs,
+                                                                 eta=eta, trusted=True)
+                        except Exception as exc:   # noqa: BLE001 - whatever the model / kwargs did that a capture does not allow
+                            import warnings
+                            warnings.warn(f"use_hip_graph: capturing a sampling step failed ({type(exc).__name__}: {exc}); continuing eagerly")
+                            th.cuda.synchronize(img.device)
+                            graphed, graph = False, None
+                            out = GaussianDiffusion._sample(self, mode, model, img, t_all[i], x_cond, clip_denoised, denoised_fn, model_kwargs,
+                                                            eta=eta, trusted=True)
+                            yield out
+                            img = out["sample"]
+                            continue
                     else:
                         x_buf.copy_(img)
                         t_buf.copy_(t_all[i])
                     graph.replay()
-                    out = gout
+                    out = {k: v.clone() for k, v in gout.items()}
                 yield out
                 img = out["sample"]
 

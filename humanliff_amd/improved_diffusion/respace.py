@@ -68,45 +68,37 @@ class SpacedDiffusion(GaussianDiffusion):
         return self._wrap_model(model)
 
     def _wrap_model(self, model):
-        """One wrapper per model object (the reference builds a new one - and a new device tensor of the timestep map - on every call,
-        respace.py:97-122).  The cache holds the model WEAKLY: a model carries its parameters plus the packed HIP copy and workspaces
-        (several GB on the device), and deleting it must free them while the diffusion object lives on.  Callables that cannot be weakly
-        referenced (a bare function object can, a bound C callable cannot) get a throwaway wrapper like in the reference."""
+        """A wrapper per call, like the reference (respace.py:97-122) - but the device tensor of the timestep map it would rebuild every
+        time is shared: the cache maps a model object to the per-(device, dtype) map tensors.  The cache holds the model WEAKLY (a model
+        carries its parameters plus the packed HIP copy and workspaces - several GB on the device - and deleting it must free them while
+        the diffusion object lives on); the wrapper handed to the caller holds it STRONGLY, so a temporary callable (a lambda, a
+        functools.partial, a bound method) passed to a sampling loop lives as long as the loop does.  Callables that cannot be weakly
+        referenced get a wrapper with private map tensors."""
         if isinstance(model, _WrappedModel):
             return model
         hit = self._wrapped.get(id(model))
         if hit is not None and hit[0]() is model:
-            return hit[1]
-        wrapper = _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps, weak=True)
-        if wrapper._ref is None:
-            return wrapper
-        key = id(model)
-        self._wrapped[key] = (weakref.ref(model, lambda _, k=key, d=self._wrapped: d.pop(k, None)), wrapper)
-        return wrapper
+            return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps, maps=hit[1])
+        try:
+            key = id(model)
+            ref = weakref.ref(model, lambda _, k=key, d=self._wrapped: d.pop(k, None))
+        except TypeError:
+            return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+        maps = {}
+        self._wrapped[key] = (ref, maps)
+        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps, maps=maps)
 
     def _scale_timesteps(self, t):
         return t  # scaling is done by the wrapped model
 
 
 class _WrappedModel:
-    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps, weak=False):
-        # weak=True (the cached wrappers of SpacedDiffusion): the wrapper must not keep the model alive
-        self._ref = self._strong = None
-        if weak:
-            try:
-                self._ref = weakref.ref(model)
-            except TypeError:
-                self._strong = model
-        else:
-            self._strong = model
+    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps, maps=None):
+        self.model = model                       # strong: the wrapper keeps its model alive (the cache of SpacedDiffusion does not)
         self.timestep_map = timestep_map
         self.rescale_timesteps = rescale_timesteps
         self.original_num_steps = original_num_steps
-        self._maps = {}
-
-    @property
-    def model(self):
-        return self._strong if self._ref is None else self._ref()
+        self._maps = {} if maps is None else maps   # (device, dtype) -> device tensor of the timestep map, shared between wrappers of one model
 
     def parameters(self):
         return self.model.parameters()

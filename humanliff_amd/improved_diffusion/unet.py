@@ -371,9 +371,14 @@ class UNetModel(nn.Module):
             # the same network as a chain of autograd.Functions whose forward and backward are HIP kernels (unet_train.py).
             # Sampling never gets here: the loops run under no_grad and the scripts call model.eval()
             if self.use_3d_aware or self.cond_type == "cross_attention":
+                # (documented limit: these two configurations have no differentiable HIP path - also not for a gradient with respect to x
+                #  alone; under no_grad / with x.requires_grad False they sample on the fused inference kernels)
                 raise NotImplementedError("the HIP training path does not cover use_3d_aware=True / cond_type='cross_attention' (sampling does)")
             from .unet_train import forward_train
-            self._hip_stale = True     # an optimizer step follows; fused optimizers do not bump Tensor._version (see _bind)
+            if self.training and self._any_param_requires_grad():
+                # an optimizer step follows; fused optimizers do not bump Tensor._version (see _bind).  A guidance call (eval mode, gradient
+                # with respect to x only) leaves the parameters alone: the packed copies stay valid and the next sampling call does not re-pack
+                self._hip_stale = True
             return forward_train(self, x, timesteps, x_cond, y)
         handle = self._bind()
         L = _lib.lib()

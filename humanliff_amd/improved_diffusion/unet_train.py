@@ -26,6 +26,7 @@ both against the reference's vectors.
 import ctypes as C
 import math
 
+import threading
 import weakref
 
 import torch as th
@@ -35,7 +36,10 @@ from .. import _lib
 from . import unet as U
 
 _MODE = _lib.HL_CONV_FP32
-_ARITH = {"mode": None, "autocast": None}   # set_train_arithmetic's choice; the dtype of the caller's autocast region (forward_train)
+_ARITH = {"mode": None}                     # set_train_arithmetic's choice (process-wide, set by the user)
+_TLS = threading.local()                    # .autocast: the dtype of the CALLING THREAD's autocast region (forward_train); DataParallel runs its
+                                            # replicas in threads that inherit the autocast state - a module global would leak between them
+_LOGGED = set()
 _KIND_MODE = {"fp32": _lib.HL_CONV_FP32, "bf16": _lib.HL_CONV_BF16, "fp16": _lib.HL_CONV_FP16}
 
 
@@ -57,7 +61,7 @@ def set_train_arithmetic(kind=None):
 def _conv_mode():
     kind = _ARITH["mode"]
     if kind is None:
-        kind = _ARITH["autocast"] or "fp32"
+        kind = getattr(_TLS, "autocast", None) or "fp32"
     return _MODE if kind == "fp32" else _KIND_MODE[kind]
 
 
@@ -280,13 +284,18 @@ def forward_train(model, x, timesteps, x_cond=None, y=None):
         # autocasting of the few tensor ops of this function is switched off; the convolutions take the autocast dtype as their operand
         # precision (k_conv_h16: 16-bit operands, fp32 accumulation) unless set_train_arithmetic pinned another arithmetic.
         dt = th.get_autocast_dtype("cuda") if hasattr(th, "get_autocast_dtype") else th.get_autocast_gpu_dtype()
-        prev = _ARITH["autocast"]
-        _ARITH["autocast"] = "bf16" if dt == th.bfloat16 else "fp16"
+        prev = getattr(_TLS, "autocast", None)
+        _TLS.autocast = "bf16" if dt == th.bfloat16 else "fp16"
+        if _ARITH["mode"] is None and _TLS.autocast not in _LOGGED:   # said once: autocast changes the arithmetic of the convolutions
+            _LOGGED.add(_TLS.autocast)
+            import warnings
+            warnings.warn(f"humanliff_amd: training under torch.autocast - convolutions and 3x3 weight gradients take {_TLS.autocast} operands "
+                          "(fp32 accumulation); set_train_arithmetic('fp32') pins fp32", stacklevel=3)
         try:
             with th.autocast(device_type="cuda", enabled=False):
                 return forward_train(model, x.float(), timesteps, None if x_cond is None else x_cond.float(), y)
         finally:
-            _ARITH["autocast"] = prev
+            _TLS.autocast = prev
     emb = model.time_embed[2](_silu(model.time_embed[0](_embedding(timesteps, model.model_channels))))
     if model.cond_type == "AdaGN":           # unet.py:574-578 (like the embedding MLP: three tiny torch modules, autograd's own backward)
         assert x_cond is not None, "cond_type='AdaGN' needs x_cond"
@@ -315,7 +324,7 @@ def forward_train(model, x, timesteps, x_cond=None, y=None):
         h = _run(blk, th.cat([h, skip], dim=-1), emb)
     out = conv(gn_act(h, model.out[0]), model.out[2])                       # (N, H, W, C_out)
     out = out.permute(0, 3, 1, 2).contiguous().to(x.dtype)
-    if out.requires_grad:
+    if out.requires_grad and model.training and model._any_param_requires_grad():
         # backward is what precedes an optimizer step: from here on the packed inference weights count as stale, also when a sampling
         # call between this forward and the step has re-packed them meanwhile (fused optimizers do not bump Tensor._version)
         out.register_hook(lambda g, m=weakref.ref(model): (setattr(m(), "_hip_stale", True) if m() is not None else None, g)[1])

@@ -155,6 +155,10 @@ def test_conv_winograd_matches_torch(N, C, H, W, Cout, with_gn):
     (9, 48, 64, 64, 384, False, 0),     # 12 channel blocks, odd k-tile count (6) and batch
     (2, 16, 128, 256, 192, False, 0),   # two k-tiles
     (4, 96, 64, 48, 192, False, 1),     # nearest x2 upsample in front (the patch DMA reads source pixel (y>>1, x>>1))
+    # the three dispatch regimes of k_conv_wino4w (64-channel workgroups, one per CU; W = N x H/16 x W/32 x Cout/64 workgroups):
+    (4, 32, 256, 256, 192, False, 0),   # W = 1536 >= 768: three rounds and more (the 256-pixel level at batch >= 2)
+    (4, 64, 64, 64, 384, True, 0),      # W = 192 in [160, 256]: one nearly full round (the 64-pixel level at batch 4), GroupNorm prologue + residual
+    (1, 384, 64, 64, 384, False, 0),    # W = 48 < 160: input channels split into slabs, summed by k_splitk_finish (the 64-pixel level at batch 1)
 ])
 def test_conv_winograd_f43_matches_torch(N, C, H, W, Cout, with_gn, ups):
     """HL_CONV_FP32 takes Winograd F(4x4,3x3) with the points (0, +-3/4, +-3/2, inf) where it fills the chip - a quarter of the direct
