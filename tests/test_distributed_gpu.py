@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _flow(dev, images_root=None):
+def _flow(dev, images_root=None, n_subjects=N_SUBJECTS, batch=1):
     """The same closures for the 1-process and the 2-process run: tiny controlnet UNet (class-conditional, attention, 27x32x32 tri-planes)
     on the HIP kernels, DDIM-4 per cloth layer chained through x_cond, HIP renders of the finished tri-plane."""
     from humanliff_amd import distributed as hd, synthetic as syn
@@ -58,12 +58,12 @@ def _flow(dev, images_root=None):
         return render_view(RES, RES, K, R, (-R @ cam).reshape(3, 1), planes, tp, rend, n_samples=32, n_importance=32, u=u)[0]
 
     with torch.no_grad():
-        smp, img = hd.sample_and_render(sample_fn, render_fn, N_SUBJECTS, N_LAYERS, shape, 1, N_VIEWS, (RES, RES, 3), dev, as_uint8=True,
+        smp, img = hd.sample_and_render(sample_fn, render_fn, n_subjects, N_LAYERS, shape, batch, N_VIEWS, (RES, RES, 3), dev, as_uint8=True,
                                         images_root=images_root)
     return smp, img, calls
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, n_subjects=N_SUBJECTS, batch=1):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
@@ -71,9 +71,9 @@ def _worker(rank, world, port, out_path):
     _lib.lib()                                   # the HIP library, or nothing
     r, w, dev = hd.init_distributed("gloo")      # both ranks on cuda:0 (LOCAL_RANK 0)
     assert (r, w) == (rank, world) and dev.type == "cuda"
-    smp, img, calls = _flow(dev, images_root=0)
-    per = (N_SUBJECTS + world - 1) // world
-    assert all(min(i, N_SUBJECTS - 1) // per == rank for _, ids in calls["sample"] for i in ids)
+    smp, img, calls = _flow(dev, images_root=0, n_subjects=n_subjects, batch=batch)
+    per = (n_subjects + world - 1) // world
+    assert all(min(i, n_subjects - 1) // per == rank for _, ids in calls["sample"] for i in ids)
     assert all(s // per == rank for s, _ in calls["render"])
     assert (img is None) == (rank != 0)
     torch.save({"samples": smp.cpu(), "images": None if img is None else img.cpu(), "n_sample_calls": len(calls["sample"]),
@@ -109,3 +109,36 @@ def test_two_ranks_on_the_hip_path_equal_one_process(tmp_path):
     assert res[0]["n_sample_calls"] == 2 * N_LAYERS and res[1]["n_sample_calls"] == 2 * N_LAYERS
     assert res[0]["n_render_calls"] == 2 * N_VIEWS and res[1]["n_render_calls"] == 2 * N_VIEWS
     assert len(calls1["sample"]) == N_SUBJECTS * N_LAYERS
+
+
+@pytest.mark.timeout(1500)
+def test_eight_ranks_sixty_four_subjects_rehearsal(tmp_path):
+    """BASELINE configs[3] / [4] at their real PARTITIONING - 64 subjects over 8 ranks, 8 per rank sampled as one batch of 8, every rank
+    renders its own subjects' views, per-subject asynchronous uint8 gathers, root-only assembly - rehearsed with eight processes on one GPU
+    over gloo (tiny network, 32x32 tri-planes): the block sharding, the call pattern and the gathered order of an 8-GPU run; the values of
+    four subjects spread over the ranks are checked against a single-process run of those subjects."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    world, nsub, batch = 8, 64, 8
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    out = str(tmp_path / "ranks8")
+    ps = [ctx.Process(target=_worker, args=(r, world, port, out, nsub, batch)) for r in range(world)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(1400)
+        assert p.exitcode == 0, p.exitcode
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    for r in range(world):
+        assert tuple(res[r]["samples"].shape) == (nsub, N_LAYERS, 27, 32, 32)
+        assert torch.equal(res[r]["samples"], res[0]["samples"])                   # every rank holds all samples, in the same (rank-major) order
+        assert (res[r]["images"] is None) == (r != 0)
+        assert res[r]["n_sample_calls"] == N_LAYERS and res[r]["n_render_calls"] == 8 * N_VIEWS      # one batch of 8 per layer; 8 subjects' views
+    img = res[0]["images"]
+    assert tuple(img.shape) == (nsub, N_VIEWS, RES, RES, 3) and img.dtype == torch.uint8
+    # subjects 0..7 as ONE process computes them in one batch of 8 = rank 0's block: same kernels, same batch -> equal bits; and the per-subject
+    # noise seeds make every subject's result independent of which rank owned it
+    dev = torch.device("cuda:0")
+    want_smp, want_img, _ = _flow(dev, n_subjects=8, batch=8)
+    assert torch.equal(res[0]["samples"][:8], want_smp.cpu()) and torch.equal(img[:8], want_img.cpu())
+    assert len({float(res[0]["samples"][i].double().sum()) for i in range(nsub)}) == nsub                # 64 different subjects
