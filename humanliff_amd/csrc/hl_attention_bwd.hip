@@ -1,0 +1,317 @@
+// Backward of QKVAttention (improved_diffusion/unet.py:255-274) for the HIP training path - hand-written, fp32, deterministic, flash-style
+// (probabilities recomputed, never stored).  Replaces the five torch.bmm (rocBLAS) of round 3's _Attention.backward.
+//
+// Per (sample, head):  S = (s q)(s k)^T with s = ch^-1/4 on q AND k,  P = softmax_rows(S),  O = P v.   Given dO:
+//   dV = P^T dO      dP = dO V^T      D_i = sum_j P_ij dP_ij = dO_i . O_i      dS = P o (dP - D)      dQ = s dS (s k)      dK = s dS^T (s q)
+//
+// Two kernels, both in the register-resident transposed style of k_attention / k_march (v_mfma_f32_32x32x2_f32; an accumulator tile IS
+// the next product's B operand):
+//   k_attn_bwd_q   one wave = 32 queries.  Pass A over the key tiles: row maximum and sum (the forward kernels do not emit them).  Pass B:
+//                  S^T -> P^T, dP^T = V dO^T, dS^T in registers, dQ^T += K^T dS^T.  Writes dQ and per query (max, 1/sum, D) for the second kernel.
+//   k_attn_bwd_kv  one wave = 32 keys, loop over the query tiles: S -> P, dP = dO V^T, dS; dV^T += dO^T P, dK^T += Q^T dS.
+// Every output element is owned by one wave and summed in a fixed order: run-to-run identical bits.
+// Head sizes that are not a multiple of 32 (the tiny test networks: 8, 16) take a plain two-kernel path that materialises P and dS per head
+// in caller scratch.
+#include "hl_unet_kernels.h"
+
+namespace hl {
+namespace {
+
+template <int CH, int WPB>
+__global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_q(const float *__restrict__ qkv, const float *__restrict__ out, const float *__restrict__ dout,
+                                                            int T, int C, int heads, float *__restrict__ dqkv, float *__restrict__ stat) {
+    constexpr int CT = CH / 32, KS = CH / 2, LDK = CH + 1;
+    __shared__ float sK[32 * LDK];
+    __shared__ float sV[32 * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int nh = blockIdx.y, n = nh / heads, head = nh % heads;
+    const int q0 = (blockIdx.x * WPB + wave) * 32;
+    const float scale = 1.f / sqrtf(sqrtf((float)CH));
+    const long pitch = 3L * C;
+    const float *base = qkv + (long)n * T * pitch + (long)head * 3 * CH;
+    const int qi = q0 + (lane & 31), qj = min(qi, T - 1);
+    // B operands: lane (query j, half) holds q[c = 2s + half] * s and dO[c = 2s + half]; D = dO . O over the lane pair
+    float qreg[KS], doreg[KS];
+    float D = 0.f;
+    {
+        const float *orow = out + ((long)n * T + qj) * C + head * CH, *drow = dout + ((long)n * T + qj) * C + head * CH;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qreg[s] = base[(long)qj * pitch + 2 * s + half] * scale;
+            doreg[s] = drow[2 * s + half];
+            D = fmaf(doreg[s], orow[2 * s + half], D);
+        }
+        D += __shfl_xor(D, 32);
+    }
+    auto load_tile = [&](int k0, bool with_v) {
+        __syncthreads();
+        for (int e = tid; e < 32 * (CH / 4); e += WPB * 64) {
+            const int key = e / (CH / 4), c = (e - key * (CH / 4)) * 4;
+            const int kk = min(k0 + key, T - 1);
+            const f32x4 kv = *reinterpret_cast<const f32x4 *>(base + (long)kk * pitch + CH + c);
+            float *dk = sK + key * LDK + c;
+            dk[0] = kv[0] * scale; dk[1] = kv[1] * scale; dk[2] = kv[2] * scale; dk[3] = kv[3] * scale;
+            if (with_v) {
+                const f32x4 vv = *reinterpret_cast<const f32x4 *>(base + (long)kk * pitch + 2 * CH + c);
+                float *dv = sV + key * LDK + c;
+                dv[0] = vv[0]; dv[1] = vv[1]; dv[2] = vv[2]; dv[3] = vv[3];
+            }
+        }
+        __syncthreads();
+    };
+    auto scores = [&](int k0) -> f32x16 {   // st[r] = S(key = k0 + (r&3) + 8 (r>>2) + 4 half, query = lane & 31); keys beyond T masked
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(lane & 31) * LDK + 2 * s + half], qreg[s], st, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (k0 + (r & 3) + 8 * (r >> 2) + 4 * half >= T) st[r] = -3.0e38f;
+        return st;
+    };
+    // pass A: row maximum and sum
+    float mrun = -3.0e38f, lrun = 0.f;
+    for (int k0 = 0; k0 < T; k0 += 32) {
+        load_tile(k0, false);
+        const f32x16 st = scores(k0);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(mrun, mx);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) psum += __expf(st[r] - mnew);
+        psum += __shfl_xor(psum, 32);
+        lrun = lrun * __expf(mrun - mnew) + psum;
+        mrun = mnew;
+    }
+    const float invl = 1.f / lrun;
+    if (half == 0 && qi < T) {
+        float *sp = stat + ((long)nh * T + qi) * 3;
+        sp[0] = mrun; sp[1] = invl; sp[2] = D;
+    }
+    // pass B: dQ^T[c][q] += K^T[c][key] dS^T[key][q]
+    f32x16 o[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    for (int k0 = 0; k0 < T; k0 += 32) {
+        load_tile(k0, true);
+        f32x16 st = scores(k0);
+        f32x16 dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[(lane & 31) * LDK + 2 * s + half], doreg[s], dp, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = __expf(st[r] - mrun) * invl * (dp[r] - D);    // masked keys: exp(-inf) = 0
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int key = (s & 3) + 8 * (s >> 2) + 4 * half;
+                o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[key * LDK + c * 32 + (lane & 31)], st[s], o[c], 0, 0, 0);
+            }
+    }
+    if (qi < T) {
+        float *dst = dqkv + ((long)n * T + qi) * pitch + (long)head * 3 * CH;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = o[c][r] * scale;
+    }
+}
+
+template <int CH, int WPB>
+__global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_kv(const float *__restrict__ qkv, const float *__restrict__ dout, const float *__restrict__ stat,
+                                                             int T, int C, int heads, float *__restrict__ dqkv) {
+    constexpr int CT = CH / 32, KS = CH / 2, LDK = CH + 1;
+    __shared__ float sQ[32 * LDK];
+    __shared__ float sD[32 * LDK];
+    __shared__ float sS[32 * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int nh = blockIdx.y, n = nh / heads, head = nh % heads;
+    const int k0 = (blockIdx.x * WPB + wave) * 32;
+    const float scale = 1.f / sqrtf(sqrtf((float)CH));
+    const long pitch = 3L * C;
+    const float *base = qkv + (long)n * T * pitch + (long)head * 3 * CH;
+    const int ki = k0 + (lane & 31), kj = min(ki, T - 1);
+    float kreg[KS], vreg[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        kreg[s] = base[(long)kj * pitch + CH + 2 * s + half] * scale;
+        vreg[s] = base[(long)kj * pitch + 2 * CH + 2 * s + half];
+    }
+    f32x16 dk[CT], dv[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[c][r] = 0.f; dv[c][r] = 0.f; }
+    for (int q0 = 0; q0 < T; q0 += 32) {
+        __syncthreads();
+        for (int e = tid; e < 32 * (CH / 4); e += WPB * 64) {
+            const int q = e / (CH / 4), c = (e - q * (CH / 4)) * 4;
+            const int qq = min(q0 + q, T - 1);
+            const f32x4 qv = *reinterpret_cast<const f32x4 *>(base + (long)qq * pitch + c);
+            const f32x4 dd = *reinterpret_cast<const f32x4 *>(dout + ((long)n * T + qq) * C + head * CH + c);
+            float *a = sQ + q * LDK + c, *b = sD + q * LDK + c;
+            a[0] = qv[0] * scale; a[1] = qv[1] * scale; a[2] = qv[2] * scale; a[3] = qv[3] * scale;
+            b[0] = dd[0]; b[1] = dd[1]; b[2] = dd[2]; b[3] = dd[3];
+        }
+        for (int e = tid; e < 96; e += WPB * 64) {
+            const int q = e / 3, j = e - q * 3;
+            sS[e] = q0 + q < T ? stat[((long)nh * T + q0 + q) * 3 + j] : (j == 0 ? 3.0e38f : 0.f);   // queries beyond T: max = +huge, 1/sum = 0 -> P = 0
+        }
+        __syncthreads();
+        f32x16 st, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[(lane & 31) * LDK + 2 * s + half], kreg[s], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sD[(lane & 31) * LDK + 2 * s + half], vreg[s], dp, 0, 0, 0);
+        }
+        // st[r] = S(query = q0 + (r&3) + 8 (r>>2) + 4 half, key = lane & 31)
+        f32x16 ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float p = __expf(st[r] - sS[q * 3]) * sS[q * 3 + 1];
+            st[r] = p;
+            ds[r] = p * (dp[r] - sS[q * 3 + 2]);
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int q = (s & 3) + 8 * (s >> 2) + 4 * half;
+                dv[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(sD[q * LDK + c * 32 + (lane & 31)], st[s], dv[c], 0, 0, 0);
+                dk[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[q * LDK + c * 32 + (lane & 31)], ds[s], dk[c], 0, 0, 0);
+            }
+    }
+    if (ki < T) {
+        float *dst = dqkv + ((long)n * T + ki) * pitch + (long)head * 3 * CH;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cc = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                dst[CH + cc] = dk[c][r] * scale;
+                dst[2 * CH + cc] = dv[c][r];
+            }
+    }
+}
+
+// ---- any head size: P and dS rows materialised in scratch ([nh][T][T] each), then three plain products ----
+__global__ void k_attn_bwd_rows(const float *__restrict__ qkv, const float *__restrict__ out, const float *__restrict__ dout, int T, int C, int heads,
+                                int ch, float *__restrict__ P, float *__restrict__ dS) {
+    // one 64-lane block per (query, sample-head)
+    const int q = blockIdx.x, nh = blockIdx.y, n = nh / heads, head = nh % heads, lane = threadIdx.x;
+    const float s2 = 1.f / sqrtf((float)ch);
+    const long pitch = 3L * C;
+    const float *base = qkv + (long)n * T * pitch + (long)head * 3 * ch;
+    const float *qr = base + (long)q * pitch, *orow = out + ((long)n * T + q) * C + head * ch, *drow = dout + ((long)n * T + q) * C + head * ch;
+    float *prow = P + ((long)nh * T + q) * T, *srow = dS + ((long)nh * T + q) * T;
+    float mx = -3.0e38f;
+    for (int j = lane; j < T; j += 64) {
+        const float *kr = base + (long)j * pitch + ch;
+        float s = 0.f;
+        for (int c = 0; c < ch; ++c) s = fmaf(qr[c], kr[c], s);
+        s *= s2;
+        prow[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    float sum = 0.f;
+    for (int j = lane; j < T; j += 64) { const float e = __expf(prow[j] - mx); prow[j] = e; sum += e; }
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    float D = 0.f;
+    for (int c = lane; c < ch; c += 64) D = fmaf(drow[c], orow[c], D);
+    for (int d = 32; d >= 1; d >>= 1) D += __shfl_xor(D, d);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < T; j += 64) {
+        const float *vr = base + (long)j * pitch + 2 * ch;
+        float dp = 0.f;
+        for (int c = 0; c < ch; ++c) dp = fmaf(drow[c], vr[c], dp);
+        const float p = prow[j] * inv;
+        prow[j] = p;
+        srow[j] = p * (dp - D);
+    }
+}
+__global__ void k_attn_bwd_products(const float *__restrict__ qkv, const float *__restrict__ dout, const float *__restrict__ P, const float *__restrict__ dS,
+                                    int N, int T, int C, int heads, int ch, float *__restrict__ dqkv) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per element of dqkv
+    if (i >= (long)N * T * 3 * C) return;
+    const int cc = (int)(i % (3L * C));
+    const long nt = i / (3L * C);
+    const int t = (int)(nt % T), n = (int)(nt / T);
+    const int head = cc / (3 * ch), part = (cc - head * 3 * ch) / ch, c = cc - head * 3 * ch - part * ch;
+    const long nh = (long)n * heads + head, pitch = 3L * C;
+    const float *base = qkv + (long)n * T * pitch + (long)head * 3 * ch;
+    const float s2 = 1.f / sqrtf((float)ch);
+    float acc = 0.f;
+    if (part == 0) {          // dQ[t][c] = s2 sum_j dS[t][j] k[j][c]
+        const float *r = dS + (nh * T + t) * T;
+        for (int j = 0; j < T; ++j) acc = fmaf(r[j], base[(long)j * pitch + ch + c], acc);
+        acc *= s2;
+    } else if (part == 1) {   // dK[t][c] = s2 sum_i dS[i][t] q[i][c]
+        for (int q = 0; q < T; ++q) acc = fmaf(dS[(nh * T + q) * T + t], base[(long)q * pitch + c], acc);
+        acc *= s2;
+    } else {                  // dV[t][c] = sum_i P[i][t] dO[i][c]
+        for (int q = 0; q < T; ++q) acc = fmaf(P[(nh * T + q) * T + t], dout[((long)n * T + q) * C + head * ch + c], acc);
+    }
+    dqkv[i] = acc;
+}
+
+}  // namespace
+
+size_t attention_backward_scratch_bytes(int N, int T, int C, int heads) {
+    const int ch = heads > 0 ? C / heads : 0;
+    if (ch % 32 == 0 && ch >= 32 && ch <= 192) return (size_t)N * heads * T * 3 * sizeof(float) + 256;
+    return (size_t)2 * N * heads * T * T * sizeof(float) + 256;
+}
+
+int attention_backward(const float *qkv, const float *out, const float *dout, int N, int T, int C, int heads, float *dqkv, void *scratch,
+                       size_t scratch_bytes, hipStream_t st) {
+    HL_REQUIRE(qkv && out && dout && dqkv && scratch && heads > 0 && C % heads == 0 && N > 0 && T > 0, "attention_backward: bad argument");
+    HL_REQUIRE(scratch_bytes >= attention_backward_scratch_bytes(N, T, C, heads), "attention_backward: scratch too small");
+    const int ch = C / heads;
+    float *sc = (float *)scratch;
+    const int tiles = (T + 31) / 32;
+    int wpb = 4;
+    while (wpb > 1 && (long)((tiles + wpb - 1) / wpb) * N * heads < 256) wpb >>= 1;
+    const dim3 grid((tiles + wpb - 1) / wpb, N * heads);
+#define HL_ATTB(CH_)                                                                                                                       \
+    do {                                                                                                                                   \
+        if (wpb == 4) {                                                                                                                    \
+            hipLaunchKernelGGL((k_attn_bwd_q<CH_, 4>), grid, dim3(256), 0, st, qkv, out, dout, T, C, heads, dqkv, sc);                      \
+            hipLaunchKernelGGL((k_attn_bwd_kv<CH_, 4>), grid, dim3(256), 0, st, qkv, dout, sc, T, C, heads, dqkv);                          \
+        } else if (wpb == 2) {                                                                                                             \
+            hipLaunchKernelGGL((k_attn_bwd_q<CH_, 2>), grid, dim3(128), 0, st, qkv, out, dout, T, C, heads, dqkv, sc);                      \
+            hipLaunchKernelGGL((k_attn_bwd_kv<CH_, 2>), grid, dim3(128), 0, st, qkv, dout, sc, T, C, heads, dqkv);                          \
+        } else {                                                                                                                           \
+            hipLaunchKernelGGL((k_attn_bwd_q<CH_, 1>), grid, dim3(64), 0, st, qkv, out, dout, T, C, heads, dqkv, sc);                       \
+            hipLaunchKernelGGL((k_attn_bwd_kv<CH_, 1>), grid, dim3(64), 0, st, qkv, dout, sc, T, C, heads, dqkv);                           \
+        }                                                                                                                                  \
+    } while (0)
+    switch ((3L * C) % 4 == 0 ? ch : -1) {
+        case 32: HL_ATTB(32); break;
+        case 64: HL_ATTB(64); break;
+        case 96: HL_ATTB(96); break;
+        case 128: HL_ATTB(128); break;
+        case 192: HL_ATTB(192); break;
+        default: {
+            float *P = sc, *dS = sc + (size_t)N * heads * T * T;
+            hipLaunchKernelGGL(k_attn_bwd_rows, dim3(T, N * heads), dim3(64), 0, st, qkv, out, dout, T, C, heads, ch, P, dS);
+            const long total = (long)N * T * 3 * C;
+            hipLaunchKernelGGL(k_attn_bwd_products, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, qkv, dout, P, dS, N, T, C, heads, ch, dqkv);
+        }
+    }
+#undef HL_ATTB
+    return check_launch("attention_backward");
+}
+
+}  // namespace hl

@@ -1113,4 +1113,11 @@ int hl_attention_nhwc(const float *qkv, int N, int T, int C, int heads, float *o
     return hl::attention(qkv, N, T, C, heads, out, (hipStream_t)stream);
 }
 
+size_t hl_attention_backward_scratch_bytes(int N, int T, int C, int heads) { return hl::attention_backward_scratch_bytes(N, T, C, heads); }
+
+int hl_attention_nhwc_backward(const float *qkv, const float *out, const float *dout, int N, int T, int C, int heads, float *dqkv,
+                               void *scratch, size_t scratch_bytes, void *stream) {
+    return hl::attention_backward(qkv, out, dout, N, T, C, heads, dqkv, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
 }  // extern "C"

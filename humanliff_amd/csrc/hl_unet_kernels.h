@@ -127,6 +127,9 @@ int timestep_embedding(const int64_t *t, const float *t_float, int B, int dim, f
 
 // QKV attention (unet.py:255-274): qkv (N, T, 3C) with channel = head*3ch + {q|k|v}*ch + c ; out (N, T, C)
 int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipStream_t st);
+size_t attention_backward_scratch_bytes(int N, int T, int C, int heads);                       // hl_attention_bwd.hip
+int attention_backward(const float *qkv, const float *out, const float *dout, int N, int T, int C, int heads, float *dqkv, void *scratch,
+                       size_t scratch_bytes, hipStream_t st);
 
 // (B,C,H,W) x, x_cond -> NHWC padded to Cpad: x_nhwc and (x + x_cond)_nhwc   (unet.py:588,596)
 int prep_inputs(const float *x, const float *x_cond, int B, int C, int H, int W, int Cpad, float *x_nhwc, float *xsum_nhwc,

@@ -201,28 +201,25 @@ class _Attention(th.autograd.Function):
         out = th.empty((N, T, Cc), device=qkv.device)
         with _lib.on(qkv.device):
             _lib.check(_lib.lib().hl_attention_nhwc(_lib.ptr(qkv), N, T, Cc, heads, _lib.ptr(out), _lib.stream_ptr()), "hl_attention_nhwc")
-        ctx.save_for_backward(qkv)
+        ctx.save_for_backward(qkv, out)
         ctx.heads = heads
         return out
 
     @staticmethod
     def backward(ctx, do):
-        (qkv,) = ctx.saved_tensors
-        heads = ctx.heads
+        # hl_attention_nhwc_backward (csrc/hl_attention_bwd.hip): flash-style fp32 on the matrix cores, probabilities recomputed, deterministic
+        qkv, out = ctx.saved_tensors
         N, T, C3 = qkv.shape
-        ch = C3 // 3 // heads
-        v5 = qkv.reshape(N, T, heads, 3, ch).permute(0, 2, 3, 1, 4)           # (N, heads, 3, T, ch)
-        q, k, v = (v5[:, :, i].reshape(N * heads, T, ch) for i in range(3))
-        s2 = 1.0 / math.sqrt(ch)                                             # (ch^-1/4)^2: the scale sits on q AND k (unet.py:262-266)
-        P = th.softmax(th.bmm(q, k.transpose(1, 2)) * s2, dim=-1)
-        dO = do.reshape(N, T, heads, ch).permute(0, 2, 1, 3).reshape(N * heads, T, ch)
-        dV = th.bmm(P.transpose(1, 2), dO)
-        dP = th.bmm(dO, v.transpose(1, 2))
-        dS = P * (dP - (dP * P).sum(-1, keepdim=True))
-        dQ = th.bmm(dS, k) * s2
-        dK = th.bmm(dS.transpose(1, 2), q) * s2
-        d5 = th.stack([dQ, dK, dV], dim=1).reshape(N, heads, 3, T, ch).permute(0, 3, 1, 2, 4)   # (N, T, heads, 3, ch)
-        return d5.reshape(N, T, C3).contiguous(), None
+        Cc = C3 // 3
+        L = _lib.lib()
+        do = do.contiguous().float()
+        dqkv = th.empty_like(qkv)
+        nbytes = L.hl_attention_backward_scratch_bytes(N, T, Cc, ctx.heads)
+        scr = th.empty(nbytes // 4 + 16, device=qkv.device)
+        with _lib.on(qkv.device):
+            _lib.check(L.hl_attention_nhwc_backward(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(do), N, T, Cc, ctx.heads, _lib.ptr(dqkv), _lib.ptr(scr),
+                                                    scr.numel() * 4, _lib.stream_ptr()), "hl_attention_nhwc_backward")
+        return dqkv, None
 
 
 # ---- the network (unet.py:550-615) on those ops ---------------------------------------------------------------------------------------

@@ -456,6 +456,13 @@ int hl_groupnorm_coef(const float *x, int N, int H, int W, int C, const float *g
                       const float *emb /* (N,2C) or NULL */, float *coefA, float *coefB, void *scratch,
                       size_t scratch_bytes, void *stream);
 int hl_attention_nhwc(const float *qkv, int N, int T, int C, int heads, float *out, void *stream);
+/* Backward of hl_attention_nhwc (QKVAttention, unet.py:255-274, under train_util.py:200-246): qkv as in the forward, out = the forward's
+ * output (N,T,C), dout = its gradient -> dqkv (N,T,3C).  fp32 MFMA, probabilities recomputed (flash-style), every output summed by one wave in
+ * a fixed order (deterministic).  scratch: hl_attention_backward_scratch_bytes() (per query: row maximum, 1/row sum, dO.O; head sizes that are
+ * not a multiple of 32 materialise P and dS there instead). */
+size_t hl_attention_backward_scratch_bytes(int N, int T, int C, int heads);
+int hl_attention_nhwc_backward(const float *qkv, const float *out, const float *dout, int N, int T, int C, int heads, float *dqkv,
+                               void *scratch, size_t scratch_bytes, void *stream);
 /* timestep_embedding (nn.py:103-121): t int64 (B) or t_float fp32 (B) -> out (B, dim), dim even */
 int hl_timestep_embedding(const int64_t *t, const float *t_float, int B, int dim, float *out, void *stream);
 
