@@ -14,8 +14,8 @@ include/humanliff_hip.h), activations NHWC fp32:
     _GroupNormAct  forward   hl_groupnorm_train_forward (statistics -> affine with scale/shift -> apply + SiLU)
                    backward  hl_groupnorm_train_backward (per-(n,c) reductions, the (N,C) algebra, dx; parameter / scale-shift gradients)
     _Attention     forward   hl_attention_nhwc (fp32 flash-style kernel)
-                   backward  recomputed probabilities, five batched GEMMs through torch.bmm (rocBLAS - a plain library GEMM; 2 % of the
-                             network's FLOPs)
+                   backward  hl_attention_nhwc_backward (csrc/hl_attention_bwd.hip: fp32 MFMA, probabilities recomputed, deterministic; round 4 -
+                             rounds 2-3 used five torch.bmm here)
 The (N, 768)-sized embedding MLP (time_embed, label_emb, the ResBlocks' emb_layers: 0.004 % of the FLOPs), residual adds and channel
 concatenations are torch tensor ops.  No convolution, normalisation or attention runs through MIOpen / torch.nn.functional.
 
