@@ -104,7 +104,6 @@ SIGNATURES = {
     "hl_conv2d_nhwc_mode": (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
     "hl_conv2d_nhwc_gn": (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, C.POINTER(C.c_int), _p, _sz, _p]),
     "hl_conv2d_nhwc_bwd_data": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
-    "hl_conv2d_wgrad_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p]),
     "hl_conv2d_wgrad_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "hl_conv2d_wgrad_nhwc_ws": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _sz, _p]),
     "hl_conv2d_wgrad_nhwc_ws_mode": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _sz, _p]),

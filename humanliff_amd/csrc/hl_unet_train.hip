@@ -5,13 +5,13 @@
 // of the stock ops is replaced, op by op (humanliff_amd/improved_diffusion/unet_train.py holds the autograd.Functions), by
 //   conv forward / backward-data   the FORWARD conv kernels of hl_unet_kernels.hip: backward-data of a 3x3 / 1x1 convolution is the
 //                                  same convolution of the output gradient with the flipped, channel-transposed weights
-//   k_conv_wgrad_t / k_conv_wgrad  backward-weights + bias:  dW[co][ci][ky][kx] = sum_p dY[p][co] * X[p*stride + (ky,kx) - pad][ci]
+//   k_conv_wgrad_t / _1x1          backward-weights + bias:  dW[co][ci][ky][kx] = sum_p dY[p][co] * X[p*stride + (ky,kx) - pad][ci]
 //                                  as a GEMM over the pixels on v_mfma_f32_32x32x2_f32 (3x3 layers: _t, all taps per workgroup)
 //   k_gn_apply (hl_unet_kernels)   GroupNorm32 (+scale/shift) (+SiLU) apply, nn.py:100, unet.py:198-219
 //   k_gn_bwd_reduce / _apply       its backward: per-(n,c) reductions, then dx = k1*du + k2*x + k3
 // No float atomics on this path: the GroupNorm reductions and the convolutions' weight / bias gradients are partial sums added in a fixed
-// order (k_gn_bwd_fin, k_wgrad_finish), so the kernels of a training step give the same bits run to run.  (Only the fallback k_conv_wgrad
-// for channel counts that are not multiples of 4 - no layer of the network - still ends in atomics.)
+// order (k_gn_bwd_fin, k_wgrad_finish), so the kernels of a training step give the same bits run to run.  (The atomics-based fallback
+// k_conv_wgrad for channel counts that are not multiples of 4 - no layer of the network - was removed in round 4.)
 #include "hl_unet_kernels.h"
 
 namespace hl {
@@ -19,135 +19,11 @@ namespace {
 
 __device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v)); }
 
-// ---------------------------------------------------------------------------------------------
-// backward-weights
-// ---------------------------------------------------------------------------------------------
-// GEMM view: M = output channels, N = input channels (of one tap), K = output pixels.  NHWC makes BOTH operands MFMA-ready straight
-// from memory: v_mfma_f32_32x32x2_f32 wants A[m][k] in lane (m, k) and B[k][n] in lane (n, k) - lane (l & 31, l >> 5) reads channel
-// l & 31 of pixel 2q + (l >> 5): 32 consecutive floats per pixel.  One 8-byte load per lane serves two channel tiles (row m of tile r
-// is channel c0 + 2m + r - any assignment of channels to rows works as long as the store undoes it), so a k-step of two pixels costs a
-// wave 2 x 512 B of loads for 4 MFMAs (a 64 x 64 block of dW for one tap).
-// Grid: x = (co block, ci block, tap), y = pixel slab; the 4 waves of a workgroup interleave the pixel pairs of the slab and add their
-// blocks to dW with float atomics (dW zeroed by the caller).  Zero padding / the nearest-x2 upsample / stride 2 are per-lane source
-// offsets; lanes outside the image or the tensor read zeros through the buffer descriptor's range check.
-struct WgradK {
-    const float *x; long x_pitch; int N, Hin, Win, Cx;        // conv input (NHWC, Cx channels present, Cx even)
-    const float *dy; long dy_pitch; int Hout, Wout, Cy;       // output gradient (NHWC, Cy channels present, Cy even)
-    int ks, stride, ups;
-    float *dw; int Cout_w, Cin_w;                              // dW (Cout_w, Cin_w, ks, ks) - the reference's OIHW parameter layout
-    float *db;                                                 // (Cout_w) or null
-    int n_co, n_ci; long P, slab;                              // blocks of 64 channels; output pixels; pixels per (workgroup) slab
-};
-
-__global__ __launch_bounds__(256) void k_conv_wgrad(const WgradK p) {
-    constexpr unsigned OOB = 0x80000000u;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, m = lane & 31;
-    const int taps = p.ks * p.ks;
-    int bi = blockIdx.x;
-    const int tap = bi % taps; bi /= taps;
-    const int cib = bi % p.n_ci, cob = bi / p.n_ci;
-    const int co0 = cob * 64, ci0 = cib * 64;
-    const int ky = p.ks == 3 ? tap / 3 : 0, kx = p.ks == 3 ? tap - ky * 3 : 0, pad = p.ks >> 1;
-    const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
-    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)p.dy, (short)0, (int)(p.P * p.dy_pitch * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsX =
-        __builtin_amdgcn_make_buffer_rsrc((void *)p.x, (short)0, (int)((long)p.N * p.Hin * p.Win * p.x_pitch * 4), 0x00020000);
-    const bool a_ok = co0 + 2 * m < p.Cy, b_ok = ci0 + 2 * m < p.Cx;          // (channel counts are even: the pair is in or out together)
-    const long s0 = (long)blockIdx.y * p.slab, s1 = min(p.P, s0 + p.slab);
-    // this lane's first output pixel and its (n, y, x)
-    long pix = s0 + 2 * wave + kh;
-    const int hw = p.Hout * p.Wout;
-    int n = (int)(pix / hw), rem = (int)(pix - (long)n * hw);
-    int yo = rem / p.Wout, xo = rem - yo * p.Wout;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bs0 = 0.f, bs1 = 0.f;
-    const bool want_b = p.db != nullptr && tap == 0 && cib == 0;
-    auto offs = [&](unsigned &oa, unsigned &ob) {
-        const bool in = pix < s1;
-        const int yi = yo * p.stride + ky - pad, xi = xo * p.stride + kx - pad;
-        const bool v = in && yi >= 0 && yi < Hv && xi >= 0 && xi < Wv;
-        const int ys = p.ups ? yi >> 1 : yi, xs = p.ups ? xi >> 1 : xi;
-        oa = (in && a_ok) ? (unsigned)((pix * p.dy_pitch + co0 + 2 * m) * 4) : OOB;
-        ob = (v && b_ok) ? (unsigned)((((long)n * p.Hin + ys) * p.Win + xs) * p.x_pitch + ci0 + 2 * m) * 4u : OOB;
-    };
-    auto advance = [&]() {   // the wave's next pixel pair is 8 pixels on
-        pix += 8;
-        xo += 8;
-        while (xo >= p.Wout) { xo -= p.Wout; if (++yo == p.Hout) { yo = 0; ++n; } }
-    };
-    const long npairs = (s1 - s0 + 1) / 2;                      // pixel pairs of the slab; this wave takes pairs wave, wave+4, ...
-    const long mine = npairs > wave ? (npairs - wave + 3) / 4 : 0;
-    for (long it = 0; it < mine; it += 4) {                     // four k-steps of loads in flight
-        float2 a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            unsigned oa, ob;
-            offs(oa, ob);
-            if (it + u >= mine) { oa = OOB; ob = OOB; }
-            a[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsY, oa, 0, 0));
-            b[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsX, ob, 0, 0));
-            advance();
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc[1][1], 0, 0, 0);
-            bs0 += a[u].x; bs1 += a[u].y;
-        }
-    }
-    // the four waves' blocks meet in LDS (fixed order), then ONE set of float atomics per workgroup: the L2 atomic units (~25 G/s)
-    // were the whole kernel time when every wave added its own 4096 values
-    __shared__ float red[3][4][16][64];                          // waves 1..3: [i*2+j][r][lane]
-    if (wave > 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[wave - 1][i * 2 + j][r][lane] = acc[i][j][r];
-    }
-    __syncthreads();
-    // dW[co][ci][ky][kx]: accumulator r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
-    if (wave == 0) {
-        const int ci = ci0 + 2 * m;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = ((acc[i][j][r] + red[0][i * 2 + j][r][lane]) + red[1][i * 2 + j][r][lane]) + red[2][i * 2 + j][r][lane];
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    const int co = co0 + 2 * row + i, cc = ci + j;
-                    if (co < p.Cout_w && cc < p.Cin_w) {
-                        float *q = p.dw + ((long)co * p.Cin_w + cc) * taps + tap;
-                        if (gridDim.y == 1) *q = v; else atomicAdd(q, v);     // a single slab owns its block of dW: plain stores
-                    }
-                }
-    }
-    if (want_b) {
-        bs0 += __shfl_xor(bs0, 32);
-        bs1 += __shfl_xor(bs1, 32);
-        if (kh == 0) {
-            // (the four waves of the workgroup add their shares: atomics also with a single slab)
-            if (co0 + 2 * m < p.Cout_w) atomicAdd(p.db + co0 + 2 * m, bs0);
-            if (co0 + 2 * m + 1 < p.Cout_w) atomicAdd(p.db + co0 + 2 * m + 1, bs1);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // backward-weights of the 3x3 layers, all nine taps per workgroup (k_conv_wgrad_t + k_wgrad_finish)
 // ---------------------------------------------------------------------------------------------
-// k_conv_wgrad above takes its operands straight from L2 - 1 KiB per four MFMAs and wave - and gives every tap a workgroup of its
+// The first version (k_conv_wgrad, removed) took its operands straight from L2 - 1 KiB per four MFMAs and wave - and gave every tap a workgroup of its
 // own, so a 3x3 layer pulls X and dY through the L2 nine times per channel-block pair: the kernel runs at the L2's delivery rate
 // (0.38 of the fp32 matrix peak over the production network).  Here a workgroup owns a (64 co x 64 ci) block of dW for ALL nine taps
 // and walks a slab of 8x8-pixel output tiles (4x8 for stride 2):
@@ -755,30 +631,6 @@ using namespace hl;
 
 extern "C" {
 
-int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
-                         float *dw, int Cout, int Cin, float *db, void *stream) {
-    HL_REQUIRE(x && dy && dw, "hl_conv2d_wgrad_nhwc: null argument");
-    HL_REQUIRE((ks == 1 || ks == 3) && (stride == 1 || (stride == 2 && !upsample)), "hl_conv2d_wgrad_nhwc: kernel size / stride");
-    HL_REQUIRE(Cx % 2 == 0 && Cy % 2 == 0 && Cin <= Cx && Cout <= Cy, "hl_conv2d_wgrad_nhwc: channel counts (x %d, dy %d) must be even and cover the weight (%d, %d)", Cx, Cy, Cout, Cin);
-    const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
-    WgradK p{};
-    p.x = x; p.x_pitch = Cx; p.N = N; p.Hin = H; p.Win = W; p.Cx = Cx;
-    p.dy = dy; p.dy_pitch = Cy; p.Hout = (Hv + 2 * pad - ks) / stride + 1; p.Wout = (Wv + 2 * pad - ks) / stride + 1; p.Cy = Cy;
-    p.ks = ks; p.stride = stride; p.ups = upsample; p.dw = dw; p.Cout_w = Cout; p.Cin_w = Cin; p.db = db;
-    p.n_co = (Cout + 63) / 64; p.n_ci = (Cin + 63) / 64;
-    p.P = (long)N * p.Hout * p.Wout;
-    HL_REQUIRE(p.P * Cy * 4 < (1L << 31) && (long)N * H * W * Cx * 4 < (1L << 31), "hl_conv2d_wgrad_nhwc: tensors of 2 GiB and more are not addressed");
-    const long tiles = (long)p.n_co * p.n_ci * ks * ks;
-    long slabs = (1024 + tiles - 1) / tiles;                     // ~1024 workgroups (4 per CU); every workgroup ends in 4096 atomics
-    const long max_slabs = (p.P + 1023) / 1024;                  // at least 1024 pixels (128 pairs per wave) per workgroup
-    if (slabs > max_slabs) slabs = max_slabs;
-    if (slabs < 1) slabs = 1;
-    p.slab = ((p.P + slabs - 1) / slabs + 7) / 8 * 8;            // multiple of 8: the waves' pair interleave starts aligned
-    slabs = (p.P + p.slab - 1) / p.slab;
-    hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)tiles, (unsigned)slabs), dim3(256), 0, (hipStream_t)stream, p);
-    return check_launch("k_conv_wgrad");
-}
-
 // k_conv_wgrad_t geometry: 8x8 output tiles (4x8 for stride 2); k_conv_wgrad_1x1: 64 consecutive pixels; ~512 workgroups (two per CU,
 // one round)
 static void wgrad_t_plan(int N, int Hout, int Wout, int Cout, int Cin, int ks, int stride, WgradT &p) {
@@ -823,8 +675,8 @@ int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const f
 int hl_conv2d_wgrad_nhwc_ws_mode(int conv_mode, const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                                  float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream) {
     const bool h16 = (conv_mode == HL_CONV_FP16 || conv_mode == HL_CONV_BF16) && ks == 3 && stride == 1;
-    if (!wgrad_t_applies(Cx, Cy, ks, stride, upsample))
-        return hl_conv2d_wgrad_nhwc(x, N, H, W, Cx, dy, Cy, ks, stride, upsample, dw, Cout, Cin, db, stream);
+    HL_REQUIRE(wgrad_t_applies(Cx, Cy, ks, stride, upsample), "hl_conv2d_wgrad_nhwc_ws: channel counts (x %d, dy %d) must be multiples of 4 (the atomics-based "
+               "fallback for other counts is gone: every kernel of the training step sums in a fixed order)", Cx, Cy);
     HL_REQUIRE(x && dy && dw, "hl_conv2d_wgrad_nhwc_ws: null argument");
     HL_REQUIRE(stride == 1 || (stride == 2 && !upsample), "hl_conv2d_wgrad_nhwc_ws: stride");
     HL_REQUIRE(Cin <= Cx && Cout <= Cy, "hl_conv2d_wgrad_nhwc_ws: channel counts (x %d, dy %d) must cover the weight (%d, %d)", Cx, Cy, Cout, Cin);

@@ -389,10 +389,9 @@ int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int
  * (hl_conv2d_nhwc_bwd_data); stride 2 goes through hl_zero_stuff2_nhwc first, the nearest-x2 upsample through
  * hl_upsample2_backward_nhwc afterwards.  humanliff_amd/improved_diffusion/unet_train.py holds the autograd.Functions.
  *
- * hl_conv2d_wgrad_nhwc: dW[co][ci][ky][kx] += sum_p dY[p][co] * X[p*stride + (ky,kx) - pad][ci] and db[co] += sum_p dY[p][co]
- * (float atomics: dw (Cout, Cin, ks, ks) - the reference's OIHW parameter layout - and db (Cout) or NULL must be zeroed by the caller).
- * x (N,H,W,Cx), dy (N,Hout,Wout,Cy) dense NHWC with Cx >= Cin, Cy >= Cout even (zero-padded channels are ignored); `upsample`:
- * the convolution ran on the nearest-x2 upsampled x. */
+ * Weight gradient: dW[co][ci][ky][kx] = sum_p dY[p][co] * X[p*stride + (ky,kx) - pad][ci] and db[co] = sum_p dY[p][co] with dw (Cout, Cin,
+ * ks, ks) in the reference's OIHW parameter layout; x (N,H,W,Cx), dy (N,Hout,Wout,Cy) dense NHWC with Cx >= Cin, Cy >= Cout (zero-padded
+ * channels are ignored); `upsample`: the convolution ran on the nearest-x2 upsampled x.  (hl_conv2d_wgrad_nhwc_ws below.) */
 /* hl_conv2d_nhwc_bwd_data: d input of a convolution from d output, through the forward kernels: dy (N,Ho,Wo,Cy) dense NHWC with
  * Cy >= Cout a multiple of 16 (zero-padded channels), w the convolution's own (Cout, Cin, ks, ks) weights - read flipped and
  * channel-transposed while they are re-laid for the kernel, no flipped copy is made -, dx (N,H,W,Cx) with Cx >= Cin (channels
@@ -400,14 +399,11 @@ int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int
  * scratch: the re-laid weights (5 * round_up(Cin,64) * Cy * ks^2 floats) + 16 MiB + the zero-stuffed / upsampled gradient. */
 int hl_conv2d_nhwc_bwd_data(int conv_mode, const float *dy, int N, int Ho, int Wo, int Cy, const float *w_oihw, int Cout, int Cin, int ks,
                             int stride, int upsample, float *dx, int Cx, void *scratch, size_t scratch_bytes, void *stream);
-int hl_conv2d_wgrad_nhwc(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
-                         float *dw, int Cout, int Cin, float *db, void *stream);
-/* hl_conv2d_wgrad_nhwc_ws: the same gradients without atomics.  3x3 layers: k_conv_wgrad_t (a workgroup owns a 64x64 channel block of
+/* hl_conv2d_wgrad_nhwc_ws: the weight / bias gradients, without atomics.  3x3 layers: k_conv_wgrad_t (a workgroup owns a 64x64 channel block of
  * dW for all nine taps; dY rows and input patch of an 8x8-pixel tile staged in LDS once); 1x1 layers: k_conv_wgrad_1x1 (192 x 64 channel
  * block, 64-pixel tiles).  Per-slab partial blocks go to `scratch` and k_wgrad_finish sums them in a fixed order: dw / db are plainly
  * stored (no need to zero them) and bit-reproducible.  Needs Cx, Cy multiples of 4 and `scratch` of
- * hl_conv2d_wgrad_scratch_bytes(...) bytes; other channel counts fall through to hl_conv2d_wgrad_nhwc (scratch size 0: dw / db must
- * then be zeroed by the caller). */
+ * hl_conv2d_wgrad_scratch_bytes(...) bytes; other channel counts are refused (the atomics-based entry of rounds 2-3 is gone). */
 size_t hl_conv2d_wgrad_scratch_bytes(int N, int H, int W, int Cx, int Cy, int ks, int stride, int upsample, int Cout, int Cin);
 int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                             float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream);
