@@ -1,7 +1,7 @@
 """Sum FETCH_SIZE / WRITE_SIZE (KB) per kernel family over a rocprofv3 --pmc run of bench.py.
 usage: python scripts/pmc_bench_summary.py <fetch_dir> <write_dir> [out.md]
 FETCH_SIZE under-counts 16 B/lane streams by 2x on gfx950 (calibrated with a device copy, see
-profiles/r01_pmc_hbm_traffic.md), so reads are reported doubled ("corrected")."""
+profiles/notes_design_rounds_1_to_3.md, section 6), so reads are reported doubled ("corrected")."""
 import csv, glob, re, sys, collections
 
 FAMILIES = [("conv (k_conv_wino4w / k_conv_wino4 / k_conv_wino / k_conv_dma / k_conv + k_gn_apply + k_splitk_finish[_st])", r"k_conv<|k_conv_dma<|k_conv_wino<|k_conv_wino4<|k_conv_wino4w<|k_conv_bf3<|k_gn_apply|k_splitk_finish"),

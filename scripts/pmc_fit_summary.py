@@ -1,6 +1,6 @@
 """FETCH_SIZE / WRITE_SIZE (KB) per kernel of the fitting iteration from two rocprofv3 --pmc runs of scripts/train_bench.py.
 usage: python scripts/pmc_fit_summary.py <fetch_dir> <write_dir> [out.md]     (FETCH doubled: gfx950 under-count for 16 B/lane streams,
-see profiles/r01_pmc_hbm_traffic.md)"""
+see profiles/notes_design_rounds_1_to_3.md, section 6)"""
 import collections, csv, glob, re, sys
 
 KERNELS = [("k_march<.., ACTS> (evaluate + activation matrix)", r"k_march<true, true, 8, false, true>"), ("k_mlp_bwd", r"k_mlp_bwd"), ("k_wgrad", r"k_wgrad"),
