@@ -17,20 +17,24 @@
 namespace hl {
 namespace {
 
-template <int CH, int WPB>
-__global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_q(const float *__restrict__ qkv, const float *__restrict__ out, const float *__restrict__ dout,
+// KS waves of a workgroup share ONE 32-row tile and split the other dimension (every KS-th key tile / query tile each, wave-private LDS
+// tiles, no workgroup barrier inside the loops); their partial sums meet in LDS and are added in a fixed order.  The UNet's attention levels
+// have 32 / 8 / 2 tiles per head and 8 (sample, head) pairs at microbatch 2: one wave per tile pair left three quarters of the SIMDs idle and
+// ran a 1024-key loop serially (565 + 350 us per layer at T = 1024; with the split 1/KS of that).
+template <int CH, int KS_>
+__global__ __launch_bounds__(KS_ * 64, 1) void k_attn_bwd_q(const float *__restrict__ qkv, const float *__restrict__ out, const float *__restrict__ dout,
                                                             int T, int C, int heads, float *__restrict__ dqkv, float *__restrict__ stat) {
-    constexpr int CT = CH / 32, KS = CH / 2, LDK = CH + 1;
-    __shared__ float sK[32 * LDK];
-    __shared__ float sV[32 * LDK];
+    constexpr int CT = CH / 32, KS = CH / 2, LDK = CH + 1, TILE = 32 * LDK;
+    extern __shared__ float lds_q[];                    // per wave: K tile, V tile (2 x 32 x LDK); reused for the partial dQ tiles at the end
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    float *sK = lds_q + wave * 2 * TILE, *sV = sK + TILE;
+    __shared__ float sML[KS_ * 2 * 32];
     const int nh = blockIdx.y, n = nh / heads, head = nh % heads;
-    const int q0 = (blockIdx.x * WPB + wave) * 32;
+    const int q0 = blockIdx.x * 32;
     const float scale = 1.f / sqrtf(sqrtf((float)CH));
     const long pitch = 3L * C;
     const float *base = qkv + (long)n * T * pitch + (long)head * 3 * CH;
     const int qi = q0 + (lane & 31), qj = min(qi, T - 1);
-    // B operands: lane (query j, half) holds q[c = 2s + half] * s and dO[c = 2s + half]; D = dO . O over the lane pair
     float qreg[KS], doreg[KS];
     float D = 0.f;
     {
@@ -43,9 +47,8 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_q(const float *__restr
         }
         D += __shfl_xor(D, 32);
     }
-    auto load_tile = [&](int k0, bool with_v) {
-        __syncthreads();
-        for (int e = tid; e < 32 * (CH / 4); e += WPB * 64) {
+    auto load_tile = [&](int k0, bool with_v) {   // wave-private: the wave's own LDS reads of the previous tile are behind it in program order
+        for (int e = lane; e < 32 * (CH / 4); e += 64) {
             const int key = e / (CH / 4), c = (e - key * (CH / 4)) * 4;
             const int kk = min(k0 + key, T - 1);
             const f32x4 kv = *reinterpret_cast<const f32x4 *>(base + (long)kk * pitch + CH + c);
@@ -57,7 +60,8 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_q(const float *__restr
                 dv[0] = vv[0]; dv[1] = vv[1]; dv[2] = vv[2]; dv[3] = vv[3];
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
     auto scores = [&](int k0) -> f32x16 {   // st[r] = S(key = k0 + (r&3) + 8 (r>>2) + 4 half, query = lane & 31); keys beyond T masked
         f32x16 st;
@@ -70,9 +74,9 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_q(const float *__restr
             if (k0 + (r & 3) + 8 * (r >> 2) + 4 * half >= T) st[r] = -3.0e38f;
         return st;
     };
-    // pass A: row maximum and sum
+    // pass A: row maximum and sum over this wave's key tiles, then over the waves
     float mrun = -3.0e38f, lrun = 0.f;
-    for (int k0 = 0; k0 < T; k0 += 32) {
+    for (int k0 = wave * 32; k0 < T; k0 += 32 * KS_) {
         load_tile(k0, false);
         const f32x16 st = scores(k0);
         float mx = -3.0e38f;
@@ -86,19 +90,30 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_q(const float *__restr
         psum += __shfl_xor(psum, 32);
         lrun = lrun * __expf(mrun - mnew) + psum;
         mrun = mnew;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (half == 0) { sML[(wave * 2) * 32 + lane] = mrun; sML[(wave * 2 + 1) * 32 + lane] = lrun; }
+    __syncthreads();
+    {
+        float m = -3.0e38f, l = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS_; ++w) m = fmaxf(m, sML[(w * 2) * 32 + (lane & 31)]);
+#pragma unroll
+        for (int w = 0; w < KS_; ++w) l += sML[(w * 2 + 1) * 32 + (lane & 31)] * __expf(sML[(w * 2) * 32 + (lane & 31)] - m);   // waves without keys: l = 0
+        mrun = m; lrun = l;
     }
     const float invl = 1.f / lrun;
-    if (half == 0 && qi < T) {
+    if (wave == 0 && half == 0 && qi < T) {
         float *sp = stat + ((long)nh * T + qi) * 3;
         sp[0] = mrun; sp[1] = invl; sp[2] = D;
     }
-    // pass B: dQ^T[c][q] += K^T[c][key] dS^T[key][q]
+    // pass B: dQ^T[c][q] += K^T[c][key] dS^T[key][q] over this wave's key tiles
     f32x16 o[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
-    for (int k0 = 0; k0 < T; k0 += 32) {
+    for (int k0 = wave * 32; k0 < T; k0 += 32 * KS_) {
         load_tile(k0, true);
         f32x16 st = scores(k0);
         f32x16 dp;
@@ -115,26 +130,38 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_q(const float *__restr
                 const int key = (s & 3) + 8 * (s >> 2) + 4 * half;
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[key * LDK + c * 32 + (lane & 31)], st[s], o[c], 0, 0, 0);
             }
+        __builtin_amdgcn_wave_barrier();
     }
+    // the waves' partial dQ tiles meet in LDS ([wave][CT * 16][64 lanes], inside the wave's own tile space) and are added in wave order
+    __syncthreads();
+    float *part = lds_q + wave * 2 * TILE;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(c * 16 + r) * 64 + lane] = o[c][r];
+    __syncthreads();
     if (qi < T) {
         float *dst = dqkv + ((long)n * T + qi) * pitch + (long)head * 3 * CH;
+        for (int e = wave; e < CT * 16; e += KS_) {      // register rows split over the waves
+            float v = 0.f;
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dst[c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = o[c][r] * scale;
+            for (int w = 0; w < KS_; ++w) v += lds_q[w * 2 * TILE + e * 64 + lane];
+            const int c = e >> 4, r = e & 15;
+            dst[c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v * scale;
+        }
     }
 }
 
-template <int CH, int WPB>
-__global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_kv(const float *__restrict__ qkv, const float *__restrict__ dout, const float *__restrict__ stat,
+template <int CH, int KS_>
+__global__ __launch_bounds__(KS_ * 64, 1) void k_attn_bwd_kv(const float *__restrict__ qkv, const float *__restrict__ dout, const float *__restrict__ stat,
                                                              int T, int C, int heads, float *__restrict__ dqkv) {
-    constexpr int CT = CH / 32, KS = CH / 2, LDK = CH + 1;
-    __shared__ float sQ[32 * LDK];
-    __shared__ float sD[32 * LDK];
-    __shared__ float sS[32 * 3];
+    constexpr int CT = CH / 32, KS = CH / 2, LDK = CH + 1, TILE = 32 * LDK;
+    extern __shared__ float lds_k[];                    // per wave: Q tile, dO tile, 96 floats of (max, 1/sum, D); reused for the partial dK / dV tiles
+    constexpr int WSZ = 2 * TILE + 96 + ((2 * TILE + 96) & 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    float *sQ = lds_k + wave * WSZ, *sD = sQ + TILE, *sS = sD + TILE;
     const int nh = blockIdx.y, n = nh / heads, head = nh % heads;
-    const int k0 = (blockIdx.x * WPB + wave) * 32;
+    const int k0 = blockIdx.x * 32;
     const float scale = 1.f / sqrtf(sqrtf((float)CH));
     const long pitch = 3L * C;
     const float *base = qkv + (long)n * T * pitch + (long)head * 3 * CH;
@@ -150,9 +177,8 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_kv(const float *__rest
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[c][r] = 0.f; dv[c][r] = 0.f; }
-    for (int q0 = 0; q0 < T; q0 += 32) {
-        __syncthreads();
-        for (int e = tid; e < 32 * (CH / 4); e += WPB * 64) {
+    for (int q0 = wave * 32; q0 < T; q0 += 32 * KS_) {
+        for (int e = lane; e < 32 * (CH / 4); e += 64) {
             const int q = e / (CH / 4), c = (e - q * (CH / 4)) * 4;
             const int qq = min(q0 + q, T - 1);
             const f32x4 qv = *reinterpret_cast<const f32x4 *>(base + (long)qq * pitch + c);
@@ -161,11 +187,12 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_kv(const float *__rest
             a[0] = qv[0] * scale; a[1] = qv[1] * scale; a[2] = qv[2] * scale; a[3] = qv[3] * scale;
             b[0] = dd[0]; b[1] = dd[1]; b[2] = dd[2]; b[3] = dd[3];
         }
-        for (int e = tid; e < 96; e += WPB * 64) {
+        for (int e = lane; e < 96; e += 64) {
             const int q = e / 3, j = e - q * 3;
             sS[e] = q0 + q < T ? stat[((long)nh * T + q0 + q) * 3 + j] : (j == 0 ? 3.0e38f : 0.f);   // queries beyond T: max = +huge, 1/sum = 0 -> P = 0
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         f32x16 st, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
@@ -191,17 +218,25 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attn_bwd_kv(const float *__rest
                 dv[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(sD[q * LDK + c * 32 + (lane & 31)], st[s], dv[c], 0, 0, 0);
                 dk[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[q * LDK + c * 32 + (lane & 31)], ds[s], dk[c], 0, 0, 0);
             }
+        __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
+    float *part = lds_k + wave * WSZ;                    // [2 CT * 16][64]: 2 * CT * 1024 floats <= 2 * TILE
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { part[(c * 16 + r) * 64 + lane] = dk[c][r]; part[((CT + c) * 16 + r) * 64 + lane] = dv[c][r]; }
+    __syncthreads();
     if (ki < T) {
         float *dst = dqkv + ((long)n * T + ki) * pitch + (long)head * 3 * CH;
+        for (int e = wave; e < 2 * CT * 16; e += KS_) {
+            float v = 0.f;
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cc = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                dst[CH + cc] = dk[c][r] * scale;
-                dst[2 * CH + cc] = dv[c][r];
-            }
+            for (int w = 0; w < KS_; ++w) v += lds_k[w * WSZ + e * 64 + lane];
+            const int isv = e >= CT * 16, ee = isv ? e - CT * 16 : e, c = ee >> 4, r = ee & 15;
+            const int cc = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (isv) dst[2 * CH + cc] = v; else dst[CH + cc] = v * scale;
+        }
     }
 }
 
@@ -281,21 +316,17 @@ int attention_backward(const float *qkv, const float *out, const float *dout, in
     const int ch = C / heads;
     float *sc = (float *)scratch;
     const int tiles = (T + 31) / 32;
-    int wpb = 4;
-    while (wpb > 1 && (long)((tiles + wpb - 1) / wpb) * N * heads < 256) wpb >>= 1;
-    const dim3 grid((tiles + wpb - 1) / wpb, N * heads);
+    const dim3 grid(tiles, N * heads);
+    // waves per workgroup = how many ways the other dimension is split: 4 while the wave-private tiles fit LDS (head sizes <= 96), else 2
 #define HL_ATTB(CH_)                                                                                                                       \
     do {                                                                                                                                   \
-        if (wpb == 4) {                                                                                                                    \
-            hipLaunchKernelGGL((k_attn_bwd_q<CH_, 4>), grid, dim3(256), 0, st, qkv, out, dout, T, C, heads, dqkv, sc);                      \
-            hipLaunchKernelGGL((k_attn_bwd_kv<CH_, 4>), grid, dim3(256), 0, st, qkv, dout, sc, T, C, heads, dqkv);                          \
-        } else if (wpb == 2) {                                                                                                             \
-            hipLaunchKernelGGL((k_attn_bwd_q<CH_, 2>), grid, dim3(128), 0, st, qkv, out, dout, T, C, heads, dqkv, sc);                      \
-            hipLaunchKernelGGL((k_attn_bwd_kv<CH_, 2>), grid, dim3(128), 0, st, qkv, dout, sc, T, C, heads, dqkv);                          \
-        } else {                                                                                                                           \
-            hipLaunchKernelGGL((k_attn_bwd_q<CH_, 1>), grid, dim3(64), 0, st, qkv, out, dout, T, C, heads, dqkv, sc);                       \
-            hipLaunchKernelGGL((k_attn_bwd_kv<CH_, 1>), grid, dim3(64), 0, st, qkv, dout, sc, T, C, heads, dqkv);                           \
-        }                                                                                                                                  \
+        constexpr int KS_ = CH_ <= 96 ? 4 : 2;                                                                                             \
+        constexpr size_t lq = (size_t)KS_ * 2 * 32 * (CH_ + 1) * sizeof(float), lk = (size_t)KS_ * (2 * 32 * (CH_ + 1) + 96) * sizeof(float);  \
+        static const bool ok_ = hipFuncSetAttribute((const void *)k_attn_bwd_q<CH_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq) == hipSuccess && \
+                                hipFuncSetAttribute((const void *)k_attn_bwd_kv<CH_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lk) == hipSuccess;   \
+        HL_REQUIRE(ok_, "attention_backward: cannot raise the dynamic LDS limit");                                                         \
+        hipLaunchKernelGGL((k_attn_bwd_q<CH_, KS_>), grid, dim3(KS_ * 64), lq, st, qkv, out, dout, T, C, heads, dqkv, sc);                  \
+        hipLaunchKernelGGL((k_attn_bwd_kv<CH_, KS_>), grid, dim3(KS_ * 64), lk, st, qkv, dout, sc, T, C, heads, dqkv);                      \
     } while (0)
     switch ((3L * C) % 4 == 0 ? ch : -1) {
         case 32: HL_ATTB(32); break;
