@@ -39,12 +39,12 @@ FULL_FLOP_PER_POINT = 132608            # density + colour MLP at one sample poi
 FINE_FLOP_PER_RAY = 256 * 132608
 COARSE_FLOP_PER_RAY = 128 * 79616
 FINE_FLOP_PER_RAY_TOTAL = FINE_FLOP_PER_RAY + COARSE_FLOP_PER_RAY   # the reference's schedule: 44 138 496 FLOP per ray
-# Fabric-side bytes per launch of the two dominant kernels from the separate rocprofv3 PMC passes (FETCH_SIZE
-# doubled per the gfx950 calibration, WRITE_SIZE as is): profiles/r03_pmc_hbm_traffic.md.  Not measured by this
-# script - PMC collection needs its own runs.
-PMC_TRAFFIC = {"k_conv_avg_launch_b4": 308e6, "k_march_fine_512x512": 4.1e9, "k_march_eval_512x512": 0.72e9,
-               "source": "profiles/r03_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv path: (343.78 GB read "
-                         "+ 129.81 GB written) / 6 forwards / 256 launches) and profiles/r02_pmc_hbm_traffic.md (k_march<true,true>: (1.50 + 4.29 GB) / 8 launches)"}
+# Fabric-side bytes per launch of the dominant kernels from the separate rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
+# calibration, WRITE_SIZE as is).  Not measured by this script - PMC collection needs its own runs (scripts/refresh_profiles_r4.sh).
+PMC_TRAFFIC = {"k_conv_avg_launch_b4": 308e6, "k_march_fine_512x512": 4.1e9, "k_march_eval_512x512": 0.72e9, "k_march_b3w_eval_512x512": 0.73e9,
+               "source": "profiles/r04_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv path: (341.80 GB read "
+                         "+ 131.00 GB written) / 6 forwards / 256 launches), profiles/r04_pmc_render_traffic.md (k_march_b3w: 193.6 MB read + 536.9 MB written "
+                         "per launch) and profiles/notes_design_rounds_1_to_3.md (k_march<true,true>: (1.50 + 4.29 GB) / 8 launches)"}
 
 F4 = dict(image_size=256, in_channels=27, out_channels=27, num_channels=192, num_res_blocks=3, num_heads=4,
           num_heads_upsample=-1, attention_resolutions="32,16,8", dropout=0.0, learn_sigma=False, sigma_small=False,
@@ -731,7 +731,8 @@ def bench_render(args, rank, world, dev):
             "achieved": round(issued / (t_b * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(issued / (t_b * 1e-3) / 1e12 / 2500.0, 4),
             "peak_note": "dense bf16 MFMA peak (MI355X_MICROARCH.md); `achieved` = bf16 FLOPs issued.  In the path's own unit: "
                          f"{eval_flop / (t_b * 1e-3) / 1e12:.1f} TFLOP/s of algorithmic fp32 work = {eval_flop / (t_b * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS:.2f} x the fp32 matrix peak",
-            "fp32_equivalent_tflops": round(eval_flop / (t_b * 1e-3) / 1e12, 2), "traffic": None, "launch_ms": round(t_b, 3),
+            "fp32_equivalent_tflops": round(eval_flop / (t_b * 1e-3) / 1e12, 2), "traffic": PMC_TRAFFIC["k_march_b3w_eval_512x512"],
+            "traffic_source": PMC_TRAFFIC["source"], "launch_ms": round(t_b, 3),
             "view": {"ms": round(view_ms, 3), "eval_coarse_ms": round(t_a, 3), "importance_ms": round(t_i, 3),
                      "eval_importance_ms": round(t_b, 3), "composite_ms": round(t_c, 3),
                      "algorithmic_tflops": round(R * FINE_FLOP_PER_RAY_TOTAL / (view_ms * 1e-3) / 1e12, 2),

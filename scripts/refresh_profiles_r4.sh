@@ -39,7 +39,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] == c and "k_" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:60]].append(float(r["Counter_Value"]))
+            agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]].append(float(r["Counter_Value"]))
     for k, v in agg.items(): out[k][c] = (len(v), sum(v) / len(v))
 print("| kernel | launches | FETCH_SIZE per launch (KB) | read per launch, doubled per the gfx950 calibration (MB) | WRITE_SIZE per launch (KB) | written per launch (MB) |\n|---|---|---|---|---|---|")
 for k, d in sorted(out.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", (0, 0))[1]):
