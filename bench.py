@@ -815,7 +815,7 @@ def bench_fit(args, rank, world, dev, iters=10):
     ro, rd, nr, fr = (t[pick].to(dev) for t in (ro, rd, nr, fr))
     target = torch.rand((bs, R, 3), device=dev)
     tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].expand(bs, 2, 3).to(dev)}
-    ids, layer = torch.tensor([0, 1]), torch.tensor([1, 3])
+    ids, layer = torch.tensor([0, 1], device=dev), torch.tensor([1, 3], device=dev)   # the reference's loop indexes with the batch's device tensors (to_cuda, run_nerf_batch.py:233)
     t = torch.linspace(0., 1., steps=N, device=dev)
 
     def one():

@@ -66,6 +66,7 @@ class Renderer(nn.Module):
         # (recon_NeRF/lib/renderer.py:288) does not clamp and clears the second flag
         self._depth_flags = _lib.HL_RENDER_NORMALIZE_DEPTH | _lib.HL_RENDER_CLAMP_DEPTH
         self.uniforms_on_device = False      # extension: draw sample_pdf's uniforms with the device generator (see render())
+        self.subject_streams = True          # training mode: subjects after the first on their own HIP streams (see _render_training)
         self.mlp_fp16 = False                # extension, opt-in: the MLP with fp16 operands / fp32 accumulation (HL_RENDER_MLP_FP16, k_march16) in
                                              # render() without canonical space; canonical-space rendering, density_grid() and training stay fp32
         self.mlp_products = "bf16x3"         # how render() forms the fp32 products of the MLP in the evaluate-once pipeline (test mode, world space):
@@ -177,7 +178,10 @@ class Renderer(nn.Module):
             if u is None:
                 # the reference draws sample_pdf's uniforms on the CPU generator and uploads them (renderer.py:545); `uniforms_on_device`
                 # (an extension, off by default) draws them on the device instead: same distribution, no 2 MB upload per fitting step
-                u = torch.rand([bs * R, n_importance], device=dev) if self.uniforms_on_device else torch.rand([bs * R, n_importance]).to(dev)
+                # The CPU draw lands in pinned memory and is uploaded asynchronously: the same values from the same generator, without
+                # the stream-draining synchronous copy of pageable memory that cost the fitting loop its run-ahead (0.8 ms per step).
+                u = torch.rand([bs * R, n_importance], device=dev) if self.uniforms_on_device else \
+                    torch.rand([bs * R, n_importance], pin_memory=True).to(dev, non_blocking=True)
             u = u.reshape(bs, R, n_importance)
         if not self.test:
             return self._render_training(tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,
@@ -216,12 +220,10 @@ class Renderer(nn.Module):
         """Renderer.render with test=False (renderer.py:212, 276-281): Gaussian noise on the raw densities of the fine pass and
         outputs attached to the autograd graph - gradients for tri_planes and the MLP come from the HIP backward kernels
         (NeRF/train.py).  The noise is drawn like the reference's randn_like: one (bs*R*(n_samples+n_importance), 1) draw on the device."""
-        from .train import RenderRaysFunction
         assert n_importance > 0, "training mode is built for the hierarchical schedule (n_importance = n_samples)"
         bs, R = rays_o.shape[:2]
         dev = tri_planes.device
         S = n_samples + n_importance
-        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         if z_vals is None:
             t = torch.linspace(0., 1., steps=n_samples, device=dev)
             z_vals = near[..., None] * (1. - t) + far[..., None] * t
@@ -234,26 +236,65 @@ class Renderer(nn.Module):
         # sample point): 2048 rays x 256 samples need 1.3 GB; larger ray batches go down in pieces (rays are independent)
         rc = self._train_ray_chunk(S)
         outs = []
+        # Subjects are independent until the loss: subject b > 0 goes to its own HIP stream (forward here, and - because autograd runs a
+        # node's backward on the stream of its forward - backward too), so one subject's HBM-bound kernels (k_wgrad, k_plane_scatter)
+        # overlap the other's matrix-bound ones (k_march, k_mlp_bwd).  Tensors of the caller's stream that a side stream reads are
+        # recorded on it (the caching allocator must not hand their memory out while the side stream still reads).
+        main = torch.cuda.current_stream(dev)
+        side = self._subject_streams(dev, bs - 1) if self.subject_streams else []
+        for st in side:                   # fork before anything of this call is queued: a side stream waits for the inputs only
+            st.wait_stream(main)
+            tri_planes.record_stream(st)
         for b in range(bs):
-            dfm = None
-            if tp_canonical is not None:      # per-subject deformation tables (NeRF/deform.py); `bounds` is t_world_bounds here
-                from .deform import deform_tables
-                if self.SMPL_NEUTRAL is None:
-                    raise RuntimeError("use_canonical_space=True needs the body model: set renderer.SMPL_NEUTRAL to the SMPL_to_tensor dict")
-                one = lambda d: {k: v[b:b + 1] for k, v in d.items()}  # noqa: E731
-                dfm = deform_tables(self.SMPL_NEUTRAL, one(tp_canonical['params']), one(tp_canonical['t_params']),
-                                    tp_canonical['vertices'][b:b + 1].to(dev))
-            parts = []
-            for i in range(0, R, rc):
-                sl = slice(i, min(R, i + rc))
-                geo = {"deform": dfm, "rays_o": f32(rays_o[b, sl]), "rays_d": f32(rays_d[b, sl]), "near": f32(near[b, sl]), "far": f32(far[b, sl]),
-                       "bounds": f32(bounds[b]), "z": f32(z_vals[b, sl]), "u": f32(u[b, sl]), "noise": f32(noise[b, sl]), "flags": flags}
-                parts.append(RenderRaysFunction.apply(self, geo, tri_planes[b], *mlp))
-            outs.append(parts[0] if len(parts) == 1 else tuple(torch.cat([q[k] for q in parts]) for k in range(3)))
+            st = side[b - 1] if (b > 0 and side) else None
+            if st is None:
+                outs.append(self._train_one_subject(b, None, tri_planes, bounds, z_vals, rays_o, rays_d, near, far, u, noise, flags, mlp, rc,
+                                                    tp_canonical))
+                continue
+            with torch.cuda.stream(st):
+                outs.append(self._train_one_subject(b, st, tri_planes, bounds, z_vals, rays_o, rays_d, near, far, u, noise, flags, mlp, rc,
+                                                    tp_canonical))
+        for b in range(1, bs if side else 0):
+            main.wait_stream(side[b - 1])
+            for t in outs[b]:
+                t.record_stream(main)
         rgb = torch.stack([o[0] for o in outs])
         acc = torch.stack([o[1] for o in outs])
         depth = torch.stack([o[2] for o in outs])
         return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
+
+    def _subject_streams(self, dev, n):
+        pool = self.__dict__.setdefault("_side_streams", {})
+        have = pool.setdefault(dev, [])
+        while len(have) < n:
+            have.append(torch.cuda.Stream(device=dev))
+        return have[:n]
+
+    def _train_one_subject(self, b, side, tri_planes, bounds, z_vals, rays_o, rays_d, near, far, u, noise, flags, mlp, rc, tp_canonical):
+        from .train import RenderRaysFunction
+        dev = tri_planes.device
+        R = rays_o.shape[1]
+
+        def f32(t):
+            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if side is not None:
+                t.record_stream(side)
+            return t
+        dfm = None
+        if tp_canonical is not None:      # per-subject deformation tables (NeRF/deform.py); `bounds` is t_world_bounds here
+            from .deform import deform_tables
+            if self.SMPL_NEUTRAL is None:
+                raise RuntimeError("use_canonical_space=True needs the body model: set renderer.SMPL_NEUTRAL to the SMPL_to_tensor dict")
+            one = lambda d: {k: v[b:b + 1] for k, v in d.items()}  # noqa: E731
+            dfm = deform_tables(self.SMPL_NEUTRAL, one(tp_canonical['params']), one(tp_canonical['t_params']),
+                                tp_canonical['vertices'][b:b + 1].to(dev))
+        parts = []
+        for i in range(0, R, rc):
+            sl = slice(i, min(R, i + rc))
+            geo = {"deform": dfm, "rays_o": f32(rays_o[b, sl]), "rays_d": f32(rays_d[b, sl]), "near": f32(near[b, sl]), "far": f32(far[b, sl]),
+                   "bounds": f32(bounds[b]), "z": f32(z_vals[b, sl]), "u": f32(u[b, sl]), "noise": f32(noise[b, sl]), "flags": flags}
+            parts.append(RenderRaysFunction.apply(self, geo, tri_planes[b], *mlp))
+        return parts[0] if len(parts) == 1 else tuple(torch.cat([q[k] for q in parts]) for k in range(3))
 
     # ---- rendering through the canonical-space deformation -------------------------
     def _render_canonical(self, tp_input, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd, n_samples, u):

@@ -41,7 +41,7 @@ if canonical:
     pick = torch.nonzero(f2 != 1).flatten()
     pick = pick[torch.randperm(pick.numel())[:R]]
     ro, rd, nr, fr = (t[pick].to(dev) for t in (o2, d2, n2, f2))
-ids, layer = torch.tensor([0, 1]), torch.tensor([1, 3])
+ids, layer = torch.tensor([0, 1], device=dev), torch.tensor([1, 3], device=dev)   # device index tensors, like the reference's to_cuda batch
 t = torch.linspace(0., 1., steps=N, device=dev)
 ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
 tf = tb = to = 0.0

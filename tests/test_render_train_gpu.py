@@ -144,6 +144,50 @@ def test_fitting_loop_two_subjects(dev, fused):
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.5 * np.mean(losses[:5]), losses
 
 
+def test_subject_streams_change_nothing(dev):
+    """Training mode puts subjects after the first on their own HIP streams (forward and, through autograd's stream rule, backward):
+    three subjects with the switch on and off must give the same images and the same gradients (the weight gradient sums float atomics:
+    relative 1e-5, the rest bit for bit), repeated so that the allocator reuses blocks across streams."""
+    from humanliff_amd import synthetic as syn
+    torch.manual_seed(3)
+    r = make_renderer(syn.render_mlp_state(3), dev)
+    tri = torch.nn.Parameter((0.1 * torch.randn((3, 4, 3, 9, 32, 32))).to(dev))
+    ro, rd, nr, fr = syn.orbit_rays(2, 8, 32, 32)
+    pick = torch.nonzero(fr != 1).flatten()[:256]
+    ro, rd, nr, fr = (t[pick].to(dev) for t in (ro, rd, nr, fr))
+    bs, R, N = 3, 256, 16
+    tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].expand(bs, 2, 3).to(dev)}
+    ids, layer = torch.tensor([0, 2, 1], device=dev), torch.tensor([1, 3, 0], device=dev)
+    t = torch.linspace(0., 1., steps=N, device=dev)
+    z = (nr[:, None] * (1. - t) + fr[:, None] * t)[None].expand(bs, R, N).contiguous()
+    g = torch.Generator().manual_seed(9)
+    u = torch.rand((bs * R, N), generator=g).to(dev)
+    noise = torch.randn((bs * R * 2 * N, 1), generator=g).to(dev)
+    target = torch.rand((bs, R, 3), generator=g).to(dev)
+
+    def run(on):
+        r.subject_streams = on
+        res = []
+        for _ in range(4):
+            r.zero_grad()
+            tri.grad = None
+            out = r.render(tp, None, z, ro[None].expand(bs, R, 3), rd[None].expand(bs, R, 3), nr[None, :, None].expand(bs, R, 1),
+                           fr[None, :, None].expand(bs, R, 1), tri[ids, layer], N, False, u=u, noise=noise)
+            loss = ((out["rgb_map"] - target) ** 2).mean() + 0.1 * ((out["acc_map"] - 1.0) ** 2).mean()
+            loss.backward()
+            res.append((out["rgb_map"].detach().clone(), out["acc_map"].detach().clone(), tri.grad.clone(),
+                        [p.grad.clone() for p in r.parameters()]))
+        torch.cuda.synchronize()
+        return res
+    ref = run(False)[0]
+    for got in run(True):
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        assert (got[2] - ref[2]).abs().max() <= 1e-5 * ref[2].abs().max()
+        for a, b in zip(got[3], ref[3]):
+            assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-12
+    r.subject_streams = True
+
+
 def test_recon_twin_training_step(dev):
     """recon_NeRF/run_nerf_batch.py:236-265 through the mirrors of its own names: Renderer with the tri_planes Parameter inside,
     render(chunk, rays_o, ..., tp_input, renderer=DataParallel-like wrapper, perturb=1), TV + L1 regularisers, Adam on two groups."""
