@@ -36,8 +36,10 @@ step(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(iters):
     loss = step()
+t_enq = (time.perf_counter() - t0) / iters        # host time to enqueue a step; equal to the wall time = something blocks the host
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / iters
+print(f"host enqueue {t_enq * 1e3:.1f} ms/step of {dt * 1e3:.1f} ms wall")
 fl = 3 * 2015.4e9 * B          # forward + backward-data + backward-weights, direct-convolution FLOPs
 print(f"UNet training step ({'PyTorch-op twin, MIOpen' if twin else 'HIP kernels, ' + os.environ.get('HL_TRAIN_ARITH', 'fp32')}), batch {B}: {dt * 1e3:.1f} ms/step = {B / dt:.2f} samples/s = {fl / dt / 1e12:.1f} TFLOP/s algorithmic "
       f"(3 x 2015.4 GFLOP per sample); loss {float(loss):.4f}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
