@@ -89,8 +89,23 @@ __device__ __forceinline__ void mfma_tile(f32x16 &c, float a, float b) {
     else if constexpr (T == 15) asm volatile("v_mfma_f32_32x32x2_f32 a[240:255], %0, %1, a[240:255]" ::"v"(a), "v"(b) : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
     else asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ void acc_zero() {   // (the assembler's loop: 256 x v_accvgpr_write_b32)
-    asm volatile(".set hl_w4w_i, 0\n\t.rept 256\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a0", "a255");
+__device__ __forceinline__ void acc_zero() {   // 256 x v_accvgpr_write_b32, one statement per accumulator tile with its sixteen registers declared
+    asm volatile(".set hl_w4w_i, 0\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+    asm volatile(".set hl_w4w_i, 16\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+    asm volatile(".set hl_w4w_i, 32\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    asm volatile(".set hl_w4w_i, 48\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
+    asm volatile(".set hl_w4w_i, 64\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
+    asm volatile(".set hl_w4w_i, 80\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+    asm volatile(".set hl_w4w_i, 96\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
+    asm volatile(".set hl_w4w_i, 112\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+    asm volatile(".set hl_w4w_i, 128\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143");
+    asm volatile(".set hl_w4w_i, 144\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
+    asm volatile(".set hl_w4w_i, 160\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175");
+    asm volatile(".set hl_w4w_i, 176\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
+    asm volatile(".set hl_w4w_i, 192\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207");
+    asm volatile(".set hl_w4w_i, 208\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223");
+    asm volatile(".set hl_w4w_i, 224\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
+    asm volatile(".set hl_w4w_i, 240\n\t.rept 16\n\tv_accvgpr_write_b32 a[hl_w4w_i], 0\n\t.set hl_w4w_i, hl_w4w_i+1\n\t.endr" ::: "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
 }
 template <int T, int R>
 __device__ __forceinline__ float acc_get(const f32x16 (&cv)[2]) {

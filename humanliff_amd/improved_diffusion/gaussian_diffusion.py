@@ -67,9 +67,22 @@ def _bcast(vec, shape):
     return vec.expand(shape)
 
 
+_TABLES = {}      # (table bytes, device) -> the fp64 table on that device
+
+
 def _extract_into_tensor(arr, timesteps, broadcast_shape):
-    """Reference helper (:850-863), kept for callers; sampling uses the cached device tables instead."""
-    return _bcast(th.from_numpy(arr).to(device=timesteps.device)[timesteps].float(), broadcast_shape)
+    """Reference helper (:850-863): arr[timesteps] as float32, broadcast.  The reference uploads the fp64 table on every call; a
+    synchronous copy of pageable memory drains the stream, which cost the training step its run-ahead (8 uploads per step).  The
+    tables are constants of the schedule, so they are uploaded once per (content, device) - keyed by content because callers pass
+    temporaries (1.0 - alphas_cumprod) whose addresses get reused - and indexed on the device: same fp64 values, same cast."""
+    arr = np.ascontiguousarray(arr)
+    key = (arr.dtype.str, arr.tobytes(), str(timesteps.device))
+    tab = _TABLES.get(key)
+    if tab is None:
+        if len(_TABLES) >= 256:
+            _TABLES.clear()
+        tab = _TABLES[key] = th.from_numpy(arr.copy()).to(device=timesteps.device)
+    return _bcast(tab[timesteps].float(), broadcast_shape)
 
 
 class GaussianDiffusion:
