@@ -795,7 +795,7 @@ def bench_render(args, rank, world, dev):
     return secs, roof, views * R
 
 
-def bench_fit(args, rank, world, dev, iters=10):
+def bench_fit(args, rank, world, dev, iters=30):
     """one tri-plane fitting iteration at the reference's training configuration
     (recon_NeRF/configs/SynBody.txt: 2 subjects x n_rand 2048 rays x 128+128 stratified samples, density noise, MSE on rgb + 0.1 MSE on
     acc, Adam on MLP and tri-planes; run_nerf_batch.py:236-265).  Every rank fits its own subjects (no exchange)."""
@@ -846,14 +846,18 @@ def bench_fit(args, rank, world, dev, iters=10):
     secs = timed()                       # reference-faithful: sample_pdf's uniforms drawn on the CPU generator and uploaded
     r.uniforms_on_device = True          # extension: drawn on the device
     secs_dev = timed()
-    r.uniforms_on_device = False
+    r.subject_streams = True             # extension: the second subject on its own HIP stream, forward and backward
+    secs_dev_streams = timed()
+    r.uniforms_on_device = r.subject_streams = False
     pts = bs * R * 2 * N
     stages = fit_stage_times(r, tri[0, 0].detach(), tp["world_bounds"][0].contiguous(), ro, rd, nr, fr, N, dev)
     return {"stages_ms_per_subject": stages["ms"], "roofline": stages["roofline"], "metric": "fitting-iterations/sec", "value": round(world * iters / secs, 2), "unit": "it/s", "ms_per_iteration": round(secs * 1e3 / iters, 3),
             "sample_points_per_sec": round(world * iters * pts / secs), "iterations": iters,
             "uniforms_on_device": {"value": round(world * iters / secs_dev, 2), "unit": "it/s", "ms_per_iteration": round(secs_dev * 1e3 / iters, 3),
                                    "what": "Renderer.uniforms_on_device = True: sample_pdf's uniforms from the device generator instead of "
-                                           "CPU draw + 2 MB upload per step (same distribution; NOT used for `value`)"},
+                                           "CPU draw + 2 MB upload per step (same distribution; NOT used for `value`)",
+                                   "with_subject_streams": {"value": round(world * iters / secs_dev_streams, 2), "unit": "it/s",
+                                                            "what": "+ Renderer.subject_streams = True (NOT used for `value`)"}},
             "config": {"workload": "recon_NeRF SynBody training step: 2 subjects x 2048 rays x (128+128) samples, 256x256x27 tri-planes, "
                                    "forward + HIP backward + Adam", "sample_points_per_iteration": pts}}
 

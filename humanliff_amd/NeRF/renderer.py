@@ -66,7 +66,9 @@ class Renderer(nn.Module):
         # (recon_NeRF/lib/renderer.py:288) does not clamp and clears the second flag
         self._depth_flags = _lib.HL_RENDER_NORMALIZE_DEPTH | _lib.HL_RENDER_CLAMP_DEPTH
         self.uniforms_on_device = False      # extension: draw sample_pdf's uniforms with the device generator (see render())
-        self.subject_streams = True          # training mode: subjects after the first on their own HIP streams (see _render_training)
+        self.subject_streams = False         # extension, opt-in: training mode puts subjects after the first on their own HIP streams (see
+                                             # _render_training; +4 % on the fitting step with device uniforms, and PyTorch warns once that the
+                                             # parameters' AccumulateGrad nodes sit on another stream than the gradients)
         self.mlp_fp16 = False                # extension, opt-in: the MLP with fp16 operands / fp32 accumulation (HL_RENDER_MLP_FP16, k_march16) in
                                              # render() without canonical space; canonical-space rendering, density_grid() and training stay fp32
         self.mlp_products = "bf16x3"         # how render() forms the fp32 products of the MLP in the evaluate-once pipeline (test mode, world space):

@@ -145,8 +145,8 @@ def test_fitting_loop_two_subjects(dev, fused):
 
 
 def test_subject_streams_change_nothing(dev):
-    """Training mode puts subjects after the first on their own HIP streams (forward and, through autograd's stream rule, backward):
-    three subjects with the switch on and off must give the same images and the same gradients (the weight gradient sums float atomics:
+    """Renderer.subject_streams (opt-in) puts subjects after the first on their own HIP streams (forward and, through autograd's stream
+    rule, backward): three subjects with the switch on and off must give the same images and the same gradients (the weight gradient sums float atomics:
     relative 1e-5, the rest bit for bit), repeated so that the allocator reuses blocks across streams."""
     from humanliff_amd import synthetic as syn
     torch.manual_seed(3)
@@ -185,7 +185,7 @@ def test_subject_streams_change_nothing(dev):
         assert (got[2] - ref[2]).abs().max() <= 1e-5 * ref[2].abs().max()
         for a, b in zip(got[3], ref[3]):
             assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-12
-    r.subject_streams = True
+    r.subject_streams = False
 
 
 def test_recon_twin_training_step(dev):
