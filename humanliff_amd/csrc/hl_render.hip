@@ -2942,9 +2942,12 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter_pts(const ScatterP
 // the two matrices, contiguous along the reduction.  A workgroup takes one layer and a range of points; per 32 points it stages the
 // layer's delta rows (<= 128) and activation rows (<= 155) through LDS with full-line loads (8 lanes x 16 B per row), then wave w
 // multiplies delta rows 32w..32w+31 against all activation rows: a lane reads 16 points of "its" row per operand tile (lanes 0-31:
-// points 0-15, lanes 32-63: points 16-31; row pitch 36 floats keeps the 16-byte reads conflict-free) and feeds 16 k-steps of
-// v_mfma_f32_32x32x2_f32, pairing point j with point 16+j.  The row sums of delta (the bias gradients) fall out of the A operand on
-// the VALU.  Partial results of the point ranges are added to the gradient tensors with float atomics.
+// points 0-15, lanes 32-63: points 16-31; row pitch 36 floats keeps the 16-byte reads conflict-free) = two 8-wide k-groups of
+// v_mfma_f32_32x32x16_bf16.  The fp32 products come from exact three-way bf16 splits of both operands (truncation: v_and / v_perm /
+// v_sub), six partial products per k-group, fp32 accumulation - 12 MFMAs of 32 cycles where v_mfma_f32_32x32x2_f32 needs 16 of 64
+// (round 4: 0.91 -> 0.68 ms per subject, 3.1 -> 4.2 TB/s; the fp32 MFMAs, not HBM, were what the kernel waited for).  The row sums of
+// delta (the bias gradients) fall out of the A operand on the VALU.  Partial results of the point ranges are added to the gradient
+// tensors with float atomics.
 struct WgradJob {
     int a_row0, M, b_row0, N;   // rows of the A / B operand; C[i][n] goes to out[i * ld_i + n * ld_n]
     int a_is_act;               // 0: A rows from the delta matrix, B rows from the activation matrix; 1: the other way round (the two
@@ -2959,6 +2962,19 @@ struct WgradArgs {
     long long del_stride, act_stride, n_cols;
     int k_per_wg;                          // points per workgroup (multiple of 32)
 };
+
+// eight consecutive points of a row -> the three bf16 planes of one v_mfma_f32_32x32x16_bf16 operand (exact split by truncation)
+__device__ __forceinline__ void wg_split8(const f32x4 &lo, const f32x4 &hi4, u32x4 (&pl)[3]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x = q < 2 ? lo[2 * q] : hi4[2 * q - 4], y = q < 2 ? lo[2 * q + 1] : hi4[2 * q - 3];
+        pl[0][q] = b3_pack(x, y);
+        x -= __builtin_bit_cast(float, b3_hi(x)); y -= __builtin_bit_cast(float, b3_hi(y));
+        pl[1][q] = b3_pack(x, y);
+        x -= __builtin_bit_cast(float, b3_hi(x)); y -= __builtin_bit_cast(float, b3_hi(y));
+        pl[2][q] = b3_pack(x, y);
+    }
+}
 
 __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 #if __HIP_DEVICE_COMPILE__
@@ -3013,16 +3029,28 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
             f32x4 av[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) av[q] = ldsv[(32 * wave + row) * (WG_PITCH / 4) + 4 * half + q];
+            {
+                // fp32 products from exact three-way bf16 splits of both operands (six partial products, smallest first, fp32 accumulation):
+                // a lane's 16 points are two 8-wide k-groups of v_mfma_f32_32x32x16_bf16; 12 MFMAs of 32 cycles replace 16 of 64
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+                u32x4 ap[2][3];
+                wg_split8(av[0], av[1], ap[0]);
+                wg_split8(av[2], av[3], ap[1]);
 #pragma unroll
-            for (int t = 0; t < WGRAD_MAX_NB; ++t) {
-                if (t < NB) {
-                    f32x4 bv[4];
+                for (int t = 0; t < WGRAD_MAX_NB; ++t) {
+                    if (t < NB) {
+                        f32x4 bv[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bv[q] = ldsv[(WG_AROWS + 32 * t + row) * (WG_PITCH / 4) + 4 * half + q];
+                        for (int q = 0; q < 4; ++q) bv[q] = ldsv[(WG_AROWS + 32 * t + row) * (WG_PITCH / 4) + 4 * half + q];
+                        u32x4 bp[2][3];
+                        wg_split8(bv[0], bv[1], bp[0]);
+                        wg_split8(bv[2], bv[3], bp[1]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                        for (int i = 0; i < 6; ++i)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][k], bv[q][k], acc[t], 0, 0, 0);
+                            for (int b = 0; b < 2; ++b)
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[b][PA[i]]), __builtin_bit_cast(bf16x8, bp[b][PB[i]]), acc[t], 0, 0, 0);
+                    }
                 }
             }
             if (!jb.a_is_act) {

@@ -162,7 +162,8 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
  *   hl_render_mlp_pack_bwd        transposed weights for hl_render_mlp_backward (redo after every optimizer step, like
  *                                 hl_render_mlp_pack)
  *   hl_render_weight_grads        all 14 parameter gradients from the two matrices over n_cols sample points (multiple of 32), ADDED
- *                                 to the tensors of `grads` (PyTorch layouts, zero them first) with float atomics */
+ *                                 to the tensors of `grads` (PyTorch layouts, zero them first) with float atomics; fp32 products
+ *                                 from exact three-way bf16 splits of both operands, fp32 accumulation (k_wgrad) */
 /* Canonical-space training (use_canonical_space=True with test=False; README.md:123 TightCap fitting): the deformation has no
  * parameters and the points get no gradient, so the backward is the one above with two substitutions -
  *   hl_render_eval_points_acts     hl_render_eval_points that also writes the activation matrix (forward, per pass)
