@@ -1556,6 +1556,22 @@ __global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
     const int tot_n = N + Ni;
     int P = 1;
     while (P < tot_n) P <<= 1;
+    // The densities of this wave's (up to) 8 rays at one sample share a 128-byte line of the tile-major records.  Walking the rays one after
+    // the other fetched every line 8 times from HBM (24 waves per CU x 16 KB of lines do not survive in L1 / L2: 4.5 GB read per 512x512
+    // view for 0.54 GB of lines): for N <= 128 a lane now fetches "its" samples of all the wave's rays up front - eight dword loads from one
+    // line - and the per-ray loop takes them from registers (sg[0], shifted down after every ray).
+    constexpr int PRE_B = 2;
+    const bool pre = N <= 64 * PRE_B;
+    float sg[8][PRE_B];
+    if (pre) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int b = 0; b < PRE_B; ++b) {
+                const int i = 64 * b + lane, j = wv * 8 + part * a.rays_per_wave + rr;
+                sg[rr][b] = (rr < a.rays_per_wave && i < N) ? a.sigma[((tile * 32 * (long long)N + j) + 32LL * i) * a.sig_stride] : 0.f;
+            }
+    }
     for (int rr = 0; rr < a.rays_per_wave; ++rr) {
         const int j = wv * 8 + part * a.rays_per_wave + rr;
         const long long ray_raw = tile * 32 + j;
@@ -1580,7 +1596,8 @@ __global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
                 zi = zval(i);
                 float dist = (i + 1 < N) ? zval(i + 1) - zi : 1e10f;
                 dist = dist * dn;
-                alpha = 1.f - expf(-softplus_exact(sig[32LL * i * a.sig_stride]) * dist);
+                const float sraw = pre ? (base == 0 ? sg[0][0] : sg[0][1]) : sig[32LL * i * a.sig_stride];
+                alpha = 1.f - expf(-softplus_exact(sraw) * dist);
                 s_z[i] = zi;
             }
             const float fct = (i < N) ? (1.f - alpha + 1e-10f) : 1.f;
@@ -1653,6 +1670,10 @@ __global__ __launch_bounds__(256) void k_importance(const ImpArgs a) {
             for (int i = lane; i < tot_n; i += 64) zout[32LL * i] = s_z[i];
         }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int b = 0; b < PRE_B; ++b) sg[k][b] = sg[k + 1][b];
     }
 }
 
@@ -3299,7 +3320,12 @@ int hl_render_composite_noise(const float *near, const float *far, const float *
         hipLaunchKernelGGL(k_composite_wave<false>, dim3((unsigned)(tiles32(n_rays) * 8)), dim3(256), 0, (hipStream_t)stream, b);
         return hl::check_launch("k_composite_wave<fwd>");
     }
-    hipLaunchKernelGGL(k_composite, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c);
+    // 80 KB of unused dynamic LDS per workgroup = two workgroups (eight waves) per CU: the merge walk of a wave keeps ~12 KB of record lines
+    // open, and with 16+ waves per CU the lines are evicted before the neighbouring rays have used them (rocprofv3, 512x512 view: 976 us
+    // unlimited, 954 us at four workgroups, 780 us at two, 1 150 us at one)
+    constexpr int COMP_OCC_LDS = 80000;
+    static const bool occ_ok = hipFuncSetAttribute((const void *)k_composite, hipFuncAttributeMaxDynamicSharedMemorySize, COMP_OCC_LDS) == hipSuccess;
+    hipLaunchKernelGGL(k_composite, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), occ_ok ? COMP_OCC_LDS : 0, (hipStream_t)stream, c);
     return hl::check_launch("k_composite");
 }
 
