@@ -2,6 +2,7 @@
 
 There is no fallback: if the HIP library is missing or a call fails, this raises.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -163,11 +164,26 @@ def ptr(t, dtype=None):
 
 
 def stream_ptr(device=None):
-    """hipStream_t of torch's current stream on `device` (default: the current device)."""
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """hipStream_t of torch's current stream on `device` (default: the current device).  Through the raw-stream query (what torch's own
+    generated launch code uses: ~0.3 us) rather than torch.cuda.current_stream(), whose Stream object costs ~9 us a call - 5 ms of the
+    ~70 ms of Python a UNet training step spends enqueueing its ~1 300 launches."""
+    if device is None:
+        idx = torch.cuda.current_device()
+    else:
+        idx = torch.device(device).index if not isinstance(device, int) else device
+        if idx is None:
+            idx = torch.cuda.current_device()
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+
+
+_SAME_DEVICE = contextlib.nullcontext()
 
 
 def on(device):
     """Context that makes `device` the current HIP device for the launches inside it: the library launches on the caller's stream,
-    and a stream can only be used from its own device."""
-    return torch.cuda.device(device)
+    and a stream can only be used from its own device.  Nothing to do - and no torch.cuda.device object to build, ~10 us a use - when it
+    is the current device already, the case of every launch of a one-process-per-GPU job."""
+    idx = device if isinstance(device, int) else torch.device(device).index
+    if idx is None or idx == torch.cuda.current_device():
+        return _SAME_DEVICE
+    return torch.cuda.device(idx)
