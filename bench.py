@@ -640,6 +640,28 @@ def bench_train(model, diffusion, dev, rank, world, iters=3, B=2):
         finally:
             ut.set_train_arithmetic(None)
     assert torch.isfinite(loss16.detach()).all()
+    # extension: the whole step (loss -> backward -> optimizer) as ONE HIP graph, replayed (unet_train.GraphedTrainStep): no Python per launch
+    graphed = {}
+    del loss, loss16          # a live loss keeps the parameters' AccumulateGrad nodes bound to the stream of its step; capture runs on another one
+    import gc
+    gc.collect()
+    for kind in ("fp32", "bf16"):
+        ut.set_train_arithmetic(kind)
+        try:
+            gopt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.0, fused=True, capturable=True)
+            tg = torch.randint(0, 1000, (B,), device=dev, generator=g)
+            gstep = ut.GraphedTrainStep(diffusion, model, gopt, x0, xc, tg, {"y": y}, warmup=2)
+            gstep(x0, xc, tg, {"y": y})
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(iters):
+                lg = gstep(x0, xc, torch.randint(0, 1000, (B,), device=dev, generator=g), {"y": y})
+            torch.cuda.synchronize()
+            graphed[kind] = {"ms_per_step": round((time.perf_counter() - tb) / iters * 1e3, 2)}
+            assert torch.isfinite(lg).all()
+            del gstep, gopt
+        finally:
+            ut.set_train_arithmetic(None)
     model.train(was_training)
     del opt
     for p in model.parameters():
@@ -651,6 +673,8 @@ def bench_train(model, diffusion, dev, rank, world, iters=3, B=2):
                                 "what": "unet_train.set_train_arithmetic('fp16' / 'bf16'), chosen automatically under torch.autocast (train_util.py:214): 16-bit "
                                         "operands / fp32 accumulation on v_mfma_f32_32x32x16 for forward, backward-data (k_conv_h16) and the weight gradients "
                                         "(k_conv_wgrad_h16) of the 3x3 / stride-1 layers; fp32 tensors and master weights; `value` above is the fp32 arithmetic"},
+            "hip_graph_step": {"fp32_ms_per_step": graphed["fp32"]["ms_per_step"], "bf16_ms_per_step": graphed["bf16"]["ms_per_step"],
+                               "what": "unet_train.GraphedTrainStep: loss + backward + capturable fused AdamW captured once, replayed (extension; NOT used for `value`)"},
             "algorithmic_tflops": round(world * 3 * UNET_GFLOP_PER_SAMPLE_STEP * B / dt / 1e3, 2),
             "config": {"workload": "production F4 UNet, training_losses (MSE) + backward on the HIP kernels + AdamW (torch, fused=True), microbatch 2 (README.md:104)",
                        "flop_count": "3 x 2015.4 GFLOP per sample (forward, backward-data, backward-weights; direct-convolution FLOPs)"}}

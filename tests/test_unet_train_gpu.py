@@ -669,3 +669,78 @@ def test_conv_h16_split_k_on_small_layers(f16):
         err = float((outs[0].cpu().double() - ref).abs().max())
         rel = float((outs[0].cpu().double() - ref).norm() / ref.norm())
         assert err < 5e-5 and rel < 2e-6, (N, H, W, C, Co, err, rel)      # (the fp32 kernels would sit at the operand rounding: rel 2e-4 / 2e-3)
+
+
+def test_graphed_train_step_equals_eager_steps():
+    """GraphedTrainStep (the whole step as one HIP graph) against the same steps issued from Python: same batches, timesteps and noise, a
+    capturable fused AdamW on both sides - the kernels sum in a fixed order, so parameters and losses agree bit for bit; construction leaves
+    parameters and optimizer state untouched, and a sampling call afterwards sees the updated weights."""
+    from tests.test_train_loss_cpu import inputs, tiny_model
+    from humanliff_amd.improved_diffusion.unet_train import GraphedTrainStep
+    x0, xc = (t.to(dev) for t in inputs())
+    x0 = x0.clamp(-1, 1)
+    gen = torch.Generator().manual_seed(11)
+    batches = [((x0 + 0.1 * torch.randn(x0.shape, generator=gen).to(dev)).clamp(-1, 1), torch.randint(0, 1000, (2,), generator=gen).to(dev),
+                torch.randn(x0.shape, generator=gen).to(dev), torch.randint(0, 4, (2,), generator=gen).to(dev)) for _ in range(4)]
+
+    def fresh():
+        torch.manual_seed(0)
+        model, diffusion = tiny_model()
+        model = model.to(dev).train()
+        return model, diffusion, torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0, fused=True, capturable=True)
+
+    m1, d1, o1 = fresh()
+    eager = []
+    for x, t, n, y in batches:
+        o1.zero_grad(set_to_none=True)
+        loss = d1.training_losses(m1, x, xc, t, model_kwargs={"y": y}, noise=n)["loss"].mean()
+        loss.backward()
+        o1.step()
+        eager.append(float(loss.detach()))
+    m2, d2, o2 = fresh()
+    before = [p.detach().clone() for p in m2.parameters()]
+    step = GraphedTrainStep(d2, m2, o2, batches[0][0], xc, batches[0][1], {"y": batches[0][3]}, with_noise=True)
+    assert all(torch.equal(a, b) for a, b in zip(before, m2.parameters())), "construction must leave the parameters as they were"
+    graphed = [float(step(x, xc, t, {"y": y}, noise=n)) for x, t, n, y in batches]
+    assert graphed == eager, (graphed, eager)
+    bad = [k for (k, a), b in zip(m1.named_parameters(), m2.parameters()) if not torch.equal(a, b)]
+    assert not bad, bad
+    m1.eval(), m2.eval()
+    with torch.no_grad():
+        t, y = batches[0][1], batches[0][3]
+        assert torch.equal(m1(x0, t, xc, y=y), m2(x0, t, xc, y=y))       # the packed inference weights were re-laid after the replayed steps
+
+
+def test_graphed_train_step_takes_over_from_eager_steps():
+    """Capture in the middle of a run: one eager step (its loss dropped - a live loss pins the AccumulateGrad nodes to its stream), then the
+    graph for the remaining batches; the optimizer's running state must survive construction (warm-up iterations are rolled back) and the
+    result equal the all-eager run."""
+    from tests.test_train_loss_cpu import inputs, tiny_model
+    from humanliff_amd.improved_diffusion.unet_train import GraphedTrainStep
+    x0, xc = (t.to(dev) for t in inputs())
+    gen = torch.Generator().manual_seed(12)
+    batches = [((x0 + 0.1 * torch.randn(x0.shape, generator=gen).to(dev)).clamp(-1, 1), torch.randint(0, 1000, (2,), generator=gen).to(dev),
+                torch.randn(x0.shape, generator=gen).to(dev), torch.randint(0, 4, (2,), generator=gen).to(dev)) for _ in range(3)]
+
+    def fresh():
+        torch.manual_seed(0)
+        model, diffusion = tiny_model()
+        model = model.to(dev).train()
+        return model, diffusion, torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0, fused=True, capturable=True)
+
+    def eager(m, d, o, b):
+        x, t, n, y = b
+        o.zero_grad(set_to_none=True)
+        d.training_losses(m, x, xc, t, model_kwargs={"y": y}, noise=n)["loss"].mean().backward()
+        o.step()
+
+    m1, d1, o1 = fresh()
+    for b in batches:
+        eager(m1, d1, o1, b)
+    m2, d2, o2 = fresh()
+    eager(m2, d2, o2, batches[0])
+    step = GraphedTrainStep(d2, m2, o2, batches[1][0], xc, batches[1][1], {"y": batches[1][3]}, with_noise=True)
+    for x, t, n, y in batches[1:]:
+        step(x, xc, t, {"y": y}, noise=n)
+    bad = [k for (k, a), b in zip(m1.named_parameters(), m2.parameters()) if not torch.equal(a, b)]
+    assert not bad, bad
