@@ -175,6 +175,26 @@ def test_production_shape_vs_oracle(dev):
     assert psnr(out["rgb_map"], rgb) > 80.0
 
 
+@pytest.mark.parametrize("products", PRODUCTS)
+def test_sample_counts_beyond_128_match_oracle(products, dev):
+    """192 + 192 samples per ray: more than two samples per lane in k_importance (the densities are then read per ray instead of being
+    fetched up front), three 64-sample groups in the scans and a 256-slot sort - against the oracle on 300 rays."""
+    from oracle import render_oracle as ro
+    from humanliff_amd import synthetic as syn
+    planes = syn.triplane(seed=13, H=64, W=64)
+    mlp = syn.render_mlp_state(3, gain=2.0)
+    ro_, rd_, nr_, fr_ = syn.orbit_rays(3, 36, 64, 64)
+    sl = slice(64 * 20 + 5, 64 * 20 + 5 + 300)
+    N = 192
+    i = dict(planes=planes, bounds=torch.tensor(syn.WORLD_BOUNDS), rays_o=ro_[sl], rays_d=rd_[sl], near=nr_[sl], far=fr_[sl],
+             u=syn.importance_u(300, N, seed=6), mlp=mlp, n_samples=N, n_importance=N, white_bkgd=True)
+    _, out = hip_render(i, dev, products=products)
+    rgb, acc, depth = ro.render_rays(mlp, planes[0], i["bounds"], i["rays_o"], i["rays_d"], i["near"], i["far"], N, N, u=i["u"], white_bkgd=True)
+    assert (out["rgb_map"] - rgb).abs().max() < 5e-5
+    assert (out["acc_map"] - acc).abs().max() < 5e-5
+    assert (out["depth_map"] - depth).abs().max() < 2e-4
+
+
 def test_bad_arguments_raise(dev):
     from humanliff_amd.NeRF import Renderer
     i, _ = load_render_case("a")
