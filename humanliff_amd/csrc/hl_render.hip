@@ -1250,6 +1250,14 @@ __device__ __forceinline__ void split_b3t(const f32x16 &v, int hi, u32x4 (&pl)[3
         pl[2][q] = b3_pack(x, y);
     }
 }
+template <int I0, int I1>
+__device__ __forceinline__ void softplus_b3_r(f32x16 &v) {   // registers I0 .. I1-1 of softplus16_b3, in place
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(v[i]));
+        v[i] = fmaf(0.693147180559945309f, __builtin_amdgcn_logf(1.f + e), b3_max0(v[i]));
+    }
+}
 __device__ __forceinline__ f32x16 softplus16_b3(f32x16 v) {   // softplus_hidden with max(x, 0) as v_max_i32 (no canonicalising v_max in front)
     f32x16 o;
 #pragma unroll
@@ -1378,6 +1386,15 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
 #define B3_VM(V_, M_)                                                                      \
     if constexpr (ROT) { M_; __builtin_amdgcn_sched_barrier(0); V_; __builtin_amdgcn_sched_barrier(0); } \
     else { V_; __builtin_amdgcn_sched_barrier(0); M_; __builtin_amdgcn_sched_barrier(0); }
+    // B3_MV24, the chunks of the hidden layers: ONE scheduling region with the chunk's 24 MFMAs and the preparation of the next operand - softplus of
+    // one HALF of a tile + its exact three-way split, ~100 VALU instructions - asked of the scheduler as [1 MFMA, K_ VALU] x 24 (sched_group_barrier):
+    // the preparation rides in the shadow of the matrix pipe instead of standing as a block beside the chunk.  The softplus of a tile is spread
+    // over both of its chunks (4.2 VALU per MFMA each; the whole tile in every second chunk, 6.5 against 1.8, gains half as much).
+    // Same-box A/B, ms per 512x512 view: blocks 43.5 - 44.0, whole-tile softplus 42.4, this 41.7 - 42.0 (profiles/r04_render_b3_ablations.md).
+#define B3_MV24(K_, M_, ...)                                                               \
+    { __VA_ARGS__; M_;                                                                     \
+      _Pragma("unroll") for (int g_ = 0; g_ < 24; ++g_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, K_, 0); } \
+      __builtin_amdgcn_sched_barrier(0); }
 
     auto body = [&](auto rotc) {
     constexpr bool ROT = decltype(rotc)::value;
@@ -1440,38 +1457,35 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
         mma_b3<4>(X, bf0, B3_AT(0), 0, lane);                                       // L0: chunks 0, 1
         B3_ADV(1) mma_b3<4>(X, bf1, B3_AT(1), 0, lane);
         load_bias<4>(Y, small + SM_B1, half);
-        X[0] = softplus16_b3(X[0]);
+        softplus_b3_r<0, 8>(X[0]);                                                  // (the second half: behind the first chunk of the layer)
         split_b3t(X[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L1: chunks 2..9 = (tile k of X, half 0 | 1)
             B3_ADV(2 + 2 * k)
-            B3_VM(split_b3t(X[k], 1, bb), mma_b3<4>(Y, ba, B3_AT(2 + 2 * k), 0, lane))
+            B3_MV24(5, mma_b3<4>(Y, ba, B3_AT(2 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(X[k]); split_b3t(X[k], 1, bb); })
             B3_ADV(3 + 2 * k)
-            B3_VM(if (k < 3) { X[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); },
-                  mma_b3<4>(Y, bb, B3_AT(3 + 2 * k), 0, lane))
+            B3_MV24(5, mma_b3<4>(Y, bb, B3_AT(3 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         load_bias<4>(X, small + SM_B2, half);
         B3_ADV(10) mma_b3<4>(X, bf0, B3_AT(10), 0, lane);                          // L2 (features): chunks 10, 11; the first hidden operand rides along
         B3_ADV(11)
-        B3_VM({ Y[0] = softplus16_b3(Y[0]); split_b3t(Y[0], 0, ba); }, mma_b3<4>(X, bf1, B3_AT(11), 0, lane))
+        B3_VM({ (softplus_b3_r<0, 8>(Y[0])); split_b3t(Y[0], 0, ba); }, mma_b3<4>(X, bf1, B3_AT(11), 0, lane))
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L2 (hidden): chunks 12..19
             B3_ADV(12 + 2 * k)
-            B3_VM(split_b3t(Y[k], 1, bb), mma_b3<4>(X, ba, B3_AT(12 + 2 * k), 0, lane))
+            B3_MV24(5, mma_b3<4>(X, ba, B3_AT(12 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(Y[k]); split_b3t(Y[k], 1, bb); })
             B3_ADV(13 + 2 * k)
-            B3_VM(if (k < 3) { Y[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(Y[k + 1 < 4 ? k + 1 : 3]); split_b3t(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); },
-                  mma_b3<4>(X, bb, B3_AT(13 + 2 * k), 0, lane))
+            B3_MV24(5, mma_b3<4>(X, bb, B3_AT(13 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(Y[k + 1 < 4 ? k + 1 : 3]); split_b3t(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         load_bias<4>(Y, small + SM_BF, half);
-        X[0] = softplus16_b3(X[0]);
+        softplus_b3_r<0, 8>(X[0]);                                                  // (the second half: behind the first chunk of the layer)
         split_b3t(X[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // feature_linear: chunks 20..27
             B3_ADV(20 + 2 * k)
-            B3_VM(split_b3t(X[k], 1, bb), mma_b3<4>(Y, ba, B3_AT(20 + 2 * k), 0, lane))
+            B3_MV24(5, mma_b3<4>(Y, ba, B3_AT(20 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(X[k]); split_b3t(X[k], 1, bb); })
             B3_ADV(21 + 2 * k)
-            B3_VM(if (k < 3) { X[k + 1 < 4 ? k + 1 : 3] = softplus16_b3(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); },
-                  mma_b3<4>(Y, bb, B3_AT(21 + 2 * k), 0, lane))
+            B3_MV24(5, mma_b3<4>(Y, bb, B3_AT(21 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];   // X holds softplus(pts_linears.2) by now
         f32x16 V[2];
@@ -1506,6 +1520,7 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
     if ((tid >> 6) < 4) body(std::false_type{});
     else body(std::true_type{});
 #undef B3_VM
+#undef B3_MV24
 #undef B3_ADV
 #undef B3_AT
 }
