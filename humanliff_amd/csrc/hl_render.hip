@@ -1276,9 +1276,9 @@ __device__ __forceinline__ void mma_b3(f32x16 (&acc)[NT], const u32x4 (&b)[3], c
     for (int t0 = 0; t0 < NT; t0 += 2) {
         u32x4 w[2][3];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int p = 2; p >= 0; --p)                           // in the order of first use (plane 2 of both tiles, plane 1, plane 0): the first MFMAs wait for two reads, not six
 #pragma unroll
-            for (int p = 0; p < 3; ++p) w[t][p] = ch[((q0 + t0 + t) * 3 + p) * 64 + lane];
+            for (int t = 0; t < 2; ++t) w[t][p] = ch[((q0 + t0 + t) * 3 + p) * 64 + lane];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
