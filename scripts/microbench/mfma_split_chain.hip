@@ -31,8 +31,13 @@ __device__ __forceinline__ void prep(const f32x16 &src, u32x4 (&pl)[3], Tmp &t) 
 template <int N, class F, int... I> __device__ __forceinline__ void seq_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void seq(F &&f) { seq_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
+// MODE 5 / 6: as MODE 3, and the A operands are weight fragments read from LDS the way k_march_b3w reads them: six ds_read_b128 (two tiles x three planes) in
+// front of every 12 MFMAs (MODE 5), or the same reads issued one group EARLY (MODE 6: the reads of group g + 1 behind the first MFMAs of group g, 24 more registers)
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void k(const float *src, int iters, float *sink) {
+    __shared__ __attribute__((aligned(16))) u32x4 frag[3072];     // 48 KB: two chunk pairs of fragments
+    for (int i = threadIdx.x; i < 3072; i += 512) frag[i] = u32x4{0x3f803f80u, (unsigned)i, 0, 0x3f80u};
+    __syncthreads();
     f32x16 A[4], B[4], Cst[4];
     const float a0 = src[threadIdx.x];
     for (int t = 0; t < 4; ++t)
@@ -42,7 +47,42 @@ __global__ __launch_bounds__(512, 2) void k(const float *src, int iters, float *
     for (int p = 0; p < 3; ++p) { pa[p] = w; pb[p] = w; }
     Tmp tm{};
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    const int lane = threadIdx.x & 63;
+    u32x4 wf[2][3], wn[2][3];
+    int gcount = 0;
+    auto rd = [&](u32x4 (&d)[2][3], int g) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) d[t][p] = frag[((g & 7) * 6 + t * 3 + p) * 64 + lane];
+    };
+    if constexpr (MODE == 6) rd(wn, 0);
     auto layer = [&](f32x16 (&IN)[4], f32x16 (&OUT)[4]) {
+        if constexpr (MODE >= 5) {
+            constexpr int PW[6] = {2, 1, 0, 1, 0, 0};
+            seq<4>([&](auto gc) {                                   // four groups of 12 MFMAs (two tiles x six products)
+                constexpr int g = decltype(gc)::value, c = g >> 1;
+                u32x4 (&use)[3] = (c == 0) ? pa : pb;
+                u32x4 (&mk)[3] = (c == 0) ? pb : pa;
+                if constexpr (MODE == 5) rd(wf, gcount + g);
+                else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) wf[t][p] = wn[t][p];
+                }
+                seq<12>([&](auto ic) {
+                    constexpr int idx = decltype(ic)::value, t = idx & 1, i = idx >> 1;
+                    OUT[2 * (g & 1) + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[t][PW[i]]), __builtin_bit_cast(bf16x8, use[PB[i]]), OUT[2 * (g & 1) + t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (MODE == 6 && idx == 1) rd(wn, gcount + g + 1);
+                    prep<1, c, ((g & 1) * 12 + idx) / 6, ((g & 1) * 12 + idx) % 6>(IN[c], mk, tm);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            gcount += 4;
+            return;
+        }
         // 48 MFMAs = two "chunks" of 24 (4 tiles x 6 products); behind chunk c the operand of the other kind is prepared from IN[c]
         seq<2>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
@@ -60,9 +100,15 @@ __global__ __launch_bounds__(512, 2) void k(const float *src, int iters, float *
             });
         });
     };
-    for (int it = 0; it < iters; ++it) {
-        layer(A, B);
-        layer(B, A);
+#ifndef UNROLL_PAIRS
+#define UNROLL_PAIRS 1      // layer pairs (192 MFMAs + their preparation, ~1 100 instructions = ~8 KB of code) per loop iteration: the code size knob
+#endif
+    for (int it = 0; it < iters; it += UNROLL_PAIRS) {
+#pragma unroll
+        for (int u = 0; u < UNROLL_PAIRS; ++u) {
+            layer(A, B);
+            layer(B, A);
+        }
     }
     float o = 0.f;
     for (int t = 0; t < 4; ++t) o += A[t][0] + B[t][3] + Cst[t][1];
@@ -72,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void k(const float *src, int iters, float *
 
 template <int MODE>
 static void run(const char *what, const float *src, float *sink) {
-    const int iters = 1000, blocks = 256;
+    const int iters = 960, blocks = 256;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     k<MODE><<<blocks, 512>>>(src, 10, sink);
@@ -94,5 +140,7 @@ int main() {
     run<2>("+ softplus + split of the input tiles (24 steps per 24 MFMAs), operands not consumed", src, sink);
     run<3>("+ softplus + split, the prepared planes ARE the next chunk's B operands", src, sink);
     run<4>("+ softplus + split of registers no MFMA writes", src, sink);
+    run<5>("+ softplus + split (as 3) + six fragment ds_read_b128 in front of every 12 MFMAs", src, sink);
+    run<6>("+ softplus + split (as 3) + the fragment reads issued one group early", src, sink);
     return 0;
 }
