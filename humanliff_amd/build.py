@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhumanliff_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"] + os.environ.get("HL_FLAGS", "").split()   # HL_FLAGS: developer variants (-D...) for every file
 # per-file overrides (the last -std wins): k_conv_wino4w's compile-time slot schedule uses templated lambdas
 FILE_FLAGS = {"hl_conv_wino4w.hip": ["-std=c++20"] + os.environ.get("HL_W4W_FLAGS", "").split(), "hl_conv_h16.hip": ["-std=c++20"] + os.environ.get("HL_H16_FLAGS", "").split(),
               "hl_render.hip": os.environ.get("HL_RENDER_FLAGS", "").split()}   # HL_*_FLAGS: developer variants (-D...)

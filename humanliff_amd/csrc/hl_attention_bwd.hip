@@ -303,9 +303,15 @@ __global__ void k_attn_bwd_products(const float *__restrict__ qkv, const float *
 
 }  // namespace
 
+// head sizes with a register-resident kernel pair (HL_ATTB below); every other size takes the row kernels, whose scratch holds P and dS.
+// ONE predicate for the scratch size and for the dispatch (round-4 advisor: 160 was sized as fast and dispatched as generic).
+static bool attn_bwd_fast(int C, int ch) {
+    return (3L * C) % 4 == 0 && (ch == 32 || ch == 64 || ch == 96 || ch == 128 || ch == 192);
+}
+
 size_t attention_backward_scratch_bytes(int N, int T, int C, int heads) {
     const int ch = heads > 0 ? C / heads : 0;
-    if (ch % 32 == 0 && ch >= 32 && ch <= 192) return (size_t)N * heads * T * 3 * sizeof(float) + 256;
+    if (attn_bwd_fast(C, ch)) return (size_t)N * heads * T * 3 * sizeof(float) + 256;
     return (size_t)2 * N * heads * T * T * sizeof(float) + 256;
 }
 
@@ -328,7 +334,7 @@ int attention_backward(const float *qkv, const float *out, const float *dout, in
         hipLaunchKernelGGL((k_attn_bwd_q<CH_, KS_>), grid, dim3(KS_ * 64), lq, st, qkv, out, dout, T, C, heads, dqkv, sc);                  \
         hipLaunchKernelGGL((k_attn_bwd_kv<CH_, KS_>), grid, dim3(KS_ * 64), lk, st, qkv, dout, sc, T, C, heads, dqkv);                      \
     } while (0)
-    switch ((3L * C) % 4 == 0 ? ch : -1) {
+    switch (attn_bwd_fast(C, ch) ? ch : -1) {
         case 32: HL_ATTB(32); break;
         case 64: HL_ATTB(64); break;
         case 96: HL_ATTB(96); break;

@@ -21,6 +21,7 @@
 // layers with few tiles (blockIdx.z, raw sums to the split-K workspace, k_splitk_finish adds them in a fixed order); k_conv1_h16 for the 1x1
 // layers (256 consecutive pixels per workgroup, chunks of 96 channels).  The weight gradients live in hl_unet_train.hip (k_conv_wgrad_h16).
 #include "hl_unet_kernels.h"
+#include "hl_stats.h"
 
 #include <type_traits>
 #include <utility>
@@ -128,7 +129,7 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
             finish(std::integral_constant<int, 17>{}, std::integral_constant<int, 8>{});
             if (pr0 < 3) finish(std::integral_constant<int, 25>{}, std::integral_constant<int, 1>{});      // slots 125, 126, 127
         }
-        auto put_stats = [&](float *st, const f32x4 a_sm, const f32x4 a_sq) {   // slot = (tile, round) = 128 pixels; the five pixel groups meet in LDS
+        auto put_stats = [&](float *st, const f32x4 a_sm, const f32x4 a_sq) {   // (tile, round) = 128 pixels of one image; the five pixel groups meet in LDS
             __syncthreads();
             if (pr0 < 5) {
                 *reinterpret_cast<f32x4 *>(ep + (pr0 * 48 * 2 + (cq >> 2) * 2) * 4) = a_sm;
@@ -142,9 +143,9 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
                     a += *reinterpret_cast<const f32x4 *>(ep + (g * 48 * 2 + tid * 2) * 4);
                     b += *reinterpret_cast<const f32x4 *>(ep + (g * 48 * 2 + tid * 2 + 1) * 4);
                 }
-                float *d = st + ((tile * 2 + q) * p.Cout + n0 + tid * 4) * 2;
-                *reinterpret_cast<f32x4 *>(d) = f32x4{a[0], b[0], a[1], b[1]};
-                *reinterpret_cast<f32x4 *>(d + 4) = f32x4{a[2], b[2], a[3], b[3]};
+                const long img = (tile * 256) / ((long)p.Hout * p.Wout);   // (a tile = 256 pixels of one image)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) stat_add(st, p.N, img, ((st == p.st1 ? p.st1_c0 : p.st2_c0) + n0 + tid * 4 + i) / (st == p.st1 ? p.st1_cg : p.st2_cg), (long)p.Hout * p.Wout, a[i], b[i]);
             }
         };
         if (p.st1 && !p.partial) put_stats(p.st1, sm, sq);      // GroupNorm statistics of the stored tensor(s)

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "hl_unet_kernels.h"
+#include "hl_stats.h"
 
 namespace hl {
 namespace {
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
         y[2] = __builtin_elementwise_fma((f32x4)(W4_B * W4_B), s2, (W4_A * W4_A) * s1);
         y[3] = __builtin_elementwise_fma((f32x4)(W4_B * W4_B * W4_B), d2, __builtin_elementwise_fma((f32x4)(W4_A * W4_A * W4_A), d1, m5));
     };
+    f32x4 st_sm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, st_sq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // GroupNorm sums of out / out2
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         __syncthreads();
@@ -512,24 +514,13 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) v2[k] += v[k];
         }
-        // GroupNorm statistics: slot = (tile block, round, wave): the wave's four tiles of the round = 64 pixels of one image
-        auto stats = [&](float *st, const f32x4(&vv)[16]) {
-            f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+        // GroupNorm statistics: the wave's four tiles of the round = 64 pixels of one image; the sums of both rounds stay in registers
+        auto stats = [&](f32x4 &sm_t, f32x4 &sq_t, const f32x4(&vv)[16]) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { sm += vv[k]; sq += vv[k] * vv[k]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sm[i] += __shfl_xor(sm[i], 16); sm[i] += __shfl_xor(sm[i], 32);
-                sq[i] += __shfl_xor(sq[i], 16); sq[i] += __shfl_xor(sq[i], 32);
-            }
-            if (lane < 16) {
-                float *d = st + ((((long)tb * 2 + q) * 4 + wave) * p.Cout + n) * 2;
-                *reinterpret_cast<f32x4 *>(d) = f32x4{sm[0], sq[0], sm[1], sq[1]};
-                *reinterpret_cast<f32x4 *>(d + 4) = f32x4{sm[2], sq[2], sm[3], sq[3]};
-            }
+            for (int k = 0; k < 16; ++k) { sm_t += vv[k]; sq_t += vv[k] * vv[k]; }
         };
-        if (p.st1) stats(p.st1, v);
-        if (p.st2) stats(p.st2, v2);
+        if (p.st1) stats(st_sm[0], st_sq[0], v);
+        if (p.st2) stats(st_sm[1], st_sq[1], v2);
         if (p.out_nchw) {
             float *op = p.out + ((long)img * p.Cout + n) * hw + (m0 - (long)img * hw);
 #pragma unroll
@@ -546,6 +537,25 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino4w(const ConvK p) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4 *>(op + (long)((k >> 2) * Wv + (k & 3)) * p.out2_pitch) = v2[k];
         }
+    }
+    if (p.st1 || p.st2) {   // the four waves' sums meet in LDS (the exchange buffer is free): ONE atomic pair per channel and workgroup
+        __syncthreads();
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+            if (!(w2 ? p.st2 : p.st1)) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                st_sm[w2][i] += __shfl_xor(st_sm[w2][i], 16); st_sm[w2][i] += __shfl_xor(st_sm[w2][i], 32);
+                st_sq[w2][i] += __shfl_xor(st_sq[w2][i], 16); st_sq[w2][i] += __shfl_xor(st_sq[w2][i], 32);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wg_stat_put<64>(lds + w2 * 512, wave, nq + i, st_sm[w2][i], st_sq[w2][i]);
+            }
+        }
+        __syncthreads();
+        if (p.st1) wg_group_flush<64, 4>(lds, reinterpret_cast<unsigned long long *>(lds + 1024), p.st1, p.N, img, p.Cout, n0, p.st1_c0, p.st1_cg, hw, tid);
+        if (p.st2) wg_group_flush<64, 4>(lds + 512, reinterpret_cast<unsigned long long *>(lds + 1024), p.st2, p.N, img, p.Cout, n0, p.st2_c0, p.st2_cg, hw, tid);
     }
 #endif
 }

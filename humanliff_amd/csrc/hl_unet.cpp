@@ -426,7 +426,19 @@ struct Exec {
     int rc = 0;
     // GroupNorm statistics travel from the kernel that stores a tensor to the layer that normalises it (ConvArgs::stats): keyed by
     // the address of channel 0 of the stored region, so a decoder "concat" finds its two producers at x.p and x.p + C0
-    struct StatReg { const float *buf; int Cn, slots; };
+    // (buf = the group totals of the normalised view, viewC its channels, c0 / covered = the channel range this tensor fills of it)
+    struct StatReg { float *buf; int viewC, c0, covered; };
+    // the two halves of a decoder "concat" buffer are normalised as ONE view: their producers add into one statistics block (run pass only)
+    struct PartInfo { float *buf; int viewC, c0; };
+    std::unordered_map<const float *, PartInfo> part_reg;
+    // the fixed-point totals live in one arena behind the activation scratch, zeroed by ONE memset at the start of the forward
+    char *stat_base = nullptr;
+    size_t stat_off = 0, stat_bytes = 0;
+    float *alloc_stat(size_t floats) {
+        float *p = run ? reinterpret_cast<float *>(stat_base + stat_off) : nullptr;
+        stat_off += (floats * sizeof(float) + 255) / 256 * 256;
+        return p;
+    }
     std::unordered_map<const float *, StatReg> stat_reg;
     bool want_stats = true;
 
@@ -459,17 +471,30 @@ struct Exec {
     int span_key[5] = {-1, 0, 0, 0, 0};
     long span_mid = -1;
 
-    void conv(const Conv &c, const View &in, const View &out, int stride, int ups, const float *cA, const float *cB, int act,
+    // the affine of a GroupNorm in front of a convolution: arrays (cA, cB) or - no launch - the producers' group statistics (gn.gs0 set)
+    struct Aff { float *cA = nullptr, *cB = nullptr; hl::GnSrc gn{}; bool on = false; };
+    const Aff none{};
+    void conv(const Conv &c, const View &in, const View &out, int stride, int ups, const Aff &af, int act,
               const float *res, long res_pitch, float *out2 = nullptr, long out2_pitch = 0, const float *res2 = nullptr,
               long res2_pitch = 0, int nchw = 0) {
+        const float *cA = af.cA, *cB = af.cB;
         if (!run) {   // sizing pass (pointers are null here): the largest conv input is also the largest normalised one
             const size_t need = (size_t)in.pixels() * c.Cin_pad;
             if (need > act_need) act_need = need;
         }
         // room for the output statistics (same allocations in the sizing pass)
         const bool st_ok = want_stats && !nchw;
-        float *st1 = st_ok ? alloc(hl::conv_stats_floats(out.pixels(), c.Cout)) : nullptr;
-        float *st2 = (st_ok && out2_pitch != 0) ? alloc(hl::conv_stats_floats(out.pixels(), c.Cout)) : nullptr;
+        // (sizing pass: every output gets its own block - an upper bound; run pass: the halves of a concat share the block made with the buffer)
+        PartInfo pi1{nullptr, c.Cout, 0}, pi2{nullptr, c.Cout, 0};
+        if (st_ok) {
+            auto f1 = run ? part_reg.find(out.p) : part_reg.end();
+            if (f1 != part_reg.end()) pi1 = f1->second; else pi1.buf = alloc_stat(hl::conv_stats_floats(B, (long)out.H * out.W));
+            if (out2_pitch != 0) {
+                auto f2 = run ? part_reg.find(out2) : part_reg.end();
+                if (f2 != part_reg.end()) pi2 = f2->second; else pi2.buf = alloc_stat(hl::conv_stats_floats(B, (long)out.H * out.W));
+            }
+        }
+        float *st1 = pi1.buf, *st2 = pi2.buf;
         if (!run) return;
         ConvArgs a{};
         a.in = in; a.in.C = c.Cin_pad;
@@ -477,12 +502,13 @@ struct Exec {
         a.w_wino = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_F23 || n.conv_mode == HL_CONV_FP16) ? c.w_wino : nullptr;
         a.w_h16 = n.conv_mode == HL_CONV_FP16 ? c.w_h16 : nullptr; a.h16_fp16 = 1;
         a.w_wino4 = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP16) ? c.w_wino4 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
-        a.coefA = cA; a.coefB = cB; a.act = act;
+        a.coefA = cA; a.coefB = cB; a.act = act; a.gn = af.gn;
         a.out = out; a.res = res; a.res_pitch = res_pitch;
         a.out2 = out2; a.out2_pitch = out2_pitch; a.res2 = res2; a.res2_pitch = res2_pitch; a.out_nchw = nchw;
         a.splitk_ws = splitk_ws; a.splitk_ws_bytes = hl::conv_splitk_ws_bytes();
         a.act_ws = act_ws; a.act_ws_bytes = act_need * sizeof(float);
         a.stats = st1; a.stats2 = st2;
+        a.st_cg = pi1.viewC / 32; a.st_c0 = pi1.c0; a.st2_cg = pi2.viewC / 32; a.st2_c0 = pi2.c0;
         const size_t e0 = span_begin();
         size_t emid = 0;
         if (n.prof) { emid = n.next_event(); a.ev_mid = n.ev_pool[emid]; }
@@ -500,50 +526,59 @@ struct Exec {
         span_end(CAT_CONV, e0, fl, a.path == 1 ? fl * (16.0 / 36.0) : (a.path == 3 ? fl * 0.25 : (a.path == 2 ? fl * 6.0 : fl)));
         // whoever stored the tensor last owns its statistics
         if (a.stat_slots > 0) {
-            stat_reg[out.p] = {st1, c.Cout, a.stat_slots};
-            if (out2) stat_reg[out2] = {st2, c.Cout, a.stat_slots};
+            stat_reg[out.p] = {st1, pi1.viewC, pi1.c0, c.Cout};
+            if (out2) stat_reg[out2] = {st2, pi2.viewC, pi2.c0, c.Cout};
         } else {
             stat_reg.erase(out.p);
             if (out2) stat_reg.erase(out2);
         }
     }
-    void coef(const View &x, const Norm &g, const float *emb, float *&cA, float *&cB) {
-        cA = alloc((size_t)B * x.C);
-        cB = alloc((size_t)B * x.C);
-        if (run) {
-            const size_t e0 = span_begin();
-            // statistics emitted by the producer(s) of x, if every channel of x is covered; otherwise one pass over the tensor
-            hl::StatSrc src[2];
-            int nsrc = 0;
-            auto it = stat_reg.find(x.p);
-            if (it != stat_reg.end() && it->second.Cn <= x.C) {
-                src[nsrc++] = {it->second.buf, it->second.Cn, it->second.slots};
-                if (it->second.Cn < x.C) {
-                    auto it2 = stat_reg.find(x.p + it->second.Cn);
-                    if (it2 != stat_reg.end() && it->second.Cn + it2->second.Cn == x.C) src[nsrc++] = {it2->second.buf, it2->second.Cn, it2->second.slots};
-                    else nsrc = 0;
-                }
+    // force_arrays: the caller needs cA / cB in memory (gn_apply_3d)
+    Aff coef(const View &x, const Norm &g, const float *emb, bool force_arrays = false) {
+        Aff af;
+        af.on = true;
+        af.cA = alloc((size_t)B * x.C);
+        af.cB = alloc((size_t)B * x.C);
+        if (!run) return af;
+        // group totals left by the producer(s) of x, if they were formed for exactly this view and cover every channel of it; otherwise one
+        // pass over the tensor
+        const float *gt = nullptr;
+        auto it = stat_reg.find(x.p);
+        if (it != stat_reg.end() && it->second.viewC == x.C && it->second.c0 == 0) {
+            if (it->second.covered == x.C) gt = it->second.buf;
+            else {
+                auto it2 = stat_reg.find(x.p + it->second.covered);
+                if (it2 != stat_reg.end() && it2->second.buf == it->second.buf && it2->second.c0 == it->second.covered &&
+                    it->second.covered + it2->second.covered == x.C) gt = it->second.buf;
             }
-            if (nsrc) ok(hl::groupnorm_coef_stats(x, src, nsrc, g.gamma, g.beta, emb, n.emb_total, cA, cB, st, g.eps));
-            else ok(hl::groupnorm_coef(x, g.gamma, g.beta, emb, n.emb_total, cA, cB, gn_scratch, st, nullptr, g.eps));
-            span_end(CAT_GN, e0, 0.0);
         }
+        if (gt && !force_arrays && !n.prof) {
+            // the consumer kernels form the coefficients themselves from the totals the producers left: no launch here
+            af.cA = af.cB = nullptr;
+            af.gn.gt = gt; af.gn.C = x.C; af.gn.HW = x.H * x.W;
+            af.gn.gamma = g.gamma; af.gn.beta = g.beta; af.gn.emb = emb; af.gn.emb_pitch = n.emb_total; af.gn.eps = g.eps;
+            return af;
+        }
+        const size_t e0 = span_begin();
+        if (gt) ok(hl::groupnorm_coef_stats(x, gt, g.gamma, g.beta, emb, n.emb_total, af.cA, af.cB, st, g.eps));
+        else ok(hl::groupnorm_coef(x, g.gamma, g.beta, emb, n.emb_total, af.cA, af.cB, gn_scratch, st, nullptr, g.eps));
+        span_end(CAT_GN, e0, 0.0);
+        return af;
     }
     void res_block(const Res &r, const View &x, const View &dst) {
-        float *a1, *b1, *a2, *b2;
-        coef(x, r.n1, nullptr, a1, b1);
+        Aff a1 = coef(x, r.n1, nullptr), a2;
         View h = plain(H / dst.H, r.Cout);
         if (n.cfg.no_scale_shift) {
             // use_scale_shift_norm=False (unet.py:216-218): h = h + emb_out[..., None, None]; h = out_layers(h).  The sum is materialised in
             // place and its GroupNorm statistics come from a pass over the tensor (the producer's epilogue saw h without the embedding)
             want_stats = false;
-            conv(r.c1, x, h, 1, 0, a1, b1, 1, nullptr, 0);
+            conv(r.c1, x, h, 1, 0, a1, 1, nullptr, 0);
             want_stats = true;
             if (run) ok(hl::add_rowvec(h, emb_all + r.emb_off, st, n.emb_total));
-            coef(h, r.n2, nullptr, a2, b2);
+            a2 = coef(h, r.n2, nullptr, r.aware);
         } else {
-            conv(r.c1, x, h, 1, 0, a1, b1, 1, nullptr, 0);
-            coef(h, r.n2, run ? emb_all + r.emb_off : nullptr, a2, b2);
+            conv(r.c1, x, h, 1, 0, a1, 1, nullptr, 0);
+            a2 = coef(h, r.n2, run ? emb_all + r.emb_off : nullptr, r.aware);
         }
         if (r.aware) {
             // unet.py:208-214: every plane sees, next to its own normalised features, the other two planes averaged along the axis
@@ -552,34 +587,33 @@ struct Exec {
             float *sums = alloc((size_t)B * 3 * (h.H + h.W / 3) * r.Cout);
             if (run) {
                 const size_t e0 = span_begin();
-                ok(hl::gn_apply_3d(h, a2, b2, sums, h3.p, st));
+                ok(hl::gn_apply_3d(h, a2.cA, a2.cB, sums, h3.p, st));
                 span_end(CAT_GN, e0, 0.0);
             }
             if (r.has_skip) {
                 want_stats = false;
-                conv(r.skip, x, dst, 1, 0, nullptr, nullptr, 0, nullptr, 0);
+                conv(r.skip, x, dst, 1, 0, none, 0, nullptr, 0);
                 want_stats = true;
-                conv(r.c2, h3, dst, 1, 0, nullptr, nullptr, 0, dst.p, dst.pitch);
+                conv(r.c2, h3, dst, 1, 0, none, 0, dst.p, dst.pitch);
             } else {
-                conv(r.c2, h3, dst, 1, 0, nullptr, nullptr, 0, x.p, x.pitch);
+                conv(r.c2, h3, dst, 1, 0, none, 0, x.p, x.pitch);
             }
             return;
         }
         if (r.has_skip) {
             want_stats = false;          // dst is finished by c2 below
-            conv(r.skip, x, dst, 1, 0, nullptr, nullptr, 0, nullptr, 0);
+            conv(r.skip, x, dst, 1, 0, none, 0, nullptr, 0);
             want_stats = true;
-            conv(r.c2, h, dst, 1, 0, a2, b2, 1, dst.p, dst.pitch);
+            conv(r.c2, h, dst, 1, 0, a2, 1, dst.p, dst.pitch);
         } else {
-            conv(r.c2, h, dst, 1, 0, a2, b2, 1, x.p, x.pitch);
+            conv(r.c2, h, dst, 1, 0, a2, 1, x.p, x.pitch);
         }
     }
     void attn_block(const Attn &a, const View &x, const View &dst) {
-        float *ca, *cb;
-        coef(x, a.norm, nullptr, ca, cb);
+        const Aff af = coef(x, a.norm, nullptr);
         View qkv = plain(H / x.H, 3 * a.C);
         want_stats = false;              // qkv is not normalised
-        conv(a.qkv, x, qkv, 1, 0, ca, cb, 0, nullptr, 0);
+        conv(a.qkv, x, qkv, 1, 0, af, 0, nullptr, 0);
         want_stats = true;
         View o = plain(H / x.H, a.C);
         if (run) {
@@ -588,41 +622,40 @@ struct Exec {
             const double T = (double)x.H * x.W;
             span_end(CAT_ATTN, e0, 4.0 * B * T * T * a.C);
         }
-        conv(a.proj, o, dst, 1, 0, nullptr, nullptr, 0, x.p, x.pitch);
+        conv(a.proj, o, dst, 1, 0, none, 0, x.p, x.pitch);
     }
     // SpatialTransformer (spatial_transformer.py:136-178, BasicTransformerBlock :115-134), depth 1, context = ONE token per image:
     //   h = proj_in(GroupNorm(x));  h += to_out(self-attention(LayerNorm1(h)));  h += to_out2(to_v2(context))  [softmax over a single key
     //   is 1, so norm2 / to_q / to_k of attn2 cannot act];  h += ff_out(GEGLU(ff_in(LayerNorm3(h))));  y = proj_out(h) + x
     void xf_block(const Xf &a, const View &x, const View &dst) {
         const int ds = H / x.H;
-        float *ca, *cb;
-        coef(x, a.norm, nullptr, ca, cb);
+        const Aff af = coef(x, a.norm, nullptr);
         const bool ws_keep = want_stats;
         want_stats = false;              // nothing in here feeds a GroupNorm
         View h = plain(ds, a.C), ln = plain(ds, a.C), qkv = plain(ds, 3 * a.C), o = plain(ds, a.C), h1 = plain(ds, a.C);
         View ln3 = plain(ds, a.C), f8 = plain(ds, 8 * a.C), f4 = plain(ds, 4 * a.C), h2 = plain(ds, a.C);
         float *v2 = alloc((size_t)B * a.C), *r2 = alloc((size_t)B * a.C);
-        conv(a.proj_in, x, h, 1, 0, ca, cb, 0, nullptr, 0);
+        conv(a.proj_in, x, h, 1, 0, af, 0, nullptr, 0);
         if (run) ok(hl::layernorm(h, a.ln1_g, a.ln1_b, ln.p, st));
-        conv(a.qkv, ln, qkv, 1, 0, nullptr, nullptr, 0, nullptr, 0);
+        conv(a.qkv, ln, qkv, 1, 0, none, 0, nullptr, 0);
         if (run) {
             const size_t e0 = span_begin();
             ok(hl::attention(qkv.p, B, x.H * x.W, a.C, a.heads, o.p, st));
             const double T = (double)x.H * x.W;
             span_end(CAT_ATTN, e0, 4.0 * B * T * T * a.C);
         }
-        conv(a.out1, o, h1, 1, 0, nullptr, nullptr, 0, h.p, h.pitch);
+        conv(a.out1, o, h1, 1, 0, none, 0, h.p, h.pitch);
         if (run) {
             ok(hl::linear_small(ctx, n.E, B, n.E, a.v2_w, nullptr, a.C, 0, nullptr, nullptr, v2, a.C, st));
             ok(hl::linear_small(v2, a.C, B, a.C, a.o2_w, a.o2_b, a.C, 0, nullptr, nullptr, r2, a.C, st));
             ok(hl::add_rowvec(h1, r2, st));
             ok(hl::layernorm(h1, a.ln3_g, a.ln3_b, ln3.p, st));
         }
-        conv(a.ff_in, ln3, f8, 1, 0, nullptr, nullptr, 0, nullptr, 0);
+        conv(a.ff_in, ln3, f8, 1, 0, none, 0, nullptr, 0);
         if (run) ok(hl::geglu(f8.p, f8.pixels(), 4 * a.C, f4.p, st));
-        conv(a.ff_out, f4, h2, 1, 0, nullptr, nullptr, 0, h1.p, h1.pitch);
+        conv(a.ff_out, f4, h2, 1, 0, none, 0, h1.p, h1.pitch);
         want_stats = ws_keep;
-        conv(a.proj_out, h2, dst, 1, 0, nullptr, nullptr, 0, x.p, x.pitch);
+        conv(a.proj_out, h2, dst, 1, 0, none, 0, x.p, x.pitch);
     }
     // run one TimestepEmbedSequential; the last layer writes into dst
     void block(const Block &b, View x, const View &dst) {
@@ -641,12 +674,12 @@ struct Exec {
             }
             View y = last ? dst : plain(ds_out, Cout);
             switch (L.kind) {
-                case K_CONV: conv(n.convs[L.idx], x, y, 1, 0, nullptr, nullptr, 0, nullptr, 0); break;
+                case K_CONV: conv(n.convs[L.idx], x, y, 1, 0, none, 0, nullptr, 0); break;
                 case K_RES: res_block(n.res[L.idx], x, y); break;
                 case K_ATTN: attn_block(n.attn[L.idx], x, y); break;
                 case K_XF: xf_block(n.xf[L.idx], x, y); break;
-                case K_DOWN: conv(n.convs[L.idx], x, y, 2, 0, nullptr, nullptr, 0, nullptr, 0); break;
-                case K_UP: conv(n.convs[L.idx], x, y, 1, 1, nullptr, nullptr, 0, nullptr, 0); break;
+                case K_DOWN: conv(n.convs[L.idx], x, y, 2, 0, none, 0, nullptr, 0); break;
+                case K_UP: conv(n.convs[L.idx], x, y, 1, 1, none, 0, nullptr, 0); break;
             }
             x = y;
         }
@@ -654,6 +687,7 @@ struct Exec {
 
     void forward(const float *x, const int64_t *t, const float *tf, const float *x_cond, const int64_t *y, float *out) {
         const hl_unet_cfg &c = n.cfg;
+        if (run && stat_bytes) ok(hipMemsetAsync(stat_base, 0, stat_bytes, st) == hipSuccess ? 0 : hl::fail(HL_ERR_RUNTIME, "hl_unet_forward: memset of the statistics arena"));
         gn_scratch = alloc(hl::gn_scratch_floats(B));
         splitk_ws = alloc(hl::conv_splitk_ws_bytes() / sizeof(float));
         gn_scratch2 = alloc(hl::gn_scratch_floats(B));
@@ -683,8 +717,8 @@ struct Exec {
                 ok(hl::prep_inputs(x_cond, nullptr, B, c.out_channels, H, W, ac.C, ac.p, nullptr, st));
             }
             View a1w = a1; a1w.C = 6;                                 // the conv writes 6 of the 16 (zeroed) channels
-            conv(n.ada1, ac, a1w, 2, 0, nullptr, nullptr, 0, nullptr, 0);
-            conv(n.ada2, a1, a2, 2, 0, nullptr, nullptr, 0, nullptr, 0);
+            conv(n.ada1, ac, a1w, 2, 0, none, 0, nullptr, 0);
+            conv(n.ada2, a1, a2, 2, 0, none, 0, nullptr, 0);
         }
         if (run) {
             const size_t e0 = span_begin();
@@ -710,6 +744,19 @@ struct Exec {
                 const Block &src = n.in_blocks[nb - 1 - j];
                 cat[j] = plain(src.ds_out, ch + src.Cout);
                 ch = n.out_blocks[j].Cout;
+            }
+        }
+        // one statistics block per concat view; its two halves (the decoder's running tensor | encoder skip + control residual) register as parts
+        {
+            std::vector<float *> cat_st(nb);
+            for (size_t j = 0; j < nb; ++j) cat_st[j] = alloc_stat(hl::conv_stats_floats(B, (long)cat[j].H * cat[j].W));
+            if (run && c.controlnet) {
+                int ch = n.middle.Cout;
+                for (size_t j = 0; j < nb; ++j) {
+                    part_reg[cat[j].p] = {cat_st[j], cat[j].C, 0};
+                    part_reg[cat[j].p + ch] = {cat_st[j], cat[j].C, ch};
+                    ch = n.out_blocks[j].Cout;
+                }
             }
         }
         auto first_part = [&](size_t j, int C) { View v = cat[j]; v.C = C; return v; };
@@ -741,7 +788,7 @@ struct Exec {
                 const size_t j = nb - 1 - i;
                 const int Ch = cat[j].C - hs[i].C;
                 if (fork) hipStreamWaitEvent(n.side, n.ev_block[i], 0);
-                conv(n.convs[n.proj_cond[i]], tmp, pj, 1, 0, nullptr, nullptr, 0, nullptr, 0,
+                conv(n.convs[n.proj_cond[i]], tmp, pj, 1, 0, none, 0, nullptr, 0,
                      run ? cat[j].p + Ch : nullptr, cat[j].pitch, hs[i].p, hs[i].pitch);
                 hc = pj;
             }
@@ -756,8 +803,7 @@ struct Exec {
                 const int Ch = cat[j].C - hs[i].C;
                 hipMemcpy2DAsync(cat[j].p + Ch, cat[j].pitch * sizeof(float), hs[i].p, hs[i].pitch * sizeof(float),
                                  (size_t)hs[i].C * sizeof(float), (size_t)hs[i].pixels(), hipMemcpyDeviceToDevice, st);
-                auto sr = stat_reg.find(hs[i].p);   // the copy has the statistics of its source
-                if (sr != stat_reg.end()) stat_reg[cat[j].p + Ch] = sr->second; else stat_reg.erase(cat[j].p + Ch);
+                stat_reg.erase(cat[j].p + Ch);   // (the source's totals are grouped for its own norm, not for the concat: the decoder norm takes a pass over the tensor)
             }
         }
         // decoder
@@ -767,16 +813,15 @@ struct Exec {
             block(n.out_blocks[j], cat[j], dst);
             last = dst;
         }
-        float *ca, *cb;
-        coef(last, n.out_norm, nullptr, ca, cb);
+        const Aff afo = coef(last, n.out_norm, nullptr);
         View o; o.N = B; o.H = H; o.W = W; o.C = c.out_channels; o.pitch = c.out_channels; o.p = out;
         if (c.aware3d) {   // unet.py:613-614: the planes go back to channels
             o.p = alloc((size_t)o.pixels() * c.out_channels);
-            conv(n.out_conv, last, o, 1, 0, ca, cb, 1, nullptr, 0, nullptr, 0, nullptr, 0, 1);
+            conv(n.out_conv, last, o, 1, 0, afo, 1, nullptr, 0, nullptr, 0, nullptr, 0, 1);
             if (run) ok(hl::unroll_planes(o.p, B, c.out_channels, H, W / 3, out, st));
             return;
         }
-        conv(n.out_conv, last, o, 1, 0, ca, cb, 1, nullptr, 0, nullptr, 0, nullptr, 0, 1);
+        conv(n.out_conv, last, o, 1, 0, afo, 1, nullptr, 0, nullptr, 0, nullptr, 0, 1);
     }
 };
 
@@ -859,7 +904,7 @@ size_t hl_unet_workspace_bytes(void *handle, int B, int H, int W) {
     Net &n = *static_cast<Net *>(handle);
     Exec e{n, false, nullptr, 0, nullptr, B, H, n.cfg.aware3d ? 3 * W : W};
     e.forward(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    return e.off + 2 * e.act_need * sizeof(float) + 1024;
+    return e.off + 2 * e.act_need * sizeof(float) + e.stat_off + 1024;
 }
 
 int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float *t_float, const float *x_cond,
@@ -880,6 +925,9 @@ int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float 
     e.act_need = dry.act_need;
     e.act_ws = reinterpret_cast<float *>(static_cast<char *>(workspace) + (dry.off + 255) / 256 * 256);
     e.act_ws2 = e.act_ws + dry.act_need;
+    e.stat_base = reinterpret_cast<char *>(e.act_ws2 + dry.act_need);
+    e.stat_base += (256 - (reinterpret_cast<uintptr_t>(e.stat_base) & 255)) & 255;
+    e.stat_bytes = dry.stat_off;
     for (auto &row : n.census) for (auto &v : row) v = 0;
     e.forward(x, t, t_float, x_cond, y, out);
     return e.rc;
@@ -994,6 +1042,7 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
         a.splitk_ws_bytes = scratch_bytes - used;
     }
     a.stats = stats;
+    if (stats) HL_HIP(hipMemsetAsync(stats, 0, hl::conv_stats_floats(N, (long)a.out.H * a.out.W) * sizeof(float), (hipStream_t)stream));   // the epilogues ADD to the totals
     a.plan_only = 1;
     int rc = hl::conv2d(a, (hipStream_t)stream);
     if (rc) return rc;
@@ -1062,7 +1111,7 @@ int hl_conv2d_nhwc_gn(int conv_mode, const float *in, int N, int H, int W, int C
     HL_REQUIRE(gamma && beta && next_coefA && next_coefB && scratch, "hl_conv2d_nhwc_gn: null argument");
     const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     const int Ho = (Hv + 2 * pad - ks) / stride + 1, Wo = (Wv + 2 * pad - ks) / stride + 1;
-    const size_t stf = (hl::conv_stats_floats((long)N * Ho * Wo, Cout) * sizeof(float) + 255) / 256 * 256;
+    const size_t stf = (hl::conv_stats_floats(N, (long)Ho * Wo) * sizeof(float) + 255) / 256 * 256;
     const size_t gnf = (hl::gn_scratch_floats(N) * sizeof(float) + 255) / 256 * 256;
     HL_REQUIRE(scratch_bytes > stf + gnf, "hl_conv2d_nhwc_gn: scratch too small");
     float *stats = static_cast<float *>(scratch);
@@ -1074,8 +1123,7 @@ int hl_conv2d_nhwc_gn(int conv_mode, const float *in, int N, int H, int W, int C
     View v; v.p = out; v.N = N; v.H = Ho; v.W = Wo; v.C = Cout; v.pitch = Cout;
     if (h_used_stats) *h_used_stats = slots;
     if (slots > 0) {
-        hl::StatSrc src{stats, Cout, slots};
-        return hl::groupnorm_coef_stats(v, &src, 1, gamma, beta, nullptr, 0, next_coefA, next_coefB, (hipStream_t)stream);
+        return hl::groupnorm_coef_stats(v, stats, gamma, beta, nullptr, 0, next_coefA, next_coefB, (hipStream_t)stream);
     }
     return hl::groupnorm_coef(v, gamma, beta, nullptr, 0, next_coefA, next_coefB, gn_scr, (hipStream_t)stream);
 }

@@ -12,6 +12,19 @@ struct View {
     long pixels() const { return (long)N * H * W; }
 };
 
+// Where a kernel that normalises its input gets the per-(image, channel) affine y = x*A + B of GroupNorm32 [+ scale/shift] from: the
+// arrays cA / cB (groupnorm_coef / groupnorm_coef_stats wrote them), or - gt set - the fixed-point group totals its producer(s) left
+// (ConvArgs::stats) plus the norm's own parameters: every consumer workgroup then forms the coefficients of its image itself
+// (coef_to_lds, hl_stats.h) and no coefficient launch sits between producer and consumer.  C = channels of the normalised view, HW =
+// pixels per image (it also fixes the number of shards of the totals).
+struct GnSrc {
+    const float *gt;
+    int C, HW;
+    const float *gamma, *beta, *emb;   // emb (N, emb_pitch) holds [scale(C) | shift(C)] or null
+    long emb_pitch;
+    float eps;
+};
+
 struct ConvArgs {
     View in;             // C must be a multiple of 16 (pad channels are zero and have zero weights)
     const float *w;      // packed [Cout_pad][Ktot], K order = kt_decode() in hl_unet_kernels.hip (groups of two 16-channel chunks, taps inside)
@@ -28,6 +41,7 @@ struct ConvArgs {
     int ups;             // 1: input is read through a nearest x2 upsample (unet.py:77)
     const float *coefA;  // per-(n, cin) affine applied before the conv (GroupNorm [+scale/shift]) or null
     const float *coefB;
+    GnSrc gn;            // alternative to coefA / coefB (gn.t0 != null): the affine formed in the kernels from the producers' totals
     int act;             // 1: SiLU after the affine
     View out;            // NHWC (pitch honoured) unless out_nchw
     const float *res;    // residual added to out (may alias out.p), pitch res_pitch; or null
@@ -43,11 +57,15 @@ struct ConvArgs {
     float *splitk_ws;    // optional scratch for split-K partial sums (small-M layers); null disables split-K
     size_t splitk_ws_bytes;
     // GroupNorm statistics of the OUTPUT for the layer that will normalise it, emitted by the epilogue of whichever kernel stores
-    // the tensor: per slot of consecutive pixels and per channel (sum, sumsq), [slot][Cout][2].  `stats` (and `stats2` for out2)
-    // need conv_stats_floats(out pixels, Cout) floats each; null = not wanted.  On return stat_slots is the number of slots PER
-    // IMAGE that were written, or 0 when this path emits none (register-staged / bf16x3 / NCHW / odd sizes): the consumer then
-    // computes the statistics from the tensor (groupnorm_coef).
+    // the tensor: per image and GROUP of the normalised view the totals (sum x, sum x^2), as 64-bit FIXED-POINT integers [shard][N][32][2]
+    // that the workgroups add to with integer atomics (hl_stats.h) - integer addition is associative, so the totals are bit-identical
+    // from run to run.  `stats` (and `stats2` for out2) need conv_stats_floats(N, pixels per image) floats each, ZEROED before the first
+    // producer of the view runs; null = not wanted.  st_cg = channels per group of the view (0: Cout / 32), st_c0 = channel of the view
+    // that output channel 0 is (a decoder "concat" has two producers adding into one block).  On return stat_slots is 1 when the launch
+    // added its totals, 0 when this path emits none (register-staged / bf16x3 / NCHW / odd sizes): the consumer then computes the
+    // statistics from the tensor (groupnorm_coef).
     float *stats, *stats2;
+    int st_cg, st_c0, st2_cg, st2_c0;
     mutable int stat_slots;
     hipEvent_t ev_mid;   // optional (profiling): recorded between the GroupNorm pre-pass and the convolution kernel, when there is a pre-pass
     mutable int ev_mid_used;
@@ -59,16 +77,18 @@ struct ConvK {
     int Hout, Wout, ks, stride, ups, taps;
     const float *w; const void *w_bf3; const float *w_wino; long Ktot; const float *bias; int Cout;
     const float *cA; const float *cB; int act;
+    GnSrc gn;          // (cA null and gn.t0 set: the coefficients are formed in the kernel, coef_to_lds)
     float *out; long out_pitch; const float *res; long res_pitch;
     float *out2; long out2_pitch; const float *res2; long res2_pitch;
     int out_nchw; long M; int wrows;
     int kt_per;        // k-tiles per split (blockIdx.z); gridDim.z == 1 -> whole K
     int n_mtiles, n_nblocks;
     float *partial;    // split-K: raw accumulators [z][M][Cout]
-    // GroupNorm statistics of the OUTPUT, emitted by the epilogue for the layer that will normalise it (nn.py:17-19): per slot of
-    // consecutive output pixels (32 rows of M; a Winograd workgroup: one column parity of its 16x8 block = 64 pixels) and per
-    // output channel (sum, sum of squares) of the stored value (after bias / residual), [slot][Cout][2]; null = not wanted.
-    // st2: the same for out2.  Deterministic (no atomics); k_gn_coef_st folds the slots of an image.
+    // GroupNorm statistics of the OUTPUT, emitted by the epilogue for the layer that will normalise it (nn.py:17-19): fixed-point totals
+    // (sum, sum of squares) of the stored value (after bias / residual) per image and group of the normalised view, [shard][N][32][2]
+    // 64-bit integers the epilogues add to atomically (hl_stats.h); null = not wanted.  st2: the same for out2.  cg / c0: channels per
+    // group of the view, the view channel of output channel 0.  Deterministic (integer adds commute).
+    int st1_cg, st1_c0, st2_cg, st2_c0;
     float *st1, *st2;
     int in16;          // k_conv_h16 / k_conv1_h16: `in` holds 16-bit values (the GroupNorm pass wrote them), in_pitch counts them
 };
@@ -85,7 +105,11 @@ size_t conv_packed_h16_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_h16(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, int f16, hipStream_t st, int tf = 0);
 int conv_h16_launch(const ConvK &p, int f16, hipStream_t st, int splits = 1);
 
-inline size_t conv_stats_floats(long out_pixels, int Cout) { return (size_t)(out_pixels / 32 + 1) * Cout * 2; }
+// Statistics block of one normalised VIEW (ConvArgs::stats): [shard][N][32 groups][2] 64-bit fixed-point totals.  Levels with many
+// workgroups per image keep stat_shards(HW) = 8 copies (a workgroup adds to copy blockIdx.x % 8: atomics on one word serialise), the low
+// levels one.
+constexpr int stat_shards(long HW) { return HW >= 4096 ? 8 : 1; }
+constexpr size_t conv_stats_floats(int N, long HW) { return (size_t)stat_shards(HW) * N * 32 * 4; }
 size_t conv_splitk_ws_bytes();
 int conv2d(const ConvArgs &a, hipStream_t st);
 size_t conv_packed_floats(int Cout, int Cin_pad, int ks);
@@ -106,10 +130,8 @@ int conv_pack_weights_bf3(const float *w_oihw, int Cout, int Cin, int Cin_pad, i
 // optional scale/shift (ResBlock use_scale_shift_norm, unet.py:203-206): y = GN(x)*(1+scale)+shift,
 // where emb (N, emb_pitch) holds [scale(C) | shift(C)] starting at emb + n*emb_pitch.
 size_t gn_scratch_floats(int N);
-// the same affine from the statistics the producers emitted (ConvArgs::stats): source 0 covers channels [0, src[0].Cn) of the view,
-// source 1 (decoder concats: the control branch's half) the rest; `slots` = ConvArgs::stat_slots of the producing launch
-struct StatSrc { const float *p; int Cn, slots; };
-int groupnorm_coef_stats(const View &x, const StatSrc *src, int nsrc, const float *gamma, const float *beta, const float *emb,
+// the same affine (as arrays) from the group totals the producer(s) of the view left (ConvArgs::stats)
+int groupnorm_coef_stats(const View &x, const float *group_totals, const float *gamma, const float *beta, const float *emb,
                          long emb_pitch, float *coefA, float *coefB, hipStream_t st, float eps = 1e-5f);
 // gstat (optional): (N, 32, 2) = (mean, rstd) of every group, for the backward pass of the training path
 int groupnorm_coef(const View &x, const float *gamma, const float *beta, const float *emb, long emb_pitch, float *coefA,

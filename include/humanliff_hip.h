@@ -441,8 +441,9 @@ int hl_upsample2_backward_nhwc(const float *d_up, int N, int H, int W, int C, fl
 int hl_zero_stuff2_nhwc(const float *dy, int N, int Ho, int Wo, int C, float *z, void *stream);
 
 /* hl_conv2d_nhwc_mode followed by the GroupNorm32 affine of its OUTPUT (nn.py:17-19,100: y = out*A[n,c] + B[n,c] for the layer
- * that normalises `out` next): the statistics come from the epilogue of the kernel that stored `out` (per-slot partial sums, folded
- * in a fixed order) - the tensor is not read again; *h_used_stats returns the slots per image that were emitted, 0 when the kernel
+ * that normalises `out` next): the statistics come from the epilogue of the kernel that stored `out` (fixed-point group totals added
+ * with integer atomics: order-free, bit-reproducible) - the tensor is not read again; *h_used_stats returns nonzero when the epilogue
+ * emitted them, 0 when the kernel
  * path taken emits none and the statistics were computed from the tensor instead.  scratch as hl_conv2d_nhwc_mode plus
  * (N*Hout*Wout/32 + 1)*Cout*8 + N*32 KiB bytes. */
 int hl_conv2d_nhwc_gn(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,

@@ -162,6 +162,9 @@ def test_training_step_gradients_are_bit_reproducible():
     (1, 256, 768, 4),     # production: 16x16 level
     (2, 40, 128, 4),      # T not a multiple of the 32-row tiles (masked rows / keys)
     (2, 16, 64, 4),       # head size 16 (the tiny test networks): the plain path through scratch
+    (1, 64, 320, 2),      # head size 160: a multiple of 32 WITHOUT a register-resident kernel pair - scratch sized for the row kernels
+    (2, 96, 256, 4),      # head size 64
+    (1, 128, 256, 2),     # head size 128
 ])
 def test_attention_backward_matches_torch_autograd(N, T, C, heads, monkeypatch):
     """hl_attention_nhwc_backward (csrc/hl_attention_bwd.hip) against float64 autograd of the reference's QKVAttention arithmetic
