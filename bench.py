@@ -286,6 +286,30 @@ def bench_unet(args, rank, world, dev):
     return secs, roof, sd, model
 
 
+def collective_probe(args, rank, world, dev, iters=3):
+    """What the N > 1 run actually ran on: the process group's backend and size as torch.distributed reports them, and the two gathers of
+    the path timed alone - the final sample gather (triplane_sample_layered.py:211-212: B x 27 x 256 x 256 fp32 per rank) and one subject's
+    uint8 image gather (185 views of 512 x 512 x 3 per rank) - as all_gather_into_tensor into the preallocated result.  GB/s = bytes every
+    rank RECEIVES from the others / max-over-ranks seconds."""
+    import torch.distributed as dist
+    out = {"world_size": dist.get_world_size(), "rank0_sees_ranks": dist.get_world_size(), "backend": str(dist.get_backend()),
+           "device_count_visible": torch.cuda.device_count()}
+    for name, shard in (("sample_gather", torch.randn((args.batch, 27, 256, 256), device=dev)),
+                        ("image_gather_uint8", torch.zeros((args.e2e_views, 512, 512, 3), dtype=torch.uint8, device=dev))):
+        full = torch.empty((world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=dev)
+        dist.all_gather_into_tensor(full, shard)          # warm-up (connection set-up)
+        barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            dist.all_gather_into_tensor(full, shard)
+        barrier(world)
+        dt = max_over_ranks(time.perf_counter() - t0, world, dev) / iters
+        recv = shard.numel() * shard.element_size() * (world - 1)
+        out[name] = {"bytes_per_rank_shard": shard.numel() * shard.element_size(), "ms": round(dt * 1e3, 3), "recv_gb_per_s_per_rank": round(recv / dt / 1e9, 2)}
+        del full
+    return out
+
+
 def create_gaussian_diffusion_for_bench(respacing):
     from humanliff_amd.improved_diffusion.script_util import create_gaussian_diffusion
     return create_gaussian_diffusion(steps=1000, timestep_respacing=respacing)
@@ -1110,6 +1134,19 @@ def main():
                     help="issue the control encoder on the caller's stream instead of the side stream (used for the "
                          "per-kernel rocprof trace: concurrent kernels stretch each other's durations)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become one - one rank per GPU under torch.distributed.run on this node (RCCL over
+        # xGMI), same arguments; the ranks' output (rank 0 prints the JSON line) passes straight through.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL / tensor sharing across processes)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     from humanliff_amd import _lib
     _lib.lib()   # fail loudly if the HIP library was not built
@@ -1119,6 +1156,7 @@ def main():
 
     secs, roof, sd, model = bench_unet(args, rank, world, dev)
     value = world * args.batch * args.steps / secs
+    rccl = collective_probe(args, rank, world, dev) if world > 1 else None
     parity = None
     if rank == 0 and world == 1 and not args.no_parity:
         chain = e2e_chain(model, dev)
@@ -1172,8 +1210,23 @@ def main():
                        "parallelism": f"replicas x{world} (subjects sharded, final all-gather only)",
                        "gflop_per_sample_step": UNET_GFLOP_PER_SAMPLE_STEP},
             "step_tflops": round(world * args.batch * args.steps * UNET_GFLOP_PER_SAMPLE_STEP / secs / 1e3, 2),
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "render": render, "fit": fit, "train": train,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "render": render, "fit": fit, "train": train, "rccl": rccl,
         }
+        # flat copies of the other headline figures: inside `roofline` (a driver that keeps its scalars keeps these) and as the LAST key of the line
+        sweep = (roof or {}).get("batch_sweep") or {}
+        summary = {"denoise_steps_per_s_b4": round(value / world, 3),
+                   "denoise_steps_per_s_b1": (sweep.get("batch1") or {}).get("eager", {}).get("value"),
+                   "denoise_steps_per_s_b8": (sweep.get("batch8") or {}).get("eager", {}).get("value"),
+                   "e2e_seconds_per_subject": (e2e or {}).get("seconds_per_subject"),
+                   "e2e_psnr_db_vs_oracle": ((e2e or {}).get("parity") or {}).get("psnr_db"),
+                   "render_mrays_per_s": (render or {}).get("value"),
+                   "render_host_inclusive_mrays_per_s": ((render or {}).get("host_inclusive") or {}).get("value"),
+                   "fit_iters_per_s": (fit or {}).get("value"), "n_gpus": world,
+                   "rccl_backend": (rccl or {}).get("backend"), "rccl_world_size": (rccl or {}).get("world_size")}
+        for k, v in summary.items():
+            if isinstance(roof, dict) and v is not None and k not in ("n_gpus",):
+                roof["hl_" + k] = v
+        line["summary"] = summary
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -38,6 +38,9 @@ _MLP_ORDER = ("pts_linears.0", "pts_linears.1", "pts_linears.2", "feature_linear
               "views_linear", "rgb_linear")
 
 
+_SIDE_STREAMS = {}   # device -> HIP streams of Renderer.subject_streams (process-wide pool)
+
+
 class Renderer(nn.Module):
     def __init__(self, use_canonical_space=True, num_instances=1, triplane_dim=256, triplane_ch=18,
                  smpl_type='smpl', test=False):
@@ -139,8 +142,11 @@ class Renderer(nn.Module):
         uniforms, otherwise they are drawn exactly like the reference does - torch.rand on the
         CPU generator, then copied to the device (renderer.py:545).  reevaluate=True makes the fine pass run
         the network on all n_samples + n_importance depths like the reference (re-evaluating the coarse
-        points); by default every point is evaluated once and the two sorted halves are merged - the images
-        are bit-identical, the default does 23 % less arithmetic.
+        points); by default every point is evaluated once and the two sorted halves are merged - 23 % less arithmetic.  With
+        mlp_products="fp32" the two schedules give bit-identical images; the default products ("bf16x3") exist in the evaluate-once
+        kernel only, so reevaluate=True runs the fp32-MFMA kernel (as do canonical-space rendering, density_grid() and training) and its
+        images differ from the default's within the fp32 tolerance (rgb 7e-7).  Precedence: mlp_fp16=True (opt-in, NOT fp32 tolerance)
+        overrides mlp_products.
 
         test=False (training mode, renderer.py:212, 280): the fine pass adds Gaussian noise to the raw densities (`noise`
         (bs*R*(n_samples+n_importance), 1) supplies it, otherwise it is drawn on the device like the reference's randn_like) and
@@ -194,9 +200,14 @@ class Renderer(nn.Module):
         rgb = torch.empty((bs, R, 3), dtype=torch.float32, device=dev)
         acc = torch.empty((bs, R), dtype=torch.float32, device=dev)
         depth = torch.empty((bs, R), dtype=torch.float32, device=dev)
-        flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0) | \
-            (_lib.HL_RENDER_REEVALUATE if reevaluate else 0) | (_lib.HL_RENDER_MLP_FP16 if getattr(self, "mlp_fp16", False) else 0) | \
-            (_lib.HL_RENDER_MLP_BF16X3 if getattr(self, "mlp_products", "fp32") == "bf16x3" else 0)
+        products = getattr(self, "mlp_products", "fp32")
+        if products not in ("bf16x3", "fp32"):
+            raise ValueError(f"Renderer.mlp_products must be 'bf16x3' or 'fp32', not {products!r}")
+        fp16 = bool(getattr(self, "mlp_fp16", False))
+        # explicit precedence: the opt-in fp16-operand kernel first; the bf16x3 products only in the evaluate-once schedule (the re-evaluating
+        # one exists on the fp32-MFMA kernel alone)
+        flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0) | (_lib.HL_RENDER_REEVALUATE if reevaluate else 0) | \
+            (_lib.HL_RENDER_MLP_FP16 if fp16 else (_lib.HL_RENDER_MLP_BF16X3 if (products == "bf16x3" and not reevaluate) else 0))
         f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
         for b in range(bs):
             pp = self._packed_planes(tri_planes[b])
@@ -243,7 +254,7 @@ class Renderer(nn.Module):
         # overlap the other's matrix-bound ones (k_march, k_mlp_bwd).  Tensors of the caller's stream that a side stream reads are
         # recorded on it (the caching allocator must not hand their memory out while the side stream still reads).
         main = torch.cuda.current_stream(dev)
-        side = self._subject_streams(dev, bs - 1) if self.subject_streams else []
+        side = self._subject_streams(dev, bs - 1) if getattr(self, "subject_streams", False) else []
         for st in side:                   # fork before anything of this call is queued: a side stream waits for the inputs only
             st.wait_stream(main)
             tri_planes.record_stream(st)
@@ -266,8 +277,8 @@ class Renderer(nn.Module):
         return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
 
     def _subject_streams(self, dev, n):
-        pool = self.__dict__.setdefault("_side_streams", {})
-        have = pool.setdefault(dev, [])
+        # (the pool lives outside the module: stream objects in an nn.Module's __dict__ would ride along into copy.deepcopy / torch.save)
+        have = _SIDE_STREAMS.setdefault(dev, [])
         while len(have) < n:
             have.append(torch.cuda.Stream(device=dev))
         return have[:n]
@@ -287,9 +298,15 @@ class Renderer(nn.Module):
             from .deform import deform_tables
             if self.SMPL_NEUTRAL is None:
                 raise RuntimeError("use_canonical_space=True needs the body model: set renderer.SMPL_NEUTRAL to the SMPL_to_tensor dict")
-            one = lambda d: {k: v[b:b + 1] for k, v in d.items()}  # noqa: E731
+            def rec(t):                   # inputs of the caller's stream that this subject's (side) stream reads
+                if side is not None and torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(side)
+                return t
+            one = lambda d: {k: rec(v[b:b + 1]) for k, v in d.items()}  # noqa: E731
+            for v in self.SMPL_NEUTRAL.values():
+                rec(v)
             dfm = deform_tables(self.SMPL_NEUTRAL, one(tp_canonical['params']), one(tp_canonical['t_params']),
-                                tp_canonical['vertices'][b:b + 1].to(dev))
+                                rec(tp_canonical['vertices'][b:b + 1].to(dev)))
         parts = []
         for i in range(0, R, rc):
             sl = slice(i, min(R, i + rc))

@@ -26,8 +26,19 @@ def _deps():
     return deps
 
 
+STAMP = LIB + ".flags"   # (next to the library: it travels with it)
+
+
+def _flag_key():
+    """Every flag the objects are compiled with (the HL_*_FLAGS developer variants included): a flags-only change must rebuild too -
+    an A / B of two -D variants that silently compares a library with itself measures nothing."""
+    return repr((HIPCC, FLAGS, sorted(FILE_FLAGS.items())))
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    if not os.path.exists(STAMP) or open(STAMP).read() != _flag_key():
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(d) > t for d in _deps())
@@ -56,6 +67,8 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
+    with open(STAMP, "w") as f:
+        f.write(_flag_key())
     return LIB
 
 

@@ -2678,8 +2678,8 @@ static inline long hw_o_early(const ConvArgs &a) { return (long)a.out.H * a.out.
 
 // k_conv_h16 is taken from this many workgroups on (HL_H16_MIN_BLOCKS overrides: the unit tests run it on single tiles)
 static long h16_min_blocks() {
-    const char *e = getenv("HL_H16_MIN_BLOCKS");
-    return e ? atol(e) : 48;
+    static const long v = [] { const char *e = getenv("HL_H16_MIN_BLOCKS"); return e ? atol(e) : 48L; }();   // (read once)
+    return v;
 }
 
 int conv2d(const ConvArgs &a, hipStream_t st) {

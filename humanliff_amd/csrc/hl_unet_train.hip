@@ -675,8 +675,10 @@ int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const f
 int hl_conv2d_wgrad_nhwc_ws_mode(int conv_mode, const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                                  float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream) {
     const bool h16 = (conv_mode == HL_CONV_FP16 || conv_mode == HL_CONV_BF16) && ks == 3 && stride == 1;
-    HL_REQUIRE(wgrad_t_applies(Cx, Cy, ks, stride, upsample), "hl_conv2d_wgrad_nhwc_ws: channel counts (x %d, dy %d) must be multiples of 4 (the atomics-based "
+    HL_REQUIRE(Cx % 4 == 0 && Cy % 4 == 0, "hl_conv2d_wgrad_nhwc_ws: channel counts (x %d, dy %d) must be multiples of 4 (the atomics-based "
                "fallback for other counts is gone: every kernel of the training step sums in a fixed order)", Cx, Cy);
+    HL_REQUIRE(wgrad_t_applies(Cx, Cy, ks, stride, upsample), "hl_conv2d_wgrad_nhwc_ws: a %dx%d convolution with stride %d%s has no weight-gradient kernel "
+               "(3x3: stride 1 / 2 / behind an upsample; 1x1: stride 1 only - the UNet has no other)", ks, ks, stride, upsample ? " behind an upsample" : "");
     HL_REQUIRE(x && dy && dw, "hl_conv2d_wgrad_nhwc_ws: null argument");
     HL_REQUIRE(stride == 1 || (stride == 2 && !upsample), "hl_conv2d_wgrad_nhwc_ws: stride");
     HL_REQUIRE(Cin <= Cx && Cout <= Cy, "hl_conv2d_wgrad_nhwc_ws: channel counts (x %d, dy %d) must cover the weight (%d, %d)", Cx, Cy, Cout, Cin);

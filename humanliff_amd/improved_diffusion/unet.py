@@ -333,15 +333,6 @@ class UNetModel(nn.Module):
     def _any_param_requires_grad(self):
         return any(p.requires_grad for p in self.parameters())
 
-    def forward_autograd(self, x, timesteps, x_cond=None, y=None):
-        """The same function in plain PyTorch ops, differentiable (unet_autograd.py): the CPU-checkable statement of the network that
-        the gradient tests compare with the reference's vectors and with the HIP training path.  Nothing in the product calls it:
-        training goes through forward() -> unet_train.forward_train (HIP forward and backward), sampling through the HIP forward."""
-        from .unet_autograd import forward_autograd
-        if th.is_grad_enabled():
-            self._hip_stale = True     # a differentiable call: parameters may be updated behind Tensor._version (see _bind)
-        return forward_autograd(self, x, timesteps, x_cond, y)
-
     def forward(self, x, timesteps, x_cond=None, y=None):
         """Same contract as the reference: x (N,C,H,W), timesteps (N,), x_cond (N,C,H,W), y (N,) -> (N,C_out,H,W)."""
         if self.num_classes is not None:

@@ -20,7 +20,7 @@ The (N, 768)-sized embedding MLP (time_embed, label_emb, the ResBlocks' emb_laye
 concatenations are torch tensor ops.  No convolution, normalisation or attention runs through MIOpen / torch.nn.functional.
 
 UNetModel.forward takes this path when gradients are enabled on a model in training mode (unet.py); the samplers (no_grad, eval) never
-do.  The PyTorch-op twin (unet_autograd.py) remains as the CPU-checkable statement of the same function that the gradient tests compare
+do.  The PyTorch-op twin (tests/unet_autograd_twin.py, test infrastructure) remains as the CPU-checkable statement of the same function that the gradient tests compare
 both against the reference's vectors.
 """
 import ctypes as C
@@ -129,11 +129,10 @@ class _Conv(th.autograd.Function):
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dy2 = _pad_c(dy, 4)
             geom = (N, x.shape[1], x.shape[2], x.shape[3], dy2.shape[-1], ks, stride, ups, Cout, Cin)
-            nbytes = L.hl_conv2d_wgrad_scratch_bytes(*geom)          # per-slab partial blocks (0: odd channel counts, per-tap kernel)
+            nbytes = L.hl_conv2d_wgrad_scratch_bytes(*geom)          # per-slab partial blocks (the kernels store every element of dw / db)
             part = th.empty(max(1, nbytes // 4), device=dy.device, dtype=th.float32)
-            alloc = th.empty if nbytes else th.zeros                 # the slab kernels store, the per-tap kernel adds with atomics
-            dw = alloc(w4.shape, device=dy.device, dtype=th.float32)
-            db = alloc((Cout,), device=dy.device, dtype=th.float32) if has_b else None
+            dw = th.empty(w4.shape, device=dy.device, dtype=th.float32)
+            db = th.empty((Cout,), device=dy.device, dtype=th.float32) if has_b else None
             with _lib.on(dy.device):
                 _lib.check(L.hl_conv2d_wgrad_nhwc_ws_mode(bmode, _lib.ptr(x), N, x.shape[1], x.shape[2], x.shape[3], _lib.ptr(dy2), dy2.shape[-1], ks,
                                                           stride, ups, _lib.ptr(dw), Cout, Cin, _lib.ptr(db), _lib.ptr(part), nbytes, _lib.stream_ptr()),
@@ -348,6 +347,10 @@ class GraphedTrainStep:
     def __init__(self, diffusion, model, optimizer, x_start, x_cond, t, model_kwargs=None, *, autocast=None, with_noise=False, warmup=3):
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainStep needs a capturable optimizer, e.g. torch.optim.AdamW(params, fused=True, capturable=True)")
+        if not isinstance(optimizer, (th.optim.Adam, th.optim.AdamW)):
+            # the warm-up below resets a FRESH optimizer's state to zeros - right for Adam / AdamW (zero moments, step 0), wrong for
+            # optimizers whose initial state is not zero (NAdam mu_product = 1, Rprop step_size = lr, ASGD eta / mu)
+            raise ValueError("GraphedTrainStep supports torch.optim.Adam / AdamW (capturable=True)")
         self.model, self.optimizer = model, optimizer
         clone = lambda v: v.detach().clone() if th.is_tensor(v) else v  # noqa: E731
         self._x, self._t = clone(x_start), clone(t)
@@ -368,6 +371,9 @@ class GraphedTrainStep:
         tensors = lambda p: {k: v.detach().clone() for k, v in optimizer.state[p].items() if th.is_tensor(v)}  # noqa: E731
         fresh = not any(len(optimizer.state.get(p, {})) for p in params)
         saved_s = None if fresh else [tensors(p) for p in params]
+        # the warm-up must leave no trace in the device RNG stream (dropout, q_sample noise): the eager run that did not warm up draws the same numbers.
+        # (.grad belongs to the graph from here on: gradients accumulated before construction are discarded - step() leaves each replay's in place)
+        rng_state = th.cuda.get_rng_state(self._x.device)
         side = th.cuda.Stream(device=self._x.device)
         side.wait_stream(th.cuda.current_stream(self._x.device))
         with th.cuda.stream(side):
@@ -388,6 +394,7 @@ class GraphedTrainStep:
                     for k, v in s_.items():
                         optimizer.state[p][k].copy_(v)
         th.cuda.current_stream(self._x.device).wait_stream(side)
+        th.cuda.set_rng_state(rng_state, self._x.device)
         self.graph = th.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         with th.cuda.graph(self.graph):

@@ -404,7 +404,8 @@ int hl_conv2d_nhwc_bwd_data(int conv_mode, const float *dy, int N, int Ho, int W
  * dW for all nine taps; dY rows and input patch of an 8x8-pixel tile staged in LDS once); 1x1 layers: k_conv_wgrad_1x1 (192 x 64 channel
  * block, 64-pixel tiles).  Per-slab partial blocks go to `scratch` and k_wgrad_finish sums them in a fixed order: dw / db are plainly
  * stored (no need to zero them) and bit-reproducible.  Needs Cx, Cy multiples of 4 and `scratch` of
- * hl_conv2d_wgrad_scratch_bytes(...) bytes; other channel counts are refused (the atomics-based entry of rounds 2-3 is gone). */
+ * hl_conv2d_wgrad_scratch_bytes(...) bytes (0 = this geometry has no kernel: channel counts that are not multiples of 4, or a 1x1
+ * convolution with stride 2 / behind an upsample - hl_conv2d_wgrad_nhwc_ws refuses those; the atomics-based entry of rounds 2-3 is gone). */
 size_t hl_conv2d_wgrad_scratch_bytes(int N, int H, int W, int Cx, int Cy, int ks, int stride, int upsample, int Cout, int Cin);
 int hl_conv2d_wgrad_nhwc_ws(const float *x, int N, int H, int W, int Cx, const float *dy, int Cy, int ks, int stride, int upsample,
                             float *dw, int Cout, int Cin, float *db, void *scratch, size_t scratch_bytes, void *stream);

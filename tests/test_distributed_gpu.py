@@ -142,3 +142,27 @@ def test_eight_ranks_sixty_four_subjects_rehearsal(tmp_path):
     want_smp, want_img, _ = _flow(dev, n_subjects=8, batch=8)
     assert torch.equal(res[0]["samples"][:8], want_smp.cpu()) and torch.equal(img[:8], want_img.cpu())
     assert len({float(res[0]["samples"][i].double().sum()) for i in range(nsub)}) == nsub                # 64 different subjects
+
+
+def test_bench_self_launches_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` as the driver issues it - a plain process, no launcher, no WORLD_SIZE - must start its own ranks
+    (torch.distributed.run) and print ONE JSON line with n_gpus = 2 and the `rccl` block (ranks seen, backend, gather rates).  Rehearsed
+    with HL_BENCH_BACKEND=gloo: both ranks share the one GPU of this box; on an 8-GPU node the same path runs on RCCL."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env["HL_BENCH_BACKEND"] = "gloo"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "1", "--sustained-steps", "0",
+           "--no-cpu-baseline", "--no-parity", "--no-batch-sweep", "--no-render", "--no-e2e", "--no-train", "--no-fit", "--no-bf16x3-leg", "--e2e-views", "4"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["metric"] == "denoise-steps/sec" and line["value"] > 0
+    assert line["rccl"]["world_size"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert line["rccl"]["sample_gather"]["recv_gb_per_s_per_rank"] > 0 and line["rccl"]["image_gather_uint8"]["ms"] > 0
+    assert line["summary"]["n_gpus"] == 2 and line["summary"]["rccl_world_size"] == 2

@@ -15,6 +15,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from tests.unet_autograd_twin import forward_autograd
 
 from tests.golden_util import GOLDEN, psnr
 from humanliff_amd import synthetic as syn
@@ -380,7 +381,7 @@ def test_unet_3d_aware_matches_reference(tag, cond):
     t, yl = torch.tensor([999, 17], device=dev), torch.tensor([3, 0], device=dev)
     with torch.no_grad():
         y = model(x.to(dev), t, xc.to(dev) if cond else None, y=yl).cpu()
-        tw = model.forward_autograd(x.to(dev), t, xc.to(dev) if cond else None, y=yl).cpu()
+        tw = forward_autograd(model, x.to(dev), t, xc.to(dev) if cond else None, y=yl).cpu()
     want = torch.from_numpy(g[f"{tag}_out"])
     assert y.shape == want.shape == (2, 27, 32, 32)
     assert (y - want).abs().max() < 1e-4 and (tw - want).abs().max() < 1e-4
@@ -410,7 +411,7 @@ def test_unet_cross_attention_matches_reference():
     with torch.no_grad():
         y = model(x.to(dev), t, xc.to(dev), y=yl).cpu()
         y0 = model(x.to(dev), t, torch.zeros_like(xc).to(dev), y=yl).cpu()
-        tw = model.forward_autograd(x.to(dev), t, xc.to(dev), y=yl).cpu()
+        tw = forward_autograd(model, x.to(dev), t, xc.to(dev), y=yl).cpu()
     assert (y[:, :, ::8, ::8] - torch.from_numpy(g["xattn_out_s8"])).abs().max() < 1e-4
     n = y.numel()
     assert abs(float(y.double().sum()) - g["xattn_sums"][0]) < 2e-5 * n and abs(float(y.double().abs().sum()) - g["xattn_sums"][1]) < 2e-5 * n
@@ -446,7 +447,7 @@ def test_unet_adagn_matches_reference():
     assert abs(float((y - y0).abs().max()) - float(g["adagn_cond_effect"])) < 1e-3          # the condition acts through the embedding
     # the differentiable twin (and with it the training path's embedding) states the same function
     with torch.no_grad():
-        tw = model.forward_autograd(x.to(dev), t, xc.to(dev), y=yl).cpu()
+        tw = forward_autograd(model, x.to(dev), t, xc.to(dev), y=yl).cpu()
     assert (tw - y).abs().max() < 1e-4
 
 

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from tests.unet_autograd_twin import forward_autograd
 import torch.nn.functional as F
 
 from tests.golden_util import GOLDEN
@@ -444,7 +445,7 @@ def test_training_path_matches_inference_forward_and_twin():
     with torch.no_grad():
         hip = model(x0, t, xc, y=y)
         train = forward_train(model, x0, t, xc, y)
-        twin = model.forward_autograd(x0, t, xc, y=y)
+        twin = forward_autograd(model, x0, t, xc, y=y)
     scale = max(1.0, float(twin.abs().max()))
     assert (hip - train).abs().max() < 5e-5 * scale            # same kernels, different fusion (materialised GroupNorm, no concat buffers)
     assert (hip - twin).abs().max() < 2e-4 * scale             # MIOpen vs the HIP kernels: different summation orders

@@ -1,7 +1,7 @@
 """UNetModel.forward in plain PyTorch ops, differentiable - the CPU-checkable statement of the network.
 
-Nothing in the product calls this: sampling runs the fused HIP forward (unet.py -> hl_unet_forward), training the HIP forward +
-backward behind autograd.Functions (unet_train.py).  It exists for the gradient tests: tests/test_train_loss_cpu.py pins it to the
+TEST INFRASTRUCTURE (it lives under tests/, outside the product package): sampling runs the fused HIP forward (unet.py ->
+hl_unet_forward), training the HIP forward + backward behind autograd.Functions (unet_train.py).  It exists for the gradient tests: tests/test_train_loss_cpu.py pins it to the
 reference's loss and parameter gradients on the CPU, tests/test_unet_train_gpu.py pins the HIP training path to the same vectors (with
 this module patched to raise), and tests/test_unet_gpu.py checks that all three statements agree on the GPU; scripts/unet_train_bench.py
 can time it (MIOpen / rocBLAS) next to the HIP path.
@@ -16,7 +16,7 @@ import math
 import torch as th
 import torch.nn.functional as F
 
-from . import unet as U
+from humanliff_amd.improved_diffusion import unet as U
 
 
 def _embedding(timesteps, dim, max_period=10000):
