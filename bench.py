@@ -739,6 +739,36 @@ def bench_render(args, rank, world, dev):
     barrier(world)
     secs = max_over_ranks(time.perf_counter() - t0, world, dev)
     assert torch.isfinite(imgs[0]).all()
+    # ---- host-inclusive leg: the DROP-IN call, u = None - sample_pdf's uniforms are the reference's (torch.rand of the CPU generator,
+    # renderer.py:545), per view: continued on the device from the CPU generator's state (NeRF/cpu_rng.py), and, beside it, drawn on the host ----
+    host_incl = None
+    if world == 1:
+        def one_none(v):
+            ro, rd, nr, fr = rays[v]
+            return r.render(tp, None, None, ro[None], rd[None], nr[None], fr[None], planes, N, False, n_samples=N, u=None)
+        hv = min(views, 8)
+        rows = {}
+        for host in (False, True):
+            r.cpu_uniforms_on_host = host
+            torch.manual_seed(5)
+            one_none(views)
+            torch.cuda.synchronize()
+            th0 = time.perf_counter()
+            for v in range(hv):
+                last = one_none(v)["rgb_map"]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - th0
+            rows["host_draw" if host else "device_draw"] = {"value": round(hv * H * W / dt / 1e6, 4), "ms_per_view": round(dt * 1e3 / hv, 3)}
+            assert torch.isfinite(last).all()
+            if host:
+                same = torch.equal(last, keep)
+            keep = last
+        r.cpu_uniforms_on_host = False
+        host_incl = {"value": rows["device_draw"]["value"], "unit": "Mrays/s", "views": hv, "ms_per_view": rows["device_draw"]["ms_per_view"],
+                     "what": "Renderer.render(..., u=None) per view - the reference's call: sample_pdf's uniforms are torch.rand of the CPU generator (134 MB per "
+                             "512x512 view).  Default: the device continues the CPU generator's mt19937 stream bit for bit (hl_mt19937_uniform, beside the "
+                             "coarse pass) and the host generator is advanced; host_draw: drawn on the host and uploaded, as the reference does it literally",
+                     "host_draw": rows["host_draw"], "images_bit_equal_between_the_two": bool(same)}
     # ---- roofline leg: the four stages of one view (the default evaluate-once schedule) timed with events on the launch stream ----
     L = _lib.lib()
     R = H * W
@@ -840,6 +870,7 @@ def bench_render(args, rank, world, dev):
                                      "stay fp32.  NOT used for `value`",
                              "value": round(views * R / d16 / 1e6, 4), "unit": "Mrays/s", "ms_per_view": round(d16 * 1e3 / views, 3),
                              "psnr_db_vs_fp32_views": [round(x, 1) for x in ps], "finite": bool(torch.isfinite(imgs16[0]).all())}
+    roof["host_inclusive"] = host_incl
     return secs, roof, views * R
 
 
@@ -1188,7 +1219,7 @@ def main():
         render = {"metric": "Mrays/sec@256spp", "value": round(world * rays_per_rank / rsecs / 1e6, 4), "unit": "Mrays/s",
                   "dtype": "f32 results; MLP products = bf16x3 (exact three-way bf16 splits, six partial products, fp32 accumulation - fp32 tolerance, same test "
                            "bounds as the fp32-MFMA kernel whose figure is roofline.fp32_products)",
-                  "views_per_gpu": args.views, "ms_per_view": round(rsecs * 1e3 / args.views, 3), "roofline": rroof,
+                  "views_per_gpu": args.views, "ms_per_view": round(rsecs * 1e3 / args.views, 3), "host_inclusive": rroof.pop("host_inclusive", None), "roofline": rroof,
                   "config": {"workload": "configs[2]: tri-plane NeRF render 512x512, n_samples=128 + n_importance=128, "
                                          "views of a 36-view orbit, random 256x256x27 tri-plane", "rays_per_view": 512 * 512}}
     fit = None

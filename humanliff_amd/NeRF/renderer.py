@@ -69,6 +69,8 @@ class Renderer(nn.Module):
         # (recon_NeRF/lib/renderer.py:288) does not clamp and clears the second flag
         self._depth_flags = _lib.HL_RENDER_NORMALIZE_DEPTH | _lib.HL_RENDER_CLAMP_DEPTH
         self.uniforms_on_device = False      # extension: draw sample_pdf's uniforms with the device generator (see render())
+        self.cpu_uniforms_on_host = False    # True: draw the reference's CPU-generator uniforms on the host and upload them (renderer.py:545 literally);
+                                             # default: the SAME numbers continued on the device from the CPU generator's state (NeRF/cpu_rng.py)
         self.subject_streams = False         # extension, opt-in: training mode puts subjects after the first on their own HIP streams (see
                                              # _render_training; +4 % on the fitting step with device uniforms, and PyTorch warns once that the
                                              # parameters' AccumulateGrad nodes sit on another stream than the gradients)
@@ -180,6 +182,7 @@ class Renderer(nn.Module):
             n_samples = z_vals.shape[2]
         assert n_samples is not None and n_samples >= 2
         bounds = tp_input['t_world_bounds' if self.use_canonical_space else 'world_bounds'].reshape(bs, 2, 3)
+        pending_draw = None
         if n_importance > 0:
             assert n_importance == n_samples, \
                 "the reference reshapes coarse densities to n_importance (renderer.py:250): counts must match"
@@ -188,8 +191,16 @@ class Renderer(nn.Module):
                 # (an extension, off by default) draws them on the device instead: same distribution, no 2 MB upload per fitting step
                 # The CPU draw lands in pinned memory and is uploaded asynchronously: the same values from the same generator, without
                 # the stream-draining synchronous copy of pageable memory that cost the fitting loop its run-ahead (0.8 ms per step).
-                u = torch.rand([bs * R, n_importance], device=dev) if self.uniforms_on_device else \
-                    torch.rand([bs * R, n_importance], pin_memory=True).to(dev, non_blocking=True)
+                if self.uniforms_on_device:
+                    u = torch.rand([bs * R, n_importance], device=dev)
+                elif self.test and not getattr(self, "cpu_uniforms_on_host", False) and bs * R * n_importance >= (1 << 16):
+                    # the reference's numbers (torch.rand of the CPU generator), written by the device: the host generator is advanced below,
+                    # once everything of this call is enqueued (the draw of a 512x512 view costs the host 50 - 80 ms, the device runs it next to
+                    # the coarse pass)
+                    from .cpu_rng import rand_like_cpu
+                    u, pending_draw = rand_like_cpu([bs * R, n_importance], dev)
+                else:
+                    u = torch.rand([bs * R, n_importance], pin_memory=True).to(dev, non_blocking=True)
             u = u.reshape(bs, R, n_importance)
         if not self.test:
             return self._render_training(tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,
@@ -219,6 +230,8 @@ class Renderer(nn.Module):
                 _lib.ptr(fr), _lib.ptr(zb), _lib.ptr(ub), R, n_samples, n_importance, flags,
                 _lib.ptr(rgb[b]), _lib.ptr(acc[b]), _lib.ptr(depth[b]), _lib.ptr(ws), _lib.stream_ptr()),
                 "hl_render_rays")
+        if pending_draw is not None:
+            pending_draw.finish()             # the CPU generator now stands where the reference's torch.rand would have left it
         # normal_map aliases rgb_map in the reference (renderer.py:228)
         return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
 
@@ -335,8 +348,13 @@ class Renderer(nn.Module):
             n_samples = z_vals.shape[2]
         assert n_samples is not None and n_importance == n_samples, \
             "the reference reshapes coarse densities to n_importance (renderer.py:250): counts must match"
+        pending_draw = None
         if u is None:
-            u = torch.rand([R, n_importance]).to(dev)
+            if getattr(self, "cpu_uniforms_on_host", False) or R * n_importance < (1 << 16):
+                u = torch.rand([R, n_importance]).to(dev)
+            else:
+                from .cpu_rng import rand_like_cpu
+                u, pending_draw = rand_like_cpu([R, n_importance], dev)
         verts4, table, Rh, Th = deform_tables(self.SMPL_NEUTRAL, tp_input['params'], tp_input['t_params'],
                                               tp_input['vertices'].to(dev))
         L = _lib.lib()
@@ -356,6 +374,8 @@ class Renderer(nn.Module):
             _lib.ptr(ub), R, n_samples, n_importance, flags, Rh.ctypes.data, Th.ctypes.data, _lib.ptr(verts4), _lib.ptr(table),
             int(verts4.shape[0]), _lib.ptr(rgb), _lib.ptr(acc), _lib.ptr(depth), _lib.ptr(ws), _lib.stream_ptr()),
             "hl_render_rays_canonical")
+        if pending_draw is not None:
+            pending_draw.finish()
         return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
 
     # ---- the density grid behind extract_geometry ---------------------
@@ -471,6 +491,19 @@ def render(chunk=1024 * 32, rays_o=None, rays_d=None, near=0., far=1., tri_plane
         z = torch.cat(zs, 1)
     if n_importance > 0 and getattr(core, "uniforms_on_device", False):
         u = torch.rand([batch_size, R, n_importance], device=rays_o.device)      # extension, see Renderer.render
+    elif n_importance > 0 and core.test and not getattr(core, "cpu_uniforms_on_host", False) and batch_size * R * n_importance >= (1 << 16) \
+            and rays_o.is_cuda:
+        # the reference's per-chunk draws (torch.rand([bs * chunk_rays, n_importance]) per chunk) are consecutive pieces of ONE serial stream:
+        # the device continues the CPU generator's stream for all of them and the pieces are put where the chunks would have put them
+        from .cpu_rng import rand_like_cpu
+        flat, pending = rand_like_cpu([batch_size * R * n_importance], rays_o.device)
+        pieces, o = [], 0
+        for i in range(0, R, chunk):
+            cr = min(chunk, R - i)
+            pieces.append(flat[o:o + batch_size * cr * n_importance].reshape(batch_size, cr, n_importance))
+            o += batch_size * cr * n_importance
+        u = pieces[0] if len(pieces) == 1 else torch.cat(pieces, 1)
+        pending.finish()
     elif n_importance > 0:
         for i in range(0, R, chunk):
             cr = min(chunk, R - i)

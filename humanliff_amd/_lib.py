@@ -121,6 +121,8 @@ SIGNATURES = {
     "hl_attention_backward_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "hl_attention_nhwc_backward": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "hl_timestep_embedding": (_i, [_p, _p, _i, _i, _p, _p]),
+    "hl_mt19937_uniform": (_i, [_p, _i, _p, C.c_int64, _p, _p]),
+    "hl_debug_set_h16_min_blocks": (_i, [C.c_long]),
 }
 
 

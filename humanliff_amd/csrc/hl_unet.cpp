@@ -1145,6 +1145,8 @@ int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int
                          scratch, scratch_bytes, stream);
 }
 
+int hl_debug_set_h16_min_blocks(long v) { hl::set_h16_min_blocks(v); return HL_OK; }
+
 int hl_groupnorm_coef(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta, const float *emb,
                       float *coefA, float *coefB, void *scratch, size_t scratch_bytes, void *stream) {
     HL_REQUIRE(scratch && scratch_bytes >= hl::gn_scratch_floats(N) * sizeof(float), "hl_groupnorm_coef: scratch too small");

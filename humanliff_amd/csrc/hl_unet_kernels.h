@@ -104,6 +104,7 @@ bool conv_h16_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride,
 size_t conv_packed_h16_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_h16(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, int f16, hipStream_t st, int tf = 0);
 int conv_h16_launch(const ConvK &p, int f16, hipStream_t st, int splits = 1);
+void set_h16_min_blocks(long v);   // developer / test switch: workgroups from which the dispatch takes k_conv_h16 (< 0: the default, 48)
 
 // Statistics block of one normalised VIEW (ConvArgs::stats): [shard][N][32 groups][2] 64-bit fixed-point totals.  Levels with many
 // workgroups per image keep stat_shards(HW) = 8 copies (a workgroup adds to copy blockIdx.x % 8: atomics on one word serialise), the low

@@ -2676,11 +2676,14 @@ int conv_pack_weights_wino4(const float *w, int Cout, int Cin, int Cin_pad, floa
 
 static inline long hw_o_early(const ConvArgs &a) { return (long)a.out.H * a.out.W; }
 
-// k_conv_h16 is taken from this many workgroups on (HL_H16_MIN_BLOCKS overrides: the unit tests run it on single tiles)
+// k_conv_h16 is taken from this many workgroups on.  The default (48; HL_H16_MIN_BLOCKS, read ONCE) is what the network dispatch uses; the
+// unit tests that run the kernel on single tiles set it through hl_debug_set_h16_min_blocks (no getenv per convolution launch).
+static long g_h16_min_blocks = -1;
 static long h16_min_blocks() {
-    static const long v = [] { const char *e = getenv("HL_H16_MIN_BLOCKS"); return e ? atol(e) : 48L; }();   // (read once)
-    return v;
+    static const long dflt = [] { const char *e = getenv("HL_H16_MIN_BLOCKS"); return e ? atol(e) : 48L; }();
+    return g_h16_min_blocks >= 0 ? g_h16_min_blocks : dflt;
 }
+void set_h16_min_blocks(long v) { g_h16_min_blocks = v; }
 
 int conv2d(const ConvArgs &a, hipStream_t st) {
     a.path = 0;

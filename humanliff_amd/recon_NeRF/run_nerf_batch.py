@@ -17,6 +17,9 @@ class _Bare:
     def __init__(self, core):
         self.core = core
 
+    def __getattr__(self, name):            # (test, uniforms_on_device, cpu_uniforms_on_host ...: the module's own switches)
+        return getattr(self.__dict__["core"], name)
+
     def render(self, tp_input, world_pts, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance=128, white_bkgd=False, **kw):
         from ..NeRF.renderer import Renderer as _Renderer
         return _Renderer.render(self.core, tp_input, world_pts, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance, white_bkgd, **kw)

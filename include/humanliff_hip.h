@@ -465,6 +465,17 @@ int hl_attention_nhwc_backward(const float *qkv, const float *out, const float *
 /* timestep_embedding (nn.py:103-121): t int64 (B) or t_float fp32 (B) -> out (B, dim), dim even */
 int hl_timestep_embedding(const int64_t *t, const float *t_float, int B, int dim, float *out, void *stream);
 
+/* Developer / test switch: the number of workgroups from which the convolution dispatch takes k_conv_h16 in the 16-bit modes (default 48,
+ * or HL_H16_MIN_BLOCKS read once at the first launch); v < 0 restores the default.  The unit tests run the kernel on single tiles with it. */
+int hl_debug_set_h16_min_blocks(long v);
+
+/* sample_pdf's uniforms on the device, bit for bit (replaces `u = torch.rand(...)` on the CPU generator + upload, NeRF/renderer.py:545):
+ * continues the mt19937 stream of ATen's CPU generator from `state` (624 words, device) at position `pos` (words of the current block
+ * already drawn; 624 = block used up, also the freshly seeded generator) and writes the next n floats u = (word & (2^24 - 1)) * 2^-24 to
+ * out; state_out (625 words, device) receives the state and position behind the last number - the host side advances its generator
+ * with it (humanliff_amd/NeRF/cpu_rng.py).  One workgroup; enqueue-only. */
+int hl_mt19937_uniform(const uint32_t *state, int pos, float *out, int64_t n, uint32_t *state_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

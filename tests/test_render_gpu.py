@@ -499,3 +499,64 @@ def test_canonical_density_grid_matches_oracle(dev):
     err = (u.reshape(-1) + sig).abs()
     assert (err < 5e-5).float().mean() > 0.999          # near-tie nearest vertices may resolve differently in float32
     assert torch.isfinite(u).all()
+
+
+@pytest.mark.parametrize("seed,burn,shape", [(0, 0, (4096, 128)), (12345, 17, (1000, 32)), (2 ** 40 + 7, 700, (257, 129)), (5, 623, (65536, 1))])
+def test_device_mt19937_continues_the_cpu_generator_bit_for_bit(seed, burn, shape, dev):
+    """sample_pdf's uniforms (`u = torch.rand(...)` on the CPU generator, NeRF/renderer.py:545) drawn by the device from the CPU generator's
+    state: the same bits as torch.rand, from any position of the 624-word block (fresh seed, mid-block, last word), ragged sizes, and the
+    CPU generator ends up in exactly the state torch.rand would have left it in - also across chunked consecutive draws."""
+    from humanliff_amd.NeRF.cpu_rng import rand_like_cpu
+    torch.manual_seed(seed)
+    if burn:
+        torch.rand(burn)
+    st = torch.get_rng_state()
+    want = torch.rand(shape)
+    want2 = torch.rand(1000)                       # what the NEXT host draw must be
+    st_after = torch.get_rng_state()
+    torch.set_rng_state(st)
+    got, pend = rand_like_cpu(list(shape), dev)
+    assert torch.equal(torch.get_rng_state(), st)  # the host generator has not moved yet
+    pend.finish()
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(torch.rand(1000), want2) and torch.equal(torch.get_rng_state(), st_after)
+    # three consecutive device draws = one stream
+    torch.set_rng_state(st)
+    n = int(np.prod(shape))
+    cuts = [0, n // 3, n // 3 + 625, n]
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            p_, pe = rand_like_cpu([b - a], dev)
+            pe.finish()
+            parts.append(p_)
+    assert torch.equal(torch.cat(parts).cpu(), want.reshape(-1))
+
+
+def test_render_with_u_none_replays_the_reference_call_on_the_device(dev):
+    """The drop-in call (u = None): render() draws the reference's CPU-generator uniforms on the device - same images as with host-drawn
+    uniforms, bit for bit, chunked call pattern included, and the CPU generator advanced identically."""
+    from humanliff_amd import synthetic as syn
+    from humanliff_amd.NeRF import Renderer, render
+    rend = Renderer(use_canonical_space=False, triplane_dim=64, triplane_ch=27, smpl_type="smpl", test=True)
+    rend.load_state_dict(syn.render_mlp_state(3, gain=2.0), strict=False)
+    rend = rend.to(dev)
+    g = torch.Generator().manual_seed(11)
+    planes = (torch.randn((1, 3, 9, 64, 64), generator=g) * 0.3).clamp(-1, 1).to(dev)
+    R = 3000                                        # ragged against the chunk below
+    ro = torch.tensor([0.0, 0.0, -3.0]).expand(1, R, 3).contiguous().to(dev)
+    rd = torch.nn.functional.normalize(torch.randn((1, R, 3), generator=g) * 0.15 + torch.tensor([0.0, 0.0, 1.0]), dim=-1).to(dev)
+    near, far = torch.full((1, R), 2.0, device=dev), torch.full((1, R), 4.0, device=dev)
+    tp = {"world_bounds": torch.tensor([[[-1.0, -1.1, -1.0], [1.0, 1.1, 1.0]]], device=dev)}
+    outs, states = [], []
+    for host in (True, False):
+        rend.cpu_uniforms_on_host = host
+        torch.manual_seed(77)
+        torch.rand(5)
+        outs.append(render(chunk=1024, rays_o=ro, rays_d=rd, near=near, far=far, tri_planes=planes, tp_input=tp, renderer=rend, n_samples=32,
+                           n_importance=32))
+        states.append(torch.get_rng_state())
+    assert torch.equal(states[0], states[1])
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert float(outs[0][1].max()) > 0.5            # (the rays hit the volume)

@@ -441,13 +441,22 @@ def test_16bit_weight_gradient_equals_the_gradient_of_the_rounded_operands(kind)
         assert ew < 2e-5 and eb < 1e-5, (N, H, W, C, Co, ew, eb)
 
 
+@pytest.fixture
+def h16_single_tiles():
+    """The dispatch takes k_conv_h16 from 48 workgroups on; these unit tests run it on single tiles too (hl_debug_set_h16_min_blocks)."""
+    from humanliff_amd import _lib
+    L = _lib.lib()
+    L.hl_debug_set_h16_min_blocks(1)
+    yield
+    L.hl_debug_set_h16_min_blocks(-1)
+
+
 @pytest.mark.parametrize("f16", [0, 1])
-def test_conv_h16_equals_the_convolution_of_the_rounded_operands(f16, monkeypatch):
+def test_conv_h16_equals_the_convolution_of_the_rounded_operands(f16, h16_single_tiles):
     """k_conv_h16 through the C ABI (hl_conv2d_nhwc_mode / hl_conv2d_nhwc_gn): the kernel's result is the float64 convolution of the operands
     rounded to 16 bits, up to fp32 summation - ragged tile counts, a residual, the GroupNorm + SiLU pre-pass, the emitted GroupNorm statistics."""
     from humanliff_amd import _lib
     L = _lib.lib()
-    monkeypatch.setenv("HL_H16_MIN_BLOCKS", "1")             # (the dispatch takes the kernel from 48 workgroups on; here also single tiles)
     mode, dt = (_lib.HL_CONV_FP16, torch.float16) if f16 else (_lib.HL_CONV_BF16, torch.bfloat16)
     for (N, H, W, C, Co, use_res, gn, ups) in ((1, 16, 16, 32, 192, 0, 0, 0), (2, 48, 80, 64, 384, 1, 0, 0), (3, 32, 16, 96, 192, 1, 1, 0), (2, 16, 24, 64, 192, 1, 0, 1)):
         g = torch.Generator().manual_seed(N + C)
@@ -581,13 +590,12 @@ def test_no_scale_shift_norm_and_dropout_on_hip():
 
 
 @pytest.mark.parametrize("f16", [0, 1])
-def test_conv1_h16_equals_the_product_of_the_rounded_operands(f16, monkeypatch):
+def test_conv1_h16_equals_the_product_of_the_rounded_operands(f16, h16_single_tiles):
     """k_conv1_h16 (1x1 layers of the 16-bit modes: 256 pixels x 192 channels per workgroup, chunks of 96 input channels) through the C ABI:
     the float64 product of the operands rounded to 16 bits up to fp32 summation; residual, GroupNorm pre-pass (no SiLU: the qkv convolution),
     a channel pitch on the input (a slice of a concat buffer is what the decoder's skip convolutions read)."""
     from humanliff_amd import _lib
     L = _lib.lib()
-    monkeypatch.setenv("HL_H16_MIN_BLOCKS", "1")
     mode, dt = (_lib.HL_CONV_FP16, torch.float16) if f16 else (_lib.HL_CONV_BF16, torch.bfloat16)
     for (N, H, W, C, Co, use_res, gn) in ((2, 16, 16, 96, 192, 0, 0), (1, 32, 32, 384, 384, 1, 0), (2, 16, 32, 192, 576, 1, 1), (1, 16, 16, 1344, 192, 0, 0)):
         g = torch.Generator().manual_seed(N + C)
