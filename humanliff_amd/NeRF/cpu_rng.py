@@ -64,10 +64,11 @@ class PendingDraw:
 _SIDE = {}
 
 
-def rand_like_cpu(shape, device):
+def rand_like_cpu(shape, device, defer_wait=False):
     """`torch.rand(shape)` of the CPU generator, bit for bit, as a device tensor - drawn by the device on a side stream (it overlaps whatever
     the caller has queued; consumers on the current stream wait for it).  Returns (u, pending): call pending.finish() once the rest of
-    the work is enqueued; until then the CPU generator has not moved."""
+    the work is enqueued; until then the CPU generator has not moved.  defer_wait=True: the current stream is NOT made to wait here - the
+    caller orders its consumer behind pending.u_event itself (hl_render_rays_u_event: only the importance-sampling launch waits)."""
     L = _lib.lib()
     n = int(np.prod(shape))
     state = torch.get_rng_state()
@@ -79,18 +80,22 @@ def rand_like_cpu(shape, device):
     if side is None:
         side = _SIDE[device] = torch.cuda.Stream(device=device)
     with _lib.on(device):
-        u = torch.empty(shape, dtype=torch.float32, device=device)
-        side.wait_stream(cur)                       # (u's memory may have been in use on the current stream)
         with torch.cuda.stream(side):
+            # (everything the generator touches is allocated on ITS stream: it does not wait for what the caller has queued - the draw for
+            #  view k + 1 runs beside the fine pass of view k)
+            u = torch.empty(shape, dtype=torch.float32, device=device)
             st_in = host_in.to(device, non_blocking=True)
             st_out = torch.empty(_N + 1, dtype=torch.int32, device=device)
             _lib.check(L.hl_mt19937_uniform(_lib.ptr(st_in, torch.int32), pos, _lib.ptr(u), n, _lib.ptr(st_out, torch.int32), _lib.stream_ptr()), "hl_mt19937_uniform")
+            u_ev = torch.cuda.Event()
+            u_ev.record(side)
             host_out.copy_(st_out, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(side)
-        for t in (u, st_in, st_out):
-            t.record_stream(side)
-        cur.wait_stream(side)                       # consumers of u on the current stream
+        u.record_stream(cur)                        # (consumed on the caller's stream)
+        if not defer_wait:
+            cur.wait_event(u_ev)                    # consumers of u on the current stream
     pend = PendingDraw(state, host_out, ev)
+    pend.u_event = u_ev
     pend._keep = (host_in, st_in, st_out)
     return u, pend

@@ -198,7 +198,7 @@ class Renderer(nn.Module):
                     # once everything of this call is enqueued (the draw of a 512x512 view costs the host 50 - 80 ms, the device runs it next to
                     # the coarse pass)
                     from .cpu_rng import rand_like_cpu
-                    u, pending_draw = rand_like_cpu([bs * R, n_importance], dev)
+                    u, pending_draw = rand_like_cpu([bs * R, n_importance], dev, defer_wait=True)
                 else:
                     u = torch.rand([bs * R, n_importance], pin_memory=True).to(dev, non_blocking=True)
             u = u.reshape(bs, R, n_importance)
@@ -225,9 +225,11 @@ class Renderer(nn.Module):
             zb = f32(z_vals[b]) if z_vals is not None else None
             ub = f32(u[b]) if n_importance > 0 else None
             ro, rd, nr, fr, bd = f32(rays_o[b]), f32(rays_d[b]), f32(near[b]), f32(far[b]), f32(bounds[b])
-            _lib.check(L.hl_render_rays(
+            # (u drawn by the device on a side stream: only the importance-sampling launch waits for it, the coarse pass runs beside the generator)
+            u_ev = pending_draw.u_event.cuda_event if pending_draw is not None else None
+            _lib.check(L.hl_render_rays_u_event(
                 _lib.ptr(packed), _lib.ptr(pp), H, W, _lib.ptr(bd), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(nr),
-                _lib.ptr(fr), _lib.ptr(zb), _lib.ptr(ub), R, n_samples, n_importance, flags,
+                _lib.ptr(fr), _lib.ptr(zb), _lib.ptr(ub), u_ev, R, n_samples, n_importance, flags,
                 _lib.ptr(rgb[b]), _lib.ptr(acc[b]), _lib.ptr(depth[b]), _lib.ptr(ws), _lib.stream_ptr()),
                 "hl_render_rays")
         if pending_draw is not None:

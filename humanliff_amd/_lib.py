@@ -61,6 +61,7 @@ SIGNATURES = {
     "hl_planes_pack": (_i, [_p, _i, _i, _p, _p]),
     "hl_render_workspace_bytes": (_sz, [_i64, _i, _i]),
     "hl_render_rays": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _u, _p, _p, _p, _p, _p]),
+    "hl_render_rays_u_event": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _u, _p, _p, _p, _p, _p]),
     "hl_render_coarse": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p]),
     "hl_render_importance": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _p, _p]),
     "hl_deform_points": (_i, [_p, _p, _p, _p, _p, _p, _i, _i64, _p, _p, _p, _p]),

@@ -8,9 +8,10 @@
 // host generator is advanced as if it had drawn them: a drop-in call with u = None sees the reference's numbers.
 //
 // mt19937 is a linear recurrence x[k+624] = x[k+397] ^ twist(x[k], x[k+1]): 227 consecutive words are independent of each other, so one
-// regeneration of the 624-word block is three dependent phases (words 0..226, 227..453, 454..623) of one workgroup, ping-ponging between two
-// LDS images (no read / write overlap inside a phase), each new word tempered, masked and stored as it is formed.  One workgroup of 256
-// threads: ~0.3 us per block of 624 numbers; the launch runs next to the coarse evaluate pass, whose output k_importance needs first anyway.
+// regeneration of the 624-word block is three dependent phases (words 0..226, 227..453, 454..623).  Thread t forms words t, t + 227, t + 454:
+// the lag-397 operand of a phase is the word the same thread formed in the phase before, so a block needs ONE barrier (two LDS images, the
+// previous block is only read), each new word tempered, masked and stored as it is formed.  One workgroup of 256 threads; the launch runs
+// on its own stream next to the evaluate passes (the importance-sampling launch alone waits for it, hl_render_rays_u_event).
 #include "hl_common.h"
 
 namespace {
@@ -43,33 +44,35 @@ __global__ __launch_bounds__(256) void k_mt19937_uniform(const unsigned *__restr
         done = cnt;
         pos += (int)cnt;
     }
+    // One regeneration per barrier: thread t < 227 forms words t, t + 227 and t + 454 - the lag-397 operand of the second and third is the word
+    // the SAME thread has just formed (x[k + 397 - 624] = x[k - 227]), so only values of the previous block are read from LDS (all reads of a
+    // thread are issued together: one LDS latency per block); word 623 twists with the NEW word 0, which its thread forms again for itself.
+    const int k2 = tid + (MT_N - MT_M), k3 = tid + 2 * (MT_N - MT_M);
+    const bool act = tid < MT_N - MT_M, has3 = k3 < MT_N;
     while (done < n) {
         const unsigned *o = buf[cur];
         unsigned *w = buf[cur ^ 1];
         const long left = n - done;
-        // phase 1: words 0..226 from the old block alone
-        if (tid < MT_N - MT_M) {
-            const unsigned y = o[tid + MT_M] ^ mt_twist(o[tid], o[tid + 1]);
-            w[tid] = y;
-            if (tid < left) out[done + tid] = mt_uniform(y);
+        if (act) {
+            const unsigned a0 = o[tid], a1 = o[tid + 1], am = o[tid + MT_M], b0 = o[k2], b1 = o[k2 + 1];
+            const unsigned c0 = has3 ? o[k3] : 0u, c1o = (has3 && k3 + 1 < MT_N) ? o[k3 + 1] : 0u;
+            const unsigned n0 = o[MT_M] ^ mt_twist(o[0], o[1]);          // the new word 0 (broadcast reads)
+            const unsigned y1 = am ^ mt_twist(a0, a1);
+            const unsigned y2 = y1 ^ mt_twist(b0, b1);
+            w[tid] = y1;
+            w[k2] = y2;
+            if (tid < left) out[done + tid] = mt_uniform(y1);
+            if (k2 < left) out[done + k2] = mt_uniform(y2);
+            if (has3) {
+                const unsigned y3 = y2 ^ mt_twist(c0, k3 == MT_N - 1 ? n0 : c1o);
+                w[k3] = y3;
+                if (k3 < left) out[done + k3] = mt_uniform(y3);
+            }
         }
-        __syncthreads();
-        // phase 2: words 227..453 (x[k+397-624] = the new words 0..226)
-        if (tid < MT_N - MT_M) {
-            const int k = tid + (MT_N - MT_M);
-            const unsigned y = w[k - (MT_N - MT_M)] ^ mt_twist(o[k], o[k + 1]);
-            w[k] = y;
-            if (k < left) out[done + k] = mt_uniform(y);
-        }
-        __syncthreads();
-        // phase 3: words 454..623 (the last one twists with the NEW word 0)
-        if (tid < MT_N - 2 * (MT_N - MT_M)) {
-            const int k = tid + 2 * (MT_N - MT_M);
-            const unsigned y = w[k - (MT_N - MT_M)] ^ mt_twist(o[k], k == MT_N - 1 ? w[0] : o[k + 1]);
-            w[k] = y;
-            if (k < left) out[done + k] = mt_uniform(y);
-        }
-        __syncthreads();
+        // (LDS only: __syncthreads() would also wait for the global stores of this block - their latency, not the recurrence, then sets the pace)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         cur ^= 1;
         pos = (int)min(left, (long)MT_N);
         done += pos;

@@ -3530,6 +3530,20 @@ int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int
                    const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z_vals,
                    const float *u, int64_t n_rays, int n_samples, int n_importance, unsigned flags, float *rgb,
                    float *acc, float *depth, void *workspace, void *stream) {
+    return hl_render_rays_u_event(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, u, nullptr, n_rays, n_samples,
+                                  n_importance, flags, rgb, acc, depth, workspace, stream);
+}
+
+int hl_render_rays_u_event(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
+                           const float *rays_o, const float *rays_d, const float *near, const float *far, const float *z_vals,
+                           const float *u, void *u_ready_event, int64_t n_rays, int n_samples, int n_importance, unsigned flags, float *rgb,
+                           float *acc, float *depth, void *workspace, void *stream) {
+    // u_ready_event (hipEvent_t or null): `u` is being written on ANOTHER stream (hl_mt19937_uniform continuing the CPU generator); the
+    // stream waits for it only in front of the importance-sampling launch - the coarse pass does not read u and runs next to the generator
+    auto wait_u = [&]() -> int {
+        if (u_ready_event) HL_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)u_ready_event, 0));
+        return HL_OK;
+    };
     if (n_importance > 0) {
         // renderer.py:250 reshapes the coarse densities to (.., n_importance): only equal counts are valid
         HL_REQUIRE(n_importance == n_samples, "render: n_importance (%d) must equal n_samples (%d)", n_importance,
@@ -3548,6 +3562,8 @@ int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int
             int rcode = render_eval_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, 0, n_rays, n_samples,
                                          vc, h16, stream);
             if (rcode) return rcode;
+            rcode = wait_u();
+            if (rcode) return rcode;
             rcode = hl_render_importance_new(vc, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, zn, stream);
             if (rcode) return rcode;
             rcode = render_eval_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, zn, 1, n_rays, n_importance, vn,
@@ -3559,6 +3575,8 @@ int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int
         float *z_all = sigma + (size_t)tiles32(n_rays) * 32 * n_samples;
         int rcode = hl_render_coarse(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, n_rays,
                                      n_samples, sigma, stream);
+        if (rcode) return rcode;
+        rcode = wait_u();
         if (rcode) return rcode;
         rcode = hl_render_importance(sigma, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, z_all, stream);
         if (rcode) return rcode;

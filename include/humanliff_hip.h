@@ -100,6 +100,12 @@ int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int
                    const float *rays_o, const float *rays_d, const float *near, const float *far,
                    const float *z_vals, const float *u, int64_t n_rays, int n_samples, int n_importance,
                    unsigned flags, float *rgb, float *acc, float *depth, void *workspace, void *stream);
+/* hl_render_rays whose `u` is still being written on another stream (hl_mt19937_uniform): u_ready_event (hipEvent_t, recorded behind that
+ * writer; NULL = none) is waited for in front of the importance-sampling launch only, so the coarse evaluate pass overlaps the generator. */
+int hl_render_rays_u_event(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,
+                   const float *rays_o, const float *rays_d, const float *near, const float *far,
+                   const float *z_vals, const float *u, void *u_ready_event, int64_t n_rays, int n_samples, int n_importance,
+                   unsigned flags, float *rgb, float *acc, float *depth, void *workspace, void *stream);
 
 /* The three stages of hl_render_rays, exposed for tests and profiling.  sigma_out / sigma and z_all_out /
  * z_all use the tile-major workspace layout described above (buffers sized for ceil(R/32)*32 rays);
