@@ -532,7 +532,7 @@ def e2e_slice(model, dev, rank, world, n_layers=4, ddim=50, n_views=185, res=512
     assert torch.isfinite(samples).all()
     out = {"workload": f"configs[3]/[4] per-GPU slice at its real size: {spg} subjects per GPU (sampled {batch} at a time) x {n_layers} cloth layers x DDIM-{ddim} "
                        f"(production F4 net, layers chained through x_cond) -> reshape(1,3,9,256,256) -> {n_views} orbit views {res}x{res} @128+128 per subject "
-                       "(Renderer.mlp_products = bf16x3) -> gather of samples (fp32) and, per subject and asynchronously, images (uint8); "
+                       "(Renderer.mlp_products = fp16x2) -> gather of samples (fp32) and, per subject and asynchronously, images (uint8); "
                        "humanliff_amd.distributed.sample_and_render",
            "seconds": round(secs, 3), "subjects": nsub, "subjects_per_gpu": spg, "seconds_per_subject": round(secs / spg, 3), "denoise_steps": steps, "rays": rays,
            "sampling": {"seconds_rank0": round(t_sample, 3), "denoise_steps_per_sec_per_gpu": round(spg * n_layers * ddim / t_sample, 2), "batch": batch},
@@ -797,25 +797,42 @@ def bench_render(args, rank, world, dev):
         return [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
 
     eval_flop = R * N * FULL_FLOP_PER_POINT                     # one evaluate launch: full MLP at 128 points per ray
-    # default product mode (Renderer.mlp_products = "bf16x3"): k_march_b3w.  Its MFMAs: 768 v_mfma_f32_32x32x16_bf16 per 32 points and
-    # sample (32 chunks x 4 positions x 6 partial products) = 786 432 FLOP per point issued on the 16-bit pipe (dense peak 2.5 PFLOP/s)
-    t_a, t_i, t_b, t_c = stages(_lib.HL_RENDER_MLP_BF16X3)
-    issued = R * N * 786432.0
+    # default product mode (Renderer.mlp_products = "fp16x2"): k_march_plw<2>.  Its MFMAs: 384 v_mfma_f32_32x32x16_f16 per 32 points and
+    # sample (32 chunks x 4 positions x 3 partial products) = 393 216 FLOP per point issued on the 16-bit pipe (dense peak 2.5 PFLOP/s)
+    t_a, t_i, t_b, t_c = stages(_lib.HL_RENDER_MLP_FP16X2)
+    issued = R * N * 393216.0
     view_ms = t_a + t_i + t_b + t_c
-    roof = {"bound": "mfma", "kernel": "k_march_b3w (evaluate pass: tri-plane gather + full MLP at 128 depths per ray, every fp32 product as six bf16 partial products "
-                                       "of exact three-way splits, fp32 accumulation, raw records out), two launches per 512x512 view (coarse depths, importance depths)",
-            "products": "bf16x3 (exact three-way bf16 split of both operands, six partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; dropped terms "
-                        "below one fp32 rounding) - an fp32-tolerance mode: same test bounds as the fp32-MFMA kernel",
+    roof = {"bound": "mfma", "kernel": "k_march_plw<2> (evaluate pass: tri-plane gather + full MLP at 128 depths per ray, every fp32 product as three fp16 partial "
+                                       "products of two-plane splits, fp32 accumulation, raw records out), two launches per 512x512 view (coarse depths, importance depths)",
+            "products": "fp16x2 (x = h0 + h1 with two fp16 planes, 2^-20 |x|; weights nearest-even, 2^-22; h0 w0 + h0 w1 + h1 w0 on v_mfma_f32_32x32x16_f16, fp32 "
+                        "accumulation) - an fp32-tolerance mode: same test bounds as the fp32-MFMA kernel, rgb within 7e-7 of it on full views",
             "achieved": round(issued / (t_b * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(issued / (t_b * 1e-3) / 1e12 / 2500.0, 4),
-            "peak_note": "dense bf16 MFMA peak (MI355X_MICROARCH.md); `achieved` = bf16 FLOPs issued.  In the path's own unit: "
+            "peak_note": "dense fp16 MFMA peak (MI355X_MICROARCH.md); `achieved` = fp16 FLOPs issued.  In the path's own unit: "
                          f"{eval_flop / (t_b * 1e-3) / 1e12:.1f} TFLOP/s of algorithmic fp32 work = {eval_flop / (t_b * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS:.2f} x the fp32 matrix peak",
             "fp32_equivalent_tflops": round(eval_flop / (t_b * 1e-3) / 1e12, 2), "traffic": PMC_TRAFFIC["k_march_b3w_eval_512x512"],
-            "traffic_source": PMC_TRAFFIC["source"], "launch_ms": round(t_b, 3),
+            "traffic_source": PMC_TRAFFIC["source"] + " (the fp16x2 launch moves the same bytes: same gather, same records)", "launch_ms": round(t_b, 3),
             "view": {"ms": round(view_ms, 3), "eval_coarse_ms": round(t_a, 3), "importance_ms": round(t_i, 3),
                      "eval_importance_ms": round(t_b, 3), "composite_ms": round(t_c, 3),
                      "algorithmic_tflops": round(R * FINE_FLOP_PER_RAY_TOTAL / (view_ms * 1e-3) / 1e12, 2),
                      "note": "algorithmic = the reference's schedule, 128 x 79 616 + 256 x 132 608 FLOP per ray (SURVEY 8(d)); this "
                              "schedule evaluates every point once (256 x 132 608)"}}
+    # the exact-split mode beside it: Renderer.mlp_products = "bf16x3" (k_march_plw<3>: three bf16 planes, six partial products - round 4's default)
+    b_a, b_i, b_b, b_c = stages(_lib.HL_RENDER_MLP_BF16X3)
+    r.mlp_products = "bf16x3"
+    try:
+        one(views)
+        torch.cuda.synchronize()
+        tb_ = time.perf_counter()
+        imgs_b3 = [one(v)["rgb_map"] for v in range(views)]
+        torch.cuda.synchronize()
+        db3 = time.perf_counter() - tb_
+    finally:
+        r.mlp_products = "fp16x2"
+    roof["bf16x3_products"] = {"what": "the same views with Renderer.mlp_products = 'bf16x3' (k_march_plw<3>: EXACT three-way bf16 splits, six partial products)",
+                               "value": round(views * R / db3 / 1e6, 4), "unit": "Mrays/s", "ms_per_view": round(db3 * 1e3 / views, 3), "launch_ms": round(b_b, 3),
+                               "issued_tflops": round(R * N * 786432.0 / (b_b * 1e-3) / 1e12, 1), "frac_of_bf16_peak": round(R * N * 786432.0 / (b_b * 1e-3) / 1e12 / 2500.0, 4),
+                               "rgb_max_abs_vs_fp16x2": max(float((imgs_b3[v][0] - mine[v][0]).abs().max()) for v in range(min(views, 3)))}
+    del imgs_b3
     # the native-fp32 figure beside it: Renderer.mlp_products = "fp32" (k_march<true,true,8> on v_mfma_f32_32x32x2_f32)
     f_a, f_i, f_b, f_c = stages(0)
     r.mlp_products = "fp32"
@@ -827,7 +844,7 @@ def bench_render(args, rank, world, dev):
         torch.cuda.synchronize()
         d32 = time.perf_counter() - tf_
     finally:
-        r.mlp_products = "bf16x3"
+        r.mlp_products = "fp16x2"
     diff = max(float((imgs32[v][0] - mine[v][0]).abs().max()) for v in range(min(views, 3)))
     roof["fp32_products"] = {"what": "the same views with Renderer.mlp_products = 'fp32' (k_march<true,true,8>, v_mfma_f32_32x32x2_f32): the native-fp32 figure",
                              "value": round(views * R / d32 / 1e6, 4), "unit": "Mrays/s", "ms_per_view": round(d32 * 1e3 / views, 3),
@@ -1217,7 +1234,7 @@ def main():
     if not args.no_render:
         rsecs, rroof, rays_per_rank = bench_render(args, rank, world, dev)
         render = {"metric": "Mrays/sec@256spp", "value": round(world * rays_per_rank / rsecs / 1e6, 4), "unit": "Mrays/s",
-                  "dtype": "f32 results; MLP products = bf16x3 (exact three-way bf16 splits, six partial products, fp32 accumulation - fp32 tolerance, same test "
+                  "dtype": "f32 results; MLP products = fp16x2 (two fp16 planes per operand, three partial products, fp32 accumulation - fp32 tolerance, same test "
                            "bounds as the fp32-MFMA kernel whose figure is roofline.fp32_products)",
                   "views_per_gpu": args.views, "ms_per_view": round(rsecs * 1e3 / args.views, 3), "host_inclusive": rroof.pop("host_inclusive", None), "roofline": rroof,
                   "config": {"workload": "configs[2]: tri-plane NeRF render 512x512, n_samples=128 + n_importance=128, "

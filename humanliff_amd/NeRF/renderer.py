@@ -76,10 +76,12 @@ class Renderer(nn.Module):
                                              # parameters' AccumulateGrad nodes sit on another stream than the gradients)
         self.mlp_fp16 = False                # extension, opt-in: the MLP with fp16 operands / fp32 accumulation (HL_RENDER_MLP_FP16, k_march16) in
                                              # render() without canonical space; canonical-space rendering, density_grid() and training stay fp32
-        self.mlp_products = "bf16x3"         # how render() forms the fp32 products of the MLP in the evaluate-once pipeline (test mode, world space):
-                                             # "bf16x3" (default) = both operands split EXACTLY into three bf16 planes, six partial products on
-                                             # v_mfma_f32_32x32x16_bf16, fp32 accumulation - dropped terms below one fp32 rounding (k_march_b3,
-                                             # HL_RENDER_MLP_BF16X3); "fp32" = v_mfma_f32_32x32x2_f32 (k_march).  Same tolerances, tested on both.
+        self.mlp_products = "fp16x2"         # how render() forms the fp32 products of the MLP in the evaluate-once pipeline (test mode, world space):
+                                             # "fp16x2" (default, round 5) = both operands as TWO fp16 planes (activations h0 + h1 to 2^-20, weights
+                                             # nearest-even to 2^-22), the three partial products h0 w0 + h0 w1 + h1 w0 on v_mfma_f32_32x32x16_f16, fp32
+                                             # accumulation (k_march_plw<2>, HL_RENDER_MLP_FP16X2); "bf16x3" = both operands split EXACTLY into three bf16
+                                             # planes, six partial products (k_march_plw<3>, HL_RENDER_MLP_BF16X3); "fp32" = v_mfma_f32_32x32x2_f32
+                                             # (k_march).  Same tolerances, tested on all three; rgb of the three within 7e-7 of each other on full views.
         self._ws = None
 
     # ---- packing caches ------------------------------------------------------------------------
@@ -145,7 +147,7 @@ class Renderer(nn.Module):
         CPU generator, then copied to the device (renderer.py:545).  reevaluate=True makes the fine pass run
         the network on all n_samples + n_importance depths like the reference (re-evaluating the coarse
         points); by default every point is evaluated once and the two sorted halves are merged - 23 % less arithmetic.  With
-        mlp_products="fp32" the two schedules give bit-identical images; the default products ("bf16x3") exist in the evaluate-once
+        mlp_products="fp32" the two schedules give bit-identical images; the split products ("fp16x2", the default, and "bf16x3") exist in the evaluate-once
         kernel only, so reevaluate=True runs the fp32-MFMA kernel (as do canonical-space rendering, density_grid() and training) and its
         images differ from the default's within the fp32 tolerance (rgb 7e-7).  Precedence: mlp_fp16=True (opt-in, NOT fp32 tolerance)
         overrides mlp_products.
@@ -212,13 +214,13 @@ class Renderer(nn.Module):
         acc = torch.empty((bs, R), dtype=torch.float32, device=dev)
         depth = torch.empty((bs, R), dtype=torch.float32, device=dev)
         products = getattr(self, "mlp_products", "fp32")
-        if products not in ("bf16x3", "fp32"):
-            raise ValueError(f"Renderer.mlp_products must be 'bf16x3' or 'fp32', not {products!r}")
+        if products not in ("fp16x2", "bf16x3", "fp32"):
+            raise ValueError(f"Renderer.mlp_products must be 'fp16x2', 'bf16x3' or 'fp32', not {products!r}")
         fp16 = bool(getattr(self, "mlp_fp16", False))
         # explicit precedence: the opt-in fp16-operand kernel first; the bf16x3 products only in the evaluate-once schedule (the re-evaluating
         # one exists on the fp32-MFMA kernel alone)
         flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0) | (_lib.HL_RENDER_REEVALUATE if reevaluate else 0) | \
-            (_lib.HL_RENDER_MLP_FP16 if fp16 else (_lib.HL_RENDER_MLP_BF16X3 if (products == "bf16x3" and not reevaluate) else 0))
+            (_lib.HL_RENDER_MLP_FP16 if fp16 else (0 if reevaluate else {"bf16x3": _lib.HL_RENDER_MLP_BF16X3, "fp16x2": _lib.HL_RENDER_MLP_FP16X2}.get(products, 0)))
         f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
         for b in range(bs):
             pp = self._packed_planes(tri_planes[b])

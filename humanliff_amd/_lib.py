@@ -9,10 +9,11 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhumanliff_hip.so")
+LIB_PATH = os.environ.get("HL_LIB_PATH") or os.path.join(_HERE, "libhumanliff_hip.so")   # (HL_LIB_PATH: developer A / B of build variants)
 
 HL_RENDER_MLP_FP16 = 16
 HL_RENDER_MLP_BF16X3 = 32
+HL_RENDER_MLP_FP16X2 = 64
 HL_CONV_FP32 = 0
 HL_CONV_BF16X3 = 1
 HL_CONV_FP32_F23 = 3

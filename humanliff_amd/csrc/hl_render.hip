@@ -853,6 +853,29 @@ __global__ void k_pack_mlp_b3(PackArgs a, unsigned short *out) {   // [position]
     out[idx] = h;
 }
 
+// the same layout with TWO fp16 planes, nearest even at both levels (fp16x2 products, k_march_plw<2>): [position][plane][lane 64][8 fp16]
+__global__ void k_pack_mlp_h2(PackArgs a, unsigned short *out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P16_FRAGS * 2 * 512) return;
+    const int i = idx & 7, lane = (idx >> 3) & 63, rest = idx >> 9, plane = rest % 2, f = rest / 2;
+    int pi = 6;
+    while (pi > 0 && f < c_parts16[pi].base) --pi;
+    const Part16 d = c_parts16[pi];
+    const int rel = f - d.base, j = rel / d.nt, t = rel - j * d.nt;
+    const int g = lane >> 5, outu = 32 * t + (lane & 31);
+    int in = -1;
+    if (d.kind == 1) {
+        in = unit_of(j >> 1, (j & 1) * 8 + i, g);
+    } else {
+        const int sidx = j * 8 + i, per = d.kind == 0 ? 15 : 14, k = sidx + per * g;
+        if (sidx < per && k < 27) in = k;
+    }
+    float v = in >= 0 ? a.w[d.w][outu * d.ld + d.col0 + in] : 0.f;
+    _Float16 h = (_Float16)v;                                   // nearest even
+    if (plane == 1) h = (_Float16)(v - (float)h);               // (the residual is exact in fp32)
+    out[idx] = __builtin_bit_cast(unsigned short, h);
+}
+
 // registers 8hi..8hi+7 of an accumulator tile -> three planes of 8 bf16 (v = p0 + p1 + p2 exactly)
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     unsigned r;
@@ -1231,7 +1254,12 @@ __global__ __launch_bounds__(256, 1) void k_march_b3(const MarchArgs a, const un
 // covers what one wave per SIMD has to schedule by hand (LDS and L2 latencies, the VALU phases between MFMA groups), and 256 rays share every
 // weight chunk that goes through LDS - half the ring traffic per ray, which is what bounds k_march_b3 (profiles/r04_render_b3_ablations.md).
 constexpr int B3W_NPAIR = (B3_NCH - 1) / 2;                                               // 16 chunk pairs per sample: chunk 32 (direction encoding) runs once per ray
-constexpr size_t B3W_LDS = (size_t)2 * B3R_SLOT_U4 * 16 + SMALL_FLOATS * sizeof(float) + (size_t)8 * 512 * 16;
+// NPL = operand planes: 3 = bf16x3 (six partial products), 2 = fp16x2 (three partial products, below)
+template <int NPL> constexpr int PLW_CH_U4 = B3_POS * NPL * 64;            // u32x4 per chunk (4 fragment positions x NPL planes x 64 lanes)
+template <int NPL> constexpr int PLW_SLOT_U4 = 2 * PLW_CH_U4<NPL>;         // a ring slot = a PAIR of chunks (24 KB / 16 KB)
+template <int NPL> constexpr size_t PLW_BYTES = (size_t)P16_FRAGS * NPL * 1024;
+template <int NPL> constexpr size_t PLW_LDS = (size_t)2 * PLW_SLOT_U4<NPL> * 16 + SMALL_FLOATS * sizeof(float) + (size_t)8 * 512 * 16;
+constexpr size_t B3W_LDS = PLW_LDS<3>;
 template <int NT>
 __device__ __forceinline__ void load_bias_global(f32x16 (&acc)[NT], const float *__restrict__ tbl, int half) {   // load_bias from the packed image in global memory
 #pragma unroll
@@ -1287,9 +1315,57 @@ __device__ __forceinline__ void mma_b3(f32x16 (&acc)[NT], const u32x4 (&b)[3], c
     }
 }
 
-__global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const unsigned short *__restrict__ packed_b3) {
+// ---- fp16x2 (round 5): x = h0 + h1 with TWO fp16 planes (2 x 11 significand bits: |x - h0 - h1| <= 2^-20 |x| with the truncating split below,
+// 2^-22 with nearest-even planes as the weights get at pack time), three partial products h0 w0 + h0 w1 + h1 w0 accumulated in fp32 on
+// v_mfma_f32_32x32x16_f16 - HALF the MFMAs of the bf16x3 scheme at the same fp32-class error (the dropped h1 w1 is below 2^-20 |x w|): against
+// the REFERENCE's golden renders rgb max-abs 1.2e-7 / 2.7e-7 / 9.5e-7 in a CPU emulation of exactly this arithmetic, 6e-8 / 1.5e-7 / 4.2e-7 for
+// plain fp32 (profiles/r05_render_fp16x2.md).  h0 = the value with its low 13 mantissa bits cleared (v_and: what a round-toward-zero conversion
+// to fp16 keeps), so the residual x - h0 is exact in fp32; both planes packed by v_cvt_pkrtz_f16_f32.  Range: |x| < 65504 (fp16); values below
+// 2^-14 keep an ABSOLUTE error of 2^-24.
+__device__ __forceinline__ void split_h2t(const f32x16 &v, int hi, u32x4 (&pl)[2]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x = v[8 * hi + 2 * q], y = v[8 * hi + 2 * q + 1];
+        const float hx = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffffe000u), hy = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, y) & 0xffffe000u);
+        pl[0][q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hx, hy));
+        pl[1][q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy));
+    }
+}
+__device__ __forceinline__ void split_plt(const f32x16 &v, int hi, u32x4 (&pl)[3]) { split_b3t(v, hi, pl); }
+__device__ __forceinline__ void split_plt(const f32x16 &v, int hi, u32x4 (&pl)[2]) { split_h2t(v, hi, pl); }
+// NT output tiles x one 8-wide k-group for NPL planes: the partial products, smallest first, two tiles at a time
+template <int NT, int NPL>   // (both deduced from the arguments: the call sites sit inside macro arguments, where a template comma would split them)
+__device__ __forceinline__ void mma_pl(f32x16 (&acc)[NT], const u32x4 (&b)[NPL], const u32x4 *__restrict__ ch, int q0, int lane) {
+    if constexpr (NPL == 3) mma_b3<NT>(acc, b, ch, q0, lane);
+    else {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        constexpr int PW[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int t0 = 0; t0 < NT; t0 += 2) {
+            u32x4 w[2][2];
+#pragma unroll
+            for (int p = 1; p >= 0; --p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) w[t][p] = ch[((q0 + t0 + t) * 2 + p) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, w[t][PW[i]]), __builtin_bit_cast(h8, b[PB[i]]), acc[t0 + t], 0, 0, 0);
+        }
+    }
+}
+
+#ifndef HL_H2_K
+#define HL_H2_K 5   // VALU instructions asked for behind every MFMA of a hidden-layer chunk in the fp16x2 kernel (12 MFMAs, ~80 VALU of preparation)
+#endif
+template <int NPL>
+__global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const unsigned short *__restrict__ packed_b3) {
+    constexpr int B3R_SLOT_U4 = PLW_SLOT_U4<NPL>, B3_CH_U4 = PLW_CH_U4<NPL>;      // (shadow the bf16x3 constants of k_march_b3)
+    constexpr size_t B3_BYTES = PLW_BYTES<NPL>;
+    constexpr int NMF = NPL == 3 ? 24 : 12;                                        // MFMAs of a chunk (4 tiles x 6 | 3 products)
     extern __shared__ __attribute__((aligned(16))) float ldsb[];   // [ring: 2 x 24 KB][small 4 KB][per wave: the 2 x 16 x 64 accumulator image of views_linear's bias + direction part, 8 KB]
-    constexpr int NT = 512, NST = B3R_SLOT_U4 / NT;   // threads; u32x4 per thread and chunk pair (3)
+    constexpr int NT = 512, NST = B3R_SLOT_U4 / NT;   // threads; u32x4 per thread and chunk pair (3 | 2)
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const long long wg = (long long)xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
@@ -1325,7 +1401,7 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
 
     // view-direction encoding, this half's 14 of the 27 (+1 pad) entries (as k_march), split once per ray
     {
-        u32x4 bev0[3], bev1[3];
+        u32x4 bev0[NPL], bev1[NPL];
         f32x16 ev;
         const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
         const float vd[3] = {dx / nrm, dy / nrm, dz / nrm};
@@ -1349,14 +1425,14 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
             }
             ev[s] = val;
         }
-        split_b3t(ev, 0, bev0);
-        split_b3t(ev, 1, bev1);
+        split_plt(ev, 0, bev0);
+        split_plt(ev, 1, bev1);
     // views_linear's direction part does not depend on the sample: bias + W_dir enc(dir) is formed once per ray (chunk 32, fragments straight
     // from global memory) and parked in LDS as the accumulator image every sample starts views_linear from
         f32x16 V0[2];
         load_bias_global<2>(V0, a.packed + NCH_FULL * CHUNK_FLOATS + SM_BV, half);
-        mma_b3<2>(V0, bev0, gb3 + (B3_NCH - 1) * B3_CH_U4, 0, lane);
-        mma_b3<2>(V0, bev1, gb3 + (B3_NCH - 1) * B3_CH_U4, 2, lane);
+        mma_pl(V0, bev0, gb3 + (B3_NCH - 1) * B3_CH_U4, 0, lane);
+        mma_pl(V0, bev1, gb3 + (B3_NCH - 1) * B3_CH_U4, 2, lane);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1393,7 +1469,7 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
     // Same-box A/B, ms per 512x512 view: blocks 43.5 - 44.0, whole-tile softplus 42.4, this 41.7 - 42.0 (profiles/r04_render_b3_ablations.md).
 #define B3_MV24(K_, M_, ...)                                                               \
     { __VA_ARGS__; M_;                                                                     \
-      _Pragma("unroll") for (int g_ = 0; g_ < 24; ++g_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, K_, 0); } \
+      _Pragma("unroll") for (int g_ = 0; g_ < NMF; ++g_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, NPL == 3 ? K_ : HL_H2_K, 0); } \
       __builtin_amdgcn_sched_barrier(0); }
 
     auto body = [&](auto rotc) {
@@ -1446,46 +1522,46 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
             f[3 * i + 1] = live ? r1 : 0.f;
             f[3 * i + 2] = live ? r2 : 0.f;
         }
-        u32x4 bf0[3], bf1[3], ba[3], bb[3];
-        split_b3t(f, 0, bf0);
-        split_b3t(f, 1, bf1);
+        u32x4 bf0[NPL], bf1[NPL], ba[NPL], bb[NPL];
+        split_plt(f, 0, bf0);
+        split_plt(f, 1, bf1);
         // ---- MLP  [renderer.py:134-156]: chunk g = fragment positions 4g .. 4g+3.  Software-pipelined: the operand of chunk g+1 is prepared
         // (softplus of a tile at its first use, three-way split of one half) in the same scheduling region as the MFMAs of chunk g, and the
         // (__builtin_amdgcn_sched_group_barrier patterns over regions of this size do not finish compiling) ----
         f32x16 X[4], Y[4];
         load_bias<4>(X, small + SM_B0, half);
-        mma_b3<4>(X, bf0, B3_AT(0), 0, lane);                                       // L0: chunks 0, 1
-        B3_ADV(1) mma_b3<4>(X, bf1, B3_AT(1), 0, lane);
+        mma_pl(X, bf0, B3_AT(0), 0, lane);                                       // L0: chunks 0, 1
+        B3_ADV(1) mma_pl(X, bf1, B3_AT(1), 0, lane);
         load_bias<4>(Y, small + SM_B1, half);
         softplus_b3_r<0, 8>(X[0]);                                                  // (the second half: behind the first chunk of the layer)
-        split_b3t(X[0], 0, ba);
+        split_plt(X[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L1: chunks 2..9 = (tile k of X, half 0 | 1)
             B3_ADV(2 + 2 * k)
-            B3_MV24(5, mma_b3<4>(Y, ba, B3_AT(2 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(X[k]); split_b3t(X[k], 1, bb); })
+            B3_MV24(5, mma_pl(Y, ba, B3_AT(2 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(X[k]); split_plt(X[k], 1, bb); })
             B3_ADV(3 + 2 * k)
-            B3_MV24(5, mma_b3<4>(Y, bb, B3_AT(3 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(Y, bb, B3_AT(3 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(X[k + 1 < 4 ? k + 1 : 3]); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         load_bias<4>(X, small + SM_B2, half);
-        B3_ADV(10) mma_b3<4>(X, bf0, B3_AT(10), 0, lane);                          // L2 (features): chunks 10, 11; the first hidden operand rides along
+        B3_ADV(10) mma_pl(X, bf0, B3_AT(10), 0, lane);                          // L2 (features): chunks 10, 11; the first hidden operand rides along
         B3_ADV(11)
-        B3_VM({ (softplus_b3_r<0, 8>(Y[0])); split_b3t(Y[0], 0, ba); }, mma_b3<4>(X, bf1, B3_AT(11), 0, lane))
+        B3_VM({ (softplus_b3_r<0, 8>(Y[0])); split_plt(Y[0], 0, ba); }, mma_pl(X, bf1, B3_AT(11), 0, lane))
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L2 (hidden): chunks 12..19
             B3_ADV(12 + 2 * k)
-            B3_MV24(5, mma_b3<4>(X, ba, B3_AT(12 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(Y[k]); split_b3t(Y[k], 1, bb); })
+            B3_MV24(5, mma_pl(X, ba, B3_AT(12 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(Y[k]); split_plt(Y[k], 1, bb); })
             B3_ADV(13 + 2 * k)
-            B3_MV24(5, mma_b3<4>(X, bb, B3_AT(13 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(Y[k + 1 < 4 ? k + 1 : 3]); split_b3t(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(X, bb, B3_AT(13 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(Y[k + 1 < 4 ? k + 1 : 3]); split_plt(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         load_bias<4>(Y, small + SM_BF, half);
         softplus_b3_r<0, 8>(X[0]);                                                  // (the second half: behind the first chunk of the layer)
-        split_b3t(X[0], 0, ba);
+        split_plt(X[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // feature_linear: chunks 20..27
             B3_ADV(20 + 2 * k)
-            B3_MV24(5, mma_b3<4>(Y, ba, B3_AT(20 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(X[k]); split_b3t(X[k], 1, bb); })
+            B3_MV24(5, mma_pl(Y, ba, B3_AT(20 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(X[k]); split_plt(X[k], 1, bb); })
             B3_ADV(21 + 2 * k)
-            B3_MV24(5, mma_b3<4>(Y, bb, B3_AT(21 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(X[k + 1 < 4 ? k + 1 : 3]); split_b3t(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(Y, bb, B3_AT(21 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(X[k + 1 < 4 ? k + 1 : 3]); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];   // X holds softplus(pts_linears.2) by now
         f32x16 V[2];
@@ -1496,12 +1572,12 @@ __global__ __launch_bounds__(512, 2) void k_march_b3w(const MarchArgs a, const u
                 const f32x4 v4 = vinit[(t * 4 + q) * 64 + lane];
                 V[t][4 * q] = v4[0]; V[t][4 * q + 1] = v4[1]; V[t][4 * q + 2] = v4[2]; V[t][4 * q + 3] = v4[3];
             }
-        split_b3t(Y[0], 0, ba);
+        split_plt(Y[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // views_linear (feature part): chunks 28..31, two k-groups each
             B3_ADV(28 + k)
-            B3_VM(split_b3t(Y[k], 1, bb), mma_b3<2>(V, ba, B3_AT(28 + k), 0, lane))
-            B3_VM(if (k < 3) split_b3t(Y[k + 1 < 4 ? k + 1 : 3], 0, ba), mma_b3<2>(V, bb, B3_AT(28 + k), 2, lane))
+            B3_VM(split_plt(Y[k], 1, bb), mma_pl(V, ba, B3_AT(28 + k), 0, lane))
+            B3_VM(if (k < 3) split_plt(Y[k + 1 < 4 ? k + 1 : 3], 0, ba), mma_pl(V, bb, B3_AT(28 + k), 2, lane))
         }
         V[0] = softplus16_b3(V[0]);
         V[1] = softplus16_b3(V[1]);
@@ -3124,7 +3200,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 extern "C" {
 
 // fp32 image + the fp16 fragments of k_march16 + the three bf16 planes of k_march_b3
-size_t hl_render_mlp_packed_bytes(void) { return (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024 + B3_BYTES; }
+// (+ the two fp16 planes of the fp16x2 products)
+size_t hl_render_mlp_packed_bytes(void) { return (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024 + B3_BYTES + (size_t)P16_FRAGS * 2 * 1024; }
 
 int hl_render_mlp_pack(const hl_render_mlp_params *p, void *packed, void *stream) {
     HL_REQUIRE(p && packed, "hl_render_mlp_pack: null argument");
@@ -3144,7 +3221,11 @@ int hl_render_mlp_pack(const hl_render_mlp_params *p, void *packed, void *stream
     if (rc) return rc;
     hipLaunchKernelGGL(k_pack_mlp_b3, dim3(P16_FRAGS * 3 * 2), dim3(256), 0, (hipStream_t)stream, a,
                        reinterpret_cast<unsigned short *>(static_cast<char *>(packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024));
-    return hl::check_launch("k_pack_mlp_b3");
+    rc = hl::check_launch("k_pack_mlp_b3");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pack_mlp_h2, dim3(P16_FRAGS * 2 * 2), dim3(256), 0, (hipStream_t)stream, a,
+                       reinterpret_cast<unsigned short *>(static_cast<char *>(packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024 + B3_BYTES));
+    return hl::check_launch("k_pack_mlp_h2");
 }
 
 size_t hl_planes_packed_bytes(int H, int W) { return (size_t)9 * H * W * sizeof(float4); }
@@ -3241,13 +3322,20 @@ static int render_eval_impl(const void *mlp_packed, const void *planes_packed, i
     int rcode = fill_march(a, mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far);
     if (rcode) return rcode;
     a.z = z; a.z_tiled = z_tiled; a.R = n_rays; a.S = n_samples; a.flags = 0; a.vals_out = (float4 *)records_out;
+    if (mlp_mode == 3) {   // HL_RENDER_MLP_FP16X2: two fp16 planes per operand, three partial products, fp32 accumulation
+        const unsigned short *ph2 = reinterpret_cast<const unsigned short *>(static_cast<const char *>(mlp_packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024 + B3_BYTES);
+        static const bool okh = hipFuncSetAttribute((const void *)k_march_plw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLW_LDS<2>) == hipSuccess;
+        HL_REQUIRE(okh, "k_march_plw<2>: cannot raise the dynamic LDS limit to %zu bytes", PLW_LDS<2>);
+        hipLaunchKernelGGL(k_march_plw<2>, dim3((unsigned)((n_rays + 255) / 256)), dim3(512), PLW_LDS<2>, (hipStream_t)stream, a, ph2);
+        return hl::check_launch("k_march_plw<2>");
+    }
     if (mlp_mode == 2) {   // HL_RENDER_MLP_BF16X3: exact three-way bf16 split of both operands, six partial products, fp32 accumulation
         const unsigned short *pb3 = reinterpret_cast<const unsigned short *>(static_cast<const char *>(mlp_packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024);
         static const int b3_waves = getenv("HL_B3_WAVES") ? atoi(getenv("HL_B3_WAVES")) : 8;   // developer switch: 4 = k_march_b3 (one wave per SIMD, hand-scheduled)
         if (b3_waves == 8) {
-            static const bool okw = hipFuncSetAttribute((const void *)k_march_b3w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3W_LDS) == hipSuccess;
+            static const bool okw = hipFuncSetAttribute((const void *)k_march_plw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3W_LDS) == hipSuccess;
             HL_REQUIRE(okw, "k_march_b3w: cannot raise the dynamic LDS limit to %zu bytes", B3W_LDS);
-            hipLaunchKernelGGL(k_march_b3w, dim3((unsigned)((n_rays + 255) / 256)), dim3(512), B3W_LDS, (hipStream_t)stream, a, pb3);
+            hipLaunchKernelGGL(k_march_plw<3>, dim3((unsigned)((n_rays + 255) / 256)), dim3(512), B3W_LDS, (hipStream_t)stream, a, pb3);
             return hl::check_launch("k_march_b3w");
         }
         const dim3 grid((unsigned)((n_rays + 127) / 128));
@@ -3300,7 +3388,7 @@ int hl_render_eval_products(const void *mlp_packed, const void *planes_packed, i
                             const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
                             int n_samples, unsigned flags, float *records_out, void *stream) {
     return render_eval_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z, z_tiled, n_rays, n_samples, records_out,
-                            (flags & HL_RENDER_MLP_FP16) ? 1 : ((flags & HL_RENDER_MLP_BF16X3) ? 2 : 0), stream);
+                            (flags & HL_RENDER_MLP_FP16) ? 1 : ((flags & HL_RENDER_MLP_FP16X2) ? 3 : ((flags & HL_RENDER_MLP_BF16X3) ? 2 : 0)), stream);
 }
 
 int hl_render_importance_new(const float *records, const float *rays_d, const float *near, const float *far, const float *z_vals,
@@ -3558,7 +3646,7 @@ int hl_render_rays_u_event(const void *mlp_packed, const void *planes_packed, in
             const size_t T32 = (size_t)tiles32(n_rays) * 32;
             float *vc = (float *)workspace, *vn = vc + T32 * n_samples * 4;
             float *zn = vn + T32 * n_importance * 4;
-            const int h16 = (flags & HL_RENDER_MLP_FP16) ? 1 : ((flags & HL_RENDER_MLP_BF16X3) ? 2 : 0);
+            const int h16 = (flags & HL_RENDER_MLP_FP16) ? 1 : ((flags & HL_RENDER_MLP_FP16X2) ? 3 : ((flags & HL_RENDER_MLP_BF16X3) ? 2 : 0));
             int rcode = render_eval_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, z_vals, 0, n_rays, n_samples,
                                          vc, h16, stream);
             if (rcode) return rcode;

@@ -2715,7 +2715,8 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     // 1 = 128x32 (Cout <= 32), 2 = 64x64.  Small-M layers keep the efficient main tile and split K instead
     // (deterministic slabs + k_splitk_finish) until the grid covers the chip.
     const long main_blocks = ((M + 127) / 128) * (cpad / 96);
-    const int max_splits = a.splitk_ws ? (nk / 8 < 16 ? nk / 8 : 16) : 1;
+    static const int split_cap = [] { const char *e_ = getenv("HL_MAX_SPLITS"); return e_ ? atoi(e_) : 16; }();   // developer knob (read once)
+    const int max_splits = a.splitk_ws ? (nk / 8 < split_cap ? nk / 8 : split_cap) : 1;
     int cfg;
     long blocks;
     if (cpad % 96 == 0 && main_blocks * (max_splits > 0 ? max_splits : 1) >= 192) { cfg = 0; blocks = main_blocks; }
@@ -2736,7 +2737,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     if (a.splitk_ws && blocks <= target / 2 && nk >= 16) {
         splits = (int)(target / blocks);
         if (splits > nk / 8) splits = nk / 8;
-        if (splits > 16) splits = 16;
+        if (splits > split_cap) splits = split_cap;
         while (splits > 1 && (size_t)splits * M * a.Cout * sizeof(float) > a.splitk_ws_bytes) --splits;
         if (splits < 1) splits = 1;
     }

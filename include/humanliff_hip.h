@@ -77,6 +77,10 @@ int hl_planes_pack(const float *planes, int H, int W, void *packed, void *stream
                                         EXACT three-way bf16 split of both operands - six partial products on v_mfma_f32_32x32x16_bf16, fp32
                                         accumulation, dropped terms < 2^-24 |a b| (k_march_b3); an fp32-tolerance mode, not a reduced-precision one */
 
+#define HL_RENDER_MLP_FP16X2 64u     /* the same pipeline with TWO fp16 planes per operand (x = h0 + h1 to 2^-20 |x|; weights nearest-even, 2^-22) and the three
+                                        partial products h0 w0 + h0 w1 + h1 w0 on v_mfma_f32_32x32x16_f16, fp32 accumulation (k_march_plw<2>): half the
+                                        matrix instructions of BF16X3 at the same fp32-class error against the reference's renders; values < 65504 */
+
 size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
 
 /* Replaces Renderer.render (human_diffusion/NeRF/renderer.py:234-281,
