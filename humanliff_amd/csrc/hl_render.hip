@@ -1280,6 +1280,8 @@ __device__ __forceinline__ void split_b3t(const f32x16 &v, int hi, u32x4 (&pl)[3
 }
 template <int I0, int I1>
 __device__ __forceinline__ void softplus_b3_r(f32x16 &v) {   // registers I0 .. I1-1 of softplus16_b3, in place
+    // (round 5: the packed-fp32 form - v_pk_mul / v_pk_add / v_pk_fma on pairs, |.| folded into v_exp_f32's source modifiers, 5 + 4 issues per pair instead
+    //  of 8 + 4 - measured SLOWER on the same box, 27.6 against 27.0 ms per view: a packed fp32 instruction is two passes, and the pairs cost moves)
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
         const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(v[i]));
