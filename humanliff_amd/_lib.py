@@ -101,6 +101,7 @@ SIGNATURES = {
     "hl_unet_profile_read": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "hl_unet_profile_read_ex": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "hl_unet_dispatch_census": (_i, [_p, C.POINTER(C.c_int64)]),
+    "hl_unet_dispatch_census_ex": (_i, [_p, _p, _i]),
     "hl_unet_profile_dominant": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "hl_diffusion_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p, _p]),
     "hl_conv2d_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),

@@ -144,8 +144,17 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
                     b += *reinterpret_cast<const f32x4 *>(ep + (g * 48 * 2 + tid * 2 + 1) * 4);
                 }
                 const long img = (tile * 256) / ((long)p.Hout * p.Wout);   // (a tile = 256 pixels of one image)
+                // the thread's four consecutive channels: one atomic pair per group they fall in (atomics on one word serialise)
+                const int c0_ = st == p.st1 ? p.st1_c0 : p.st2_c0, cg_ = st == p.st1 ? p.st1_cg : p.st2_cg;
+                int g_run = (c0_ + n0 + tid * 4) / cg_;
+                float s_run = a[0], q_run = b[0];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) stat_add(st, p.N, img, ((st == p.st1 ? p.st1_c0 : p.st2_c0) + n0 + tid * 4 + i) / (st == p.st1 ? p.st1_cg : p.st2_cg), (long)p.Hout * p.Wout, a[i], b[i]);
+                for (int i = 1; i < 4; ++i) {
+                    const int g_i = (c0_ + n0 + tid * 4 + i) / cg_;
+                    if (g_i != g_run) { stat_add(st, p.N, img, g_run, (long)p.Hout * p.Wout, s_run, q_run); g_run = g_i; s_run = 0.f; q_run = 0.f; }
+                    s_run += a[i]; q_run += b[i];
+                }
+                stat_add(st, p.N, img, g_run, (long)p.Hout * p.Wout, s_run, q_run);
             }
         };
         if (p.st1 && !p.partial) put_stats(p.st1, sm, sq);      // GroupNorm statistics of the stored tensor(s)
@@ -394,6 +403,153 @@ __global__ __launch_bounds__(256, 1) void k_conv1_h16(const ConvK p) {
 #endif
 }
 
+// k_conv1_h2 (round 5): the 1x1 convolutions of the DEFAULT fp32 mode with fp16x2 products - every operand as two fp16 planes (activations
+// h0 = the value with its low 13 mantissa bits cleared, h1 = the truncated residual: 2^-20; weights nearest-even planes at pack time: 2^-22),
+// x w ~ h1 w0 + h0 w1 + h0 w0 accumulated in fp32 on v_mfma_f32_32x32x16_f16.  These layers (ResBlock skips, attention qkv / proj_out, the
+// control tower's zero convolutions) are bound by HBM once they leave the fp32 matrix pipe (a 384->192 layer at 256x256 moves 600 MB for 39
+// GFLOP): the three products cost nothing next to the memory time, and the fp32 kernel (k_conv_dma, 0.83 of the fp32 matrix peak) takes twice as
+// long.  Error: a CPU emulation of exactly this arithmetic in ALL 1x1 layers of the production network moves its output by 3.1e-6 against the fp32
+// oracle (scripts/unet_fp16x2_emulation.py; the fp32 kernels sit at 4.5e-6, the parity bound is 5e-5).  Same workgroup shape, wave split and
+// epilogue as k_conv1_h16; K in chunks of 48 input channels = three k-steps (two planes of a chunk: 2 x 28 KB per stage), pixel pitch 112 bytes
+// (7 quarters: odd), weights [channel block of 192][chunk of 48][k-step 3][plane 2][wn][fragment nf][lane][8], three k-steps in flight.
+constexpr int H2_PITCH = 112, H2_PLANE = 256 * H2_PITCH, H2_STAGE = 2 * H2_PLANE;
+
+struct H2Pair { unsigned p0, p1; };
+__device__ __forceinline__ H2Pair split_h2(float x, float y) {   // a pair of values -> the two packed planes
+    const float hx = __builtin_bit_cast(float, __float_as_uint(x) & 0xffffe000u), hy = __builtin_bit_cast(float, __float_as_uint(y) & 0xffffe000u);
+    return H2Pair{__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hx, hy)), __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy))};
+}
+
+__global__ __launch_bounds__(256, 1) void k_conv1_h2(const ConvK p) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int NUT = 6;                                         // staging units per thread: 256 px x 6 groups of 8 channels / 256 threads
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int total = p.n_mtiles * p.n_nblocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int tb = __builtin_amdgcn_readfirstlane(wi / p.n_nblocks), nb = wi - tb * p.n_nblocks;
+    const long m0 = (long)tb * 256;
+    const int nch = p.Cin / 48;
+    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * pitch4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * nch * 3 * 12288), 0x00020000);
+
+    unsigned sv[NUT], sl[NUT];
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) {
+        const int u = tid + 256 * j, pix = u / 6, grp = u - pix * 6;
+        sv[j] = (unsigned)(m0 + pix) * pitch4 + grp * 32;
+        sl[j] = (unsigned)(pix * H2_PITCH + grp * 16);
+    }
+    u32x4 ar[NUT][2];
+    auto a_load = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NUT; ++j) {
+            ar[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j], chunk * 192, 0);
+            ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] + 16, chunk * 192, 0);
+        }
+    };
+    auto a_store = [&](int stage, int j) {
+        const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
+        const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
+        const u32x4 h0 = {q0.p0, q1.p0, q2.p0, q3.p0}, h1 = {q0.p1, q1.p1, q2.p1, q3.p1};
+        *reinterpret_cast<u32x4 *>(lds + stage * H2_STAGE + sl[j]) = h0;
+        *reinterpret_cast<u32x4 *>(lds + stage * H2_STAGE + H2_PLANE + sl[j]) = h1;
+    };
+    unsigned aoff[4];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) aoff[mf] = (unsigned)((128 * wm + 32 * mf + (lane & 31)) * H2_PITCH + (lane >> 5) * 16);
+    const unsigned wv = (unsigned)lane * 16u;
+    const int wbase = nb * nch * 3 * 12288 + wn * 3072;
+    u32x4 ring[3][2][3];                                            // [k-step of the chunk][plane][fragment nf]
+    auto w_load = [&](int slot_, int step) {
+        const int so = wbase + min(step, nch * 3 - 1) * 12288;       // (past the end: the last step again, never used)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) ring[slot_][pl][nf] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wv, so + pl * 6144 + nf * 1024, 0);
+    };
+    f32x16 acc[4][3];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+
+    a_load(0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) w_load(s, s);
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) a_store(0, j);
+    __syncthreads();
+
+    u32x4 af[2][2][4];                                              // [buffer][plane][fragment mf]
+    auto a_read = [&](const char *st, int k2, u32x4 (&dst)[2][4]) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) dst[pl][mf] = *reinterpret_cast<const u32x4 *>(st + pl * H2_PLANE + aoff[mf] + k2 * 32);
+    };
+    for (int c = 0; c < nch; ++c) {
+        const char *st = lds + (c & 1) * H2_STAGE;
+        a_load(c + 1 < nch ? c + 1 : c);                             // (last chunk: staged again, never read)
+        a_read(st, 0, af[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ([&] {
+                constexpr int cur = S & 1;
+                if constexpr (S + 1 < 3) a_read(st, S + 1, af[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf) {                 // smallest partial product first
+                        acc[mf][nf] = mma<true>(af[cur][1][mf], ring[S][0][nf], acc[mf][nf]);
+                        acc[mf][nf] = mma<true>(af[cur][0][mf], ring[S][1][nf], acc[mf][nf]);
+                        acc[mf][nf] = mma<true>(af[cur][0][mf], ring[S][0][nf], acc[mf][nf]);
+                    }
+                w_load(S, c * 3 + S + 3);
+                a_store((c + 1) & 1, 2 * S);
+                a_store((c + 1) & 1, 2 * S + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, 3>{});
+        __syncthreads();
+    }
+    h16_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, [&](int q, int pc) {
+        return m0 + 128 * (pc >> 6) + 32 * (2 * q + ((pc >> 5) & 1)) + (pc & 31);
+    });
+#endif
+}
+
+// fp16x2 weights of a 1x1 layer: [channel block of 192][chunk of 48 inputs][k-step 3][plane 2][wn][fragment nf][lane][8], nearest even at both levels
+__global__ void k_pack_conv1_h2(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, unsigned short *__restrict__ dst, int tf) {
+    const int nch = Cin_pad / 48;
+    const long n = (long)(Cout / 192) * nch * 3 * 2 * 3072;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+        long t = i >> 9;
+        const int nf = (int)(t % 3); t /= 3;
+        const int wn = (int)(t & 1); t >>= 1;
+        const int pl = (int)(t & 1); t >>= 1;
+        const int k2 = (int)(t % 3); t /= 3;
+        const int chunk = (int)(t % nch);
+        const int nb = (int)(t / nch);
+        const int o = nb * 192 + wn * 96 + nf * 32 + (l & 31), cin = chunk * 48 + k2 * 16 + (l >> 5) * 8 + j;
+        float v = 0.f;
+        if (cin < Cin) v = tf ? w[(long)cin * Cout + o] : w[(long)o * Cin + cin];
+        _Float16 h = (_Float16)v;
+        if (pl) h = (_Float16)(v - (float)h);
+        dst[i] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+
 // weights -> 16-bit values in fragment order: [channel block of 192][chunk of 32 inputs][tap][k-half][wn][fragment nf][lane][8]
 // lane l of fragment (wn, nf) holds output channel 192 nb + 96 wn + 32 nf + (l & 31), inputs 32 chunk + 16 k-half + 8 (l >> 5) + 0..7
 __global__ void k_pack_conv_h16(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, unsigned short *__restrict__ dst, int f16, int tf) {
@@ -468,6 +624,23 @@ int conv_pack_weights_h16(const float *w, int Cout, int Cin, int Cin_pad, int ks
     if (ks == 3) hipLaunchKernelGGL(k_pack_conv_h16, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), f16, tf);
     else hipLaunchKernelGGL(k_pack_conv1_h16, dim3(512), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), f16, tf);
     return check_launch("k_pack_conv_h16");
+}
+
+bool conv1_h2_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int ups) {
+    return ks == 1 && stride == 1 && !ups && ((long)Hout * Wout) % 256 == 0 && Cin % 48 == 0 && Cout % 192 == 0 && (long)Cout * Cin * 4 < (1L << 31);
+}
+size_t conv_packed_h2_bytes(int Cout, int Cin_pad, int ks) { return (ks == 1 && Cout % 192 == 0 && Cin_pad % 48 == 0) ? (size_t)Cout * Cin_pad * 4 : 0; }
+int conv_pack_weights_h2(const float *w, int Cout, int Cin, int Cin_pad, void *packed, hipStream_t st, int tf) {
+    HL_REQUIRE(w && packed && conv_packed_h2_bytes(Cout, Cin_pad, 1) && Cin <= Cin_pad, "conv_pack_weights_h2: bad argument");
+    hipLaunchKernelGGL(k_pack_conv1_h2, dim3(512), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), tf);
+    return check_launch("k_pack_conv1_h2");
+}
+int conv1_h2_launch(const ConvK &p, hipStream_t st) {
+    HL_REQUIRE(p.w_bf3 && conv1_h2_applies(p.Hout, p.Wout, p.Cin, p.Cout, p.ks, p.stride, p.ups) && !p.in16 && !p.partial, "k_conv1_h2: bad layer");
+    static const bool attr_ok = hipFuncSetAttribute((const void *)k_conv1_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * H2_STAGE)) == hipSuccess;
+    HL_REQUIRE(attr_ok, "k_conv1_h2: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(k_conv1_h2, dim3((unsigned)(p.n_mtiles * p.n_nblocks)), dim3(256), (size_t)2 * H2_STAGE, st, p);   // 112 KB (the epilogue exchange needs 98 KB)
+    return check_launch("k_conv1_h2");
 }
 
 size_t conv_h16_lds_bytes() { return (size_t)2 * H1_STAGE; }   // 104 KB: the two 1x1 stages (the epilogue exchange needs 98 KB, the 3x3 patch stages 45 KB)

@@ -26,6 +26,7 @@ struct Conv {
     const float *w = nullptr;  // packed
     const void *w_bf3 = nullptr;  // packed split-bf16 copy (layers that take the DMA tile), used when Net::conv_mode == 1
     const float *w_wino = nullptr;  // Winograd-domain copy (3x3 layers), used when Net::conv_mode == 0
+    const void *w_h2 = nullptr;     // 1x1 layers: two fp16 planes in MFMA-fragment order (k_conv1_h2: fp16x2 products), used when Net::conv_mode == HL_CONV_FP32
     const void *w_h16 = nullptr;    // fp16 copy in MFMA-fragment order (3x3 layers k_conv_h16 covers), used when Net::conv_mode == HL_CONV_FP16
     const float *w_wino4 = nullptr; // Winograd F(4x4,3x3) copy (3x3 layers up to 64 MB of it), used when Net::conv_mode == HL_CONV_FP32
     const float *bias = nullptr;
@@ -110,7 +111,7 @@ struct Net {
     size_t ev_used = 0;
     // which kernel family each convolution of the LAST forward took, per resolution level (hl_unet_dispatch_census):
     // [path 0 direct / 1 Winograd F(2x2) / 2 bf16x3 / 3 Winograd F(4x4)][log2(H / H_out)]
-    int64_t census[4][8] = {};
+    int64_t census[5][8] = {};   // (row 4: k_conv1_h2, the 1x1 layers with fp16x2 products)
     ~Net() {
         for (auto e : ev_pool) if (e) hipEventDestroy(e);
         for (auto e : ev_block) if (e) hipEventDestroy(e);
@@ -185,6 +186,15 @@ Conv make_conv_w(Net &n, const float *w, const float *bias, int Cin, int Cout, i
             c.w_wino4 = dst;
         }
         n.packed_off += (wino4 / 4 + 63) / 64 * 64;
+    }
+    const size_t h2 = hl::conv_packed_h2_bytes(Cout, c.Cin_pad, ks);
+    if (h2) {
+        if (!n.dry && w) {
+            void *dst = n.packed + n.packed_off;
+            if (hl::conv_pack_weights_h2(w, Cout, Cin, c.Cin_pad, dst, n.st) != 0 && n.err.empty()) n.err = hl_last_error();
+            c.w_h2 = dst;
+        }
+        n.packed_off += (h2 / 4 + 63) / 64 * 64;
     }
     const size_t h16 = hl::conv_packed_h16_bytes(Cout, c.Cin_pad, ks);
     if (h16) {
@@ -501,6 +511,7 @@ struct Exec {
         a.w = c.w; a.w_bf3 = (n.conv_mode == HL_CONV_BF16X3 || n.conv_mode == HL_CONV_BF16) ? c.w_bf3 : nullptr; a.bf16_single = n.conv_mode == HL_CONV_BF16;
         a.w_wino = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_F23 || n.conv_mode == HL_CONV_FP16) ? c.w_wino : nullptr;
         a.w_h16 = n.conv_mode == HL_CONV_FP16 ? c.w_h16 : nullptr; a.h16_fp16 = 1;
+        a.w_h2 = n.conv_mode == HL_CONV_FP32 ? c.w_h2 : nullptr;
         a.w_wino4 = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP16) ? c.w_wino4 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
         a.coefA = cA; a.coefB = cB; a.act = act; a.gn = af.gn;
         a.out = out; a.res = res; a.res_pitch = res_pitch;
@@ -517,7 +528,7 @@ struct Exec {
         {
             int lvl = 0;
             while (lvl < 7 && (out.H << lvl) < H) ++lvl;
-            n.census[a.path == 5 ? 2 : (a.path & 3)][lvl] += 1;   // (k_conv_h16 counts with the other kernels of the 16-bit matrix pipe)
+            n.census[a.path == 6 ? 4 : (a.path == 5 ? 2 : (a.path & 3))][lvl] += 1;   // (k_conv_h16 counts with the other kernels of the 16-bit matrix pipe)
             // (keyed like a rocprofv3 per-kernel, per-grid row: kernel family, level, Cout, kernel size - the input channel counts of a level share a row)
             span_key[0] = a.path; span_key[1] = lvl; span_key[2] = ups ? 1 : 0; span_key[3] = c.Cout; span_key[4] = c.ks;
         }
@@ -940,6 +951,13 @@ int hl_unet_dispatch_census(void *handle, int64_t *h_counts) {
     return HL_OK;
 }
 
+int hl_unet_dispatch_census_ex(void *handle, int64_t *h_counts, int rows) {
+    HL_REQUIRE(handle && h_counts && rows >= 1 && rows <= 5, "hl_unet_dispatch_census_ex: bad argument");
+    const Net &n = *static_cast<Net *>(handle);
+    for (int p = 0; p < rows; ++p) for (int l = 0; l < 8; ++l) h_counts[p * 8 + l] = n.census[p][l];
+    return HL_OK;
+}
+
 int hl_unet_profile(void *handle, int enable) {
     HL_REQUIRE(handle, "hl_unet_profile: null handle");
     Net &n = *static_cast<Net *>(handle);
@@ -1014,6 +1032,7 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
                       : (mode == HL_CONV_FP32_F23 ? hl::conv_packed_wino_bytes(Cout, Cin, ks)
                          : (f32m ? std::max(hl::conv_packed_wino_bytes(Cout, Cin, ks), hl::conv_packed_wino4_bytes(Cout, Cin, ks)) : 0));
     if (h16m) extra = std::max(extra, hl::conv_packed_h16_bytes(Cout, Cin, ks));
+    if (mode == HL_CONV_FP32 && !tf) extra = std::max(extra, hl::conv_packed_h2_bytes(Cout, Cin, ks));
     const size_t need = need32 + (extra + 255) / 256 * 256;
     HL_REQUIRE(scratch && scratch_bytes >= need, "hl_conv2d_nhwc: scratch too small (%zu < %zu)", scratch_bytes, need);
     ConvArgs a{};
@@ -1024,6 +1043,7 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     if ((f32m || mode == HL_CONV_FP32_F23) && hl::conv_packed_wino_bytes(Cout, Cin, ks)) a.w_wino = static_cast<float *>(extra_dst);
     if (f32m && hl::conv_packed_wino4_bytes(Cout, Cin, ks)) a.w_wino4 = static_cast<float *>(extra_dst);
     if (h16m && hl::conv_packed_h16_bytes(Cout, Cin, ks)) { a.w_h16 = extra_dst; a.h16_fp16 = mode == HL_CONV_FP16; }
+    if (mode == HL_CONV_FP32 && !tf && hl::conv_packed_h2_bytes(Cout, Cin, ks)) a.w_h2 = extra_dst;
     a.coefA = coefA; a.coefB = coefB; a.act = silu;
     const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     a.out.p = out; a.out.N = N; a.out.H = (Hv + 2 * pad - ks) / stride + 1; a.out.W = (Wv + 2 * pad - ks) / stride + 1;
@@ -1050,6 +1070,9 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     if (a.path == 5) {
         rc = hl::conv_pack_weights_h16(w_oihw, Cout, Cin_w, Cin, ks, extra_dst, a.h16_fp16, (hipStream_t)stream, tf);
         a.w_wino = nullptr; a.w_wino4 = nullptr; a.w_bf3 = nullptr;
+    } else if (a.path == 6) {
+        rc = hl::conv_pack_weights_h2(w_oihw, Cout, Cin_w, Cin, extra_dst, (hipStream_t)stream, tf);
+        a.w_wino = nullptr; a.w_wino4 = nullptr; a.w_bf3 = nullptr;
     } else if (a.path == 3) {
         rc = hl::conv_pack_weights_wino4(w_oihw, Cout, Cin_w, Cin, static_cast<float *>(extra_dst), (hipStream_t)stream, tf);
         a.w_wino = nullptr;
@@ -1064,6 +1087,7 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     }
     if (rc) return rc;
     if (a.path != 5) a.w_h16 = nullptr;
+    if (a.path != 6) a.w_h2 = nullptr;
     rc = hl::conv2d(a, (hipStream_t)stream);
     if (stat_slots) *stat_slots = a.stat_slots;
     return rc;

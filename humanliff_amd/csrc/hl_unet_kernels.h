@@ -30,6 +30,7 @@ struct ConvArgs {
     const float *w;      // packed [Cout_pad][Ktot], K order = kt_decode() in hl_unet_kernels.hip (groups of two 16-channel chunks, taps inside)
     const void *w_bf3;   // optional: the same weights split into three bf16 planes (conv_pack_weights_bf3); selects k_conv_bf3
     int bf16_single;     // with w_bf3: 1 = HL_CONV_BF16 (activations rounded to bf16 x the weights' two leading bf16 planes), 0 = bf16x3 emulation
+    const void *w_h2;    // optional (1x1 layers): two fp16 planes in MFMA-fragment order (conv_pack_weights_h2); selects k_conv1_h2 where it fills the chip
     const void *w_h16;   // optional: 16-bit weights in MFMA-fragment order (conv_pack_weights_h16); selects k_conv_h16 where conv_h16_applies
     int h16_fp16;        // with w_h16: 1 = fp16 operands (HL_CONV_FP16), 0 = bf16 (HL_CONV_BF16)
     const float *w_wino; // optional: Winograd-domain weights (conv_pack_weights_wino); selects k_conv_wino for large 3x3 layers
@@ -53,7 +54,7 @@ struct ConvArgs {
     int out_nchw;        // write (N, Cout, H, W) instead of NHWC
     float *act_ws;       // optional scratch (pixels*Cin floats) for the materialised GroupNorm(+SiLU) input of k_conv_dma
     size_t act_ws_bytes;
-    mutable int path;    // set by conv2d: 0 direct implicit GEMM, 1 Winograd F(2x2,3x3), 2 bf16x3 emulation, 3 Winograd F(4x4,3x3), 5 k_conv_h16
+    mutable int path;    // set by conv2d: 0 direct implicit GEMM, 1 Winograd F(2x2,3x3), 2 bf16x3 emulation, 3 Winograd F(4x4,3x3), 5 k_conv_h16, 6 k_conv1_h2
     float *splitk_ws;    // optional scratch for split-K partial sums (small-M layers); null disables split-K
     size_t splitk_ws_bytes;
     // GroupNorm statistics of the OUTPUT for the layer that will normalise it, emitted by the epilogue of whichever kernel stores
@@ -104,6 +105,12 @@ bool conv_h16_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride,
 size_t conv_packed_h16_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_h16(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, int f16, hipStream_t st, int tf = 0);
 int conv_h16_launch(const ConvK &p, int f16, hipStream_t st, int splits = 1);
+// k_conv1_h2 (hl_conv_h16.hip): the 1x1 / stride-1 convolutions of the default fp32 mode with fp16x2 products (two fp16 planes per operand, three partial
+// products, fp32 accumulation); weights conv_pack_weights_h2 laid out (ConvK::w_bf3), ConvK::n_mtiles = pixels / 256, n_nblocks = Cout / 192.
+bool conv1_h2_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int ups);
+size_t conv_packed_h2_bytes(int Cout, int Cin_pad, int ks);
+int conv_pack_weights_h2(const float *w_oihw, int Cout, int Cin, int Cin_pad, void *packed, hipStream_t st, int tf = 0);
+int conv1_h2_launch(const ConvK &p, hipStream_t st);
 void set_h16_min_blocks(long v);   // developer / test switch: workgroups from which the dispatch takes k_conv_h16 (< 0: the default, 48)
 
 // Statistics block of one normalised VIEW (ConvArgs::stats): [shard][N][32 groups][2] 64-bit fixed-point totals.  Levels with many

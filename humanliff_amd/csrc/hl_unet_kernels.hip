@@ -2858,8 +2858,15 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         }
         if (h16_splits < 2 || h16_blocks * h16_splits < h16_min_blocks()) { h16 = false; h16_splits = 1; }
     }
+    // 1x1 / stride-1 layers of the DEFAULT mode on the 16-bit matrix pipe with fp16x2 products (k_conv1_h2): once off the fp32 pipe they are bound by HBM, the
+    // fp32 kernel takes twice as long.  From h2_min_blocks workgroups of 256 pixels x 192 channels on (fewer: the split-K fp32 path keeps the layer).
+    static const long h2_min_blocks = [] { const char *e_ = getenv("HL_H2_MIN_BLOCKS"); return e_ ? atol(e_) : 48L; }();   // developer knob (read once); < 0 disables
+    const long h2_blocks = (M / 256) * (a.Cout / 192);
+    const bool h2 = !h16 && a.w_h2 && h2_min_blocks >= 0 && (!gn_on || a.act_ws) && !a.out_nchw && !a.w_bf3 &&
+                    conv1_h2_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
+                    (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0 && h2_blocks >= h2_min_blocks;
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
-        a.path = h16 ? 5 : (wino4 ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
+        a.path = h16 ? 5 : h2 ? 6 : (wino4 ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
         return HL_OK;
     }
     if (h16) {
@@ -2899,6 +2906,32 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             return finish("k_conv_h16");
         }
         return conv_h16_launch(p, a.h16_fp16, st);
+    }
+    if (h2) {
+        a.path = 6;
+        if (mode != 0) {   // GroupNorm(+SiLU) materialised once as dense fp32 (the kernel splits into its two fp16 planes while staging)
+            HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
+            const long npix = a.in.pixels();
+            if (a.coefA == nullptr) {
+                const int ppw = std::max(1, 1024 / (a.in.C / 4));
+                hipLaunchKernelGGL(k_gn_apply_gs<0>, dim3((unsigned)((a.in.H * a.in.W + ppw - 1) / ppw), (unsigned)a.in.N), dim3(256), (size_t)(2 * a.in.C + COEF_SCR_FLOATS) * sizeof(float), st,
+                                   a.in.p, a.in.pitch, a.in.H * a.in.W, a.in.C, a.gn, a.in.N, a.act, (void *)a.act_ws, 0, ppw);
+            } else {
+                long g = (npix * (a.in.C / 4) + 255) / 256;
+                if (g > 4096) g = 4096;
+                hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix, a.in.C, a.coefA, a.coefB, a.act, a.act_ws);
+            }
+            p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0; p.gn = GnSrc{};
+            if (a.ev_mid) { hipEventRecord(a.ev_mid, st); a.ev_mid_used = 1; }
+        }
+        p.w_bf3 = a.w_h2; p.in16 = 0; p.partial = nullptr;
+        p.n_nblocks = a.Cout / 192;
+        p.n_mtiles = (int)(M / 256);
+        if (a.stats) {   // statistics from the epilogue (128 pixels of one image per round)
+            p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
+            a.stat_slots = 1;
+        }
+        return conv1_h2_launch(p, st);
     }
     bool blk4 = false;
     if (dma || wino4) {

@@ -315,13 +315,13 @@ class UNetModel(nn.Module):
 
     def dispatch_census(self):
         """Which kernel family every convolution of the LAST inference forward took (hl_unet_dispatch_census):
-        {"direct" | "wino2" | "bf16x3" | "wino4": [launches per resolution level, level = log2(H / H_out)]}.  Kernel selection depends
+        {"direct" | "wino2" | "bf16x3" | "wino4" | "fp16x2": [launches per resolution level, level = log2(H / H_out)]} ("fp16x2": the 1x1 layers on k_conv1_h2).  Kernel selection depends
         on the batch size, so parity tests state with this which dispatch they covered."""
         if self._hip is None:
             raise RuntimeError("dispatch_census: no forward has run yet")
-        counts = (C.c_int64 * 32)()
-        _lib.check(_lib.lib().hl_unet_dispatch_census(self._hip[0], counts), "hl_unet_dispatch_census")
-        return {name: [int(counts[p * 8 + l]) for l in range(8)] for p, name in enumerate(("direct", "wino2", "bf16x3", "wino4"))}
+        counts = (C.c_int64 * 40)()
+        _lib.check(_lib.lib().hl_unet_dispatch_census_ex(self._hip[0], counts, 5), "hl_unet_dispatch_census_ex")
+        return {name: [int(counts[p * 8 + l]) for l in range(8)] for p, name in enumerate(("direct", "wino2", "bf16x3", "wino4", "fp16x2"))}
 
     def __del__(self):
         try:

@@ -363,6 +363,9 @@ int hl_unet_profile_dominant(void *handle, double *h_vals, int *h_key);
  * (k_conv_wino4); level = log2(H / H_out) of the layer's output.  Kernel selection depends on the batch size (a layer takes a Winograd
  * kernel only where its workgroups fill the chip), so parity tests use this to state WHICH dispatch they covered. */
 int hl_unet_dispatch_census(void *handle, int64_t *h_counts);
+/* The same with `rows` <= 5 rows of 8 levels: direct | Winograd F(2x2) | bf16x3 / 16-bit operand kernels | Winograd F(4x4) | k_conv1_h2 (1x1 layers of the
+ * default mode with fp16x2 products: two fp16 planes per operand, three partial products, fp32 accumulation). */
+int hl_unet_dispatch_census_ex(void *handle, int64_t *h_counts, int rows);
 
 /* Fused sampler update (everything after the model call in p_sample / ddim_sample,
  * gaussian_diffusion.py:293-333, 356-388, 484-529) for EPSILON prediction with a fixed

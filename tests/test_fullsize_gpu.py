@@ -102,6 +102,7 @@ def test_production_b4_dispatch_matches_oracle(production):
     # its input channels split into slabs), F(2x2,3x3) on the 16-pixel level, no bf16 emulation in the default mode
     assert all(census["wino4"][l] > 0 for l in range(4)), census
     assert census["wino2"][4] > 0 and census["bf16x3"] == [0] * 8, census
+    assert all(census["fp16x2"][l] > 0 for l in range(4)), census          # the 1x1 layers of the upper levels on k_conv1_h2 (fp16x2 products)
     scale = float(eps0.abs().mean())
     e0 = float((got0 - eps0).abs().max())
     assert scale > 0.05 and e0 < 5e-5 * max(1.0, scale), (e0, scale)        # measured ~5e-6, like B=1

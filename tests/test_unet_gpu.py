@@ -510,3 +510,45 @@ def test_conv_epilogue_groupnorm_statistics(N, C, H, W, Cout, ks, stride, ups, m
     wantB = beta.double()[None] - (mean[:, :, None].expand(N, 32, cg).reshape(N, Cout)) * wantA
     assert (nA.cpu().double() - wantA).abs().max() < 2e-6 * wantA.abs().max()
     assert (nB.cpu().double() - wantB).abs().max() < 2e-6 * max(1.0, float(wantB.abs().max()))
+
+
+@pytest.mark.parametrize("N,H,W,C,Cout,res,gn", [(4, 64, 64, 384, 192, True, False), (2, 128, 128, 192, 192, False, False), (1, 256, 256, 576, 192, True, False),
+                                               (4, 32, 32, 384, 1152, False, True), (2, 64, 64, 768, 384, True, False)])
+def test_conv1x1_fp16x2_products_match_float64(N, H, W, C, Cout, res, gn):
+    """The 1x1 convolutions of the DEFAULT mode run on k_conv1_h2 from 48 workgroups on: two fp16 planes per operand, three partial products, fp32
+    accumulation.  Against the float64 convolution of the fp32 operands: the error of an fp32 convolution's class (bound 4e-6 of the output scale;
+    a plain fp32 MFMA kernel measures ~1e-6 here), with residual and with the GroupNorm pre-pass of the attention's qkv convolution."""
+    from humanliff_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(N + C + Cout)
+    x = torch.randn((N, H, W, C), generator=g) * 1.5
+    w = torch.randn((Cout, C, 1, 1), generator=g) / C ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn((N, H, W, Cout), generator=g)
+    cA, cB = torch.rand((N, C), generator=g) + 0.5, torch.randn((N, C), generator=g) * 0.1
+    xin = (x * cA[:, None, None, :] + cB[:, None, None, :]).to(dev).cpu() if gn else x     # (the pre-pass runs in fp32 on the GPU)
+    ref = torch.einsum("nhwc,oc->nhwo", xin.double(), w[:, :, 0, 0].double()) + b.double()
+    if res:
+        ref = ref + r.double()
+    xd, wd, bd, rd, ad, bd2 = (t.to(dev) for t in (x, w, b, r, cA, cB))
+    out = torch.zeros((N, H, W, Cout), device=dev)
+    scratch = torch.empty(Cout * C * 8 + 256 + (8 << 20) + N * H * W * C, device=dev)
+    import ctypes
+    plan = ctypes.c_int(-1)
+    _lib.check(L.hl_conv2d_nhwc_mode(_lib.HL_CONV_FP32, _lib.ptr(xd), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Cout, 1, 1, 0, _lib.ptr(ad) if gn else None,
+                                     _lib.ptr(bd2) if gn else None, 0, _lib.ptr(rd) if res else None, _lib.ptr(out), _lib.ptr(scratch), scratch.numel() * 4,
+                                     _lib.stream_ptr()), "hl_conv2d_nhwc_mode")
+    # the fp32 direct kernel on the same operands, for scale
+    out32 = torch.zeros_like(out)
+    _lib.check(L.hl_conv2d_nhwc_mode(_lib.HL_CONV_FP32_DIRECT, _lib.ptr(xd), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Cout, 1, 1, 0, _lib.ptr(ad) if gn else None,
+                                     _lib.ptr(bd2) if gn else None, 0, _lib.ptr(rd) if res else None, _lib.ptr(out32), _lib.ptr(scratch), scratch.numel() * 4,
+                                     _lib.stream_ptr()), "hl_conv2d_nhwc_mode")
+    scale = float(ref.abs().mean())
+    e2, e32 = float((out.cpu().double() - ref).abs().max()), float((out32.cpu().double() - ref).abs().max())
+    print(f"1x1 {C}->{Cout} @{H}x{W} N{N}: fp16x2 max-abs {e2:.2e}, fp32 direct {e32:.2e} (output mean-abs {scale:.2f})")
+    assert not torch.equal(out, out32)                      # the default mode really took the other kernel
+    l2, l32 = float((out.cpu().double() - ref).norm() / ref.norm()), float((out32.cpu().double() - ref).norm() / ref.norm())
+    print(f"    rel-L2: fp16x2 {l2:.2e}, fp32 direct {l32:.2e}")
+    # measured on MI355X: max-abs 3.6e-6 ... 7.5e-6 against 2.9e-6 ... 9.3e-6 of the fp32 direct kernel; rel-L2 3.1e-7 ... 3.7e-7
+    assert e2 < 6e-6 * max(1.0, scale) * (C / 384) ** 0.5, (e2, scale)
+    assert l2 < 8e-7 and l2 < 4 * l32 + 2e-7, (l2, l32)
