@@ -93,7 +93,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/humanliff_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert L.hl_version() >= 100
-    assert L.hl_render_mlp_packed_bytes() == (17 * 4096 + 1024) * 4 + 132 * 1024 + 3 * 132 * 1024      # fp32 image + the 132 fp16 fragments of k_march16 + the three bf16 planes of k_march_b3
+    assert L.hl_render_mlp_packed_bytes() == (17 * 4096 + 1024) * 4 + 132 * 1024 + 3 * 132 * 1024 + 2 * 132 * 1024      # fp32 image + the 132 fp16 fragments of k_march16 + the three bf16 planes (bf16x3) + the two fp16 planes (fp16x2)
     assert L.hl_planes_packed_bytes(256, 256) == 9 * 256 * 256 * 16
 
 
