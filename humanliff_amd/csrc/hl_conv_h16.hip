@@ -162,7 +162,19 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
     }
 }
 
-template <bool F16>
+struct H2Pair { unsigned p0, p1; };
+__device__ __forceinline__ H2Pair split_h2(float x, float y) {   // a pair of values -> the two packed planes
+    const float hx = __builtin_bit_cast(float, __float_as_uint(x) & 0xffffe000u), hy = __builtin_bit_cast(float, __float_as_uint(y) & 0xffffe000u);
+    return H2Pair{__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hx, hy)), __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy))};
+}
+
+
+// NPL = operand planes: 1 = 16-bit operands (the opt-in modes), 2 = fp16x2 (round 5: the DEFAULT mode's 3x3 layers where this kernel beats the fp32 Winograd
+// kernels): two fp16 planes per operand - activations h0 = the value with its low 13 mantissa bits cleared, h1 = the truncated residual (2^-20), weights
+// nearest-even planes (2^-22) - and the three partial products h1 w0 + h0 w1 + h0 w0 per k-step, fp32 accumulation: a DIRECT convolution, no transform
+// in front of the products, so its error is the fp32 direct kernel's class (and below F(4x4,3x3)'s).  Planes: LDS stage = [plane][patch], weights
+// [..][k-half][plane][wn][fragment][lane][8], a two-plane activation image (k_gn_apply_*: ConvK::in16 = 2) is [plane][pixel][C].
+template <bool F16, int NPL>
 __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__
     constexpr unsigned OOB = 0x80000000u;
@@ -179,12 +191,15 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
     const int img = tb / (bw * bh), brem = tb - img * (bw * bh);
     const int y0 = (brem / bw) * 16, x0 = (brem - (brem / bw) * bw) * 16;
     const int nch = p.Cin >> 5;
+    constexpr int RING = NPL == 2 ? 3 : H16_RING;                            // k-steps of weights in flight (two planes: half as deep, the same registers)
+    constexpr int STG = NPL * H16_STAGE;                                      // bytes per stage (all planes)
     const unsigned pitch4 = (unsigned)p.in_pitch * (p.in16 ? 2u : 4u);      // bytes per pixel (16-bit image from the GroupNorm pass, or fp32)
+    const unsigned plane_b = (unsigned)((long)p.N * p.Hin * p.Win * p.in_pitch * 2);   // (in16 == 2: the second plane of the image)
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * pitch4), 0x00020000);
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * pitch4 * (p.in16 == 2 ? 2 : 1)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * nch * 18 * 6144), 0x00020000);
+        (void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * nch * 18 * 6144 * NPL), 0x00020000);
 
     // ---- patch staging: unit u = (pixel of the 18x18 patch, group of 8 channels) -> two 16-byte fp32 loads, one 16-byte LDS write ----
     unsigned sv[NUT], sl[NUT];
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
         const bool ok = u < NU && y >= 0 && y < p.Hout && x >= 0 && x < p.Wout;
         const int ys = p.ups ? y >> 1 : y, xs = p.ups ? x >> 1 : x;
         sv[j] = ok ? (unsigned)((img * p.Hin + ys) * p.Win + xs) * pitch4 + grp * (p.in16 ? 16 : 32) : OOB;
-        sl[j] = u < NU ? (unsigned)((py * H16_LP + px) * 64 + ((grp ^ ((px >> 2) & 3)) << 4)) : (unsigned)(2 * H16_STAGE + (tid & 63) * 16);   // (no unit: a dump slot behind the stages)
+        sl[j] = u < NU ? (unsigned)((py * H16_LP + px) * 64 + ((grp ^ ((px >> 2) & 3)) << 4)) : (unsigned)(2 * STG + (tid & 63) * 16);   // (no unit: a dump slot behind the stages)
     }
     u32x4 ar[NUT][2];
     auto a_load = [&](int chunk) {
@@ -205,13 +220,25 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
             const int so = (H16_ABL & 16) ? 0 : chunk * (p.in16 ? 64 : 128);      // (16: the patch from L2-hot addresses)
             ar[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j], so, 0);
             if (!p.in16) ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] == OOB ? OOB : sv[j] + 16, so, 0);
+            else if (NPL == 2) ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] == OOB ? OOB : sv[j] + plane_b, so, 0);
         }
     };
     auto a_store = [&](int stage, int j) {
         const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
-        const u32x4 h = p.in16 ? ar[j][0]
-                               : u32x4{pack2<F16>(v0[0], v0[1]), pack2<F16>(v0[2], v0[3]), pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3])};
-        *reinterpret_cast<u32x4 *>(lds + (sl[j] >= 2u * H16_STAGE ? 0 : stage * H16_STAGE) + sl[j]) = h;
+        char *dst = lds + (sl[j] >= 2u * STG ? 0 : stage * STG) + sl[j];
+        if constexpr (NPL == 2) {
+            u32x4 h0 = ar[j][0], h1 = ar[j][1];
+            if (!p.in16) {
+                const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
+                h0 = u32x4{q0.p0, q1.p0, q2.p0, q3.p0}; h1 = u32x4{q0.p1, q1.p1, q2.p1, q3.p1};
+            }
+            *reinterpret_cast<u32x4 *>(dst) = h0;
+            if (sl[j] < 2u * STG) *reinterpret_cast<u32x4 *>(dst + H16_STAGE) = h1;
+        } else {
+            const u32x4 h = p.in16 ? ar[j][0]
+                                   : u32x4{pack2<F16>(v0[0], v0[1]), pack2<F16>(v0[2], v0[3]), pack2<F16>(v1[0], v1[1]), pack2<F16>(v1[2], v1[3])};
+            *reinterpret_cast<u32x4 *>(dst) = h;
+        }
     };
 
     // ---- A fragments: row r of fragment mf = pixel (8wm + 2mf + (r >> 4), r & 15) of the tile; lane half g holds channels 8g..8g+7 of the k-step
@@ -228,16 +255,18 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
     }
     // ---- weights: packed [channel block][chunk][tap][k-half][wn][fragment][lane][8] -> one 16-byte load per lane and fragment
     const unsigned wv = (unsigned)lane * 16u;
-    const int wbase = nb * nch * 18 * 6144 + wn * 3072;
-    u32x4 ring[H16_RING][3];
+    const int wbase = nb * nch * 18 * 6144 * NPL + wn * 3072;
+    u32x4 ring[RING][NPL][3];
     // split-K (layers with few tiles): blockIdx.z owns the chunks [c0, c1) and stores raw accumulators to p.partial (k_splitk_finish sums
     // the slabs in a fixed order and applies bias / residual / statistics).  (A per-workgroup rotation of the chunk order,
     // tried against L2-channel hot spots - changed nothing and is gone.)
     const int c0 = (int)blockIdx.z * p.kt_per, c1 = min(nch, c0 + p.kt_per);
     auto w_load = [&](int slot_, int chunk, int s18) {
-        const int so = wbase + (chunk * 18 + s18) * 6144;
+        const int so = wbase + (chunk * 18 + s18) * 6144 * NPL;
 #pragma unroll
-        for (int nf = 0; nf < 3; ++nf) ring[slot_][nf] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wv, so + nf * 1024, 0);
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) ring[slot_][pl][nf] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wv, so + pl * 6144 + nf * 1024, 0);
     };
 
     f32x16 acc[4][3];
@@ -251,18 +280,20 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
     // ---- prologue: the first chunk staged, the first H16_RING k-steps of weights in flight
     a_load(c0);
 #pragma unroll
-    for (int s = 0; s < H16_RING; ++s) w_load(s, c0 + s / 18 < nch ? c0 + s / 18 : c0, s % 18);
+    for (int s = 0; s < RING; ++s) w_load(s, c0 + s / 18 < nch ? c0 + s / 18 : c0, s % 18);
 #pragma unroll
     for (int j = 0; j < NUT; ++j) a_store(0, j);
     __syncthreads();
 
-    u32x4 af[2][4];                                                // A fragments of the current / next k-step
-    auto a_read = [&](const char *st, int tap, int k2, u32x4 (&dst)[4]) {
+    u32x4 af[2][NPL][4];                                           // A fragments of the current / next k-step (per plane)
+    auto a_read = [&](const char *st, int tap, int k2, u32x4 (&dst)[NPL][4]) {
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) dst[mf] = *reinterpret_cast<const u32x4 *>(st + (tap / 3) * (H16_LP * 64) + (aoff[mf][tap % 3] ^ (k2 ? 32u : 0u)));
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) dst[pl][mf] = *reinterpret_cast<const u32x4 *>(st + pl * H16_STAGE + (tap / 3) * (H16_LP * 64) + (aoff[mf][tap % 3] ^ (k2 ? 32u : 0u)));
     };
     for (int c = c0; c < c1; ++c) {
-        const char *st = lds + ((c - c0) & 1) * H16_STAGE;
+        const char *st = lds + ((c - c0) & 1) * STG;
         const int cc = c;                                                // this chunk / the next one (past the end: a valid chunk, never used)
         const int ccn = cc + 1 < nch ? cc + 1 : 0;
         if (!(H16_ABL & 2) && !(H16_ABL & 64)) a_load(ccn);              // (last chunk: a valid chunk again, staged and never read)
@@ -270,15 +301,21 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
         __builtin_amdgcn_sched_barrier(0);
         [&]<int... S>(std::integer_sequence<int, S...>) {
             ([&] {
-                constexpr int rs = S % H16_RING, cur = S & 1;
+                constexpr int rs = S % RING, cur = S & 1;
                 if constexpr (S + 1 < 18 && !(H16_ABL & 4)) a_read(st, (S + 1) >> 1, (S + 1) & 1, af[cur ^ 1]);
                 __builtin_amdgcn_sched_barrier(0);                 // the next step's fragments are on their way before this step's MFMAs
 #pragma unroll
                 for (int nf = 0; nf < 3; ++nf)
 #pragma unroll
                     for (int mf = 0; mf < 4; ++mf)
-                        if constexpr (!(H16_ABL & 8)) acc[mf][nf] = mma<F16>(af[(H16_ABL & 4) ? 0 : cur][mf], ring[rs][nf], acc[mf][nf]);
-                if constexpr (!(H16_ABL & 1)) w_load(rs, S + H16_RING < 18 ? cc : ccn, (S + H16_RING) % 18);
+                        if constexpr (!(H16_ABL & 8)) {
+                            if constexpr (NPL == 2) {               // smallest partial product first
+                                acc[mf][nf] = mma<true>(af[cur][1][mf], ring[rs][0][nf], acc[mf][nf]);
+                                acc[mf][nf] = mma<true>(af[cur][0][mf], ring[rs][1][nf], acc[mf][nf]);
+                                acc[mf][nf] = mma<true>(af[cur][0][mf], ring[rs][0][nf], acc[mf][nf]);
+                            } else acc[mf][nf] = mma<F16>(af[(H16_ABL & 4) ? 0 : cur][0][mf], ring[rs][0][nf], acc[mf][nf]);
+                        }
+                if constexpr (!(H16_ABL & 1)) w_load(rs, S + RING < 18 ? cc : ccn, (S + RING) % 18);
                 if constexpr (S >= H16_ST0 && S < H16_ST0 + NUT) {
                     if (!(H16_ABL & 2) && !(H16_ABL & 32)) a_store((c - c0 + 1) & 1, S - H16_ST0);
                 }
@@ -414,12 +451,6 @@ __global__ __launch_bounds__(256, 1) void k_conv1_h16(const ConvK p) {
 // (7 quarters: odd), weights [channel block of 192][chunk of 48][k-step 3][plane 2][wn][fragment nf][lane][8], three k-steps in flight.
 constexpr int H2_PITCH = 112, H2_PLANE = 256 * H2_PITCH, H2_STAGE = 2 * H2_PLANE;
 
-struct H2Pair { unsigned p0, p1; };
-__device__ __forceinline__ H2Pair split_h2(float x, float y) {   // a pair of values -> the two packed planes
-    const float hx = __builtin_bit_cast(float, __float_as_uint(x) & 0xffffe000u), hy = __builtin_bit_cast(float, __float_as_uint(y) & 0xffffe000u);
-    return H2Pair{__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hx, hy)), __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy))};
-}
-
 __global__ __launch_bounds__(256, 1) void k_conv1_h2(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__
     constexpr int NUT = 6;                                         // staging units per thread: 256 px x 6 groups of 8 channels / 256 threads
@@ -528,6 +559,29 @@ __global__ __launch_bounds__(256, 1) void k_conv1_h2(const ConvK p) {
 #endif
 }
 
+// fp16x2 weights of a 3x3 layer: [channel block of 192][chunk of 32 inputs][tap][k-half][plane 2][wn][fragment nf][lane][8], nearest even at both levels
+__global__ void k_pack_conv_h2(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, unsigned short *__restrict__ dst, int tf) {
+    const int nch = Cin_pad >> 5;
+    const long n = (long)(Cout / 192) * nch * 18 * 2 * 3072;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+        long t = i >> 9;
+        const int nf = (int)(t % 3); t /= 3;
+        const int wn = (int)(t & 1); t >>= 1;
+        const int pl = (int)(t & 1); t >>= 1;
+        const int k2 = (int)(t & 1); t >>= 1;
+        const int tap = (int)(t % 9); t /= 9;
+        const int chunk = (int)(t % nch);
+        const int nb = (int)(t / nch);
+        const int o = nb * 192 + wn * 96 + nf * 32 + (l & 31), cin = chunk * 32 + k2 * 16 + (l >> 5) * 8 + j;
+        float v = 0.f;
+        if (cin < Cin) v = tf ? w[((long)cin * Cout + o) * 9 + (8 - tap)] : w[((long)o * Cin + cin) * 9 + tap];
+        _Float16 h = (_Float16)v;
+        if (pl) h = (_Float16)(v - (float)h);
+        dst[i] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+
 // fp16x2 weights of a 1x1 layer: [channel block of 192][chunk of 48 inputs][k-step 3][plane 2][wn][fragment nf][lane][8], nearest even at both levels
 __global__ void k_pack_conv1_h2(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, unsigned short *__restrict__ dst, int tf) {
     const int nch = Cin_pad / 48;
@@ -629,12 +683,28 @@ int conv_pack_weights_h16(const float *w, int Cout, int Cin, int Cin_pad, int ks
 bool conv1_h2_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int ups) {
     return ks == 1 && stride == 1 && !ups && ((long)Hout * Wout) % 256 == 0 && Cin % 48 == 0 && Cout % 192 == 0 && (long)Cout * Cin * 4 < (1L << 31);
 }
-size_t conv_packed_h2_bytes(int Cout, int Cin_pad, int ks) { return (ks == 1 && Cout % 192 == 0 && Cin_pad % 48 == 0) ? (size_t)Cout * Cin_pad * 4 : 0; }
-int conv_pack_weights_h2(const float *w, int Cout, int Cin, int Cin_pad, void *packed, hipStream_t st, int tf) {
-    HL_REQUIRE(w && packed && conv_packed_h2_bytes(Cout, Cin_pad, 1) && Cin <= Cin_pad, "conv_pack_weights_h2: bad argument");
-    hipLaunchKernelGGL(k_pack_conv1_h2, dim3(512), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), tf);
-    return check_launch("k_pack_conv1_h2");
+size_t conv_packed_h2_bytes(int Cout, int Cin_pad, int ks) {
+    if (ks == 3) return (Cout % 192 == 0 && Cin_pad % 32 == 0) ? (size_t)Cout * Cin_pad * 9 * 4 : 0;
+    return (ks == 1 && Cout % 192 == 0 && Cin_pad % 48 == 0) ? (size_t)Cout * Cin_pad * 4 : 0;
 }
+int conv_pack_weights_h2(const float *w, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st, int tf) {
+    HL_REQUIRE(w && packed && conv_packed_h2_bytes(Cout, Cin_pad, ks) && Cin <= Cin_pad, "conv_pack_weights_h2: bad argument");
+    if (ks == 3) hipLaunchKernelGGL(k_pack_conv_h2, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), tf);
+    else hipLaunchKernelGGL(k_pack_conv1_h2, dim3(512), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), tf);
+    return check_launch("k_pack_conv_h2");
+}
+// the 3x3 / stride-1 layers with fp16x2 products (k_conv_h16<true, 2>)
+static size_t conv3_h2_lds_bytes() { return (size_t)2 * H1_STAGE; }   // (two stages of two planes + the dump slot = 93 KB; the epilogue exchange 98 KB)
+static_assert(4 * H16_STAGE + 1024 <= 2 * H1_STAGE, "k_conv_h2 stages");
+int conv3_h2_launch(const ConvK &p, hipStream_t st, int splits) {
+    HL_REQUIRE(p.w_bf3 && p.ks == 3 && conv_h16_applies(p.Hout, p.Wout, p.Cin, p.Cout, p.ks, p.stride, p.ups) && (splits == 1 || p.partial), "k_conv_h2: bad layer");
+    const size_t sh = conv3_h2_lds_bytes();
+    static const bool attr_ok = hipFuncSetAttribute((const void *)k_conv_h16<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv3_h2_lds_bytes()) == hipSuccess;
+    HL_REQUIRE(attr_ok, "k_conv_h2: cannot raise the dynamic LDS limit to %zu bytes", sh);
+    hipLaunchKernelGGL((k_conv_h16<true, 2>), dim3((unsigned)(p.n_mtiles * p.n_nblocks), 1, (unsigned)splits), dim3(256), sh, st, p);
+    return check_launch("k_conv_h2");
+}
+
 int conv1_h2_launch(const ConvK &p, hipStream_t st) {
     HL_REQUIRE(p.w_bf3 && conv1_h2_applies(p.Hout, p.Wout, p.Cin, p.Cout, p.ks, p.stride, p.ups) && !p.in16 && !p.partial, "k_conv1_h2: bad layer");
     static const bool attr_ok = hipFuncSetAttribute((const void *)k_conv1_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * H2_STAGE)) == hipSuccess;
@@ -652,8 +722,8 @@ int conv_h16_launch(const ConvK &p, int f16, hipStream_t st, int splits) {
     const size_t sh = conv_h16_lds_bytes();
     static const bool attr_ok = [] {
         const int b = (int)conv_h16_lds_bytes();
-        return hipFuncSetAttribute((const void *)k_conv_h16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess &&
-               hipFuncSetAttribute((const void *)k_conv_h16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess &&
+        return hipFuncSetAttribute((const void *)k_conv_h16<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess &&
+               hipFuncSetAttribute((const void *)k_conv_h16<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess &&
                hipFuncSetAttribute((const void *)k_conv1_h16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess &&
                hipFuncSetAttribute((const void *)k_conv1_h16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b) == hipSuccess;
     }();
@@ -663,8 +733,8 @@ int conv_h16_launch(const ConvK &p, int f16, hipStream_t st, int splits) {
         else hipLaunchKernelGGL((k_conv1_h16<false>), grid, dim3(256), sh, st, p);
         return check_launch("k_conv1_h16");
     }
-    if (f16) hipLaunchKernelGGL((k_conv_h16<true>), grid, dim3(256), sh, st, p);
-    else hipLaunchKernelGGL((k_conv_h16<false>), grid, dim3(256), sh, st, p);
+    if (f16) hipLaunchKernelGGL((k_conv_h16<true, 1>), grid, dim3(256), sh, st, p);
+    else hipLaunchKernelGGL((k_conv_h16<false, 1>), grid, dim3(256), sh, st, p);
     return check_launch("k_conv_h16");
 }
 

@@ -191,7 +191,7 @@ Conv make_conv_w(Net &n, const float *w, const float *bias, int Cin, int Cout, i
     if (h2) {
         if (!n.dry && w) {
             void *dst = n.packed + n.packed_off;
-            if (hl::conv_pack_weights_h2(w, Cout, Cin, c.Cin_pad, dst, n.st) != 0 && n.err.empty()) n.err = hl_last_error();
+            if (hl::conv_pack_weights_h2(w, Cout, Cin, c.Cin_pad, ks, dst, n.st) != 0 && n.err.empty()) n.err = hl_last_error();
             c.w_h2 = dst;
         }
         n.packed_off += (h2 / 4 + 63) / 64 * 64;
@@ -1071,7 +1071,7 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
         rc = hl::conv_pack_weights_h16(w_oihw, Cout, Cin_w, Cin, ks, extra_dst, a.h16_fp16, (hipStream_t)stream, tf);
         a.w_wino = nullptr; a.w_wino4 = nullptr; a.w_bf3 = nullptr;
     } else if (a.path == 6) {
-        rc = hl::conv_pack_weights_h2(w_oihw, Cout, Cin_w, Cin, extra_dst, (hipStream_t)stream, tf);
+        rc = hl::conv_pack_weights_h2(w_oihw, Cout, Cin_w, Cin, ks, extra_dst, (hipStream_t)stream, tf);
         a.w_wino = nullptr; a.w_wino4 = nullptr; a.w_bf3 = nullptr;
     } else if (a.path == 3) {
         rc = hl::conv_pack_weights_wino4(w_oihw, Cout, Cin_w, Cin, static_cast<float *>(extra_dst), (hipStream_t)stream, tf);

@@ -109,8 +109,9 @@ int conv_h16_launch(const ConvK &p, int f16, hipStream_t st, int splits = 1);
 // products, fp32 accumulation); weights conv_pack_weights_h2 laid out (ConvK::w_bf3), ConvK::n_mtiles = pixels / 256, n_nblocks = Cout / 192.
 bool conv1_h2_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int ups);
 size_t conv_packed_h2_bytes(int Cout, int Cin_pad, int ks);
-int conv_pack_weights_h2(const float *w_oihw, int Cout, int Cin, int Cin_pad, void *packed, hipStream_t st, int tf = 0);
+int conv_pack_weights_h2(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st, int tf = 0);
 int conv1_h2_launch(const ConvK &p, hipStream_t st);
+int conv3_h2_launch(const ConvK &p, hipStream_t st, int splits = 1);   // 3x3 / stride 1: k_conv_h16's workgroups with two planes (ConvK::in16 = 2: a two-plane image from the GroupNorm pass)
 void set_h16_min_blocks(long v);   // developer / test switch: workgroups from which the dispatch takes k_conv_h16 (< 0: the default, 48)
 
 // Statistics block of one normalised VIEW (ConvArgs::stats): [shard][N][32 groups][2] 64-bit fixed-point totals.  Levels with many

@@ -1734,8 +1734,23 @@ __global__ void k_gn_apply(const float *__restrict__ x, long pitch, long pixels_
     }
 }
 
-// the same pass writing 16-bit values (fp16 / bf16, nearest even): the activation image of the k_conv_h16 / k_conv1_h16 layers behind a
-// GroupNorm - half the bytes written here and read there, no rounding in the convolution's staging
+// the two fp16 planes of four values (fp16x2 products, hl_conv_h16.hip: h0 = the value with its low 13 mantissa bits cleared - exact in fp16 inside
+// its range -, h1 = the truncated residual): image [plane][pixel][C]
+__device__ __forceinline__ void store_h2_planes(unsigned short *y, long at, long plane, const f32x4 o) {
+    unsigned q0[2], q1[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float a = o[2 * k], b = o[2 * k + 1];
+        const float ha = __builtin_bit_cast(float, __float_as_uint(a) & 0xffffe000u), hb = __builtin_bit_cast(float, __float_as_uint(b) & 0xffffe000u);
+        q0[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ha, hb));
+        q1[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - ha, b - hb));
+    }
+    *reinterpret_cast<uint2 *>(y + at) = uint2{q0[0], q0[1]};
+    *reinterpret_cast<uint2 *>(y + plane + at) = uint2{q1[0], q1[1]};
+}
+
+// the same pass writing 16-bit values (fp16 / bf16, nearest even; f16 = 2: the two fp16x2 planes): the activation image of the k_conv_h16 /
+// k_conv1_h16 layers behind a GroupNorm - half the bytes written here and read there, no rounding in the convolution's staging
 __global__ void k_gn_apply_h16(const float *__restrict__ x, long pitch, long pixels_per_img, long npix, int C, const float *__restrict__ cA,
                                const float *__restrict__ cB, int act, unsigned short *__restrict__ y, int f16) {
     const int cq = C >> 2;
@@ -1749,6 +1764,7 @@ __global__ void k_gn_apply_h16(const float *__restrict__ x, long pitch, long pix
         const f32x4 b = *reinterpret_cast<const f32x4 *>(cB + n * C + c);
         f32x4 o = v * a + b;
         if (act) { o[0] = silu_f(o[0]); o[1] = silu_f(o[1]); o[2] = silu_f(o[2]); o[3] = silu_f(o[3]); }
+        if (f16 == 2) { store_h2_planes(y, pix * C + c, npix * C, o); continue; }
         unsigned short h[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1787,6 +1803,8 @@ __global__ __launch_bounds__(256) void k_gn_apply_gs(const float *__restrict__ x
         if (act) { o[0] = silu_f(o[0]); o[1] = silu_f(o[1]); o[2] = silu_f(o[2]); o[3] = silu_f(o[3]); }
         if (OUT16 == 0) {
             *reinterpret_cast<f32x4 *>(static_cast<float *>(yv) + pix * C + c) = o;
+        } else if (f16 == 2) {
+            store_h2_planes(static_cast<unsigned short *>(yv), pix * C + c, (long)N * HW * C, o);
         } else {
             unsigned short h[4];
 #pragma unroll
@@ -2865,8 +2883,17 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     const bool h2 = !h16 && a.w_h2 && h2_min_blocks >= 0 && (!gn_on || a.act_ws) && !a.out_nchw && !a.w_bf3 &&
                     conv1_h2_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
                     (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0 && h2_blocks >= h2_min_blocks;
+    // 3x3 / stride-1 layers of the default mode in the same arithmetic (k_conv_h16<., 2>: k_conv_h16's workgroups, two planes, three products) where the
+    // layer has 100 ... 300 workgroups of 256 pixels x 192 channels, i.e. up to about one round of the chip: there the direct kernel beats the Winograd
+    // kernels' partial rounds (same box, forward wall time: B = 1 12.69 -> 12.41 ms, B = 4 31.88 -> 31.37, B = 8 57.81 -> 56.73).  Outside the window
+    // nothing moves although the kernel alone is 12 % faster on the 256-pixel level (461 against 523 us): profiles/r05_unet_fill_experiments.md.
+    static const long h3_min_blocks = [] { const char *e_ = getenv("HL_H2_CONV3_MIN_BLOCKS"); return e_ ? atol(e_) : 100L; }();   // developer knobs (read once); min < 0 disables
+    static const long h3_max_blocks = [] { const char *e_ = getenv("HL_H2_CONV3_MAX_BLOCKS"); return e_ ? atol(e_) : 300L; }();
+    const bool h3 = !h16 && !h2 && a.w_h2 && a.ks == 3 && h3_min_blocks >= 0 && (!gn_on || (a.act_ws && !a.ups)) && !a.out_nchw && !a.w_bf3 &&
+                    conv_h16_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
+                    (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0 && h16_blocks >= h3_min_blocks && h16_blocks <= h3_max_blocks;
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
-        a.path = h16 ? 5 : h2 ? 6 : (wino4 ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
+        a.path = h16 ? 5 : (h2 || h3) ? 6 : (wino4 ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
         return HL_OK;
     }
     if (h16) {
@@ -2906,6 +2933,36 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             return finish("k_conv_h16");
         }
         return conv_h16_launch(p, a.h16_fp16, st);
+    }
+    if (h3) {
+        a.path = 6;
+        p.in16 = 0;
+        if (mode != 0) {   // GroupNorm(+SiLU) materialised once, as the two-plane image the kernel stages without conversion (the same bytes as fp32)
+            HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
+            const long npix = a.in.pixels();
+            if (a.coefA == nullptr) {
+                const int ppw = std::max(1, 1024 / (a.in.C / 4));
+                hipLaunchKernelGGL(k_gn_apply_gs<1>, dim3((unsigned)((a.in.H * a.in.W + ppw - 1) / ppw), (unsigned)a.in.N), dim3(256), (size_t)(2 * a.in.C + COEF_SCR_FLOATS) * sizeof(float), st,
+                                   a.in.p, a.in.pitch, a.in.H * a.in.W, a.in.C, a.gn, a.in.N, a.act, (void *)a.act_ws, 2, ppw);
+            } else {
+                long g = (npix * (a.in.C / 4) + 255) / 256;
+                if (g > 4096) g = 4096;
+                hipLaunchKernelGGL(k_gn_apply_h16, dim3((unsigned)g), dim3(256), 0, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix, a.in.C, a.coefA,
+                                   a.coefB, a.act, reinterpret_cast<unsigned short *>(a.act_ws), 2);
+            }
+            p.in = a.act_ws; p.in_pitch = a.in.C; p.cA = nullptr; p.cB = nullptr; p.act = 0; p.gn = GnSrc{};
+            p.in16 = 2;
+            if (a.ev_mid) { hipEventRecord(a.ev_mid, st); a.ev_mid_used = 1; }
+        }
+        p.w_bf3 = a.w_h2; p.partial = nullptr;
+        p.kt_per = a.in.C / 32;
+        p.n_nblocks = a.Cout / 192;
+        p.n_mtiles = (int)((long)a.out.N * a.out.H * a.out.W / 256);
+        if (a.stats) {
+            p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
+            a.stat_slots = a.out.H * a.out.W / 128;
+        }
+        return conv3_h2_launch(p, st);
     }
     if (h2) {
         a.path = 6;

@@ -552,3 +552,47 @@ def test_conv1x1_fp16x2_products_match_float64(N, H, W, C, Cout, res, gn):
     # measured on MI355X: max-abs 3.6e-6 ... 7.5e-6 against 2.9e-6 ... 9.3e-6 of the fp32 direct kernel; rel-L2 3.1e-7 ... 3.7e-7
     assert e2 < 6e-6 * max(1.0, scale) * (C / 384) ** 0.5, (e2, scale)
     assert l2 < 8e-7 and l2 < 4 * l32 + 2e-7, (l2, l32)
+
+
+@pytest.mark.parametrize("N,H,W,C,Cout,res,gn,ups", [(1, 256, 256, 192, 192, True, True, 0), (4, 128, 128, 192, 192, False, False, 0), (4, 64, 64, 384, 384, True, True, 0),
+                                                   (4, 32, 32, 384, 384, False, False, 1), (2, 64, 64, 768, 384, False, True, 0)])
+def test_conv3x3_fp16x2_products_match_float64(N, H, W, C, Cout, res, gn, ups):
+    """The 3x3 / stride-1 layers of the DEFAULT mode with about one round of workgroups (100 ... 300 tiles of 256 pixels x 192 channels) run on
+    k_conv_h16<., 2>: a direct convolution, two fp16 planes per operand, three partial products, fp32 accumulation - against the float64 convolution
+    of the fp32 operands, with the GroupNorm pre-pass writing the two-plane image, the residual, and the nearest-x2 upsample in the patch gather."""
+    import torch.nn.functional as F
+    from humanliff_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(N + C + Cout + H)
+    x = torch.randn((N, H, W, C), generator=g) * 1.5
+    w = torch.randn((Cout, C, 3, 3), generator=g) / (9 * C) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    r = torch.randn((N, Ho, Wo, Cout), generator=g)
+    cA, cB = torch.rand((N, C), generator=g) + 0.5, torch.randn((N, C), generator=g) * 0.1
+    xin = F.silu((x * cA[:, None, None, :] + cB[:, None, None, :]).to(dev)).cpu() if gn else x     # (the pre-pass runs in fp32 on the GPU)
+    xi = xin.permute(0, 3, 1, 2).double()
+    if ups:
+        xi = F.interpolate(xi, scale_factor=2, mode="nearest")
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = F.conv2d(xi, w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    if res:
+        ref = ref + r.double()
+    xd, wd, bd, rd, ad, bd2 = (t.to(dev) for t in (x, w, b, r, cA, cB))
+    scratch = torch.empty(Cout * C * 9 * 8 + 256 + (64 << 20) + N * H * W * C, device=dev)
+    outs = {}
+    for mode in (_lib.HL_CONV_FP32, _lib.HL_CONV_FP32_DIRECT):
+        out = torch.zeros((N, Ho, Wo, Cout), device=dev)
+        _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(xd), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Cout, 3, 1, ups, _lib.ptr(ad) if gn else None,
+                                         _lib.ptr(bd2) if gn else None, 1 if gn else 0, _lib.ptr(rd) if res else None, _lib.ptr(out), _lib.ptr(scratch), scratch.numel() * 4,
+                                         _lib.stream_ptr()), "hl_conv2d_nhwc_mode")
+        outs[mode] = out.cpu().double()
+    out, out32 = outs[_lib.HL_CONV_FP32], outs[_lib.HL_CONV_FP32_DIRECT]
+    scale = float(ref.abs().mean())
+    e2, e32 = float((out - ref).abs().max()), float((out32 - ref).abs().max())
+    l2, l32 = float((out - ref).norm() / ref.norm()), float((out32 - ref).norm() / ref.norm())
+    print(f"3x3 {C}->{Cout} @{Ho}x{Wo} N{N}: fp16x2 max-abs {e2:.2e} rel-L2 {l2:.2e}; fp32 direct {e32:.2e} / {l32:.2e} (output mean-abs {scale:.2f})")
+    assert not torch.equal(out, out32)                      # the default mode really took another kernel
+    # measured on MI355X: max-abs 6.8e-6 ... 1.9e-5 (fp32 direct kernel 7.5e-6 ... 1.5e-5), rel-L2 5.0e-7 ... 1.2e-6 (fp32 direct 4.2e-7 ... 6.3e-7)
+    assert e2 < 6e-6 * max(1.0, scale) * (9 * C / 384) ** 0.5, (e2, scale)     # (the 1x1 test's bound at this reduction length)
+    assert l2 < 1.6e-6 and l2 < 4 * l32 + 2e-7, (l2, l32)
