@@ -304,6 +304,17 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
                 constexpr int rs = S % RING, cur = S & 1;
                 if constexpr (S + 1 < 18 && !(H16_ABL & 4)) a_read(st, (S + 1) >> 1, (S + 1) & 1, af[cur ^ 1]);
                 __builtin_amdgcn_sched_barrier(0);                 // the next step's fragments are on their way before this step's MFMAs
+#ifdef H2_ORDER_PRODUCT_OUTER
+                if constexpr (NPL == 2 && !(H16_ABL & 8)) {
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                        for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+                            for (int mf = 0; mf < 4; ++mf)
+                                acc[mf][nf] = mma<true>(af[cur][pr == 0 ? 1 : 0][mf], ring[rs][pr == 1 ? 1 : 0][nf], acc[mf][nf]);
+                } else
+#endif
 #pragma unroll
                 for (int nf = 0; nf < 3; ++nf)
 #pragma unroll

@@ -1790,37 +1790,54 @@ __global__ __launch_bounds__(256) void k_gn_apply_gs(const float *__restrict__ x
     const int n = blockIdx.y, tid = threadIdx.x;
     const int cq = C >> 2;
     const int p0 = blockIdx.x * ppw, p1 = min(HW, p0 + ppw);
-    f32x4 v0 = {0.f, 0.f, 0.f, 0.f};                      // the thread's first quad is requested before the coefficients are formed
-    if (tid < (p1 - p0) * cq) v0 = *reinterpret_cast<const f32x4 *>(x + ((long)n * HW + p0 + tid / cq) * pitch + (tid % cq) * 4);
-    coef_to_lds(nullptr, nullptr, gn, N, n, sA, sB, sh + 2 * C, tid, 256);
-    for (int i = tid; i < (p1 - p0) * cq; i += 256) {
-        const int px = i / cq, c = (i - px * cq) * 4;
-        const long pix = (long)n * HW + p0 + px;
-        const f32x4 v = i == tid ? v0 : *reinterpret_cast<const f32x4 *>(x + pix * pitch + c);
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(sA + c);
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(sB + c);
-        f32x4 o = v * a + b;
-        if (act) { o[0] = silu_f(o[0]); o[1] = silu_f(o[1]); o[2] = silu_f(o[2]); o[3] = silu_f(o[3]); }
-        if (OUT16 == 0) {
-            *reinterpret_cast<f32x4 *>(static_cast<float *>(yv) + pix * C + c) = o;
-        } else if (f16 == 2) {
-            store_h2_planes(static_cast<unsigned short *>(yv), pix * C + c, (long)N * HW * C, o);
-        } else {
-            unsigned short h[4];
+    const int nq = (p1 - p0) * cq;
+    const float *xb = x + ((long)n * HW + p0) * pitch;
+    // four quads per thread in flight; the first four are requested before the coefficients are formed (their round trips overlap)
+    f32x4 v[4];
+    auto fetch = [&](int i0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (f16) {
-                    const _Float16 hh = (_Float16)o[k];
-                    h[k] = __builtin_bit_cast(unsigned short, hh);
-                } else {
-                    const unsigned u = __float_as_uint(o[k]);
-                    h[k] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            if (i < nq) { const int px = i / cq; v[k] = *reinterpret_cast<const f32x4 *>(xb + (long)px * pitch + (i - px * cq) * 4); }
+        }
+    };
+    fetch(tid);
+    coef_to_lds(nullptr, nullptr, gn, N, n, sA, sB, sh + 2 * C, tid, 256);
+    for (int i0 = tid; i0 < nq; i0 += 1024) {
+        if (i0 != tid) fetch(i0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            if (i >= nq) break;
+            const int px = i / cq, c = (i - px * cq) * 4;
+            const long pix = (long)n * HW + p0 + px;
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(sA + c);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(sB + c);
+            f32x4 o = v[k] * a + b;
+            if (act) { o[0] = silu_f(o[0]); o[1] = silu_f(o[1]); o[2] = silu_f(o[2]); o[3] = silu_f(o[3]); }
+            if (OUT16 == 0) {
+                *reinterpret_cast<f32x4 *>(static_cast<float *>(yv) + pix * C + c) = o;
+            } else if (f16 == 2) {
+                store_h2_planes(static_cast<unsigned short *>(yv), pix * C + c, (long)N * HW * C, o);
+            } else {
+                unsigned short h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (f16) {
+                        const _Float16 hh = (_Float16)o[e];
+                        h[e] = __builtin_bit_cast(unsigned short, hh);
+                    } else {
+                        const unsigned u = __float_as_uint(o[e]);
+                        h[e] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+                    }
                 }
+                *reinterpret_cast<uint2 *>(static_cast<unsigned short *>(yv) + pix * C + c) = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
             }
-            *reinterpret_cast<uint2 *>(static_cast<unsigned short *>(yv) + pix * C + c) = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
         }
     }
 }
+// pixels per workgroup of that pass: about one round of workgroups (8 per compute unit) over the launch, at least four quads per thread
+static inline int gn_gs_ppw(int HW, int N, int C) { return std::max(std::max(1, 1024 / (C / 4)), (int)(((long)HW * N + 2047) / 2048)); }
 
 // split-K epilogue: sum the slabs in a fixed order (deterministic), then bias / residual / second output
 __global__ void k_splitk_finish(const ConvK p, int splits) {
@@ -2904,7 +2921,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             long g = (npix * (a.in.C / 4) + 255) / 256;
             if (g > 4096) g = 4096;
             if (a.coefA == nullptr) {
-                const int ppw = std::max(1, 1024 / (a.in.C / 4));
+                const int ppw = gn_gs_ppw(a.in.H * a.in.W, a.in.N, a.in.C);
                 hipLaunchKernelGGL(k_gn_apply_gs<1>, dim3((unsigned)((a.in.H * a.in.W + ppw - 1) / ppw), (unsigned)a.in.N), dim3(256), (size_t)(2 * a.in.C + COEF_SCR_FLOATS) * sizeof(float), st,
                                    a.in.p, a.in.pitch, a.in.H * a.in.W, a.in.C, a.gn, a.in.N, a.act, (void *)a.act_ws, a.h16_fp16, ppw);
             } else
@@ -2941,7 +2958,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
             const long npix = a.in.pixels();
             if (a.coefA == nullptr) {
-                const int ppw = std::max(1, 1024 / (a.in.C / 4));
+                const int ppw = gn_gs_ppw(a.in.H * a.in.W, a.in.N, a.in.C);
                 hipLaunchKernelGGL(k_gn_apply_gs<1>, dim3((unsigned)((a.in.H * a.in.W + ppw - 1) / ppw), (unsigned)a.in.N), dim3(256), (size_t)(2 * a.in.C + COEF_SCR_FLOATS) * sizeof(float), st,
                                    a.in.p, a.in.pitch, a.in.H * a.in.W, a.in.C, a.gn, a.in.N, a.act, (void *)a.act_ws, 2, ppw);
             } else {
@@ -2970,7 +2987,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
             const long npix = a.in.pixels();
             if (a.coefA == nullptr) {
-                const int ppw = std::max(1, 1024 / (a.in.C / 4));
+                const int ppw = gn_gs_ppw(a.in.H * a.in.W, a.in.N, a.in.C);
                 hipLaunchKernelGGL(k_gn_apply_gs<0>, dim3((unsigned)((a.in.H * a.in.W + ppw - 1) / ppw), (unsigned)a.in.N), dim3(256), (size_t)(2 * a.in.C + COEF_SCR_FLOATS) * sizeof(float), st,
                                    a.in.p, a.in.pitch, a.in.H * a.in.W, a.in.C, a.gn, a.in.N, a.act, (void *)a.act_ws, 0, ppw);
             } else {
@@ -3015,7 +3032,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
                 hipLaunchKernelGGL(k_gn_apply_blk, dim3((unsigned)(npix / tp / reps)), dim3(256), shb, st, a.in.p, a.in.pitch, (long)a.in.H * a.in.W, npix,
                                    a.in.C, a.coefA, a.coefB, a.act, a.act_ws, tp, a.in.C + pad, a.gn, a.in.N, reps);
             } else if (a.coefA == nullptr) {
-                const int ppw = std::max(1, 1024 / (a.in.C / 4));
+                const int ppw = gn_gs_ppw(a.in.H * a.in.W, a.in.N, a.in.C);
                 hipLaunchKernelGGL(k_gn_apply_gs<0>, dim3((unsigned)((a.in.H * a.in.W + ppw - 1) / ppw), (unsigned)a.in.N), dim3(256), (size_t)(2 * a.in.C + COEF_SCR_FLOATS) * sizeof(float), st,
                                    a.in.p, a.in.pitch, a.in.H * a.in.W, a.in.C, a.gn, a.in.N, a.act, (void *)a.act_ws, 0, ppw);
             } else
