@@ -1007,9 +1007,11 @@ def fit_stage_times(r, planes, bounds, ro, rd, nr, fr, N, dev):
         ("mlp_backward_new", lambda: L.hl_render_mlp_backward(p(packed), p(bwd), H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zn), 1, R, N, p(d_rec[T32 * N:]),
                                                               p(act), LD, T32 * N, p(delta), LD, T32 * N, st)),
         ("plane_grads", lambda: L.hl_render_plane_grads(H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(z), p(untile_rows(zn, R, N).contiguous()), 1, R, N, N,
-                                                        p(delta), LD, p(d_planes), st)),
-        ("weight_grads", lambda: L.hl_render_weight_grads(p(delta), LD, p(act), LD, P, C.byref(gp), st)),
+                                                        p(delta), LD, p(d_planes), p(pg_scratch), st)),
+        ("weight_grads", lambda: L.hl_render_weight_grads(p(delta), LD, p(act), LD, P, C.byref(gp), p(wg_scratch), st)),
     ]
+    pg_scratch = torch.empty(L.hl_render_plane_grads_scratch_bytes(R) // 4, dtype=torch.float32, device=dev)
+    wg_scratch = torch.empty(L.hl_render_weight_grads_scratch_bytes(P) // 4, dtype=torch.float32, device=dev)
     ms = {}
     for rep in range(2):          # second round is the measurement
         for name, fn in calls:

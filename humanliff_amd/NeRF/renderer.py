@@ -195,18 +195,23 @@ class Renderer(nn.Module):
                 # the stream-draining synchronous copy of pageable memory that cost the fitting loop its run-ahead (0.8 ms per step).
                 if self.uniforms_on_device:
                     u = torch.rand([bs * R, n_importance], device=dev)
-                elif self.test and not getattr(self, "cpu_uniforms_on_host", False) and bs * R * n_importance >= (1 << 16):
+                elif not getattr(self, "cpu_uniforms_on_host", False) and bs * R * n_importance >= (1 << 16):
                     # the reference's numbers (torch.rand of the CPU generator), written by the device: the host generator is advanced below,
                     # once everything of this call is enqueued (the draw of a 512x512 view costs the host 50 - 80 ms, the device runs it next to
-                    # the coarse pass)
+                    # the coarse pass; a fitting step's 0.5 M numbers cost the host ~1 ms and a 2 MB upload).  Test mode: only the importance
+                    # launch waits for the generator (hl_render_rays_u_event); training mode: the current stream waits (the generator runs on its
+                    # own stream, beside the tail of the previous step).
                     from .cpu_rng import rand_like_cpu
-                    u, pending_draw = rand_like_cpu([bs * R, n_importance], dev, defer_wait=True)
+                    u, pending_draw = rand_like_cpu([bs * R, n_importance], dev, defer_wait=self.test)
                 else:
                     u = torch.rand([bs * R, n_importance], pin_memory=True).to(dev, non_blocking=True)
             u = u.reshape(bs, R, n_importance)
         if not self.test:
-            return self._render_training(tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,
-                                         noise, tp_input if self.use_canonical_space else None)
+            out = self._render_training(tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,
+                                        noise, tp_input if self.use_canonical_space else None)
+            if pending_draw is not None:
+                pending_draw.finish()         # the CPU generator now stands where the reference's torch.rand would have left it
+            return out
         L = _lib.lib()
         packed = self._packed_mlp(dev)
         ws = self._workspace(L.hl_render_workspace_bytes(R, n_samples, n_importance), dev)

@@ -135,8 +135,9 @@ class RenderRaysFunction(torch.autograd.Function):
         elif ctx.needs_input_grad[2]:
             from .renderer import untile_rows
             zr = untile_rows(zn, R, Ni).contiguous()      # the scatter walks one ray per wave: give it the depths of a ray in one line
+            sb = torch.empty(L.hl_render_plane_grads_scratch_bytes(R) // 4, dtype=torch.float32, device=dev)
             _lib.check(L.hl_render_plane_grads(H, W, p(bd), p(ro), p(rd), p(nr), p(fr), p(zb), p(zr), 1, R, N, Ni, p(delta), LD, p(d_planes),
-                                               st), "hl_render_plane_grads")
+                                               p(sb), st), "hl_render_plane_grads")
         # all 14 parameter gradients: rows of `delta` x rows of `act` over the sample points (include/humanliff_hip.h lists the rows)
         flat = torch.zeros(sum(t.numel() for t in mlp), dtype=torch.float32, device=dev)
         grads, o = [], 0
@@ -144,7 +145,8 @@ class RenderRaysFunction(torch.autograd.Function):
             grads.append(flat[o:o + t.numel()].view(t.shape))
             o += t.numel()
         gp = _lib.RenderMlpParams(*[C.c_void_p(g.data_ptr()) for g in grads])
-        _lib.check(L.hl_render_weight_grads(p(delta), LD, p(act), LD, P, C.byref(gp), st), "hl_render_weight_grads")
+        wsb = torch.empty(L.hl_render_weight_grads_scratch_bytes(P) // 4, dtype=torch.float32, device=dev)    # the point ranges' partial results
+        _lib.check(L.hl_render_weight_grads(p(delta), LD, p(act), LD, P, C.byref(gp), p(wsb), st), "hl_render_weight_grads")
         needs = ctx.needs_input_grad   # (renderer, geo, planes, *mlp)
         out = [None, None, d_planes.view(3, 9, H, W) if needs[2] else None]
         out += [g if needs[3 + i] else None for i, g in enumerate(grads)]

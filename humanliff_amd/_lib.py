@@ -85,9 +85,11 @@ SIGNATURES = {
     "hl_render_eval_points_acts": (_i, [_p, _p, _i, _i, _p, _p, _p, _i64, _i, _p, _p, _i64, _i64, _p]),
     "hl_render_plane_grads_points_scratch_bytes": (_sz, [_i64, _i, _i]),
     "hl_render_plane_grads_points": (_i, [_i, _i, _p, _p, _p, _i64, _i, _i, _p, _i64, _p, _p, _p]),
-    "hl_render_weight_grads": (_i, [_p, _i64, _p, _i64, _i64, C.POINTER(RenderMlpParams), _p]),
+    "hl_render_weight_grads": (_i, [_p, _i64, _p, _i64, _i64, C.POINTER(RenderMlpParams), _p, _p]),
+    "hl_render_weight_grads_scratch_bytes": (_sz, [_i64]),
+    "hl_render_plane_grads_scratch_bytes": (_sz, [_i64]),
     "hl_render_mlp_backward": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _p, _p, _i64, _i64, _p, _i64, _i64, _p]),
-    "hl_render_plane_grads": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _i64, _p, _p]),
+    "hl_render_plane_grads": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _i64, _p, _p, _p]),
     "hl_render_fine": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _u, _p, _p, _p, _p]),
     "hl_unet_packed_bytes": (_sz, [C.POINTER(UNetCfg)]),
     "hl_unet_create": (_i, [C.POINTER(UNetCfg), _i, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),

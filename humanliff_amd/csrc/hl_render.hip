@@ -2781,13 +2781,18 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 // The feature-delta rows come out of k_mlp_bwd in the record order (tile-major: 32 rays per sample side by side); the scatter kernels
 // walk one ray per wave with lanes = samples, which in that order is a 4-byte gather per lane (measured 0.9-1.8 GB of sector traffic
 // for 57 MB of payload).  k_df_transpose rewrites the 27 rows ray-major (row DROW_DFT + k, column pass offset + ray * S + s).
+// Each workgroup also records the largest |value| it moved (as a bit pattern: NaN > inf > finite) in wmax[tile * 27 + k]: the scatter kernels
+// derive the scale of their fixed-point accumulators from the maximum over all of them (sc_fixed_scale).
 struct DfTransposeArgs {
     float *del;
     long long del_stride, R;
     int N, Ni;
+    unsigned *wmax;
 };
 __global__ __launch_bounds__(256) void k_df_transpose(const DfTransposeArgs a) {
     __shared__ float t[64][33];
+    __shared__ unsigned wred[4];
+    unsigned vmax = 0;
     const int k = blockIdx.x;
     const long long tile = blockIdx.y;
     const long long tiles_n = (a.R + 31) / 32, colsA = tiles_n * 32 * a.N;
@@ -2799,7 +2804,7 @@ __global__ __launch_bounds__(256) void k_df_transpose(const DfTransposeArgs a) {
         for (int s0 = 0; s0 < S; s0 += 64) {
             for (int i = threadIdx.x; i < 64 * 32; i += 256) {
                 const int s = s0 + (i >> 5), r = i & 31;
-                if (s < S) t[i >> 5][r] = src[base + (tile * S + s) * 32 + r];
+                if (s < S) { const float v = src[base + (tile * S + s) * 32 + r]; t[i >> 5][r] = v; vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu); }
             }
             __syncthreads();
             for (int i = threadIdx.x; i < 64 * 32; i += 256) {
@@ -2810,6 +2815,38 @@ __global__ __launch_bounds__(256) void k_df_transpose(const DfTransposeArgs a) {
             __syncthreads();
         }
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, d));
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) a.wmax[tile * 27 + k] = max(max(wred[0], wred[1]), max(wred[2], wred[3]));
+}
+
+// Fixed-point accumulation of the scatter kernels (bit-reproducible: integer additions commute).  vmax = the largest |feature delta| of the
+// call (2^E <= vmax < 2^(E+1)), n_pts = sample points: a texel's sum of |delta x bilinear weight| stays below n_pts x 2^(E+1), so with the unit
+// 2^-k, k = 61 - ceil(log2 n_pts) - (E + 1), the 64-bit accumulator cannot overflow and a contribution is rounded at 2^-(43 ... 62) of vmax -
+// below fp32's own rounding of the sum.  Returns false when a delta is not finite (the outputs are NaN then).
+__device__ __forceinline__ bool sc_fixed_scale(const unsigned *wmax, long long n_wmax, long long n_pts, unsigned *red, double &scale, double &inv) {
+    unsigned m = 0;
+    for (long long i = threadIdx.x; i < n_wmax; i += blockDim.x) m = max(m, wmax[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = max(m, red[w]);
+    __syncthreads();
+    if (m >= 0x7f800000u) return false;
+    const int E = (int)(m >> 23) - 127;
+    int cl = 0;
+    while ((1LL << cl) < n_pts) ++cl;
+    const int k = 61 - cl - (E + 1);
+    scale = ldexp(1.0, k);
+    inv = ldexp(1.0, -k);
+    return true;
+}
+__device__ __forceinline__ void sc_add(unsigned long long *t, float c, double scale) {
+    atomicAdd(t, (unsigned long long)__double2ll_rn((double)c * scale));
 }
 
 // Tri-plane gradient: transpose of the bilinear lookup [renderer.py:502-531].  Sending every sample point's 27 feature deltas
@@ -2817,7 +2854,7 @@ __global__ __launch_bounds__(256) void k_df_transpose(const DfTransposeArgs a) {
 // backward kernel, bound by the L2 atomic units).  Instead one workgroup OWNS a 16x16-texel tile of one (plane, group) image
 // - 3 channels, 3 KB of LDS; 2 304 workgroups of 512 threads at 256x256: measured best of 8..64-texel tiles - scans all sample points of the batch (recomputing the forward pass's texel coordinates bit for bit),
 // accumulates the taps that fall into its tile with LDS atomics, and writes the tile out with plain stores: no global atomics, no
-// zero-fill, and the result depends on the run only through the order of LDS additions.
+// zero-fill; the LDS accumulators are 64-bit fixed point (sc_fixed_scale), so the result is the same bits on every run.
 struct ScatterArgs {
     const float *rays_o, *rays_d, *near, *far, *bounds;
     const float *zc, *zn;        // coarse depths: rows (R,N) or null -> linspace; new depths: rows (R,Ni) (zn_rows) or tile-major
@@ -2827,16 +2864,26 @@ struct ScatterArgs {
     const float *del;            // rows DROW_DF..+26, columns: coarse pass then new depths
     long long del_stride;
     float *dplanes;              // (27, H, W), overwritten
+    const unsigned *wmax;        // k_df_transpose's per-workgroup maxima
 };
 constexpr int SC_TILE = 16, SC_THREADS = 512;
 
 __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs a) {
-    __shared__ float acc[3 * SC_TILE * SC_TILE];
+    __shared__ unsigned long long acc[3 * SC_TILE * SC_TILE];
+    __shared__ unsigned red[SC_THREADS / 64];
     const int q = blockIdx.x, p = q / 3, g = q % 3;
     const int tiles_x = (a.W + SC_TILE - 1) / SC_TILE;
     const int tx0 = (int)(blockIdx.y % tiles_x) * SC_TILE, ty0 = (int)(blockIdx.y / tiles_x) * SC_TILE;
-    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) acc[i] = 0.f;
-    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) acc[i] = 0ull;
+    double scale, inv;
+    const bool finite = sc_fixed_scale(a.wmax, ((a.R + 31) / 32) * 27, a.R * (long long)(a.N + a.Ni), red, scale, inv);      // (ends with a barrier)
+    if (!finite) {
+        for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) {
+            const int c = i / (SC_TILE * SC_TILE), y = (i / SC_TILE) % SC_TILE + ty0, x = i % SC_TILE + tx0;
+            if (y < a.H && x < a.W) a.dplanes[((long long)(3 * q + c) * a.H + y) * a.W + x] = __builtin_nanf("");
+        }
+        return;
+    }
     const long long tiles_n = (a.R + 31) / 32;
     const long long colsA = tiles_n * 32 * a.N;
     const float offH = (float)(1.0 / (double)a.H);
@@ -2920,11 +2967,11 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs 
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float v = df[(long long)c * a.del_stride + col];
-                    float *t = acc + c * SC_TILE * SC_TILE;
-                    if (vx0 & vy0) atomicAdd(t + y0 * SC_TILE + x0, v * w_nw);
-                    if (vx1 & vy0) atomicAdd(t + y0 * SC_TILE + x1, v * w_ne);
-                    if (vx0 & vy1) atomicAdd(t + y1 * SC_TILE + x0, v * w_sw);
-                    if (vx1 & vy1) atomicAdd(t + y1 * SC_TILE + x1, v * w_se);
+                    unsigned long long *t = acc + c * SC_TILE * SC_TILE;
+                    if (vx0 & vy0) sc_add(t + y0 * SC_TILE + x0, v * w_nw, scale);
+                    if (vx1 & vy0) sc_add(t + y0 * SC_TILE + x1, v * w_ne, scale);
+                    if (vx0 & vy1) sc_add(t + y1 * SC_TILE + x0, v * w_sw, scale);
+                    if (vx1 & vy1) sc_add(t + y1 * SC_TILE + x1, v * w_se, scale);
                 }
             }
         }
@@ -2933,7 +2980,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter(const ScatterArgs 
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) {
         const int c = i / (SC_TILE * SC_TILE), y = (i / SC_TILE) % SC_TILE + ty0, x = i % SC_TILE + tx0;
-        if (y < a.H && x < a.W) a.dplanes[((long long)(3 * q + c) * a.H + y) * a.W + x] = acc[i];
+        if (y < a.H && x < a.W) a.dplanes[((long long)(3 * q + c) * a.H + y) * a.W + x] = (float)((double)(long long)acc[i] * inv);
     }
 }
 
@@ -2950,6 +2997,7 @@ struct ScatterPtsArgs {
     long long del_stride;
     float *dplanes;
     float *bbox;                 // [blocks][6]: min xyz, max xyz of the block's normalised coordinates
+    const unsigned *wmax;        // k_df_transpose's per-workgroup maxima
 };
 
 __device__ __forceinline__ void scatter_blocks(const ScatterPtsArgs &a, int &nbA, int &nbB) { nbA = (a.N + 63) / 64; nbB = (a.Ni + 63) / 64; }
@@ -2980,12 +3028,21 @@ __global__ __launch_bounds__(256) void k_block_bbox(const ScatterPtsArgs a) {
 }
 
 __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter_pts(const ScatterPtsArgs a) {
-    __shared__ float acc[3 * SC_TILE * SC_TILE];
+    __shared__ unsigned long long acc[3 * SC_TILE * SC_TILE];
+    __shared__ unsigned red[SC_THREADS / 64];
     const int q = blockIdx.x, p = q / 3, g = q % 3;
     const int tiles_x = (a.W + SC_TILE - 1) / SC_TILE;
     const int tx0 = (int)(blockIdx.y % tiles_x) * SC_TILE, ty0 = (int)(blockIdx.y / tiles_x) * SC_TILE;
-    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) acc[i] = 0.f;
-    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) acc[i] = 0ull;
+    double scale, inv;
+    const bool finite = sc_fixed_scale(a.wmax, ((a.R + 31) / 32) * 27, a.R * (long long)(a.N + a.Ni), red, scale, inv);      // (ends with a barrier)
+    if (!finite) {
+        for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) {
+            const int c = i / (SC_TILE * SC_TILE), y = (i / SC_TILE) % SC_TILE + ty0, x = i % SC_TILE + tx0;
+            if (y < a.H && x < a.W) a.dplanes[((long long)(3 * q + c) * a.H + y) * a.W + x] = __builtin_nanf("");
+        }
+        return;
+    }
     int nbA, nbB;
     scatter_blocks(a, nbA, nbB);
     const long long tiles_n = (a.R + 31) / 32;
@@ -3037,18 +3094,18 @@ __global__ __launch_bounds__(SC_THREADS) void k_plane_scatter_pts(const ScatterP
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float v = df[(long long)c * a.del_stride + col];
-                float *t = acc + c * SC_TILE * SC_TILE;
-                if (vx0 & vy0) atomicAdd(t + y0 * SC_TILE + x0, v * w_nw);
-                if (vx1 & vy0) atomicAdd(t + y0 * SC_TILE + x1, v * w_ne);
-                if (vx0 & vy1) atomicAdd(t + y1 * SC_TILE + x0, v * w_sw);
-                if (vx1 & vy1) atomicAdd(t + y1 * SC_TILE + x1, v * w_se);
+                unsigned long long *t = acc + c * SC_TILE * SC_TILE;
+                if (vx0 & vy0) sc_add(t + y0 * SC_TILE + x0, v * w_nw, scale);
+                if (vx1 & vy0) sc_add(t + y0 * SC_TILE + x1, v * w_ne, scale);
+                if (vx0 & vy1) sc_add(t + y1 * SC_TILE + x0, v * w_sw, scale);
+                if (vx1 & vy1) sc_add(t + y1 * SC_TILE + x1, v * w_se, scale);
             }
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * SC_TILE * SC_TILE; i += SC_THREADS) {
         const int c = i / (SC_TILE * SC_TILE), y = (i / SC_TILE) % SC_TILE + ty0, x = i % SC_TILE + tx0;
-        if (y < a.H && x < a.W) a.dplanes[((long long)(3 * q + c) * a.H + y) * a.W + x] = acc[i];
+        if (y < a.H && x < a.W) a.dplanes[((long long)(3 * q + c) * a.H + y) * a.W + x] = (float)((double)(long long)acc[i] * inv);
     }
 }
 
@@ -3075,6 +3132,8 @@ struct WgradArgs {
     const float *del, *act;
     long long del_stride, act_stride, n_cols;
     int k_per_wg;                          // points per workgroup (multiple of 32)
+    float *part;                           // partial results [point range][part_len]: job j at part_off[j], C[i][n] at i * N + n, the bias sums behind
+    int part_off[WGRAD_JOBS], part_len;
 };
 
 // eight consecutive points of a row -> the three bf16 planes of one v_mfma_f32_32x32x16_bf16 operand (exact split by truncation)
@@ -3180,6 +3239,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
         }
     }
     if (wave >= MT) return;
+    float *pt = a.part + (long long)blockIdx.y * a.part_len + a.part_off[blockIdx.x];
     // C[i][n]: lane holds column n = 32 t + row and rows i = 32 wave + unit_of(0, r, half)
 #pragma unroll
     for (int t = 0; t < WGRAD_MAX_NB; ++t) {
@@ -3188,15 +3248,43 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = 32 * wave + unit_of(0, r, half);
-                if (i < jb.M) atomicAdd(jb.out + (long long)i * jb.ld_i + (long long)n * jb.ld_n, acc[t][r]);
+                if (i < jb.M) pt[i * jb.N + n] = acc[t][r];
             }
         }
     }
     bsum += __shfl_xor(bsum, 32);
     const int m = 32 * wave + row;
-    if (!jb.a_is_act) { if (half == 0 && m < jb.M && jb.bias_out) atomicAdd(jb.bias_out + m, bsum); }
-    else if (wave == 0 && half == 0 && row < jb.N && jb.bias_out) atomicAdd(jb.bias_out + row, bsum);
+    if (!jb.a_is_act) { if (half == 0 && m < jb.M) pt[jb.M * jb.N + m] = bsum; }
+    else if (wave == 0 && half == 0 && row < jb.N) pt[jb.M * jb.N + row] = bsum;
 #endif
+}
+
+// the point ranges' partial results summed in a FIXED order and added to the gradient tensors (plain stores: the result is the same bits on every run)
+__global__ __launch_bounds__(256) void k_wgrad_finish(const WgradArgs a, int n_ranges) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.part_len) return;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < WGRAD_JOBS; ++q) j = e >= a.part_off[q] ? q : j;
+    const WgradJob jb = a.job[j];
+    const int le = e - a.part_off[j];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four interleaved chains (ranges y = 0, 4, 8 ... / 1, 5, ... ), always combined the same way
+    const float *src = a.part + e;
+    int y = 0;
+    for (; y + 4 <= n_ranges; y += 4) {
+        s0 += src[(long long)y * a.part_len];
+        s1 += src[(long long)(y + 1) * a.part_len];
+        s2 += src[(long long)(y + 2) * a.part_len];
+        s3 += src[(long long)(y + 3) * a.part_len];
+    }
+    for (; y < n_ranges; ++y) s0 += src[(long long)y * a.part_len];
+    const float tot = (s0 + s1) + (s2 + s3);
+    if (le < jb.M * jb.N) {
+        const int i = le / jb.N, n = le - i * jb.N;
+        jb.out[(long long)i * jb.ld_i + (long long)n * jb.ld_n] += tot;
+    } else {
+        jb.bias_out[le - jb.M * jb.N] += tot;
+    }
 }
 
 extern "C" {
@@ -3535,13 +3623,14 @@ int hl_render_mlp_backward(const void *mlp_packed, const void *mlp_bwd_packed, i
 
 int hl_render_plane_grads(int H, int W, const float *bounds, const float *rays_o, const float *rays_d, const float *near, const float *far,
                           const float *z_vals, const float *z_new, int z_new_rows, int64_t n_rays, int n_samples, int n_importance,
-                          const float *del, int64_t del_stride, float *d_planes, void *stream) {
-    HL_REQUIRE(bounds && rays_o && rays_d && near && far && z_new && del && d_planes, "hl_render_plane_grads: null argument");
+                          const float *del, int64_t del_stride, float *d_planes, void *scratch, void *stream) {
+    HL_REQUIRE(bounds && rays_o && rays_d && near && far && z_new && del && d_planes && scratch, "hl_render_plane_grads: null argument");
     HL_REQUIRE(H > 0 && W > 0 && n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_plane_grads: bad sizes");
     HL_REQUIRE(del_stride >= tiles32(n_rays) * 32 * (int64_t)(n_samples + n_importance), "hl_render_plane_grads: delta rows too short");
-    DfTransposeArgs tr{const_cast<float *>(del), del_stride, n_rays, n_samples, n_importance};
+    DfTransposeArgs tr{const_cast<float *>(del), del_stride, n_rays, n_samples, n_importance, (unsigned *)scratch};
     hipLaunchKernelGGL(k_df_transpose, dim3(27, (unsigned)tiles32(n_rays)), dim3(256), 0, (hipStream_t)stream, tr);
-    ScatterArgs a{rays_o, rays_d, near, far, bounds, z_vals, z_new, z_new_rows, n_rays, n_samples, n_importance, H, W, del, del_stride, d_planes};
+    ScatterArgs a{rays_o, rays_d, near, far, bounds, z_vals, z_new, z_new_rows, n_rays, n_samples, n_importance, H, W, del, del_stride, d_planes,
+                  (const unsigned *)scratch};
     const unsigned tiles = (unsigned)(((W + SC_TILE - 1) / SC_TILE) * ((H + SC_TILE - 1) / SC_TILE));
     hipLaunchKernelGGL(k_plane_scatter, dim3(9, tiles), dim3(SC_THREADS), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_plane_scatter");
@@ -3568,8 +3657,11 @@ int hl_render_eval_points_acts(const void *mlp_packed, const void *planes_packed
     return hl::check_launch("k_march<eval points, acts>");
 }
 
+// (per-workgroup maxima of k_df_transpose: 27 per tile of 32 rays)
+size_t hl_render_plane_grads_scratch_bytes(int64_t n_rays) { return ((size_t)tiles32(n_rays) * 27 * sizeof(unsigned) + 255) / 256 * 256; }
+
 size_t hl_render_plane_grads_points_scratch_bytes(int64_t n_rays, int n_samples, int n_importance) {
-    return (size_t)n_rays * (size_t)((n_samples + 63) / 64 + (n_importance + 63) / 64) * 6 * sizeof(float) + 256;
+    return hl_render_plane_grads_scratch_bytes(n_rays) + (size_t)n_rays * (size_t)((n_samples + 63) / 64 + (n_importance + 63) / 64) * 6 * sizeof(float) + 256;
 }
 
 int hl_render_plane_grads_points(int H, int W, const float *bounds, const float *pts_coarse, const float *pts_new, int64_t n_rays,
@@ -3578,10 +3670,10 @@ int hl_render_plane_grads_points(int H, int W, const float *bounds, const float 
     HL_REQUIRE(bounds && pts_coarse && pts_new && del && d_planes && scratch, "hl_render_plane_grads_points: null argument");
     HL_REQUIRE(H > 0 && W > 0 && n_rays > 0 && n_samples >= 1 && n_importance >= 1, "hl_render_plane_grads_points: bad sizes");
     HL_REQUIRE(del_stride >= tiles32(n_rays) * 32 * (int64_t)(n_samples + n_importance), "hl_render_plane_grads_points: delta rows too short");
-    DfTransposeArgs tr{const_cast<float *>(del), del_stride, n_rays, n_samples, n_importance};
+    DfTransposeArgs tr{const_cast<float *>(del), del_stride, n_rays, n_samples, n_importance, (unsigned *)scratch};
     hipLaunchKernelGGL(k_df_transpose, dim3(27, (unsigned)tiles32(n_rays)), dim3(256), 0, (hipStream_t)stream, tr);
     ScatterPtsArgs a{{(const float4 *)pts_coarse, (const float4 *)pts_new}, bounds, n_rays, n_samples, n_importance, H, W, del, del_stride,
-                     d_planes, (float *)scratch};
+                     d_planes, reinterpret_cast<float *>(static_cast<char *>(scratch) + hl_render_plane_grads_scratch_bytes(n_rays)), (const unsigned *)scratch};
     const long long nblk = n_rays * ((n_samples + 63) / 64 + (n_importance + 63) / 64);
     hipLaunchKernelGGL(k_block_bbox, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     int rcode = hl::check_launch("k_block_bbox");
@@ -3591,29 +3683,54 @@ int hl_render_plane_grads_points(int H, int W, const float *bounds, const float 
     return hl::check_launch("k_plane_scatter_pts");
 }
 
+static int64_t wgrad_points_per_range(int64_t n_cols) {   // 256 point ranges of at least 1024 points
+    int64_t per = ((n_cols + 255) / 256 + 31) / 32 * 32;
+    return per < 1024 ? 1024 : per;
+}
+static void wgrad_jobs(WgradArgs &a, const hl_render_mlp_grads *g) {
+    a.job[0] = WgradJob{DROW_X0, 128, ROW_F, 27, 0, 27, 1, g ? g->pts0_w : nullptr, g ? g->pts0_b : nullptr};
+    a.job[1] = WgradJob{DROW_X1, 128, ROW_X0, 128, 0, 128, 1, g ? g->pts1_w : nullptr, g ? g->pts1_b : nullptr};
+    a.job[2] = WgradJob{DROW_X2, 128, ROW_F, 155, 0, 155, 1, g ? g->pts2_w : nullptr, g ? g->pts2_b : nullptr};       // input = [features | hidden1] = rows 0..154
+    a.job[3] = WgradJob{DROW_Y, 128, ROW_X2, 128, 0, 128, 1, g ? g->feat_w : nullptr, g ? g->feat_b : nullptr};
+    a.job[4] = WgradJob{DROW_V, 64, ROW_Y, 155, 0, 155, 1, g ? g->views_w : nullptr, g ? g->views_b : nullptr};        // input = [feature | view encoding]
+    // heads, operands swapped: A = activation rows (128 / 64), B = their 1 / 3 delta rows; C[i][n] -> weight[n][i]
+    a.job[5] = WgradJob{ROW_X2, 128, DROW_REC, 1, 1, 1, 128, g ? g->alpha_w : nullptr, g ? g->alpha_b : nullptr};
+    a.job[6] = WgradJob{ROW_V, 64, DROW_REC + 1, 3, 1, 1, 64, g ? g->rgb_w : nullptr, g ? g->rgb_b : nullptr};
+    int off = 0;
+    for (int j = 0; j < WGRAD_JOBS; ++j) {
+        a.part_off[j] = off;
+        off += a.job[j].M * a.job[j].N + (a.job[j].a_is_act ? a.job[j].N : a.job[j].M);      // the products, then the bias sums (rows of the delta operand)
+    }
+    a.part_len = off;
+}
+
+size_t hl_render_weight_grads_scratch_bytes(int64_t n_cols) {
+    if (n_cols <= 0) return 0;
+    WgradArgs a{};
+    wgrad_jobs(a, nullptr);
+    const int64_t per = wgrad_points_per_range(n_cols);
+    return (size_t)((n_cols + per - 1) / per) * a.part_len * sizeof(float);
+}
+
 int hl_render_weight_grads(const float *del, int64_t del_stride, const float *act, int64_t act_stride, int64_t n_cols,
-                           const hl_render_mlp_grads *g, void *stream) {
-    HL_REQUIRE(del && act && g && n_cols > 0 && n_cols % 32 == 0 && del_stride >= n_cols && act_stride >= n_cols,
+                           const hl_render_mlp_grads *g, void *scratch, void *stream) {
+    HL_REQUIRE(del && act && g && scratch && n_cols > 0 && n_cols % 32 == 0 && del_stride >= n_cols && act_stride >= n_cols,
                "hl_render_weight_grads: bad argument");
     HL_REQUIRE((int64_t)ACT_ROWS * act_stride * 4 < (1LL << 31) && (int64_t)DEL_ROWS * del_stride * 4 < (1LL << 31),
                "hl_render_weight_grads: activation / delta matrices must stay below 2 GiB");
     WgradArgs a{};
-    a.job[0] = WgradJob{DROW_X0, 128, ROW_F, 27, 0, 27, 1, g->pts0_w, g->pts0_b};
-    a.job[1] = WgradJob{DROW_X1, 128, ROW_X0, 128, 0, 128, 1, g->pts1_w, g->pts1_b};
-    a.job[2] = WgradJob{DROW_X2, 128, ROW_F, 155, 0, 155, 1, g->pts2_w, g->pts2_b};       // input = [features | hidden1] = rows 0..154
-    a.job[3] = WgradJob{DROW_Y, 128, ROW_X2, 128, 0, 128, 1, g->feat_w, g->feat_b};
-    a.job[4] = WgradJob{DROW_V, 64, ROW_Y, 155, 0, 155, 1, g->views_w, g->views_b};        // input = [feature | view encoding]
-    // heads, operands swapped: A = activation rows (128 / 64), B = their 1 / 3 delta rows; C[i][n] -> weight[n][i]
-    a.job[5] = WgradJob{ROW_X2, 128, DROW_REC, 1, 1, 1, 128, g->alpha_w, g->alpha_b};
-    a.job[6] = WgradJob{ROW_V, 64, DROW_REC + 1, 3, 1, 1, 64, g->rgb_w, g->rgb_b};
+    wgrad_jobs(a, g);
     for (int j = 0; j < WGRAD_JOBS; ++j) HL_REQUIRE(a.job[j].out && a.job[j].bias_out, "hl_render_weight_grads: null gradient pointer %d", j);
     a.del = del; a.act = act; a.del_stride = del_stride; a.act_stride = act_stride; a.n_cols = n_cols;
-    // 7 layers x 256 point ranges of at least 1024 points
-    int64_t per = ((n_cols + 255) / 256 + 31) / 32 * 32;
-    if (per < 1024) per = 1024;
+    const int64_t per = wgrad_points_per_range(n_cols);
     a.k_per_wg = (int)per;
-    hipLaunchKernelGGL(k_wgrad, dim3(WGRAD_JOBS, (unsigned)((n_cols + per - 1) / per)), dim3(256), 0, (hipStream_t)stream, a);
-    return hl::check_launch("k_wgrad");
+    a.part = static_cast<float *>(scratch);
+    const int n_ranges = (int)((n_cols + per - 1) / per);
+    hipLaunchKernelGGL(k_wgrad, dim3(WGRAD_JOBS, (unsigned)n_ranges), dim3(256), 0, (hipStream_t)stream, a);
+    int rc = hl::check_launch("k_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((a.part_len + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, n_ranges);
+    return hl::check_launch("k_wgrad_finish");
 }
 
 int hl_render_rays(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds,

@@ -167,13 +167,19 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
  *                                 then the new depths); scratch: hl_render_composite_backward_scratch_bytes()
  *   hl_render_mlp_backward        one pass's d_records + activations -> its columns of the delta matrix
  *   hl_render_plane_grads         feature deltas of both passes -> d_planes (27,H,W), overwritten: the transposed bilinear lookup;
- *                                 each workgroup owns a tile of texels and accumulates in LDS (no global atomics; LDS float atomics:
- *                                 summation order, hence the last bits, vary from run to run)
+ *                                 each workgroup owns a tile of texels and accumulates in LDS (no global atomics) in 64-bit FIXED
+ *                                 POINT whose unit comes from the largest |delta| of the call: integer additions commute, so the
+ *                                 result is the same bits on every run (round 5; rounding per contribution 2^-43 of that maximum
+ *                                 or finer); a delta that is not finite makes the output NaN.
+ *                                 scratch: hl_render_plane_grads_scratch_bytes()
  *   hl_render_mlp_pack_bwd        transposed weights for hl_render_mlp_backward (redo after every optimizer step, like
  *                                 hl_render_mlp_pack)
  *   hl_render_weight_grads        all 14 parameter gradients from the two matrices over n_cols sample points (multiple of 32), ADDED
- *                                 to the tensors of `grads` (PyTorch layouts, zero them first) with float atomics; fp32 products
- *                                 from exact three-way bf16 splits of both operands, fp32 accumulation (k_wgrad) */
+ *                                 to the tensors of `grads` (PyTorch layouts, zero them first); fp32 products from exact
+ *                                 three-way bf16 splits of both operands, fp32 accumulation (k_wgrad).  The 256 point ranges
+ *                                 write their partial results to `scratch` (hl_render_weight_grads_scratch_bytes(n_cols)) and
+ *                                 k_wgrad_finish sums them in a fixed order: the same bits on every run (round 5; before: float
+ *                                 atomics) */
 /* Canonical-space training (use_canonical_space=True with test=False; README.md:123 TightCap fitting): the deformation has no
  * parameters and the points get no gradient, so the backward is the one above with two substitutions -
  *   hl_render_eval_points_acts     hl_render_eval_points that also writes the activation matrix (forward, per pass)
@@ -191,8 +197,9 @@ typedef struct hl_render_mlp_grads {
     float *pts0_w, *pts0_b, *pts1_w, *pts1_b, *pts2_w, *pts2_b, *feat_w, *feat_b, *alpha_w, *alpha_b, *views_w, *views_b, *rgb_w,
         *rgb_b;   /* same order and shapes as hl_render_mlp_params */
 } hl_render_mlp_grads;
+size_t hl_render_weight_grads_scratch_bytes(int64_t n_cols);
 int hl_render_weight_grads(const float *del, int64_t del_stride, const float *act, int64_t act_stride, int64_t n_cols,
-                           const hl_render_mlp_grads *grads, void *stream);
+                           const hl_render_mlp_grads *grads, void *scratch, void *stream);
 int hl_render_composite_noise(const float *near, const float *far, const float *z_vals, const float *z_new, const float *rec_coarse,
                               const float *rec_new, const float *noise, int64_t n_rays, int n_samples, int n_importance,
                               unsigned flags, float *rgb, float *acc, float *depth, void *stream);
@@ -216,7 +223,8 @@ int hl_render_plane_grads(int H, int W, const float *bounds, const float *rays_o
                           const float *far, const float *z_vals /* coarse rows or NULL */, const float *z_new,
                           int z_new_rows /* 1: rows (R, n_importance), faster; 0: tile-major as hl_render_importance_new wrote them */,
                           int64_t n_rays, int n_samples, int n_importance, const float *del, int64_t del_stride, float *d_planes,
-                          void *stream);
+                          void *scratch, void *stream);
+size_t hl_render_plane_grads_scratch_bytes(int64_t n_rays);
 
 /* Per-view ray generation on the device.  Replaces get_rays
  * (human_diffusion/SynBodyView_datasets.py:316-329), the float32 casts and the near=0 / far=1 fill of

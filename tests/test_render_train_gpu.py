@@ -1,7 +1,8 @@
 """GPU parity of the renderer's training mode: forward with density noise and the HIP backward kernels against
 gradient vectors from the reference's autograd (tests/golden/render_grad_*.npz) and against the oracle's autograd at a larger size.
-Gradients are sums of ~1e4..1e6 fp32 terms accumulated in a different order (MFMA chains, float atomics on the tri-plane, rocBLAS for
-the weight products): the bar is 2e-4 of the largest entry of each tensor (+2e-6 absolute), written next to each check."""
+Gradients are sums of ~1e4..1e6 fp32 terms accumulated in a different order than autograd's (MFMA chains, fixed-point tile sums on the
+tri-plane, point ranges summed in a fixed order for the weight products): the bar is 2e-4 of the largest entry of each tensor (+2e-6 absolute),
+written next to each check.  Since round 5 the backward has no floating-point atomics: two runs give the same bits (tested below)."""
 import numpy as np
 import pytest
 import torch
@@ -83,6 +84,46 @@ def test_gradients_at_training_sample_counts(dev):
         close(d_mlp[k], o_mlp[k], k)
 
 
+def test_gradients_are_the_same_bits_on_every_run(dev):
+    """No floating-point atomics in the backward: the tri-plane gradient accumulates in 64-bit fixed point (integer additions commute), the
+    weight gradients are partial results of fixed point ranges summed in a fixed order - five runs of the golden case (ragged sizes) and three
+    at the fitting sample counts must agree bit for bit, images and all 15 gradient tensors."""
+    from humanliff_amd import synthetic as syn
+    i, _ = load_grad_case("a")
+    g = torch.Generator().manual_seed(21)
+    ro, rd, nr, fr = syn.orbit_rays(2, 8, 96, 96)
+    pick = torch.nonzero(fr != 1).flatten()
+    pick = pick[torch.randperm(pick.numel(), generator=g)[:2048]]
+    ro, rd, nr, fr = ro[pick], rd[pick], nr[pick], fr[pick]
+    N = 128
+    t = torch.linspace(0., 1., steps=N)
+    z = nr[:, None] * (1. - t) + fr[:, None] * t
+    big = dict(planes=syn.triplane(seed=14), bounds=torch.tensor(syn.WORLD_BOUNDS), mlp=syn.render_mlp_state(6),
+               rays_o=ro, rays_d=rd, near=nr, far=fr, z=z, u=torch.rand((2048, N), generator=g), noise=torch.randn((2048, 2 * N), generator=g),
+               G_rgb=torch.randn((2048, 3), generator=g) / 2048, G_acc=torch.randn((2048,), generator=g) / 2048, n_samples=N, white_bkgd=False)
+    for case, runs in ((i, 5), (big, 3)):
+        ref = hip_grads(case, dev)
+        assert float(ref[2].abs().max()) > 0 and all(float(v.abs().max()) > 0 for v in ref[3].values())
+        for _ in range(runs - 1):
+            got = hip_grads(case, dev)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+            assert torch.equal(got[2], ref[2]), f"tri-plane gradient differs by {float((got[2] - ref[2]).abs().max()):.3e}"
+            for k in MLP_KEYS:
+                assert torch.equal(got[3][k], ref[3][k]), f"{k} differs by {float((got[3][k] - ref[3][k]).abs().max()):.3e}"
+
+
+def test_a_delta_that_is_not_finite_poisons_the_plane_gradient(dev):
+    """The fixed-point tile sums cannot carry inf / NaN: a cotangent that is not finite makes the whole tri-plane gradient NaN (loud), where float
+    atomics would have put NaN into the touched texels only."""
+    i, _ = load_grad_case("a")
+    i = dict(i)
+    G = i["G_rgb"].clone()
+    G[3, 1] = float("inf")
+    i["G_rgb"] = G
+    _, _, d_planes, _ = hip_grads(i, dev)
+    assert bool(torch.isnan(d_planes).all())
+
+
 def test_gradients_match_oracle_larger(dev):
     """1 000 rays x (48+48) samples on a 72x72 tri-plane (ragged scatter tiles), ragged last ray tile, stratified depths; cotangents
     like an MSE loss."""
@@ -146,8 +187,8 @@ def test_fitting_loop_two_subjects(dev, fused):
 
 def test_subject_streams_change_nothing(dev):
     """Renderer.subject_streams (opt-in) puts subjects after the first on their own HIP streams (forward and, through autograd's stream
-    rule, backward): three subjects with the switch on and off must give the same images and the same gradients (the weight gradient sums float atomics:
-    relative 1e-5, the rest bit for bit), repeated so that the allocator reuses blocks across streams."""
+    rule, backward): three subjects with the switch on and off must give the same images and the same gradients, bit for bit (the backward has no
+    floating-point atomics), repeated so that the allocator reuses blocks across streams."""
     from humanliff_amd import synthetic as syn
     torch.manual_seed(3)
     r = make_renderer(syn.render_mlp_state(3), dev)
@@ -182,9 +223,9 @@ def test_subject_streams_change_nothing(dev):
     ref = run(False)[0]
     for got in run(True):
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
-        assert (got[2] - ref[2]).abs().max() <= 1e-5 * ref[2].abs().max()
+        assert torch.equal(got[2], ref[2])
         for a, b in zip(got[3], ref[3]):
-            assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-12
+            assert torch.equal(a, b)
     r.subject_streams = False
 
 
@@ -280,6 +321,16 @@ def test_canonical_space_training_gradients_match_oracle(dev):
     ((out["rgb_map"][0] * G_rgb.to(dev)).sum() + (out["acc_map"][0] * G_acc.to(dev)).sum()).backward()
     torch.cuda.synchronize()
     sd = dict(r.named_parameters())
+    # the same step again: the same bits (k_plane_scatter_pts accumulates in fixed point, k_wgrad_finish sums in a fixed order)
+    first = [tri.grad.clone()] + [sd[k].grad.clone() for k in MLP_KEYS]
+    tri.grad = None
+    r.zero_grad()
+    out2 = r.render(pose, None, z[None].to(dev), ro[None].to(dev), rd[None].to(dev), nr[None, :, None].to(dev), fr[None, :, None].to(dev), tri,
+                    N, False, u=u.to(dev), noise=noise.reshape(-1, 1).to(dev))
+    ((out2["rgb_map"][0] * G_rgb.to(dev)).sum() + (out2["acc_map"][0] * G_acc.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    for a, b in zip(first, [tri.grad] + [sd[k].grad for k in MLP_KEYS]):
+        assert torch.equal(a, b)
 
     # oracle
     tb = pose["t_world_bounds"][0]
@@ -309,3 +360,42 @@ def test_canonical_space_training_gradients_match_oracle(dev):
     for k in MLP_KEYS:
         e, sc = float((sd[k].grad.cpu() - om[k].grad).abs().max()), float(om[k].grad.abs().max())
         assert e < 2e-6 + 2e-3 * sc, f"{k}: {e:.3e} vs {sc:.3e}"
+
+
+def test_training_mode_draws_the_cpu_generators_uniforms_on_the_device(dev):
+    """u = None in training mode (renderer.py:545: torch.rand on the CPU generator): from 65 536 numbers on they are written by the device
+    (hl_mt19937_uniform continues the generator's stream) - same images, same gradients, and the CPU generator ends where torch.rand leaves it."""
+    from humanliff_amd import synthetic as syn
+    r = make_renderer(syn.render_mlp_state(2), dev)
+    bs, R, N = 2, 640, 64                                       # 81 920 uniforms
+    ro, rd, nr, fr = syn.orbit_rays(3, 8, 64, 64)
+    pick = torch.nonzero(fr != 1).flatten()[:R]
+    ro, rd, nr, fr = (t[pick].to(dev) for t in (ro, rd, nr, fr))
+    tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].expand(bs, 2, 3).to(dev)}
+    t = torch.linspace(0., 1., steps=N, device=dev)
+    z = (nr[:, None] * (1. - t) + fr[:, None] * t)[None].expand(bs, R, N).contiguous()
+    g = torch.Generator().manual_seed(4)
+    noise = torch.randn((bs * R * 2 * N, 1), generator=g).to(dev)
+    planes = torch.stack([syn.triplane(seed=3, H=64, W=64)[0], syn.triplane(seed=4, H=64, W=64)[0]]).to(dev)
+
+    def run(u):
+        tri = planes.clone().requires_grad_(True)
+        r.zero_grad()
+        out = r.render(tp, None, z, ro[None].expand(bs, R, 3), rd[None].expand(bs, R, 3), nr[None, :, None].expand(bs, R, 1),
+                       fr[None, :, None].expand(bs, R, 1), tri, N, False, u=u, noise=noise)
+        (out["rgb_map"].square().mean() + out["acc_map"].mean()).backward()
+        torch.cuda.synchronize()
+        return out["rgb_map"].detach().clone(), tri.grad.clone(), [p.grad.clone() for p in r.parameters()]
+    torch.manual_seed(77)
+    torch.rand(100)                                             # (the generator mid-block)
+    a = run(None)
+    after_a = torch.rand(5)
+    torch.manual_seed(77)
+    torch.rand(100)
+    u = torch.rand((bs * R, N))
+    b = run(u.to(dev))
+    after_b = torch.rand(5)
+    assert torch.equal(after_a, after_b)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        assert torch.equal(x, y)
