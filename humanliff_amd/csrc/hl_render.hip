@@ -871,6 +871,12 @@ __global__ void k_pack_mlp_h2(PackArgs a, unsigned short *out) {
         if (sidx < per && k < 27) in = k;
     }
     float v = in >= 0 ? a.w[d.w][outu * d.ld + d.col0 + in] : 0.f;
+#ifndef HL_H2_NO_LOG2
+    // log2-domain softplus (k_march_plw<2>, see softplus_l2): a layer in front of a softplus produces log2(e) x its pre-activation, a layer behind one
+    // consumes log2-unit activations (x ln 2) - for hidden -> hidden layers the two cancel and the planes are those of the unscaled weights
+    constexpr float PSC[7] = {1.44269504088896341f, 1.f, 1.44269504088896341f, 1.f, 0.693147180559945309f, 1.44269504088896341f, 1.44269504088896341f};
+    v *= PSC[pi];
+#endif
     _Float16 h = (_Float16)v;                                   // nearest even
     if (plane == 1) h = (_Float16)(v - (float)h);               // (the residual is exact in fp32)
     out[idx] = __builtin_bit_cast(unsigned short, h);
@@ -1278,6 +1284,17 @@ __device__ __forceinline__ void split_b3t(const f32x16 &v, int hi, u32x4 (&pl)[3
         pl[2][q] = b3_pack(x, y);
     }
 }
+// fp16x2 kernel (round 5): softplus in the log2 DOMAIN.  With x' = log2(e) x arriving from the matrix pipe (scaled weights, k_pack_mlp_h2) and the consumers
+// taking y' = softplus(x) / ln 2 (their weights x ln 2), a unit costs v_exp_f32, v_add_f32, v_log_f32: y' = log2(1 + 2^x') - one plain and two
+// quarter-rate issues where the natural-log form needs four and two (scale, |x|, max, fma).  Accuracy: for x' << 0 the sum 1 + 2^x' rounds exactly as
+// 1 + e^-|x| does in the other form; for x' >> 0 the result carries v_log_f32's 1 ulp of ITS magnitude (relative 1e-7, the class of every fp32 operation
+// here).  Range: 2^x' overflows at x' = 128, i.e. a pre-activation of 88.7 gives inf where F.softplus returns x (threshold 20) - far inside the range
+// limit the fp16 planes already impose on this mode (65504), and loud.
+template <int I0, int I1>
+__device__ __forceinline__ void softplus_l2_r(f32x16 &v) {
+#pragma unroll
+    for (int i = I0; i < I1; ++i) v[i] = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(v[i]));
+}
 template <int I0, int I1>
 __device__ __forceinline__ void softplus_b3_r(f32x16 &v) {   // registers I0 .. I1-1 of softplus16_b3, in place
     // (round 5: the packed-fp32 form - v_pk_mul / v_pk_add / v_pk_fma on pairs, |.| folded into v_exp_f32's source modifiers, 5 + 4 issues per pair instead
@@ -1359,13 +1376,20 @@ __device__ __forceinline__ void mma_pl(f32x16 (&acc)[NT], const u32x4 (&b)[NPL],
 }
 
 #ifndef HL_H2_K
-#define HL_H2_K 5   // VALU instructions asked for behind every MFMA of a hidden-layer chunk in the fp16x2 kernel (12 MFMAs, ~80 VALU of preparation)
+#define HL_H2_K 4   // VALU instructions asked for behind every MFMA of a hidden-layer chunk in the fp16x2 kernel (12 MFMAs, ~48 VALU of preparation with the
+                    // log2-domain softplus; same box, ms per 512x512 view: 3: 25.56, 4: 25.74, 5: 25.81 - 26.00, 6: 26.35; natural-log softplus at 5: 26.71)
 #endif
 template <int NPL>
 __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const unsigned short *__restrict__ packed_b3) {
     constexpr int B3R_SLOT_U4 = PLW_SLOT_U4<NPL>, B3_CH_U4 = PLW_CH_U4<NPL>;      // (shadow the bf16x3 constants of k_march_b3)
     constexpr size_t B3_BYTES = PLW_BYTES<NPL>;
     constexpr int NMF = NPL == 3 ? 24 : 12;                                        // MFMAs of a chunk (4 tiles x 6 | 3 products)
+#ifndef HL_H2_NO_LOG2
+    constexpr bool LOG2D = NPL == 2;                                               // softplus in the log2 domain (softplus_l2_r; scaled planes and tables)
+#else
+    constexpr bool LOG2D = false;
+#endif
+    constexpr float L2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
     extern __shared__ __attribute__((aligned(16))) float ldsb[];   // [ring: 2 x 24 KB][small 4 KB][per wave: the 2 x 16 x 64 accumulator image of views_linear's bias + direction part, 8 KB]
     constexpr int NT = 512, NST = B3R_SLOT_U4 / NT;   // threads; u32x4 per thread and chunk pair (3 | 2)
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -1381,7 +1405,11 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
     u32x4 *ring = reinterpret_cast<u32x4 *>(ldsb);
     float *small = ldsb + 2 * B3R_SLOT_U4 * 4;
     f32x4 *vinit = reinterpret_cast<f32x4 *>(small + SMALL_FLOATS) + (tid >> 6) * 512;
-    for (int i = tid; i < SMALL_FLOATS; i += NT) small[i] = a.packed[NCH_FULL * CHUNK_FLOATS + i];
+    for (int i = tid; i < SMALL_FLOATS; i += NT) {
+        float v = a.packed[NCH_FULL * CHUNK_FLOATS + i];
+        if constexpr (LOG2D) v *= (i < SM_BF || (i >= SM_BV && i < SM_AW)) ? L2E : ((i >= SM_AW && i < SM_AB) ? LN2 : 1.f);   // biases in front of a softplus; head weights behind one
+        small[i] = v;
+    }
     const u32x4 *gb3 = reinterpret_cast<const u32x4 *>(packed_b3);
 #pragma unroll
     for (int q = 0; q < 2 * NST; ++q) ring[q * NT + tid] = gb3[q * NT + tid];                  // chunk pairs 0, 1 -> slots 0, 1
@@ -1433,6 +1461,12 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
     // from global memory) and parked in LDS as the accumulator image every sample starts views_linear from
         f32x16 V0[2];
         load_bias_global<2>(V0, a.packed + NCH_FULL * CHUNK_FLOATS + SM_BV, half);
+        if constexpr (LOG2D) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) V0[t][r] *= L2E;
+        }
         mma_pl(V0, bev0, gb3 + (B3_NCH - 1) * B3_CH_U4, 0, lane);
         mma_pl(V0, bev1, gb3 + (B3_NCH - 1) * B3_CH_U4, 2, lane);
 #pragma unroll
@@ -1458,6 +1492,7 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
         _Pragma("unroll") for (int q_ = 0; q_ < NST; ++q_) st[q_] = ldw(((((g) >> 1) + 2) % B3W_NPAIR) * B3R_SLOT_U4 + q_ * NT); \
     }
 #define B3_AT(g) (ring + cur + ((g) & 1) * B3_CH_U4)
+#define SP_R(I0_, I1_, V_) { if constexpr (LOG2D) softplus_l2_r<I0_, I1_>(V_); else softplus_b3_r<I0_, I1_>(V_); }
     // The two waves of a SIMD (w and w + 4) run the same chunks between the same barriers; left alone they prepare operands (VALU) at the same
     // time and multiply (MFMA) at the same time and the two pipes take turns.  B3_VM orders every chunk as [prepare the next operand, multiply]
     // in waves 0-3 and as [multiply, prepare] in waves 4-7 (ROT): one wave's VALU phase meets the other's MFMA phase.
@@ -1535,35 +1570,35 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
         mma_pl(X, bf0, B3_AT(0), 0, lane);                                       // L0: chunks 0, 1
         B3_ADV(1) mma_pl(X, bf1, B3_AT(1), 0, lane);
         load_bias<4>(Y, small + SM_B1, half);
-        softplus_b3_r<0, 8>(X[0]);                                                  // (the second half: behind the first chunk of the layer)
+        SP_R(0, 8, X[0]);                                                  // (the second half: behind the first chunk of the layer)
         split_plt(X[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L1: chunks 2..9 = (tile k of X, half 0 | 1)
             B3_ADV(2 + 2 * k)
-            B3_MV24(5, mma_pl(Y, ba, B3_AT(2 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(X[k]); split_plt(X[k], 1, bb); })
+            B3_MV24(5, mma_pl(Y, ba, B3_AT(2 + 2 * k), 0, lane), { SP_R(8, 16, X[k]); split_plt(X[k], 1, bb); })
             B3_ADV(3 + 2 * k)
-            B3_MV24(5, mma_pl(Y, bb, B3_AT(3 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(X[k + 1 < 4 ? k + 1 : 3]); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(Y, bb, B3_AT(3 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3]); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         load_bias<4>(X, small + SM_B2, half);
         B3_ADV(10) mma_pl(X, bf0, B3_AT(10), 0, lane);                          // L2 (features): chunks 10, 11; the first hidden operand rides along
         B3_ADV(11)
-        B3_VM({ (softplus_b3_r<0, 8>(Y[0])); split_plt(Y[0], 0, ba); }, mma_pl(X, bf1, B3_AT(11), 0, lane))
+        B3_VM({ SP_R(0, 8, Y[0]); split_plt(Y[0], 0, ba); }, mma_pl(X, bf1, B3_AT(11), 0, lane))
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L2 (hidden): chunks 12..19
             B3_ADV(12 + 2 * k)
-            B3_MV24(5, mma_pl(X, ba, B3_AT(12 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(Y[k]); split_plt(Y[k], 1, bb); })
+            B3_MV24(5, mma_pl(X, ba, B3_AT(12 + 2 * k), 0, lane), { SP_R(8, 16, Y[k]); split_plt(Y[k], 1, bb); })
             B3_ADV(13 + 2 * k)
-            B3_MV24(5, mma_pl(X, bb, B3_AT(13 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(Y[k + 1 < 4 ? k + 1 : 3]); split_plt(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(X, bb, B3_AT(13 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, Y[k + 1 < 4 ? k + 1 : 3]); split_plt(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         load_bias<4>(Y, small + SM_BF, half);
-        softplus_b3_r<0, 8>(X[0]);                                                  // (the second half: behind the first chunk of the layer)
+        SP_R(0, 8, X[0]);                                                  // (the second half: behind the first chunk of the layer)
         split_plt(X[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // feature_linear: chunks 20..27
             B3_ADV(20 + 2 * k)
-            B3_MV24(5, mma_pl(Y, ba, B3_AT(20 + 2 * k), 0, lane), { softplus_b3_r<8, 16>(X[k]); split_plt(X[k], 1, bb); })
+            B3_MV24(5, mma_pl(Y, ba, B3_AT(20 + 2 * k), 0, lane), { SP_R(8, 16, X[k]); split_plt(X[k], 1, bb); })
             B3_ADV(21 + 2 * k)
-            B3_MV24(5, mma_pl(Y, bb, B3_AT(21 + 2 * k), 0, lane), if (k < 3) { softplus_b3_r<0, 8>(X[k + 1 < 4 ? k + 1 : 3]); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(Y, bb, B3_AT(21 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3]); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];   // X holds softplus(pts_linears.2) by now
         f32x16 V[2];
@@ -1581,8 +1616,8 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
             B3_VM(split_plt(Y[k], 1, bb), mma_pl(V, ba, B3_AT(28 + k), 0, lane))
             B3_VM(if (k < 3) split_plt(Y[k + 1 < 4 ? k + 1 : 3], 0, ba), mma_pl(V, bb, B3_AT(28 + k), 2, lane))
         }
-        V[0] = softplus16_b3(V[0]);
-        V[1] = softplus16_b3(V[1]);
+        if constexpr (LOG2D) { softplus_l2_r<0, 16>(V[0]); softplus_l2_r<0, 16>(V[1]); }
+        else { V[0] = softplus16_b3(V[0]); V[1] = softplus16_b3(V[1]); }
         const float cr = dot_lane<2>(V, small + SM_RW, half) + small[SM_RB + 0];
         const float cg = dot_lane<2>(V, small + SM_RW + 64, half) + small[SM_RB + 1];
         const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
@@ -1601,6 +1636,7 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
 #undef B3_MV24
 #undef B3_ADV
 #undef B3_AT
+#undef SP_R
 }
 
 // ---------------------------------------------------------------------------------------------
