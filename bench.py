@@ -176,7 +176,9 @@ def bench_unet(args, rank, world, dev):
     dv, dk = (C.c_double * 4)(), (C.c_int * 5)()
     _lib.check(L.hl_unet_profile_dominant(handle, dv, dk))
     _lib.check(L.hl_unet_profile(handle, 0))
-    fam = ("k_conv_dma / k_conv (direct implicit GEMM)", "k_conv_wino (Winograd F(2x2,3x3))", "k_conv_bf3 (bf16x3)", "k_conv_wino4w / k_conv_wino4 (Winograd F(4x4,3x3))")[dk[0] & 3]
+    fam = {0: "k_conv_dma / k_conv (direct implicit GEMM)", 1: "k_conv_wino (Winograd F(2x2,3x3))", 2: "k_conv_bf3 (bf16x3)",
+           3: "k_conv_wino4w / k_conv_wino4 (Winograd F(4x4,3x3))", 5: "k_conv_h16 / k_conv1_h16 (16-bit operands)",
+           6: "k_conv_h16<., 2> / k_conv1_h2 (direct, fp16x2 products)"}.get(dk[0], f"path {dk[0]}")
     dom_ms = dv[0] / max(dv[3], 1.0)
     dom_exec = dv[2] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     dominant = {"kernel": fam, "layers": f"{dk[4]}x{dk[4]} convolutions with {dk[3]} output channels @{256 >> dk[1]}x{256 >> dk[1]}, batch {B}"
@@ -201,8 +203,8 @@ def bench_unet(args, rank, world, dev):
                             "note": "direct-convolution FLOPs (SURVEY 8(d): 2*M*Cout*Cin*taps) of the same launches over the same time; not a roofline fraction"},
             "note": "fp32 MFMA and the vector ALU share the SIMD's fp32 lanes (scripts/microbench/mfma_fill.hip): the kernel's own input transform (VALU) is "
                     "added to its MFMA time, so 1.0 is not reachable for a Winograd kernel - MFMAs alone run this launch shape at 0.70 (profiles/r03_wino4w_ablations.md)",
-            "conv_path": {"what": "all convolution launches of one denoise step (k_conv_wino4w / k_conv_wino4 / k_conv_wino / k_conv_dma / k_conv) with their pre / post "
-                                  "passes (k_gn_apply, k_splitk_finish)", "executed_tflops": round(executed, 2), "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+            "conv_path": {"what": "all convolution launches of one denoise step (k_conv_wino4w / k_conv_wino4 / k_conv_wino / k_conv_dma / k_conv / k_conv_h16<.,2> / k_conv1_h2) with their pre / post "
+                                  "passes (k_gn_apply, k_splitk_finish); the fp16x2 kernels' products are counted once (fp32-equivalent work), not three times", "executed_tflops": round(executed, 2), "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
                           "algorithmic_tflops": round(achieved, 2), "algorithmic_x_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                           "launches_per_step": int(conv_n), "gflop_per_step": round(conv_fl / 1e9, 1), "executed_gflop_per_step": round(xf[0] / 1e9, 1),
                           "ms_per_step": round(conv_ms, 3), "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4)},
@@ -251,6 +253,33 @@ def bench_unet(args, rank, world, dev):
                     "opt-in, NOT used for `value`",
             "value": round(B * k3 / s3, 3), "unit": "denoise-steps/s", "steps": k3, "ms_per_step": round(s3 * 1e3 / k3, 3),
             "max_abs_diff_vs_fp32_forward": float((alt - ref).abs().max()), "forward_output_mean_abs": float(ref.abs().mean())}
+    # ---- the default's dispatch with EVERY product on the fp32 matrix pipe (no fp16x2 kernels): the reference point for `value` ----
+    roof["fp32_mfma_mode"] = None
+    if world == 1 and not args.no_bf16x3_leg:
+        xx = torch.randn((B, 27, 256, 256), generator=torch.Generator().manual_seed(99)).to(dev)
+        tt = torch.full((B,), 500, dtype=torch.int64, device=dev)
+        with torch.no_grad():
+            ref = model(xx, tt, x_cond, y=y)
+            model.set_conv_mode("fp32_mfma")
+            alt = model(xx, tt, x_cond, y=y)
+        it3 = diffusion.p_sample_loop_progressive(model, (B, 27, 256, 256), x_cond=x_cond, noise=x_T, clip_denoised=True,
+                                                  model_kwargs={"y": y}, device=dev)
+        next(it3); next(it3)
+        torch.cuda.synchronize()
+        k3 = max(2, min(args.steps, 10))
+        t3 = time.perf_counter()
+        for _ in range(k3):
+            next(it3)
+        torch.cuda.synchronize()
+        s3 = time.perf_counter() - t3
+        del it3
+        model.set_conv_mode("fp32")
+        roof["fp32_mfma_mode"] = {
+            "what": "UNetModel.set_conv_mode('fp32_mfma') / HL_CONV_FP32_MFMA: the default's dispatch without k_conv1_h2 / k_conv_h16<.,2> - every product on "
+                    "v_mfma_f32_32x32x2_f32 (the default of rounds 3-4).  `value` uses the default mode, whose 1x1 layers and one-round 3x3 layers form fp32 products "
+                    "from two fp16 planes per operand (fp32 accumulation; float64-checked in tests/test_unet_gpu.py, same oracle bounds)",
+            "value": round(B * k3 / s3, 3), "unit": "denoise-steps/s", "steps": k3, "ms_per_step": round(s3 * 1e3 / k3, 3),
+            "max_abs_diff_default_vs_fp32_mfma_forward": float((alt - ref).abs().max()), "forward_output_mean_abs": float(ref.abs().mean())}
     # ---- opt-in arithmetic mode (not the headline): fp16 operands / fp32 accumulation on the 3x3 layers (k_conv_h16) ----
     roof["fp16_mode"] = None
     if world == 1 and not args.no_bf16x3_leg:
@@ -1254,7 +1283,12 @@ def main():
         line = {
             "metric": "denoise-steps/sec", "value": round(value, 3), "unit": "denoise-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(secs * 1e3 / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32",
+            "dtype_note": "fp32 tensors and accumulators; Winograd / direct kernels on the fp32 matrix pipe; the 1x1 layers and the 3x3 layers of about one round of workgroups "
+                          "form their fp32 products from two fp16 planes per operand (fp32-class error, float64-checked, same oracle bounds); roofline.fp32_mfma_mode = every "
+                          "product on the fp32 pipe",
+            "data": "synthetic",
             "config": {"workload": "configs[1]: 256x256x27 tri-plane UNet (controlnet, 497M params), 1000-step DDPM "
                                    "p_sample_loop, batch=4 per GPU", "global_batch": world * args.batch,
                        "parallelism": f"replicas x{world} (subjects sharded, final all-gather only)",

@@ -20,6 +20,7 @@ HL_CONV_FP32_F23 = 3
 HL_CONV_FP32_DIRECT = 2
 HL_CONV_BF16 = 4
 HL_CONV_FP16 = 5
+HL_CONV_FP32_MFMA = 6
 HL_RENDER_WHITE_BKGD = 1
 HL_RENDER_NORMALIZE_DEPTH = 2
 HL_RENDER_REEVALUATE = 4

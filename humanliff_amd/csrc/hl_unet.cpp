@@ -509,10 +509,10 @@ struct Exec {
         ConvArgs a{};
         a.in = in; a.in.C = c.Cin_pad;
         a.w = c.w; a.w_bf3 = (n.conv_mode == HL_CONV_BF16X3 || n.conv_mode == HL_CONV_BF16) ? c.w_bf3 : nullptr; a.bf16_single = n.conv_mode == HL_CONV_BF16;
-        a.w_wino = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_F23 || n.conv_mode == HL_CONV_FP16) ? c.w_wino : nullptr;
+        a.w_wino = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_MFMA || n.conv_mode == HL_CONV_FP32_F23 || n.conv_mode == HL_CONV_FP16) ? c.w_wino : nullptr;
         a.w_h16 = n.conv_mode == HL_CONV_FP16 ? c.w_h16 : nullptr; a.h16_fp16 = 1;
         a.w_h2 = n.conv_mode == HL_CONV_FP32 ? c.w_h2 : nullptr;
-        a.w_wino4 = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP16) ? c.w_wino4 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
+        a.w_wino4 = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_MFMA || n.conv_mode == HL_CONV_FP16) ? c.w_wino4 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
         a.coefA = cA; a.coefB = cB; a.act = act; a.gn = af.gn;
         a.out = out; a.res = res; a.res_pitch = res_pitch;
         a.out2 = out2; a.out2_pitch = out2_pitch; a.res2 = res2; a.res2_pitch = res2_pitch; a.out_nchw = nchw;
@@ -903,7 +903,7 @@ int hl_unet_set_overlap(void *handle, int enable) {
 
 int hl_unet_set_conv_mode(void *handle, int mode) {
     HL_REQUIRE(handle, "hl_unet_set_conv_mode: null handle");
-    HL_REQUIRE(mode == HL_CONV_FP32 || mode == HL_CONV_BF16X3 || mode == HL_CONV_FP32_DIRECT || mode == HL_CONV_FP32_F23 || mode == HL_CONV_BF16 || mode == HL_CONV_FP16, "hl_unet_set_conv_mode: unknown mode %d", mode);
+    HL_REQUIRE(mode == HL_CONV_FP32 || mode == HL_CONV_FP32_MFMA || mode == HL_CONV_BF16X3 || mode == HL_CONV_FP32_DIRECT || mode == HL_CONV_FP32_F23 || mode == HL_CONV_BF16 || mode == HL_CONV_FP16, "hl_unet_set_conv_mode: unknown mode %d", mode);
     static_cast<Net *>(handle)->conv_mode = mode;
     return HL_OK;
 }
@@ -1027,7 +1027,7 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     const size_t need32 = (hl::conv_packed_floats(Cout, Cin, ks) * sizeof(float) + 255) / 256 * 256;
     const bool bf = mode == HL_CONV_BF16X3 || mode == HL_CONV_BF16;
     const bool h16m = mode == HL_CONV_BF16 || mode == HL_CONV_FP16;      // 16-bit operands where k_conv_h16 applies
-    const bool f32m = mode == HL_CONV_FP32 || mode == HL_CONV_FP16;      // (HL_CONV_FP16: the other layers as HL_CONV_FP32)
+    const bool f32m = mode == HL_CONV_FP32 || mode == HL_CONV_FP32_MFMA || mode == HL_CONV_FP16;      // (HL_CONV_FP16: the other layers as HL_CONV_FP32)
     size_t extra = bf ? hl::conv_packed_bf3_bytes(Cout, Cin, ks)
                       : (mode == HL_CONV_FP32_F23 ? hl::conv_packed_wino_bytes(Cout, Cin, ks)
                          : (f32m ? std::max(hl::conv_packed_wino_bytes(Cout, Cin, ks), hl::conv_packed_wino4_bytes(Cout, Cin, ks)) : 0));
@@ -1131,7 +1131,7 @@ int hl_conv2d_nhwc_gn(int conv_mode, const float *in, int N, int H, int W, int C
                       int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu, const float *residual,
                       float *out, const float *gamma, const float *beta, float *next_coefA, float *next_coefB, int *h_used_stats,
                       void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16 || conv_mode == HL_CONV_FP16, "hl_conv2d_nhwc_gn: unknown mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_FP32_MFMA || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16 || conv_mode == HL_CONV_FP16, "hl_conv2d_nhwc_gn: unknown mode %d", conv_mode);
     HL_REQUIRE(gamma && beta && next_coefA && next_coefB && scratch, "hl_conv2d_nhwc_gn: null argument");
     const int pad = ks / 2, Hv = upsample ? 2 * H : H, Wv = upsample ? 2 * W : W;
     const int Ho = (Hv + 2 * pad - ks) / stride + 1, Wo = (Wv + 2 * pad - ks) / stride + 1;
@@ -1164,7 +1164,7 @@ int hl_conv2d_nhwc(const float *in, int N, int H, int W, int Cin, const float *w
 int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias,
                         int Cout, int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                         const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream) {
-    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16 || conv_mode == HL_CONV_FP16, "hl_conv2d_nhwc_mode: unknown mode %d", conv_mode);
+    HL_REQUIRE(conv_mode == HL_CONV_FP32 || conv_mode == HL_CONV_FP32_MFMA || conv_mode == HL_CONV_BF16X3 || conv_mode == HL_CONV_FP32_DIRECT || conv_mode == HL_CONV_FP32_F23 || conv_mode == HL_CONV_BF16 || conv_mode == HL_CONV_FP16, "hl_conv2d_nhwc_mode: unknown mode %d", conv_mode);
     return conv2d_single(conv_mode, in, N, H, W, Cin, w_oihw, bias, Cout, ks, stride, upsample, coefA, coefB, silu, residual, out,
                          scratch, scratch_bytes, stream);
 }

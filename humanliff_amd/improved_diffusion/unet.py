@@ -296,15 +296,17 @@ class UNetModel(nn.Module):
         return handle
 
     def set_conv_mode(self, mode):
-        """Arithmetic of the large convolutions: "fp32" (default; fp32 MFMA throughout - Winograd F(4x4,3x3) / F(2x2,3x3) for
-        the large 3x3 layers, direct implicit GEMM elsewhere), "fp32_f23" (no F(4x4,3x3)), "fp32_direct" (direct implicit GEMM only: every product
+        """Arithmetic of the large convolutions: "fp32" (default; fp32-class products and fp32 accumulation throughout - Winograd F(4x4,3x3) / F(2x2,3x3) on the
+        fp32 matrix pipe for the large 3x3 layers, direct implicit GEMM elsewhere; since round 5 the 1x1 layers and the 3x3 layers of about one round of
+        workgroups form their fp32 products from two fp16 planes per operand on the 16-bit matrix pipe, error of the fp32 direct kernel's class),
+        "fp32_mfma" (the same dispatch with every product on v_mfma_f32_32x32x2_f32: the default of rounds 3-4), "fp32_f23" (no F(4x4,3x3)), "fp32_direct" (direct implicit GEMM only: every product
         a*b of the reference's sum is formed exactly once) or "bf16x3" (opt-in extension, not in the reference: the
         same fp32 tensors and accumulators, each product formed on the bf16 matrix pipe from exact three-way bf16
         splits of both factors, six partial products; error per product <= 3*2^-24 - fp32 class, not bit-identical) or "fp16" (opt-in:
         fp16 operands / fp32 accumulation on the 3x3 / stride-1 layers k_conv_h16 covers - the operand precision the reference's own
         convolutions have under TF32 on its hardware, 10 explicit significand bits - every other layer as "fp32").
         See include/humanliff_hip.h HL_CONV_*."""
-        modes = {"fp32": _lib.HL_CONV_FP32, "bf16x3": _lib.HL_CONV_BF16X3, "fp32_direct": _lib.HL_CONV_FP32_DIRECT, "fp32_f23": _lib.HL_CONV_FP32_F23,
+        modes = {"fp32": _lib.HL_CONV_FP32, "fp32_mfma": _lib.HL_CONV_FP32_MFMA, "bf16x3": _lib.HL_CONV_BF16X3, "fp32_direct": _lib.HL_CONV_FP32_DIRECT, "fp32_f23": _lib.HL_CONV_FP32_F23,
                  "fp16": _lib.HL_CONV_FP16}
         if mode not in modes:
             raise ValueError(f"unknown conv mode {mode!r} (expected one of {sorted(modes)})")

@@ -319,10 +319,16 @@ int hl_unet_forward(void *handle, const float *x, const int64_t *t, const float 
 int hl_unet_set_overlap(void *handle, int enable);
 
 /* Arithmetic of the large convolutions - all modes keep fp32 tensors and fp32 accumulators.
- * HL_CONV_FP32 (default): fp32 products on v_mfma_f32_32x32x2_f32; 3x3 / stride-1 layers take Winograd F(4x4,3x3) (36 fp32
+ * HL_CONV_FP32 (default): fp32-class products, fp32 accumulation.  3x3 / stride-1 layers take Winograd F(4x4,3x3) on v_mfma_f32_32x32x2_f32 (36 fp32
  *   multiplies per 4x4 outputs instead of 144; interpolation points 0, +-3/4, +-3/2, inf) where 32x16-pixel x 32-channel
  *   workgroups fill the chip (the 256- and 128-pixel levels at batch 4), Winograd F(2x2,3x3) (16 per 2x2 instead of 36) on the
- *   smaller levels, everything else the direct implicit GEMM.
+ *   smaller levels, everything else the direct implicit GEMM.  Round 5: the 1x1 / stride-1 layers from 48 workgroups (256 pixels x 192
+ *   channels) on, and the 3x3 / stride-1 layers of 100 ... 300 workgroups (about one round of the chip), are DIRECT convolutions whose
+ *   fp32 products come from TWO fp16 planes per operand on v_mfma_f32_32x32x16_f16 (k_conv1_h2, k_conv_h16<., 2>): activation
+ *   x = h0 + h1 (h0 = x with its low 13 mantissa bits cleared, h1 = the truncated residual: |x - h0 - h1| < 2^-20 |x|), weight planes
+ *   nearest even (2^-22), h1 w0 + h0 w1 + h0 w0 accumulated in fp32 - error of the fp32 direct kernel's class, checked against float64
+ *   (tests/test_unet_gpu.py: rel-L2 3e-7 ... 1.2e-6 against 2e-7 ... 6e-7 of HL_CONV_FP32_DIRECT); range |x| < 65504.
+ * HL_CONV_FP32_MFMA: HL_CONV_FP32 without those two kernels - every product on v_mfma_f32_32x32x2_f32 (the default of rounds 3-4).
  * HL_CONV_FP32_F23: the same without F(4x4,3x3) (the arithmetic of the round-2 library).
  * HL_CONV_FP32_DIRECT: the direct implicit GEMM only - every product of the reference's sum is formed exactly once.
  * HL_CONV_BF16X3 (opt-in, direct only): each product a*b is formed on the bf16 matrix pipe from exact three-way splits
@@ -346,6 +352,7 @@ int hl_unet_set_overlap(void *handle, int enable);
  * operand precision of the reference's own convolutions on its hardware (TF32: 10 explicit significand bits) and of its autocast training;
  * every other layer as HL_CONV_FP32.  HL_CONV_BF16 takes the same kernel with bf16 operands on those layers. */
 #define HL_CONV_FP16 5
+#define HL_CONV_FP32_MFMA 6
 int hl_unet_set_conv_mode(void *handle, int mode);
 
 /* Instrumentation for the roofline measurement (bench.py): with profiling enabled every kernel launch
