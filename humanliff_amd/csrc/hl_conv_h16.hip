@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256, 1) void k_conv1_h16(const ConvK p) {
         }(std::make_integer_sequence<int, 6>{});
         __syncthreads();
     }
+    if constexpr (H16_ABL & 128) { if (acc[0][0][0] == 12345.f) p.out[0] = acc[1][1][1] + acc[3][2][5]; return; }
     h16_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, [&](int q, int pc) {
         return m0 + 128 * (pc >> 6) + 32 * (2 * q + ((pc >> 5) & 1)) + (pc & 31);
     });
@@ -540,25 +541,24 @@ __global__ __launch_bounds__(256, 1) void k_conv1_h2(const ConvK p) {
     };
     for (int c = 0; c < nch; ++c) {
         const char *st = lds + (c & 1) * H2_STAGE;
-        a_load(c + 1 < nch ? c + 1 : c);                             // (last chunk: staged again, never read)
+        if (!(H16_ABL & 2)) a_load(c + 1 < nch ? c + 1 : c);          // (last chunk: staged again, never read)
         a_read(st, 0, af[0]);
         __builtin_amdgcn_sched_barrier(0);
         [&]<int... S>(std::integer_sequence<int, S...>) {
             ([&] {
                 constexpr int cur = S & 1;
-                if constexpr (S + 1 < 3) a_read(st, S + 1, af[cur ^ 1]);
+                if constexpr (S + 1 < 3 && !(H16_ABL & 4)) a_read(st, S + 1, af[cur ^ 1]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nf = 0; nf < 3; ++nf)
 #pragma unroll
-                    for (int mf = 0; mf < 4; ++mf) {                 // smallest partial product first
+                    for (int mf = 0; mf < 4; ++mf) if constexpr (!(H16_ABL & 8)) {                 // smallest partial product first
                         acc[mf][nf] = mma<true>(af[cur][1][mf], ring[S][0][nf], acc[mf][nf]);
                         acc[mf][nf] = mma<true>(af[cur][0][mf], ring[S][1][nf], acc[mf][nf]);
                         acc[mf][nf] = mma<true>(af[cur][0][mf], ring[S][0][nf], acc[mf][nf]);
                     }
-                w_load(S, c * 3 + S + 3);
-                a_store((c + 1) & 1, 2 * S);
-                a_store((c + 1) & 1, 2 * S + 1);
+                if constexpr (!(H16_ABL & 1)) w_load(S, c * 3 + S + 3);
+                if constexpr (!(H16_ABL & 2)) { a_store((c + 1) & 1, 2 * S); a_store((c + 1) & 1, 2 * S + 1); }
                 __builtin_amdgcn_sched_barrier(0);
             }(), ...);
         }(std::make_integer_sequence<int, 3>{});

@@ -70,6 +70,7 @@ struct ConvArgs {
     mutable int stat_slots;
     hipEvent_t ev_mid;   // optional (profiling): recorded between the GroupNorm pre-pass and the convolution kernel, when there is a pre-pass
     mutable int ev_mid_used;
+    int solo;            // 1: nothing else of this forward runs beside this launch (the decoder; the encoder towers overlap on two streams): widens the fp16x2 3x3 window
     int plan_only;       // 1: no launch, only set `path` (w / w_wino / w_bf3 are then just non-null markers of what could be packed)
 };
 // kernel-side argument block of the convolution kernels (filled by conv2d)

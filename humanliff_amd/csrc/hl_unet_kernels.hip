@@ -2906,9 +2906,10 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     // nothing moves although the kernel alone is 12 % faster on the 256-pixel level (461 against 523 us): profiles/r05_unet_fill_experiments.md.
     static const long h3_min_blocks = [] { const char *e_ = getenv("HL_H2_CONV3_MIN_BLOCKS"); return e_ ? atol(e_) : 100L; }();   // developer knobs (read once); min < 0 disables
     static const long h3_max_blocks = [] { const char *e_ = getenv("HL_H2_CONV3_MAX_BLOCKS"); return e_ ? atol(e_) : 300L; }();
+    static const bool h3_solo = [] { const char *e_ = getenv("HL_H2_CONV3_SOLO"); return e_ ? atoi(e_) != 0 : true; }();   // no upper bound where nothing runs beside the launch (the decoder)
     const bool h3 = !h16 && !h2 && a.w_h2 && a.ks == 3 && h3_min_blocks >= 0 && (!gn_on || (a.act_ws && !a.ups)) && !a.out_nchw && !a.w_bf3 &&
                     conv_h16_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
-                    (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0 && h16_blocks >= h3_min_blocks && h16_blocks <= h3_max_blocks;
+                    (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0 && h16_blocks >= h3_min_blocks && (h16_blocks <= h3_max_blocks || (a.solo && h3_solo));
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
         a.path = h16 ? 5 : (h2 || h3) ? 6 : (wino4 ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
         return HL_OK;
