@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{f16,bf16}, dense
 UNET_GFLOP_PER_SAMPLE_STEP = 2015.4
 RENDER_FLOP_PER_RAY = 128 * 79616 + 256 * 132608   # 44 138 496 at 128+128
 FULL_FLOP_PER_POINT = 132608            # density + colour MLP at one sample point
@@ -178,9 +179,16 @@ def bench_unet(args, rank, world, dev):
     _lib.check(L.hl_unet_profile(handle, 0))
     fam = {0: "k_conv_dma / k_conv (direct implicit GEMM)", 1: "k_conv_wino (Winograd F(2x2,3x3))", 2: "k_conv_bf3 (bf16x3)",
            3: "k_conv_wino4w / k_conv_wino4 (Winograd F(4x4,3x3))", 5: "k_conv_h16 / k_conv1_h16 (16-bit operands)",
-           6: "k_conv_h16<., 2> / k_conv1_h2 (direct, fp16x2 products)"}.get(dk[0], f"path {dk[0]}")
+           6: "k_conv_h2s / k_conv1_h2s (direct convolution, fp32 products from two fp16 planes per operand: three fp16 MFMAs per product, fp32 accumulation)"}.get(dk[0], f"path {dk[0]}")
     dom_ms = dv[0] / max(dv[3], 1.0)
     dom_exec = dv[2] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    dom_peak, dom_note = PEAK_F32_MFMA_TFLOPS, None
+    if dk[0] == 6:      # fp16x2 kernels: three fp16 partial products per fp32 product, issued on the 16-bit matrix pipe
+        dom_exec = 3.0 * dv[1] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        dom_peak = PEAK_BF16_MFMA_TFLOPS       # (v_mfma_f32_32x32x16_f16 and _bf16 share the dense 16-bit peak)
+        dom_note = ("fp16 FLOPs ISSUED (three partial products per fp32 product of the direct convolution) against the dense fp16 matrix peak; the same launches in the "
+                    "path's own unit: `algorithmic` (fp32-equivalent work) - under this load the matrix pipe runs at 1.5 - 1.7 GHz, MFMAs alone take 0.73 of the kernel's time "
+                    "(profiles/r05_unet_fill_experiments.md, sections 6 - 8)")
     dominant = {"kernel": fam, "layers": f"{dk[4]}x{dk[4]} convolutions with {dk[3]} output channels @{256 >> dk[1]}x{256 >> dk[1]}, batch {B}"
                                          + (" behind a nearest-x2 upsample" if dk[2] else "") + " (all input channel counts: one rocprofv3 kernel / grid row)",
                 "launches_per_step": int(dv[3]), "avg_launch_ms": round(dom_ms, 4), "total_ms_per_step": round(dv[0], 3),
@@ -197,12 +205,12 @@ def bench_unet(args, rank, world, dev):
     # the fp32 MFMA peak - a real fraction.  `algorithmic` is the same launch priced in direct-convolution FLOPs (exceeds the
     # peak); `conv_path` the same two figures for ALL convolution launches of the step with their pre / post passes (round 2's `frac`).
     roof = {"bound": "mfma", "kernel": dominant["kernel"] + ": " + dominant["layers"],
-            "achieved": round(dom_exec, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dom_exec / PEAK_F32_MFMA_TFLOPS, 4),
+            "achieved": round(dom_exec, 2), "peak": dom_peak, "unit": "TFLOP/s", "frac": round(dom_exec / dom_peak, 4),
             "avg_launch_ms": dominant["avg_launch_ms"], "launches_per_step": dominant["launches_per_step"], "ms_per_step_in_this_kernel": dominant["total_ms_per_step"],
             "algorithmic": {"tflops": dominant["algorithmic_tflops"], "x_peak": round((dominant["algorithmic_tflops"] or 0.0) / PEAK_F32_MFMA_TFLOPS, 4),
                             "note": "direct-convolution FLOPs (SURVEY 8(d): 2*M*Cout*Cin*taps) of the same launches over the same time; not a roofline fraction"},
-            "note": "fp32 MFMA and the vector ALU share the SIMD's fp32 lanes (scripts/microbench/mfma_fill.hip): the kernel's own input transform (VALU) is "
-                    "added to its MFMA time, so 1.0 is not reachable for a Winograd kernel - MFMAs alone run this launch shape at 0.70 (profiles/r03_wino4w_ablations.md)",
+            "note": dom_note or ("fp32 MFMA and the vector ALU share the SIMD's fp32 lanes (scripts/microbench/mfma_fill.hip): the kernel's own input transform (VALU) is "
+                                 "added to its MFMA time, so 1.0 is not reachable for a Winograd kernel - MFMAs alone run this launch shape at 0.70 (profiles/r03_wino4w_ablations.md)"),
             "conv_path": {"what": "all convolution launches of one denoise step (k_conv_wino4w / k_conv_wino4 / k_conv_wino / k_conv_dma / k_conv / k_conv_h16<.,2> / k_conv1_h2) with their pre / post "
                                   "passes (k_gn_apply, k_splitk_finish); the fp16x2 kernels' products are counted once (fp32-equivalent work), not three times", "executed_tflops": round(executed, 2), "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
                           "algorithmic_tflops": round(achieved, 2), "algorithmic_x_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),

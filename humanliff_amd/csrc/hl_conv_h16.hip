@@ -344,6 +344,248 @@ __global__ __launch_bounds__(256, 1) void k_conv_h16(const ConvK p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// k_conv_h2s: the fp16x2 3x3 kernel on an 8x16-pixel tile (128 pixels x 192 channels per workgroup, 96 accumulator registers per wave) so that TWO
+// workgroups share a CU: the 16x16 kernel owns a CU alone (474 registers, 93 KB of LDS) and nothing overlaps its prologue, staging VALU and epilogue
+// (no-MFMA ablation 106 of 461 us at 192 -> 192, 256 px, B = 4; the matrix pipe alone 336 - 350 us).  Same arithmetic, same weight image, same
+// two-plane activation image; weight ring two k-steps deep; the epilogue exchange in two channel halves of 128 slots x 96 channels (50 KB).
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+constexpr int H2S_PH = 10, H2S_NPIX = H2S_PH * H16_PW;               // patch of an 8x16 tile: 10 rows x 18 columns
+constexpr int H2S_PLANE = H2S_PH * H16_LP * 64, H2S_STG = 2 * H2S_PLANE;   // bytes per plane / per stage (both planes)
+constexpr int H2S_EP = 100;                                            // epilogue row pitch in floats (96 + 4)
+constexpr int H2S_LDS = 2 * H2S_STG + 1024 > 128 * H2S_EP * 4 ? 2 * H2S_STG + 1024 : 128 * H2S_EP * 4;
+
+template <class PixFn>
+__device__ __forceinline__ void h2s_epilogue(const ConvK &p, char *lds, const f32x16 (&acc)[2][3], int tid, int lane, int wm, int wn, int n0, long tile, PixFn pix) {
+    float *ep = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                      // channel half h = the tiles of the waves with wn == h
+        if (h) __syncthreads();
+        if (wn == h) {
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int r = (i >> 2) * 8 + (lane >> 5) * 4 + (i & 3);
+                        ep[(wm * 64 + m2 * 32 + r) * H2S_EP + nf * 32 + (lane & 31)] = acc[m2][nf][i];
+                    }
+        }
+        __syncthreads();
+        // thread (pr0 = tid / 24 < 10, channel quad tid % 24 of this half) finishes pixel slots pr0, pr0 + 10, ... (<= 13 of the 128) in three batches:
+        // the residual loads of a batch are in flight before its first store
+        const int pr0 = tid / 24, cq = h * 96 + (tid - pr0 * 24) * 4, cl = cq - h * 96;
+        f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f}, sm2 = {0.f, 0.f, 0.f, 0.f}, sq2 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && pr0 < 10) bs = *reinterpret_cast<const f32x4 *>(p.bias + n0 + cq);
+        auto finish = [&](auto kc0, auto nbc) {
+            constexpr int K0 = decltype(kc0)::value, NB = decltype(nbc)::value;
+            long mm[NB];
+            f32x4 v[NB], rr[NB], r2[NB];
+            bool on[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int pc = pr0 + 10 * (K0 + k);
+                on[k] = pc < 128;
+                mm[k] = pix(on[k] ? pc : 0);
+                if (p.res && !p.partial && on[k]) rr[k] = *reinterpret_cast<const f32x4 *>(p.res + mm[k] * p.res_pitch + n0 + cq);
+                if (p.out2 && !p.partial && on[k]) r2[k] = *reinterpret_cast<const f32x4 *>(p.res2 + mm[k] * p.res2_pitch + n0 + cq);
+                v[k] = *reinterpret_cast<const f32x4 *>(ep + (on[k] ? pc : 0) * H2S_EP + cl);
+            }
+            if (p.partial) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) if (on[k]) *reinterpret_cast<f32x4 *>(p.partial + ((long)blockIdx.z * p.M + mm[k]) * p.Cout + n0 + cq) = v[k];
+                return;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) if (on[k]) {
+                v[k] += bs;
+                if (p.res) v[k] += rr[k];
+                sm += v[k]; sq += v[k] * v[k];
+                *reinterpret_cast<f32x4 *>(p.out + mm[k] * p.out_pitch + n0 + cq) = v[k];
+                if (p.out2) {
+                    r2[k] += v[k];
+                    sm2 += r2[k]; sq2 += r2[k] * r2[k];
+                    *reinterpret_cast<f32x4 *>(p.out2 + mm[k] * p.out2_pitch + n0 + cq) = r2[k];
+                }
+            }
+        };
+        if (pr0 < 10) {
+            finish(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+            finish(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+            finish(std::integral_constant<int, 9>{}, std::integral_constant<int, 4>{});
+        }
+        auto put_stats = [&](float *st, const f32x4 a_sm, const f32x4 a_sq) {   // (tile, half) = 128 pixels of one image x 96 channels; the ten pixel groups meet in LDS
+            __syncthreads();
+            if (pr0 < 10) {
+                *reinterpret_cast<f32x4 *>(ep + ((pr0 * 24 + (cl >> 2)) * 2) * 4) = a_sm;
+                *reinterpret_cast<f32x4 *>(ep + ((pr0 * 24 + (cl >> 2)) * 2 + 1) * 4) = a_sq;
+            }
+            __syncthreads();
+            if (tid < 24) {
+                f32x4 a = *reinterpret_cast<const f32x4 *>(ep + (tid * 2) * 4), b = *reinterpret_cast<const f32x4 *>(ep + (tid * 2 + 1) * 4);
+#pragma unroll
+                for (int g = 1; g < 10; ++g) {
+                    a += *reinterpret_cast<const f32x4 *>(ep + ((g * 24 + tid) * 2) * 4);
+                    b += *reinterpret_cast<const f32x4 *>(ep + ((g * 24 + tid) * 2 + 1) * 4);
+                }
+                const long img = (tile * 128) / ((long)p.Hout * p.Wout);
+                const int c0_ = st == p.st1 ? p.st1_c0 : p.st2_c0, cg_ = st == p.st1 ? p.st1_cg : p.st2_cg;
+                const int ch0 = c0_ + n0 + h * 96 + tid * 4;
+                int g_run = ch0 / cg_;
+                float s_run = a[0], q_run = b[0];
+#pragma unroll
+                for (int i = 1; i < 4; ++i) {
+                    const int g_i = (ch0 + i) / cg_;
+                    if (g_i != g_run) { stat_add(st, p.N, img, g_run, (long)p.Hout * p.Wout, s_run, q_run); g_run = g_i; s_run = 0.f; q_run = 0.f; }
+                    s_run += a[i]; q_run += b[i];
+                }
+                stat_add(st, p.N, img, g_run, (long)p.Hout * p.Wout, s_run, q_run);
+            }
+        };
+        if (p.st1 && !p.partial) put_stats(p.st1, sm, sq);
+        if (p.st2 && !p.partial) put_stats(p.st2, sm2, sq2);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NU = H2S_NPIX * 4, NUT = (NU + 255) / 256;      // staging units (pixel, 8-channel group): 720 -> 3 per thread
+#ifndef H2S_RING
+#define H2S_RING 2
+#endif
+#ifndef H2S_ST0
+#define H2S_ST0 12
+#endif
+    constexpr int RING = H2S_RING;                                 // k-steps of weights in flight (divides 18)
+    constexpr int ST0 = H2S_ST0;                                   // k-step behind which the next chunk's patch goes to LDS (3 units, one per step)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int total = p.n_mtiles * p.n_nblocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int tb = __builtin_amdgcn_readfirstlane(wi / p.n_nblocks), nb = wi - tb * p.n_nblocks;
+    const int bw = p.Wout >> 4, bh = p.Hout >> 3;
+    const int img = tb / (bw * bh), brem = tb - img * (bw * bh);
+    const int y0 = (brem / bw) * 8, x0 = (brem - (brem / bw) * bw) * 16;
+    const int nch = p.Cin >> 5;
+    const unsigned pitch4 = (unsigned)p.in_pitch * (p.in16 ? 2u : 4u);
+    const unsigned plane_b = (unsigned)((long)p.N * p.Hin * p.Win * p.in_pitch * 2);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * pitch4 * (p.in16 == 2 ? 2 : 1)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * nch * 18 * 6144 * 2), 0x00020000);
+
+    unsigned sv[NUT], sl[NUT];
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) {
+        const int u = tid + 256 * j, pix = u >> 2, grp = u & 3;
+        const int py = pix / H16_PW, px = pix - py * H16_PW;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        const bool ok = u < NU && y >= 0 && y < p.Hout && x >= 0 && x < p.Wout;
+        const int ys = p.ups ? y >> 1 : y, xs = p.ups ? x >> 1 : x;
+        sv[j] = ok ? (unsigned)((img * p.Hin + ys) * p.Win + xs) * pitch4 + grp * (p.in16 ? 16 : 32) : OOB;
+        sl[j] = u < NU ? (unsigned)((py * H16_LP + px) * 64 + ((grp ^ ((px >> 2) & 3)) << 4)) : (unsigned)(2 * H2S_STG + (tid & 63) * 16);
+    }
+    u32x4 ar[NUT][2];
+    auto a_load = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NUT; ++j) {
+            const int so = chunk * (p.in16 ? 64 : 128);
+            ar[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j], so, 0);
+            ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] == OOB ? OOB : sv[j] + (p.in16 ? plane_b : 16u), so, 0);
+        }
+    };
+    auto a_store = [&](int stage, int j) {
+        u32x4 h0 = ar[j][0], h1 = ar[j][1];
+        if (!p.in16) {
+            const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
+            const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
+            h0 = u32x4{q0.p0, q1.p0, q2.p0, q3.p0}; h1 = u32x4{q0.p1, q1.p1, q2.p1, q3.p1};
+        }
+        char *dst = lds + (sl[j] >= 2u * H2S_STG ? 0 : stage * H2S_STG) + sl[j];
+        *reinterpret_cast<u32x4 *>(dst) = h0;
+        if (sl[j] < 2u * H2S_STG) *reinterpret_cast<u32x4 *>(dst + H2S_PLANE) = h1;
+    };
+    unsigned aoff[2][3];
+    {
+        const int r = lane & 31, g = lane >> 5;
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int py = 4 * wm + 2 * mf + (r >> 4), px = (r & 15) + kx;
+                aoff[mf][kx] = (unsigned)((py * H16_LP + px) * 64 + ((g ^ ((px >> 2) & 3)) << 4));
+            }
+    }
+    const unsigned wv = (unsigned)lane * 16u;
+    const int wbase = nb * nch * 18 * 6144 * 2 + wn * 3072;
+    u32x4 ring[RING][2][3];
+    const int c0 = (int)blockIdx.z * p.kt_per, c1 = min(nch, c0 + p.kt_per);
+    auto w_load = [&](int slot_, int chunk, int s18) {
+        const int so = wbase + (chunk * 18 + s18) * 6144 * 2;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) ring[slot_][pl][nf] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wv, so + pl * 6144 + nf * 1024, 0);
+    };
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+
+    a_load(c0);
+#pragma unroll
+    for (int s = 0; s < RING; ++s) w_load(s, c0, s);
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) a_store(0, j);
+    __syncthreads();
+
+    u32x4 af[2][2];                                                // [plane][fragment mf] of the current k-step (read at its start: the partner wave of the SIMD covers the LDS latency)
+    auto a_read = [&](const char *st, int tap, int k2, u32x4 (&dst)[2][2]) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) dst[pl][mf] = *reinterpret_cast<const u32x4 *>(st + pl * H2S_PLANE + (tap / 3) * (H16_LP * 64) + (aoff[mf][tap % 3] ^ (k2 ? 32u : 0u)));
+    };
+    for (int c = c0; c < c1; ++c) {
+        const char *st = lds + ((c - c0) & 1) * H2S_STG;
+        const int cc = c, ccn = cc + 1 < nch ? cc + 1 : 0;
+        a_load(ccn);
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ([&] {
+                constexpr int rs = S % RING;
+                a_read(st, S >> 1, S & 1, af);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) {                // smallest partial product first
+                        acc[mf][nf] = mma<true>(af[1][mf], ring[rs][0][nf], acc[mf][nf]);
+                        acc[mf][nf] = mma<true>(af[0][mf], ring[rs][1][nf], acc[mf][nf]);
+                        acc[mf][nf] = mma<true>(af[0][mf], ring[rs][0][nf], acc[mf][nf]);
+                    }
+                w_load(rs, S + RING < 18 ? cc : ccn, (S + RING) % 18);
+                if constexpr (S >= ST0 && S < ST0 + NUT) a_store((c - c0 + 1) & 1, S - ST0);
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, 18>{});
+        __syncthreads();
+    }
+    h2s_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, [&](int pc) {
+        const int wmm = pc >> 6, m2 = (pc >> 5) & 1, r = pc & 31;
+        return ((long)img * p.Hout + y0 + 4 * wmm + 2 * m2 + (r >> 4)) * p.Wout + x0 + (r & 15);
+    });
+#endif
+}
+
 // k_conv1_h16: the 1x1 convolutions (skip / qkv / proj) in the same arithmetic.  A workgroup = 256 consecutive pixels x 192 output channels,
 // the same 2x2 wave split, weight ring and epilogue; K in chunks of 96 input channels = six k-steps: the chunk's [256 px][96 ch] slab is fetched
 // as fp32 one chunk ahead, rounded and written to LDS with a pixel pitch of 208 bytes (13 quarters: 13 is odd, so the 16 lanes a ds_read_b128
@@ -570,6 +812,108 @@ __global__ __launch_bounds__(256, 1) void k_conv1_h2(const ConvK p) {
 #endif
 }
 
+// k_conv1_h2s: k_conv1_h2 on 128 pixels x 192 channels per workgroup (96 accumulator registers per wave, 56 KB of LDS): TWO workgroups share a CU, so the
+// prologue (the first slab's HBM round trip) and the epilogue of one overlap the main loop of the other - with one 256-pixel workgroup per CU they were ~14 of
+// ~46 us per workgroup (timing ablations, profiles/r05_unet_fill_experiments.md section 7).  Same arithmetic, same weight image, h2s_epilogue.
+constexpr int H2S1_PLANE = 128 * H2_PITCH, H2S1_STAGE = 2 * H2S1_PLANE;          // 14 KB per plane, 28 KB per stage
+constexpr int H2S1_LDS = 2 * H2S1_STAGE > 128 * H2S_EP * 4 ? 2 * H2S1_STAGE : 128 * H2S_EP * 4;
+
+__global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int NUT = 3;                                         // staging units per thread: 128 px x 6 groups of 8 channels / 256 threads
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int total = p.n_mtiles * p.n_nblocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int tb = __builtin_amdgcn_readfirstlane(wi / p.n_nblocks), nb = wi - tb * p.n_nblocks;
+    const long m0 = (long)tb * 128;
+    const int nch = p.Cin / 48;
+    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * pitch4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * nch * 3 * 12288), 0x00020000);
+    unsigned sv[NUT], sl[NUT];
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) {
+        const int u = tid + 256 * j, pix = u / 6, grp = u - pix * 6;
+        sv[j] = (unsigned)(m0 + pix) * pitch4 + grp * 32;
+        sl[j] = (unsigned)(pix * H2_PITCH + grp * 16);
+    }
+    u32x4 ar[NUT][2];
+    auto a_load = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NUT; ++j) {
+            ar[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j], chunk * 192, 0);
+            ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] + 16, chunk * 192, 0);
+        }
+    };
+    auto a_store = [&](int stage, int j) {
+        const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
+        const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
+        const u32x4 h0 = {q0.p0, q1.p0, q2.p0, q3.p0}, h1 = {q0.p1, q1.p1, q2.p1, q3.p1};
+        *reinterpret_cast<u32x4 *>(lds + stage * H2S1_STAGE + sl[j]) = h0;
+        *reinterpret_cast<u32x4 *>(lds + stage * H2S1_STAGE + H2S1_PLANE + sl[j]) = h1;
+    };
+    unsigned aoff[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) aoff[mf] = (unsigned)((64 * wm + 32 * mf + (lane & 31)) * H2_PITCH + (lane >> 5) * 16);
+    const unsigned wv = (unsigned)lane * 16u;
+    const int wbase = nb * nch * 3 * 12288 + wn * 3072;
+    u32x4 ring[3][2][3];                                            // [k-step of the chunk][plane][fragment nf]
+    auto w_load = [&](int slot_, int step) {
+        const int so = wbase + min(step, nch * 3 - 1) * 12288;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) ring[slot_][pl][nf] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wv, so + pl * 6144 + nf * 1024, 0);
+    };
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+    a_load(0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) w_load(s, s);
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) a_store(0, j);
+    __syncthreads();
+    u32x4 af[2][2];                                                 // [plane][fragment mf] of the current k-step (the partner wave of the SIMD covers the LDS latency)
+    for (int c = 0; c < nch; ++c) {
+        const char *st = lds + (c & 1) * H2S1_STAGE;
+        a_load(c + 1 < nch ? c + 1 : c);                             // (last chunk: staged again, never read)
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ([&] {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) af[pl][mf] = *reinterpret_cast<const u32x4 *>(st + pl * H2S1_PLANE + aoff[mf] + S * 32);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) {                 // smallest partial product first
+                        acc[mf][nf] = mma<true>(af[1][mf], ring[S][0][nf], acc[mf][nf]);
+                        acc[mf][nf] = mma<true>(af[0][mf], ring[S][1][nf], acc[mf][nf]);
+                        acc[mf][nf] = mma<true>(af[0][mf], ring[S][0][nf], acc[mf][nf]);
+                    }
+                w_load(S, c * 3 + S + 3);
+                a_store((c + 1) & 1, S);
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, 3>{});
+        __syncthreads();
+    }
+    h2s_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, [&](int pc) { return m0 + pc; });
+#endif
+}
+
 // fp16x2 weights of a 3x3 layer: [channel block of 192][chunk of 32 inputs][tap][k-half][plane 2][wn][fragment nf][lane][8], nearest even at both levels
 __global__ void k_pack_conv_h2(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, unsigned short *__restrict__ dst, int tf) {
     const int nch = Cin_pad >> 5;
@@ -714,6 +1058,24 @@ int conv3_h2_launch(const ConvK &p, hipStream_t st, int splits) {
     HL_REQUIRE(attr_ok, "k_conv_h2: cannot raise the dynamic LDS limit to %zu bytes", sh);
     hipLaunchKernelGGL((k_conv_h16<true, 2>), dim3((unsigned)(p.n_mtiles * p.n_nblocks), 1, (unsigned)splits), dim3(256), sh, st, p);
     return check_launch("k_conv_h2");
+}
+
+// the same layers on the 8x16-pixel tile (two workgroups per CU): p.n_mtiles = pixels / 128
+int conv3_h2s_launch(const ConvK &p, hipStream_t st, int splits) {
+    HL_REQUIRE(p.w_bf3 && p.ks == 3 && conv_h16_applies(p.Hout, p.Wout, p.Cin, p.Cout, p.ks, p.stride, p.ups) && (splits == 1 || p.partial), "k_conv_h2s: bad layer");
+    static const bool attr_ok = hipFuncSetAttribute((const void *)k_conv_h2s, hipFuncAttributeMaxDynamicSharedMemorySize, H2S_LDS) == hipSuccess;
+    HL_REQUIRE(attr_ok, "k_conv_h2s: cannot raise the dynamic LDS limit to %d bytes", H2S_LDS);
+    hipLaunchKernelGGL(k_conv_h2s, dim3((unsigned)(p.n_mtiles * p.n_nblocks), 1, (unsigned)splits), dim3(256), (size_t)H2S_LDS, st, p);
+    return check_launch("k_conv_h2s");
+}
+
+// the 1x1 layers on 128-pixel tiles (two workgroups per CU): p.n_mtiles = pixels / 128
+int conv1_h2s_launch(const ConvK &p, hipStream_t st) {
+    HL_REQUIRE(p.w_bf3 && conv1_h2_applies(p.Hout, p.Wout, p.Cin, p.Cout, p.ks, p.stride, p.ups) && !p.partial && !p.in16, "k_conv1_h2s: bad layer");
+    static const bool attr_ok = hipFuncSetAttribute((const void *)k_conv1_h2s, hipFuncAttributeMaxDynamicSharedMemorySize, H2S1_LDS) == hipSuccess;
+    HL_REQUIRE(attr_ok, "k_conv1_h2s: cannot raise the dynamic LDS limit to %d bytes", H2S1_LDS);
+    hipLaunchKernelGGL(k_conv1_h2s, dim3((unsigned)(p.n_mtiles * p.n_nblocks)), dim3(256), (size_t)H2S1_LDS, st, p);
+    return check_launch("k_conv1_h2s");
 }
 
 int conv1_h2_launch(const ConvK &p, hipStream_t st) {

@@ -431,7 +431,6 @@ struct Exec {
     float *gn_scratch = nullptr;
     float *splitk_ws = nullptr;
     float *gn_scratch2 = nullptr, *splitk_ws2 = nullptr;   // second set for the side stream
-    bool solo = true;                                      // no second stream is active (outside the two encoder towers)
     float *act_ws = nullptr, *act_ws2 = nullptr;           // materialised GroupNorm(+SiLU) inputs (k_conv_dma path)
     size_t act_need = 0;                                   // floats, largest normalised conv input seen
     int rc = 0;
@@ -513,7 +512,6 @@ struct Exec {
         a.w_wino = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_MFMA || n.conv_mode == HL_CONV_FP32_F23 || n.conv_mode == HL_CONV_FP16) ? c.w_wino : nullptr;
         a.w_h16 = n.conv_mode == HL_CONV_FP16 ? c.w_h16 : nullptr; a.h16_fp16 = 1;
         a.w_h2 = n.conv_mode == HL_CONV_FP32 ? c.w_h2 : nullptr;
-        a.solo = solo ? 1 : 0;
         a.w_wino4 = (n.conv_mode == HL_CONV_FP32 || n.conv_mode == HL_CONV_FP32_MFMA || n.conv_mode == HL_CONV_FP16) ? c.w_wino4 : nullptr; a.bias = c.bias; a.Cout = c.Cout; a.ks = c.ks; a.stride = stride; a.ups = ups;
         a.coefA = cA; a.coefB = cB; a.act = act; a.gn = af.gn;
         a.out = out; a.res = res; a.res_pitch = res_pitch;
@@ -777,7 +775,6 @@ struct Exec {
         // They are independent except that control block i's zero-conv adds the main encoder's hs[i].
         const bool fork = run && c.controlnet && n.overlap && !n.prof && n.side;
         hipStream_t main_st = st;
-        solo = !c.controlnet;      // (by position, not by whether the overlap is on: profiling and hl_unet_set_overlap(0) keep the dispatch)
         if (fork) {
             hipEventRecord(n.ev_fork, main_st);
             hipStreamWaitEvent(n.side, n.ev_fork, 0);
@@ -821,7 +818,6 @@ struct Exec {
             }
         }
         // decoder
-        solo = true;
         View last;
         for (size_t j = 0; j < nb; ++j) {
             View dst = (j + 1 < nb) ? first_part(j + 1, n.out_blocks[j].Cout) : plain(n.out_blocks[j].ds_out, n.out_blocks[j].Cout);

@@ -70,7 +70,6 @@ struct ConvArgs {
     mutable int stat_slots;
     hipEvent_t ev_mid;   // optional (profiling): recorded between the GroupNorm pre-pass and the convolution kernel, when there is a pre-pass
     mutable int ev_mid_used;
-    int solo;            // 1: nothing else of this forward runs beside this launch (the decoder; the encoder towers overlap on two streams): widens the fp16x2 3x3 window
     int plan_only;       // 1: no launch, only set `path` (w / w_wino / w_bf3 are then just non-null markers of what could be packed)
 };
 // kernel-side argument block of the convolution kernels (filled by conv2d)
@@ -112,6 +111,8 @@ bool conv1_h2_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride,
 size_t conv_packed_h2_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_h2(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st, int tf = 0);
 int conv1_h2_launch(const ConvK &p, hipStream_t st);
+int conv1_h2s_launch(const ConvK &p, hipStream_t st);               // the same on 128-pixel tiles, two workgroups per CU (p.n_mtiles = pixels / 128)
+int conv3_h2s_launch(const ConvK &p, hipStream_t st, int splits = 1);  // the same on 8x16-pixel tiles, two workgroups per CU (p.n_mtiles = pixels / 128)
 int conv3_h2_launch(const ConvK &p, hipStream_t st, int splits = 1);   // 3x3 / stride 1: k_conv_h16's workgroups with two planes (ConvK::in16 = 2: a two-plane image from the GroupNorm pass)
 void set_h16_min_blocks(long v);   // developer / test switch: workgroups from which the dispatch takes k_conv_h16 (< 0: the default, 48)
 

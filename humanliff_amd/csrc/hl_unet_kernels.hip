@@ -2895,21 +2895,21 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     }
     // 1x1 / stride-1 layers of the DEFAULT mode on the 16-bit matrix pipe with fp16x2 products (k_conv1_h2): once off the fp32 pipe they are bound by HBM, the
     // fp32 kernel takes twice as long.  From h2_min_blocks workgroups of 256 pixels x 192 channels on (fewer: the split-K fp32 path keeps the layer).
-    static const long h2_min_blocks = [] { const char *e_ = getenv("HL_H2_MIN_BLOCKS"); return e_ ? atol(e_) : 48L; }();   // developer knob (read once); < 0 disables
+    static const long h2_min_blocks = [] { const char *e_ = getenv("HL_H2_MIN_BLOCKS"); return e_ ? atol(e_) : 12L; }();   // developer knob (read once); < 0 disables (12: with the 128-pixel tiles; 48 with the 256-pixel ones)
     const long h2_blocks = (M / 256) * (a.Cout / 192);
     const bool h2 = !h16 && a.w_h2 && h2_min_blocks >= 0 && (!gn_on || a.act_ws) && !a.out_nchw && !a.w_bf3 &&
                     conv1_h2_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
                     (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0 && h2_blocks >= h2_min_blocks;
-    // 3x3 / stride-1 layers of the default mode in the same arithmetic (k_conv_h16<., 2>: k_conv_h16's workgroups, two planes, three products) where the
-    // layer has 100 ... 300 workgroups of 256 pixels x 192 channels, i.e. up to about one round of the chip: there the direct kernel beats the Winograd
-    // kernels' partial rounds (same box, forward wall time: B = 1 12.69 -> 12.41 ms, B = 4 31.88 -> 31.37, B = 8 57.81 -> 56.73).  Outside the window
-    // nothing moves although the kernel alone is 12 % faster on the 256-pixel level (461 against 523 us): profiles/r05_unet_fill_experiments.md.
+    // 3x3 / stride-1 layers of the default mode in the same arithmetic, from 100 workgroups of 256 pixels x 192 channels on: k_conv_h2s, a direct convolution on
+    // 8x16-pixel tiles with TWO workgroups per CU (late round 5).  Same box, forward wall time: B = 1 12.8 -> 12.2 ms, B = 4 32.5 -> 30.4, B = 8 58.9 -> 54.9 (both
+    // small-tile kernels).  The first version of the kernel (16x16 tiles, one workgroup per CU: k_conv_h16<., 2>, HL_H2_SMALL=0) won only where a layer was about one
+    // round of workgroups: alone it beat k_conv_wino4w by 12 % on the 256-pixel level and the forward's wall time did not move - a kernel that owns whole CUs cannot fill
+    // the other encoder tower's bubbles, and nothing overlapped its own prologue / staging / epilogue (profiles/r05_unet_fill_experiments.md, sections 6 - 8).
     static const long h3_min_blocks = [] { const char *e_ = getenv("HL_H2_CONV3_MIN_BLOCKS"); return e_ ? atol(e_) : 100L; }();   // developer knobs (read once); min < 0 disables
-    static const long h3_max_blocks = [] { const char *e_ = getenv("HL_H2_CONV3_MAX_BLOCKS"); return e_ ? atol(e_) : 300L; }();
-    static const bool h3_solo = [] { const char *e_ = getenv("HL_H2_CONV3_SOLO"); return e_ ? atoi(e_) != 0 : true; }();   // no upper bound where nothing runs beside the launch (the decoder)
+    static const long h3_max_blocks = [] { const char *e_ = getenv("HL_H2_CONV3_MAX_BLOCKS"); return e_ ? atol(e_) : (1L << 40); }();
     const bool h3 = !h16 && !h2 && a.w_h2 && a.ks == 3 && h3_min_blocks >= 0 && (!gn_on || (a.act_ws && !a.ups)) && !a.out_nchw && !a.w_bf3 &&
                     conv_h16_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
-                    (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0 && h16_blocks >= h3_min_blocks && (h16_blocks <= h3_max_blocks || (a.solo && h3_solo));
+                    (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0 && h16_blocks >= h3_min_blocks && h16_blocks <= h3_max_blocks;
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
         a.path = h16 ? 5 : (h2 || h3) ? 6 : (wino4 ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
         return HL_OK;
@@ -2980,6 +2980,11 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
             a.stat_slots = a.out.H * a.out.W / 128;
         }
+        static const int h3_small = [] { const char *e_ = getenv("HL_H2_SMALL"); return e_ ? atoi(e_) : 1; }();   // developer knob (read once): 8x16-pixel tiles, two workgroups per CU
+        if (h3_small) {
+            p.n_mtiles *= 2;
+            return conv3_h2s_launch(p, st);
+        }
         return conv3_h2_launch(p, st);
     }
     if (h2) {
@@ -3005,6 +3010,11 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         if (a.stats) {   // statistics from the epilogue (128 pixels of one image per round)
             p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
             a.stat_slots = 1;
+        }
+        static const int h2_small = [] { const char *e_ = getenv("HL_H2_SMALL1"); return e_ ? atoi(e_) : 1; }();   // developer knob (read once): 128-pixel tiles, two workgroups per CU
+        if (h2_small) {
+            p.n_mtiles *= 2;
+            return conv1_h2s_launch(p, st);
         }
         return conv1_h2_launch(p, st);
     }

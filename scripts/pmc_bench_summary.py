@@ -4,9 +4,9 @@ FETCH_SIZE under-counts 16 B/lane streams by 2x on gfx950 (calibrated with a dev
 profiles/notes_design_rounds_1_to_3.md, section 6), so reads are reported doubled ("corrected")."""
 import csv, glob, re, sys, collections
 
-FAMILIES = [("conv (k_conv_wino4w / k_conv_wino4 / k_conv_wino / k_conv_dma / k_conv / k_conv_h16<.,2> / k_conv1_h2 + k_gn_apply + k_splitk_finish[_st])", r"k_conv<|k_conv_dma<|k_conv_wino<|k_conv_wino4<|k_conv_wino4w<|k_conv_bf3<|k_conv_h16<|k_conv1_h2|k_conv1_h16<|k_gn_apply|k_splitk_finish"),
-            ("k_conv_h16<., 2> only (3x3, fp16x2 products)", r"k_conv_h16<"),
-            ("k_conv1_h2 only (1x1, fp16x2 products)", r"k_conv1_h2"),
+FAMILIES = [("conv (k_conv_wino4w / k_conv_wino4 / k_conv_wino / k_conv_dma / k_conv / k_conv_h2s / k_conv1_h2s + k_gn_apply + k_splitk_finish[_st])", r"k_conv<|k_conv_dma<|k_conv_wino<|k_conv_wino4<|k_conv_wino4w<|k_conv_bf3<|k_conv_h16<|k_conv_h2s|k_conv1_h2|k_conv1_h16<|k_gn_apply|k_splitk_finish"),
+            ("k_conv_h2s only (3x3, fp16x2 products, 8x16-pixel tiles)", r"k_conv_h2s|k_conv_h16<"),
+            ("k_conv1_h2s only (1x1, fp16x2 products, 128-pixel tiles)", r"k_conv1_h2"),
             ("k_conv_wino4w only", r"k_conv_wino4w<"),
             ("k_conv_wino4 only", r"k_conv_wino4<"),
             ("k_conv_wino only", r"k_conv_wino<"),

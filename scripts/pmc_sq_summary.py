@@ -8,7 +8,7 @@ Derived columns (per dispatch, then averaged over the dispatches of a shape):
 import collections, csv, glob, re, sys
 
 out, dirs = sys.argv[1], sys.argv[2:]
-KEEP = re.compile(r"k_conv_wino4w<|k_conv_wino4<|k_conv_wino<|k_conv_dma<|k_conv_h16<|k_conv1_h2|k_conv1_h16<|k_gn_apply|k_splitk_finish|k_gn_coef_st")
+KEEP = re.compile(r"k_conv_wino4w<|k_conv_wino4<|k_conv_wino<|k_conv_dma<|k_conv_h16<|k_conv_h2s|k_conv1_h2|k_conv1_h16<|k_gn_apply|k_splitk_finish|k_gn_coef_st")
 shape = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in dirs:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):

@@ -100,13 +100,11 @@ def test_production_b4_dispatch_matches_oracle(production):
         got0 = model(x_T.to(dev), torch.full((B,), 999, device=dev), xc.to(dev), y=y.to(dev)).cpu()
     census = model.dispatch_census()
     print("dispatch at B=4:", {k: v[:6] for k, v in census.items() if any(v)})
-    # the headline dispatch: F(4x4,3x3) on the 256- and 32-pixel levels (k_conv_wino4w; the 32-pixel level with its input channels split into
-    # slabs), the direct fp16x2 kernel on the 128- and 64-pixel levels (about one round of workgroups), F(2x2,3x3) on the 16-pixel level,
-    # no bf16 emulation in the default mode
-    assert all(census["wino4"][l] > 0 for l in (0, 3)), census
+    # the headline dispatch (late round 5): the 256-, 128- and 64-pixel levels on the direct fp16x2 kernels (k_conv_h2s, k_conv1_h2s: two workgroups per CU),
+    # F(4x4,3x3) on the 32-pixel level (input channels split into slabs), F(2x2,3x3) on the 16-pixel level, no bf16 emulation in the default mode
+    assert census["wino4"][3] > 0 and census["wino4"][0] <= 1, census          # (256-pixel level: only the 27-channel input convolution stays on F(4x4,3x3))
     assert census["wino2"][4] > 0 and census["bf16x3"] == [0] * 8, census
-    assert all(census["fp16x2"][l] > 0 for l in range(4)), census          # the 1x1 layers of the upper levels on k_conv1_h2 + those 3x3 layers
-    assert census["fp16x2"][1] > census["fp16x2"][0], census               # (3x3 layers counted on the 128-pixel level)
+    assert all(census["fp16x2"][l] > 20 for l in range(3)) and census["fp16x2"][3] > 0, census
     scale = float(eps0.abs().mean())
     e0 = float((got0 - eps0).abs().max())
     assert scale > 0.05 and e0 < 5e-5 * max(1.0, scale), (e0, scale)        # measured ~5e-6, like B=1
@@ -156,7 +154,7 @@ def test_production_b8_dispatch_matches_oracle(production):
         got = model(x.to(dev), t.to(dev), xc.to(dev), y=y.to(dev)).cpu()
     census = model.dispatch_census()
     print("dispatch at B=8:", {k: v[:6] for k, v in census.items() if any(v)})
-    assert all(census["wino4"][l] > 0 for l in (0, 1, 3)), census           # F(4x4,3x3) on the 256-, 128- and 32-pixel levels; the 64-pixel level (one round) on the fp16x2 kernel
+    assert all(census["fp16x2"][l] > 20 for l in range(4)) and sum(census["wino4"][:3]) <= 1, census   # the 256- ... 32-pixel levels on the direct fp16x2 kernels at this batch
     assert census["bf16x3"] == [0] * 8, census                              # no 16-bit emulation in the default mode
     scale = float(want.abs().mean())
     errs = [float((got[i] - want[i]).abs().max()) for i in range(B)]

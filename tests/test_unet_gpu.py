@@ -515,7 +515,7 @@ def test_conv_epilogue_groupnorm_statistics(N, C, H, W, Cout, ks, stride, ups, m
 @pytest.mark.parametrize("N,H,W,C,Cout,res,gn", [(4, 64, 64, 384, 192, True, False), (2, 128, 128, 192, 192, False, False), (1, 256, 256, 576, 192, True, False),
                                                (4, 32, 32, 384, 1152, False, True), (2, 64, 64, 768, 384, True, False)])
 def test_conv1x1_fp16x2_products_match_float64(N, H, W, C, Cout, res, gn):
-    """The 1x1 convolutions of the DEFAULT mode run on k_conv1_h2 from 48 workgroups on: two fp16 planes per operand, three partial products, fp32
+    """The 1x1 convolutions of the DEFAULT mode run on k_conv1_h2s (128-pixel tiles, two workgroups per CU) from 12 workgroups' worth of 256 pixels x 192 channels on: two fp16 planes per operand, three partial products, fp32
     accumulation.  Against the float64 convolution of the fp32 operands: the error of an fp32 convolution's class (bound 4e-6 of the output scale;
     a plain fp32 MFMA kernel measures ~1e-6 here), with residual and with the GroupNorm pre-pass of the attention's qkv convolution."""
     from humanliff_amd import _lib
@@ -555,11 +555,12 @@ def test_conv1x1_fp16x2_products_match_float64(N, H, W, C, Cout, res, gn):
 
 
 @pytest.mark.parametrize("N,H,W,C,Cout,res,gn,ups", [(1, 256, 256, 192, 192, True, True, 0), (4, 128, 128, 192, 192, False, False, 0), (4, 64, 64, 384, 384, True, True, 0),
-                                                   (4, 32, 32, 384, 384, False, False, 1), (2, 64, 64, 768, 384, False, True, 0)])
+                                                   (4, 32, 32, 384, 384, False, False, 1), (2, 64, 64, 768, 384, False, True, 0), (3, 112, 144, 96, 192, True, False, 0)])
 def test_conv3x3_fp16x2_products_match_float64(N, H, W, C, Cout, res, gn, ups):
-    """The 3x3 / stride-1 layers of the DEFAULT mode with about one round of workgroups (100 ... 300 tiles of 256 pixels x 192 channels) run on
-    k_conv_h16<., 2>: a direct convolution, two fp16 planes per operand, three partial products, fp32 accumulation - against the float64 convolution
-    of the fp32 operands, with the GroupNorm pre-pass writing the two-plane image, the residual, and the nearest-x2 upsample in the patch gather."""
+    """The 3x3 / stride-1 layers of the DEFAULT mode from 100 workgroups' worth of work on (256 pixels x 192 channels each) run on k_conv_h2s: a direct
+    convolution on 8x16-pixel tiles, two fp16 planes per operand, three partial products, fp32 accumulation - against the float64 convolution of the fp32
+    operands, with the GroupNorm pre-pass writing the two-plane image, the residual, the nearest-x2 upsample in the patch gather, and a non-square image
+    whose tile rows end in the middle of the last 16-row band."""
     import torch.nn.functional as F
     from humanliff_amd import _lib
     L = _lib.lib()
