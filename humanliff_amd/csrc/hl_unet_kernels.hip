@@ -2907,9 +2907,18 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     // the other encoder tower's bubbles, and nothing overlapped its own prologue / staging / epilogue (profiles/r05_unet_fill_experiments.md, sections 6 - 8).
     static const long h3_min_blocks = [] { const char *e_ = getenv("HL_H2_CONV3_MIN_BLOCKS"); return e_ ? atol(e_) : 100L; }();   // developer knobs (read once); min < 0 disables
     static const long h3_max_blocks = [] { const char *e_ = getenv("HL_H2_CONV3_MAX_BLOCKS"); return e_ ? atol(e_) : (1L << 40); }();
-    const bool h3 = !h16 && !h2 && a.w_h2 && a.ks == 3 && h3_min_blocks >= 0 && (!gn_on || (a.act_ws && !a.ups)) && !a.out_nchw && !a.w_bf3 &&
-                    conv_h16_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
-                    (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0 && h16_blocks >= h3_min_blocks && h16_blocks <= h3_max_blocks;
+    const bool h3_base = !h16 && !h2 && a.w_h2 && a.ks == 3 && h3_min_blocks >= 0 && (!gn_on || (a.act_ws && !a.ups)) && !a.out_nchw && !a.w_bf3 &&
+                         conv_h16_applies(a.out.H, a.out.W, a.in.C, a.Cout, a.ks, a.stride, a.ups) &&
+                         (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0;
+    bool h3 = h3_base && h16_blocks >= h3_min_blocks && h16_blocks <= h3_max_blocks;
+    // below that: the input channels split into slabs of >= 2 chunks until about one round of 128-pixel workgroups runs (k_splitk_finish[_st] sums the slabs)
+    static const long h3_split_min = [] { const char *e_ = getenv("HL_H2_CONV3_SPLIT_MIN"); return e_ ? atol(e_) : 8L; }();   // developer knob (read once); < 0: no split-K on this kernel
+    int h3_splits = 1;
+    if (h3_base && !h3 && h3_split_min >= 0 && h16_blocks >= h3_split_min && h16_blocks < h3_min_blocks && a.splitk_ws && !a.out2) {
+        h3_splits = (int)std::min<long>(std::min<long>(256 / h16_blocks, (a.in.C / 32) / 2), 16);
+        while (h3_splits > 1 && (size_t)h3_splits * M * a.Cout * sizeof(float) > a.splitk_ws_bytes) --h3_splits;
+        if (h3_splits >= 2) h3 = true; else h3_splits = 1;
+    }
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
         a.path = h16 ? 5 : (h2 || h3) ? 6 : (wino4 ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
         return HL_OK;
@@ -2972,13 +2981,24 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             p.in16 = 2;
             if (a.ev_mid) { hipEventRecord(a.ev_mid, st); a.ev_mid_used = 1; }
         }
-        p.w_bf3 = a.w_h2; p.partial = nullptr;
-        p.kt_per = a.in.C / 32;
+        p.w_bf3 = a.w_h2;
+        splits = h3_splits;
+        p.kt_per = (a.in.C / 32 + splits - 1) / splits;                  // chunks of 32 input channels per slab
+        splits = (a.in.C / 32 + p.kt_per - 1) / p.kt_per;
+        p.partial = splits > 1 ? a.splitk_ws : nullptr;
         p.n_nblocks = a.Cout / 192;
         p.n_mtiles = (int)((long)a.out.N * a.out.H * a.out.W / 256);
         if (a.stats) {
             p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
             a.stat_slots = a.out.H * a.out.W / 128;
+        }
+        if (splits > 1) {   // the finish kernel adds bias / residual and emits the statistics
+            p.st1 = p.st2 = nullptr;
+            a.stat_slots = 0;
+            p.n_mtiles *= 2;
+            int rc = conv3_h2s_launch(p, st, splits);
+            if (rc) return rc;
+            return finish("k_conv_h2s");
         }
         static const int h3_small = [] { const char *e_ = getenv("HL_H2_SMALL"); return e_ ? atoi(e_) : 1; }();   // developer knob (read once): 8x16-pixel tiles, two workgroups per CU
         if (h3_small) {

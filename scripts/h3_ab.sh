@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of the dispatch thresholds of the small-tile fp16x2 kernels (same box); thresholds in workgroups of 256 pixels x 192 channels
+# A/B (same box): split-K on the small-tile fp16x2 3x3 kernel for layers below the 100-workgroup threshold (HL_H2_CONV3_SPLIT_MIN = smallest layer, in 256-pixel x 192-channel units)
 cd /root/repo
-export HL_B=1,4,8 HL_H2_CONV3_MAX_BLOCKS=1099511627776
-for cfg in "100 12" "48 12" "24 12" "100 12" "48 6" "100 0"; do
-  set -- $cfg
-  echo "== HL_H2_CONV3_MIN_BLOCKS=$1 HL_H2_MIN_BLOCKS=$2"
-  HL_H2_CONV3_MIN_BLOCKS=$1 HL_H2_MIN_BLOCKS=$2 timeout 300 python scripts/fwd_time.py 2>&1 | grep "B="
+timeout 900 python -m pytest tests/test_unet_gpu.py -m gpu -q -x 2>&1 | tail -2
+export HL_B=1,4,8
+for v in -1 8 16 32 4 -1 8; do
+  echo "== HL_H2_CONV3_SPLIT_MIN=$v"
+  HL_H2_CONV3_SPLIT_MIN=$v timeout 300 python scripts/fwd_time.py 2>&1 | grep "B="
 done
