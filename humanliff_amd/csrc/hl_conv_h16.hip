@@ -449,6 +449,8 @@ __device__ __forceinline__ void h2s_epilogue(const ConvK &p, char *lds, const f3
     }
 }
 
+__device__ __forceinline__ float h2s_silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v)); }   // (= silu_f of the GroupNorm passes)
+
 __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__
     constexpr unsigned OOB = 0x80000000u;
@@ -480,6 +482,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * nch * 18 * 6144 * 2), 0x00020000);
 
+    // GroupNorm affine (+ SiLU) of the INPUT applied while staging (ConvK::cA / cB arrays, or ConvK::gn: coefficients formed here from the producers' group
+    // totals): no pre-pass over the tensor.  The table sits behind the stages; padding pixels are zero AFTER the activation (the convolution pads the activated tensor).
+    const bool aff = p.cA != nullptr || p.gn.gt != nullptr;
+    float *sA = reinterpret_cast<float *>(lds + H2S_LDS), *sB = sA + p.Cin;
     unsigned sv[NUT], sl[NUT];
 #pragma unroll
     for (int j = 0; j < NUT; ++j) {
@@ -500,10 +506,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
             ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] == OOB ? OOB : sv[j] + (p.in16 ? plane_b : 16u), so, 0);
         }
     };
-    auto a_store = [&](int stage, int j) {
+    auto a_store = [&](int stage, int j, int chunk) {
         u32x4 h0 = ar[j][0], h1 = ar[j][1];
         if (!p.in16) {
-            const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
+            f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
+            if (aff) {
+                const int cb = chunk * 32 + (tid & 3) * 8;           // this unit's eight channels (the group is tid & 3 for every unit of the thread)
+                v0 = v0 * *reinterpret_cast<const f32x4 *>(sA + cb) + *reinterpret_cast<const f32x4 *>(sB + cb);
+                v1 = v1 * *reinterpret_cast<const f32x4 *>(sA + cb + 4) + *reinterpret_cast<const f32x4 *>(sB + cb + 4);
+                if (p.act) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v0[i] = h2s_silu(v0[i]); v1[i] = h2s_silu(v1[i]); }
+                }
+                if (sv[j] == OOB) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+            }
             const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
             h0 = u32x4{q0.p0, q1.p0, q2.p0, q3.p0}; h1 = u32x4{q0.p1, q1.p1, q2.p1, q3.p1};
         }
@@ -544,8 +560,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
     a_load(c0);
 #pragma unroll
     for (int s = 0; s < RING; ++s) w_load(s, c0, s);
+    if (aff) {   // (the first patch and weights are on their way)
+        if (p.cA) {
+            for (int c = tid; c < p.Cin; c += 256) { sA[c] = p.cA[(long)img * p.Cin + c]; sB[c] = p.cB[(long)img * p.Cin + c]; }
+            __syncthreads();
+        } else coef_to_lds(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256);      // (ends with a barrier)
+    }
 #pragma unroll
-    for (int j = 0; j < NUT; ++j) a_store(0, j);
+    for (int j = 0; j < NUT; ++j) a_store(0, j, c0);
     __syncthreads();
 
     u32x4 af[2][2];                                                // [plane][fragment mf] of the current k-step (read at its start: the partner wave of the SIMD covers the LDS latency)
@@ -573,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
                         acc[mf][nf] = mma<true>(af[0][mf], ring[rs][0][nf], acc[mf][nf]);
                     }
                 w_load(rs, S + RING < 18 ? cc : ccn, (S + RING) % 18);
-                if constexpr (S >= ST0 && S < ST0 + NUT) a_store((c - c0 + 1) & 1, S - ST0);
+                if constexpr (S >= ST0 && S < ST0 + NUT) a_store((c - c0 + 1) & 1, S - ST0, ccn);
                 __builtin_amdgcn_sched_barrier(0);
             }(), ...);
         }(std::make_integer_sequence<int, 18>{});
@@ -1063,9 +1085,13 @@ int conv3_h2_launch(const ConvK &p, hipStream_t st, int splits) {
 // the same layers on the 8x16-pixel tile (two workgroups per CU): p.n_mtiles = pixels / 128
 int conv3_h2s_launch(const ConvK &p, hipStream_t st, int splits) {
     HL_REQUIRE(p.w_bf3 && p.ks == 3 && conv_h16_applies(p.Hout, p.Wout, p.Cin, p.Cout, p.ks, p.stride, p.ups) && (splits == 1 || p.partial), "k_conv_h2s: bad layer");
-    static const bool attr_ok = hipFuncSetAttribute((const void *)k_conv_h2s, hipFuncAttributeMaxDynamicSharedMemorySize, H2S_LDS) == hipSuccess;
-    HL_REQUIRE(attr_ok, "k_conv_h2s: cannot raise the dynamic LDS limit to %d bytes", H2S_LDS);
-    hipLaunchKernelGGL(k_conv_h2s, dim3((unsigned)(p.n_mtiles * p.n_nblocks), 1, (unsigned)splits), dim3(256), (size_t)H2S_LDS, st, p);
+    constexpr int LDS_MAX = H2S_LDS + (2 * 4096 + COEF_SCR_FLOATS) * 4;         // + the coefficient table of a fused GroupNorm (<= 4096 input channels)
+    static const bool attr_ok = hipFuncSetAttribute((const void *)k_conv_h2s, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) == hipSuccess;
+    HL_REQUIRE(attr_ok, "k_conv_h2s: cannot raise the dynamic LDS limit to %d bytes", LDS_MAX);
+    const bool aff = p.cA != nullptr || p.gn.gt != nullptr;
+    HL_REQUIRE(!aff || (p.Cin <= 4096 && !p.in16 && !p.ups), "k_conv_h2s: fused GroupNorm needs a raw fp32 input of <= 4096 channels");
+    const size_t lds_bytes = (size_t)H2S_LDS + (aff ? (size_t)(2 * p.Cin + COEF_SCR_FLOATS) * 4 : 0);
+    hipLaunchKernelGGL(k_conv_h2s, dim3((unsigned)(p.n_mtiles * p.n_nblocks), 1, (unsigned)splits), dim3(256), lds_bytes, st, p);
     return check_launch("k_conv_h2s");
 }
 

@@ -2964,7 +2964,11 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     if (h3) {
         a.path = 6;
         p.in16 = 0;
-        if (mode != 0) {   // GroupNorm(+SiLU) materialised once, as the two-plane image the kernel stages without conversion (the same bytes as fp32)
+        // GroupNorm(+SiLU) of the input: applied by k_conv_h2s while it stages the patch (its two workgroups per CU hide the VALU) - no pass over the tensor
+        static const int h3_fuse = [] { const char *e_ = getenv("HL_H2_FUSE_GN"); return e_ ? atoi(e_) : 1; }();   // developer knob (read once)
+        static const int h3_small_ = [] { const char *e_ = getenv("HL_H2_SMALL"); return e_ ? atoi(e_) : 1; }();
+        const bool fuse = mode != 0 && h3_fuse && h3_small_ && !a.ups && a.in.C <= 4096;
+        if (mode != 0 && !fuse) {   // GroupNorm(+SiLU) materialised once, as the two-plane image the kernel stages without conversion (the same bytes as fp32)
             HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
             const long npix = a.in.pixels();
             if (a.coefA == nullptr) {
