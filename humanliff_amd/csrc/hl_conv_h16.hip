@@ -858,10 +858,16 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
         (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * pitch4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * nch * 3 * 12288), 0x00020000);
+    // GroupNorm affine (+ SiLU) of the input applied while staging, as in k_conv_h2s (ConvK::cA / cB arrays or ConvK::gn); a tile = 128 pixels of ONE image
+    const bool aff = p.cA != nullptr || p.gn.gt != nullptr;
+    float *sA = reinterpret_cast<float *>(lds + H2S1_LDS), *sB = sA + p.Cin;
+    const int img = (int)(m0 / ((long)p.Hout * p.Wout));
     unsigned sv[NUT], sl[NUT];
+    int sg[NUT];
 #pragma unroll
     for (int j = 0; j < NUT; ++j) {
         const int u = tid + 256 * j, pix = u / 6, grp = u - pix * 6;
+        sg[j] = grp * 8;
         sv[j] = (unsigned)(m0 + pix) * pitch4 + grp * 32;
         sl[j] = (unsigned)(pix * H2_PITCH + grp * 16);
     }
@@ -873,8 +879,17 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
             ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] + 16, chunk * 192, 0);
         }
     };
-    auto a_store = [&](int stage, int j) {
-        const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
+    auto a_store = [&](int stage, int j, int chunk) {
+        f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
+        if (aff) {
+            const int cb = chunk * 48 + sg[j];
+            v0 = v0 * *reinterpret_cast<const f32x4 *>(sA + cb) + *reinterpret_cast<const f32x4 *>(sB + cb);
+            v1 = v1 * *reinterpret_cast<const f32x4 *>(sA + cb + 4) + *reinterpret_cast<const f32x4 *>(sB + cb + 4);
+            if (p.act) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v0[i] = h2s_silu(v0[i]); v1[i] = h2s_silu(v1[i]); }
+            }
+        }
         const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
         const u32x4 h0 = {q0.p0, q1.p0, q2.p0, q3.p0}, h1 = {q0.p1, q1.p1, q2.p1, q3.p1};
         *reinterpret_cast<u32x4 *>(lds + stage * H2S1_STAGE + sl[j]) = h0;
@@ -903,13 +918,20 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
     a_load(0);
 #pragma unroll
     for (int s = 0; s < 3; ++s) w_load(s, s);
+    if (aff) {   // (the first slab and weights are on their way)
+        if (p.cA) {
+            for (int c = tid; c < p.Cin; c += 256) { sA[c] = p.cA[(long)img * p.Cin + c]; sB[c] = p.cB[(long)img * p.Cin + c]; }
+            __syncthreads();
+        } else coef_to_lds(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256);      // (ends with a barrier)
+    }
 #pragma unroll
-    for (int j = 0; j < NUT; ++j) a_store(0, j);
+    for (int j = 0; j < NUT; ++j) a_store(0, j, 0);
     __syncthreads();
     u32x4 af[2][2];                                                 // [plane][fragment mf] of the current k-step (the partner wave of the SIMD covers the LDS latency)
     for (int c = 0; c < nch; ++c) {
         const char *st = lds + (c & 1) * H2S1_STAGE;
-        a_load(c + 1 < nch ? c + 1 : c);                             // (last chunk: staged again, never read)
+        const int cn = c + 1 < nch ? c + 1 : c;                      // (last chunk: staged again, never read)
+        a_load(cn);
         [&]<int... S>(std::integer_sequence<int, S...>) {
             ([&] {
 #pragma unroll
@@ -926,7 +948,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
                         acc[mf][nf] = mma<true>(af[0][mf], ring[S][0][nf], acc[mf][nf]);
                     }
                 w_load(S, c * 3 + S + 3);
-                a_store((c + 1) & 1, S);
+                a_store((c + 1) & 1, S, cn);
                 __builtin_amdgcn_sched_barrier(0);
             }(), ...);
         }(std::make_integer_sequence<int, 3>{});
@@ -1098,9 +1120,13 @@ int conv3_h2s_launch(const ConvK &p, hipStream_t st, int splits) {
 // the 1x1 layers on 128-pixel tiles (two workgroups per CU): p.n_mtiles = pixels / 128
 int conv1_h2s_launch(const ConvK &p, hipStream_t st) {
     HL_REQUIRE(p.w_bf3 && conv1_h2_applies(p.Hout, p.Wout, p.Cin, p.Cout, p.ks, p.stride, p.ups) && !p.partial && !p.in16, "k_conv1_h2s: bad layer");
-    static const bool attr_ok = hipFuncSetAttribute((const void *)k_conv1_h2s, hipFuncAttributeMaxDynamicSharedMemorySize, H2S1_LDS) == hipSuccess;
-    HL_REQUIRE(attr_ok, "k_conv1_h2s: cannot raise the dynamic LDS limit to %d bytes", H2S1_LDS);
-    hipLaunchKernelGGL(k_conv1_h2s, dim3((unsigned)(p.n_mtiles * p.n_nblocks)), dim3(256), (size_t)H2S1_LDS, st, p);
+    constexpr int LDS_MAX = H2S1_LDS + (2 * 4096 + COEF_SCR_FLOATS) * 4;        // + the coefficient table of a fused GroupNorm (<= 4096 input channels)
+    static const bool attr_ok = hipFuncSetAttribute((const void *)k_conv1_h2s, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) == hipSuccess;
+    HL_REQUIRE(attr_ok, "k_conv1_h2s: cannot raise the dynamic LDS limit to %d bytes", LDS_MAX);
+    const bool aff = p.cA != nullptr || p.gn.gt != nullptr;
+    HL_REQUIRE(!aff || (p.Cin <= 4096 && ((long)p.Hout * p.Wout) % 128 == 0), "k_conv1_h2s: fused GroupNorm needs <= 4096 input channels and whole tiles per image");
+    const size_t lds_bytes = (size_t)H2S1_LDS + (aff ? (size_t)(2 * p.Cin + COEF_SCR_FLOATS) * 4 : 0);
+    hipLaunchKernelGGL(k_conv1_h2s, dim3((unsigned)(p.n_mtiles * p.n_nblocks)), dim3(256), lds_bytes, st, p);
     return check_launch("k_conv1_h2s");
 }
 

@@ -3013,7 +3013,10 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     }
     if (h2) {
         a.path = 6;
-        if (mode != 0) {   // GroupNorm(+SiLU) materialised once as dense fp32 (the kernel splits into its two fp16 planes while staging)
+        static const int h2_fuse = [] { const char *e_ = getenv("HL_H2_FUSE_GN"); return e_ ? atoi(e_) : 1; }();     // developer knobs (read once)
+        static const int h2_small_ = [] { const char *e_ = getenv("HL_H2_SMALL1"); return e_ ? atoi(e_) : 1; }();
+        const bool fuse1 = mode != 0 && h2_fuse && h2_small_ && a.in.C <= 4096;      // GroupNorm(+SiLU) applied by k_conv1_h2s while staging
+        if (mode != 0 && !fuse1) {   // GroupNorm(+SiLU) materialised once as dense fp32 (the kernel splits into its two fp16 planes while staging)
             HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
             const long npix = a.in.pixels();
             if (a.coefA == nullptr) {
