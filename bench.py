@@ -42,9 +42,9 @@ COARSE_FLOP_PER_RAY = 128 * 79616
 FINE_FLOP_PER_RAY_TOTAL = FINE_FLOP_PER_RAY + COARSE_FLOP_PER_RAY   # the reference's schedule: 44 138 496 FLOP per ray
 # Fabric-side bytes per launch of the dominant kernels from the separate rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
 # calibration, WRITE_SIZE as is).  Not measured by this script - PMC collection needs its own runs (scripts/refresh_profiles_r4.sh).
-PMC_TRAFFIC = {"k_conv_avg_launch_b4": 306e6, "k_march_fine_512x512": 4.1e9, "k_march_eval_512x512": 0.72e9, "k_march_b3w_eval_512x512": 0.726e9,
-               "source": "profiles/r05_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; conv path: (341.43 GB read "
-                         "+ 129.03 GB written) / 6 forwards / 256 launches), profiles/r05_pmc_render_traffic.md (k_march_plw<2>: 188.8 MB read + 536.9 MB written "
+PMC_TRAFFIC = {"k_conv_avg_launch_b4": 267e6, "k_march_fine_512x512": 4.1e9, "k_march_eval_512x512": 0.72e9, "k_march_b3w_eval_512x512": 0.726e9,
+               "source": "profiles/r05_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; k_conv_h2s: (122.75 GB read "
+                         "+ 48.69 GB written) / 642 launches of all its shapes = 267 MB per launch; the whole conv path 198.0 + 81.3 GB per 6 forwards), profiles/r05_pmc_render_traffic.md (k_march_plw<2>: 188.8 MB read + 536.9 MB written "
                          "per launch; k_march_plw<3> the same bytes) and profiles/notes_design_rounds_1_to_3.md (k_march<true,true>: (1.50 + 4.29 GB) / 8 launches)"}
 
 F4 = dict(image_size=256, in_channels=27, out_channels=27, num_channels=192, num_res_blocks=3, num_heads=4,
