@@ -458,6 +458,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
 #ifndef H2S_RING
 #define H2S_RING 2
 #endif
+#ifndef H2S_ABL   // timing ablations (wrong results): 1 no weight loads in the loop, 2 no patch loads / staging, 4 no A-fragment reads, 8 no MFMAs
+#define H2S_ABL 0
+#endif
 #ifndef H2S_ST0
 #define H2S_ST0 12
 #endif
@@ -580,22 +583,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
     for (int c = c0; c < c1; ++c) {
         const char *st = lds + ((c - c0) & 1) * H2S_STG;
         const int cc = c, ccn = cc + 1 < nch ? cc + 1 : 0;
-        a_load(ccn);
+        if (!(H2S_ABL & 2)) a_load(ccn);
         [&]<int... S>(std::integer_sequence<int, S...>) {
             ([&] {
                 constexpr int rs = S % RING;
-                a_read(st, S >> 1, S & 1, af);
+                if constexpr (!(H2S_ABL & 4) || S == 0) a_read(st, S >> 1, S & 1, af);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nf = 0; nf < 3; ++nf)
 #pragma unroll
-                    for (int mf = 0; mf < 2; ++mf) {                // smallest partial product first
+                    for (int mf = 0; mf < 2; ++mf) if constexpr (!(H2S_ABL & 8)) {                // smallest partial product first
                         acc[mf][nf] = mma<true>(af[1][mf], ring[rs][0][nf], acc[mf][nf]);
                         acc[mf][nf] = mma<true>(af[0][mf], ring[rs][1][nf], acc[mf][nf]);
                         acc[mf][nf] = mma<true>(af[0][mf], ring[rs][0][nf], acc[mf][nf]);
                     }
-                w_load(rs, S + RING < 18 ? cc : ccn, (S + RING) % 18);
-                if constexpr (S >= ST0 && S < ST0 + NUT) a_store((c - c0 + 1) & 1, S - ST0, ccn);
+                if constexpr (!(H2S_ABL & 1)) w_load(rs, S + RING < 18 ? cc : ccn, (S + RING) % 18);
+                if constexpr (S >= ST0 && S < ST0 + NUT && !(H2S_ABL & 2)) a_store((c - c0 + 1) & 1, S - ST0, ccn);
                 __builtin_amdgcn_sched_barrier(0);
             }(), ...);
         }(std::make_integer_sequence<int, 18>{});
