@@ -297,8 +297,8 @@ class UNetModel(nn.Module):
 
     def set_conv_mode(self, mode):
         """Arithmetic of the large convolutions: "fp32" (default; fp32-class products and fp32 accumulation throughout - Winograd F(4x4,3x3) / F(2x2,3x3) on the
-        fp32 matrix pipe for the large 3x3 layers, direct implicit GEMM elsewhere; since round 5 the 1x1 layers and the 3x3 layers of about one round of
-        workgroups form their fp32 products from two fp16 planes per operand on the 16-bit matrix pipe, error of the fp32 direct kernel's class),
+        fp32 matrix pipe or the fp32 direct implicit GEMM where the following does not apply; since round 5 every 3x3 / stride-1 and 1x1 layer with Cout a multiple of 192
+        and enough work is a direct convolution that forms its fp32 products from two fp16 planes per operand on the 16-bit matrix pipe, error of the fp32 direct kernel's class),
         "fp32_mfma" (the same dispatch with every product on v_mfma_f32_32x32x2_f32: the default of rounds 3-4), "fp32_f23" (no F(4x4,3x3)), "fp32_direct" (direct implicit GEMM only: every product
         a*b of the reference's sum is formed exactly once) or "bf16x3" (opt-in extension, not in the reference: the
         same fp32 tensors and accumulators, each product formed on the bf16 matrix pipe from exact three-way bf16
@@ -317,7 +317,8 @@ class UNetModel(nn.Module):
 
     def dispatch_census(self):
         """Which kernel family every convolution of the LAST inference forward took (hl_unet_dispatch_census):
-        {"direct" | "wino2" | "bf16x3" | "wino4" | "fp16x2": [launches per resolution level, level = log2(H / H_out)]} ("fp16x2": the 1x1 layers on k_conv1_h2).  Kernel selection depends
+        {"direct" | "wino2" | "bf16x3" | "wino4" | "fp16x2": [launches per resolution level, level = log2(H / H_out)]} ("fp16x2": the direct convolutions with fp16x2
+        products, k_conv_h2s / k_conv1_h2s).  Kernel selection depends
         on the batch size, so parity tests state with this which dispatch they covered."""
         if self._hip is None:
             raise RuntimeError("dispatch_census: no forward has run yet")

@@ -322,12 +322,15 @@ int hl_unet_set_overlap(void *handle, int enable);
  * HL_CONV_FP32 (default): fp32-class products, fp32 accumulation.  3x3 / stride-1 layers take Winograd F(4x4,3x3) on v_mfma_f32_32x32x2_f32 (36 fp32
  *   multiplies per 4x4 outputs instead of 144; interpolation points 0, +-3/4, +-3/2, inf) where 32x16-pixel x 32-channel
  *   workgroups fill the chip (the 256- and 128-pixel levels at batch 4), Winograd F(2x2,3x3) (16 per 2x2 instead of 36) on the
- *   smaller levels, everything else the direct implicit GEMM.  Round 5: the 1x1 / stride-1 layers from 48 workgroups (256 pixels x 192
- *   channels) on, and the 3x3 / stride-1 layers of 100 ... 300 workgroups (about one round of the chip), are DIRECT convolutions whose
- *   fp32 products come from TWO fp16 planes per operand on v_mfma_f32_32x32x16_f16 (k_conv1_h2, k_conv_h16<., 2>): activation
- *   x = h0 + h1 (h0 = x with its low 13 mantissa bits cleared, h1 = the truncated residual: |x - h0 - h1| < 2^-20 |x|), weight planes
- *   nearest even (2^-22), h1 w0 + h0 w1 + h0 w0 accumulated in fp32 - error of the fp32 direct kernel's class, checked against float64
- *   (tests/test_unet_gpu.py: rel-L2 3e-7 ... 1.2e-6 against 2e-7 ... 6e-7 of HL_CONV_FP32_DIRECT); range |x| < 65504.
+ *   smaller levels, everything else the direct implicit GEMM.  Round 5: every 3x3 / stride-1 layer (also behind the nearest-x2 upsample) and every
+ *   1x1 / stride-1 layer with Cout a multiple of 192, Cin a multiple of 32 / 96 and enough work (3x3: from 8 workgroups' worth of 256 pixels x 192
+ *   channels, split-K below 100; 1x1: from 12) is a DIRECT convolution whose fp32 products come from TWO fp16 planes per operand on
+ *   v_mfma_f32_32x32x16_f16 (k_conv_h2s, k_conv1_h2s: 8x16-pixel / 128-pixel tiles, two workgroups per CU): activation x = h0 + h1 (h0 = x with its
+ *   low 13 mantissa bits cleared, h1 = the truncated residual: |x - h0 - h1| < 2^-20 |x|), weight planes nearest even (2^-22),
+ *   h1 w0 + h0 w1 + h0 w0 accumulated in fp32 - error of the fp32 direct kernel's class, checked against float64 (tests/test_unet_gpu.py: rel-L2
+ *   3e-7 ... 1.2e-6 against 2e-7 ... 6e-7 of HL_CONV_FP32_DIRECT); range |x| < 65504.  A GroupNorm (+ SiLU) in front of such a layer is applied
+ *   while the kernel stages its input (no pass over the tensor).  The F(4x4,3x3) / F(2x2,3x3) kernels keep the layers the direct kernels do not
+ *   take (the 27-channel input convolution, Cout not a multiple of 192, small single-op calls).
  * HL_CONV_FP32_MFMA: HL_CONV_FP32 without those two kernels - every product on v_mfma_f32_32x32x2_f32 (the default of rounds 3-4).
  * HL_CONV_FP32_F23: the same without F(4x4,3x3) (the arithmetic of the round-2 library).
  * HL_CONV_FP32_DIRECT: the direct implicit GEMM only - every product of the reference's sum is formed exactly once.
@@ -378,8 +381,8 @@ int hl_unet_profile_dominant(void *handle, double *h_vals, int *h_key);
  * (k_conv_wino4); level = log2(H / H_out) of the layer's output.  Kernel selection depends on the batch size (a layer takes a Winograd
  * kernel only where its workgroups fill the chip), so parity tests use this to state WHICH dispatch they covered. */
 int hl_unet_dispatch_census(void *handle, int64_t *h_counts);
-/* The same with `rows` <= 5 rows of 8 levels: direct | Winograd F(2x2) | bf16x3 / 16-bit operand kernels | Winograd F(4x4) | k_conv1_h2 (1x1 layers of the
- * default mode with fp16x2 products: two fp16 planes per operand, three partial products, fp32 accumulation). */
+/* The same with `rows` <= 5 rows of 8 levels: direct | Winograd F(2x2) | bf16x3 / 16-bit operand kernels | Winograd F(4x4) | the direct convolutions of the
+ * default mode with fp16x2 products (k_conv_h2s, k_conv1_h2s: two fp16 planes per operand, three partial products, fp32 accumulation). */
 int hl_unet_dispatch_census_ex(void *handle, int64_t *h_counts, int rows);
 
 /* Fused sampler update (everything after the model call in p_sample / ddim_sample,
