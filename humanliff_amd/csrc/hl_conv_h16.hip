@@ -837,6 +837,128 @@ __global__ __launch_bounds__(256, 1) void k_conv1_h2(const ConvK p) {
 #endif
 }
 
+// k_conv_h2d: the 3x3 / STRIDE-2 layers (Downsample, unet.py:100) in the same arithmetic: 8x16 OUTPUT pixels x 192 channels per workgroup, two workgroups per CU.  The 17x33-pixel
+// input patch is staged de-interleaved by (row parity, column parity) into four 9x17 sub-images, so tap (ky, kx) of the 16 consecutive output pixels of a fragment row reads 16
+// consecutive pixels of sub-image (ky & 1, kx & 1) at offset (ky >> 1, kx >> 1) - the access pattern of the stride-1 kernel.  Chunks of 16 input channels (32 bytes per pixel and
+// plane, one k-step per tap), ONE stage of 46 KB: the next chunk's patch waits in registers while this one is multiplied (the partner workgroup of the CU covers the refill).
+constexpr int H2D_SR = 9, H2D_LP = 20;                                      // rows / row pitch (pixels) of a sub-image
+constexpr int H2D_SUB = H2D_SR * H2D_LP * 32, H2D_PLANE = 4 * H2D_SUB, H2D_STG = 2 * H2D_PLANE;   // bytes: sub-image, plane (four of them), stage (two planes)
+constexpr int H2D_LDS = H2D_STG + 1024 > 128 * H2S_EP * 4 ? H2D_STG + 1024 : 128 * H2S_EP * 4;
+
+__global__ __launch_bounds__(256, 2) void k_conv_h2d(const ConvK p) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NU = 17 * 33 * 2, NUT = (NU + 255) / 256;        // staging units (patch pixel, 8-channel group of the 16-channel chunk): 1 122 -> 5 per thread
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int total = p.n_mtiles * p.n_nblocks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int wi = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int tb = __builtin_amdgcn_readfirstlane(wi / p.n_nblocks), nb = wi - tb * p.n_nblocks;
+    const int bw = p.Wout >> 4, bh = p.Hout >> 3;
+    const int img = tb / (bw * bh), brem = tb - img * (bw * bh);
+    const int y0 = (brem / bw) * 8, x0 = (brem - (brem / bw) * bw) * 16;
+    const int nch = p.Cin >> 4;                                    // chunks of 16 input channels
+    const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * pitch4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)p.w_bf3, (short)0, (int)((long)p.n_nblocks * (p.Cin >> 5) * 18 * 6144 * 2), 0x00020000);
+    unsigned sv[NUT], sl[NUT];
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) {
+        const int u = tid + 256 * j, pix = u >> 1, grp = u & 1;
+        const int py = pix / 33, px = pix - py * 33;
+        const int y = 2 * y0 - 1 + py, x = 2 * x0 - 1 + px;
+        const bool ok = u < NU && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+        sv[j] = ok ? (unsigned)((img * p.Hin + y) * p.Win + x) * pitch4 + grp * 32 : OOB;
+        const int sub = (py & 1) * 2 + (px & 1), sy = py >> 1, sx = px >> 1;
+        sl[j] = u < NU ? (unsigned)(sub * H2D_SUB + (sy * H2D_LP + sx) * 32 + ((grp ^ ((sx >> 3) & 1)) << 4)) : (unsigned)(H2D_STG + (tid & 63) * 16);   // (no unit: a dump slot)
+    }
+    u32x4 ar[NUT][2];
+    auto a_load = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NUT; ++j) {
+            ar[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j], chunk * 64, 0);
+            ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] == OOB ? OOB : sv[j] + 16u, chunk * 64, 0);
+        }
+    };
+    auto a_store = [&](int j) {
+        const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
+        const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
+        *reinterpret_cast<u32x4 *>(lds + sl[j]) = u32x4{q0.p0, q1.p0, q2.p0, q3.p0};
+        if (sl[j] < (unsigned)H2D_STG) *reinterpret_cast<u32x4 *>(lds + H2D_PLANE + sl[j]) = u32x4{q0.p1, q1.p1, q2.p1, q3.p1};
+    };
+    // A fragments: row r of fragment mf = output pixel (4 wm + 2 mf + (r >> 4), r & 15); column offset dx = kx >> 1 in its sub-image
+    unsigned aoff[2][2];
+    {
+        const int r = lane & 31, g = lane >> 5;
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int sy = 4 * wm + 2 * mf + (r >> 4), sx = (r & 15) + dx;
+                aoff[mf][dx] = (unsigned)((sy * H2D_LP + sx) * 32 + ((g ^ ((sx >> 3) & 1)) << 4));
+            }
+    }
+    const unsigned wv = (unsigned)lane * 16u;
+    const int wbase = nb * (p.Cin >> 5) * 18 * 6144 * 2 + wn * 3072;
+    u32x4 ring[3][2][3];                                           // three taps of weights in flight (a chunk has nine)
+    auto w_load = [&](int slot_, int c16, int tap) {               // k-step (tap, half c16 & 1) of the 32-channel chunk c16 >> 1 of the packed image
+        const int so = wbase + ((c16 >> 1) * 18 + tap * 2 + (c16 & 1)) * 6144 * 2;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) ring[slot_][pl][nf] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wv, so + pl * 6144 + nf * 1024, 0);
+    };
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+    a_load(0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) w_load(s, 0, s);
+    u32x4 af[2][2];
+    for (int c = 0; c < nch; ++c) {
+        if (c) __syncthreads();                                      // everybody is done with the previous chunk's patch
+#pragma unroll
+        for (int j = 0; j < NUT; ++j) a_store(j);
+        __syncthreads();
+        const int cn = c + 1 < nch ? c + 1 : c;                      // (past the end: a valid chunk, fetched and never written)
+        a_load(cn);
+        [&]<int... T>(std::integer_sequence<int, T...>) {
+            ([&] {
+                constexpr int ky = T / 3, kx = T % 3, rs = T % 3;
+                const char *sb = lds + ((ky & 1) * 2 + (kx & 1)) * H2D_SUB + (ky >> 1) * (H2D_LP * 32);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) af[pl][mf] = *reinterpret_cast<const u32x4 *>(sb + pl * H2D_PLANE + aoff[mf][kx >> 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) {                // smallest partial product first
+                        acc[mf][nf] = mma<true>(af[1][mf], ring[rs][0][nf], acc[mf][nf]);
+                        acc[mf][nf] = mma<true>(af[0][mf], ring[rs][1][nf], acc[mf][nf]);
+                        acc[mf][nf] = mma<true>(af[0][mf], ring[rs][0][nf], acc[mf][nf]);
+                    }
+                w_load(rs, T + 3 < 9 ? c : cn, (T + 3) % 9);
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, 9>{});
+    }
+    __syncthreads();
+    h2s_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, [&](int pc) {
+        const int wmm = pc >> 6, m2 = (pc >> 5) & 1, r = pc & 31;
+        return ((long)img * p.Hout + y0 + 4 * wmm + 2 * m2 + (r >> 4)) * p.Wout + x0 + (r & 15);
+    });
+#endif
+}
+
 // k_conv1_h2s: k_conv1_h2 on 128 pixels x 192 channels per workgroup (96 accumulator registers per wave, 56 KB of LDS): TWO workgroups share a CU, so the
 // prologue (the first slab's HBM round trip) and the epilogue of one overlap the main loop of the other - with one 256-pixel workgroup per CU they were ~14 of
 // ~46 us per workgroup (timing ablations, profiles/r05_unet_fill_experiments.md section 7).  Same arithmetic, same weight image, h2s_epilogue.
@@ -1118,6 +1240,17 @@ int conv3_h2s_launch(const ConvK &p, hipStream_t st, int splits) {
     const size_t lds_bytes = (size_t)H2S_LDS + (aff ? (size_t)(2 * p.Cin + COEF_SCR_FLOATS) * 4 : 0);
     hipLaunchKernelGGL(k_conv_h2s, dim3((unsigned)(p.n_mtiles * p.n_nblocks), 1, (unsigned)splits), dim3(256), lds_bytes, st, p);
     return check_launch("k_conv_h2s");
+}
+
+// the 3x3 / stride-2 layers: p.n_mtiles = output pixels / 128
+bool conv3_h2d_applies(int Hout, int Wout, int Cin, int Cout) { return Hout % 8 == 0 && Wout % 16 == 0 && Cin % 32 == 0 && Cout % 192 == 0 && (long)Cout * Cin * 36 < (1L << 31); }
+int conv3_h2d_launch(const ConvK &p, hipStream_t st) {
+    HL_REQUIRE(p.w_bf3 && p.ks == 3 && p.stride == 2 && !p.ups && !p.in16 && !p.partial && conv3_h2d_applies(p.Hout, p.Wout, p.Cin, p.Cout) && p.cA == nullptr && p.gn.gt == nullptr,
+               "k_conv_h2d: bad layer");
+    static const bool attr_ok = hipFuncSetAttribute((const void *)k_conv_h2d, hipFuncAttributeMaxDynamicSharedMemorySize, H2D_LDS) == hipSuccess;
+    HL_REQUIRE(attr_ok, "k_conv_h2d: cannot raise the dynamic LDS limit to %d bytes", H2D_LDS);
+    hipLaunchKernelGGL(k_conv_h2d, dim3((unsigned)(p.n_mtiles * p.n_nblocks)), dim3(256), (size_t)H2D_LDS, st, p);
+    return check_launch("k_conv_h2d");
 }
 
 // the 1x1 layers on 128-pixel tiles (two workgroups per CU): p.n_mtiles = pixels / 128

@@ -2919,8 +2919,13 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         while (h3_splits > 1 && (size_t)h3_splits * M * a.Cout * sizeof(float) > a.splitk_ws_bytes) --h3_splits;
         if (h3_splits >= 2) h3 = true; else h3_splits = 1;
     }
+    // 3x3 / stride-2 layers (Downsample) of the default mode in the same arithmetic (k_conv_h2d), from h3d_min_blocks workgroups' worth of output (256 pixels x 192 channels) on
+    static const long h3d_min_blocks = [] { const char *e_ = getenv("HL_H2_CONV3S2_MIN_BLOCKS"); return e_ ? atol(e_) : 32L; }();   // developer knob (read once); < 0 disables
+    const bool h3d = !h16 && !h2 && !h3 && a.w_h2 && a.ks == 3 && a.stride == 2 && !a.ups && mode == 0 && h3d_min_blocks >= 0 && !a.out_nchw && !a.w_bf3 &&
+                     conv3_h2d_applies(a.out.H, a.out.W, a.in.C, a.Cout) && (long)a.in.N * a.in.H * a.in.W * a.in.pitch * 4 < (1L << 31) && a.in.pitch % 4 == 0 &&
+                     h16_blocks >= h3d_min_blocks;
     if (a.plan_only) {   // which weight layout will this launch read?  (single-op entry points pack only that one)
-        a.path = h16 ? 5 : (h2 || h3) ? 6 : (wino4 ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
+        a.path = h16 ? 5 : (h2 || h3 || h3d) ? 6 : (wino4 ? 3 : ((dma && wino) ? 1 : ((dma && a.w_bf3 && (long)cpad * p.Ktot * 6 < (1L << 31)) ? 2 : 0)));
         return HL_OK;
     }
     if (h16) {
@@ -2960,6 +2965,17 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             return finish("k_conv_h16");
         }
         return conv_h16_launch(p, a.h16_fp16, st);
+    }
+    if (h3d) {
+        a.path = 6;
+        p.in16 = 0; p.w_bf3 = a.w_h2; p.partial = nullptr;
+        p.n_nblocks = a.Cout / 192;
+        p.n_mtiles = (int)((long)a.out.N * a.out.H * a.out.W / 128);
+        if (a.stats) {
+            p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
+            a.stat_slots = a.out.H * a.out.W / 128;
+        }
+        return conv3_h2d_launch(p, st);
     }
     if (h3) {
         a.path = 6;

@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B (same box): the library in the tree against a previous build kept as humanliff_amd/exp/lib_prev.so
+# A/B (same box): threshold of the stride-2 fp16x2 kernel (HL_H2_CONV3S2_MIN_BLOCKS, workgroups' worth of 256 output pixels x 192 channels)
 cd /root/repo
-timeout 900 python -m pytest tests/test_unet_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x 2>&1 | tail -3
 export HL_B=1,4,8
-for v in prev new prev new; do
-  echo "== $v"
-  if [ $v = prev ]; then HL_LIB_PATH=/root/repo/humanliff_amd/exp/lib_prev.so timeout 300 python scripts/fwd_time.py 2>&1 | grep "B="; else timeout 300 python scripts/fwd_time.py 2>&1 | grep "B="; fi
+for v in 32 8 16 64 -1 32; do
+  echo "== HL_H2_CONV3S2_MIN_BLOCKS=$v"
+  HL_H2_CONV3S2_MIN_BLOCKS=$v timeout 300 python scripts/fwd_time.py 2>&1 | grep "B="
 done
+timeout 1500 python -m pytest tests/test_unet_gpu.py tests/test_fullsize_gpu.py tests/test_e2e_gpu.py tests/test_unet_train_gpu.py -m gpu -q -x 2>&1 | tail -3

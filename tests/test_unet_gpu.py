@@ -597,3 +597,34 @@ def test_conv3x3_fp16x2_products_match_float64(N, H, W, C, Cout, res, gn, ups):
     # measured on MI355X: max-abs 6.8e-6 ... 1.9e-5 (fp32 direct kernel 7.5e-6 ... 1.5e-5), rel-L2 5.0e-7 ... 1.2e-6 (fp32 direct 4.2e-7 ... 6.3e-7)
     assert e2 < 6e-6 * max(1.0, scale) * (9 * C / 384) ** 0.5, (e2, scale)     # (the 1x1 test's bound at this reduction length)
     assert l2 < 1.6e-6 and l2 < 4 * l32 + 2e-7, (l2, l32)
+
+
+@pytest.mark.parametrize("N,H,W,C,Cout", [(1, 256, 256, 192, 192), (2, 128, 128, 96, 192), (4, 64, 64, 384, 384), (3, 96, 160, 64, 192)])
+def test_conv3x3_stride2_fp16x2_products_match_float64(N, H, W, C, Cout):
+    """The Downsample convolutions (3x3, stride 2, unet.py:100) of the DEFAULT mode from 32 workgroups' worth of output on run on k_conv_h2d: the input patch staged
+    de-interleaved by row / column parity, fp16x2 products, fp32 accumulation - against the float64 convolution of the fp32 operands and the fp32 direct kernel."""
+    import torch.nn.functional as F
+    from humanliff_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(N + C + Cout + H)
+    x = torch.randn((N, H, W, C), generator=g) * 1.5
+    w = torch.randn((Cout, C, 3, 3), generator=g) / (9 * C) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=2, padding=1).permute(0, 2, 3, 1)
+    xd, wd, bd = (t.to(dev) for t in (x, w, b))
+    scratch = torch.empty(Cout * C * 9 * 8 + 256 + (64 << 20), device=dev)
+    outs = {}
+    for mode in (_lib.HL_CONV_FP32, _lib.HL_CONV_FP32_DIRECT):
+        out = torch.zeros((N, H // 2, W // 2, Cout), device=dev)
+        _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(xd), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Cout, 3, 2, 0, None, None, 0, None, _lib.ptr(out), _lib.ptr(scratch),
+                                         scratch.numel() * 4, _lib.stream_ptr()), "hl_conv2d_nhwc_mode")
+        outs[mode] = out.cpu().double()
+    out, out32 = outs[_lib.HL_CONV_FP32], outs[_lib.HL_CONV_FP32_DIRECT]
+    scale = float(ref.abs().mean())
+    e2, e32 = float((out - ref).abs().max()), float((out32 - ref).abs().max())
+    l2, l32 = float((out - ref).norm() / ref.norm()), float((out32 - ref).norm() / ref.norm())
+    print(f"3x3 stride 2 {C}->{Cout} @{H // 2}x{W // 2} N{N}: fp16x2 max-abs {e2:.2e} rel-L2 {l2:.2e}; fp32 direct {e32:.2e} / {l32:.2e} (output mean-abs {scale:.2f})")
+    assert not torch.equal(out, out32)                      # the default mode really took another kernel
+    assert e2 < 6e-6 * max(1.0, scale) * (9 * C / 384) ** 0.5, (e2, scale)
+    assert l2 < 1.6e-6 and l2 < 4 * l32 + 2e-7, (l2, l32)
