@@ -124,6 +124,7 @@ SIGNATURES = {
     "hl_zero_stuff2_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "hl_groupnorm_coef": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "hl_attention_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "hl_attention_nhwc_mode": (_i, [_i, _p, _i, _i, _i, _i, _p, _p]),
     "hl_attention_backward_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "hl_attention_nhwc_backward": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "hl_timestep_embedding": (_i, [_p, _p, _i, _i, _p, _p]),

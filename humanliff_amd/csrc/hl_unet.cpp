@@ -629,7 +629,7 @@ struct Exec {
         View o = plain(H / x.H, a.C);
         if (run) {
             const size_t e0 = span_begin();
-            ok(hl::attention(qkv.p, B, x.H * x.W, a.C, a.heads, o.p, st));
+            ok(hl::attention(qkv.p, B, x.H * x.W, a.C, a.heads, o.p, st, n.conv_mode == HL_CONV_FP32));
             const double T = (double)x.H * x.W;
             span_end(CAT_ATTN, e0, 4.0 * B * T * T * a.C);
         }
@@ -651,7 +651,7 @@ struct Exec {
         conv(a.qkv, ln, qkv, 1, 0, none, 0, nullptr, 0);
         if (run) {
             const size_t e0 = span_begin();
-            ok(hl::attention(qkv.p, B, x.H * x.W, a.C, a.heads, o.p, st));
+            ok(hl::attention(qkv.p, B, x.H * x.W, a.C, a.heads, o.p, st, n.conv_mode == HL_CONV_FP32));
             const double T = (double)x.H * x.W;
             span_end(CAT_ATTN, e0, 4.0 * B * T * T * a.C);
         }
@@ -1185,6 +1185,10 @@ int hl_timestep_embedding(const int64_t *t, const float *t_float, int B, int dim
 
 int hl_attention_nhwc(const float *qkv, int N, int T, int C, int heads, float *out, void *stream) {
     return hl::attention(qkv, N, T, C, heads, out, (hipStream_t)stream);
+}
+
+int hl_attention_nhwc_mode(int conv_mode, const float *qkv, int N, int T, int C, int heads, float *out, void *stream) {
+    return hl::attention(qkv, N, T, C, heads, out, (hipStream_t)stream, conv_mode == HL_CONV_FP32);
 }
 
 size_t hl_attention_backward_scratch_bytes(int N, int T, int C, int heads) { return hl::attention_backward_scratch_bytes(N, T, C, heads); }

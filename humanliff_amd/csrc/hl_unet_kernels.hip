@@ -2307,7 +2307,26 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attention(const float *__restri
 // loop: K rows go straight from global memory into the MFMA A operand (lane = key, the two halves of the wave take
 // alternate groups of 4 channels; Q is loaded with the same permutation), V tiles are staged in a wave-private LDS
 // region, and with PF the next tile's K and V are in flight (registers) while the current one is multiplied.
-template <int CH, int KW, bool PF>
+// eight values (two f32x4, scaled by `sc`) -> the two fp16 planes of one 32x32x16 operand (h0 = the value with its low 13 mantissa bits cleared, h1 = the truncated residual)
+__device__ __forceinline__ void att_split8(const f32x4 a, const f32x4 b, float sc, u32x4 &p0, u32x4 &p1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x = (q < 2 ? a[2 * q] : b[2 * q - 4]) * sc, y = (q < 2 ? a[2 * q + 1] : b[2 * q - 3]) * sc;
+        const float hx = __builtin_bit_cast(float, __float_as_uint(x) & 0xffffe000u), hy = __builtin_bit_cast(float, __float_as_uint(y) & 0xffffe000u);
+        p0[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hx, hy));
+        p1[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy));
+    }
+}
+typedef _Float16 att_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 att_mma(const u32x4 a, const u32x4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(att_f16x8, a), __builtin_bit_cast(att_f16x8, b), c, 0, 0, 0);
+}
+
+// H2 (round 5, the default mode): both products - scores K Q^T and O^T += V^T P - from fp16x2 operands on v_mfma_f32_32x32x16_f16 (two fp16 planes per operand, three partial
+// products, fp32 accumulation; the convolutions' scheme): a k-step of the scores = two of the 8-channel groups (the lane half's 2 x 4 channels of K against the same channels
+// of Q, split once per query tile); a k-step of O^T = 8 of the lane half's 16 keys - the probabilities are the score accumulators split in place, V comes from the wave's LDS
+// tile as before (one dword per key and lane).  36 (CH = 96) / 72 (CH = 192) MFMAs of 32 cycles per key tile instead of 96 / 192 of 64.
+template <int CH, int KW, bool PF, bool H2>
 __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__restrict__ qkv, int T, int C, int heads,
                                                              float *__restrict__ out) {
     constexpr int CT = CH / 32, NG = CH / 8, WLDS = CH * 33 + 64;
@@ -2329,6 +2348,11 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
         qreg[m] = *reinterpret_cast<const f32x4 *>(base + (long)qj * pitch + 8 * m + 4 * half);
 #pragma unroll
         for (int i = 0; i < 4; ++i) qreg[m][i] *= scale;
+    }
+    u32x4 qp[H2 ? NG / 2 : 1][2];                        // (H2) Q as two fp16 planes per k-step: channels of groups 2j, 2j + 1
+    if constexpr (H2) {
+#pragma unroll
+        for (int j = 0; j < NG / 2; ++j) att_split8(qreg[2 * j], qreg[2 * j + 1], 1.f, qp[j][0], qp[j][1]);
     }
     auto loadK = [&](int k0, f32x4(&kr)[NG]) {
         const int kk = min(k0 + (lane & 31), T - 1);
@@ -2367,10 +2391,21 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        if constexpr (H2) {
 #pragma unroll
-        for (int m = 0; m < NG; ++m)
+            for (int j = 0; j < NG / 2; ++j) {
+                u32x4 k0p, k1p;
+                att_split8(kc[2 * j], kc[2 * j + 1], scale, k0p, k1p);
+                st = att_mma(k1p, qp[j][0], st);           // smallest partial product first
+                st = att_mma(k0p, qp[j][1], st);
+                st = att_mma(k0p, qp[j][0], st);
+            }
+        } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[m][i] * scale, qreg[m][i], st, 0, 0, 0);
+            for (int m = 0; m < NG; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[m][i] * scale, qreg[m][i], st, 0, 0, 0);
+        }
         // st[r] = score(key = (r&3)+8*(r>>2)+4*half, query = lane&31); mask keys beyond T
         float mx = -3.0e38f;
 #pragma unroll
@@ -2391,6 +2426,31 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
         psum += __shfl_xor(psum, 32);
         lrun = lrun * alpha + psum;
         mrun = mnew;
+        if constexpr (H2) {
+            u32x4 pp[2][2];                                  // the probabilities of this lane half's keys st[8 jj .. 8 jj + 7] as two planes
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                att_split8(f32x4{st[8 * jj], st[8 * jj + 1], st[8 * jj + 2], st[8 * jj + 3]}, f32x4{st[8 * jj + 4], st[8 * jj + 5], st[8 * jj + 6], st[8 * jj + 7]}, 1.f, pp[jj][0], pp[jj][1]);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    f32x4 va, vb;                            // V of this lane's channel at the same eight keys, in the same order
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        va[i] = sV[(i + 16 * jj + 4 * half) * CH + c * 32 + (lane & 31)];
+                        vb[i] = sV[(i + 8 + 16 * jj + 4 * half) * CH + c * 32 + (lane & 31)];
+                    }
+                    u32x4 v0p, v1p;
+                    att_split8(va, vb, 1.f, v0p, v1p);
+                    o[c] = att_mma(v1p, pp[jj][0], o[c]);
+                    o[c] = att_mma(v0p, pp[jj][1], o[c]);
+                    o[c] = att_mma(v0p, pp[jj][0], o[c]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
 #pragma unroll
@@ -2400,6 +2460,7 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
                 const int key = (s & 3) + 8 * (s >> 2) + 4 * half;  // the key this lane's st[s] belongs to
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[key * CH + c * 32 + (lane & 31)], st[s], o[c], 0, 0, 0);
             }
+        }
         }
         if constexpr (PF) {
 #pragma unroll
@@ -3262,8 +3323,10 @@ int timestep_embedding(const int64_t *t, const float *tf, int B, int dim, float 
     return check_launch("k_timestep_embedding");
 }
 
-int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipStream_t st) {
+int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipStream_t st, int h2) {
     HL_REQUIRE(qkv && out && heads > 0 && C % heads == 0, "attention: bad argument");
+    static const int att_h2 = [] { const char *e_ = getenv("HL_ATT_H2"); return e_ ? atoi(e_) : 1; }();   // developer knob (read once): 0 = the fp32-MFMA kernels in every mode
+    if (!att_h2) h2 = 0;
     const int ch = C / heads;
     // 32 queries per wave; pick waves per workgroup so the grid has at least ~256 workgroups (K/V tiles are
     // shared through LDS inside a workgroup, and are L2-resident across workgroups)
@@ -3278,13 +3341,19 @@ int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipS
         else hipLaunchKernelGGL((k_attention<CH_, 1>), grid, dim3(64), 0, st, qkv, T, C, heads, out);                \
     } while (0)
     // short sequences: split the keys over the 4 waves of a workgroup instead (one query tile per workgroup)
-    if ((long)qtiles * N * heads < 1024 && (ch == 96 || ch == 192) && (3L * C) % 4 == 0) {
+    // (with fp16x2 products the key-split kernel also takes the 1 024-token level of batches 8 ... 16: B = 8 49.4 -> 49.0 ms per forward)
+    static const long ks_max = [] { const char *e_ = getenv("HL_ATT_KS_MAX"); return e_ ? atol(e_) : 4097L; }();   // developer knob (read once)
+    if ((long)qtiles * N * heads < (h2 ? std::max(ks_max, 1024L) : 1024L) && (ch == 96 || ch == 192) && (3L * C) % 4 == 0) {
         dim3 gks(qtiles, N * heads);
-        if (ch == 96)
-            hipLaunchKernelGGL((k_attention_ks<96, 4, true>), gks, dim3(256), (size_t)4 * (96 * 33 + 64) * sizeof(float), st, qkv, T, C,
+        if (ch == 96 && h2)
+            hipLaunchKernelGGL((k_attention_ks<96, 4, true, true>), gks, dim3(256), (size_t)4 * (96 * 33 + 64) * sizeof(float), st, qkv, T, C, heads, out);
+        else if (ch == 96)
+            hipLaunchKernelGGL((k_attention_ks<96, 4, true, false>), gks, dim3(256), (size_t)4 * (96 * 33 + 64) * sizeof(float), st, qkv, T, C,
                                heads, out);
+        else if (h2)
+            hipLaunchKernelGGL((k_attention_ks<192, 4, false, true>), gks, dim3(256), (size_t)4 * (192 * 33 + 64) * sizeof(float), st, qkv, T, C, heads, out);
         else
-            hipLaunchKernelGGL((k_attention_ks<192, 4, false>), gks, dim3(256), (size_t)4 * (192 * 33 + 64) * sizeof(float), st, qkv, T,
+            hipLaunchKernelGGL((k_attention_ks<192, 4, false, false>), gks, dim3(256), (size_t)4 * (192 * 33 + 64) * sizeof(float), st, qkv, T,
                                C, heads, out);
         return check_launch("k_attention_ks");
     }

@@ -1,9 +1,8 @@
 #!/bin/bash
-# A/B (same box): threshold of the stride-2 fp16x2 kernel (HL_H2_CONV3S2_MIN_BLOCKS, workgroups' worth of 256 output pixels x 192 channels)
+# A/B (same box): upper bound (query tiles x batch x heads) of the key-split attention kernel with fp16x2 products
 cd /root/repo
-export HL_B=1,4,8
-for v in 32 8 16 64 -1 32; do
-  echo "== HL_H2_CONV3S2_MIN_BLOCKS=$v"
-  HL_H2_CONV3S2_MIN_BLOCKS=$v timeout 300 python scripts/fwd_time.py 2>&1 | grep "B="
+export HL_B=4,8,16
+for v in 1024 1025 2049 4097 1024 2049; do
+  echo "== HL_ATT_KS_MAX=$v"
+  HL_ATT_KS_MAX=$v timeout 300 python scripts/fwd_time.py 2>&1 | grep "B="
 done
-timeout 1500 python -m pytest tests/test_unet_gpu.py tests/test_fullsize_gpu.py tests/test_e2e_gpu.py tests/test_unet_train_gpu.py -m gpu -q -x 2>&1 | tail -3

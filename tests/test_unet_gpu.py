@@ -249,7 +249,10 @@ def test_groupnorm_affine_matches_torch(N, C, H, W, use_emb):
 
 @pytest.mark.parametrize("N,T,C,heads", [(2, 64, 128, 4), (1, 256, 384, 4), (2, 1024, 384, 4), (1, 64, 768, 4), (1, 100, 64, 4),
                                           (1, 100, 384, 4), (2, 200, 768, 4), (4, 1024, 384, 4), (16, 1024, 384, 4)])
-def test_attention_matches_torch(N, T, C, heads):
+@pytest.mark.parametrize("h2", [False, True])
+def test_attention_matches_torch(N, T, C, heads, h2):
+    """h2: the attention of the default conv mode (hl_attention_nhwc_mode(HL_CONV_FP32)): scores and probabilities x values from fp16x2 operands where the kernel has that
+    form (head sizes 96 / 192 on short sequences), same bound."""
     from humanliff_amd import _lib
     g = torch.Generator().manual_seed(T + C)
     qkv = torch.randn((N, 3 * C, T), generator=g)          # reference layout (b, 3C, T)
@@ -260,9 +263,14 @@ def test_attention_matches_torch(N, T, C, heads):
     want = torch.einsum("bts,bcs->bct", wgt, v).reshape(N, C, T)
     qd = qkv.permute(0, 2, 1).contiguous().to(dev)          # (N, T, 3C)
     out = torch.empty((N, T, C), device=dev)
-    _lib.check(_lib.lib().hl_attention_nhwc(_lib.ptr(qd), N, T, C, heads, _lib.ptr(out), _lib.stream_ptr()))
+    if h2:
+        _lib.check(_lib.lib().hl_attention_nhwc_mode(_lib.HL_CONV_FP32, _lib.ptr(qd), N, T, C, heads, _lib.ptr(out), _lib.stream_ptr()))
+    else:
+        _lib.check(_lib.lib().hl_attention_nhwc(_lib.ptr(qd), N, T, C, heads, _lib.ptr(out), _lib.stream_ptr()))
     torch.cuda.synchronize()
-    assert (out.cpu().permute(0, 2, 1) - want).abs().max() < 2e-5
+    err = float((out.cpu().permute(0, 2, 1) - want).abs().max())
+    print(f"attention N{N} T{T} C{C} h2={h2}: max-abs {err:.2e}")
+    assert err < 2e-5
 
 
 def test_timestep_embedding_matches_reference():
