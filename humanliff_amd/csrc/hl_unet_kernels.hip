@@ -3043,7 +3043,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         p.in16 = 0;
         // GroupNorm(+SiLU) of the input: applied by k_conv_h2s while it stages the patch (its two workgroups per CU hide the VALU) - no pass over the tensor
         static const int h3_fuse = [] { const char *e_ = getenv("HL_H2_FUSE_GN"); return e_ ? atoi(e_) : 1; }();   // developer knob (read once)
-        static const int h3_small_ = [] { const char *e_ = getenv("HL_H2_SMALL"); return e_ ? atoi(e_) : 1; }();
+        static const int h3_small_ = [] { const char *e_ = getenv("HL_H2_SMALL"); return e_ ? atoi(e_) : 1; }();      // 0: the 16x16-pixel kernel, one workgroup per CU
         const bool fuse = mode != 0 && h3_fuse && h3_small_ && !a.ups && a.in.C <= 4096;
         if (mode != 0 && !fuse) {   // GroupNorm(+SiLU) materialised once, as the two-plane image the kernel stages without conversion (the same bytes as fp32)
             HL_REQUIRE((size_t)a.in.pixels() * a.in.C * sizeof(float) <= a.act_ws_bytes, "conv2d: act scratch too small");
@@ -3081,8 +3081,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             if (rc) return rc;
             return finish("k_conv_h2s");
         }
-        static const int h3_small = [] { const char *e_ = getenv("HL_H2_SMALL"); return e_ ? atoi(e_) : 1; }();   // developer knob (read once): 8x16-pixel tiles, two workgroups per CU
-        if (h3_small) {
+        if (h3_small_) {   // 8x16-pixel tiles, two workgroups per CU
             p.n_mtiles *= 2;
             return conv3_h2s_launch(p, st);
         }
@@ -3115,8 +3114,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             p.st1 = a.stats; p.st2 = a.out2 ? a.stats2 : nullptr;
             a.stat_slots = 1;
         }
-        static const int h2_small = [] { const char *e_ = getenv("HL_H2_SMALL1"); return e_ ? atoi(e_) : 1; }();   // developer knob (read once): 128-pixel tiles, two workgroups per CU
-        if (h2_small) {
+        if (h2_small_) {   // 128-pixel tiles, two workgroups per CU
             p.n_mtiles *= 2;
             return conv1_h2s_launch(p, st);
         }
