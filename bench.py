@@ -976,21 +976,21 @@ def bench_fit(args, rank, world, dev, iters=30):
         assert torch.isfinite(loss.detach()).all()
         return s
 
-    secs = timed()                       # reference-faithful: sample_pdf's uniforms drawn on the CPU generator and uploaded
-    r.uniforms_on_device = True          # extension: drawn on the device
-    secs_dev = timed()
-    r.subject_streams = True             # extension: the second subject on its own HIP stream, forward and backward
+    secs = timed()                       # the defaults: sample_pdf's uniforms = the CPU generator's stream continued on the device, subjects on their own streams
+    r.subject_streams = False            # one stream for all subjects (rounds 1-4's default)
+    secs_one_stream = timed()
+    r.subject_streams = True
+    r.uniforms_on_device = True          # extension: the device generator's own uniforms (another random stream)
     secs_dev_streams = timed()
-    r.uniforms_on_device = r.subject_streams = False
+    r.uniforms_on_device = False
     pts = bs * R * 2 * N
     stages = fit_stage_times(r, tri[0, 0].detach(), tp["world_bounds"][0].contiguous(), ro, rd, nr, fr, N, dev)
     return {"stages_ms_per_subject": stages["ms"], "roofline": stages["roofline"], "metric": "fitting-iterations/sec", "value": round(world * iters / secs, 2), "unit": "it/s", "ms_per_iteration": round(secs * 1e3 / iters, 3),
             "sample_points_per_sec": round(world * iters * pts / secs), "iterations": iters,
-            "uniforms_on_device": {"value": round(world * iters / secs_dev, 2), "unit": "it/s", "ms_per_iteration": round(secs_dev * 1e3 / iters, 3),
-                                   "what": "Renderer.uniforms_on_device = True: sample_pdf's uniforms from the device generator instead of "
-                                           "CPU draw + 2 MB upload per step (same distribution; NOT used for `value`)",
-                                   "with_subject_streams": {"value": round(world * iters / secs_dev_streams, 2), "unit": "it/s",
-                                                            "what": "+ Renderer.subject_streams = True (NOT used for `value`)"}},
+            "one_stream": {"value": round(world * iters / secs_one_stream, 2), "unit": "it/s", "ms_per_iteration": round(secs_one_stream * 1e3 / iters, 3),
+                           "what": "Renderer.subject_streams = False: every subject on the caller's stream (rounds 1-4's default; same bits)"},
+            "uniforms_on_device": {"value": round(world * iters / secs_dev_streams, 2), "unit": "it/s", "ms_per_iteration": round(secs_dev_streams * 1e3 / iters, 3),
+                                   "what": "Renderer.uniforms_on_device = True: sample_pdf's uniforms from the device generator's own stream (same distribution, other numbers; NOT used for `value`)"},
             "config": {"workload": "recon_NeRF SynBody training step: 2 subjects x 2048 rays x (128+128) samples, 256x256x27 tri-planes, "
                                    "forward + HIP backward + Adam", "sample_points_per_iteration": pts}}
 

@@ -71,9 +71,10 @@ class Renderer(nn.Module):
         self.uniforms_on_device = False      # extension: draw sample_pdf's uniforms with the device generator (see render())
         self.cpu_uniforms_on_host = False    # True: draw the reference's CPU-generator uniforms on the host and upload them (renderer.py:545 literally);
                                              # default: the SAME numbers continued on the device from the CPU generator's state (NeRF/cpu_rng.py)
-        self.subject_streams = False         # extension, opt-in: training mode puts subjects after the first on their own HIP streams (see
-                                             # _render_training; +4 % on the fitting step with device uniforms, and PyTorch warns once that the
-                                             # parameters' AccumulateGrad nodes sit on another stream than the gradients)
+        self.subject_streams = True          # training mode puts subjects after the first on their own HIP streams (see _render_training): one subject's HBM-bound
+                                             # kernels overlap the other's matrix-bound ones, +9 % on the fitting step.  Since round 5 the backward has no float
+                                             # atomics, so images and gradients are the same BITS with the switch on or off (tests/test_render_train_gpu.py); PyTorch warns
+                                             # once that the parameters' AccumulateGrad nodes sit on another stream than the incoming gradients.  False: one stream.
         self.mlp_fp16 = False                # extension, opt-in: the MLP with fp16 operands / fp32 accumulation (HL_RENDER_MLP_FP16, k_march16) in
                                              # render() without canonical space; canonical-space rendering, density_grid() and training stay fp32
         self.mlp_products = "fp16x2"         # how render() forms the fp32 products of the MLP in the evaluate-once pipeline (test mode, world space):

@@ -1379,8 +1379,11 @@ __device__ __forceinline__ void mma_pl(f32x16 (&acc)[NT], const u32x4 (&b)[NPL],
 #define HL_H2_K 4   // VALU instructions asked for behind every MFMA of a hidden-layer chunk in the fp16x2 kernel (12 MFMAs, ~48 VALU of preparation with the
                     // log2-domain softplus; same box, ms per 512x512 view: 3: 25.56, 4: 25.74, 5: 25.81 - 26.00, 6: 26.35; natural-log softplus at 5: 26.71)
 #endif
-template <int NPL>
-__global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const unsigned short *__restrict__ packed_b3) {
+// ACTS (training; round 5): the evaluate pass of the fitting step on this kernel - every activation of the MLP is also written to the
+// activation matrix (row = unit, column = sample point; the rows k_mlp_bwd and k_wgrad read), a workgroup takes the sample range blockIdx.y * s_per ... of its 256 rays
+// (a fitting batch has few rays), one workgroup per CU (the stores need registers).  Softplus outputs are stored in natural units (x ln 2 in the log2 domain).
+template <int NPL, bool ACTS = false>
+__global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs a, const unsigned short *__restrict__ packed_b3) {
     constexpr int B3R_SLOT_U4 = PLW_SLOT_U4<NPL>, B3_CH_U4 = PLW_CH_U4<NPL>;      // (shadow the bf16x3 constants of k_march_b3)
     constexpr size_t B3_BYTES = PLW_BYTES<NPL>;
     constexpr int NMF = NPL == 3 ? 24 : 12;                                        // MFMAs of a chunk (4 tiles x 6 | 3 products)
@@ -1457,6 +1460,18 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
         }
         split_plt(ev, 0, bev0);
         split_plt(ev, 1, bev1);
+        if constexpr (ACTS) {   // the encoding is a row block of the activation matrix, the same for every sample of the ray: written here for the whole sample range
+            const int s_lo_ = (int)blockIdx.y * a.s_per, s_hi_ = min(a.S, s_lo_ + a.s_per);
+            const unsigned as4 = (unsigned)a.act_stride * 4u;
+            const i32x4 rs_ = matrix_rsrc(a.act, (unsigned)ACT_ROWS * as4);
+            if (tile * 32 < a.R)
+                for (int s = s_lo_; s < s_hi_; ++s) {
+                    const unsigned col4 = (unsigned)(a.act_off + zt_base + 32LL * s) * 4u;
+#pragma unroll
+                    for (int j = 0; j < 14; ++j)
+                        if (j + 14 * half < 27) hidden_store(rs_, col4 + (unsigned)half * 14u * as4, (unsigned)(ROW_EV + j) * as4, ev[j]);
+                }
+        }
     // views_linear's direction part does not depend on the sample: bias + W_dir enc(dir) is formed once per ray (chunk 32, fragments straight
     // from global memory) and parked in LDS as the accumulator image every sample starts views_linear from
         f32x16 V0[2];
@@ -1475,9 +1490,16 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
             for (int q = 0; q < 4; ++q) vinit[(t * 4 + q) * 64 + lane] = f32x4{V0[t][4 * q], V0[t][4 * q + 1], V0[t][4 * q + 2], V0[t][4 * q + 3]};
     }
 
+    int s_lo = 0, s_hi = S;
+    if constexpr (ACTS) {
+        s_lo = (int)blockIdx.y * a.s_per;
+        s_hi = min(S, s_lo + a.s_per);
+    }
+    const unsigned act_stride4 = ACTS ? (unsigned)a.act_stride * 4u : 0u;
+    const i32x4 act_rs = matrix_rsrc(a.act, ACTS ? (unsigned)ACT_ROWS * act_stride4 : 0u);
     float zc;
-    if (a.z) zc = a.z_tiled ? a.z[zt_base] : a.z[rc * S];
-    else zc = nr * (1.f - linspace01(0, S)) + fr_ * linspace01(0, S);
+    if (a.z) zc = a.z_tiled ? a.z[zt_base + 32LL * s_lo] : a.z[rc * S + s_lo];
+    else zc = nr * (1.f - linspace01(s_lo, S)) + fr_ * linspace01(s_lo, S);
     __syncthreads();
 
     // Ring of two 24 KB slots, each a PAIR of chunks (8 fragment positions x 3 planes).  While pair P is multiplied: slot `cur` holds P, the other
@@ -1511,7 +1533,7 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
 
     auto body = [&](auto rotc) {
     constexpr bool ROT = decltype(rotc)::value;
-    for (int s = 0; s < S; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
         float zn = 0.f;
         if (s + 1 < S) {
             if (a.z) zn = a.z_tiled ? a.z[zt_base + 32LL * (s + 1)] : a.z[rc * S + s + 1];
@@ -1559,6 +1581,29 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
             f[3 * i + 1] = live ? r1 : 0.f;
             f[3 * i + 2] = live ? r2 : 0.f;
         }
+        const bool act_on = ACTS && tile * 32 < a.R;
+        unsigned acol = 0;       // byte offset of this sample point's column (+ this half's 4 rows) in the activation matrix
+        auto act_rows = [&](int row0, auto &h, float sc) {          // rows row0 + unit_of(t, r, half) of this column (sc: log2 units -> natural)
+            if constexpr (ACTS) {
+                if (act_on) {
+                    constexpr int NT_ = sizeof(h) / sizeof(h[0]);
+#pragma unroll
+                    for (int t = 0; t < NT_; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) hidden_store(act_rs, acol, (unsigned)(row0 + unit_of(t, r, 0)) * act_stride4, h[t][r] * sc);
+                }
+            }
+        };
+        if constexpr (ACTS) {
+            const unsigned col4 = (unsigned)(a.act_off + zt_base + 32LL * s) * 4u;
+            acol = col4 + (unsigned)half * 4u * act_stride4;
+            if (act_on) {
+#pragma unroll
+                for (int j = 0; j < 15; ++j)
+                    if (j + 15 * half < 27) hidden_store(act_rs, col4 + (unsigned)half * 15u * act_stride4, (unsigned)(ROW_F + j) * act_stride4, f[j]);
+            }
+        }
+        constexpr float SPU = LOG2D ? LN2 : 1.f;                    // softplus outputs of this kernel -> natural units
         u32x4 bf0[NPL], bf1[NPL], ba[NPL], bb[NPL];
         split_plt(f, 0, bf0);
         split_plt(f, 1, bf1);
@@ -1579,6 +1624,7 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
             B3_ADV(3 + 2 * k)
             B3_MV24(5, mma_pl(Y, bb, B3_AT(3 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3]); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
+        act_rows(ROW_X0, X, SPU);
         load_bias<4>(X, small + SM_B2, half);
         B3_ADV(10) mma_pl(X, bf0, B3_AT(10), 0, lane);                          // L2 (features): chunks 10, 11; the first hidden operand rides along
         B3_ADV(11)
@@ -1590,6 +1636,7 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
             B3_ADV(13 + 2 * k)
             B3_MV24(5, mma_pl(X, bb, B3_AT(13 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, Y[k + 1 < 4 ? k + 1 : 3]); split_plt(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
+        act_rows(ROW_X1, Y, SPU);
         load_bias<4>(Y, small + SM_BF, half);
         SP_R(0, 8, X[0]);                                                  // (the second half: behind the first chunk of the layer)
         split_plt(X[0], 0, ba);
@@ -1600,6 +1647,8 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
             B3_ADV(21 + 2 * k)
             B3_MV24(5, mma_pl(Y, bb, B3_AT(21 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3]); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
+        act_rows(ROW_X2, X, SPU);
+        act_rows(ROW_Y, Y, 1.f);
         const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];   // X holds softplus(pts_linears.2) by now
         f32x16 V[2];
 #pragma unroll
@@ -1618,6 +1667,7 @@ __global__ __launch_bounds__(512, 2) void k_march_plw(const MarchArgs a, const u
         }
         if constexpr (LOG2D) { softplus_l2_r<0, 16>(V[0]); softplus_l2_r<0, 16>(V[1]); }
         else { V[0] = softplus16_b3(V[0]); V[1] = softplus16_b3(V[1]); }
+        act_rows(ROW_V, V, SPU);
         const float cr = dot_lane<2>(V, small + SM_RW, half) + small[SM_RB + 0];
         const float cg = dot_lane<2>(V, small + SM_RW + 64, half) + small[SM_RB + 1];
         const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
@@ -3597,8 +3647,18 @@ int hl_render_eval_acts(const void *mlp_packed, const void *planes_packed, int H
     const unsigned groups = (unsigned)((n_rays + 255) / 256);
     const unsigned splits = sample_splits(groups, n_samples);
     a.s_per = (n_samples + (int)splits - 1) / (int)splits;
-    hipLaunchKernelGGL((k_march<true, true, 8, false, true>), dim3(groups, (unsigned)((n_samples + a.s_per - 1) / a.s_per)), dim3(512), 0,
-                       (hipStream_t)stream, a);
+    // round 5: the evaluate pass of the fitting step on the fp16x2 kernel (k_march_plw<2, ACTS>: the inference default's arithmetic; the backward reads the
+    // activations it writes).  HL_FIT_FP32=1 (developer knob, read once): the fp32-MFMA kernel of rounds 1-4.
+    static const int fit_fp32 = [] { const char *e_ = getenv("HL_FIT_FP32"); return e_ ? atoi(e_) : 0; }();
+    const dim3 grid(groups, (unsigned)((n_samples + a.s_per - 1) / a.s_per));
+    if (!fit_fp32) {
+        const unsigned short *ph2 = reinterpret_cast<const unsigned short *>(static_cast<const char *>(mlp_packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024 + B3_BYTES);
+        static const bool okh = hipFuncSetAttribute((const void *)k_march_plw<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLW_LDS<2>) == hipSuccess;
+        HL_REQUIRE(okh, "k_march_plw<2, acts>: cannot raise the dynamic LDS limit to %zu bytes", PLW_LDS<2>);
+        hipLaunchKernelGGL((k_march_plw<2, true>), grid, dim3(512), PLW_LDS<2>, (hipStream_t)stream, a, ph2);
+        return hl::check_launch("k_march_plw<2, acts>");
+    }
+    hipLaunchKernelGGL((k_march<true, true, 8, false, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_march<eval, acts>");
 }
 
@@ -3719,8 +3779,9 @@ int hl_render_plane_grads_points(int H, int W, const float *bounds, const float 
     return hl::check_launch("k_plane_scatter_pts");
 }
 
-static int64_t wgrad_points_per_range(int64_t n_cols) {   // 256 point ranges of at least 1024 points
-    int64_t per = ((n_cols + 255) / 256 + 31) / 32 * 32;
+static int64_t wgrad_points_per_range(int64_t n_cols) {   // 256 point ranges (HL_WGRAD_RANGES: developer knob, read once) of at least 1024 points
+    static const int64_t nr = [] { const char *e_ = getenv("HL_WGRAD_RANGES"); return e_ ? (int64_t)atol(e_) : (int64_t)256; }();
+    int64_t per = ((n_cols + nr - 1) / nr + 31) / 32 * 32;
     return per < 1024 ? 1024 : per;
 }
 static void wgrad_jobs(WgradArgs &a, const hl_render_mlp_grads *g) {

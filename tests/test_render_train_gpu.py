@@ -186,7 +186,7 @@ def test_fitting_loop_two_subjects(dev, fused):
 
 
 def test_subject_streams_change_nothing(dev):
-    """Renderer.subject_streams (opt-in) puts subjects after the first on their own HIP streams (forward and, through autograd's stream
+    """Renderer.subject_streams (on by default since round 5) puts subjects after the first on their own HIP streams (forward and, through autograd's stream
     rule, backward): three subjects with the switch on and off must give the same images and the same gradients, bit for bit (the backward has no
     floating-point atomics), repeated so that the allocator reuses blocks across streams."""
     from humanliff_amd import synthetic as syn
@@ -226,7 +226,7 @@ def test_subject_streams_change_nothing(dev):
         assert torch.equal(got[2], ref[2])
         for a, b in zip(got[3], ref[3]):
             assert torch.equal(a, b)
-    r.subject_streams = False
+    r.subject_streams = True
 
 
 def test_recon_twin_training_step(dev):
