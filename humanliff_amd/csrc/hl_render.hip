@@ -2690,11 +2690,79 @@ __global__ void k_pack_mlp_bwd(PackArgs a) {
     a.out[idx] = v;
 }
 
+// The same transposed weights as two fp16 planes (nearest even at both levels) for k_mlp_bwd<., true>: the u32x4 at [(t * ns4 + s4) * 64 + lane] of a chunk holds, for s4 even,
+// plane 0 of the eight contraction steps 4 s4 .. 4 s4 + 7 of this lane half, for s4 odd plane 1 of the steps 4 (s4 - 1) .. - the byte count and the ring of the fp32 image.
+__global__ void k_pack_mlp_bwd_h2(PackArgs a, unsigned short *out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NCH_BWD * CHUNK_FLOATS * 2) return;
+    const int c = idx / (CHUNK_FLOATS * 2), e = idx % (CHUNK_FLOATS * 2);
+    const ChunkDesc d = c_chunks_bwd[c];
+    const int ns4 = d.nsteps / 4;
+    const int q = e & 7, lane = (e >> 3) & 63, rest = e >> 9;
+    const int s4 = rest % ns4, t = rest / ns4;
+    float v = 0.f;
+    if (t < d.nt) {
+        const int sp = d.base + (s4 >> 1) * 8 + q, half = lane >> 5, o = 32 * t + (lane & 31);
+        const int u = unit_of(sp >> 4, sp & 15, half);
+        if (d.kind == 3 || o < 27) v = a.w[d.w][u * d.ld + d.col0 + o];
+    }
+    _Float16 h = (_Float16)v;
+    if (s4 & 1) h = (_Float16)(v - (float)h);
+    out[idx] = __builtin_bit_cast(unsigned short, h);
+}
+
+// fp16x2 form of mma16 (k_mlp_bwd<., true>): bp[jj][plane] = the B tile's registers 8 jj .. 8 jj + 7 of this lane half as two fp16 planes (scaled by the caller);
+// the weights' planes from the LDS chunk (k_pack_mlp_bwd_h2); three partial products per k-step, smallest first
+typedef _Float16 bwd_h8 __attribute__((ext_vector_type(8)));
+template <int NT, int NS4>
+__device__ __forceinline__ void mma16_h2(f32x16 (&acc)[NT], const u32x4 (&bp)[2][2], const f32x4 *__restrict__ ldsA, int s4base, int lane) {
+    const u32x4 *A = reinterpret_cast<const u32x4 *>(ldsA);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        u32x4 a0[NT], a1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { a0[t] = A[(t * NS4 + s4base + 2 * jj) * 64 + lane]; a1[t] = A[(t * NS4 + s4base + 2 * jj + 1) * 64 + lane]; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bwd_h8, a1[t]), __builtin_bit_cast(bwd_h8, bp[jj][0]), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bwd_h8, a0[t]), __builtin_bit_cast(bwd_h8, bp[jj][1]), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bwd_h8, a0[t]), __builtin_bit_cast(bwd_h8, bp[jj][0]), acc[t], 0, 0, 0);
+        }
+    }
+}
+// power-of-two scale that brings the largest |value| of a column's delta tiles to [2^13, 2^14) (deltas are far below fp16's normal range), and its inverse
+template <int NT>
+__device__ __forceinline__ void bwd_scale(const f32x16 (&v)[NT], int ntiles, float &sc, float &inv) {
+    unsigned m = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t < ntiles) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = max(m, __builtin_bit_cast(unsigned, v[t][r]) & 0x7fffffffu);
+        }
+    m = max(m, (unsigned)__shfl_xor((int)m, 32));          // (both lane halves of a column: one scale per ray and sample)
+    const int eb = (int)(m >> 23);
+    const bool ok = eb >= 40 && eb <= 240;                     // (zero / denormal / not finite: no scaling)
+    sc = ok ? __builtin_bit_cast(float, (unsigned)(267 - eb) << 23) : 1.f;
+    inv = ok ? __builtin_bit_cast(float, (unsigned)(eb - 13) << 23) : 1.f;
+}
+__device__ __forceinline__ void bwd_split(const f32x16 &v, float sc, u32x4 (&bp)[2][2]) {
+    f32x16 w;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = v[r] * sc;
+    u32x4 p[2];
+    split_h2t(w, 0, p); bp[0][0] = p[0]; bp[0][1] = p[1];
+    split_h2t(w, 1, p); bp[1][0] = p[0]; bp[1][1] = p[1];
+}
+
 // One wave owns 32 rays as in k_march; per sample point: deltas of views_linear, feature_linear, pts_linears.2/1/0 by MFMA against
 // the transposed weights (ring of 16 chunks), each multiplied by softplus'(pre) = 1 - exp(-activation) read back from the
 // activation matrix, stored for the weight gradients; the two 27-wide feature deltas (skip connection + first layer) are summed
 // in one accumulator tile and scattered to the tri-plane gradient through the four bilinear taps of each feature.
-template <int NWV>
+// H2 (round 5): the five transposed-weight products with fp16x2 operands on v_mfma_f32_32x32x16_f16 (weights: k_pack_mlp_bwd_h2's planes behind the fp32 image; the delta
+// tiles split in registers, scaled per ray and sample by a power of two so that their largest entry sits in [2^13, 2^14) - deltas are far below fp16's normal range - and the
+// products scaled back exactly): 384 MFMAs of 32 cycles per sample and wave instead of 1 024 of 64.
+template <int NWV, bool H2 = false>
 __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 #if __HIP_DEVICE_COMPILE__
     constexpr int NT = NWV * 64, NST = 1024 / NT;
@@ -2710,11 +2778,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
     f32x4 *ldsv = reinterpret_cast<f32x4 *>(lds);
     const float *small = lds + 2 * CHUNK_FLOATS;
     const f32x4 *gsmall = reinterpret_cast<const f32x4 *>(a.packed) + NCH_FULL * CHUNK_FLOATS / 4;
-    const f32x4 *gw = reinterpret_cast<const f32x4 *>(a.bwd_packed);
+    const f32x4 *gw = reinterpret_cast<const f32x4 *>(a.bwd_packed) + (H2 ? NCH_BWD * CHUNK_FLOATS / 4 : 0);
     for (int i = tid; i < SMALL_FLOATS / 4; i += NT) ldsv[2 * CHUNK_FLOATS / 4 + i] = gsmall[i];
 #pragma unroll
     for (int q = 0; q < 2 * NST; ++q) ldsv[q * NT + tid] = gw[q * NT + tid];
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)a.bwd_packed, (short)0, NCH_BWD * CHUNK_FLOATS * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)gw, (short)0, NCH_BWD * CHUNK_FLOATS * 4, 0x00020000);
     const int wv = tid * 16;
     auto ldw = [&](int f4_index) -> f32x4 {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wv, f4_index * 16, 0));
@@ -2790,24 +2858,47 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) D[t][r] = 0.f;
-        mma16<4, 4, 16>(D, G[0], ldsv + cur, 0, lane);
-        HL_BWD_ADVANCE(1)
-        mma16<4, 4, 16>(D, G[1], ldsv + cur, 0, lane);
+        float sc = 1.f, inv = 1.f;
+        u32x4 bp[2][2];
+        if constexpr (H2) {
+            bwd_scale<4>(G, 2, sc, inv);
+            bwd_split(G[0], sc, bp);
+            mma16_h2<4, 4>(D, bp, ldsv + cur, 0, lane);
+            HL_BWD_ADVANCE(1)
+            bwd_split(G[1], sc, bp);
+            mma16_h2<4, 4>(D, bp, ldsv + cur, 0, lane);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) D[t][r] *= inv;
+        } else {
+            mma16<4, 4, 16>(D, G[0], ldsv + cur, 0, lane);
+            HL_BWD_ADVANCE(1)
+            mma16<4, 4, 16>(D, G[1], ldsv + cur, 0, lane);
+        }
         if (tile_on) store_rows<4>(del_rs, delp, del_stride4, DROW_Y, D);
         // ---- feature_linear^T + alpha_linear^T, softplus' of pts_linears.2 ----
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) G[t][r] = small[SM_AW + (t * 2 + half) * 16 + r] * d.x;
+        if constexpr (H2) {
+            bwd_scale<4>(D, 4, sc, inv);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) G[t][r] *= sc;          // (the alpha head's term rides in the scaled accumulator: a power of two, exact)
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             HL_BWD_ADVANCE(2 + k)
-            mma16<4, 4, 16>(G, D[k], ldsv + cur, 0, lane);
+            if constexpr (H2) { bwd_split(D[k], sc, bp); mma16_h2<4, 4>(G, bp, ldsv + cur, 0, lane); }
+            else mma16<4, 4, 16>(G, D[k], ldsv + cur, 0, lane);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) G[t][r] *= dsp(ACT[t][r]);
+            for (int r = 0; r < 16; ++r) G[t][r] *= dsp(ACT[t][r]) * (H2 ? inv : 1.f);
         fetch_act(ACT, actp, ROW_X1, 4);
         if (tile_on) store_rows<4>(del_rs, delp, del_stride4, DROW_X2, G);
         // ---- pts_linears.2^T: tri-plane feature columns -> DF, hidden columns -> delta of pts_linears.1 ----
@@ -2815,8 +2906,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) DF[0][r] = 0.f;
         HL_BWD_ADVANCE(6)
+        if constexpr (H2) bwd_scale<4>(G, 4, sc, inv);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) mma16<1, 16, 16>(DF, G[k], ldsv + cur, 4 * k, lane);
+        for (int k = 0; k < 4; ++k) {
+            if constexpr (H2) { bwd_split(G[k], sc, bp); mma16_h2<1, 16>(DF, bp, ldsv + cur, 4 * k, lane); }
+            else mma16<1, 16, 16>(DF, G[k], ldsv + cur, 4 * k, lane);
+        }
+        if constexpr (H2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) DF[0][r] *= inv;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -2824,12 +2923,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             HL_BWD_ADVANCE(7 + k)
-            mma16<4, 4, 16>(D, G[k], ldsv + cur, 0, lane);
+            if constexpr (H2) { bwd_split(G[k], sc, bp); mma16_h2<4, 4>(D, bp, ldsv + cur, 0, lane); }
+            else mma16<4, 4, 16>(D, G[k], ldsv + cur, 0, lane);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) D[t][r] *= dsp(ACT[t][r]);
+            for (int r = 0; r < 16; ++r) D[t][r] *= dsp(ACT[t][r]) * (H2 ? inv : 1.f);
         fetch_act(ACT, actp, ROW_X0, 4);
         if (tile_on) store_rows<4>(del_rs, delp, del_stride4, DROW_X1, D);
         // ---- pts_linears.1^T, softplus' of pts_linears.0 ----
@@ -2837,20 +2937,34 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
+        if constexpr (H2) bwd_scale<4>(D, 4, sc, inv);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             HL_BWD_ADVANCE(11 + k)
-            mma16<4, 4, 16>(G, D[k], ldsv + cur, 0, lane);
+            if constexpr (H2) { bwd_split(D[k], sc, bp); mma16_h2<4, 4>(G, bp, ldsv + cur, 0, lane); }
+            else mma16<4, 4, 16>(G, D[k], ldsv + cur, 0, lane);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) G[t][r] *= dsp(ACT[t][r]);
+            for (int r = 0; r < 16; ++r) G[t][r] *= dsp(ACT[t][r]) * (H2 ? inv : 1.f);
         if (tile_on) store_rows<4>(del_rs, delp, del_stride4, DROW_X0, G);
         // ---- pts_linears.0^T -> DF ----
         HL_BWD_ADVANCE(15)
+        if constexpr (H2) {
+            bwd_scale<4>(G, 4, sc, inv);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) mma16<1, 16, 16>(DF, G[k], ldsv + cur, 4 * k, lane);
+            for (int r = 0; r < 16; ++r) DF[0][r] *= sc;              // (the skip connection's part, already there: scaled along, exact)
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if constexpr (H2) { bwd_split(G[k], sc, bp); mma16_h2<1, 16>(DF, bp, ldsv + cur, 4 * k, lane); }
+            else mma16<1, 16, 16>(DF, G[k], ldsv + cur, 4 * k, lane);
+        }
+        if constexpr (H2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) DF[0][r] *= inv;
+        }
         HL_BWD_ADVANCE(0)   // chunk 0 of the next sample
 
         // ---- d/d(tri-plane features) -> rows DROW_DF.. (k_plane_scatter sends them through the bilinear taps) ----
@@ -3615,7 +3729,7 @@ static inline unsigned sample_splits(unsigned ray_groups, int n_samples) {
     if (s > (unsigned)n_samples) s = (unsigned)n_samples;
     return s < 1 ? 1 : s;
 }
-size_t hl_render_mlp_bwd_packed_bytes(void) { return (size_t)NCH_BWD * CHUNK_FLOATS * sizeof(float); }
+size_t hl_render_mlp_bwd_packed_bytes(void) { return (size_t)2 * NCH_BWD * CHUNK_FLOATS * sizeof(float); }   // the fp32 image, then the two fp16 planes (k_pack_mlp_bwd_h2)
 
 int hl_render_mlp_pack_bwd(const hl_render_mlp_params *p, void *packed, void *stream) {
     HL_REQUIRE(p && packed, "hl_render_mlp_pack_bwd: null argument");
@@ -3624,7 +3738,11 @@ int hl_render_mlp_pack_bwd(const hl_render_mlp_params *p, void *packed, void *st
     for (int i = 0; i < 5; ++i) HL_REQUIRE(a.w[i], "hl_render_mlp_pack_bwd: null weight %d", i);
     a.out = (float *)packed;
     hipLaunchKernelGGL(k_pack_mlp_bwd, dim3((NCH_BWD * CHUNK_FLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
-    return hl::check_launch("k_pack_mlp_bwd");
+    int rc_ = hl::check_launch("k_pack_mlp_bwd");
+    if (rc_) return rc_;
+    hipLaunchKernelGGL(k_pack_mlp_bwd_h2, dim3((NCH_BWD * CHUNK_FLOATS * 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a,
+                       reinterpret_cast<unsigned short *>(static_cast<float *>(packed) + NCH_BWD * CHUNK_FLOATS));
+    return hl::check_launch("k_pack_mlp_bwd_h2");
 }
 
 void hl_render_train_rows(int *act_rows, int *del_rows) {
@@ -3713,7 +3831,9 @@ int hl_render_mlp_backward(const void *mlp_packed, const void *mlp_bwd_packed, i
     const unsigned groups = (unsigned)((n_rays + 255) / 256);
     const unsigned splits = sample_splits(groups, n_samples);
     a.s_per = (n_samples + (int)splits - 1) / (int)splits;
-    hipLaunchKernelGGL(k_mlp_bwd<8>, dim3(groups, (unsigned)((n_samples + a.s_per - 1) / a.s_per)), dim3(512), 0, (hipStream_t)stream, a);
+    static const int fit_fp32 = [] { const char *e_ = getenv("HL_FIT_FP32"); return e_ ? atoi(e_) : 0; }();   // developer knob (read once): the fp32-MFMA kernel of rounds 1-4
+    if (!fit_fp32) hipLaunchKernelGGL((k_mlp_bwd<8, true>), dim3(groups, (unsigned)((n_samples + a.s_per - 1) / a.s_per)), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_mlp_bwd<8, false>), dim3(groups, (unsigned)((n_samples + a.s_per - 1) / a.s_per)), dim3(512), 0, (hipStream_t)stream, a);
     return hl::check_launch("k_mlp_bwd");
 }
 

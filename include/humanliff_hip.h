@@ -167,7 +167,9 @@ int hl_render_fine(const void *mlp_packed, const void *planes_packed, int H, int
  *   hl_render_composite_backward  g_rgb (R,3), g_acc (R) -> d_records of both passes (float[4] = d/d(sigma, r, g, b) raw, record
  *                                 layout; zero on padding rays) and rows 576..579 of the delta matrix `del` (columns: coarse pass,
  *                                 then the new depths); scratch: hl_render_composite_backward_scratch_bytes()
- *   hl_render_mlp_backward        one pass's d_records + activations -> its columns of the delta matrix
+ *   hl_render_mlp_backward        one pass's d_records + activations -> its columns of the delta matrix; round 5: the five transposed-weight products with fp16x2
+ *                                 operands (weights as two fp16 planes behind the fp32 image of hl_render_mlp_pack_bwd; delta tiles split in registers, scaled per ray
+ *                                 and sample by a power of two into fp16's range and scaled back exactly): 0.39 -> 0.27 ms per pass; gradient bounds unchanged
  *   hl_render_plane_grads         feature deltas of both passes -> d_planes (27,H,W), overwritten: the transposed bilinear lookup;
  *                                 each workgroup owns a tile of texels and accumulates in LDS (no global atomics) in 64-bit FIXED
  *                                 POINT whose unit comes from the largest |delta| of the call: integer additions commute, so the

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B (same box) of the fitting step: environment knobs given as arguments "NAME=value ..." one configuration per line on stdin
+# A/B (same box) of the fitting step: one configuration of environment knobs ("NAME=value ...") per line on stdin, e.g. HL_FIT_FP32=1 (the fp32-MFMA kernels of rounds 1-4)
 cd /root/repo
 while read -r cfg; do
   echo "== $cfg"
