@@ -978,6 +978,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
     const int tb = __builtin_amdgcn_readfirstlane(wi / p.n_nblocks), nb = wi - tb * p.n_nblocks;
     const long m0 = (long)tb * 128;
     const int nch = p.Cin / 48;
+    const int c0 = (int)blockIdx.z * p.kt_per, c1 = min(nch, c0 + p.kt_per);      // split-K: blockIdx.z owns the chunks [c0, c1), raw sums go to p.partial
     const unsigned pitch4 = (unsigned)p.in_pitch * 4u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void *)p.in, (short)0, (int)((long)p.N * p.Hin * p.Win * pitch4), 0x00020000);
@@ -1040,9 +1041,9 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
         for (int nf = 0; nf < 3; ++nf)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
-    a_load(0);
+    a_load(c0);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) w_load(s, s);
+    for (int s = 0; s < 3; ++s) w_load(s, c0 * 3 + s);
     if (aff) {   // (the first slab and weights are on their way)
         if (p.cA) {
             for (int c = tid; c < p.Cin; c += 256) { sA[c] = p.cA[(long)img * p.Cin + c]; sB[c] = p.cB[(long)img * p.Cin + c]; }
@@ -1050,12 +1051,12 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
         } else coef_to_lds(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256);      // (ends with a barrier)
     }
 #pragma unroll
-    for (int j = 0; j < NUT; ++j) a_store(0, j, 0);
+    for (int j = 0; j < NUT; ++j) a_store(0, j, c0);
     __syncthreads();
     u32x4 af[2][2];                                                 // [plane][fragment mf] of the current k-step (the partner wave of the SIMD covers the LDS latency)
-    for (int c = 0; c < nch; ++c) {
-        const char *st = lds + (c & 1) * H2S1_STAGE;
-        const int cn = c + 1 < nch ? c + 1 : c;                      // (last chunk: staged again, never read)
+    for (int c = c0; c < c1; ++c) {
+        const char *st = lds + ((c - c0) & 1) * H2S1_STAGE;
+        const int cn = c + 1 < c1 ? c + 1 : c;                      // (last chunk: staged again, never read)
         a_load(cn);
         [&]<int... S>(std::integer_sequence<int, S...>) {
             ([&] {
@@ -1073,7 +1074,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
                         acc[mf][nf] = mma<true>(af[0][mf], ring[S][0][nf], acc[mf][nf]);
                     }
                 w_load(S, c * 3 + S + 3);
-                a_store((c + 1) & 1, S, cn);
+                a_store((c - c0 + 1) & 1, S, cn);
                 __builtin_amdgcn_sched_barrier(0);
             }(), ...);
         }(std::make_integer_sequence<int, 3>{});
@@ -1254,15 +1255,15 @@ int conv3_h2d_launch(const ConvK &p, hipStream_t st) {
 }
 
 // the 1x1 layers on 128-pixel tiles (two workgroups per CU): p.n_mtiles = pixels / 128
-int conv1_h2s_launch(const ConvK &p, hipStream_t st) {
-    HL_REQUIRE(p.w_bf3 && conv1_h2_applies(p.Hout, p.Wout, p.Cin, p.Cout, p.ks, p.stride, p.ups) && !p.partial && !p.in16, "k_conv1_h2s: bad layer");
+int conv1_h2s_launch(const ConvK &p, hipStream_t st, int splits) {
+    HL_REQUIRE(p.w_bf3 && conv1_h2_applies(p.Hout, p.Wout, p.Cin, p.Cout, p.ks, p.stride, p.ups) && (splits == 1 || p.partial) && !p.in16 && p.kt_per >= 1, "k_conv1_h2s: bad layer");
     constexpr int LDS_MAX = H2S1_LDS + (2 * 4096 + COEF_SCR_FLOATS) * 4;        // + the coefficient table of a fused GroupNorm (<= 4096 input channels)
     static const bool attr_ok = hipFuncSetAttribute((const void *)k_conv1_h2s, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) == hipSuccess;
     HL_REQUIRE(attr_ok, "k_conv1_h2s: cannot raise the dynamic LDS limit to %d bytes", LDS_MAX);
     const bool aff = p.cA != nullptr || p.gn.gt != nullptr;
     HL_REQUIRE(!aff || (p.Cin <= 4096 && ((long)p.Hout * p.Wout) % 128 == 0), "k_conv1_h2s: fused GroupNorm needs <= 4096 input channels and whole tiles per image");
     const size_t lds_bytes = (size_t)H2S1_LDS + (aff ? (size_t)(2 * p.Cin + COEF_SCR_FLOATS) * 4 : 0);
-    hipLaunchKernelGGL(k_conv1_h2s, dim3((unsigned)(p.n_mtiles * p.n_nblocks)), dim3(256), lds_bytes, st, p);
+    hipLaunchKernelGGL(k_conv1_h2s, dim3((unsigned)(p.n_mtiles * p.n_nblocks), 1, (unsigned)splits), dim3(256), lds_bytes, st, p);
     return check_launch("k_conv1_h2s");
 }
 

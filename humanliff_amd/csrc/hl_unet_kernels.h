@@ -111,7 +111,7 @@ bool conv1_h2_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride,
 size_t conv_packed_h2_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_h2(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st, int tf = 0);
 int conv1_h2_launch(const ConvK &p, hipStream_t st);
-int conv1_h2s_launch(const ConvK &p, hipStream_t st);               // the same on 128-pixel tiles, two workgroups per CU (p.n_mtiles = pixels / 128)
+int conv1_h2s_launch(const ConvK &p, hipStream_t st, int splits = 1);               // the same on 128-pixel tiles, two workgroups per CU (p.n_mtiles = pixels / 128)
 bool conv3_h2d_applies(int Hout, int Wout, int Cin, int Cout);        // 3x3 / stride 2 with fp16x2 products (k_conv_h2d)
 int conv3_h2d_launch(const ConvK &p, hipStream_t st);                 // p.n_mtiles = output pixels / 128
 int conv3_h2s_launch(const ConvK &p, hipStream_t st, int splits = 1);  // the same on 8x16-pixel tiles, two workgroups per CU (p.n_mtiles = pixels / 128)

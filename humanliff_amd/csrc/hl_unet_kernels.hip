@@ -3116,6 +3116,23 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         }
         if (h2_small_) {   // 128-pixel tiles, two workgroups per CU
             p.n_mtiles *= 2;
+            p.kt_per = a.in.C / 48;
+            // few workgroups (the 16- and 32-pixel levels, batch 1): the input channels split into slabs of >= 4 chunks until ~256 workgroups run (k_splitk_finish[_st] sums them)
+            static const long h2_split_max = [] { const char *e_ = getenv("HL_H2_SPLIT_MAX_BLOCKS"); return e_ ? atol(e_) : 64L; }();   // developer knob (read once); 0: no split-K
+            if (h2_blocks < h2_split_max && a.splitk_ws && !a.out2) {
+                int sp = (int)std::min<long>(std::min<long>(128 / std::max<long>(h2_blocks, 1), (a.in.C / 48) / 4), 8);
+                while (sp > 1 && (size_t)sp * M * a.Cout * sizeof(float) > a.splitk_ws_bytes) --sp;
+                if (sp >= 2) {
+                    p.kt_per = (a.in.C / 48 + sp - 1) / sp;
+                    splits = (a.in.C / 48 + p.kt_per - 1) / p.kt_per;
+                    p.partial = a.splitk_ws;
+                    p.st1 = p.st2 = nullptr;
+                    a.stat_slots = 0;
+                    int rc = conv1_h2s_launch(p, st, splits);
+                    if (rc) return rc;
+                    return finish("k_conv1_h2s");
+                }
+            }
             return conv1_h2s_launch(p, st);
         }
         return conv1_h2_launch(p, st);
