@@ -1293,9 +1293,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(secs * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",
-            "dtype_note": "fp32 tensors and accumulators; Winograd / direct kernels on the fp32 matrix pipe; the 1x1 layers and the 3x3 layers of about one round of workgroups "
-                          "form their fp32 products from two fp16 planes per operand (fp32-class error, float64-checked, same oracle bounds); roofline.fp32_mfma_mode = every "
-                          "product on the fp32 pipe",
+            "dtype_note": "fp32 tensors and accumulators; conv / attention products from two fp16 planes per operand (fp32-class error); fp32_mfma_mode = all-fp32 pipe",
             "data": "synthetic",
             "config": {"workload": "configs[1]: 256x256x27 tri-plane UNet (controlnet, 497M params), 1000-step DDPM "
                                    "p_sample_loop, batch=4 per GPU", "global_batch": world * args.batch,
@@ -1319,7 +1317,19 @@ def main():
             if isinstance(roof, dict) and v is not None and k not in ("n_gpus",):
                 roof["hl_" + k] = v
         line["summary"] = summary
-        print(json.dumps(line), flush=True)
+        # Everything measured goes to bench_detail.json; stdout gets ONE compact line (bench_line.py: < 6 KB, no long strings) - round 5's
+        # 20 KB line was more than the driver's log reader kept.
+        import bench_line
+        detail = json.dumps(line, indent=1)
+        for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+            try:
+                os.makedirs(d, exist_ok=True)
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(detail + "\n")
+            except OSError:
+                pass
+        sys.stdout.flush()
+        print(json.dumps(bench_line.compact_line(line)), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

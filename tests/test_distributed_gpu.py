@@ -164,5 +164,8 @@ def test_bench_self_launches_for_more_than_one_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["metric"] == "denoise-steps/sec" and line["value"] > 0
     assert line["rccl"]["world_size"] == 2 and line["rccl"]["backend"] == "gloo"
-    assert line["rccl"]["sample_gather"]["recv_gb_per_s_per_rank"] > 0 and line["rccl"]["image_gather_uint8"]["ms"] > 0
+    assert line["rccl"]["sample_gather_recv_gb_per_s_per_rank"] > 0 and line["rccl"]["image_gather_uint8_recv_gb_per_s_per_rank"] > 0
+    assert len(lines[0]) < 8192                                   # the compact line (bench_line.py); the rest is in bench_detail.json
+    detail = json.load(open(os.path.join(root, "bench_detail.json")))
+    assert detail["rccl"]["image_gather_uint8"]["ms"] > 0 and detail["n_gpus"] == 2
     assert line["summary"]["n_gpus"] == 2 and line["summary"]["rccl_world_size"] == 2

@@ -187,3 +187,42 @@ def test_extract_into_tensor_tables_are_keyed_by_content():
     arr32 = rng.random(1000).astype(np.float32)     # another dtype with other bytes of the same length is its own entry
     assert torch.equal(gd._extract_into_tensor(arr32, t, (4,)), torch.from_numpy(arr32)[t].float())
     assert len(gd._TABLES) <= 256
+
+
+def test_bench_line_is_compact():
+    """the driver reads ONE JSON line from bench.py's stdout.  Round 5's line had grown to 20 KB and the driver's record came back
+    unparsed; `bench_line.compact_line` now reduces everything measured to < 6 KB with no string over 160 characters (the rest goes to
+    bench_detail.json).  Canned input: round 5's full result (profiles/r05_bench.json) plus a worst-case synthetic one."""
+    import json
+    import os
+    import bench_line
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, "profiles", "r05_bench.json")))
+    line = bench_line.compact_line(full)
+    s = json.dumps(line)
+    assert len(s) < 8192 and len(s) < bench_line.MAX_LINE_BYTES and "\n" not in s
+    assert max(len(x) for x in bench_line._strings(line)) <= 160
+    back = json.loads(s)
+    assert back == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline", "parity", "summary"):
+        assert k in back, k
+    assert back["value"] == full["value"] and back["metric"] == "denoise-steps/sec" and "workload" in back["config"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in back["roofline"], k
+    assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"], k
+    for leg in ("render", "fit"):
+        assert set(("value", "unit", "roofline", "cpu_baseline")) <= set(back[leg]), leg
+    assert back["render"]["parity"]["psnr_db"] > 45
+    # worst case: every string absurdly long, non-finite numbers, an N > 1 run without the N = 1-only legs
+    junk = "x" * 5000
+    worst = dict(full, dtype_note=junk, cpu_baseline=None, parity=None, e2e=None, train=None,
+                 rccl={"world_size": 8, "backend": "nccl", "device_count_visible": 8, "sample_gather": {"recv_gb_per_s_per_rank": float("nan")},
+                       "image_gather_uint8": {"recv_gb_per_s_per_rank": 301.5, "note": junk}})
+    worst["config"] = dict(full["config"], workload=junk)
+    worst["roofline"] = dict(full["roofline"], kernel=junk, note=junk)
+    w = bench_line.compact_line(worst)
+    ws = json.dumps(w)
+    assert len(ws) < bench_line.MAX_LINE_BYTES and json.loads(ws) == w and "NaN" not in ws
+    assert w["rccl"]["backend"] == "nccl" and w["rccl"]["image_gather_uint8_recv_gb_per_s_per_rank"] == 301.5
