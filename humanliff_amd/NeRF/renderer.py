@@ -207,43 +207,45 @@ class Renderer(nn.Module):
                 else:
                     u = torch.rand([bs * R, n_importance], pin_memory=True).to(dev, non_blocking=True)
             u = u.reshape(bs, R, n_importance)
-        if not self.test:
-            out = self._render_training(tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,
-                                        noise, tp_input if self.use_canonical_space else None)
+        # Everything behind the draw runs inside try / finally: whatever happens (a launch that raises included), the CPU generator ends up where the
+        # reference's torch.rand would have left it - a failed call must not make the next one reuse the same uniforms.
+        try:
+            if not self.test:
+                out = self._render_training(tri_planes, bounds, z_vals, rays_o, rays_d, near, far, n_samples, n_importance, white_bkgd, u,
+                                            noise, tp_input if self.use_canonical_space else None)
+                return out
+            L = _lib.lib()
+            packed = self._packed_mlp(dev)
+            ws = self._workspace(L.hl_render_workspace_bytes(R, n_samples, n_importance), dev)
+            rgb = torch.empty((bs, R, 3), dtype=torch.float32, device=dev)
+            acc = torch.empty((bs, R), dtype=torch.float32, device=dev)
+            depth = torch.empty((bs, R), dtype=torch.float32, device=dev)
+            products = getattr(self, "mlp_products", "fp32")
+            if products not in ("fp16x2", "bf16x3", "fp32"):
+                raise ValueError(f"Renderer.mlp_products must be 'fp16x2', 'bf16x3' or 'fp32', not {products!r}")
+            fp16 = bool(getattr(self, "mlp_fp16", False))
+            # explicit precedence: the opt-in fp16-operand kernel first; the bf16x3 products only in the evaluate-once schedule (the re-evaluating
+            # one exists on the fp32-MFMA kernel alone)
+            flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0) | (_lib.HL_RENDER_REEVALUATE if reevaluate else 0) | \
+                (_lib.HL_RENDER_MLP_FP16 if fp16 else (0 if reevaluate else {"bf16x3": _lib.HL_RENDER_MLP_BF16X3, "fp16x2": _lib.HL_RENDER_MLP_FP16X2}.get(products, 0)))
+            f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+            for b in range(bs):
+                pp = self._packed_planes(tri_planes[b])
+                zb = f32(z_vals[b]) if z_vals is not None else None
+                ub = f32(u[b]) if n_importance > 0 else None
+                ro, rd, nr, fr, bd = f32(rays_o[b]), f32(rays_d[b]), f32(near[b]), f32(far[b]), f32(bounds[b])
+                # (u drawn by the device on a side stream: only the importance-sampling launch waits for it, the coarse pass runs beside the generator)
+                u_ev = pending_draw.u_event.cuda_event if pending_draw is not None else None
+                _lib.check(L.hl_render_rays_u_event(
+                    _lib.ptr(packed), _lib.ptr(pp), H, W, _lib.ptr(bd), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(nr),
+                    _lib.ptr(fr), _lib.ptr(zb), _lib.ptr(ub), u_ev, R, n_samples, n_importance, flags,
+                    _lib.ptr(rgb[b]), _lib.ptr(acc[b]), _lib.ptr(depth[b]), _lib.ptr(ws), _lib.stream_ptr()),
+                    "hl_render_rays")
+            # normal_map aliases rgb_map in the reference (renderer.py:228)
+            return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
+        finally:
             if pending_draw is not None:
-                pending_draw.finish()         # the CPU generator now stands where the reference's torch.rand would have left it
-            return out
-        L = _lib.lib()
-        packed = self._packed_mlp(dev)
-        ws = self._workspace(L.hl_render_workspace_bytes(R, n_samples, n_importance), dev)
-        rgb = torch.empty((bs, R, 3), dtype=torch.float32, device=dev)
-        acc = torch.empty((bs, R), dtype=torch.float32, device=dev)
-        depth = torch.empty((bs, R), dtype=torch.float32, device=dev)
-        products = getattr(self, "mlp_products", "fp32")
-        if products not in ("fp16x2", "bf16x3", "fp32"):
-            raise ValueError(f"Renderer.mlp_products must be 'fp16x2', 'bf16x3' or 'fp32', not {products!r}")
-        fp16 = bool(getattr(self, "mlp_fp16", False))
-        # explicit precedence: the opt-in fp16-operand kernel first; the bf16x3 products only in the evaluate-once schedule (the re-evaluating
-        # one exists on the fp32-MFMA kernel alone)
-        flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0) | (_lib.HL_RENDER_REEVALUATE if reevaluate else 0) | \
-            (_lib.HL_RENDER_MLP_FP16 if fp16 else (0 if reevaluate else {"bf16x3": _lib.HL_RENDER_MLP_BF16X3, "fp16x2": _lib.HL_RENDER_MLP_FP16X2}.get(products, 0)))
-        f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
-        for b in range(bs):
-            pp = self._packed_planes(tri_planes[b])
-            zb = f32(z_vals[b]) if z_vals is not None else None
-            ub = f32(u[b]) if n_importance > 0 else None
-            ro, rd, nr, fr, bd = f32(rays_o[b]), f32(rays_d[b]), f32(near[b]), f32(far[b]), f32(bounds[b])
-            # (u drawn by the device on a side stream: only the importance-sampling launch waits for it, the coarse pass runs beside the generator)
-            u_ev = pending_draw.u_event.cuda_event if pending_draw is not None else None
-            _lib.check(L.hl_render_rays_u_event(
-                _lib.ptr(packed), _lib.ptr(pp), H, W, _lib.ptr(bd), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(nr),
-                _lib.ptr(fr), _lib.ptr(zb), _lib.ptr(ub), u_ev, R, n_samples, n_importance, flags,
-                _lib.ptr(rgb[b]), _lib.ptr(acc[b]), _lib.ptr(depth[b]), _lib.ptr(ws), _lib.stream_ptr()),
-                "hl_render_rays")
-        if pending_draw is not None:
-            pending_draw.finish()             # the CPU generator now stands where the reference's torch.rand would have left it
-        # normal_map aliases rgb_map in the reference (renderer.py:228)
-        return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
+                pending_draw.finish()
 
 
     # ---- training mode (test=False) ------------------------------------------------
@@ -365,28 +367,30 @@ class Renderer(nn.Module):
             else:
                 from .cpu_rng import rand_like_cpu
                 u, pending_draw = rand_like_cpu([R, n_importance], dev)
-        verts4, table, Rh, Th = deform_tables(self.SMPL_NEUTRAL, tp_input['params'], tp_input['t_params'],
-                                              tp_input['vertices'].to(dev))
-        L = _lib.lib()
-        packed, pp = self._packed_mlp(dev), self._packed_planes(tri_planes[0])
-        ws = self._workspace(L.hl_render_canonical_workspace_bytes(R, n_samples, n_importance), dev)
-        rgb = torch.empty((1, R, 3), dtype=torch.float32, device=dev)
-        acc = torch.empty((1, R), dtype=torch.float32, device=dev)
-        depth = torch.empty((1, R), dtype=torch.float32, device=dev)
-        flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0)
-        f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
-        ro, rd, nr, fr = f32(rays_o[0]), f32(rays_d[0]), f32(near[0]), f32(far[0])
-        bd = f32(tp_input['t_world_bounds'].reshape(-1, 2, 3)[0].to(dev))
-        zb = f32(z_vals[0]) if z_vals is not None else None
-        ub = f32(u.reshape(R, n_importance))
-        _lib.check(L.hl_render_rays_canonical(
-            _lib.ptr(packed), _lib.ptr(pp), H, W, _lib.ptr(bd), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(nr), _lib.ptr(fr), _lib.ptr(zb),
-            _lib.ptr(ub), R, n_samples, n_importance, flags, Rh.ctypes.data, Th.ctypes.data, _lib.ptr(verts4), _lib.ptr(table),
-            int(verts4.shape[0]), _lib.ptr(rgb), _lib.ptr(acc), _lib.ptr(depth), _lib.ptr(ws), _lib.stream_ptr()),
-            "hl_render_rays_canonical")
-        if pending_draw is not None:
-            pending_draw.finish()
-        return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
+        try:                                      # (the generator is advanced whatever happens below: see render)
+            verts4, table, Rh, Th = deform_tables(self.SMPL_NEUTRAL, tp_input['params'], tp_input['t_params'],
+                                                  tp_input['vertices'].to(dev))
+            L = _lib.lib()
+            packed, pp = self._packed_mlp(dev), self._packed_planes(tri_planes[0])
+            ws = self._workspace(L.hl_render_canonical_workspace_bytes(R, n_samples, n_importance), dev)
+            rgb = torch.empty((1, R, 3), dtype=torch.float32, device=dev)
+            acc = torch.empty((1, R), dtype=torch.float32, device=dev)
+            depth = torch.empty((1, R), dtype=torch.float32, device=dev)
+            flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0)
+            f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+            ro, rd, nr, fr = f32(rays_o[0]), f32(rays_d[0]), f32(near[0]), f32(far[0])
+            bd = f32(tp_input['t_world_bounds'].reshape(-1, 2, 3)[0].to(dev))
+            zb = f32(z_vals[0]) if z_vals is not None else None
+            ub = f32(u.reshape(R, n_importance))
+            _lib.check(L.hl_render_rays_canonical(
+                _lib.ptr(packed), _lib.ptr(pp), H, W, _lib.ptr(bd), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(nr), _lib.ptr(fr), _lib.ptr(zb),
+                _lib.ptr(ub), R, n_samples, n_importance, flags, Rh.ctypes.data, Th.ctypes.data, _lib.ptr(verts4), _lib.ptr(table),
+                int(verts4.shape[0]), _lib.ptr(rgb), _lib.ptr(acc), _lib.ptr(depth), _lib.ptr(ws), _lib.stream_ptr()),
+                "hl_render_rays_canonical")
+            return {'rgb_map': rgb, 'acc_map': acc, 'normal_map': rgb, 'depth_map': depth}
+        finally:
+            if pending_draw is not None:
+                pending_draw.finish()
 
     # ---- the density grid behind extract_geometry ---------------------
     def density_grid(self, tp_input, tri_planes=None, resolution=512, rays_per_launch=1 << 17):

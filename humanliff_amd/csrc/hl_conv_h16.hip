@@ -91,8 +91,9 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
         // vmcnt too: a load waited for behind a store waits for the store).  One channel quad per thread = GroupNorm sums without shuffles.
         const int pr0 = tid / 48, cq = (tid - pr0 * 48) * 4;
         f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f}, sm2 = {0.f, 0.f, 0.f, 0.f}, sq2 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bs = {0.f, 0.f, 0.f, 0.f}, ws = {1.f, 1.f, 1.f, 1.f};
         if (p.bias && pr0 < 5) bs = *reinterpret_cast<const f32x4 *>(p.bias + n0 + cq);
+        if (p.wsc && pr0 < 5) ws = *reinterpret_cast<const f32x4 *>(p.wsc + n0 + cq);      // fp16x2 planes: the inverse power-of-two scales of these four channels' weights
         auto finish = [&](auto kc0, auto nbc) {   // pixel slots pr0 + 5 (K0 .. K0 + NB - 1): every load of the batch in flight before its first store
             constexpr int K0 = decltype(kc0)::value, NB = decltype(nbc)::value;
             long mm[NB];
@@ -103,7 +104,7 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
                 mm[k] = pix(q, pc);
                 if (p.res && !p.partial) rr[k] = *reinterpret_cast<const f32x4 *>(p.res + mm[k] * p.res_pitch + n0 + cq);
                 if (p.out2 && !p.partial) r2[k] = *reinterpret_cast<const f32x4 *>(p.res2 + mm[k] * p.res2_pitch + n0 + cq);
-                v[k] = *reinterpret_cast<const f32x4 *>(ep + pc * H16_EP + cq);
+                v[k] = *reinterpret_cast<const f32x4 *>(ep + pc * H16_EP + cq) * ws;
             }
             if (p.partial) {   // split-K slab: raw sums, [z][pixel][Cout]
 #pragma unroll
@@ -163,9 +164,26 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
 }
 
 struct H2Pair { unsigned p0, p1; };
-__device__ __forceinline__ H2Pair split_h2(float x, float y) {   // a pair of values -> the two packed planes
+// a pair of values -> the two packed planes.  Default (round 6, H2_SPLIT_RNE = 2): h0 = the NEAREST fp16 (v_cvt_pk_f16_f32), h1 = the nearest fp16 of the residual
+// against h0 converted back (exact in fp32): |x - h0 - h1| <= 2^-24 |x| while both planes are normal, six instructions per pair like the truncating split, and a
+// value beyond fp16's range becomes inf / NaN (loud) where round 5's v_cvt_pkrtz_f16_f32 saturated at 65504 without a trace.  The staging scales its input so
+// that neither a plane overflows nor the low plane goes subnormal wherever the tensor's totals are known (hl_stats.h).  Measured (same box, A / B of three
+// builds): forward time unchanged; rel-L2 against float64 3.50e-7 / 3.43e-7 / 3.28e-7 (stride-2, K = 864) for H2_SPLIT_RNE = 0 / 1 / 2.
+// 0: h0 = the value with its low 13 mantissa bits cleared, both conversions truncating (round 5); 1: the same h0, h1 to nearest.
+#ifndef H2_SPLIT_RNE
+#define H2_SPLIT_RNE 2
+#endif
+__device__ __forceinline__ H2Pair split_h2(float x, float y) {
     const float hx = __builtin_bit_cast(float, __float_as_uint(x) & 0xffffe000u), hy = __builtin_bit_cast(float, __float_as_uint(y) & 0xffffe000u);
+#if H2_SPLIT_RNE == 2   // h0 = the NEAREST fp16 (v_cvt_pk_f16_f32), residual against its conversion back: |x - h0 - h1| <= 2^-23 |x|, the same six instructions (hl_common.h)
+    H2Pair r;
+    hl_split2_rne(x, y, r.p0, r.p1);
+    return r;
+#elif H2_SPLIT_RNE
+    return H2Pair{pack2<true>(hx, hy), pack2<true>(x - hx, y - hy)};
+#else
     return H2Pair{__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hx, hy)), __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy))};
+#endif
 }
 
 
@@ -356,7 +374,7 @@ constexpr int H2S_EP = 100;                                            // epilog
 constexpr int H2S_LDS = 2 * H2S_STG + 1024 > 128 * H2S_EP * 4 ? 2 * H2S_STG + 1024 : 128 * H2S_EP * 4;
 
 template <class PixFn>
-__device__ __forceinline__ void h2s_epilogue(const ConvK &p, char *lds, const f32x16 (&acc)[2][3], int tid, int lane, int wm, int wn, int n0, long tile, PixFn pix) {
+__device__ __forceinline__ void h2s_epilogue(const ConvK &p, char *lds, const f32x16 (&acc)[2][3], int tid, int lane, int wm, int wn, int n0, long tile, float rsx, PixFn pix) {
     float *ep = reinterpret_cast<float *>(lds);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                      // channel half h = the tiles of the waves with wn == h
@@ -377,8 +395,10 @@ __device__ __forceinline__ void h2s_epilogue(const ConvK &p, char *lds, const f3
         // the residual loads of a batch are in flight before its first store
         const int pr0 = tid / 24, cq = h * 96 + (tid - pr0 * 24) * 4, cl = cq - h * 96;
         f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f}, sm2 = {0.f, 0.f, 0.f, 0.f}, sq2 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bs = {0.f, 0.f, 0.f, 0.f}, ws = {1.f, 1.f, 1.f, 1.f};
         if (p.bias && pr0 < 10) bs = *reinterpret_cast<const f32x4 *>(p.bias + n0 + cq);
+        if (p.wsc && pr0 < 10) ws = *reinterpret_cast<const f32x4 *>(p.wsc + n0 + cq);    // the inverse power-of-two scales of these four channels' weight planes ...
+        ws = ws * rsx;                                                                    // ... and of the activation planes (both exact)
         auto finish = [&](auto kc0, auto nbc) {
             constexpr int K0 = decltype(kc0)::value, NB = decltype(nbc)::value;
             long mm[NB];
@@ -391,7 +411,7 @@ __device__ __forceinline__ void h2s_epilogue(const ConvK &p, char *lds, const f3
                 mm[k] = pix(on[k] ? pc : 0);
                 if (p.res && !p.partial && on[k]) rr[k] = *reinterpret_cast<const f32x4 *>(p.res + mm[k] * p.res_pitch + n0 + cq);
                 if (p.out2 && !p.partial && on[k]) r2[k] = *reinterpret_cast<const f32x4 *>(p.res2 + mm[k] * p.res2_pitch + n0 + cq);
-                v[k] = *reinterpret_cast<const f32x4 *>(ep + (on[k] ? pc : 0) * H2S_EP + cl);
+                v[k] = *reinterpret_cast<const f32x4 *>(ep + (on[k] ? pc : 0) * H2S_EP + cl) * ws;
             }
             if (p.partial) {
 #pragma unroll
@@ -449,7 +469,9 @@ __device__ __forceinline__ void h2s_epilogue(const ConvK &p, char *lds, const f3
     }
 }
 
-__device__ __forceinline__ float h2s_silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v)); }   // (= silu_f of the GroupNorm passes)
+// silu of a value the staging holds multiplied by the power of two sx: v = z sx  ->  silu(z) sx = v / (1 + 2^(kq v)), kq = -log2(e) / sx (sx = 1: silu_f of the GroupNorm passes)
+__device__ __forceinline__ float h2s_silu(float v, float kq) { return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(kq * v)); }
+__device__ __forceinline__ float wave_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 
 __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
 #if __HIP_DEVICE_COMPILE__
@@ -489,6 +511,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
     // totals): no pre-pass over the tensor.  The table sits behind the stages; padding pixels are zero AFTER the activation (the convolution pads the activated tensor).
     const bool aff = p.cA != nullptr || p.gn.gt != nullptr;
     float *sA = reinterpret_cast<float *>(lds + H2S_LDS), *sB = sA + p.Cin;
+    float sx = 1.f, kq = -1.44269504088896341f;                    // power-of-two scale of the staged activations (hl_stats.h), -log2(e) / sx
     unsigned sv[NUT], sl[NUT];
 #pragma unroll
     for (int j = 0; j < NUT; ++j) {
@@ -519,10 +542,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
                 v1 = v1 * *reinterpret_cast<const f32x4 *>(sA + cb + 4) + *reinterpret_cast<const f32x4 *>(sB + cb + 4);
                 if (p.act) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { v0[i] = h2s_silu(v0[i]); v1[i] = h2s_silu(v1[i]); }
+                    for (int i = 0; i < 4; ++i) { v0[i] = h2s_silu(v0[i], kq); v1[i] = h2s_silu(v1[i], kq); }
                 }
                 if (sv[j] == OOB) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
-            }
+            } else { v0 = v0 * sx; v1 = v1 * sx; }
             const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
             h0 = u32x4{q0.p0, q1.p0, q2.p0, q3.p0}; h1 = u32x4{q0.p1, q1.p1, q2.p1, q3.p1};
         }
@@ -567,8 +590,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
         if (p.cA) {
             for (int c = tid; c < p.Cin; c += 256) { sA[c] = p.cA[(long)img * p.Cin + c]; sB[c] = p.cB[(long)img * p.Cin + c]; }
             __syncthreads();
-        } else coef_to_lds(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256);      // (ends with a barrier)
-    }
+        } else sx = wave_uniform(coef_to_lds<true>(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256));      // (ends with a barrier)
+    } else if (p.xs_gt && !p.in16) sx = wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw));
+    const float rsx = 1.f / sx;
+    kq *= rsx;
 #pragma unroll
     for (int j = 0; j < NUT; ++j) a_store(0, j, c0);
     __syncthreads();
@@ -604,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
         }(std::make_integer_sequence<int, 18>{});
         __syncthreads();
     }
-    h2s_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, [&](int pc) {
+    h2s_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, rsx, [&](int pc) {
         const int wmm = pc >> 6, m2 = (pc >> 5) & 1, r = pc & 31;
         return ((long)img * p.Hout + y0 + 4 * wmm + 2 * m2 + (r >> 4)) * p.Wout + x0 + (r & 15);
     });
@@ -883,8 +908,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2d(const ConvK p) {
             ar[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, sv[j] == OOB ? OOB : sv[j] + 16u, chunk * 64, 0);
         }
     };
+    // power-of-two scale of the raw input from its producers' totals (hl_stats.h)
+    const float axs = p.xs_gt ? wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw)) : 1.f, rsx = 1.f / axs;
     auto a_store = [&](int j) {
-        const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]), v1 = __builtin_bit_cast(f32x4, ar[j][1]);
+        const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]) * axs, v1 = __builtin_bit_cast(f32x4, ar[j][1]) * axs;
         const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
         *reinterpret_cast<u32x4 *>(lds + sl[j]) = u32x4{q0.p0, q1.p0, q2.p0, q3.p0};
         if (sl[j] < (unsigned)H2D_STG) *reinterpret_cast<u32x4 *>(lds + H2D_PLANE + sl[j]) = u32x4{q0.p1, q1.p1, q2.p1, q3.p1};
@@ -952,7 +979,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2d(const ConvK p) {
         }(std::make_integer_sequence<int, 9>{});
     }
     __syncthreads();
-    h2s_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, [&](int pc) {
+    h2s_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, rsx, [&](int pc) {
         const int wmm = pc >> 6, m2 = (pc >> 5) & 1, r = pc & 31;
         return ((long)img * p.Hout + y0 + 4 * wmm + 2 * m2 + (r >> 4)) * p.Wout + x0 + (r & 15);
     });
@@ -988,6 +1015,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
     const bool aff = p.cA != nullptr || p.gn.gt != nullptr;
     float *sA = reinterpret_cast<float *>(lds + H2S1_LDS), *sB = sA + p.Cin;
     const int img = (int)(m0 / ((long)p.Hout * p.Wout));
+    float sx = 1.f, kq = -1.44269504088896341f;                    // power-of-two scale of the staged activations (hl_stats.h), -log2(e) / sx
     unsigned sv[NUT], sl[NUT];
     int sg[NUT];
 #pragma unroll
@@ -1013,9 +1041,10 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
             v1 = v1 * *reinterpret_cast<const f32x4 *>(sA + cb + 4) + *reinterpret_cast<const f32x4 *>(sB + cb + 4);
             if (p.act) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { v0[i] = h2s_silu(v0[i]); v1[i] = h2s_silu(v1[i]); }
+                for (int i = 0; i < 4; ++i) { v0[i] = h2s_silu(v0[i], kq); v1[i] = h2s_silu(v1[i], kq); }
             }
         }
+        else { v0 = v0 * sx; v1 = v1 * sx; }
         const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
         const u32x4 h0 = {q0.p0, q1.p0, q2.p0, q3.p0}, h1 = {q0.p1, q1.p1, q2.p1, q3.p1};
         *reinterpret_cast<u32x4 *>(lds + stage * H2S1_STAGE + sl[j]) = h0;
@@ -1048,8 +1077,10 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
         if (p.cA) {
             for (int c = tid; c < p.Cin; c += 256) { sA[c] = p.cA[(long)img * p.Cin + c]; sB[c] = p.cB[(long)img * p.Cin + c]; }
             __syncthreads();
-        } else coef_to_lds(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256);      // (ends with a barrier)
-    }
+        } else sx = wave_uniform(coef_to_lds<true>(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256));      // (ends with a barrier)
+    } else if (p.xs_gt && !p.in16) sx = wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw));
+    const float rsx = 1.f / sx;
+    kq *= rsx;
 #pragma unroll
     for (int j = 0; j < NUT; ++j) a_store(0, j, c0);
     __syncthreads();
@@ -1080,12 +1111,52 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
         }(std::make_integer_sequence<int, 3>{});
         __syncthreads();
     }
-    h2s_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, [&](int pc) { return m0 + pc; });
+    h2s_epilogue(p, lds, acc, tid, lane, wm, wn, nb * 192, (long)tb, rsx, [&](int pc) { return m0 + pc; });
 #endif
 }
 
-// fp16x2 weights of a 3x3 layer: [channel block of 192][chunk of 32 inputs][tap][k-half][plane 2][wn][fragment nf][lane][8], nearest even at both levels
-__global__ void k_pack_conv_h2(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, unsigned short *__restrict__ dst, int tf) {
+// Scale of the fp16x2 weight planes (round 6).  fp16 has a 5-bit exponent: unscaled, the low plane w1 = w - fp16(w) of a weight below 2^-3 falls under
+// fp16's smallest normal (2^-14) and is rounded on the 2^-24 subnormal grid - at |w| ~ 5e-3 (the production net's own 1536 -> 768 layers at initialisation)
+// the pair keeps 2^-18 instead of 2^-22, at 1e-4 (zero_module convolutions early in training, unet.py:149,237) TF32's 2^-11.  So every OUTPUT CHANNEL's
+// weights are multiplied, before they are split, by the power of two that puts the channel's largest |w| into [2^13, 2^14): both planes are then normal
+// for every weight down to 2^-16 of the channel's largest, the pair keeps 2^-22 of it whatever the magnitude, and the scaling itself is exact.  The
+// epilogues multiply the accumulators by the inverse (a power of two: exact) before the bias; the inverses live behind the planes of the layer
+// (conv_packed_h2_bytes counts them, h2_wscale finds them).  A channel of zeros, or one whose largest weight is not finite, keeps scale 1.
+__global__ void k_wscale_h2(const float *__restrict__ w, int Cout, int Cin, int taps, int tf, float *__restrict__ inv) {
+    __shared__ float red[256];
+    const int o = blockIdx.x;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < Cin * taps; i += 256) {
+        const int cin = i / taps, tap = i - cin * taps;
+        const float v = tf ? w[((long)cin * Cout + o) * taps + tap] : w[((long)o * Cin + cin) * taps + tap];
+        m = fmaxf(m, fabsf(v));          // (fmaxf drops NaNs: a NaN weight still reaches the planes and the output through the pack below)
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        m = red[0];
+        int e = (int)((__float_as_uint(m) >> 23) & 0xff) - 127;        // floor(log2 m) for a normal m
+        float r = 1.f;
+        if (m > 0.f && e < 128) {                                      // (e == 128: inf)
+            e = e < -100 ? -100 : e;                                   // (denormal weights: 2^113 at most)
+            r = __uint_as_float((unsigned)(e - 13 + 127) << 23);       // 2^(e - 13): m / r is in [2^13, 2^14)
+        }
+        inv[o] = r;
+    }
+}
+__device__ __forceinline__ unsigned short h2_plane(float v, float inv, int pl) {   // plane pl of v / inv, nearest even at both levels
+    v = v * (1.f / inv);                       // (1 / a power of two: exact)
+    _Float16 h = (_Float16)v;
+    if (pl) h = (_Float16)(v - (float)h);
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+// fp16x2 weights of a 3x3 layer: [channel block of 192][chunk of 32 inputs][tap][k-half][plane 2][wn][fragment nf][lane][8], then Cout floats = the inverse scales
+__global__ void k_pack_conv_h2(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, unsigned short *__restrict__ dst, int tf, const float *__restrict__ inv) {
     const int nch = Cin_pad >> 5;
     const long n = (long)(Cout / 192) * nch * 18 * 2 * 3072;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -1101,14 +1172,12 @@ __global__ void k_pack_conv_h2(const float *__restrict__ w, int Cout, int Cin, i
         const int o = nb * 192 + wn * 96 + nf * 32 + (l & 31), cin = chunk * 32 + k2 * 16 + (l >> 5) * 8 + j;
         float v = 0.f;
         if (cin < Cin) v = tf ? w[((long)cin * Cout + o) * 9 + (8 - tap)] : w[((long)o * Cin + cin) * 9 + tap];
-        _Float16 h = (_Float16)v;
-        if (pl) h = (_Float16)(v - (float)h);
-        dst[i] = __builtin_bit_cast(unsigned short, h);
+        dst[i] = h2_plane(v, inv[o], pl);
     }
 }
 
-// fp16x2 weights of a 1x1 layer: [channel block of 192][chunk of 48 inputs][k-step 3][plane 2][wn][fragment nf][lane][8], nearest even at both levels
-__global__ void k_pack_conv1_h2(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, unsigned short *__restrict__ dst, int tf) {
+// fp16x2 weights of a 1x1 layer: [channel block of 192][chunk of 48 inputs][k-step 3][plane 2][wn][fragment nf][lane][8], then Cout floats = the inverse scales
+__global__ void k_pack_conv1_h2(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, unsigned short *__restrict__ dst, int tf, const float *__restrict__ inv) {
     const int nch = Cin_pad / 48;
     const long n = (long)(Cout / 192) * nch * 3 * 2 * 3072;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -1123,9 +1192,7 @@ __global__ void k_pack_conv1_h2(const float *__restrict__ w, int Cout, int Cin, 
         const int o = nb * 192 + wn * 96 + nf * 32 + (l & 31), cin = chunk * 48 + k2 * 16 + (l >> 5) * 8 + j;
         float v = 0.f;
         if (cin < Cin) v = tf ? w[(long)cin * Cout + o] : w[(long)o * Cin + cin];
-        _Float16 h = (_Float16)v;
-        if (pl) h = (_Float16)(v - (float)h);
-        dst[i] = __builtin_bit_cast(unsigned short, h);
+        dst[i] = h2_plane(v, inv[o], pl);
     }
 }
 
@@ -1208,14 +1275,23 @@ int conv_pack_weights_h16(const float *w, int Cout, int Cin, int Cin_pad, int ks
 bool conv1_h2_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int ups) {
     return ks == 1 && stride == 1 && !ups && ((long)Hout * Wout) % 256 == 0 && Cin % 48 == 0 && Cout % 192 == 0 && (long)Cout * Cin * 4 < (1L << 31);
 }
-size_t conv_packed_h2_bytes(int Cout, int Cin_pad, int ks) {
+static size_t h2_plane_bytes(int Cout, int Cin_pad, int ks) {
     if (ks == 3) return (Cout % 192 == 0 && Cin_pad % 32 == 0) ? (size_t)Cout * Cin_pad * 9 * 4 : 0;
     return (ks == 1 && Cout % 192 == 0 && Cin_pad % 48 == 0) ? (size_t)Cout * Cin_pad * 4 : 0;
 }
+size_t conv_packed_h2_bytes(int Cout, int Cin_pad, int ks) {   // the two planes + the per-channel inverse scales (k_wscale_h2)
+    const size_t b = h2_plane_bytes(Cout, Cin_pad, ks);
+    return b ? b + (size_t)Cout * sizeof(float) : 0;
+}
+const float *conv_h2_wscale(const void *packed, int Cout, int Cin_pad, int ks) {
+    return reinterpret_cast<const float *>(static_cast<const char *>(packed) + h2_plane_bytes(Cout, Cin_pad, ks));
+}
 int conv_pack_weights_h2(const float *w, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st, int tf) {
     HL_REQUIRE(w && packed && conv_packed_h2_bytes(Cout, Cin_pad, ks) && Cin <= Cin_pad, "conv_pack_weights_h2: bad argument");
-    if (ks == 3) hipLaunchKernelGGL(k_pack_conv_h2, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), tf);
-    else hipLaunchKernelGGL(k_pack_conv1_h2, dim3(512), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), tf);
+    float *inv = const_cast<float *>(conv_h2_wscale(packed, Cout, Cin_pad, ks));
+    hipLaunchKernelGGL(k_wscale_h2, dim3((unsigned)Cout), dim3(256), 0, st, w, Cout, Cin, ks * ks, tf, inv);
+    if (ks == 3) hipLaunchKernelGGL(k_pack_conv_h2, dim3(1024), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), tf, inv);
+    else hipLaunchKernelGGL(k_pack_conv1_h2, dim3(512), dim3(256), 0, st, w, Cout, Cin, Cin_pad, static_cast<unsigned short *>(packed), tf, inv);
     return check_launch("k_pack_conv_h2");
 }
 // the 3x3 / stride-1 layers with fp16x2 products (k_conv_h16<true, 2>)

@@ -44,6 +44,9 @@ constexpr int PACKED_FLOATS = NCH_FULL * CHUNK_FLOATS + SMALL_FLOATS;
 // offsets inside the small-parameter block (floats); [t][half][16] lane-order tables
 constexpr int SM_B0 = 0, SM_B1 = 128, SM_B2 = 256, SM_BF = 384, SM_BV = 512, SM_AW = 576, SM_RW = 704,
               SM_AB = 896, SM_RB = 897;
+// [SM_SC + l], l = 0..4 (pts_linears.0 / .1 / .2, feature_linear, views_linear): the power of two the fp16x2 weight planes of layer l are multiplied by
+// (k_mlp_scales_h2, round 6); [SM_SC + 8 + l] its inverse
+constexpr int SM_SC = 904;
 
 struct ChunkDesc {
     int w;      // 0 pts0, 1 pts1, 2 pts2, 3 feat, 4 views
@@ -116,9 +119,43 @@ __global__ void k_pack_mlp(PackArgs a) {
             v = a.alpha_b[0];
         } else if (s < SM_RB + 3) {
             v = a.rgb_b[s - SM_RB];
+        } else if (s >= SM_SC && s < SM_SC + 16) {
+            v = 1.f;                                    // (k_mlp_scales_h2 overwrites the entries it owns)
         }
     }
     a.out[idx] = v;
+}
+
+// Scales of the fp16x2 weight planes (round 6).  The low plane w - fp16(w) of a weight below 2^-3 is subnormal in fp16 (absolute precision 2^-25): at nn.Linear's
+// default initialisation (|w| <= 0.09 ... 0.19) the pair already keeps 2^-21 instead of 2^-22, and an MLP whose weights are 2^-8 of that would be down to TF32's
+// precision.  So every LAYER's weights are multiplied, before the split, by the power of two that puts the layer's largest |w| into [2^12, 2^13) (x log2(e) <
+// 2^14 in front of a softplus), the bias that initialises the accumulators likewise, and the kernel multiplies the accumulators by the inverse on their way into
+// the softplus (or into the next operand): exact, one v_mul per accumulator register.  One scale per layer, not per unit: the accumulators of a lane hold 16
+// different units.  grid = 5 layers.
+__global__ void k_mlp_scales_h2(PackArgs a, float *dst) {   // dst[l] = the scale of layer l, dst[8 + l] its inverse
+    __shared__ float red[256];
+    const int l = blockIdx.x;
+    const int n = l == 0 ? 128 * 27 : (l == 1 ? 128 * 128 : (l == 2 ? 128 * 155 : (l == 3 ? 128 * 128 : 64 * 155)));
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(a.w[l][i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        m = red[0];
+        int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xff) - 127;     // floor(log2 m) for a normal m
+        float sc = 1.f, inv = 1.f;
+        if (m > 0.f && e < 128) {
+            e = e < -100 ? -100 : e;
+            sc = __builtin_bit_cast(float, (unsigned)(12 - e + 127) << 23);
+            inv = __builtin_bit_cast(float, (unsigned)(e - 12 + 127) << 23);
+        }
+        dst[l] = sc;
+        dst[8 + l] = inv;
+    }
 }
 
 // planes (3,9,H,W) -> [q = plane*3 + group][y][x][4] (3 channels + 0)
@@ -876,6 +913,7 @@ __global__ void k_pack_mlp_h2(PackArgs a, unsigned short *out) {
     // consumes log2-unit activations (x ln 2) - for hidden -> hidden layers the two cancel and the planes are those of the unscaled weights
     constexpr float PSC[7] = {1.44269504088896341f, 1.f, 1.44269504088896341f, 1.f, 0.693147180559945309f, 1.44269504088896341f, 1.44269504088896341f};
     v *= PSC[pi];
+    v *= a.out[NCH_FULL * CHUNK_FLOATS + SM_SC + d.w];          // the layer's power of two (k_mlp_scales_h2): exact
 #endif
     _Float16 h = (_Float16)v;                                   // nearest even
     if (plane == 1) h = (_Float16)(v - (float)h);               // (the residual is exact in fp32)
@@ -1290,10 +1328,19 @@ __device__ __forceinline__ void split_b3t(const f32x16 &v, int hi, u32x4 (&pl)[3
 // 1 + e^-|x| does in the other form; for x' >> 0 the result carries v_log_f32's 1 ulp of ITS magnitude (relative 1e-7, the class of every fp32 operation
 // here).  Range: 2^x' overflows at x' = 128, i.e. a pre-activation of 88.7 gives inf where F.softplus returns x (threshold 20) - far inside the range
 // limit the fp16 planes already impose on this mode (65504), and loud.
+// Round 6: rs = the inverse of the power of two the layer's weight planes carry (k_mlp_scales_h2): the accumulators hold x' / rs.  And the large-x branch of
+// F.softplus (threshold 20: returns x): 2^x' overflows at x' = 128 (a pre-activation of 88.7) and round 5 returned inf there; now y' = med3(L, x', 128) with
+// L = log2(1 + 2^x'): for x' < 128, x' <= L <= 128 and the median is L; beyond, L = inf and the median is x' - one v_med3_f32, no compare / select.
+#ifndef HL_SP_NOCLAMP
+#define HL_SP_NOCLAMP 0
+#endif
 template <int I0, int I1>
-__device__ __forceinline__ void softplus_l2_r(f32x16 &v) {
+__device__ __forceinline__ void softplus_l2_r(f32x16 &v, float rs) {
 #pragma unroll
-    for (int i = I0; i < I1; ++i) v[i] = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(v[i]));
+    for (int i = I0; i < I1; ++i) {
+        const float x = v[i] * rs, l = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(x));
+        v[i] = HL_SP_NOCLAMP ? l : __builtin_amdgcn_fmed3f(l, x, 128.f);
+    }
 }
 template <int I0, int I1>
 __device__ __forceinline__ void softplus_b3_r(f32x16 &v) {   // registers I0 .. I1-1 of softplus16_b3, in place
@@ -1341,13 +1388,22 @@ __device__ __forceinline__ void mma_b3(f32x16 (&acc)[NT], const u32x4 (&b)[3], c
 // plain fp32 (profiles/r05_render_fp16x2.md).  h0 = the value with its low 13 mantissa bits cleared (v_and: what a round-toward-zero conversion
 // to fp16 keeps), so the residual x - h0 is exact in fp32; both planes packed by v_cvt_pkrtz_f16_f32.  Range: |x| < 65504 (fp16); values below
 // 2^-14 keep an ABSOLUTE error of 2^-24.
+#ifndef HL_RENDER_SPLIT_RNE
+#define HL_RENDER_SPLIT_RNE 0   // 1 (round 6, measured and NOT taken: +1.0 ms per 512x512 view, 26.1 -> 27.0 on the same box - the kernel is bound by its vector ALU and v_cvt_f32_f16 is not a plain-rate instruction): h0 = the nearest fp16, h1 = the nearest fp16 of the residual against h0 converted back (2^-24; a value beyond fp16 becomes inf / NaN);
+#endif                          // 0: round 5's truncating split (h0 = the low 13 mantissa bits cleared, v_cvt_pkrtz: 2^-20, saturates silently) - the same six instructions per pair
 __device__ __forceinline__ void split_h2t(const f32x16 &v, int hi, u32x4 (&pl)[2]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float x = v[8 * hi + 2 * q], y = v[8 * hi + 2 * q + 1];
+#if HL_RENDER_SPLIT_RNE
+        unsigned w0, w1;
+        hl_split2_rne(x, y, w0, w1);
+        pl[0][q] = w0; pl[1][q] = w1;
+#else
         const float hx = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffffe000u), hy = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, y) & 0xffffe000u);
         pl[0][q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hx, hy));
         pl[1][q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy));
+#endif
     }
 }
 __device__ __forceinline__ void split_plt(const f32x16 &v, int hi, u32x4 (&pl)[3]) { split_b3t(v, hi, pl); }
@@ -1408,9 +1464,16 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
     u32x4 *ring = reinterpret_cast<u32x4 *>(ldsb);
     float *small = ldsb + 2 * B3R_SLOT_U4 * 4;
     f32x4 *vinit = reinterpret_cast<f32x4 *>(small + SMALL_FLOATS) + (tid >> 6) * 512;
+    // the layers' plane scales and their inverses (k_mlp_scales_h2; 1 outside the log2-domain fp16x2 mode, whose planes are the only scaled ones)
+    const float *gsc = a.packed + NCH_FULL * CHUNK_FLOATS + SM_SC;
+    const float sc0 = LOG2D ? gsc[0] : 1.f, sc1 = LOG2D ? gsc[1] : 1.f, sc2 = LOG2D ? gsc[2] : 1.f, scF = LOG2D ? gsc[3] : 1.f, scV = LOG2D ? gsc[4] : 1.f;
+    const float rs0 = LOG2D ? gsc[8] : 1.f, rs1 = LOG2D ? gsc[9] : 1.f, rs2 = LOG2D ? gsc[10] : 1.f, rsF = LOG2D ? gsc[11] : 1.f, rsV = LOG2D ? gsc[12] : 1.f;
     for (int i = tid; i < SMALL_FLOATS; i += NT) {
         float v = a.packed[NCH_FULL * CHUNK_FLOATS + i];
-        if constexpr (LOG2D) v *= (i < SM_BF || (i >= SM_BV && i < SM_AW)) ? L2E : ((i >= SM_AW && i < SM_AB) ? LN2 : 1.f);   // biases in front of a softplus; head weights behind one
+        if constexpr (LOG2D) {   // biases in front of a softplus x log2(e), every bias x its layer's plane scale (it initialises the scaled accumulators); head weights behind a softplus x ln 2
+            v *= (i < SM_BF || (i >= SM_BV && i < SM_AW)) ? L2E : ((i >= SM_AW && i < SM_AB) ? LN2 : 1.f);
+            v *= i < SM_B1 ? sc0 : (i < SM_B2 ? sc1 : (i < SM_BF ? sc2 : (i < SM_BV ? scF : (i < SM_AW ? scV : 1.f))));
+        }
         small[i] = v;
     }
     const u32x4 *gb3 = reinterpret_cast<const u32x4 *>(packed_b3);
@@ -1480,7 +1543,7 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) V0[t][r] *= L2E;
+                for (int r = 0; r < 16; ++r) V0[t][r] *= L2E * scV;
         }
         mma_pl(V0, bev0, gb3 + (B3_NCH - 1) * B3_CH_U4, 0, lane);
         mma_pl(V0, bev1, gb3 + (B3_NCH - 1) * B3_CH_U4, 2, lane);
@@ -1514,7 +1577,7 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
         _Pragma("unroll") for (int q_ = 0; q_ < NST; ++q_) st[q_] = ldw(((((g) >> 1) + 2) % B3W_NPAIR) * B3R_SLOT_U4 + q_ * NT); \
     }
 #define B3_AT(g) (ring + cur + ((g) & 1) * B3_CH_U4)
-#define SP_R(I0_, I1_, V_) { if constexpr (LOG2D) softplus_l2_r<I0_, I1_>(V_); else softplus_b3_r<I0_, I1_>(V_); }
+#define SP_R(I0_, I1_, V_, RS_) { if constexpr (LOG2D) softplus_l2_r<I0_, I1_>(V_, RS_); else softplus_b3_r<I0_, I1_>(V_); }
     // The two waves of a SIMD (w and w + 4) run the same chunks between the same barriers; left alone they prepare operands (VALU) at the same
     // time and multiply (MFMA) at the same time and the two pipes take turns.  B3_VM orders every chunk as [prepare the next operand, multiply]
     // in waves 0-3 and as [multiply, prepare] in waves 4-7 (ROT): one wave's VALU phase meets the other's MFMA phase.
@@ -1615,39 +1678,45 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
         mma_pl(X, bf0, B3_AT(0), 0, lane);                                       // L0: chunks 0, 1
         B3_ADV(1) mma_pl(X, bf1, B3_AT(1), 0, lane);
         load_bias<4>(Y, small + SM_B1, half);
-        SP_R(0, 8, X[0]);                                                  // (the second half: behind the first chunk of the layer)
+        SP_R(0, 8, X[0], rs0);                                             // (the second half: behind the first chunk of the layer)
         split_plt(X[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L1: chunks 2..9 = (tile k of X, half 0 | 1)
             B3_ADV(2 + 2 * k)
-            B3_MV24(5, mma_pl(Y, ba, B3_AT(2 + 2 * k), 0, lane), { SP_R(8, 16, X[k]); split_plt(X[k], 1, bb); })
+            B3_MV24(5, mma_pl(Y, ba, B3_AT(2 + 2 * k), 0, lane), { SP_R(8, 16, X[k], rs0); split_plt(X[k], 1, bb); })
             B3_ADV(3 + 2 * k)
-            B3_MV24(5, mma_pl(Y, bb, B3_AT(3 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3]); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(Y, bb, B3_AT(3 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3], rs0); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         act_rows(ROW_X0, X, SPU);
         load_bias<4>(X, small + SM_B2, half);
         B3_ADV(10) mma_pl(X, bf0, B3_AT(10), 0, lane);                          // L2 (features): chunks 10, 11; the first hidden operand rides along
         B3_ADV(11)
-        B3_VM({ SP_R(0, 8, Y[0]); split_plt(Y[0], 0, ba); }, mma_pl(X, bf1, B3_AT(11), 0, lane))
+        B3_VM({ SP_R(0, 8, Y[0], rs1); split_plt(Y[0], 0, ba); }, mma_pl(X, bf1, B3_AT(11), 0, lane))
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L2 (hidden): chunks 12..19
             B3_ADV(12 + 2 * k)
-            B3_MV24(5, mma_pl(X, ba, B3_AT(12 + 2 * k), 0, lane), { SP_R(8, 16, Y[k]); split_plt(Y[k], 1, bb); })
+            B3_MV24(5, mma_pl(X, ba, B3_AT(12 + 2 * k), 0, lane), { SP_R(8, 16, Y[k], rs1); split_plt(Y[k], 1, bb); })
             B3_ADV(13 + 2 * k)
-            B3_MV24(5, mma_pl(X, bb, B3_AT(13 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, Y[k + 1 < 4 ? k + 1 : 3]); split_plt(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(X, bb, B3_AT(13 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, Y[k + 1 < 4 ? k + 1 : 3], rs1); split_plt(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         act_rows(ROW_X1, Y, SPU);
         load_bias<4>(Y, small + SM_BF, half);
-        SP_R(0, 8, X[0]);                                                  // (the second half: behind the first chunk of the layer)
+        SP_R(0, 8, X[0], rs2);                                             // (the second half: behind the first chunk of the layer)
         split_plt(X[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // feature_linear: chunks 20..27
             B3_ADV(20 + 2 * k)
-            B3_MV24(5, mma_pl(Y, ba, B3_AT(20 + 2 * k), 0, lane), { SP_R(8, 16, X[k]); split_plt(X[k], 1, bb); })
+            B3_MV24(5, mma_pl(Y, ba, B3_AT(20 + 2 * k), 0, lane), { SP_R(8, 16, X[k], rs2); split_plt(X[k], 1, bb); })
             B3_ADV(21 + 2 * k)
-            B3_MV24(5, mma_pl(Y, bb, B3_AT(21 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3]); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(Y, bb, B3_AT(21 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3], rs2); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         act_rows(ROW_X2, X, SPU);
+        if constexpr (LOG2D) {   // feature_linear has no activation: its accumulators leave the plane scale here, on their way into views_linear's operand
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[t][r] *= rsF;
+        }
         act_rows(ROW_Y, Y, 1.f);
         const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];   // X holds softplus(pts_linears.2) by now
         f32x16 V[2];
@@ -1665,7 +1734,7 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
             B3_VM(split_plt(Y[k], 1, bb), mma_pl(V, ba, B3_AT(28 + k), 0, lane))
             B3_VM(if (k < 3) split_plt(Y[k + 1 < 4 ? k + 1 : 3], 0, ba), mma_pl(V, bb, B3_AT(28 + k), 2, lane))
         }
-        if constexpr (LOG2D) { softplus_l2_r<0, 16>(V[0]); softplus_l2_r<0, 16>(V[1]); }
+        if constexpr (LOG2D) { softplus_l2_r<0, 16>(V[0], rsV); softplus_l2_r<0, 16>(V[1], rsV); }
         else { V[0] = softplus16_b3(V[0]); V[1] = softplus16_b3(V[1]); }
         act_rows(ROW_V, V, SPU);
         const float cr = dot_lane<2>(V, small + SM_RW, half) + small[SM_RB + 0];
@@ -2692,7 +2761,7 @@ __global__ void k_pack_mlp_bwd(PackArgs a) {
 
 // The same transposed weights as two fp16 planes (nearest even at both levels) for k_mlp_bwd<., true>: the u32x4 at [(t * ns4 + s4) * 64 + lane] of a chunk holds, for s4 even,
 // plane 0 of the eight contraction steps 4 s4 .. 4 s4 + 7 of this lane half, for s4 odd plane 1 of the steps 4 (s4 - 1) .. - the byte count and the ring of the fp32 image.
-__global__ void k_pack_mlp_bwd_h2(PackArgs a, unsigned short *out) {
+__global__ void k_pack_mlp_bwd_h2(PackArgs a, unsigned short *out, const float *__restrict__ wsc) {   // wsc[l]: the power of two layer l's planes are multiplied by (k_mlp_scales_h2)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= NCH_BWD * CHUNK_FLOATS * 2) return;
     const int c = idx / (CHUNK_FLOATS * 2), e = idx % (CHUNK_FLOATS * 2);
@@ -2704,7 +2773,7 @@ __global__ void k_pack_mlp_bwd_h2(PackArgs a, unsigned short *out) {
     if (t < d.nt) {
         const int sp = d.base + (s4 >> 1) * 8 + q, half = lane >> 5, o = 32 * t + (lane & 31);
         const int u = unit_of(sp >> 4, sp & 15, half);
-        if (d.kind == 3 || o < 27) v = a.w[d.w][u * d.ld + d.col0 + o];
+        if (d.kind == 3 || o < 27) v = a.w[d.w][u * d.ld + d.col0 + o] * wsc[d.w];
     }
     _Float16 h = (_Float16)v;
     if (s4 & 1) h = (_Float16)(v - (float)h);
@@ -2779,6 +2848,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
     const float *small = lds + 2 * CHUNK_FLOATS;
     const f32x4 *gsmall = reinterpret_cast<const f32x4 *>(a.packed) + NCH_FULL * CHUNK_FLOATS / 4;
     const f32x4 *gw = reinterpret_cast<const f32x4 *>(a.bwd_packed) + (H2 ? NCH_BWD * CHUNK_FLOATS / 4 : 0);
+    const float *bsc = a.bwd_packed + 2 * NCH_BWD * CHUNK_FLOATS;   // H2: [l] the power of two layer l's planes carry, [8 + l] its inverse (k_mlp_scales_h2)
     for (int i = tid; i < SMALL_FLOATS / 4; i += NT) ldsv[2 * CHUNK_FLOATS / 4 + i] = gsmall[i];
 #pragma unroll
     for (int q = 0; q < 2 * NST; ++q) ldsv[q * NT + tid] = gw[q * NT + tid];
@@ -2862,6 +2932,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
         u32x4 bp[2][2];
         if constexpr (H2) {
             bwd_scale<4>(G, 2, sc, inv);
+            inv *= bsc[8 + 4];                                       // (views_linear's planes carry bsc[4]: the products leave it with the delta scale)
             bwd_split(G[0], sc, bp);
             mma16_h2<4, 4>(D, bp, ldsv + cur, 0, lane);
             HL_BWD_ADVANCE(1)
@@ -2884,10 +2955,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
             for (int r = 0; r < 16; ++r) G[t][r] = small[SM_AW + (t * 2 + half) * 16 + r] * d.x;
         if constexpr (H2) {
             bwd_scale<4>(D, 4, sc, inv);
+            inv *= bsc[8 + 3];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) G[t][r] *= sc;          // (the alpha head's term rides in the scaled accumulator: a power of two, exact)
+                for (int r = 0; r < 16; ++r) G[t][r] *= sc * bsc[3];  // (the alpha head's term rides in the scaled accumulator: powers of two, exact)
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -2906,7 +2978,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) DF[0][r] = 0.f;
         HL_BWD_ADVANCE(6)
-        if constexpr (H2) bwd_scale<4>(G, 4, sc, inv);
+        if constexpr (H2) { bwd_scale<4>(G, 4, sc, inv); inv *= bsc[8 + 2]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if constexpr (H2) { bwd_split(G[k], sc, bp); mma16_h2<1, 16>(DF, bp, ldsv + cur, 4 * k, lane); }
@@ -2937,7 +3009,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
-        if constexpr (H2) bwd_scale<4>(D, 4, sc, inv);
+        if constexpr (H2) { bwd_scale<4>(D, 4, sc, inv); inv *= bsc[8 + 1]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             HL_BWD_ADVANCE(11 + k)
@@ -2953,8 +3025,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_bwd(const MarchArgs a) {
         HL_BWD_ADVANCE(15)
         if constexpr (H2) {
             bwd_scale<4>(G, 4, sc, inv);
+            inv *= bsc[8 + 0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) DF[0][r] *= sc;              // (the skip connection's part, already there: scaled along, exact)
+            for (int r = 0; r < 16; ++r) DF[0][r] *= sc * bsc[0];     // (the skip connection's part, already there: scaled along, exact)
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -3513,6 +3586,9 @@ int hl_render_mlp_pack(const hl_render_mlp_params *p, void *packed, void *stream
                        reinterpret_cast<unsigned short *>(static_cast<char *>(packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024));
     rc = hl::check_launch("k_pack_mlp_b3");
     if (rc) return rc;
+    hipLaunchKernelGGL(k_mlp_scales_h2, dim3(5), dim3(256), 0, (hipStream_t)stream, a, a.out + NCH_FULL * CHUNK_FLOATS + SM_SC);      // (behind k_pack_mlp, which wrote 1s there; in front of the planes that read them)
+    rc = hl::check_launch("k_mlp_scales_h2");
+    if (rc) return rc;
     hipLaunchKernelGGL(k_pack_mlp_h2, dim3(P16_FRAGS * 2 * 2), dim3(256), 0, (hipStream_t)stream, a,
                        reinterpret_cast<unsigned short *>(static_cast<char *>(packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024 + B3_BYTES));
     return hl::check_launch("k_pack_mlp_h2");
@@ -3729,7 +3805,7 @@ static inline unsigned sample_splits(unsigned ray_groups, int n_samples) {
     if (s > (unsigned)n_samples) s = (unsigned)n_samples;
     return s < 1 ? 1 : s;
 }
-size_t hl_render_mlp_bwd_packed_bytes(void) { return (size_t)2 * NCH_BWD * CHUNK_FLOATS * sizeof(float); }   // the fp32 image, then the two fp16 planes (k_pack_mlp_bwd_h2)
+size_t hl_render_mlp_bwd_packed_bytes(void) { return (size_t)(2 * NCH_BWD * CHUNK_FLOATS + 16) * sizeof(float); }   // the fp32 image, the two fp16 planes (k_pack_mlp_bwd_h2), the planes' layer scales + inverses
 
 int hl_render_mlp_pack_bwd(const hl_render_mlp_params *p, void *packed, void *stream) {
     HL_REQUIRE(p && packed, "hl_render_mlp_pack_bwd: null argument");
@@ -3740,8 +3816,12 @@ int hl_render_mlp_pack_bwd(const hl_render_mlp_params *p, void *packed, void *st
     hipLaunchKernelGGL(k_pack_mlp_bwd, dim3((NCH_BWD * CHUNK_FLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     int rc_ = hl::check_launch("k_pack_mlp_bwd");
     if (rc_) return rc_;
+    float *wsc = static_cast<float *>(packed) + 2 * NCH_BWD * CHUNK_FLOATS;
+    hipLaunchKernelGGL(k_mlp_scales_h2, dim3(5), dim3(256), 0, (hipStream_t)stream, a, wsc);
+    rc_ = hl::check_launch("k_mlp_scales_h2");
+    if (rc_) return rc_;
     hipLaunchKernelGGL(k_pack_mlp_bwd_h2, dim3((NCH_BWD * CHUNK_FLOATS * 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a,
-                       reinterpret_cast<unsigned short *>(static_cast<float *>(packed) + NCH_BWD * CHUNK_FLOATS));
+                       reinterpret_cast<unsigned short *>(static_cast<float *>(packed) + NCH_BWD * CHUNK_FLOATS), wsc);
     return hl::check_launch("k_pack_mlp_bwd_h2");
 }
 

@@ -118,17 +118,53 @@ __device__ __forceinline__ void group_mean_rstd(const float *gt, int N, int n, i
     rstd = bad ? __builtin_nanf("") : (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// ---- power-of-two activation scales of the fp16x2 kernels (round 6) -------------------------------------------------------------------------
+// The two fp16 planes of an activation hold 2^-21 of it only while both are normal: 2^-3 <= |x| < 65504.  Below, the absolute error is 2^-25 - harmless
+// when the tensor's rms is O(1), 2^-15 of the rms for a tensor at 2^-10; above, the round-toward-zero conversion saturates without a trace.  So the
+// staging multiplies by a power of two sx chosen from a BOUND of the image's largest magnitude (exact; undone in the epilogue):
+//   * raw input: |x| <= sqrt(sum x^2), the sum taken from the group totals the tensor's producer(s) left (act_scale_totals);
+//   * behind a fused GroupNorm: |gamma' xhat + beta'| <= max|gamma'| sqrt(n_g) + max|beta'| (Cauchy-Schwarz over the group's n_g values; coef_to_lds).
+// |x sx| <= 32752, so a plane cannot overflow, and whatever the tensor's magnitude the planes keep their precision relative to that bound.
+__device__ __forceinline__ float pow2_scale_for_bound(float bound) {   // the power of two sx with bound * sx in (16376, 32752]; 1 when the bound is 0 / not finite
+    if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
+    const float r = 32752.f / bound;
+    unsigned e = __float_as_uint(r) >> 23;                           // (r > 0: no sign bit)
+    e = e < 27u ? 27u : (e > 227u ? 227u : e);                       // 2^-100 ... 2^100
+    return __uint_as_float(e << 23);
+}
+// every lane of the wave returns the same value; gt = [shard][N][32][2] totals of image n's tensor (any grouping), HW its pixels per image
+__device__ __forceinline__ float act_scale_totals(const float *gt, int N, int n, long HW) {
+    const int g = threadIdx.x & 31;
+    double Q = 0.0;
+    int bad = 0;
+    const int ns = stat_shards(HW);
+    for (int sh = 0; sh < ns; ++sh) {
+        const long long q = reinterpret_cast<const long long *>(gt)[(((long)sh * N + n) * 32 + g) * 2 + 1];
+        bad |= q < 0 || (unsigned long long)q >= STAT_POISON;
+        Q += (double)q;
+    }
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        Q += __shfl_xor(Q, d);
+        bad |= __shfl_xor(bad, d);
+    }
+    // (a poisoned / overflowed block says nothing about the magnitudes: scale 1, and the planes' own range decides)
+    return bad ? 1.f : pow2_scale_for_bound((float)sqrt(Q * (1.0 / STAT_SC_SQ)) * 1.0001f + 1e-30f);
+}
+
 // ---- consumer side: the affine of image n into LDS (sA[c], sB[c], c < C) ------------------------------------------------------------------
 // From the arrays (cA != null), or from the view's group totals + the norm's parameters (GnSrc): 32 threads read their group's pair(s) and
-// form (mean, rstd), every channel gets its (A, B) - the arithmetic of k_gn_coef_tot, bit for bit.  `scr` = 64 floats of LDS.  Call with all
-// threads; ends with a barrier.
-__device__ __forceinline__ void coef_to_lds(const float *cA, const float *cB, const GnSrc &gn, int N, int n, float *sA, float *sB, float *scr,
-                                            int tid, int nthr) {
+// form (mean, rstd), every channel gets its (A, B) - the arithmetic of k_gn_coef_tot, bit for bit.  `scr` = COEF_SCR_FLOATS floats of LDS.  Call
+// with all threads; ends with a barrier.  SCALE: the table is multiplied by the power of two sx that bounds the normalised tensor (above) and sx
+// is returned (1 with arrays: nothing is known about the tensor they normalise); the caller's activation and epilogue account for it.
+template <bool SCALE = false>
+__device__ __forceinline__ float coef_to_lds(const float *cA, const float *cB, const GnSrc &gn, int N, int n, float *sA, float *sB, float *scr,
+                                             int tid, int nthr) {
     const int C = gn.C;
     if (cA) {
         for (int c = tid; c < C; c += nthr) { sA[c] = cA[(long)n * C + c]; sB[c] = cB[(long)n * C + c]; }
         __syncthreads();
-        return;
+        return 1.f;
     }
     const int cg = C / 32;
     // (the parameters of the thread's first channel are requested together with the group totals: one round trip instead of two)
@@ -142,23 +178,38 @@ __device__ __forceinline__ void coef_to_lds(const float *cA, const float *cB, co
         group_mean_rstd(gn.gt, N, n, tid, gn.HW, cg, gn.eps, m, r);
         scr[tid] = m; scr[32 + tid] = r;
     }
+    if (SCALE && tid == 0) { scr[64] = 0.f; scr[65] = 0.f; }
     __syncthreads();
+    float gmax = 0.f, bmax = 0.f;                      // max |gamma'|, max |beta'| over this thread's channels
     for (int c = tid; c < C; c += nthr) {
         const int g = c / cg;
         const bool first = c == tid;
-        float a = scr[32 + g] * (first ? ga0 : gn.gamma[c]);
-        float b = (first ? be0 : gn.beta[c]) - scr[g] * a;
+        float ga = first ? ga0 : gn.gamma[c], be = first ? be0 : gn.beta[c];
+        float a = scr[32 + g] * ga;
+        float b = be - scr[g] * a;
         if (gn.emb) {
             const float sc = 1.f + (first ? sc0 : gn.emb[(long)n * gn.emb_pitch + c]);
             const float sf = first ? sf0 : gn.emb[(long)n * gn.emb_pitch + C + c];
             a = a * sc;
             b = b * sc + sf;
+            ga = ga * sc; be = be * sc + sf;
         }
         sA[c] = a;
         sB[c] = b;
+        if (SCALE) { gmax = fmaxf(gmax, fabsf(ga)); bmax = fmaxf(bmax, fabsf(be)); }
+    }
+    if (!SCALE) { __syncthreads(); return 1.f; }
+    // (non-negative floats order like their bit patterns)
+    atomicMax(reinterpret_cast<unsigned *>(scr + 64), __float_as_uint(gmax));
+    atomicMax(reinterpret_cast<unsigned *>(scr + 65), __float_as_uint(bmax));
+    __syncthreads();
+    const float sx = pow2_scale_for_bound(scr[64] * sqrtf((float)gn.HW * (float)cg) * 1.0001f + scr[65]);
+    if (sx != 1.f) {
+        for (int c = tid; c < C; c += nthr) { sA[c] *= sx; sB[c] *= sx; }
     }
     __syncthreads();
+    return sx;
 }
-constexpr int COEF_SCR_FLOATS = 64;
+constexpr int COEF_SCR_FLOATS = 68;
 
 }  // namespace hl

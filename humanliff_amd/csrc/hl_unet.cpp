@@ -519,6 +519,7 @@ struct Exec {
         a.splitk_ws = splitk_ws; a.splitk_ws_bytes = hl::conv_splitk_ws_bytes();
         a.act_ws = act_ws; a.act_ws_bytes = act_need * sizeof(float);
         a.stats = st1; a.stats2 = st2;
+        if (af.cA == nullptr && af.gn.gt == nullptr) a.in_stats = raw_totals(in);     // (a raw input: the fp16x2 kernels scale it by a power of two from its sum x^2)
         a.st_cg = pi1.viewC / 32; a.st_c0 = pi1.c0; a.st2_cg = pi2.viewC / 32; a.st2_c0 = pi2.c0;
         const size_t e0 = span_begin();
         size_t emid = 0;
@@ -543,6 +544,17 @@ struct Exec {
             stat_reg.erase(out.p);
             if (out2) stat_reg.erase(out2);
         }
+    }
+    // the group totals the producer(s) of x left, whatever view they were grouped for, if they cover exactly x's channels (both halves of a decoder
+    // "concat" when x is one): complete when a consumer of x runs, since it is ordered behind every producer of x
+    const float *raw_totals(const View &x) const {
+        auto it = stat_reg.find(x.p);
+        if (it == stat_reg.end() || it->second.c0 != 0) return nullptr;
+        if (it->second.covered == x.C) return it->second.buf;
+        auto it2 = stat_reg.find(x.p + it->second.covered);
+        if (it2 != stat_reg.end() && it2->second.buf == it->second.buf && it2->second.c0 == it->second.covered &&
+            it->second.covered + it2->second.covered == x.C) return it->second.buf;
+        return nullptr;
     }
     // force_arrays: the caller needs cA / cB in memory (gn_apply_3d)
     Aff coef(const View &x, const Norm &g, const float *emb, bool force_arrays = false) {
@@ -1057,6 +1069,11 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
         a.act_ws_bytes = act_bytes;
         used += (act_bytes + 255) / 256 * 256;
     }
+    float *tot_room = nullptr;
+    {
+        const size_t tb = (hl::conv_stats_floats(N, (long)H * W) * sizeof(float) + 255) / 256 * 256;
+        if (scratch_bytes >= used + tb) { tot_room = reinterpret_cast<float *>(static_cast<char *>(scratch) + used); used += tb; }
+    }
     if (scratch_bytes > used + (1u << 20)) {
         a.splitk_ws = reinterpret_cast<float *>(static_cast<char *>(scratch) + used);
         a.splitk_ws_bytes = scratch_bytes - used;
@@ -1088,6 +1105,11 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     if (rc) return rc;
     if (a.path != 5) a.w_h16 = nullptr;
     if (a.path != 6) a.w_h2 = nullptr;
+    if (a.path == 6 && !coefA && tot_room) {   // fp16x2 products on a raw input: its sum x^2 fixes the power-of-two scale of the activation planes (in the network the producers leave it)
+        rc = hl::tensor_totals(a.in, tot_room, (hipStream_t)stream);
+        if (rc) return rc;
+        a.in_stats = tot_room;
+    }
     rc = hl::conv2d(a, (hipStream_t)stream);
     if (stat_slots) *stat_slots = a.stat_slots;
     return rc;

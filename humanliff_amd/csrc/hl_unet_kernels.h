@@ -31,6 +31,8 @@ struct ConvArgs {
     const void *w_bf3;   // optional: the same weights split into three bf16 planes (conv_pack_weights_bf3); selects k_conv_bf3
     int bf16_single;     // with w_bf3: 1 = HL_CONV_BF16 (activations rounded to bf16 x the weights' two leading bf16 planes), 0 = bf16x3 emulation
     const void *w_h2;    // optional (1x1 layers): two fp16 planes in MFMA-fragment order (conv_pack_weights_h2); selects k_conv1_h2 where it fills the chip
+    const float *in_stats; // optional: the group totals the producer(s) of `in` left for ANY view that covers it (conv_stats_floats(N, in.H * in.W) floats, complete
+                         // when this launch starts): the fp16x2 kernels derive the power-of-two scale of the raw input from sum x^2 (ConvK::xs_gt); null: scale 1
     const void *w_h16;   // optional: 16-bit weights in MFMA-fragment order (conv_pack_weights_h16); selects k_conv_h16 where conv_h16_applies
     int h16_fp16;        // with w_h16: 1 = fp16 operands (HL_CONV_FP16), 0 = bf16 (HL_CONV_BF16)
     const float *w_wino; // optional: Winograd-domain weights (conv_pack_weights_wino); selects k_conv_wino for large 3x3 layers
@@ -92,6 +94,13 @@ struct ConvK {
     int st1_cg, st1_c0, st2_cg, st2_c0;
     float *st1, *st2;
     int in16;          // k_conv_h16 / k_conv1_h16: `in` holds 16-bit values (the GroupNorm pass wrote them), in_pitch counts them
+    // fp16x2 kernels (round 6: the split products are scale-invariant).  wsc: [Cout] inverse power-of-two scales of the weight planes (conv_h2_wscale) - the
+    // epilogue multiplies the accumulators by them.  xs_gt: group totals of the raw INPUT tensor (the block its producer(s) left, ConvArgs::in_stats) or null:
+    // the staging multiplies the input by the power of two sx with |x| sx <= sqrt(sum x^2) sx <= 32752 (no overflow of the fp16 planes, and the low plane stays
+    // normal for values down to 2^-11 of the image's largest possible), the epilogue by 1 / sx; a fused GroupNorm takes its sx from the coefficient bound instead.
+    const float *wsc;
+    const float *xs_gt;
+    int xs_hw;         // pixels per image of the tensor the totals belong to (fixes the number of shards)
 };
 
 // k_conv_wino4w (hl_conv_wino4w.hip): Winograd F(4x4,3x3) with 64 output channels per workgroup, one wave per SIMD, 18 accumulator
@@ -110,6 +119,7 @@ int conv_h16_launch(const ConvK &p, int f16, hipStream_t st, int splits = 1);
 bool conv1_h2_applies(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int ups);
 size_t conv_packed_h2_bytes(int Cout, int Cin_pad, int ks);
 int conv_pack_weights_h2(const float *w_oihw, int Cout, int Cin, int Cin_pad, int ks, void *packed, hipStream_t st, int tf = 0);
+const float *conv_h2_wscale(const void *packed, int Cout, int Cin_pad, int ks);   // the [Cout] inverse scales behind the planes (ConvK::wsc)
 int conv1_h2_launch(const ConvK &p, hipStream_t st);
 int conv1_h2s_launch(const ConvK &p, hipStream_t st, int splits = 1);               // the same on 128-pixel tiles, two workgroups per CU (p.n_mtiles = pixels / 128)
 bool conv3_h2d_applies(int Hout, int Wout, int Cin, int Cout);        // 3x3 / stride 2 with fp16x2 products (k_conv_h2d)
@@ -124,6 +134,8 @@ void set_h16_min_blocks(long v);   // developer / test switch: workgroups from w
 constexpr int stat_shards(long HW) { return HW >= 4096 ? 8 : 1; }
 constexpr size_t conv_stats_floats(int N, long HW) { return (size_t)stat_shards(HW) * N * 32 * 4; }
 size_t conv_splitk_ws_bytes();
+// totals (conv_stats_floats(x.N, x.H * x.W) floats, zeroed here) of a tensor nobody left totals for: what ConvArgs::in_stats wants (the single-op entry points)
+int tensor_totals(const View &x, float *totals, hipStream_t st);
 int conv2d(const ConvArgs &a, hipStream_t st);
 size_t conv_packed_floats(int Cout, int Cin_pad, int ks);
 // tf = 1: the source is laid out (Cin, Cout, ks, ks) and is read flipped and channel-transposed (backward-data weights)

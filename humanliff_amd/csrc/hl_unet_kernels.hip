@@ -1734,16 +1734,13 @@ __global__ void k_gn_apply(const float *__restrict__ x, long pitch, long pixels_
     }
 }
 
-// the two fp16 planes of four values (fp16x2 products, hl_conv_h16.hip: h0 = the value with its low 13 mantissa bits cleared - exact in fp16 inside
-// its range -, h1 = the truncated residual): image [plane][pixel][C]
+// the two fp16 planes of four values (fp16x2 products, split_h2 of hl_conv_h16.hip: h0 = the nearest fp16, h1 = the nearest fp16 of the residual): image [plane][pixel][C]
 __device__ __forceinline__ void store_h2_planes(unsigned short *y, long at, long plane, const f32x4 o) {
     unsigned q0[2], q1[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float a = o[2 * k], b = o[2 * k + 1];
-        const float ha = __builtin_bit_cast(float, __float_as_uint(a) & 0xffffe000u), hb = __builtin_bit_cast(float, __float_as_uint(b) & 0xffffe000u);
-        q0[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ha, hb));
-        q1[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - ha, b - hb));
+        hl_split2_rne(a, b, q0[k], q1[k]);
     }
     *reinterpret_cast<uint2 *>(y + at) = uint2{q0[0], q0[1]};
     *reinterpret_cast<uint2 *>(y + plane + at) = uint2{q1[0], q1[1]};
@@ -2153,6 +2150,29 @@ __global__ __launch_bounds__(64) void k_gn_coef_tot(const float *__restrict__ gt
     }
 }
 
+// Totals of a tensor nobody left totals for (the single-convolution entry points): sum and sum of squares of image blockIdx.y's values, every
+// workgroup adding its slice to "group" blockIdx.x & 31 - the fp16x2 kernels only need the image's sum x^2 (act_scale_totals), any grouping serves.
+__global__ __launch_bounds__(256) void k_tensor_totals(const float *__restrict__ x, long pitch, long HW, int C, float *__restrict__ st) {
+    __shared__ float rs[256], rq[256];
+    const int n = blockIdx.y, N = gridDim.y;
+    const long per = (HW + gridDim.x - 1) / gridDim.x, p0 = (long)blockIdx.x * per, p1 = p0 + per < HW ? p0 + per : HW;
+    float s = 0.f, q = 0.f;
+    const int c4 = C / 4;
+    for (long i = (p0 * c4) + threadIdx.x; i < p1 * c4; i += 256) {
+        const long pix = i / c4;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((long)n * HW + pix) * pitch + (i - pix * c4) * 4);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+        q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    rs[threadIdx.x] = s; rq[threadIdx.x] = q;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) { rs[threadIdx.x] += rs[threadIdx.x + d]; rq[threadIdx.x] += rq[threadIdx.x + d]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && p1 > p0) stat_add(st, N, n, blockIdx.x & 31, HW, rs[0], rq[0]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // small-batch linear: one wave per output row
 // ---------------------------------------------------------------------------------------------
@@ -2307,14 +2327,15 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attention(const float *__restri
 // loop: K rows go straight from global memory into the MFMA A operand (lane = key, the two halves of the wave take
 // alternate groups of 4 channels; Q is loaded with the same permutation), V tiles are staged in a wave-private LDS
 // region, and with PF the next tile's K and V are in flight (registers) while the current one is multiplied.
-// eight values (two f32x4, scaled by `sc`) -> the two fp16 planes of one 32x32x16 operand (h0 = the value with its low 13 mantissa bits cleared, h1 = the truncated residual)
+// eight values (two f32x4, scaled by `sc`) -> the two fp16 planes of one 32x32x16 operand (round 6: h0 = the nearest fp16, h1 = the nearest fp16 of the residual - split_h2 of
+// hl_conv_h16.hip: 2^-24 while both planes are normal, and a value beyond fp16's range becomes inf / NaN instead of saturating)
 __device__ __forceinline__ void att_split8(const f32x4 a, const f32x4 b, float sc, u32x4 &p0, u32x4 &p1) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float x = (q < 2 ? a[2 * q] : b[2 * q - 4]) * sc, y = (q < 2 ? a[2 * q + 1] : b[2 * q - 3]) * sc;
-        const float hx = __builtin_bit_cast(float, __float_as_uint(x) & 0xffffe000u), hy = __builtin_bit_cast(float, __float_as_uint(y) & 0xffffe000u);
-        p0[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hx, hy));
-        p1[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy));
+        unsigned w0, w1;
+        hl_split2_rne(x, y, w0, w1);
+        p0[q] = w0; p1[q] = w1;
     }
 }
 typedef _Float16 att_f16x8 __attribute__((ext_vector_type(8)));
@@ -3030,6 +3051,8 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     if (h3d) {
         a.path = 6;
         p.in16 = 0; p.w_bf3 = a.w_h2; p.partial = nullptr;
+        p.wsc = conv_h2_wscale(a.w_h2, a.Cout, a.in.C, a.ks);
+        p.xs_gt = a.in_stats; p.xs_hw = a.in.H * a.in.W;
         p.n_nblocks = a.Cout / 192;
         p.n_mtiles = (int)((long)a.out.N * a.out.H * a.out.W / 128);
         if (a.stats) {
@@ -3063,6 +3086,8 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             if (a.ev_mid) { hipEventRecord(a.ev_mid, st); a.ev_mid_used = 1; }
         }
         p.w_bf3 = a.w_h2;
+        p.wsc = conv_h2_wscale(a.w_h2, a.Cout, a.in.C, a.ks);
+        if (mode == 0) { p.xs_gt = a.in_stats; p.xs_hw = a.in.H * a.in.W; }      // (raw input; a fused GroupNorm bounds its own output)
         splits = h3_splits;
         p.kt_per = (a.in.C / 32 + splits - 1) / splits;                  // chunks of 32 input channels per slab
         splits = (a.in.C / 32 + p.kt_per - 1) / p.kt_per;
@@ -3108,6 +3133,8 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
             if (a.ev_mid) { hipEventRecord(a.ev_mid, st); a.ev_mid_used = 1; }
         }
         p.w_bf3 = a.w_h2; p.in16 = 0; p.partial = nullptr;
+        p.wsc = conv_h2_wscale(a.w_h2, a.Cout, a.in.C, a.ks);
+        if (mode == 0) { p.xs_gt = a.in_stats; p.xs_hw = a.in.H * a.in.W; }
         p.n_nblocks = a.Cout / 192;
         p.n_mtiles = (int)(M / 256);
         if (a.stats) {   // statistics from the epilogue (128 pixels of one image per round)
@@ -3306,6 +3333,15 @@ int gn_apply(const View &x, const float *cA, const float *cB, int act, float *y,
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, x.p, x.pitch, (long)x.H * x.W, npix, x.C, cA, cB, act, y);
     return check_launch("k_gn_apply");
+}
+
+int tensor_totals(const View &x, float *totals, hipStream_t st) {
+    HL_REQUIRE(x.p && totals && x.C % 4 == 0 && x.pitch % 4 == 0, "tensor_totals: bad argument");
+    const long HW = (long)x.H * x.W;
+    if (hipMemsetAsync(totals, 0, conv_stats_floats(x.N, HW) * sizeof(float), st) != hipSuccess) return fail(HL_ERR_RUNTIME, "tensor_totals: memset");
+    const unsigned gx = (unsigned)std::min<long>(256, std::max<long>(1, HW * x.C / 16384));      // (>= 16 K values per workgroup: a contribution stays far below the capacity for sane inputs)
+    hipLaunchKernelGGL(k_tensor_totals, dim3(gx, (unsigned)x.N), dim3(256), 0, st, x.p, x.pitch, HW, x.C, totals);
+    return check_launch("k_tensor_totals");
 }
 
 int groupnorm_coef_stats(const View &x, const float *gt, const float *gamma, const float *beta, const float *emb,

@@ -18,7 +18,10 @@ class _Bare:
         self.core = core
 
     def __getattr__(self, name):            # (test, uniforms_on_device, cpu_uniforms_on_host ...: the module's own switches)
-        return getattr(self.__dict__["core"], name)
+        core = self.__dict__.get("core")
+        if core is None:                    # (copy / pickle look attributes up on an instance whose __init__ has not run: AttributeError, not KeyError)
+            raise AttributeError(name)
+        return getattr(core, name)
 
     def render(self, tp_input, world_pts, z_vals, rays_o, rays_d, near, far, tri_planes, n_importance=128, white_bkgd=False, **kw):
         from ..NeRF.renderer import Renderer as _Renderer

@@ -45,8 +45,17 @@ def _gen(seed):
     return g
 
 
-def render_mlp_state(seed=3, gain=1.0):
-    """Deterministic render-MLP parameters keyed like the reference state_dict."""
+# per-layer powers of two for the WEIGHTS (biases untouched) of the range fixtures render_d / render_e: small and large layers alternate, so the network stays a
+# non-trivial function while its weights sit 2^-8 below / 2^4 above nn.Linear's initialisation
+LAYER_EXP = {
+    "d": {"pts_linears.0": -8, "pts_linears.1": 4, "pts_linears.2": 4, "feature_linear": -8, "views_linear": 4},    # (pre-activations of pts_linears.2 reach ~100: F.softplus's x > 20 branch)
+    "e": {"pts_linears.0": 4, "pts_linears.1": -8, "pts_linears.2": 4, "feature_linear": -8, "views_linear": 4},
+    "f": {"feature_linear": 8, "views_linear": -8},                                                              # (views_linear small behind a large linear layer)
+}
+
+
+def render_mlp_state(seed=3, gain=1.0, layer_exp=None):
+    """Deterministic render-MLP parameters keyed like the reference state_dict.  layer_exp: {layer: k} multiplies that layer's weight by 2^k."""
     out = {}
     fan_in = {}
     for name, shape in RENDER_MLP_SHAPES:
@@ -57,6 +66,8 @@ def render_mlp_state(seed=3, gain=1.0):
         stem = name.rsplit(".", 1)[0]
         bound = gain / math.sqrt(fan_in[stem])
         t = (torch.rand(shape, generator=_gen(seed * 1000 + i)) * 2 - 1) * bound
+        if layer_exp and name.endswith("weight") and stem in layer_exp:
+            t = t * (2.0 ** layer_exp[stem])
         out[name] = t.float()
     return out
 

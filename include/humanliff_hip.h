@@ -77,9 +77,12 @@ int hl_planes_pack(const float *planes, int H, int W, void *packed, void *stream
                                         EXACT three-way bf16 split of both operands - six partial products on v_mfma_f32_32x32x16_bf16, fp32
                                         accumulation, dropped terms < 2^-24 |a b| (k_march_b3); an fp32-tolerance mode, not a reduced-precision one */
 
-#define HL_RENDER_MLP_FP16X2 64u     /* the same pipeline with TWO fp16 planes per operand (x = h0 + h1 to 2^-20 |x|; weights nearest-even, 2^-22) and the three
-                                        partial products h0 w0 + h0 w1 + h1 w0 on v_mfma_f32_32x32x16_f16, fp32 accumulation (k_march_plw<2>): half the
-                                        matrix instructions of BF16X3 at the same fp32-class error against the reference's renders; values < 65504 */
+#define HL_RENDER_MLP_FP16X2 64u     /* the same pipeline with TWO fp16 planes per operand (activations x = h0 + h1 to 2^-20 |x| while 2^-3 <= |x| < 65504, absolute 2^-24
+                                        below; weights: every layer's planes are those of 2^k W with max |2^k W| in [2^12, 2^13) - nearest-even, 2^-22 of the layer's
+                                        largest weight WHATEVER its magnitude (round 6; the accumulators are multiplied by 2^-k on their way into the softplus) - and
+                                        the three partial products h0 w0 + h0 w1 + h1 w0 on v_mfma_f32_32x32x16_f16, fp32 accumulation (k_march_plw<2>): half the
+                                        matrix instructions of BF16X3 at the same fp32-class error against the reference's renders (goldens a ... f: weights from
+                                        2^-8 below to 2^4 above nn.Linear's initialisation); softplus returns x beyond a pre-activation of 88.7 like F.softplus */
 
 size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
 
@@ -329,10 +332,17 @@ int hl_unet_set_overlap(void *handle, int enable);
  *   smaller levels, everything else the direct implicit GEMM.  Round 5: every 3x3 / stride-1 layer (also behind the nearest-x2 upsample) and every
  *   1x1 / stride-1 layer with Cout a multiple of 192, Cin a multiple of 32 / 96 and enough work (3x3: from 8 workgroups' worth of 256 pixels x 192
  *   channels, split-K below 100; 1x1: from 12) is a DIRECT convolution whose fp32 products come from TWO fp16 planes per operand on
- *   v_mfma_f32_32x32x16_f16 (k_conv_h2s, k_conv1_h2s: 8x16-pixel / 128-pixel tiles, two workgroups per CU): activation x = h0 + h1 (h0 = x with its
- *   low 13 mantissa bits cleared, h1 = the truncated residual: |x - h0 - h1| < 2^-20 |x|), weight planes nearest even (2^-22),
- *   h1 w0 + h0 w1 + h0 w0 accumulated in fp32 - error of the fp32 direct kernel's class, checked against float64 (tests/test_unet_gpu.py: rel-L2
- *   3e-7 ... 1.2e-6 against 2e-7 ... 6e-7 of HL_CONV_FP32_DIRECT); range |x| < 65504.  A GroupNorm (+ SiLU) in front of such a layer is applied
+ *   v_mfma_f32_32x32x16_f16 (k_conv_h2s, k_conv1_h2s: 8x16-pixel / 128-pixel tiles, two workgroups per CU): activation x = h0 + h1 (h0 = the nearest
+ *   fp16, h1 = the nearest fp16 of the residual: |x - h0 - h1| <= 2^-23 |x| while both planes are normal), weight planes nearest even,
+ *   h1 w0 + h0 w1 + h0 w0 accumulated in fp32.  Round 6 - the planes are SCALE-INVARIANT: every output channel's weights are multiplied by the power of
+ *   two that puts the channel's largest |w| into [2^13, 2^14) before the split (2^-22 of it whatever the magnitude: zero_module convolutions at 1e-4,
+ *   unet.py:149, lose nothing), and the staged input by the power of two sx with |x| sx <= 32752 - from sqrt(sum x^2) of the tensor (the group totals
+ *   its producers left; the single-op entry points form them) for a raw input, from max|gamma'| sqrt(n_group) + max|beta'| behind a fused GroupNorm -
+ *   so no plane overflows or goes subnormal where the magnitude is known; both scales leave in the epilogue (powers of two: exact).  Unknown magnitude
+ *   (a GroupNorm given as coefficient arrays, the attention output in front of proj_out): sx = 1, and a value beyond fp16's range becomes inf / NaN
+ *   (round 5 saturated silently).  Error of the fp32 direct kernel's class at EVERY scale, checked against float64 with weights x 2^0 ... 2^-18 and
+ *   activations x 2^-10 ... 2^10 (tests/test_unet_gpu.py::test_conv_fp16x2_products_are_scale_invariant: rel-L2 2.2e-7 ... 6.4e-7 against 2.0e-7 ...
+ *   7.3e-7 of HL_CONV_FP32_DIRECT, bit-identical across the scales).  A GroupNorm (+ SiLU) in front of such a layer is applied
  *   while the kernel stages its input (no pass over the tensor).  The F(4x4,3x3) / F(2x2,3x3) kernels keep the layers the direct kernels do not
  *   take (the 27-channel input convolution, Cout not a multiple of 192, small single-op calls).
  * HL_CONV_FP32_MFMA: HL_CONV_FP32 without those two kernels - every product on v_mfma_f32_32x32x2_f32 (the default of rounds 3-4).

@@ -23,9 +23,15 @@ xc = torch.zeros_like(x0)
 y = torch.zeros((B,), dtype=torch.int64, device=dev)
 
 
+if twin:      # the torch-autograd statement of the forward lives with the tests since round 5 (tests/unet_autograd_twin.py)
+    import functools
+    from tests.unet_autograd_twin import forward_autograd
+    twin_forward = functools.partial(forward_autograd, model)
+
+
 def step():
     t = torch.randint(0, 1000, (B,), device=dev, generator=g)
-    loss = diffusion.training_losses(model.forward_autograd if twin else model, x0, xc, t, model_kwargs={"y": y})["loss"].mean()
+    loss = diffusion.training_losses(twin_forward if twin else model, x0, xc, t, model_kwargs={"y": y})["loss"].mean()
     loss.backward()
     opt.step()
     opt.zero_grad(set_to_none=True)

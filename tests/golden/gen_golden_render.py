@@ -82,7 +82,7 @@ def ref_render(r, planes, bounds, rays_o, rays_d, near, far, n_samples, n_import
     return out, caught
 
 
-def case(name, plane_hw, img_hw, view, n_views, n_samples, n_importance, white_bkgd, mlp_gain=1.0, ray_slice=None):
+def case(name, plane_hw, img_hw, view, n_views, n_samples, n_importance, white_bkgd, mlp_gain=1.0, ray_slice=None, layer_exp=None):
     planes = syn.triplane(seed=11, H=plane_hw, W=plane_hw)
     bounds = torch.tensor(syn.WORLD_BOUNDS)
     rays_o, rays_d, near, far = syn.orbit_rays(view, n_views, img_hw, img_hw)
@@ -91,8 +91,8 @@ def case(name, plane_hw, img_hw, view, n_views, n_samples, n_importance, white_b
         rays_o, rays_d, near, far = rays_o[sl], rays_d[sl], near[sl], far[sl]
     Rn = rays_o.shape[0]
     r, sd = build_renderer(3)
-    if mlp_gain != 1.0:
-        sd = syn.render_mlp_state(3, gain=mlp_gain)
+    if mlp_gain != 1.0 or layer_exp:
+        sd = syn.render_mlp_state(3, gain=mlp_gain, layer_exp=syn.LAYER_EXP[layer_exp] if layer_exp else None)
         r.load_state_dict(sd, strict=False)
     u = syn.importance_u(Rn, n_importance, seed=5)
     torch.manual_seed(5)
@@ -111,7 +111,7 @@ def case(name, plane_hw, img_hw, view, n_views, n_samples, n_importance, white_b
     np.savez_compressed(
         os.path.join(HERE, f"render_{name}.npz"),
         plane_hw=plane_hw, img_hw=img_hw, view=view, n_views=n_views, n_samples=n_samples,
-        n_importance=n_importance, white_bkgd=int(white_bkgd), mlp_gain=mlp_gain,
+        n_importance=n_importance, white_bkgd=int(white_bkgd), mlp_gain=mlp_gain, layer_exp=layer_exp or "",
         ray_slice=np.array(ray_slice if ray_slice is not None else [0, Rn]),
         planes_ck=np.array(checksum(planes)), rays_ck=np.array(checksum(rays_d)), u_ck=np.array(checksum(u)),
         w_ck=np.array(checksum(torch.cat([v.flatten() for v in sd.values()]))),
@@ -172,3 +172,8 @@ if __name__ == "__main__":
     # c: sharper densities (MLP weights x3) so transmittance actually saturates; ragged ray count (R=77)
     case("c", plane_hw=32, img_hw=16, view=20, n_views=36, n_samples=32, n_importance=32, white_bkgd=False,
          mlp_gain=3.0, ray_slice=(90, 167))
+    # d, e, f (round 6): the range of the MLP's weights - layers 2^-8 below and 2^4 above nn.Linear's initialisation in three patterns (syn.LAYER_EXP), biases as they are:
+    # what pins the scaled fp16 weight planes of the default product mode (k_mlp_scales_h2) to the reference
+    case("d", plane_hw=64, img_hw=16, view=5, n_views=36, n_samples=32, n_importance=32, white_bkgd=False, layer_exp="d")
+    case("e", plane_hw=64, img_hw=16, view=7, n_views=36, n_samples=32, n_importance=32, white_bkgd=False, layer_exp="e")
+    case("f", plane_hw=64, img_hw=16, view=9, n_views=36, n_samples=32, n_importance=32, white_bkgd=False, layer_exp="f")

@@ -24,7 +24,8 @@ def load_render_case(name):
     rays_o, rays_d, near, far = rays_o[a:b], rays_d[a:b], near[a:b], far[a:b]
     n_imp = int(g["n_importance"])
     u = syn.importance_u(rays_o.shape[0], n_imp, seed=5)
-    mlp = syn.render_mlp_state(3, gain=float(g["mlp_gain"]))
+    lexp = str(g["layer_exp"]) if "layer_exp" in g.files else ""
+    mlp = syn.render_mlp_state(3, gain=float(g["mlp_gain"]), layer_exp=syn.LAYER_EXP[lexp] if lexp else None)
     # the fixture pins the inputs too: any drift in the seeded generators is caught here
     assert np.allclose(checksum(planes), g["planes_ck"], rtol=0, atol=1e-6)
     assert np.allclose(checksum(rays_d), g["rays_ck"], rtol=0, atol=1e-6)

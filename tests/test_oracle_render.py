@@ -57,7 +57,7 @@ def test_importance_sampling_matches_sample_pdf(units):
     assert (s - torch.from_numpy(units["pdf_samples"])).abs().max() < 1e-6
 
 
-@pytest.mark.parametrize("name", ["a", "b", "c"])
+@pytest.mark.parametrize("name", ["a", "b", "c", "d", "e", "f"])
 def test_full_render_matches_reference(name):
     i, e = load_render_case(name)
     rgb, acc, depth, aux = ro.render_rays(i["mlp"], i["planes"][0], i["bounds"], i["rays_o"], i["rays_d"], i["near"],

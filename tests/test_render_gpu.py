@@ -45,9 +45,11 @@ def hip_render(i, dev, z_vals=None, mlp_fp16=False, products=None):
 
 
 @pytest.mark.parametrize("products", PRODUCTS)
-@pytest.mark.parametrize("name", ["a", "b", "c"])
+@pytest.mark.parametrize("name", ["a", "b", "c", "d", "e", "f"])
 def test_render_matches_reference_golden(name, products, dev):
-    """All three product modes against the REFERENCE's renders with the same bounds (fp16x2: two fp16 planes per operand, 2^-20; bf16x3: exact splits, dropped terms below one fp32 rounding)."""
+    """All three product modes against the REFERENCE's renders with the same bounds (fp16x2: two fp16 planes per operand, 2^-20; bf16x3: exact splits, dropped terms below one fp32 rounding).
+    Cases d, e, f (round 6): the MLP's layers 2^-8 below / 2^4 above nn.Linear's initialisation (syn.LAYER_EXP) - the range of the weights, which the scaled fp16 planes
+    (k_mlp_scales_h2) must not care about; d also reaches F.softplus's x > 20 branch (pre-activations ~100: the log2-domain softplus's med3)."""
     i, e = load_render_case(name)
     r, out = hip_render(i, dev, products=products)
     assert r.mlp_products == products
@@ -56,7 +58,8 @@ def test_render_matches_reference_golden(name, products, dev):
     tiles = (R + 31) // 32
     rec = r._ws.cpu()[:tiles * N * 32 * 4].reshape(tiles, N, 32, 4)
     sigma = rec[..., 0].permute(0, 2, 1).reshape(tiles * 32, N)[:R]
-    assert (sigma - e["sigma_coarse"]).abs().max() < 2e-5          # raw densities, |sigma| ~ 1
+    # raw densities: 2e-5 while |sigma| <= 4 (cases a, b, c, e, f), relative beyond (case d, syn.LAYER_EXP: |sigma| up to 12.9 - measured 2.1e-5 / 2.0e-5 / 1.3e-5 in the three modes)
+    assert (sigma - e["sigma_coarse"]).abs().max() < 5e-6 * max(4.0, float(e["sigma_coarse"].abs().max()))
     assert (out["rgb_map"] - e["rgb"]).abs().max() < 2e-5          # colours in [0,1]
     assert (out["acc_map"] - e["acc"]).abs().max() < 2e-5
     assert (out["depth_map"] - e["depth"]).abs().max() < 5e-5

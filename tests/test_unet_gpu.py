@@ -636,3 +636,87 @@ def test_conv3x3_stride2_fp16x2_products_match_float64(N, H, W, C, Cout):
     assert not torch.equal(out, out32)                      # the default mode really took another kernel
     assert e2 < 6e-6 * max(1.0, scale) * (9 * C / 384) ** 0.5, (e2, scale)
     assert l2 < 1.6e-6 and l2 < 4 * l32 + 2e-7, (l2, l32)
+
+
+_SCALE_CASES = [(0, 0), (-6, 0), (-12, 0), (-18, 0), (0, -10), (0, -5), (0, 5), (0, 10), (-12, -10), (-18, 10), (6, -10)]
+
+
+@pytest.mark.parametrize("kind,N,H,W,C,Cout,gn", [("3x3", 4, 64, 64, 384, 384, False), ("3x3", 1, 128, 128, 192, 192, True), ("1x1", 4, 64, 64, 384, 192, False),
+                                                  ("1x1", 2, 64, 64, 384, 1152, True), ("s2", 2, 128, 128, 96, 192, False), ("3x3k", 4, 32, 32, 384, 384, False)])
+def test_conv_fp16x2_products_are_scale_invariant(kind, N, H, W, C, Cout, gn):
+    """Round 6: the split products of the DEFAULT mode must not depend on the magnitude of their operands.  fp16 has a 5-bit
+    exponent; the weight planes are scaled per output channel by a power of two at pack time (k_wscale_h2) and a raw input by the power of two that its
+    producers' sum x^2 bounds (act_scale_totals; the single-op entry point forms the totals itself), both undone exactly in the epilogue.  One float64
+    reference per shape: scaling the weights by 2^a and the input by 2^b scales it (and the fp32 direct kernel's result) exactly, so every (a, b) is
+    judged against the SAME numbers: rel-L2 of the fp16x2 kernel <= 1.3 x the fp32 direct kernel's + 5e-8 at every scale - the unscaled planes of
+    round 5 gave 4.6e-5 at 2^-6 and 2.9e-3 at 2^-12 on the weights, 2e-5 at 2^-10 on the activations.  With a GroupNorm given as coefficient ARRAYS (gn) nothing
+    is known about the normalised tensor's magnitude, so only the weights are scaled there; '3x3k' is the split-K dispatch (raw slabs scaled before they
+    are summed)."""
+    from humanliff_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(N + C + Cout + H)
+    ks, stride = (1, 1) if kind == "1x1" else (3, 2 if kind == "s2" else 1)
+    x = torch.randn((N, H, W, C), generator=g) * 1.5
+    w = torch.randn((Cout, C, ks, ks), generator=g) / (ks * ks * C) ** 0.5
+    w = w * torch.exp2(torch.randint(-6, 1, (Cout, 1, 1, 1), generator=g).float())        # channels of different magnitude inside one layer
+    b = torch.randn(Cout, generator=g) * 0.1
+    cA, cB = torch.rand((N, C), generator=g) + 0.5, torch.randn((N, C), generator=g) * 0.1
+    act = 1 if (gn and ks == 3) else 0
+    xin = x * cA[:, None, None, :] + cB[:, None, None, :] if gn else x
+    if act:
+        xin = F.silu(xin.to(dev)).cpu()
+    elif gn:
+        xin = xin.to(dev).cpu()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = F.conv2d(xin.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=stride, padding=ks // 2).permute(0, 2, 3, 1)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    scratch = torch.empty(Cout * C * ks * ks * 8 + 256 + (64 << 20) + N * H * W * C, device=dev)
+    rows = []
+    for a, bx in _SCALE_CASES:
+        if gn and bx != 0:
+            continue
+        sw, sx = 2.0 ** a, 2.0 ** bx
+        xd, wd, bd = (x * sx).to(dev), (w * sw).to(dev), (b * (sw * sx)).to(dev)
+        ad, bd2 = cA.to(dev), (cB * 1.0).to(dev)
+        outs = {}
+        for mode in (_lib.HL_CONV_FP32, _lib.HL_CONV_FP32_DIRECT):
+            out = torch.zeros((N, Ho, Wo, Cout), device=dev)
+            _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(xd), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Cout, ks, stride, 0, _lib.ptr(ad) if gn else None,
+                                             _lib.ptr(bd2) if gn else None, act, None, _lib.ptr(out), _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()),
+                       "hl_conv2d_nhwc_mode")
+            outs[mode] = out.cpu().double() / (sw * sx)
+        out, out32 = outs[_lib.HL_CONV_FP32], outs[_lib.HL_CONV_FP32_DIRECT]
+        assert not torch.equal(out, out32)                  # the default mode really took the fp16x2 kernel
+        l2, l32 = float((out - ref).norm() / ref.norm()), float((out32 - ref).norm() / ref.norm())
+        rows.append((a, bx, l2, l32))
+    print(f"{kind} {C}->{Cout} @{Ho}x{Wo} N{N} gn={gn}: " + "; ".join(f"w 2^{a} x 2^{bx}: {l2:.2e} (fp32 {l32:.2e})" for a, bx, l2, l32 in rows))
+    for a, bx, l2, l32 in rows:
+        assert l2 <= 1.3 * l32 + 5e-8, (a, bx, l2, l32)
+
+
+def test_conv_fp16x2_activations_beyond_fp16_range_match_fp32():
+    """|x| = 7e4 is beyond fp16 (65504): round 5's planes saturated silently (v_cvt_pkrtz never produces inf).  The raw input is now scaled by the power of two that
+    sqrt(sum x^2) bounds, so the same launch matches the float64 reference like the fp32 direct kernel does."""
+    from humanliff_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(77)
+    N, H, W, C, Cout = 2, 64, 64, 384, 192
+    x = torch.randn((N, H, W, C), generator=g) * 1.5
+    x[0, 3, 5, 7] = 7.0e4; x[1, 60, 2, 300] = -9.0e4; x[0, 0, 0, 0] = 6.6e4
+    w = torch.randn((Cout, C, 1, 1), generator=g) / C ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = torch.einsum("nhwc,oc->nhwo", x.double(), w[:, :, 0, 0].double()) + b.double()
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    scratch = torch.empty(Cout * C * 8 + 256 + (16 << 20), device=dev)
+    outs = {}
+    for mode in (_lib.HL_CONV_FP32, _lib.HL_CONV_FP32_DIRECT):
+        out = torch.zeros((N, H, W, Cout), device=dev)
+        _lib.check(L.hl_conv2d_nhwc_mode(mode, _lib.ptr(xd), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Cout, 1, 1, 0, None, None, 0, None, _lib.ptr(out), _lib.ptr(scratch),
+                                         scratch.numel() * 4, _lib.stream_ptr()), "hl_conv2d_nhwc_mode")
+        outs[mode] = out.cpu().double()
+    out, out32 = outs[_lib.HL_CONV_FP32], outs[_lib.HL_CONV_FP32_DIRECT]
+    assert not torch.equal(out, out32) and bool(torch.isfinite(out).all())
+    l2, l32 = float((out - ref).norm() / ref.norm()), float((out32 - ref).norm() / ref.norm())
+    big = float((out[0, 3, 5] - ref[0, 3, 5]).abs().max() / ref[0, 3, 5].abs().max())
+    print(f"|x| up to 9e4: fp16x2 rel-L2 {l2:.2e}, fp32 direct {l32:.2e}; pixel with 7e4: rel max {big:.2e}")
+    assert l2 <= 1.3 * l32 + 5e-8 and big < 2e-6, (l2, l32, big)
