@@ -226,7 +226,9 @@ class Renderer(nn.Module):
             fp16 = bool(getattr(self, "mlp_fp16", False))
             # explicit precedence: the opt-in fp16-operand kernel first; the bf16x3 products only in the evaluate-once schedule (the re-evaluating
             # one exists on the fp32-MFMA kernel alone)
+            # (Renderer.four_launch, a developer / test switch: rounds 2-5's evaluate / k_importance / evaluate / k_composite schedule instead of the two-launch one-pass form)
             flags = self._depth_flags | (_lib.HL_RENDER_WHITE_BKGD if white_bkgd else 0) | (_lib.HL_RENDER_REEVALUATE if reevaluate else 0) | \
+                (_lib.HL_RENDER_FOUR_LAUNCH if getattr(self, "four_launch", False) else 0) | \
                 (_lib.HL_RENDER_MLP_FP16 if fp16 else (0 if reevaluate else {"bf16x3": _lib.HL_RENDER_MLP_BF16X3, "fp16x2": _lib.HL_RENDER_MLP_FP16X2}.get(products, 0)))
             f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
             for b in range(bs):

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("HL_LIB_PATH") or os.path.join(_HERE, "libhumanliff_hi
 HL_RENDER_MLP_FP16 = 16
 HL_RENDER_MLP_BF16X3 = 32
 HL_RENDER_MLP_FP16X2 = 64
+HL_RENDER_FOUR_LAUNCH = 128
 HL_CONV_FP32 = 0
 HL_CONV_BF16X3 = 1
 HL_CONV_FP32_F23 = 3

@@ -183,6 +183,13 @@ __device__ __forceinline__ float softplus_exact(float x) {
     // density softplus feeds 1-exp(-sp*1e10) on the last sample: keep full relative accuracy for x << 0
     return x > 20.f ? x : log1pf(expf(x));
 }
+// Compositing arithmetic of the inference paths - k_march's own compositing, k_composite and the one-pass fine launch share it, so their images stay bit-identical
+// (round 6).  Inside a ray: the raw v_exp_f32 / v_log_f32 / v_rcp_f32 forms (~1 ulp each; alpha to ~1e-9 absolute): the one-pass launch composites inside the MLP
+// kernel, where the libm forms - ~200 instructions per sample, times the divergence of the per-lane merge loop - cost 2 ms per 512x512 view.  The LAST sample of a ray
+// (distance 1e10, renderer.py:213) keeps the exact forms: alpha = 1 - exp(-softplus(x) 1e10) needs softplus to full RELATIVE accuracy for x << 0.
+__device__ __forceinline__ float comp_alpha(float sraw, float dist) { return 1.f - __builtin_amdgcn_exp2f(-1.44269504088896341f * (softplus_hidden(sraw) * dist)); }
+__device__ __forceinline__ float comp_alpha_last(float sraw) { return 1.f - expf(-softplus_exact(sraw) * 1e10f); }
+__device__ __forceinline__ float comp_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v)); }
 __device__ __forceinline__ f32x16 softplus16(f32x16 v) {
     f32x16 o;
 #pragma unroll
@@ -272,6 +279,12 @@ struct MarchArgs {
     float *dplanes;                  // (27, H, W) gradient of the tri-plane, accumulated atomically
     int s_per;                       // ACTS / k_mlp_bwd: samples per workgroup; blockIdx.y selects the range (a fitting batch has few
                                      // rays - 2048 = 8 workgroups of 256 - so the launch is spread over the samples as well)
+    // one-pass fine launch (k_march_plw<., false, true>, round 6): the wave that owns a 32-ray tile draws its importance depths from the coarse records, evaluates
+    // them and composites coarse + new samples in depth order as it goes - no fine records, no merge kernel
+    const float4 *fz_vc;             // the coarse launch's raw records, tile-major [R/32][fz_N][32]
+    const float *fz_u;               // sample_pdf's uniforms, rows (R, S)
+    float *fz_zn;                    // scratch for the new depths, sorted, tile-major [R/32][S][32]: written and read back by the tile's own wave
+    int fz_N;                        // coarse samples per ray (<= 128; their depths are linspace(near, far))
 };
 // rows of the activation matrix ([features | hidden1] and [feature_linear | view encoding] are the concatenations the network feeds
 // to pts_linears.2 and views_linear, so their weight gradients are single products)
@@ -574,12 +587,12 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_march(const MarchArgs a) {
             //  path with 6x the spills - 1.2 KB of scratch per lane - and a third of the throughput)
             {
                 const float dist = (s + 1 < S) ? zn - zc : 1e10f;
-                const float alpha = 1.f - expf(-softplus_exact(sigma_raw) * dist);
+                const float alpha = dist == 1e10f ? comp_alpha_last(sigma_raw) : comp_alpha(sigma_raw, dist);
                 const float w = alpha * T;
                 acc_w += w;
-                acc_r += (1.f / (1.f + expf(-cr))) * w;
-                acc_g += (1.f / (1.f + expf(-cg))) * w;
-                acc_b += (1.f / (1.f + expf(-cb))) * w;
+                acc_r += comp_sigmoid(cr) * w;
+                acc_g += comp_sigmoid(cg) * w;
+                acc_b += comp_sigmoid(cb) * w;
                 acc_d += w * zc;
                 T *= (1.f - alpha + 1e-7f);
             }
@@ -1431,6 +1444,148 @@ __device__ __forceinline__ void mma_pl(f32x16 (&acc)[NT], const u32x4 (&b)[NPL],
     }
 }
 
+__device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(v, d);
+        if (lane >= d) v *= o;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_scan_add(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+
+// Phase B of the one-pass fine launch: the importance depths of ONE 32-ray tile, drawn by the wave that owns it - k_importance's arithmetic (up_sample / sample_pdf,
+// renderer.py:158-170, 533-563), one ray after the other with wave-wide scans, the cdf search and a bitonic sort of the new depths in the wave's own LDS (s_w: 128
+// floats, s_z: 256; LDS operations of one wave execute in order, so no barrier is needed where the workgroup version has them).  N coarse = N new <= 128; the coarse
+// depths are linspace(near, far).  zn_tile = the tile's [N][32] block of new depths, sorted per ray; zbuf = 16 N floats of LDS (the stage of a half tile).
+__device__ __forceinline__ void importance_tile(const float4 *__restrict__ vc_tile, const float *__restrict__ u, const float *__restrict__ rays_d, const float *__restrict__ near,
+                                                const float *__restrict__ far, long long R, int N, long long tile, int lane, float *s_w, float *s_z, float *zbuf,
+                                                float *zn_tile) {
+    const float *sig = reinterpret_cast<const float *>(vc_tile);      // .x of the record of (sample i, ray j) at (32 i + j) * 4
+    for (int r8 = 0; r8 < 32; r8 += 8) {
+        float sg[8][2];                                               // the densities of "this lane's" two samples of the next eight rays: one 128-byte line per sample
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int i = 64 * b + lane;
+                sg[rr][b] = i < N ? sig[(32LL * i + r8 + rr) * 4] : 0.f;
+            }
+        for (int rr = 0; rr < 8; ++rr) {
+            const int j = r8 + rr;
+            const long long ray_raw = tile * 32 + j;
+            const long long ray = ray_raw < R ? ray_raw : R - 1;      // padded rays recompute the last one (never read back)
+            const float nr = near[ray], fr = far[ray];
+            const float dxx = rays_d[ray * 3], dyy = rays_d[ray * 3 + 1], dzz = rays_d[ray * 3 + 2];
+            const float dn = sqrtf(dxx * dxx + dyy * dyy + dzz * dzz);
+            auto zval = [&](int i) -> float {
+                const float t = linspace01(i, N);
+                return nr * (1.f - t) + fr * t;
+            };
+            // weights w_i = alpha_i * prod_{k<i}(1 - alpha_k + 1e-10)
+            float carry = 1.f;
+            for (int base = 0; base < N; base += 64) {
+                const int i = base + lane;
+                float alpha = 0.f, zi = 0.f;
+                if (i < N) {
+                    zi = zval(i);
+                    float dist = (i + 1 < N) ? zval(i + 1) - zi : 1e10f;
+                    dist = dist * dn;
+                    const float sraw = base == 0 ? sg[0][0] : sg[0][1];
+                    alpha = 1.f - expf(-softplus_exact(sraw) * dist);
+                    s_z[i] = zi;
+                }
+                const float fct = (i < N) ? (1.f - alpha + 1e-10f) : 1.f;
+                const float incl = wave_incl_scan_mul(fct, lane);
+                float excl = __shfl_up(incl, 1);
+                if (lane == 0) excl = 1.f;
+                if (i < N) s_w[i] = alpha * (carry * excl);
+                carry *= __shfl(incl, 63);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // pdf over w[1..N-2] (+1e-5), cdf[0]=0, cdf[m]=sum_{i<=m} pdf_i   (N-1 entries)
+            const int M = N - 2;
+            float tot = 0.f;
+            for (int i = 1 + lane; i <= M; i += 64) tot += s_w[i] + 1e-5f;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+            float run = 0.f;
+            for (int base = 1; base <= M; base += 64) {
+                const int i = base + lane;
+                const float pr = (i <= M) ? (s_w[i] + 1e-5f) / tot : 0.f;
+                const float incl = wave_incl_scan_add(pr, lane) + run;
+                __builtin_amdgcn_wave_barrier();
+                if (i <= M) s_w[i] = incl;
+                run = __shfl(incl, 63);
+            }
+            if (lane == 0) s_w[0] = 0.f;
+            __builtin_amdgcn_wave_barrier();
+            // inverse CDF: idx = #(cdf <= u) (searchsorted right=True) over cdf[0..M]; this lane's two uniforms (q = lane, lane + 64) searched together: two
+            // independent chains of LDS reads instead of one after the other
+            const int nc = M + 1;
+            const int q0 = lane, q1 = lane + 64;
+            const float u0 = q0 < N ? u[ray * N + q0] : 0.f, u1 = q1 < N ? u[ray * N + q1] : 0.f;
+            int lo0 = 0, hi0 = nc, lo1 = 0, hi1 = nc;
+            while (lo0 < hi0 || lo1 < hi1) {
+                const int m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+                const float w0 = s_w[m0 < nc ? m0 : nc - 1], w1 = s_w[m1 < nc ? m1 : nc - 1];
+                if (lo0 < hi0) { if (w0 <= u0) lo0 = m0 + 1; else hi0 = m0; }
+                if (lo1 < hi1) { if (w1 <= u1) lo1 = m1 + 1; else hi1 = m1; }
+            }
+            auto inv_cdf = [&](int lo, float uq) -> float {
+                const int below = max(lo - 1, 0), above = min(lo, nc - 1);
+                const float c0 = s_w[below], c1 = s_w[above];
+                const float b0 = 0.5f * (s_z[below + 1] + s_z[below]);
+                const float b1 = 0.5f * (s_z[above + 1] + s_z[above]);
+                float den = c1 - c0;
+                den = den < 1e-5f ? 1.f : den;
+                const float t = (uq - c0) / den;
+                return b0 + t * (b1 - b0);
+            };
+            const float inf_ = __builtin_inff();
+            const float z0 = q0 < N ? inv_cdf(lo0, u0) : inf_, z1 = q1 < N ? inv_cdf(lo1, u1) : inf_;
+            // Sorted by RANK instead of a bitonic network in LDS (28 dependent LDS round trips per ray): position of z_q = #{z_j < z_q} + #{j < q : z_j = z_q}, the other
+            // lanes' values broadcast through v_readlane - no memory, ~600 plain instructions.  The sorted list is the same (the coarse depths are sorted already; the
+            // compositing merges), and equal depths are interchangeable.
+            int r0 = 0, r1 = 0;
+#pragma unroll 4
+            for (int jl = 0; jl < 64; ++jl) {      // (fully unrolled, the 128 broadcast values are all kept in scalar registers at once and spill by the hundred)
+                const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z0), jl));      // z of q = jl
+                const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z1), jl));      // z of q = 64 + jl
+                r0 += (a0 < z0 || (a0 == z0 && jl < lane)) ? 1 : 0;
+                r0 += a1 < z0 ? 1 : 0;
+                r1 += a0 <= z1 ? 1 : 0;
+                r1 += (a1 < z1 || (a1 == z1 && jl < lane)) ? 1 : 0;
+            }
+            // (by rank into the half-tile stage [sample][16 rays]: written out below as 64-byte row pieces - 4-byte stores straight into the tile-major rows cost
+            //  32 bytes of HBM write each: 1.1 GB per 512x512 view for 134 MB of depths)
+            if (q0 < N) zbuf[r0 * 16 + (j & 15)] = z0;
+            if (q1 < N) zbuf[r1 * 16 + (j & 15)] = z1;
+            if ((j & 15) == 15) {
+                __builtin_amdgcn_wave_barrier();
+                for (int e = lane * 4; e < N * 16; e += 256) {
+                    const int i = e >> 4, c = e & 15;
+                    *reinterpret_cast<f32x4 *>(zn_tile + 32LL * i + (j & 16) + c) = *reinterpret_cast<const f32x4 *>(zbuf + e);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) sg[k][b] = sg[k + 1][b];
+        }
+    }
+}
+
 #ifndef HL_H2_K
 #define HL_H2_K 4   // VALU instructions asked for behind every MFMA of a hidden-layer chunk in the fp16x2 kernel (12 MFMAs, ~48 VALU of preparation with the
                     // log2-domain softplus; same box, ms per 512x512 view: 3: 25.56, 4: 25.74, 5: 25.81 - 26.00, 6: 26.35; natural-log softplus at 5: 26.71)
@@ -1438,8 +1593,15 @@ __device__ __forceinline__ void mma_pl(f32x16 (&acc)[NT], const u32x4 (&b)[NPL],
 // ACTS (training; round 5): the evaluate pass of the fitting step on this kernel - every activation of the MLP is also written to the
 // activation matrix (row = unit, column = sample point; the rows k_mlp_bwd and k_wgrad read), a workgroup takes the sample range blockIdx.y * s_per ... of its 256 rays
 // (a fitting batch has few rays), one workgroup per CU (the stores need registers).  Softplus outputs are stored in natural units (x ln 2 in the log2 domain).
-template <int NPL, bool ACTS = false>
+// FUSE (round 6): the ONE-PASS fine launch.  Phase B - before anything of the MLP is set up, every wave draws the importance depths of its 32 rays from the coarse
+// launch's records (importance_tile: its LDS scratch is the wave's vinit block, not yet in use) and writes them, sorted, to a tile-major scratch only it reads back.
+// Phase C - the sample loop evaluates those depths and, instead of storing records, composites: every lane keeps its ray's transmittance / sums and a cursor into
+// the coarse records, and after each new sample emits the coarse samples in front of it (one 16-byte record load each, the next one requested as the cursor
+// moves) and then the sample itself - k_composite's merge order and arithmetic, sample by sample, so the image equals the four-launch pipeline's bit for bit.
+// Per 512x512 view: no k_importance / k_composite launches, no 537 MB of fine records written and read, no second read of the coarse records by a merge kernel.
+template <int NPL, bool ACTS = false, bool FUSE = false>
 __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs a, const unsigned short *__restrict__ packed_b3) {
+    static_assert(!(ACTS && FUSE), "the training pass stores records");
     constexpr int B3R_SLOT_U4 = PLW_SLOT_U4<NPL>, B3_CH_U4 = PLW_CH_U4<NPL>;      // (shadow the bf16x3 constants of k_march_b3)
     constexpr size_t B3_BYTES = PLW_BYTES<NPL>;
     constexpr int NMF = NPL == 3 ? 24 : 12;                                        // MFMAs of a chunk (4 tiles x 6 | 3 products)
@@ -1477,6 +1639,18 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
         small[i] = v;
     }
     const u32x4 *gb3 = reinterpret_cast<const u32x4 *>(packed_b3);
+    if constexpr (FUSE) {   // phase B: this wave's importance depths
+        if (tile < tiles_n && !(a.flags & 0x10000u)) {             // (0x10000: developer timing switch - the depths of an earlier call are still in the scratch)
+            // (LDS: the weights / cdf and the depths of the ray in the wave's share of the weight ring, not yet loaded; the half-tile stage of the sorted depths -
+            //  8 KB - in the wave's vinit block, not yet written)
+            float *s_w = reinterpret_cast<float *>(ring) + (tid >> 6) * 384, *s_z = s_w + 128;
+            importance_tile(a.fz_vc + tile * 32 * (long long)a.fz_N, a.fz_u, a.rays_d, a.near, a.far, a.R, a.fz_N, tile, lane, s_w, s_z,
+                            reinterpret_cast<float *>(vinit), a.fz_zn + tile * 32 * (long long)a.S);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the depths are read back below through a.z (= a.fz_zn): stores complete, then no stale line
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();                                        // (the ring is loaded next: every wave is done with its scratch in it)
+    }
 #pragma unroll
     for (int q = 0; q < 2 * NST; ++q) ring[q * NT + tid] = gb3[q * NT + tid];                  // chunk pairs 0, 1 -> slots 0, 1
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)packed_b3, (short)0, (int)B3_BYTES, 0x00020000);
@@ -1561,7 +1735,8 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
     const unsigned act_stride4 = ACTS ? (unsigned)a.act_stride * 4u : 0u;
     const i32x4 act_rs = matrix_rsrc(a.act, ACTS ? (unsigned)ACT_ROWS * act_stride4 : 0u);
     float zc;
-    if (a.z) zc = a.z_tiled ? a.z[zt_base + 32LL * s_lo] : a.z[rc * S + s_lo];
+    if constexpr (FUSE) zc = a.z[zt_base + 32LL * s_lo];                                    // (the one-pass launch reads its own tile-major depths: one address form to keep)
+    else if (a.z) zc = a.z_tiled ? a.z[zt_base + 32LL * s_lo] : a.z[rc * S + s_lo];
     else zc = nr * (1.f - linspace01(s_lo, S)) + fr_ * linspace01(s_lo, S);
     __syncthreads();
 
@@ -1594,12 +1769,69 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
       _Pragma("unroll") for (int g_ = 0; g_ < NMF; ++g_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, NPL == 3 ? K_ : HL_H2_K, 0); } \
       __builtin_amdgcn_sched_barrier(0); }
 
+    // FUSE: streaming merge + compositing state of this lane's ray (k_composite's arithmetic in k_composite's order; both lane halves of a ray carry the shared
+    // part, half 0 the red sum, half 1 green and blue): eleven registers per lane across the sample's MLP (252 of 256 in use, no spill - the addresses below are
+    // formed where they are used for that reason).  The record at the cursor is requested while views_linear runs and is in flight until the emission.
+    // registers per lane: transmittance; three sums - lane half 0 (red, sum w, sum w z), half 1 (green, blue, -); the pending sample (its alpha needs the NEXT
+    // depth): depth, raw density, two raw colours (half 0: red, -; half 1: green, blue); the cursor
+    float cT = 1.f, cA = 0.f, cB = 0.f, cC = 0.f;
+    float pzd = 0.f, ps = 0.f, pc0 = 0.f, pc1 = 0.f;
+    bool has_p = false;
+    int ci = 0;                                                 // cursor into the coarse samples
+    const int Nc = FUSE ? a.fz_N : 0;
+    // (the addresses are formed where they are used, from a lane index the optimiser cannot see through: hoisted out of the sample loop they would be live across
+    //  the MLP and spill)
+    auto opaque_tid = [&]() __attribute__((always_inline)) -> int { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; };
+    auto vcp = [&]() __attribute__((always_inline)) -> const float2 * {                        // this lane half's two entries of the record of coarse sample 0: (sigma, r) | (g, b)
+        const int t_ = opaque_tid();
+        const long long tl = wg * 8 + (t_ >> 6);
+        return reinterpret_cast<const float2 *>(a.fz_vc + (tl < tiles_n ? tl : tiles_n - 1) * 32 * (long long)Nc + (t_ & 31)) + ((t_ >> 5) & 1);
+    };
+    auto zco = [&](int i) __attribute__((always_inline)) -> float {
+        if (i >= Nc) return __builtin_inff();
+        const float t = linspace01(i, Nc);
+        return nr * (1.f - t) + fr_ * t;
+    };
+    float2 crec = make_float2(0.f, 0.f), crec1 = make_float2(0.f, 0.f);   // this half's entries of the records at the cursor and behind it
+    auto lower_half = [&](float v) __attribute__((always_inline)) -> float {                    // the value lane (lane & 31) holds: v_permlane32_swap, no LDS (both halves of a ray are always active together)
+        const unsigned x_ = __builtin_bit_cast(unsigned, v);
+        return __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(x_, x_, false, false)[0]);
+    };
+    auto finish_pending = [&](float dist) __attribute__((always_inline)) {
+        const float alpha = dist == 1e10f ? comp_alpha_last(ps) : comp_alpha(ps, dist);
+        const float w = alpha * cT;
+        cA += comp_sigmoid(pc0) * w;
+        cB += (half ? comp_sigmoid(pc1) : 1.f) * w;              // (half 0: 1 w = w exactly - the sum of the weights)
+        cC += w * pzd;
+        cT *= (1.f - alpha + 1e-7f);
+    };
+    auto emit = [&](float z, float sg_, float c0, float c1) __attribute__((always_inline)) {
+        if (has_p) finish_pending(z - pzd);
+        pzd = z; ps = sg_; pc0 = c0; pc1 = c1; has_p = true;
+    };
+    // Every coarse sample at or in front of zlim.  The record at the cursor was requested while views_linear ran; inside a run every further record costs a round trip
+    // to L2 (measured alternatives: two / four records requested together need 4 / 8 more registers from the views stage on and the allocator starts to spill -
+    // 6 ... 25 registers of scratch - which costs more than the round trips: every reload is a vmcnt(0) in front of the weight ring's counted waits).
+    auto emit_coarse_until = [&](float zlim) __attribute__((always_inline)) {
+        while (zco(ci) <= zlim) {
+            emit(zco(ci), lower_half(crec.x), half ? crec.x : crec.y, crec.y);      // (the density sits in half 0)
+            ++ci;
+            crec = crec1;                                                           // (requested one step earlier: two records are in flight inside a run)
+            if (ci + 1 < Nc) crec1 = vcp()[64LL * (ci + 1)];
+        }
+    };
     auto body = [&](auto rotc) {
     constexpr bool ROT = decltype(rotc)::value;
     for (int s = s_lo; s < s_hi; ++s) {
         float zn = 0.f;
         if (s + 1 < S) {
-            if (a.z) zn = a.z_tiled ? a.z[zt_base + 32LL * (s + 1)] : a.z[rc * S + s + 1];
+            if constexpr (FUSE) {   // (address formed here from an opaque lane index: hoisted out of the loop it is spilled, and its reload costs a vmcnt(0) per sample)
+                int t_ = tid;
+                asm volatile("" : "+v"(t_));
+                const long long tl = wg * 8 + (t_ >> 6);
+                zn = a.z[(tl < tiles_n ? tl : tiles_n - 1) * 32 * (long long)a.S + (t_ & 31) + 32LL * (s + 1)];
+            }
+            else if (a.z) zn = a.z_tiled ? a.z[zt_base + 32LL * (s + 1)] : a.z[rc * S + s + 1];
             else { const float t = linspace01(s + 1, S); zn = nr * (1.f - t) + fr_ * t; }
         }
         // ---- tri-plane features of this half (fp32, exactly as k_march)  [renderer.py:502-531] ----
@@ -1718,6 +1950,11 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
                 for (int r = 0; r < 16; ++r) Y[t][r] *= rsF;
         }
         act_rows(ROW_Y, Y, 1.f);
+        if constexpr (FUSE) {   // the coarse records at the cursor and behind it: requested here, used at the end of the sample
+            const float2 *p_ = vcp();
+            crec = p_[64LL * (ci < Nc ? ci : Nc - 1)];
+            crec1 = p_[64LL * (ci + 1 < Nc ? ci + 1 : Nc - 1)];
+        }
         const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];   // X holds softplus(pts_linears.2) by now
         f32x16 V[2];
 #pragma unroll
@@ -1741,7 +1978,10 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
         const float cg = dot_lane<2>(V, small + SM_RW + 64, half) + small[SM_RB + 1];
         const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
         B3_ADV(B3_NCH - 1)                                                          // pair 0 of the next sample (the stream of a sample is chunks 0..31)
-        if (tile * 32 < a.R) {   // lanes 0-31 store (sigma, r), lanes 32-63 (g, b); hidden store: see k_march
+        if constexpr (FUSE) {   // the coarse samples in front of (or at: k_composite takes the coarse one first) this depth, then the sample itself
+            emit_coarse_until(zc);
+            emit(zc, sigma_raw, half ? cg : cr, cb);
+        } else if (tile * 32 < a.R) {   // lanes 0-31 store (sigma, r), lanes 32-63 (g, b); hidden store: see k_march
             const float2 rec = half ? make_float2(cg, cb) : make_float2(sigma_raw, cr);
             float *dst = reinterpret_cast<float *>(a.vals_out + (zt_base + 32LL * s)) + 2 * half;
             asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst), "v"(rec) : "memory");
@@ -1751,6 +1991,34 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
     };
     if ((tid >> 6) < 4) body(std::false_type{});
     else body(std::true_type{});
+    if constexpr (FUSE) {   // the coarse samples behind the last new depth, the last sample (distance 1e10: renderer.py:213), the image
+        {
+            const float2 *p_ = vcp();
+            crec = p_[64LL * (ci < Nc ? ci : Nc - 1)];
+            crec1 = p_[64LL * (ci + 1 < Nc ? ci + 1 : Nc - 1)];
+        }
+        emit_coarse_until(3.0e38f);                                 // (zco is +inf behind the last coarse sample)
+        finish_pending(1e10f);
+        const float cW = __shfl(cB, lane & 31);                 // the sum of the weights (half 0 keeps it)
+        if (a.flags & HL_RENDER_WHITE_BKGD) {
+            const float bg = 1.f - cW;
+            cA += bg;
+            if (half) cB += bg;
+        }
+        if (a.flags & HL_RENDER_NORMALIZE_DEPTH) {
+            cC = (cC - nr) / (fr_ - nr + 1e-5f);
+            if (a.flags & HL_RENDER_CLAMP_DEPTH) {
+                cC = cC > 1.f ? 1.f : cC;
+                cC = cC < 0.f ? 0.f : cC;
+            }
+        }
+        const int t_ = opaque_tid();
+        const long long ray_ = (wg * 8 + (t_ >> 6)) * 32 + (t_ & 31);
+        if (ray_ < a.R) {
+            if (t_ & 32) { a.rgb[ray_ * 3 + 1] = cA; a.rgb[ray_ * 3 + 2] = cB; }
+            else { a.rgb[ray_ * 3 + 0] = cA; a.acc[ray_] = cB; a.depth[ray_] = cC; }
+        }
+    }
 #undef B3_VM
 #undef B3_MV24
 #undef B3_ADV
@@ -1762,23 +2030,6 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
 // importance sampling + merge: one wave per ray   [renderer.py:158-170, 533-563, 252-253]
 // ---------------------------------------------------------------------------------------------
 constexpr int IMP_MAX_N = 512;
-
-__device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(v, d);
-        if (lane >= d) v *= o;
-    }
-    return v;
-}
-__device__ __forceinline__ float wave_incl_scan_add(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
-    return v;
-}
 
 struct ImpArgs {
     const float *sigma, *rays_d, *near, *far, *z, *u;
@@ -1978,12 +2229,13 @@ __global__ __launch_bounds__(256) void k_composite(const CompArgs a) {
         }
         const float dist = (s + 1 < S) ? znext - zcur : 1e10f;
         const float sraw = a.noise ? vcur.x + a.noise[ray * S + s] : vcur.x;
-        const float alpha = 1.f - expf(-softplus_exact(sraw) * dist);
+        // (training noise: the exact forms of rounds 1-5, what k_composite_bwd differentiates; inference: the shared comp_* forms)
+        const float alpha = a.noise ? 1.f - expf(-softplus_exact(sraw) * dist) : (s + 1 < S ? comp_alpha(sraw, dist) : comp_alpha_last(sraw));
         const float w = alpha * T;
         acc_w += w;
-        acc_r += (1.f / (1.f + expf(-vcur.y))) * w;
-        acc_g += (1.f / (1.f + expf(-vcur.z))) * w;
-        acc_b += (1.f / (1.f + expf(-vcur.w))) * w;
+        acc_r += (a.noise ? 1.f / (1.f + expf(-vcur.y)) : comp_sigmoid(vcur.y)) * w;
+        acc_g += (a.noise ? 1.f / (1.f + expf(-vcur.z)) : comp_sigmoid(vcur.z)) * w;
+        acc_b += (a.noise ? 1.f / (1.f + expf(-vcur.w)) : comp_sigmoid(vcur.w)) * w;
         acc_d += w * zcur;
         T *= (1.f - alpha + 1e-7f);
         zcur = znext;
@@ -3743,6 +3995,29 @@ static int render_eval_impl(const void *mlp_packed, const void *planes_packed, i
     return hl::check_launch("k_march<eval>");
 }
 
+// the one-pass fine launch (k_march_plw<NPL, false, true>): importance depths from the coarse records `vc`, their evaluation, merge + compositing - images out
+static int render_onepass_fine(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o, const float *rays_d,
+                               const float *near, const float *far, const float *vc, const float *u, float *zn_scratch, int64_t n_rays, int n_samples,
+                               unsigned flags, int npl, float *rgb, float *acc, float *depth, void *stream) {
+    HL_REQUIRE(vc && u && zn_scratch && rgb && acc && depth && n_samples >= 3 && n_samples <= 128, "render_onepass_fine: bad argument");
+    MarchArgs a{};
+    int rcode = fill_march(a, mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far);
+    if (rcode) return rcode;
+    a.z = zn_scratch; a.z_tiled = 1; a.R = n_rays; a.S = n_samples; a.flags = flags;
+    if (const char *e_ = getenv("HL_ONEPASS_DEV")) a.flags |= (unsigned)strtoul(e_, nullptr, 0);
+    a.fz_vc = (const float4 *)vc; a.fz_u = u; a.fz_zn = zn_scratch; a.fz_N = n_samples;
+    a.rgb = rgb; a.acc = acc; a.depth = depth;
+    const dim3 grid((unsigned)((n_rays + 255) / 256));
+    if (npl == 2) {
+        const unsigned short *ph2 = reinterpret_cast<const unsigned short *>(static_cast<const char *>(mlp_packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024 + B3_BYTES);
+        static const bool okh = hipFuncSetAttribute((const void *)k_march_plw<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLW_LDS<2>) == hipSuccess;
+        HL_REQUIRE(okh, "k_march_plw<2, one-pass>: cannot raise the dynamic LDS limit to %zu bytes", PLW_LDS<2>);
+        hipLaunchKernelGGL((k_march_plw<2, false, true>), grid, dim3(512), PLW_LDS<2>, (hipStream_t)stream, a, ph2);
+        return hl::check_launch("k_march_plw<2, one-pass>");
+    }
+    return hl::fail(HL_ERR_UNSUPPORTED, "render_onepass_fine: the one-pass launch exists for the fp16x2 products only");
+}
+
 int hl_render_eval(const void *mlp_packed, const void *planes_packed, int H, int W, const float *bounds, const float *rays_o,
                    const float *rays_d, const float *near, const float *far, const float *z, int z_tiled, int64_t n_rays,
                    int n_samples, float *records_out, void *stream) {
@@ -4068,6 +4343,12 @@ int hl_render_rays_u_event(const void *mlp_packed, const void *planes_packed, in
             if (rcode) return rcode;
             rcode = wait_u();
             if (rcode) return rcode;
+            // round 6: two launches per view - the fine launch draws its own importance depths and composites as it evaluates (no fine records, no merge kernel)
+            // (fp16x2 products only: with the bf16x3 planes the fused kernel spills - measured 41.1 against 40.1 ms per view)
+            if (!(flags & HL_RENDER_FOUR_LAUNCH) && h16 == 3 && n_samples <= 128 && z_vals == nullptr) {
+                return render_onepass_fine(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, vc, u, zn, n_rays, n_samples, flags, 2,
+                                           rgb, acc, depth, stream);
+            }
             rcode = hl_render_importance_new(vc, rays_d, near, far, z_vals, u, n_rays, n_samples, n_importance, zn, stream);
             if (rcode) return rcode;
             rcode = render_eval_impl(mlp_packed, planes_packed, H, W, bounds, rays_o, rays_d, near, far, zn, 1, n_rays, n_importance, vn,

@@ -84,6 +84,12 @@ int hl_planes_pack(const float *planes, int H, int W, void *packed, void *stream
                                         matrix instructions of BF16X3 at the same fp32-class error against the reference's renders (goldens a ... f: weights from
                                         2^-8 below to 2^4 above nn.Linear's initialisation); softplus returns x beyond a pre-activation of 88.7 like F.softplus */
 
+#define HL_RENDER_FOUR_LAUNCH 128u    /* hl_render_rays: keep rounds 2-5's schedule of the evaluate-once pipeline - evaluate, k_importance, evaluate, k_composite, with the raw
+                                        records of BOTH halves through HBM.  Default (round 6, HL_RENDER_MLP_FP16X2, n_samples <= 128, linspace depths): TWO
+                                        launches per view - the coarse evaluate, then the one-pass fine launch (k_march_plw<., false, true>): the wave that owns 32
+                                        rays draws their importance depths from the coarse records (renderer.py:158-170, 533-563), evaluates them and composites
+                                        coarse + new samples in depth order as it goes (renderer.py:172-231, 252-253); bit-identical images */
+
 size_t hl_render_workspace_bytes(int64_t n_rays, int n_samples, int n_importance);
 
 /* Replaces Renderer.render (human_diffusion/NeRF/renderer.py:234-281,

@@ -365,6 +365,41 @@ def test_evaluate_once_pipeline_is_bit_identical_to_reevaluation(dev, R, N, whit
     assert Renderer(use_canonical_space=False, triplane_dim=256, triplane_ch=27, smpl_type='smpl', test=True).mlp_products == "fp16x2"   # the default
 
 
+@pytest.mark.parametrize("R,N,white", [(1, 32, False), (33, 32, True), (1000, 64, False), (4096, 128, True), (777, 128, False), (2049, 128, False), (300, 3, False)])
+def test_one_pass_fine_launch_is_bit_identical_to_the_four_launch_pipeline(dev, R, N, white):
+    """Round 6 (north star: sample + MLP + alpha-composite in ONE pass): the default schedule of the fp16x2 mode is two launches - the coarse evaluate, then
+    k_march_plw<2, false, true>, whose waves draw the importance depths of their 32 rays from the coarse records (up_sample / sample_pdf, renderer.py:158-170, 533-563),
+    evaluate them and composite coarse + new samples in depth order as they go (renderer.py:172-231, 252-253) - no k_importance, no fine records, no k_composite.
+    Renderer.four_launch keeps rounds 2-5's evaluate / k_importance / evaluate / k_composite schedule: same depths, same records, same compositing order and
+    arithmetic - the images must be the same BITS, for ragged ray counts (tiles and workgroups mostly empty), every sample count the fused launch takes (3 ... 128),
+    white background, and repeated calls."""
+    from humanliff_amd import synthetic as syn
+    r = make_renderer(syn.render_mlp_state(3), dev)
+    assert r.mlp_products == "fp16x2"
+    planes = syn.triplane(seed=11).to(dev)
+    ro, rd, nr, fr = [t[:R].to(dev) for t in syn.orbit_rays(5, 36, 64, 64)]
+    tp = {"world_bounds": torch.tensor(syn.WORLD_BOUNDS)[None].to(dev)}
+    u = torch.rand((R, N), generator=torch.Generator().manual_seed(R + N)).to(dev)
+    outs = []
+    for four in (True, False, False):
+        r.four_launch = four
+        o = r.render(tp, None, None, ro[None], rd[None], nr[None], fr[None], planes, N, white, n_samples=N, u=u[None])
+        outs.append({k: o[k].clone() for k in ("rgb_map", "acc_map", "depth_map")})
+    for k in ("rgb_map", "acc_map", "depth_map"):
+        assert bool(torch.isfinite(outs[1][k]).all()), k
+        assert torch.equal(outs[0][k], outs[1][k]), (k, float((outs[0][k] - outs[1][k]).abs().max()))
+        assert torch.equal(outs[1][k], outs[2][k]), k
+    if R >= 100:
+        assert float(outs[1]["acc_map"].max()) > 0.05      # not a vacuous all-empty render
+    # the schedules that have no one-pass form fall back to the four launches by themselves: caller-given depths, the other product modes
+    z = (nr[:, None] * (1 - torch.linspace(0, 1, N, device=dev)) + fr[:, None] * torch.linspace(0, 1, N, device=dev)) * (1 + 1e-3 * torch.rand((R, N), device=dev)).sort(dim=1)[0]
+    r.four_launch = False
+    a = r.render(tp, None, z[None], ro[None], rd[None], nr[None], fr[None], planes, N, white, u=u[None])
+    r.four_launch = True
+    b = r.render(tp, None, z[None], ro[None], rd[None], nr[None], fr[None], planes, N, white, u=u[None])
+    assert torch.equal(a["rgb_map"], b["rgb_map"])
+
+
 # ---- canonical-space deformation (SURVEY 8(f) rank 3) ----------------------------------------------------------------
 @pytest.mark.parametrize("name", ["small", "mid"])
 def test_deform_matches_reference_golden(name, dev):
