@@ -841,8 +841,9 @@ def bench_render(args, rank, world, dev):
     view_ms = t_a + t_i + t_b + t_c
     roof = {"bound": "mfma", "kernel": "k_march_plw<2> (evaluate pass: tri-plane gather + full MLP at 128 depths per ray, every fp32 product as three fp16 partial "
                                        "products of two-plane splits, fp32 accumulation, raw records out), two launches per 512x512 view (coarse depths, importance depths)",
-            "products": "fp16x2 (x = h0 + h1 with two fp16 planes, 2^-20 |x|; weights nearest-even, 2^-22; h0 w0 + h0 w1 + h1 w0 on v_mfma_f32_32x32x16_f16, fp32 "
-                        "accumulation) - an fp32-tolerance mode: same test bounds as the fp32-MFMA kernel, rgb within 7e-7 of it on full views",
+            "products": "fp16x2 (x = h0 + h1 with two fp16 planes, 2^-20 |x|; weight planes of 2^k W per layer, nearest-even, 2^-22 of the layer's largest weight at any "
+                        "magnitude; h0 w0 + h0 w1 + h1 w0 on v_mfma_f32_32x32x16_f16, fp32 accumulation) - an fp32-tolerance mode: same test bounds as the fp32-MFMA "
+                        "kernel, rgb within 7e-7 of it on full views",
             "achieved": round(issued / (t_b * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(issued / (t_b * 1e-3) / 1e12 / 2500.0, 4),
             "peak_note": "dense fp16 MFMA peak (MI355X_MICROARCH.md); `achieved` = fp16 FLOPs issued.  In the path's own unit: "
                          f"{eval_flop / (t_b * 1e-3) / 1e12:.1f} TFLOP/s of algorithmic fp32 work = {eval_flop / (t_b * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS:.2f} x the fp32 matrix peak",
@@ -853,6 +854,32 @@ def bench_render(args, rank, world, dev):
                      "algorithmic_tflops": round(R * FINE_FLOP_PER_RAY_TOTAL / (view_ms * 1e-3) / 1e12, 2),
                      "note": "algorithmic = the reference's schedule, 128 x 79 616 + 256 x 132 608 FLOP per ray (SURVEY 8(d)); this "
                              "schedule evaluates every point once (256 x 132 608)"}}
+    # ---- round 6: the schedule `value` runs on is TWO launches per view - the coarse evaluate (timed above as eval_coarse_ms) and the one-pass fine launch
+    # (k_march_plw<2, false, true>: importance depths + their evaluation + depth-ordered compositing); the whole call timed with events, both schedules ----
+    ws = r._workspace(L.hl_render_workspace_bytes(R, N, N), dev)
+
+    def whole_view(flags):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = None
+        for _ in range(3):
+            e0.record()
+            _lib.check(L.hl_render_rays(p(packed), p(pp), 256, 256, p(bd), p(ro), p(rd), p(nr), p(fr), None, p(u), R, N, N, flags, p(rgb), p(acc), p(dep), p(ws), s()))
+            e1.record()
+            torch.cuda.synchronize()
+            best = e0.elapsed_time(e1) if best is None else min(best, e0.elapsed_time(e1))
+        return best, rgb.clone()
+    v2_ms, img2 = whole_view(_lib.HL_RENDER_MLP_FP16X2 | 2)
+    v4_ms, img4 = whole_view(_lib.HL_RENDER_MLP_FP16X2 | 2 | _lib.HL_RENDER_FOUR_LAUNCH)
+    roof["launches_per_view"] = 2
+    roof["hbm_bytes_per_view"] = 3.0e9
+    roof["one_pass"] = {"what": "hl_render_rays, default schedule (two launches: coarse evaluate, one-pass fine launch) against HL_RENDER_FOUR_LAUNCH (rounds 2-5: evaluate, "
+                                "k_importance, evaluate, k_composite), one 512x512 view each, HIP events on the launch stream, best of 3",
+                        "ms_per_view": round(v2_ms, 3), "fine_launch_ms": round(v2_ms - t_a, 3), "four_launch_ms_per_view": round(v4_ms, 3),
+                        "images_bit_equal": bool(torch.equal(img2, img4)),
+                        "hbm_bytes_per_view": {"one_pass": 3.0e9, "four_launch": 7.0e9,
+                                               "source": "profiles/r06_pmc_render_traffic.md (rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE, separate passes): coarse 168 + 537 MB, "
+                                                         "fine launch 2 161 + 143 MB; four launches: 2 x (168 + 537) + 760 + 699 + 4 150 + 5 MB"}}
+    del img2, img4
     # the exact-split mode beside it: Renderer.mlp_products = "bf16x3" (k_march_plw<3>: three bf16 planes, six partial products - round 4's default)
     b_a, b_i, b_b, b_c = stages(_lib.HL_RENDER_MLP_BF16X3)
     r.mlp_products = "bf16x3"
