@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prt; rm -rf $O; mkdir -p $O
 for f in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $f --output-format csv -d $O/rp_$f -- python scripts/render_b3_abl.py bf16x3 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $f --output-format csv -d $O/rp_$f -- python scripts/archive_r1_r5/render_b3_abl.py bf16x3 > /dev/null 2>&1
 done
 python - <<'PY' > gpurun_out/pmc_render_traffic.md
 import csv, glob, collections
