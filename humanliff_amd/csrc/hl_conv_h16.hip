@@ -591,7 +591,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
             for (int c = tid; c < p.Cin; c += 256) { sA[c] = p.cA[(long)img * p.Cin + c]; sB[c] = p.cB[(long)img * p.Cin + c]; }
             __syncthreads();
         } else sx = wave_uniform(coef_to_lds<true>(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256));      // (ends with a barrier)
-    } else if (p.xs_gt && !p.in16) sx = wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw));
+    } else if (p.xs_max && !p.in16) sx = wave_uniform(pow2_scale_for_bound(p.xs_max[img]));
+    else if (p.xs_gt && !p.in16) sx = wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw));
     const float rsx = 1.f / sx;
     kq *= rsx;
 #pragma unroll
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2d(const ConvK p) {
         }
     };
     // power-of-two scale of the raw input from its producers' totals (hl_stats.h)
-    const float axs = p.xs_gt ? wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw)) : 1.f, rsx = 1.f / axs;
+    const float axs = p.xs_max ? wave_uniform(pow2_scale_for_bound(p.xs_max[img])) : (p.xs_gt ? wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw)) : 1.f), rsx = 1.f / axs;
     auto a_store = [&](int j) {
         const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]) * axs, v1 = __builtin_bit_cast(f32x4, ar[j][1]) * axs;
         const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
@@ -1078,7 +1079,8 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
             for (int c = tid; c < p.Cin; c += 256) { sA[c] = p.cA[(long)img * p.Cin + c]; sB[c] = p.cB[(long)img * p.Cin + c]; }
             __syncthreads();
         } else sx = wave_uniform(coef_to_lds<true>(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256));      // (ends with a barrier)
-    } else if (p.xs_gt && !p.in16) sx = wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw));
+    } else if (p.xs_max && !p.in16) sx = wave_uniform(pow2_scale_for_bound(p.xs_max[img]));
+    else if (p.xs_gt && !p.in16) sx = wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw));
     const float rsx = 1.f / sx;
     kq *= rsx;
 #pragma unroll

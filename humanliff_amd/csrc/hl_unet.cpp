@@ -1044,6 +1044,8 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
                       : (mode == HL_CONV_FP32_F23 ? hl::conv_packed_wino_bytes(Cout, Cin, ks)
                          : (f32m ? std::max(hl::conv_packed_wino_bytes(Cout, Cin, ks), hl::conv_packed_wino4_bytes(Cout, Cin, ks)) : 0));
     if (h16m) extra = std::max(extra, hl::conv_packed_h16_bytes(Cout, Cin, ks));
+    // (not the backward-data calls, tf = 1: measured in round 6 with the scale-invariant planes - the training step at microbatch 2 went from 102.6 to 110.1 ms as a HIP
+    //  graph: per call the gradient's abs-max pass, the weights' scale + pack, and kernels that at two rounds of workgroups are no faster than F(4x4,3x3) on the fp32 pipe)
     if (mode == HL_CONV_FP32 && !tf) extra = std::max(extra, hl::conv_packed_h2_bytes(Cout, Cin, ks));
     const size_t need = need32 + (extra + 255) / 256 * 256;
     HL_REQUIRE(scratch && scratch_bytes >= need, "hl_conv2d_nhwc: scratch too small (%zu < %zu)", scratch_bytes, need);
@@ -1105,10 +1107,11 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     if (rc) return rc;
     if (a.path != 5) a.w_h16 = nullptr;
     if (a.path != 6) a.w_h2 = nullptr;
-    if (a.path == 6 && !coefA && tot_room) {   // fp16x2 products on a raw input: its sum x^2 fixes the power-of-two scale of the activation planes (in the network the producers leave it)
-        rc = hl::tensor_totals(a.in, tot_room, (hipStream_t)stream);
+    if (a.path == 6 && !coefA && tot_room) {   // fp16x2 products on a raw input: the largest |x| of every image fixes the power-of-two scale of the activation planes
+        // (in the network the producers' sum x^2 bounds it; here one pass over the tensor - exact at any magnitude, which the backward-data calls need: gradients are 1e-4 ... 1e-9)
+        rc = hl::tensor_absmax(a.in, tot_room, (hipStream_t)stream);
         if (rc) return rc;
-        a.in_stats = tot_room;
+        a.in_absmax = tot_room;
     }
     rc = hl::conv2d(a, (hipStream_t)stream);
     if (stat_slots) *stat_slots = a.stat_slots;

@@ -31,6 +31,7 @@ struct ConvArgs {
     const void *w_bf3;   // optional: the same weights split into three bf16 planes (conv_pack_weights_bf3); selects k_conv_bf3
     int bf16_single;     // with w_bf3: 1 = HL_CONV_BF16 (activations rounded to bf16 x the weights' two leading bf16 planes), 0 = bf16x3 emulation
     const void *w_h2;    // optional (1x1 layers): two fp16 planes in MFMA-fragment order (conv_pack_weights_h2); selects k_conv1_h2 where it fills the chip
+    const float *in_absmax; // optional, instead of in_stats: [N] the largest |x| of every image of `in` (tensor_absmax)
     const float *in_stats; // optional: the group totals the producer(s) of `in` left for ANY view that covers it (conv_stats_floats(N, in.H * in.W) floats, complete
                          // when this launch starts): the fp16x2 kernels derive the power-of-two scale of the raw input from sum x^2 (ConvK::xs_gt); null: scale 1
     const void *w_h16;   // optional: 16-bit weights in MFMA-fragment order (conv_pack_weights_h16); selects k_conv_h16 where conv_h16_applies
@@ -101,6 +102,7 @@ struct ConvK {
     const float *wsc;
     const float *xs_gt;
     int xs_hw;         // pixels per image of the tensor the totals belong to (fixes the number of shards)
+    const float *xs_max;   // alternative to xs_gt: [N] the largest |x| of every image (tensor_absmax) - exact at any magnitude (the single-op entry points: gradients are 1e-4 ... 1e-9)
 };
 
 // k_conv_wino4w (hl_conv_wino4w.hip): Winograd F(4x4,3x3) with 64 output channels per workgroup, one wave per SIMD, 18 accumulator
@@ -136,6 +138,8 @@ constexpr size_t conv_stats_floats(int N, long HW) { return (size_t)stat_shards(
 size_t conv_splitk_ws_bytes();
 // totals (conv_stats_floats(x.N, x.H * x.W) floats, zeroed here) of a tensor nobody left totals for: what ConvArgs::in_stats wants (the single-op entry points)
 int tensor_totals(const View &x, float *totals, hipStream_t st);
+// [N] floats: the largest |x| of every image (zeroed here; non-negative floats order like their bit patterns: one integer atomicMax per workgroup)
+int tensor_absmax(const View &x, float *amax, hipStream_t st);
 int conv2d(const ConvArgs &a, hipStream_t st);
 size_t conv_packed_floats(int Cout, int Cin_pad, int ks);
 // tf = 1: the source is laid out (Cin, Cout, ks, ks) and is read flipped and channel-transposed (backward-data weights)

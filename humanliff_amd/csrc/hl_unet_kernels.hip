@@ -2173,6 +2173,29 @@ __global__ __launch_bounds__(256) void k_tensor_totals(const float *__restrict__
     if (threadIdx.x == 0 && p1 > p0) stat_add(st, N, n, blockIdx.x & 31, HW, rs[0], rq[0]);
 }
 
+// the largest |x| of image blockIdx.y (tensor_absmax): what bounds the power-of-two scale of a raw input of the fp16x2 kernels exactly, whatever the magnitude
+__global__ __launch_bounds__(256) void k_tensor_absmax(const float *__restrict__ x, long pitch, long HW, int C, float *__restrict__ amax) {
+    __shared__ float rm[256];
+    const int n = blockIdx.y;
+    const long per = (HW + gridDim.x - 1) / gridDim.x, p0 = (long)blockIdx.x * per, p1 = p0 + per < HW ? p0 + per : HW;
+    float m = 0.f;
+    const int c4 = C / 4;
+    for (long i = (p0 * c4) + threadIdx.x; i < p1 * c4; i += 256) {
+        const long pix = i / c4;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((long)n * HW + pix) * pitch + (i - pix * c4) * 4);
+        // (integer max of the magnitudes' bit patterns: a NaN stays the largest and reaches the consumer, whose pow2_scale_for_bound then keeps scale 1)
+        const unsigned a0 = __float_as_uint(v[0]) & 0x7fffffffu, a1 = __float_as_uint(v[1]) & 0x7fffffffu, a2 = __float_as_uint(v[2]) & 0x7fffffffu, a3 = __float_as_uint(v[3]) & 0x7fffffffu;
+        m = __uint_as_float(max(max(__float_as_uint(m), a0), max(max(a1, a2), a3)));
+    }
+    rm[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) rm[threadIdx.x] = __uint_as_float(max(__float_as_uint(rm[threadIdx.x]), __float_as_uint(rm[threadIdx.x + d])));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && p1 > p0) atomicMax(reinterpret_cast<unsigned *>(amax) + n, __float_as_uint(rm[0]));
+}
+
 // ---------------------------------------------------------------------------------------------
 // small-batch linear: one wave per output row
 // ---------------------------------------------------------------------------------------------
@@ -3052,7 +3075,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         a.path = 6;
         p.in16 = 0; p.w_bf3 = a.w_h2; p.partial = nullptr;
         p.wsc = conv_h2_wscale(a.w_h2, a.Cout, a.in.C, a.ks);
-        p.xs_gt = a.in_stats; p.xs_hw = a.in.H * a.in.W;
+        p.xs_gt = a.in_stats; p.xs_hw = a.in.H * a.in.W; p.xs_max = a.in_absmax;
         p.n_nblocks = a.Cout / 192;
         p.n_mtiles = (int)((long)a.out.N * a.out.H * a.out.W / 128);
         if (a.stats) {
@@ -3087,7 +3110,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         }
         p.w_bf3 = a.w_h2;
         p.wsc = conv_h2_wscale(a.w_h2, a.Cout, a.in.C, a.ks);
-        if (mode == 0) { p.xs_gt = a.in_stats; p.xs_hw = a.in.H * a.in.W; }      // (raw input; a fused GroupNorm bounds its own output)
+        if (mode == 0) { p.xs_gt = a.in_stats; p.xs_hw = a.in.H * a.in.W; p.xs_max = a.in_absmax; }      // (raw input; a fused GroupNorm bounds its own output)
         splits = h3_splits;
         p.kt_per = (a.in.C / 32 + splits - 1) / splits;                  // chunks of 32 input channels per slab
         splits = (a.in.C / 32 + p.kt_per - 1) / p.kt_per;
@@ -3134,7 +3157,7 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
         }
         p.w_bf3 = a.w_h2; p.in16 = 0; p.partial = nullptr;
         p.wsc = conv_h2_wscale(a.w_h2, a.Cout, a.in.C, a.ks);
-        if (mode == 0) { p.xs_gt = a.in_stats; p.xs_hw = a.in.H * a.in.W; }
+        if (mode == 0) { p.xs_gt = a.in_stats; p.xs_hw = a.in.H * a.in.W; p.xs_max = a.in_absmax; }
         p.n_nblocks = a.Cout / 192;
         p.n_mtiles = (int)(M / 256);
         if (a.stats) {   // statistics from the epilogue (128 pixels of one image per round)
@@ -3333,6 +3356,15 @@ int gn_apply(const View &x, const float *cA, const float *cB, int act, float *y,
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)g), dim3(256), 0, st, x.p, x.pitch, (long)x.H * x.W, npix, x.C, cA, cB, act, y);
     return check_launch("k_gn_apply");
+}
+
+int tensor_absmax(const View &x, float *amax, hipStream_t st) {
+    HL_REQUIRE(x.p && amax && x.C % 4 == 0 && x.pitch % 4 == 0, "tensor_absmax: bad argument");
+    const long HW = (long)x.H * x.W;
+    if (hipMemsetAsync(amax, 0, (size_t)x.N * sizeof(float), st) != hipSuccess) return fail(HL_ERR_RUNTIME, "tensor_absmax: memset");
+    const unsigned gx = (unsigned)std::min<long>(256, std::max<long>(1, HW * x.C / 16384));
+    hipLaunchKernelGGL(k_tensor_absmax, dim3(gx, (unsigned)x.N), dim3(256), 0, st, x.p, x.pitch, HW, x.C, amax);
+    return check_launch("k_tensor_absmax");
 }
 
 int tensor_totals(const View &x, float *totals, hipStream_t st) {
