@@ -1479,12 +1479,21 @@ __device__ __forceinline__ void importance_tile(const float4 *__restrict__ vc_ti
                 const int i = 64 * b + lane;
                 sg[rr][b] = i < N ? sig[(32LL * i + r8 + rr) * 4] : 0.f;
             }
+        // ... and everything else the eight rays read from memory, requested up front as well (near, far, direction, this lane's two uniforms): walking the rays one
+        // after the other with the loads where they are used exposes a round trip to HBM per ray and stage - 1.1 ms per 512x512 view for this phase, half of it waiting
+        float nr8[8], fr8[8], dx8[8], dy8[8], dz8[8], ua8[8], ub8[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const long long rw = tile * 32 + r8 + rr, ry = rw < R ? rw : R - 1;
+            nr8[rr] = near[ry]; fr8[rr] = far[ry];
+            dx8[rr] = rays_d[ry * 3]; dy8[rr] = rays_d[ry * 3 + 1]; dz8[rr] = rays_d[ry * 3 + 2];
+            ua8[rr] = lane < N ? u[ry * N + lane] : 0.f;
+            ub8[rr] = lane + 64 < N ? u[ry * N + lane + 64] : 0.f;
+        }
         for (int rr = 0; rr < 8; ++rr) {
             const int j = r8 + rr;
-            const long long ray_raw = tile * 32 + j;
-            const long long ray = ray_raw < R ? ray_raw : R - 1;      // padded rays recompute the last one (never read back)
-            const float nr = near[ray], fr = far[ray];
-            const float dxx = rays_d[ray * 3], dyy = rays_d[ray * 3 + 1], dzz = rays_d[ray * 3 + 2];
+            const float nr = nr8[0], fr = fr8[0];
+            const float dxx = dx8[0], dyy = dy8[0], dzz = dz8[0];
             const float dn = sqrtf(dxx * dxx + dyy * dyy + dzz * dzz);
             auto zval = [&](int i) -> float {
                 const float t = linspace01(i, N);
@@ -1532,7 +1541,7 @@ __device__ __forceinline__ void importance_tile(const float4 *__restrict__ vc_ti
             // independent chains of LDS reads instead of one after the other
             const int nc = M + 1;
             const int q0 = lane, q1 = lane + 64;
-            const float u0 = q0 < N ? u[ray * N + q0] : 0.f, u1 = q1 < N ? u[ray * N + q1] : 0.f;
+            const float u0 = ua8[0], u1 = ub8[0];
             int lo0 = 0, hi0 = nc, lo1 = 0, hi1 = nc;
             while (lo0 < hi0 || lo1 < hi1) {
                 const int m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
@@ -1555,15 +1564,16 @@ __device__ __forceinline__ void importance_tile(const float4 *__restrict__ vc_ti
             // Sorted by RANK instead of a bitonic network in LDS (28 dependent LDS round trips per ray): position of z_q = #{z_j < z_q} + #{j < q : z_j = z_q}, the other
             // lanes' values broadcast through v_readlane - no memory, ~600 plain instructions.  The sorted list is the same (the coarse depths are sorted already; the
             // compositing merges), and equal depths are interchangeable.
+            // (keys (depth bits, index): depths are >= 0, so their bit patterns order like the values, and the index breaks ties - one 64-bit compare per pair)
+            const unsigned long long k0 = ((unsigned long long)__builtin_bit_cast(unsigned, z0) << 32) | (unsigned)q0;
+            const unsigned long long k1 = ((unsigned long long)__builtin_bit_cast(unsigned, z1) << 32) | (unsigned)q1;
             int r0 = 0, r1 = 0;
 #pragma unroll 4
             for (int jl = 0; jl < 64; ++jl) {      // (fully unrolled, the 128 broadcast values are all kept in scalar registers at once and spill by the hundred)
-                const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z0), jl));      // z of q = jl
-                const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z1), jl));      // z of q = 64 + jl
-                r0 += (a0 < z0 || (a0 == z0 && jl < lane)) ? 1 : 0;
-                r0 += a1 < z0 ? 1 : 0;
-                r1 += a0 <= z1 ? 1 : 0;
-                r1 += (a1 < z1 || (a1 == z1 && jl < lane)) ? 1 : 0;
+                const unsigned long long a0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, z0), jl) << 32) | (unsigned)jl;          // key of q = jl
+                const unsigned long long a1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, z1), jl) << 32) | (unsigned)(jl + 64);   // key of q = 64 + jl
+                r0 += (a0 < k0 ? 1 : 0) + (a1 < k0 ? 1 : 0);
+                r1 += (a0 < k1 ? 1 : 0) + (a1 < k1 ? 1 : 0);
             }
             // (by rank into the half-tile stage [sample][16 rays]: written out below as 64-byte row pieces - 4-byte stores straight into the tile-major rows cost
             //  32 bytes of HBM write each: 1.1 GB per 512x512 view for 134 MB of depths)
@@ -1579,9 +1589,11 @@ __device__ __forceinline__ void importance_tile(const float4 *__restrict__ vc_ti
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < 7; ++k)
+            for (int k = 0; k < 7; ++k) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) sg[k][b] = sg[k + 1][b];
+                nr8[k] = nr8[k + 1]; fr8[k] = fr8[k + 1]; dx8[k] = dx8[k + 1]; dy8[k] = dy8[k + 1]; dz8[k] = dz8[k + 1]; ua8[k] = ua8[k + 1]; ub8[k] = ub8[k + 1];
+            }
         }
     }
 }
