@@ -3020,7 +3020,10 @@ int conv2d(const ConvArgs &a, hipStream_t st) {
     static const long h3_split_min = [] { const char *e_ = getenv("HL_H2_CONV3_SPLIT_MIN"); return e_ ? atol(e_) : 8L; }();   // developer knob (read once); < 0: no split-K on this kernel
     int h3_splits = 1;
     if (h3_base && !h3 && h3_split_min >= 0 && h16_blocks >= h3_split_min && h16_blocks < h3_min_blocks && a.splitk_ws && !a.out2) {
-        h3_splits = (int)std::min<long>(std::min<long>(256 / h16_blocks, (a.in.C / 32) / 2), 16);
+        static const long h3_min_chunks = [] { const char *e_ = getenv("HL_H2_SPLIT_MIN_CHUNKS"); return e_ ? std::max(1L, atol(e_)) : 2L; }();   // developer knob (read once): chunks of 32 input channels per slab, at least
+        static const long h3_max_splits = [] { const char *e_ = getenv("HL_H2_SPLIT_MAX"); return e_ ? std::max(1L, atol(e_)) : 16L; }();
+        static const long h3_target = [] { const char *e_ = getenv("HL_H2_SPLIT_TARGET"); return e_ ? std::max(1L, atol(e_)) : 256L; }();                // workgroups (of 256 pixels x 192 channels) aimed at
+        h3_splits = (int)std::min<long>(std::min<long>(h3_target / h16_blocks, (a.in.C / 32) / h3_min_chunks), h3_max_splits);
         while (h3_splits > 1 && (size_t)h3_splits * M * a.Cout * sizeof(float) > a.splitk_ws_bytes) --h3_splits;
         if (h3_splits >= 2) h3 = true; else h3_splits = 1;
     }

@@ -1,5 +1,5 @@
 """Developer check: hl_deform_rays output (canonical points / directions of every sample) -> file, for comparing the group-culling
-kernel against the full scan (HL_DEFORM_BRUTE=1) bit for bit.   python scripts/deform_cull_check.py out.pt [local]"""
+kernel against the full scan (HL_DEFORM_BRUTE=1) bit for bit.   python tests/deform_cull_check.py out.pt [local]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time

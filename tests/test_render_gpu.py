@@ -495,7 +495,7 @@ def test_canonical_space_render_matches_oracle(dev):
 def test_deform_group_culling_is_the_full_scan(mode, dev, tmp_path):
     """k_deform_rays_cull (nearest vertex among the candidates of a 64-point group) must return what the full scan returns, bit for
     bit - vertex order without locality, index-local order, and the tight-box geometry with silhouette groups that keep every vertex.
-    The full scan is selected per process (HL_DEFORM_BRUTE), so both runs go through scripts/deform_cull_check.py."""
+    The full scan is selected per process (HL_DEFORM_BRUTE), so both runs go through tests/deform_cull_check.py."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -506,7 +506,7 @@ def test_deform_group_culling_is_the_full_scan(mode, dev, tmp_path):
         if brute:
             env["HL_DEFORM_BRUTE"] = "1"
         out = str(tmp_path / f"{mode}_{int(brute)}.pt")
-        args = [sys.executable, os.path.join(root, "scripts", "deform_cull_check.py"), out] + ([] if mode == "random" else [mode])
+        args = [sys.executable, os.path.join(root, "tests", "deform_cull_check.py"), out] + ([] if mode == "random" else [mode])
         r = subprocess.run(args, env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(torch.load(out))
