@@ -131,6 +131,7 @@ SIGNATURES = {
     "hl_timestep_embedding": (_i, [_p, _p, _i, _i, _p, _p]),
     "hl_mt19937_uniform": (_i, [_p, _i, _p, C.c_int64, _p, _p]),
     "hl_debug_set_h16_min_blocks": (_i, [C.c_long]),
+    "hl_debug_set_single_op_scale_source": (_i, [_i]),
 }
 
 

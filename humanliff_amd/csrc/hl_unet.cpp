@@ -1029,6 +1029,7 @@ int hl_unet_profile_dominant(void *handle, double *h_vals, int *h_key) {
 // Cin_w <= Cin of them (the rest are zero-padded channels with zero weights).  tf = 1: `w` is laid out (Cin_w, Cout, ks, ks) and is
 // read flipped and channel-transposed - the backward-data convolution of the training path.  Only the weight layout the chosen
 // kernel reads is packed (conv2d in plan mode decides first).
+static int g_single_op_scale_from_totals = 0;   // hl_debug_set_single_op_scale_source (test switch)
 static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin, const float *w_oihw, const float *bias, int Cout,
                          int ks, int stride, int upsample, const float *coefA, const float *coefB, int silu,
                          const float *residual, float *out, void *scratch, size_t scratch_bytes, void *stream,
@@ -1109,9 +1110,15 @@ static int conv2d_single(int mode, const float *in, int N, int H, int W, int Cin
     if (a.path != 6) a.w_h2 = nullptr;
     if (a.path == 6 && !coefA && tot_room) {   // fp16x2 products on a raw input: the largest |x| of every image fixes the power-of-two scale of the activation planes
         // (in the network the producers' sum x^2 bounds it; here one pass over the tensor - exact at any magnitude, which the backward-data calls need: gradients are 1e-4 ... 1e-9)
-        rc = hl::tensor_absmax(a.in, tot_room, (hipStream_t)stream);
-        if (rc) return rc;
-        a.in_absmax = tot_room;
+        if (g_single_op_scale_from_totals) {      // (test switch: the network's scale source - the group totals - on a single layer)
+            rc = hl::tensor_totals(a.in, tot_room, (hipStream_t)stream);
+            if (rc) return rc;
+            a.in_stats = tot_room;
+        } else {
+            rc = hl::tensor_absmax(a.in, tot_room, (hipStream_t)stream);
+            if (rc) return rc;
+            a.in_absmax = tot_room;
+        }
     }
     rc = hl::conv2d(a, (hipStream_t)stream);
     if (stat_slots) *stat_slots = a.stat_slots;
@@ -1195,6 +1202,7 @@ int hl_conv2d_nhwc_mode(int conv_mode, const float *in, int N, int H, int W, int
 }
 
 int hl_debug_set_h16_min_blocks(long v) { hl::set_h16_min_blocks(v); return HL_OK; }
+int hl_debug_set_single_op_scale_source(int from_totals) { g_single_op_scale_from_totals = from_totals != 0; return HL_OK; }
 
 int hl_groupnorm_coef(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta, const float *emb,
                       float *coefA, float *coefB, void *scratch, size_t scratch_bytes, void *stream) {

@@ -523,6 +523,10 @@ int hl_timestep_embedding(const int64_t *t, const float *t_float, int B, int dim
 /* Developer / test switch: the number of workgroups from which the convolution dispatch takes k_conv_h16 in the 16-bit modes (default 48,
  * or HL_H16_MIN_BLOCKS read once at the first launch); v < 0 restores the default.  The unit tests run the kernel on single tiles with it. */
 int hl_debug_set_h16_min_blocks(long v);
+/* test switch of the single-convolution entry points (hl_conv2d_nhwc*): where the power-of-two scale of a raw input of the fp16x2 kernels comes from.
+   0 (default): an exact abs-max pass over the input (tensor_absmax); 1: the fixed-point group totals (sum x^2) - what the producers' epilogues leave inside
+   hl_unet_forward - formed here by one pass (tensor_totals), so that the network's scale source can be tested on single layers. */
+int hl_debug_set_single_op_scale_source(int from_totals);
 
 /* sample_pdf's uniforms on the device, bit for bit (replaces `u = torch.rand(...)` on the CPU generator + upload, NeRF/renderer.py:545):
  * continues the mt19937 stream of ATen's CPU generator from `state` (624 words, device) at position `pos` (words of the current block

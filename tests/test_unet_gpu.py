@@ -694,6 +694,50 @@ def test_conv_fp16x2_products_are_scale_invariant(kind, N, H, W, C, Cout, gn):
         assert l2 <= 1.3 * l32 + 5e-8, (a, bx, l2, l32)
 
 
+@pytest.mark.parametrize("kind,N,H,W,C,Cout", [("1x1", 4, 64, 64, 384, 192), ("3x3", 4, 64, 64, 384, 384), ("s2", 2, 128, 128, 96, 192)])
+def test_conv_fp16x2_scale_from_group_totals(kind, N, H, W, C, Cout):
+    """Inside hl_unet_forward the power-of-two scale of a raw input comes from the fixed-point group totals its producers left (|x| <= sqrt(sum x^2),
+    act_scale_totals); the single-op entry points use an exact abs-max pass instead.  hl_debug_set_single_op_scale_source(1) makes them form the totals (one pass,
+    k_tensor_totals) and hand those to the kernels: the network's scale source on single layers.  Same float64 reference at every scale; the totals resolve sum x^2
+    down to ~1e-7 per contribution and poison above 2.7e11 per group, so the window is narrower than the abs-max's: inside it (x 2^-8 ... 2^6 at these sizes) the
+    same bits as at scale 1, outside it the kernels fall back to scale 1 (round 5's behaviour) and only the looser bound holds."""
+    from humanliff_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(N + C + Cout + H + 1)
+    ks, stride = (1, 1) if kind == "1x1" else (3, 2 if kind == "s2" else 1)
+    x = torch.randn((N, H, W, C), generator=g) * 1.5
+    w = torch.randn((Cout, C, ks, ks), generator=g) / (ks * ks * C) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=stride, padding=ks // 2).permute(0, 2, 3, 1)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    scratch = torch.empty(Cout * C * ks * ks * 8 + 256 + (64 << 20), device=dev)
+    wd = w.to(dev)
+    rows = {}
+    try:
+        for src in (0, 1):
+            _lib.check(L.hl_debug_set_single_op_scale_source(src))
+            for bx in (-14, -8, -4, 0, 6, 12):
+                sx = 2.0 ** bx
+                xd, bd = (x * sx).to(dev), (b * sx).to(dev)
+                out = torch.zeros((N, Ho, Wo, Cout), device=dev)
+                _lib.check(L.hl_conv2d_nhwc_mode(_lib.HL_CONV_FP32, _lib.ptr(xd), N, H, W, C, _lib.ptr(wd), _lib.ptr(bd), Cout, ks, stride, 0, None, None, 0, None,
+                                                 _lib.ptr(out), _lib.ptr(scratch), scratch.numel() * 4, _lib.stream_ptr()), "hl_conv2d_nhwc_mode")
+                o = out.cpu().double() / sx
+                rows[(src, bx)] = (float((o - ref).norm() / ref.norm()), o)
+    finally:
+        _lib.check(L.hl_debug_set_single_op_scale_source(0))
+    print(f"{kind} {C}->{Cout}: " + "; ".join(f"{'totals' if s_ else 'absmax'} x 2^{bx}: {v[0]:.2e}" for (s_, bx), v in rows.items()))
+    base = rows[(0, 0)][0]
+    for bx in (-14, -8, -4, 0, 6, 12):
+        assert rows[(0, bx)][0] <= base * 1.001 + 1e-9, (bx, rows[(0, bx)][0], base)           # abs-max: exact at every magnitude
+    for bx in (-8, -4, 0, 6):
+        assert torch.equal(rows[(1, bx)][1], rows[(1, 0)][1]), bx                                # totals: the same bits inside their window ...
+        assert rows[(1, bx)][0] <= base * 1.05 + 2e-8, (bx, rows[(1, bx)][0], base)              # ... and the abs-max figure (the two scales may differ by a power of two)
+    for bx in (-14, 12):
+        assert rows[(1, bx)][0] < 5e-5, (bx, rows[(1, bx)][0])                                    # outside it: scale 1, the unscaled planes' error at that magnitude
+
+
 def test_conv_fp16x2_activations_beyond_fp16_range_match_fp32():
     """|x| = 7e4 is beyond fp16 (65504): round 5's planes saturated silently (v_cvt_pkrtz never produces inf).  The raw input is now scaled by the power of two that
     sqrt(sum x^2) bounds, so the same launch matches the float64 reference like the fp32 direct kernel does."""
