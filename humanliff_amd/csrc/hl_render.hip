@@ -1316,6 +1316,7 @@ template <int NPL> constexpr int PLW_CH_U4 = B3_POS * NPL * 64;            // u3
 template <int NPL> constexpr int PLW_SLOT_U4 = 2 * PLW_CH_U4<NPL>;         // a ring slot = a PAIR of chunks (24 KB / 16 KB)
 template <int NPL> constexpr size_t PLW_BYTES = (size_t)P16_FRAGS * NPL * 1024;
 template <int NPL> constexpr size_t PLW_LDS = (size_t)2 * PLW_SLOT_U4<NPL> * 16 + SMALL_FLOATS * sizeof(float) + (size_t)8 * 512 * 16;
+template <int NPL> constexpr size_t PLW_LDS_FUSE = PLW_LDS<NPL> + (size_t)8 * 4 * 64 * 16;      // (HL_FUSE_LQ: + the gathered coarse records, [wave 8][4][64 lanes] x 16 bytes)
 constexpr size_t B3W_LDS = PLW_LDS<3>;
 template <int NT>
 __device__ __forceinline__ void load_bias_global(f32x16 (&acc)[NT], const float *__restrict__ tbl, int half) {   // load_bias from the packed image in global memory
@@ -1824,6 +1825,38 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
     // Every coarse sample at or in front of zlim.  The record at the cursor was requested while views_linear ran; inside a run every further record costs a round trip
     // to L2 (measured alternatives: two / four records requested together need 4 / 8 more registers from the views stage on and the allocator starts to spill -
     // 6 ... 25 registers of scratch - which costs more than the round trips: every reload is a vmcnt(0) in front of the weight ring's counted waits).
+#ifndef HL_FUSE_LQ
+#define HL_FUSE_LQ 0
+#endif
+#if HL_FUSE_LQ
+    // A / B variant: the LQ records at the cursor ... cursor + LQ - 1 of every lane gathered into a per-wave LDS block [LQ][64 lanes] x 16 bytes by LDS-DMA while
+    // views_linear runs (no registers); waited for in front of the ring advance (where the only other loads in flight are the ring's staged ones, needed there anyway)
+    constexpr int LQ = 4;
+    auto lqp = [&]() __attribute__((always_inline)) -> f32x4 * { const int t_ = opaque_tid(); return reinterpret_cast<f32x4 *>(small + SMALL_FLOATS) + 8 * 512 + (t_ >> 6) * (LQ * 64); };
+    auto lq_request = [&]() __attribute__((always_inline)) {
+        const int t_ = opaque_tid();
+        const long long tl = wg * 8 + (t_ >> 6);
+        const float4 *base_ = a.fz_vc + (tl < tiles_n ? tl : tiles_n - 1) * 32 * (long long)Nc;
+        const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void *)base_, (short)0, Nc * 512, 0x00020000);
+        f32x4 *q_ = lqp();
+#pragma unroll
+        for (int k = 0; k < LQ; ++k) {
+            const int row = ci + k < Nc ? ci + k : Nc - 1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void *)(q_ + k * 64), 16, (row * 32 + (t_ & 31)) * 16, 0, 0, 0);
+        }
+    };
+    auto emit_coarse_until = [&](float zlim) __attribute__((always_inline)) {
+        const f32x4 *q_ = lqp() + (opaque_tid() & 63);
+        int k = 0;
+        while (zco(ci) <= zlim) {
+            f32x4 rec;
+            if (k < LQ) rec = q_[k * 64];
+            else { const float4 r_ = a.fz_vc[((wg * 8 + (opaque_tid() >> 6)) < tiles_n ? (wg * 8 + (opaque_tid() >> 6)) : tiles_n - 1) * 32 * (long long)Nc + 32LL * ci + (opaque_tid() & 31)]; rec = f32x4{r_.x, r_.y, r_.z, r_.w}; }
+            emit(zco(ci), rec[0], half ? rec[2] : rec[1], rec[3]);
+            ++ci; ++k;
+        }
+    };
+#else
     auto emit_coarse_until = [&](float zlim) __attribute__((always_inline)) {
         while (zco(ci) <= zlim) {
             emit(zco(ci), lower_half(crec.x), half ? crec.x : crec.y, crec.y);      // (the density sits in half 0)
@@ -1832,6 +1865,7 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
             if (ci + 1 < Nc) crec1 = vcp()[64LL * (ci + 1)];
         }
     };
+#endif
     auto body = [&](auto rotc) {
     constexpr bool ROT = decltype(rotc)::value;
     for (int s = s_lo; s < s_hi; ++s) {
@@ -1962,11 +1996,15 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
                 for (int r = 0; r < 16; ++r) Y[t][r] *= rsF;
         }
         act_rows(ROW_Y, Y, 1.f);
+#if HL_FUSE_LQ
+        if constexpr (FUSE) lq_request();
+#else
         if constexpr (FUSE) {   // the coarse records at the cursor and behind it: requested here, used at the end of the sample
             const float2 *p_ = vcp();
             crec = p_[64LL * (ci < Nc ? ci : Nc - 1)];
             crec1 = p_[64LL * (ci + 1 < Nc ? ci + 1 : Nc - 1)];
         }
+#endif
         const float sigma_raw = dot_lane<4>(X, small + SM_AW, half) + small[SM_AB];   // X holds softplus(pts_linears.2) by now
         f32x16 V[2];
 #pragma unroll
@@ -1989,6 +2027,9 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
         const float cr = dot_lane<2>(V, small + SM_RW, half) + small[SM_RB + 0];
         const float cg = dot_lane<2>(V, small + SM_RW + 64, half) + small[SM_RB + 1];
         const float cb = dot_lane<2>(V, small + SM_RW + 128, half) + small[SM_RB + 2];
+#if HL_FUSE_LQ
+        if constexpr (FUSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the gathered records (and the ring's staged pair, which B3_ADV writes first thing anyway)
+#endif
         B3_ADV(B3_NCH - 1)                                                          // pair 0 of the next sample (the stream of a sample is chunks 0..31)
         if constexpr (FUSE) {   // the coarse samples in front of (or at: k_composite takes the coarse one first) this depth, then the sample itself
             emit_coarse_until(zc);
@@ -2004,11 +2045,16 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
     if ((tid >> 6) < 4) body(std::false_type{});
     else body(std::true_type{});
     if constexpr (FUSE) {   // the coarse samples behind the last new depth, the last sample (distance 1e10: renderer.py:213), the image
+#if HL_FUSE_LQ
+        lq_request();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         {
             const float2 *p_ = vcp();
             crec = p_[64LL * (ci < Nc ? ci : Nc - 1)];
             crec1 = p_[64LL * (ci + 1 < Nc ? ci + 1 : Nc - 1)];
         }
+#endif
         emit_coarse_until(3.0e38f);                                 // (zco is +inf behind the last coarse sample)
         finish_pending(1e10f);
         const float cW = __shfl(cB, lane & 31);                 // the sum of the weights (half 0 keeps it)
@@ -4022,9 +4068,9 @@ static int render_onepass_fine(const void *mlp_packed, const void *planes_packed
     const dim3 grid((unsigned)((n_rays + 255) / 256));
     if (npl == 2) {
         const unsigned short *ph2 = reinterpret_cast<const unsigned short *>(static_cast<const char *>(mlp_packed) + (size_t)PACKED_FLOATS * sizeof(float) + (size_t)P16_FRAGS * 1024 + B3_BYTES);
-        static const bool okh = hipFuncSetAttribute((const void *)k_march_plw<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLW_LDS<2>) == hipSuccess;
-        HL_REQUIRE(okh, "k_march_plw<2, one-pass>: cannot raise the dynamic LDS limit to %zu bytes", PLW_LDS<2>);
-        hipLaunchKernelGGL((k_march_plw<2, false, true>), grid, dim3(512), PLW_LDS<2>, (hipStream_t)stream, a, ph2);
+        static const bool okh = hipFuncSetAttribute((const void *)k_march_plw<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLW_LDS_FUSE<2>) == hipSuccess;
+        HL_REQUIRE(okh, "k_march_plw<2, one-pass>: cannot raise the dynamic LDS limit to %zu bytes", PLW_LDS_FUSE<2>);
+        hipLaunchKernelGGL((k_march_plw<2, false, true>), grid, dim3(512), PLW_LDS_FUSE<2>, (hipStream_t)stream, a, ph2);
         return hl::check_launch("k_march_plw<2, one-pass>");
     }
     return hl::fail(HL_ERR_UNSUPPORTED, "render_onepass_fine: the one-pass launch exists for the fp16x2 products only");
