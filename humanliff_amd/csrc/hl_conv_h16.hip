@@ -163,19 +163,24 @@ __device__ __forceinline__ void h16_epilogue(const ConvK &p, char *lds, const f3
     }
 }
 
+#ifndef HL_ACT_SCALE
+#define HL_ACT_SCALE 1      // developer A / B: 0 = no power-of-two activation scale (sx = 1 everywhere)
+#endif
 struct H2Pair { unsigned p0, p1; };
 // a pair of values -> the two packed planes.  Default (round 6, H2_SPLIT_RNE = 2): h0 = the NEAREST fp16 (v_cvt_pk_f16_f32), h1 = the nearest fp16 of the residual
-// against h0 converted back (exact in fp32): |x - h0 - h1| <= 2^-24 |x| while both planes are normal, six instructions per pair like the truncating split, and a
-// value beyond fp16's range becomes inf / NaN (loud) where round 5's v_cvt_pkrtz_f16_f32 saturated at 65504 without a trace.  The staging scales its input so
-// that neither a plane overflows nor the low plane goes subnormal wherever the tensor's totals are known (hl_stats.h).  Measured (same box, A / B of three
-// builds): forward time unchanged; rel-L2 against float64 3.50e-7 / 3.43e-7 / 3.28e-7 (stride-2, K = 864) for H2_SPLIT_RNE = 0 / 1 / 2.
+// against h0 (v_fma_mix_f32 reads the packed halves: exact in fp32): |x - h0 - h1| <= 2^-24 |x| while both planes are normal, FOUR instructions per pair
+// (hl_split2_rne, hl_common.h) where round 5's truncating split took six, and a value beyond fp16's range becomes inf / NaN (loud) where v_cvt_pkrtz_f16_f32
+// saturated at 65504 without a trace.  The staging scales its input so that neither a plane overflows nor the low plane goes subnormal wherever the tensor's
+// totals are known (hl_stats.h).  rel-L2 against float64 3.50e-7 / 3.43e-7 / 3.28e-7 (stride-2, K = 864) for H2_SPLIT_RNE = 0 / 1 / 2.  Time: the forward is
+// 1 % (B = 1) to 3 % (B = 4) slower than round 5's on the same box, and none of it is instructions - planes that keep all their mantissa bits make the matrix
+// pipe draw more power, and the chip clocks down under its cap (profiles/r06_unet_regression.md, scripts/microbench/mfma_data_power.hip).
 // 0: h0 = the value with its low 13 mantissa bits cleared, both conversions truncating (round 5); 1: the same h0, h1 to nearest.
 #ifndef H2_SPLIT_RNE
 #define H2_SPLIT_RNE 2
 #endif
 __device__ __forceinline__ H2Pair split_h2(float x, float y) {
     const float hx = __builtin_bit_cast(float, __float_as_uint(x) & 0xffffe000u), hy = __builtin_bit_cast(float, __float_as_uint(y) & 0xffffe000u);
-#if H2_SPLIT_RNE == 2   // h0 = the NEAREST fp16 (v_cvt_pk_f16_f32), residual against its conversion back: |x - h0 - h1| <= 2^-23 |x|, the same six instructions (hl_common.h)
+#if H2_SPLIT_RNE == 2
     H2Pair r;
     hl_split2_rne(x, y, r.p0, r.p1);
     return r;
@@ -590,9 +595,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2s(const ConvK p) {
         if (p.cA) {
             for (int c = tid; c < p.Cin; c += 256) { sA[c] = p.cA[(long)img * p.Cin + c]; sB[c] = p.cB[(long)img * p.Cin + c]; }
             __syncthreads();
-        } else sx = wave_uniform(coef_to_lds<true>(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256));      // (ends with a barrier)
-    } else if (p.xs_max && !p.in16) sx = wave_uniform(pow2_scale_for_bound(p.xs_max[img]));
-    else if (p.xs_gt && !p.in16) sx = wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw));
+        } else sx = wave_uniform(coef_to_lds<HL_ACT_SCALE != 0>(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256));      // (ends with a barrier)
+    } else if (HL_ACT_SCALE && p.xs_max && !p.in16) sx = wave_uniform(pow2_scale_for_bound(p.xs_max[img]));
+    else if (HL_ACT_SCALE && p.xs_gt && !p.in16) sx = wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw));
     const float rsx = 1.f / sx;
     kq *= rsx;
 #pragma unroll
@@ -910,7 +915,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_h2d(const ConvK p) {
         }
     };
     // power-of-two scale of the raw input from its producers' totals (hl_stats.h)
-    const float axs = p.xs_max ? wave_uniform(pow2_scale_for_bound(p.xs_max[img])) : (p.xs_gt ? wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw)) : 1.f), rsx = 1.f / axs;
+    const float axs = !HL_ACT_SCALE ? 1.f : p.xs_max ? wave_uniform(pow2_scale_for_bound(p.xs_max[img])) : (p.xs_gt ? wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw)) : 1.f), rsx = 1.f / axs;
     auto a_store = [&](int j) {
         const f32x4 v0 = __builtin_bit_cast(f32x4, ar[j][0]) * axs, v1 = __builtin_bit_cast(f32x4, ar[j][1]) * axs;
         const H2Pair q0 = split_h2(v0[0], v0[1]), q1 = split_h2(v0[2], v0[3]), q2 = split_h2(v1[0], v1[1]), q3 = split_h2(v1[2], v1[3]);
@@ -1078,9 +1083,9 @@ __global__ __launch_bounds__(256, 2) void k_conv1_h2s(const ConvK p) {
         if (p.cA) {
             for (int c = tid; c < p.Cin; c += 256) { sA[c] = p.cA[(long)img * p.Cin + c]; sB[c] = p.cB[(long)img * p.Cin + c]; }
             __syncthreads();
-        } else sx = wave_uniform(coef_to_lds<true>(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256));      // (ends with a barrier)
-    } else if (p.xs_max && !p.in16) sx = wave_uniform(pow2_scale_for_bound(p.xs_max[img]));
-    else if (p.xs_gt && !p.in16) sx = wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw));
+        } else sx = wave_uniform(coef_to_lds<HL_ACT_SCALE != 0>(nullptr, nullptr, p.gn, p.N, img, sA, sB, sB + p.Cin, tid, 256));      // (ends with a barrier)
+    } else if (HL_ACT_SCALE && p.xs_max && !p.in16) sx = wave_uniform(pow2_scale_for_bound(p.xs_max[img]));
+    else if (HL_ACT_SCALE && p.xs_gt && !p.in16) sx = wave_uniform(act_scale_totals(p.xs_gt, p.N, img, p.xs_hw));
     const float rsx = 1.f / sx;
     kq *= rsx;
 #pragma unroll

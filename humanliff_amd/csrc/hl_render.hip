@@ -1403,8 +1403,14 @@ __device__ __forceinline__ void mma_b3(f32x16 (&acc)[NT], const u32x4 (&b)[3], c
 // to fp16 keeps), so the residual x - h0 is exact in fp32; both planes packed by v_cvt_pkrtz_f16_f32.  Range: |x| < 65504 (fp16); values below
 // 2^-14 keep an ABSOLUTE error of 2^-24.
 #ifndef HL_RENDER_SPLIT_RNE
-#define HL_RENDER_SPLIT_RNE 0   // 1 (round 6, measured and NOT taken: +1.0 ms per 512x512 view, 26.1 -> 27.0 on the same box - the kernel is bound by its vector ALU and v_cvt_f32_f16 is not a plain-rate instruction): h0 = the nearest fp16, h1 = the nearest fp16 of the residual against h0 converted back (2^-24; a value beyond fp16 becomes inf / NaN);
-#endif                          // 0: round 5's truncating split (h0 = the low 13 mantissa bits cleared, v_cvt_pkrtz: 2^-20, saturates silently) - the same six instructions per pair
+// 1 (round 6, measured twice and NOT taken): hl_split2_rne - h0 = the nearest fp16, h1 = the nearest fp16 of the residual (2^-24; a value beyond fp16 becomes
+// inf / NaN).  With the four-instruction form (hl_common.h) the kernels issue 7 % fewer vector instructions than with the truncating split below (7802 against
+// 8385 in k_march_plw<2>), and every instruction involved issues at full rate (scripts/microbench/valu_rate.hip) - but the coarse kernel then needs 256 registers
+// plus 84 bytes of scratch inside its sample loop (230 and none with the truncating split), and a view takes 27.2 - 27.6 ms instead of 26.4 - 26.9 on the same box.
+// 0: round 5's truncating split (h0 = the low 13 mantissa bits cleared, v_cvt_pkrtz: 2^-20, saturates silently - the clamped softplus and the sigma / rgb heads
+// keep the renderer's activations far inside fp16's range).
+#define HL_RENDER_SPLIT_RNE 0
+#endif
 __device__ __forceinline__ void split_h2t(const f32x16 &v, int hi, u32x4 (&pl)[2]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -102,12 +102,25 @@ __device__ __forceinline__ void wg_group_flush(const float *red, unsigned long l
 __device__ __forceinline__ void group_mean_rstd(const float *gt, int N, int n, int g, long HW, int cg, float eps, float &mean_f, float &rstd) {
     long long S = 0, Q = 0;
     bool bad = false;
-    const int ns = stat_shards(HW);
-    for (int sh = 0; sh < ns; ++sh) {
-        const longlong2 t = *reinterpret_cast<const longlong2 *>(reinterpret_cast<const long long *>(gt) + (((long)sh * N + n) * 32 + g) * 2);
-        S += t.x;
-        Q += t.y;
-        bad |= t.y < 0 || (unsigned long long)t.y >= STAT_POISON;
+    const long long *g0 = reinterpret_cast<const long long *>(gt) + ((long)n * 32 + g) * 2;
+    const long pitch = (long)N * 64;                  // 64-bit words per shard
+    // (the copies are requested TOGETHER: a loop of load - wait - add is eight round trips to L2 at the head of every workgroup of the upper levels)
+    if (stat_shards(HW) == 8) {
+        longlong2 t[8];
+#pragma unroll
+        for (int sh = 0; sh < 8; ++sh) t[sh] = *reinterpret_cast<const longlong2 *>(g0 + sh * pitch);
+#pragma unroll
+        for (int sh = 0; sh < 8; ++sh) {
+            S += t[sh].x;
+            Q += t[sh].y;
+            bad |= t[sh].y < 0 || (unsigned long long)t[sh].y >= STAT_POISON;
+        }
+    } else {
+        static_assert(stat_shards(0) == 1 && stat_shards(1l << 40) == 8, "stat_shards is 1 or 8");
+        const longlong2 t = *reinterpret_cast<const longlong2 *>(g0);
+        S = t.x;
+        Q = t.y;
+        bad = t.y < 0 || (unsigned long long)t.y >= STAT_POISON;
     }
     bad |= Q < 0 || (unsigned long long)Q >= STAT_POISON;
     const double cnt = (double)HW * cg;
@@ -123,7 +136,8 @@ __device__ __forceinline__ void group_mean_rstd(const float *gt, int N, int n, i
 // when the tensor's rms is O(1), 2^-15 of the rms for a tensor at 2^-10; above, the round-toward-zero conversion saturates without a trace.  So the
 // staging multiplies by a power of two sx chosen from a BOUND of the image's largest magnitude (exact; undone in the epilogue):
 //   * raw input: |x| <= sqrt(sum x^2), the sum taken from the group totals the tensor's producer(s) left (act_scale_totals);
-//   * behind a fused GroupNorm: |gamma' xhat + beta'| <= max|gamma'| sqrt(n_g) + max|beta'| (Cauchy-Schwarz over the group's n_g values; coef_to_lds).
+//   * behind a fused GroupNorm: |gamma' xhat + beta'| <= max|gamma'| sqrt(n_g) + max|beta'| (Cauchy-Schwarz over the group's n_g values; coef_to_lds;
+//     gamma' = gamma (1 + scale), beta' = beta (1 + scale) + shift: a bound that needs the parameters and the embedding only).
 // |x sx| <= 32752, so a plane cannot overflow, and whatever the tensor's magnitude the planes keep their precision relative to that bound.
 __device__ __forceinline__ float pow2_scale_for_bound(float bound) {   // the power of two sx with bound * sx in (16376, 32752]; 1 when the bound is 0 / not finite
     if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
@@ -135,21 +149,49 @@ __device__ __forceinline__ float pow2_scale_for_bound(float bound) {   // the po
 // every lane of the wave returns the same value; gt = [shard][N][32][2] totals of image n's tensor (any grouping), HW its pixels per image
 __device__ __forceinline__ float act_scale_totals(const float *gt, int N, int n, long HW) {
     const int g = threadIdx.x & 31;
-    double Q = 0.0;
+    long long Qi = 0;
     int bad = 0;
-    const int ns = stat_shards(HW);
-    for (int sh = 0; sh < ns; ++sh) {
-        const long long q = reinterpret_cast<const long long *>(gt)[(((long)sh * N + n) * 32 + g) * 2 + 1];
-        bad |= q < 0 || (unsigned long long)q >= STAT_POISON;
-        Q += (double)q;
-    }
+    const long long *g0 = reinterpret_cast<const long long *>(gt) + ((long)n * 32 + g) * 2 + 1;
+    const long pitch = (long)N * 64;
+    if (stat_shards(HW) == 8) {                       // (requested together, as in group_mean_rstd)
+        long long q[8];
 #pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        Q += __shfl_xor(Q, d);
-        bad |= __shfl_xor(bad, d);
+        for (int sh = 0; sh < 8; ++sh) q[sh] = g0[sh * pitch];
+#pragma unroll
+        for (int sh = 0; sh < 8; ++sh) {
+            bad |= q[sh] < 0 || (unsigned long long)q[sh] >= STAT_POISON;
+            Qi += q[sh];
+        }
+    } else {
+        Qi = g0[0];
+        bad = Qi < 0 || (unsigned long long)Qi >= STAT_POISON;
     }
+    bad |= Qi < 0 || (unsigned long long)Qi >= STAT_POISON;
+    // the 32 groups' sums of squares as floats (a bound needs no more; the 1.0001 below covers the rounding), added inside each row of 16 lanes with
+    // four DPP steps in a fixed order, then the two rows (lanes 32-63 hold the same 32 values again)
+    float Q = (float)Qi;
+    Q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, Q), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    Q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, Q), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    Q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, Q), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    Q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, Q), 0x140, 0xF, 0xF, true));    // row_mirror
+    const float Qt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Q), 0)) +
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Q), 16));
     // (a poisoned / overflowed block says nothing about the magnitudes: scale 1, and the planes' own range decides)
-    return bad ? 1.f : pow2_scale_for_bound((float)sqrt(Q * (1.0 / STAT_SC_SQ)) * 1.0001f + 1e-30f);
+    return __ballot(bad) ? 1.f : pow2_scale_for_bound(sqrtf(Qt * (float)(1.0 / STAT_SC_SQ)) * 1.0001f + 1e-30f);
+}
+
+// max over the wave's 64 lanes of an unsigned value, the same in every lane's return (four DPP steps leave each row of 16 with its maximum -
+// max is idempotent, so the mirror steps may count a lane twice - then one readlane per row)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = v > t ? v : t;     // quad_perm [1,0,3,2]
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); v = v > t ? v : t;     // quad_perm [2,3,0,1]
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); v = v > t ? v : t;    // row_half_mirror
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); v = v > t ? v : t;    // row_mirror
+    const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16), r2 = __builtin_amdgcn_readlane(v, 32),
+                   r3 = __builtin_amdgcn_readlane(v, 48);
+    const unsigned a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
 }
 
 // ---- consumer side: the affine of image n into LDS (sA[c], sB[c], c < C) ------------------------------------------------------------------
@@ -167,49 +209,73 @@ __device__ __forceinline__ float coef_to_lds(const float *cA, const float *cB, c
         return 1.f;
     }
     const int cg = C / 32;
-    // (the parameters of the thread's first channel are requested together with the group totals: one round trip instead of two)
-    float ga0 = 0.f, be0 = 0.f, sc0 = 0.f, sf0 = 0.f;
-    if (tid < C) {
-        ga0 = gn.gamma[tid]; be0 = gn.beta[tid];
-        if (gn.emb) { sc0 = gn.emb[(long)n * gn.emb_pitch + tid]; sf0 = gn.emb[(long)n * gn.emb_pitch + C + tid]; }
-    }
+    // The parameters of the thread's first NB channels (tid + k nthr) are requested together with the group totals - one round trip for everything a table of up to
+    // NB nthr channels needs - and stay in registers for both passes below; only wider tables (the 1536-channel decoder inputs at 256 threads) load again, a batch
+    // at a time.  (A loop of load - wait - use per channel, which is what the plain form compiles to, costs a round trip to L2 per iteration, twice with SCALE.)
+    constexpr int NB = 4;
+    float ga[NB], be[NB], sc[NB], sf[NB];
+    auto load_batch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int c = c0 + k * nthr < C ? c0 + k * nthr : C - 1;         // (clamped: unconditional loads, the stores below are predicated)
+            ga[k] = gn.gamma[c]; be[k] = gn.beta[c];
+            if (gn.emb) { sc[k] = gn.emb[(long)n * gn.emb_pitch + c]; sf[k] = gn.emb[(long)n * gn.emb_pitch + C + c]; }
+        }
+    };
+    load_batch(tid);
     if (tid < 32) {
         float m, r;
         group_mean_rstd(gn.gt, N, n, tid, gn.HW, cg, gn.eps, m, r);
         scr[tid] = m; scr[32 + tid] = r;
     }
-    if (SCALE && tid == 0) { scr[64] = 0.f; scr[65] = 0.f; }
-    __syncthreads();
-    float gmax = 0.f, bmax = 0.f;                      // max |gamma'|, max |beta'| over this thread's channels
-    for (int c = tid; c < C; c += nthr) {
-        const int g = c / cg;
-        const bool first = c == tid;
-        float ga = first ? ga0 : gn.gamma[c], be = first ? be0 : gn.beta[c];
-        float a = scr[32 + g] * ga;
-        float b = be - scr[g] * a;
-        if (gn.emb) {
-            const float sc = 1.f + (first ? sc0 : gn.emb[(long)n * gn.emb_pitch + c]);
-            const float sf = first ? sf0 : gn.emb[(long)n * gn.emb_pitch + C + c];
-            a = a * sc;
-            b = b * sc + sf;
-            ga = ga * sc; be = be * sc + sf;
+    const int nw = nthr >> 6;
+    if (SCALE) {
+        // max |gamma'|, max |beta'| of the image depend on the parameters and the embedding only, not on the statistics: formed while the 32
+        // threads above wait for their totals, reduced inside the wave with DPP (non-negative floats order like their bit patterns) and left
+        // per wave in scr[64 + w], scr[72 + w] - no atomics, no barrier and no pass over the table beyond what the unscaled form has.
+        float gmax = 0.f, bmax = 0.f;
+        for (int c0 = tid; c0 < C; c0 += NB * nthr) {
+            if (c0 != tid) load_batch(c0);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                float g1 = ga[k], b1 = be[k];
+                if (gn.emb) { const float s1 = 1.f + sc[k]; g1 = g1 * s1; b1 = b1 * s1 + sf[k]; }
+                gmax = fmaxf(gmax, fabsf(g1)); bmax = fmaxf(bmax, fabsf(b1));      // (a clamped slot repeats channel C - 1: harmless in a maximum)
+            }
         }
-        sA[c] = a;
-        sB[c] = b;
-        if (SCALE) { gmax = fmaxf(gmax, fabsf(ga)); bmax = fmaxf(bmax, fabsf(be)); }
+        const unsigned gm = wave_max_u32(__float_as_uint(gmax)), bm = wave_max_u32(__float_as_uint(bmax));
+        if ((tid & 63) == 0) { scr[64 + (tid >> 6)] = __uint_as_float(gm); scr[72 + (tid >> 6)] = __uint_as_float(bm); }
+        if (C > NB * nthr) load_batch(tid);                                        // (the registers hold the last batch: fetch the first again)
     }
-    if (!SCALE) { __syncthreads(); return 1.f; }
-    // (non-negative floats order like their bit patterns)
-    atomicMax(reinterpret_cast<unsigned *>(scr + 64), __float_as_uint(gmax));
-    atomicMax(reinterpret_cast<unsigned *>(scr + 65), __float_as_uint(bmax));
     __syncthreads();
-    const float sx = pow2_scale_for_bound(scr[64] * sqrtf((float)gn.HW * (float)cg) * 1.0001f + scr[65]);
-    if (sx != 1.f) {
-        for (int c = tid; c < C; c += nthr) { sA[c] *= sx; sB[c] *= sx; }
+    float sx = 1.f;
+    if (SCALE) {
+        float gmax = 0.f, bmax = 0.f;
+        for (int w = 0; w < nw; ++w) { gmax = fmaxf(gmax, scr[64 + w]); bmax = fmaxf(bmax, scr[72 + w]); }
+        sx = pow2_scale_for_bound(gmax * sqrtf((float)gn.HW * (float)cg) * 1.0001f + bmax);
+    }
+    for (int c0 = tid; c0 < C; c0 += NB * nthr) {
+        if (c0 != tid) load_batch(c0);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int c = c0 + k * nthr;
+            if (c < C) {
+                const int g = c / cg;
+                float a = scr[32 + g] * ga[k];
+                float b = be[k] - scr[g] * a;
+                if (gn.emb) {
+                    const float s1 = 1.f + sc[k];
+                    a = a * s1;
+                    b = b * s1 + sf[k];
+                }
+                sA[c] = a * sx;        // (sx is a power of two: the scaled table is the exact table, scaled)
+                sB[c] = b * sx;
+            }
+        }
     }
     __syncthreads();
     return sx;
 }
-constexpr int COEF_SCR_FLOATS = 68;
+constexpr int COEF_SCR_FLOATS = 80;   // 32 means, 32 rstd, 8 + 8 per-wave maxima
 
 }  // namespace hl
