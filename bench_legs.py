@@ -20,6 +20,7 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{f16,bf16}, dense
+PEAK_F16_FULL_MANTISSA_TFLOPS = 1655.0   # measured: independent v_mfma_f32_32x32x16_f16 on normal fp16 operands with random 10-bit mantissas (zeros: 2481) - scripts/microbench/mfma_data_power.hip
 UNET_GFLOP_PER_SAMPLE_STEP = 2015.4
 RENDER_FLOP_PER_RAY = 128 * 79616 + 256 * 132608   # 44 138 496 at 128+128
 FULL_FLOP_PER_POINT = 132608            # density + colour MLP at one sample point
@@ -173,8 +174,9 @@ def bench_unet(args, rank, world, dev):
         dom_exec = 3.0 * dv[1] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         dom_peak = PEAK_BF16_MFMA_TFLOPS       # (v_mfma_f32_32x32x16_f16 and _bf16 share the dense 16-bit peak)
         dom_note = ("fp16 FLOPs ISSUED (three partial products per fp32 product of the direct convolution) against the dense fp16 matrix peak; the same launches in the "
-                    "path's own unit: `algorithmic` (fp32-equivalent work) - under this load the matrix pipe runs at 1.5 - 1.7 GHz, MFMAs alone take 0.73 of the kernel's time "
-                    "(profiles/r05_unet_fill_experiments.md, sections 6 - 8)")
+                    "path's own unit: `algorithmic` (fp32-equivalent work).  The 2.5 PFLOP/s peak is reached with zero operands only: under the power cap a chain of "
+                    "independent v_mfma_f32_32x32x16_f16 on full-mantissa fp16 operands runs at 1655 TFLOP/s (`peak_full_mantissa`, scripts/microbench/mfma_data_power.hip, "
+                    "profiles/r06_unet_regression.md); MFMAs alone take 0.73 of the kernel's time (profiles/r05_unet_fill_experiments.md, sections 6 - 8)")
     dominant = {"kernel": fam, "layers": f"{dk[4]}x{dk[4]} convolutions with {dk[3]} output channels @{256 >> dk[1]}x{256 >> dk[1]}, batch {B}"
                                          + (" behind a nearest-x2 upsample" if dk[2] else "") + " (all input channel counts: one rocprofv3 kernel / grid row)",
                 "launches_per_step": int(dv[3]), "avg_launch_ms": round(dom_ms, 4), "total_ms_per_step": round(dv[0], 3),
@@ -193,6 +195,8 @@ def bench_unet(args, rank, world, dev):
     roof = {"bound": "mfma", "kernel": dominant["kernel"] + ": " + dominant["layers"],
             "achieved": round(dom_exec, 2), "peak": dom_peak, "unit": "TFLOP/s", "frac": round(dom_exec / dom_peak, 4),
             "avg_launch_ms": dominant["avg_launch_ms"], "launches_per_step": dominant["launches_per_step"], "ms_per_step_in_this_kernel": dominant["total_ms_per_step"],
+            "peak_full_mantissa": PEAK_F16_FULL_MANTISSA_TFLOPS if dk[0] == 6 else None,
+            "frac_of_full_mantissa_peak": round(dom_exec / PEAK_F16_FULL_MANTISSA_TFLOPS, 4) if dk[0] == 6 else None,
             "algorithmic": {"tflops": dominant["algorithmic_tflops"], "x_peak": round((dominant["algorithmic_tflops"] or 0.0) / PEAK_F32_MFMA_TFLOPS, 4),
                             "note": "direct-convolution FLOPs (SURVEY 8(d): 2*M*Cout*Cin*taps) of the same launches over the same time; not a roofline fraction"},
             "note": dom_note or ("fp32 MFMA and the vector ALU share the SIMD's fp32 lanes (scripts/microbench/mfma_fill.hip): the kernel's own input transform (VALU) is "

@@ -56,7 +56,7 @@ def _pick(d, keys):
 def _roofline(r, short_kernel=None):
     if not isinstance(r, dict):
         return None
-    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic"))
+    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "peak_full_mantissa", "frac_of_full_mantissa_peak"))
     out["kernel"] = _clip(short_kernel or str(r.get("kernel", "")).split(" (")[0], 100)
     out.setdefault("traffic", None)
     launch = r.get("avg_launch_ms", r.get("launch_ms"))

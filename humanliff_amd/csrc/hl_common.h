@@ -56,20 +56,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // takes v_cvt_pk_f16_f32 of the rounded product: where the two roundings differ - one fp16 ulp, a few values in a thousand - the residual is formed against another
 // h0 than the one stored and the pair is off by 2^-11 (found in the attention's scaled K operand: max-abs 4e-5 instead of 2e-6; -ffp-contract=off does not stop
 // that fold).  scripts/microbench/split_mix.hip checks these four instructions against the plain C form bit for bit, subnormals, infinities and NaN included.
-#ifndef HL_SPLIT_ASM
-#define HL_SPLIT_ASM 1
-#endif
-__device__ __forceinline__ void hl_split2_rne(float x, float y, unsigned &p0, unsigned &p1) {
-    // (ONE asm statement: the compiler, which treats every asm statement as a hazard it cannot see into, pads once per pair instead of four times; x and y are
-    // read only - the callers' values often stay live - and the residuals pass through p1 and one scratch register)
-#if HL_SPLIT_ASM
-    float t;
-    asm("v_cvt_pk_f16_f32 %0, %3, %4\n\t"
-        "v_fma_mix_f32 %1, %0, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_cvt_pk_f16_f32 %1, %1, %2"
-        : "=&v"(p0), "=&v"(p1), "=&v"(t) : "v"(x), "v"(y));
-#else
+// the same planes left to the compiler (v_cvt_pk_f16_f32, two unpacking conversions, v_pk_fma_f32 / two subtractions, v_cvt_pk_f16_f32): for kernels whose register
+// allocation the asm form upsets.  The empty asm statements pin the operands, see above.
+__device__ __forceinline__ void hl_split2_rne_c(float x, float y, unsigned &p0, unsigned &p1) {
     typedef _Float16 hl_h2 __attribute__((ext_vector_type(2)));
     typedef float hl_f2 __attribute__((ext_vector_type(2)));
     asm("" : "+v"(x), "+v"(y));
@@ -77,6 +66,15 @@ __device__ __forceinline__ void hl_split2_rne(float x, float y, unsigned &p0, un
     asm("" : "+v"(p0));
     const hl_h2 h0 = __builtin_bit_cast(hl_h2, p0);
     p1 = __builtin_bit_cast(unsigned, __builtin_convertvector((hl_f2){x - (float)h0[0], y - (float)h0[1]}, hl_h2));
-#endif
+}
+__device__ __forceinline__ void hl_split2_rne(float x, float y, unsigned &p0, unsigned &p1) {
+    // (ONE asm statement: the compiler, which treats every asm statement as a hazard it cannot see into, pads once per pair instead of four times; x and y are
+    // read only - the callers' values often stay live - and the residuals pass through p1 and one scratch register)
+    float t;
+    asm("v_cvt_pk_f16_f32 %0, %3, %4\n\t"
+        "v_fma_mix_f32 %1, %0, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %1, %1, %2"
+        : "=&v"(p0), "=&v"(p1), "=&v"(t) : "v"(x), "v"(y));
 }
 #endif

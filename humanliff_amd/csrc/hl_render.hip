@@ -1403,31 +1403,38 @@ __device__ __forceinline__ void mma_b3(f32x16 (&acc)[NT], const u32x4 (&b)[3], c
 // to fp16 keeps), so the residual x - h0 is exact in fp32; both planes packed by v_cvt_pkrtz_f16_f32.  Range: |x| < 65504 (fp16); values below
 // 2^-14 keep an ABSOLUTE error of 2^-24.
 #ifndef HL_RENDER_SPLIT_RNE
-// 1 (round 6, measured twice and NOT taken): hl_split2_rne - h0 = the nearest fp16, h1 = the nearest fp16 of the residual (2^-24; a value beyond fp16 becomes
-// inf / NaN).  With the four-instruction form (hl_common.h) the kernels issue 7 % fewer vector instructions than with the truncating split below (7802 against
-// 8385 in k_march_plw<2>), and every instruction involved issues at full rate (scripts/microbench/valu_rate.hip) - but the coarse kernel then needs 256 registers
-// plus 84 bytes of scratch inside its sample loop (230 and none with the truncating split), and a view takes 27.2 - 27.6 ms instead of 26.4 - 26.9 on the same box.
+// 1 (round 6, measured three times and NOT taken): nearest-even planes - h0 = the nearest fp16, h1 = the nearest fp16 of the residual (2^-24; a value beyond fp16
+// becomes inf / NaN).  With hl_split2_rne's four-instruction form (hl_common.h) the kernels issue 7 % fewer vector instructions than with the truncating split below
+// (7802 against 8385 in k_march_plw<2>) and every instruction involved issues at full rate (scripts/microbench/valu_rate.hip), yet a view takes 26.67 ms against
+// 25.90 on the same box - also in the build where no kernel spills (the coarse kernel takes the compiler's five-instruction form, split_h2t<1>: with the asm form
+// its sample loop needs 84 bytes of scratch).  The staging of these kernels is placed between the MFMAs by instruction class (sched_group_barrier), and an asm
+// statement belongs to no class.
 // 0: round 5's truncating split (h0 = the low 13 mantissa bits cleared, v_cvt_pkrtz: 2^-20, saturates silently - the clamped softplus and the sigma / rgb heads
 // keep the renderer's activations far inside fp16's range).
 #define HL_RENDER_SPLIT_RNE 0
 #endif
+template <int MODE = 0>   // 0: truncating; 1: nearest, left to the compiler (five instructions per pair); 2: nearest, hl_split2_rne's four - the same planes as 1, bit for bit
 __device__ __forceinline__ void split_h2t(const f32x16 &v, int hi, u32x4 (&pl)[2]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float x = v[8 * hi + 2 * q], y = v[8 * hi + 2 * q + 1];
-#if HL_RENDER_SPLIT_RNE
-        unsigned w0, w1;
-        hl_split2_rne(x, y, w0, w1);
-        pl[0][q] = w0; pl[1][q] = w1;
-#else
-        const float hx = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffffe000u), hy = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, y) & 0xffffe000u);
-        pl[0][q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hx, hy));
-        pl[1][q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy));
-#endif
+        if constexpr (MODE == 2) {
+            unsigned w0, w1;
+            hl_split2_rne(x, y, w0, w1);
+            pl[0][q] = w0; pl[1][q] = w1;
+        } else if constexpr (MODE == 1) {
+            unsigned w0, w1;
+            hl_split2_rne_c(x, y, w0, w1);
+            pl[0][q] = w0; pl[1][q] = w1;
+        } else {
+            const float hx = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffffe000u), hy = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, y) & 0xffffe000u);
+            pl[0][q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hx, hy));
+            pl[1][q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy));
+        }
     }
 }
-__device__ __forceinline__ void split_plt(const f32x16 &v, int hi, u32x4 (&pl)[3]) { split_b3t(v, hi, pl); }
-__device__ __forceinline__ void split_plt(const f32x16 &v, int hi, u32x4 (&pl)[2]) { split_h2t(v, hi, pl); }
+template <int MODE = 0> __device__ __forceinline__ void split_plt(const f32x16 &v, int hi, u32x4 (&pl)[3]) { split_b3t(v, hi, pl); }
+template <int MODE = 0> __device__ __forceinline__ void split_plt(const f32x16 &v, int hi, u32x4 (&pl)[2]) { split_h2t<MODE>(v, hi, pl); }
 // NT output tiles x one 8-wide k-group for NPL planes: the partial products, smallest first, two tiles at a time
 template <int NT, int NPL>   // (both deduced from the arguments: the call sites sit inside macro arguments, where a template comma would split them)
 __device__ __forceinline__ void mma_pl(f32x16 (&acc)[NT], const u32x4 (&b)[NPL], const u32x4 *__restrict__ ch, int q0, int lane) {
@@ -1621,6 +1628,7 @@ __device__ __forceinline__ void importance_tile(const float4 *__restrict__ vc_ti
 template <int NPL, bool ACTS = false, bool FUSE = false>
 __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs a, const unsigned short *__restrict__ packed_b3) {
     static_assert(!(ACTS && FUSE), "the training pass stores records");
+    constexpr int SPL = !HL_RENDER_SPLIT_RNE ? 0 : ((ACTS || FUSE) ? 2 : 1);   // (the coarse kernel's register allocation spills with the asm form; the planes are the same)
     constexpr int B3R_SLOT_U4 = PLW_SLOT_U4<NPL>, B3_CH_U4 = PLW_CH_U4<NPL>;      // (shadow the bf16x3 constants of k_march_b3)
     constexpr size_t B3_BYTES = PLW_BYTES<NPL>;
     constexpr int NMF = NPL == 3 ? 24 : 12;                                        // MFMAs of a chunk (4 tiles x 6 | 3 products)
@@ -1714,8 +1722,8 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
             }
             ev[s] = val;
         }
-        split_plt(ev, 0, bev0);
-        split_plt(ev, 1, bev1);
+        split_plt<SPL>(ev, 0, bev0);
+        split_plt<SPL>(ev, 1, bev1);
         if constexpr (ACTS) {   // the encoding is a row block of the activation matrix, the same for every sample of the ray: written here for the whole sample range
             const int s_lo_ = (int)blockIdx.y * a.s_per, s_hi_ = min(a.S, s_lo_ + a.s_per);
             const unsigned as4 = (unsigned)a.act_stride * 4u;
@@ -1952,8 +1960,8 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
         }
         constexpr float SPU = LOG2D ? LN2 : 1.f;                    // softplus outputs of this kernel -> natural units
         u32x4 bf0[NPL], bf1[NPL], ba[NPL], bb[NPL];
-        split_plt(f, 0, bf0);
-        split_plt(f, 1, bf1);
+        split_plt<SPL>(f, 0, bf0);
+        split_plt<SPL>(f, 1, bf1);
         // ---- MLP  [renderer.py:134-156]: chunk g = fragment positions 4g .. 4g+3.  Software-pipelined: the operand of chunk g+1 is prepared
         // (softplus of a tile at its first use, three-way split of one half) in the same scheduling region as the MFMAs of chunk g, and the
         // (__builtin_amdgcn_sched_group_barrier patterns over regions of this size do not finish compiling) ----
@@ -1963,36 +1971,36 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
         B3_ADV(1) mma_pl(X, bf1, B3_AT(1), 0, lane);
         load_bias<4>(Y, small + SM_B1, half);
         SP_R(0, 8, X[0], rs0);                                             // (the second half: behind the first chunk of the layer)
-        split_plt(X[0], 0, ba);
+        split_plt<SPL>(X[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L1: chunks 2..9 = (tile k of X, half 0 | 1)
             B3_ADV(2 + 2 * k)
-            B3_MV24(5, mma_pl(Y, ba, B3_AT(2 + 2 * k), 0, lane), { SP_R(8, 16, X[k], rs0); split_plt(X[k], 1, bb); })
+            B3_MV24(5, mma_pl(Y, ba, B3_AT(2 + 2 * k), 0, lane), { SP_R(8, 16, X[k], rs0); split_plt<SPL>(X[k], 1, bb); })
             B3_ADV(3 + 2 * k)
-            B3_MV24(5, mma_pl(Y, bb, B3_AT(3 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3], rs0); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(Y, bb, B3_AT(3 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3], rs0); split_plt<SPL>(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         act_rows(ROW_X0, X, SPU);
         load_bias<4>(X, small + SM_B2, half);
         B3_ADV(10) mma_pl(X, bf0, B3_AT(10), 0, lane);                          // L2 (features): chunks 10, 11; the first hidden operand rides along
         B3_ADV(11)
-        B3_VM({ SP_R(0, 8, Y[0], rs1); split_plt(Y[0], 0, ba); }, mma_pl(X, bf1, B3_AT(11), 0, lane))
+        B3_VM({ SP_R(0, 8, Y[0], rs1); split_plt<SPL>(Y[0], 0, ba); }, mma_pl(X, bf1, B3_AT(11), 0, lane))
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // L2 (hidden): chunks 12..19
             B3_ADV(12 + 2 * k)
-            B3_MV24(5, mma_pl(X, ba, B3_AT(12 + 2 * k), 0, lane), { SP_R(8, 16, Y[k], rs1); split_plt(Y[k], 1, bb); })
+            B3_MV24(5, mma_pl(X, ba, B3_AT(12 + 2 * k), 0, lane), { SP_R(8, 16, Y[k], rs1); split_plt<SPL>(Y[k], 1, bb); })
             B3_ADV(13 + 2 * k)
-            B3_MV24(5, mma_pl(X, bb, B3_AT(13 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, Y[k + 1 < 4 ? k + 1 : 3], rs1); split_plt(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(X, bb, B3_AT(13 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, Y[k + 1 < 4 ? k + 1 : 3], rs1); split_plt<SPL>(Y[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         act_rows(ROW_X1, Y, SPU);
         load_bias<4>(Y, small + SM_BF, half);
         SP_R(0, 8, X[0], rs2);                                             // (the second half: behind the first chunk of the layer)
-        split_plt(X[0], 0, ba);
+        split_plt<SPL>(X[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // feature_linear: chunks 20..27
             B3_ADV(20 + 2 * k)
-            B3_MV24(5, mma_pl(Y, ba, B3_AT(20 + 2 * k), 0, lane), { SP_R(8, 16, X[k], rs2); split_plt(X[k], 1, bb); })
+            B3_MV24(5, mma_pl(Y, ba, B3_AT(20 + 2 * k), 0, lane), { SP_R(8, 16, X[k], rs2); split_plt<SPL>(X[k], 1, bb); })
             B3_ADV(21 + 2 * k)
-            B3_MV24(5, mma_pl(Y, bb, B3_AT(21 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3], rs2); split_plt(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
+            B3_MV24(5, mma_pl(Y, bb, B3_AT(21 + 2 * k), 0, lane), if (k < 3) { SP_R(0, 8, X[k + 1 < 4 ? k + 1 : 3], rs2); split_plt<SPL>(X[k + 1 < 4 ? k + 1 : 3], 0, ba); })
         }
         act_rows(ROW_X2, X, SPU);
         if constexpr (LOG2D) {   // feature_linear has no activation: its accumulators leave the plane scale here, on their way into views_linear's operand
@@ -2020,12 +2028,12 @@ __global__ __launch_bounds__(512, ACTS ? 1 : 2) void k_march_plw(const MarchArgs
                 const f32x4 v4 = vinit[(t * 4 + q) * 64 + lane];
                 V[t][4 * q] = v4[0]; V[t][4 * q + 1] = v4[1]; V[t][4 * q + 2] = v4[2]; V[t][4 * q + 3] = v4[3];
             }
-        split_plt(Y[0], 0, ba);
+        split_plt<SPL>(Y[0], 0, ba);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                               // views_linear (feature part): chunks 28..31, two k-groups each
             B3_ADV(28 + k)
-            B3_VM(split_plt(Y[k], 1, bb), mma_pl(V, ba, B3_AT(28 + k), 0, lane))
-            B3_VM(if (k < 3) split_plt(Y[k + 1 < 4 ? k + 1 : 3], 0, ba), mma_pl(V, bb, B3_AT(28 + k), 2, lane))
+            B3_VM(split_plt<SPL>(Y[k], 1, bb), mma_pl(V, ba, B3_AT(28 + k), 0, lane))
+            B3_VM(if (k < 3) split_plt<SPL>(Y[k + 1 < 4 ? k + 1 : 3], 0, ba), mma_pl(V, bb, B3_AT(28 + k), 2, lane))
         }
         if constexpr (LOG2D) { softplus_l2_r<0, 16>(V[0], rsV); softplus_l2_r<0, 16>(V[1], rsV); }
         else { V[0] = softplus16_b3(V[0]); V[1] = softplus16_b3(V[1]); }
