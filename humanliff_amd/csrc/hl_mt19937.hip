@@ -16,9 +16,10 @@
 // numbers, bound by its own vector instructions; the walk alone takes 14.5 ms (270 ns per block of 624: one LDS round trip and one barrier), and a
 // drop-in render() call of a 512 x 512 view 30.5 ms against 33 before (26.1 - 26.4 with resident uniforms: `render.host_inclusive` 0.80 -> 0.87 of
 // `render.value`).  The launches run on their own stream next to the evaluate passes - the draw for view k + 1 beside the fine pass of view k - and only
-// the importance sampling waits for them (hl_render_rays_u_event).  What is left of the gap: the walk's workgroup (21 registers, 5 KB of LDS) shares a CU
-// with a workgroup of the coarse evaluate kernel (230 registers x 2 waves per SIMD) but not of the one-pass fine kernel (246 x 2): while both run, 1 024 fine
-// workgroups meet 255 CUs.
+// the importance sampling waits for them (hl_render_rays_u_event).  What is left of the gap (kernel trace, `scripts/rocpd_timeline.py`): an evaluate launch
+// that overlaps the walk takes 14.4 instead of 12 ms - its 1 024 workgroups do not share the walk's CU, so four of them run a fifth round - whichever of the
+// two evaluate launches that is (holding the walk back until the caller's queued work has finished moves the cost from the fine to the coarse pass, 31.2 against
+// 30.6 ms; a raised wave priority changes nothing).
 #include "hl_common.h"
 
 namespace {
