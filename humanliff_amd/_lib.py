@@ -132,6 +132,7 @@ SIGNATURES = {
     "hl_mt19937_uniform": (_i, [_p, _i, _p, C.c_int64, _p, _p]),
     "hl_debug_set_h16_min_blocks": (_i, [C.c_long]),
     "hl_debug_set_single_op_scale_source": (_i, [_i]),
+    "hl_debug_set_mt19937_piece": (_i, [C.c_int64]),
 }
 
 

@@ -110,10 +110,13 @@ __global__ __launch_bounds__(256) void k_mt19937_finish(float *__restrict__ out,
 
 }  // namespace
 
+static int64_t g_mt_piece = (int64_t)1 << 28;
+extern "C" int hl_debug_set_mt19937_piece(int64_t words) { g_mt_piece = words > 0 ? words : (int64_t)1 << 28; return HL_OK; }
+
 extern "C" int hl_mt19937_uniform(const uint32_t *state, int pos, float *out, int64_t n, uint32_t *state_out, void *stream) {
     HL_REQUIRE(state && out && state_out && n >= 0 && pos >= 0 && pos <= MT_N, "hl_mt19937_uniform: bad argument");
     // the walk addresses its output through a buffer descriptor (32-bit byte range): requests beyond 2^28 words continue from the state the piece before left
-    const int64_t piece = (int64_t)1 << 28;
+    const int64_t piece = g_mt_piece;
     const uint32_t *st_in = state;
     int64_t done = 0;
     do {

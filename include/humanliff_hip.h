@@ -534,6 +534,9 @@ int hl_debug_set_single_op_scale_source(int from_totals);
  * out; state_out (625 words, device) receives the state and position behind the last number - the host side advances its generator
  * with it (humanliff_amd/NeRF/cpu_rng.py).  One workgroup; enqueue-only. */
 int hl_mt19937_uniform(const uint32_t *state, int pos, float *out, int64_t n, uint32_t *state_out, void *stream);
+/* test switch: the largest number of words one walk launch of hl_mt19937_uniform produces (default 2^28: the walk addresses its output through a 32-bit buffer
+ * range; longer requests continue from the state the piece before left).  words <= 0 restores the default.  The unit tests run the chaining with small pieces. */
+int hl_debug_set_mt19937_piece(int64_t words);
 
 #ifdef __cplusplus
 }

@@ -572,6 +572,18 @@ def test_device_mt19937_continues_the_cpu_generator_bit_for_bit(seed, burn, shap
             pe.finish()
             parts.append(p_)
     assert torch.equal(torch.cat(parts).cpu(), want.reshape(-1))
+    # one request walked in pieces (the walk kernel addresses at most 2^28 words per launch; here 4 099 and 624): the same stream, the same final state
+    from humanliff_amd import _lib
+    for piece in (4099, 624):
+        _lib.check(_lib.lib().hl_debug_set_mt19937_piece(piece))
+        try:
+            torch.set_rng_state(st)
+            got, pend = rand_like_cpu(list(shape), dev)
+            pend.finish()
+            assert torch.equal(got.cpu(), want), piece
+            assert torch.equal(torch.rand(1000), want2) and torch.equal(torch.get_rng_state(), st_after), piece
+        finally:
+            _lib.check(_lib.lib().hl_debug_set_mt19937_piece(0))
 
 
 def test_render_with_u_none_replays_the_reference_call_on_the_device(dev):
