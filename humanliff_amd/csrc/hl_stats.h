@@ -8,7 +8,11 @@
 // normalised in (ConvK::st_cg channels per group, st_c0 = the tensor's first channel inside the view: the two producers of a decoder
 // "concat" add into the SAME 32 groups).  Scales: sum 2^30 (resolution 1e-9; capacity +-8.6e9 per group and image), sum of squares 2^24
 // (resolution 6e-8; capacity 2.7e11).  A contribution that is not finite or beyond the capacity sets bit 62 of the sum-of-squares word:
-// consumers turn that (and an overflowed total) into NaN coefficients.
+// consumers turn that (and an overflowed total) into NaN coefficients.  Limits, stated plainly: the reference's fp32 GroupNorm keeps working where these
+// totals give up - a tensor whose sum x^2 per (image, group, shard) exceeds 2.7e11 (rms ~1e3 at the 256-pixel level with 6 channels per group) normalises to NaN here,
+// loudly.  One hole remains: a total can wrap past 2^64 unnoticed if more than 1.1e12 of sum x^2 arrives in pieces that each stay under the 1e11 cap (eleven or more
+// workgroups at rms ~2e3 and beyond) and the wrapped value happens to land under 2^62; closing it needs a returning atomic per contribution (its latency at the end of
+// every producer workgroup) or a third word, and was not built.
 #pragma once
 #include <hip/hip_runtime.h>
 
