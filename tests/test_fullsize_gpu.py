@@ -334,10 +334,11 @@ def test_production_ddim50_matches_reference(production):
         print(s)
         # DDIM with eta = 0 re-injects nothing, so differences accumulate over the 50 network evaluations; values reach 5.3 mid-loop and
         # [-1, 1] at the end.  Measured on MI355X: max-abs 7.7e-7 / 1.8e-6 / 9.0e-6 / 2.6e-5 / 3.0e-5 after steps 1 / 10 / 25 / 40 / 50
-        # (PSNR 142 ... 118.7 dB), |sum| relative 2e-8 ... 1.6e-7.  Bounds ~10x that.
-        assert s["max_abs"] < 3e-4, s
-        assert s["psnr_db"] > 105.0 and s["abs_sum_rel"] < 2e-6, s
-    assert res["final_row100_max_abs"] < 3e-4 and res["final_channel_mean_max_abs"] < 1e-6
+        # (PSNR 142 ... 118.7 dB), |sum| relative 2e-8 ... 1.6e-7 in round 5 (unscaled fp16x2 planes; 2.6e-5 with every product on the fp32 pipe).  Round 6, scale-invariant
+        # planes: 4.2e-7 / 1.4e-6 / 5.8e-6 / 1.5e-5 / 1.8e-5 (142 ... 122.5 dB).  The bound is VERDICT r05's "done" figure for the default mode, 4e-5 at every step.
+        assert s["max_abs"] < 4e-5, s
+        assert s["psnr_db"] > 115.0 and s["abs_sum_rel"] < 1e-6, s
+    assert res["final_row100_max_abs"] < 4e-5 and res["final_channel_mean_max_abs"] < 5e-7
 
 
 def test_production_shipped_sampler_p250_matches_reference(production):
