@@ -2410,11 +2410,26 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
             vr[e] = *reinterpret_cast<const f32x4 *>(base + (long)min(k0 + key, T - 1) * pitch + 2 * CH + c);
         }
     };
+    // H2 (round 6): the V tile is stored multiplied by a power of two `vs` that puts the largest |v| the wave has seen so far just below 2^15 - the two fp16 planes of a value
+    // are both normal only above 2^-3, and V is whatever the qkv convolution produced (V x 2^-10: rel-L2 1.8e-5 against float64 without this, 3.6e-7 with).  The scale only
+    // ever shrinks; when it does, the accumulated O is multiplied by the ratio together with the softmax's own rescaling factor (a power of two: exact), and O is divided
+    // by it once before the waves' partials are merged.  A tile of zeros, or one with a value that is not finite, leaves the scale alone.
+    float vs = 3.0e38f, vs_ratio = 1.f;     // (3.0e38: no tile seen yet)
     auto storeV = [&](const f32x4(&vr)[NG]) {
+        if constexpr (H2) {
+            float tm = 0.f;
+#pragma unroll
+            for (int e = 0; e < NG; ++e) tm = fmaxf(fmaxf(fmaxf(fabsf(vr[e][0]), fabsf(vr[e][1])), fmaxf(fabsf(vr[e][2]), fabsf(vr[e][3]))), tm);
+            const float wm = __uint_as_float(wave_max_u32(__float_as_uint(tm)));      // (non-negative floats order like their bit patterns; a NaN is the largest)
+            float vt = pow2_scale_for_bound(wm);                                     // 1 for 0 / inf / NaN
+            if (!(wm > 0.f) || !(wm < 3.0e38f)) vt = vs < 3.0e38f ? vs : 1.f;
+            vs_ratio = 1.f;
+            if (vt < vs) { vs_ratio = vs < 3.0e38f ? vt / vs : 1.f; vs = vt; }
+        }
 #pragma unroll
         for (int e = 0; e < NG; ++e) {
             const int idx = e * 64 + lane, key = idx / (CH / 4), c = (idx - key * (CH / 4)) * 4;
-            *reinterpret_cast<f32x4 *>(sV + key * CH + c) = vr[e];
+            *reinterpret_cast<f32x4 *>(sV + key * CH + c) = H2 ? vr[e] * vs : vr[e];
         }
     };
 
@@ -2475,10 +2490,11 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
                 att_split8(f32x4{st[8 * jj], st[8 * jj + 1], st[8 * jj + 2], st[8 * jj + 3]}, f32x4{st[8 * jj + 4], st[8 * jj + 5], st[8 * jj + 6], st[8 * jj + 7]}, 1.f, pp[jj][0], pp[jj][1]);
+            const float alpha_o = alpha * vs_ratio;         // (O carries the V scale: both factors at once)
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[c][r] *= alpha_o;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     f32x4 va, vb;                            // V of this lane's channel at the same eight keys, in the same order
@@ -2517,10 +2533,11 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
 
     // merge the KW partials: O^T of every wave to its LDS region as [channel][33] (+ running max / sum per query)
     __syncthreads();
+    const float vinv = (H2 && vs < 3.0e38f) ? 1.f / vs : 1.f;
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sV[(c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 33 + (lane & 31)] = o[c][r];
+        for (int r = 0; r < 16; ++r) sV[(c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 33 + (lane & 31)] = o[c][r] * vinv;
     if (half == 0) {
         sV[CH * 33 + lane] = mrun;
         sV[CH * 33 + 32 + lane] = lrun;

@@ -273,6 +273,41 @@ def test_attention_matches_torch(N, T, C, heads, h2):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize("N,T,C,heads", [(2, 1024, 384, 4), (1, 256, 768, 4)])
+def test_attention_fp16x2_is_invariant_to_the_scale_of_v(N, T, C, heads):
+    """Round 6 ("the attention's K/V side"): the fp16x2 attention stores its V tiles multiplied by a running power of two (k_attention_ks<., ., ., true>),
+    so the two fp16 planes of V stay normal whatever V's magnitude.  Scaling V by 2^k scales the exact result by 2^k: the kernel's output must follow BIT FOR BIT from
+    2^-14 to 2^10 (without the scale: rel-L2 against float64 3.6e-7 as drawn, 1.8e-5 at 2^-10, 2.8e-4 at 2^-14), and stay at or below the fp32-MFMA kernel's error."""
+    from humanliff_amd import _lib
+    g = torch.Generator().manual_seed(T + C + 1)
+    base = torch.randn((N, 3 * C, T), generator=g)
+    ch = C // heads
+    s = 1.0 / (ch ** 0.25)
+
+    def run(qkv, h2):
+        qd = qkv.permute(0, 2, 1).contiguous().to(dev)
+        out = torch.empty((N, T, C), device=dev)
+        if h2:
+            _lib.check(_lib.lib().hl_attention_nhwc_mode(_lib.HL_CONV_FP32, _lib.ptr(qd), N, T, C, heads, _lib.ptr(out), _lib.stream_ptr()))
+        else:
+            _lib.check(_lib.lib().hl_attention_nhwc(_lib.ptr(qd), N, T, C, heads, _lib.ptr(out), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return out.cpu().permute(0, 2, 1)
+
+    q, k, v = base.double().reshape(N * heads, 3 * ch, T).split(ch, dim=1)
+    want = torch.einsum("bts,bcs->bct", torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s), dim=-1), v).reshape(N, C, T)
+    ref = run(base, True)
+    e2 = float((ref.double() - want).norm() / want.norm())
+    e32 = float((run(base, False).double() - want).norm() / want.norm())
+    print(f"attention T{T} C{C}: rel-L2 against float64 fp16x2 {e2:.2e}, fp32 MFMA {e32:.2e}")
+    assert e2 < 1.3 * e32 + 5e-8
+    for kexp in (-14, -10, -6, 5, 10):
+        scaled = base.clone().reshape(N * heads, 3 * ch, T)
+        scaled[:, 2 * ch:] *= 2.0 ** kexp
+        got = run(scaled.reshape(N, 3 * C, T), True)
+        assert torch.equal(got * 2.0 ** -kexp, ref), kexp
+
+
 def test_timestep_embedding_matches_reference():
     from humanliff_amd.improved_diffusion.nn import timestep_embedding
     g = np.load(os.path.join(GOLDEN, "diffusion_steps.npz"))
