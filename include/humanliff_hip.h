@@ -508,7 +508,8 @@ int hl_groupnorm_coef(const float *x, int N, int H, int W, int C, const float *g
 int hl_attention_nhwc(const float *qkv, int N, int T, int C, int heads, float *out, void *stream);
 /* The attention as hl_unet_forward runs it in `conv_mode`: HL_CONV_FP32 (the default) forms both products (scores, probabilities x values) from fp16x2 operands on
  * v_mfma_f32_32x32x16_f16 where the kernel has that form (head sizes 96 and 192 on short sequences: the UNet's 32-, 16- and 8-pixel levels); every other mode = hl_attention_nhwc
- * (fp32 MFMA). */
+ * (fp32 MFMA).  Round 6: the V tiles are staged under a running power-of-two scale, so the result follows any scaling of V exactly (2^-14 ... 2^10 tested bit for bit); Q and K
+ * are split as they are (their error enters the scores absolutely and the softmax flattens it). */
 int hl_attention_nhwc_mode(int conv_mode, const float *qkv, int N, int T, int C, int heads, float *out, void *stream);
 /* Backward of hl_attention_nhwc (QKVAttention, unet.py:255-274, under train_util.py:200-246): qkv as in the forward, out = the forward's
  * output (N,T,C), dout = its gradient -> dqkv (N,T,3C).  fp32 MFMA, probabilities recomputed (flash-style), every output summed by one wave in
