@@ -2419,7 +2419,10 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
         if constexpr (H2) {
             float tm = 0.f;
 #pragma unroll
-            for (int e = 0; e < NG; ++e) tm = fmaxf(fmaxf(fmaxf(fabsf(vr[e][0]), fabsf(vr[e][1])), fmaxf(fabsf(vr[e][2]), fabsf(vr[e][3]))), tm);
+            for (int e = 0; e < NG; ++e) {      // (two v_max3_f32 with |.| operands per four values)
+                tm = fmaxf(fmaxf(fabsf(vr[e][0]), fabsf(vr[e][1])), tm);
+                tm = fmaxf(fmaxf(fabsf(vr[e][2]), fabsf(vr[e][3])), tm);
+            }
             const float wm = __uint_as_float(wave_max_u32(__float_as_uint(tm)));      // (non-negative floats order like their bit patterns; a NaN is the largest)
             float vt = pow2_scale_for_bound(wm);                                     // 1 for 0 / inf / NaN
             if (!(wm > 0.f) || !(wm < 3.0e38f)) vt = vs < 3.0e38f ? vs : 1.f;
