@@ -174,7 +174,7 @@ def bench_unet(args, rank, world, dev):
         dom_exec = 3.0 * dv[1] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         dom_peak = PEAK_BF16_MFMA_TFLOPS       # (v_mfma_f32_32x32x16_f16 and _bf16 share the dense 16-bit peak)
         dom_note = ("fp16 FLOPs ISSUED (three partial products per fp32 product of the direct convolution) against the dense fp16 matrix peak; the same launches in the "
-                    "path's own unit: `algorithmic` (fp32-equivalent work).  The 2.5 PFLOP/s peak is reached with zero operands only: under the power cap a chain of "
+                    "path's own unit: `algorithmic` (fp32-equivalent work).  The 2.5 PFLOP/s peak is reached with zero operands only: at the same reported 2.4 GHz a chain of "
                     "independent v_mfma_f32_32x32x16_f16 on full-mantissa fp16 operands runs at 1655 TFLOP/s (`peak_full_mantissa`, scripts/microbench/mfma_data_power.hip, "
                     "profiles/r06_unet_regression.md); MFMAs alone take 0.73 of the kernel's time (profiles/r05_unet_fill_experiments.md, sections 6 - 8)")
     dominant = {"kernel": fam, "layers": f"{dk[4]}x{dk[4]} convolutions with {dk[3]} output channels @{256 >> dk[1]}x{256 >> dk[1]}, batch {B}"

@@ -173,7 +173,7 @@ struct H2Pair { unsigned p0, p1; };
 // saturated at 65504 without a trace.  The staging scales its input so that neither a plane overflows nor the low plane goes subnormal wherever the tensor's
 // totals are known (hl_stats.h).  rel-L2 against float64 3.50e-7 / 3.43e-7 / 3.28e-7 (stride-2, K = 864) for H2_SPLIT_RNE = 0 / 1 / 2.  Time: the forward is
 // 1 % (B = 1) to 3 % (B = 4) slower than round 5's on the same box, and none of it is instructions - planes that keep all their mantissa bits make the matrix
-// pipe draw more power, and the chip clocks down under its cap (profiles/r06_unet_regression.md, scripts/microbench/mfma_data_power.hip).
+// pipe issue fewer MFMAs per clock (same reported shader clock; profiles/r06_unet_regression.md, scripts/microbench/mfma_data_power.hip).
 // 0: h0 = the value with its low 13 mantissa bits cleared, both conversions truncating (round 5); 1: the same h0, h1 to nearest.
 #ifndef H2_SPLIT_RNE
 #define H2_SPLIT_RNE 2
