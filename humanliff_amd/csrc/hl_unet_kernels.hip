@@ -2415,7 +2415,7 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
     // ever shrinks; when it does, the accumulated O is multiplied by the ratio together with the softmax's own rescaling factor (a power of two: exact), and O is divided
     // by it once before the waves' partials are merged.  A tile of zeros, or one with a value that is not finite, leaves the scale alone.
     float vs = 3.0e38f, vs_ratio = 1.f;     // (3.0e38: no tile seen yet)
-    auto storeV = [&](const f32x4(&vr)[NG]) {
+    auto storeV = [&](f32x4(&vr)[NG]) {      // (H2: scales vr in place - no second copy of the tile in registers)
         if constexpr (H2) {
             float tm = 0.f;
 #pragma unroll
@@ -2432,7 +2432,8 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
 #pragma unroll
         for (int e = 0; e < NG; ++e) {
             const int idx = e * 64 + lane, key = idx / (CH / 4), c = (idx - key * (CH / 4)) * 4;
-            *reinterpret_cast<f32x4 *>(sV + key * CH + c) = H2 ? vr[e] * vs : vr[e];
+            if constexpr (H2) vr[e] *= vs;
+            *reinterpret_cast<f32x4 *>(sV + key * CH + c) = vr[e];
         }
     };
 
