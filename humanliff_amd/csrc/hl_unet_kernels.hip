@@ -2352,6 +2352,9 @@ __global__ __launch_bounds__(WPB * 64, 1) void k_attention(const float *__restri
 // region, and with PF the next tile's K and V are in flight (registers) while the current one is multiplied.
 // eight values (two f32x4, scaled by `sc`) -> the two fp16 planes of one 32x32x16 operand (round 6: h0 = the nearest fp16, h1 = the nearest fp16 of the residual - split_h2 of
 // hl_conv_h16.hip: 2^-24 while both planes are normal, and a value beyond fp16's range becomes inf / NaN instead of saturating)
+// (round 6, measured: moving K's `scale` factor to Q - so that K goes into the split as loaded, sc = 1.f - produces GARBAGE scores in k_attention_ks<96, 4, true, true>
+//  with this compiler, while sc = 1.00001f is exact to 1e-5 as it should be: the kernel keeps K's tile in accumulator registers between iterations, and the asm statement
+//  fed straight from those copies is miscompiled.  Every use below has a vector instruction between the load / copy and the asm, and the tests pin the results bit for bit.)
 __device__ __forceinline__ void att_split8(const f32x4 a, const f32x4 b, float sc, u32x4 &p0, u32x4 &p1) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
