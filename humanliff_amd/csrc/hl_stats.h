@@ -184,6 +184,17 @@ __device__ __forceinline__ float act_scale_totals(const float *gt, int N, int n,
     return __ballot(bad) ? 1.f : pow2_scale_for_bound(sqrtf(Qt * (float)(1.0 / STAT_SC_SQ)) * 1.0001f + 1e-30f);
 }
 
+// sum over the wave's 64 lanes, the same in every lane's return, in a fixed order (four DPP steps inside each row of 16, then the four rows)
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));    // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // max over the wave's 64 lanes of an unsigned value, the same in every lane's return (four DPP steps leave each row of 16 with its maximum -
 // max is idempotent, so the mirror steps may count a lane twice - then one readlane per row)
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {

@@ -639,9 +639,13 @@ struct Exec {
         conv(a.qkv, x, qkv, 1, 0, af, 0, nullptr, 0);
         want_stats = true;
         View o = plain(H / x.H, a.C);
+        // the attention's output is the RAW input of the projection convolution: the key-split kernels leave its sum x^2 like any other producer (hl_stats.h)
+        float *ost = alloc_stat(hl::conv_stats_floats(B, (long)x.H * x.W));
         if (run) {
             const size_t e0 = span_begin();
-            ok(hl::attention(qkv.p, B, x.H * x.W, a.C, a.heads, o.p, st, n.conv_mode == HL_CONV_FP32));
+            int emitted = 0;
+            ok(hl::attention(qkv.p, B, x.H * x.W, a.C, a.heads, o.p, st, n.conv_mode == HL_CONV_FP32, ost, &emitted));
+            if (emitted) stat_reg[o.p] = {ost, a.C, 0, a.C}; else stat_reg.erase(o.p);
             const double T = (double)x.H * x.W;
             span_end(CAT_ATTN, e0, 4.0 * B * T * T * a.C);
         }

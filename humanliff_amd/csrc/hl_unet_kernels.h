@@ -177,7 +177,9 @@ int linear_small(const float *in, long in_pitch, int B, int K, const float *W, c
 int timestep_embedding(const int64_t *t, const float *t_float, int B, int dim, float *out, hipStream_t st);
 
 // QKV attention (unet.py:255-274): qkv (N, T, 3C) with channel = head*3ch + {q|k|v}*ch + c ; out (N, T, C)
-int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipStream_t st, int h2 = 0);   // h2: fp16x2 products where a kernel has them (the default conv mode's attention)
+// h2: fp16x2 products where a kernel has them (the default conv mode's attention).  out_totals: optional zeroed conv_stats_floats(N, T) floats - the key-split kernels add the
+// sum x^2 of the output they store (the projection convolution's activation scale); *totals_emitted says whether the kernel that ran did
+int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipStream_t st, int h2 = 0, float *out_totals = nullptr, int *totals_emitted = nullptr);
 size_t attention_backward_scratch_bytes(int N, int T, int C, int heads);                       // hl_attention_bwd.hip
 int attention_backward(const float *qkv, const float *out, const float *dout, int N, int T, int C, int heads, float *dqkv, void *scratch,
                        size_t scratch_bytes, hipStream_t st);

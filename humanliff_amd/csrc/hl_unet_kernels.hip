@@ -2375,7 +2375,7 @@ __device__ __forceinline__ f32x16 att_mma(const u32x4 a, const u32x4 b, const f3
 // tile as before (one dword per key and lane).  36 (CH = 96) / 72 (CH = 192) MFMAs of 32 cycles per key tile instead of 96 / 192 of 64.
 template <int CH, int KW, bool PF, bool H2>
 __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__restrict__ qkv, int T, int C, int heads,
-                                                             float *__restrict__ out) {
+                                                             float *__restrict__ out, float *__restrict__ out_tot, int N) {
     constexpr int CT = CH / 32, NG = CH / 8, WLDS = CH * 33 + 64;
     extern __shared__ __attribute__((aligned(16))) float sh[];   // [KW][WLDS]: V tile (32 x CH), later O^T (CH x 33) + m,l
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -2550,6 +2550,7 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
         sV[CH * 33 + 32 + lane] = lrun;
     }
     __syncthreads();
+    float osq = 0.f;
     for (int e = tid; e < 32 * CH; e += KW * 64) {
         const int q = e / CH, c = e - q * CH;
         float ms = -3.0e38f;
@@ -2562,7 +2563,25 @@ __global__ __launch_bounds__(KW * 64, 1) void k_attention_ks(const float *__rest
             num += sh[w * WLDS + c * 33 + q] * f;
             den += sh[w * WLDS + CH * 33 + 32 + q] * f;
         }
-        if (q0 + q < T) out[((long)n * T + q0 + q) * C + head * CH + c] = num / den;
+        if (q0 + q < T) {
+            const float val = num / den;
+            out[((long)n * T + q0 + q) * C + head * CH + c] = val;
+            osq += val * val;
+        }
+    }
+    // sum x^2 of what this workgroup stored, into the fixed-point totals of the output (any "group": act_scale_totals adds all 32) - the projection convolution behind
+    // the attention reads its raw input's power-of-two scale from them (hl_stats.h), as every other raw-input convolution does from its producers' totals
+    if (out_tot) {
+        osq = wave_sum_f32(osq);
+        __syncthreads();
+        if (lane == 0) sh[wave] = osq;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < KW; ++w) t += sh[w];
+            stat_add(out_tot, N, n, (int)(blockIdx.x & 31), (long)T, 0.f, t);
+        }
     }
 }
 
@@ -3433,8 +3452,9 @@ int timestep_embedding(const int64_t *t, const float *tf, int B, int dim, float 
     return check_launch("k_timestep_embedding");
 }
 
-int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipStream_t st, int h2) {
+int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipStream_t st, int h2, float *out_totals, int *totals_emitted) {
     HL_REQUIRE(qkv && out && heads > 0 && C % heads == 0, "attention: bad argument");
+    if (totals_emitted) *totals_emitted = 0;
     static const int att_h2 = [] { const char *e_ = getenv("HL_ATT_H2"); return e_ ? atoi(e_) : 1; }();   // developer knob (read once): 0 = the fp32-MFMA kernels in every mode
     if (!att_h2) h2 = 0;
     const int ch = C / heads;
@@ -3456,15 +3476,16 @@ int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipS
     if ((long)qtiles * N * heads < (h2 ? std::max(ks_max, 1024L) : 1024L) && (ch == 96 || ch == 192) && (3L * C) % 4 == 0) {
         dim3 gks(qtiles, N * heads);
         if (ch == 96 && h2)
-            hipLaunchKernelGGL((k_attention_ks<96, 4, true, true>), gks, dim3(256), (size_t)4 * (96 * 33 + 64) * sizeof(float), st, qkv, T, C, heads, out);
+            hipLaunchKernelGGL((k_attention_ks<96, 4, true, true>), gks, dim3(256), (size_t)4 * (96 * 33 + 64) * sizeof(float), st, qkv, T, C, heads, out, out_totals, N);
         else if (ch == 96)
             hipLaunchKernelGGL((k_attention_ks<96, 4, true, false>), gks, dim3(256), (size_t)4 * (96 * 33 + 64) * sizeof(float), st, qkv, T, C,
-                               heads, out);
+                               heads, out, out_totals, N);
         else if (h2)
-            hipLaunchKernelGGL((k_attention_ks<192, 4, false, true>), gks, dim3(256), (size_t)4 * (192 * 33 + 64) * sizeof(float), st, qkv, T, C, heads, out);
+            hipLaunchKernelGGL((k_attention_ks<192, 4, false, true>), gks, dim3(256), (size_t)4 * (192 * 33 + 64) * sizeof(float), st, qkv, T, C, heads, out, out_totals, N);
         else
             hipLaunchKernelGGL((k_attention_ks<192, 4, false, false>), gks, dim3(256), (size_t)4 * (192 * 33 + 64) * sizeof(float), st, qkv, T,
-                               C, heads, out);
+                               C, heads, out, out_totals, N);
+        if (totals_emitted && out_totals) *totals_emitted = 1;
         return check_launch("k_attention_ks");
     }
     switch (ch) {

@@ -258,6 +258,55 @@ def test_other_image_sizes_dispatch_matches_oracle(image_size, B):
     assert sum(c32["fp16x2"]) == 0 and e32 < 5e-5 * max(1.0, scale), (e32, c32)
 
 
+def test_attention_branch_with_tiny_values_matches_oracle():
+    """Round 6 ("the attention's K/V side"): production widths at 64 x 64 with attention on the 32- and 8-pixel levels (heads of 96 and 192 channels: the
+    fp16x2 key-split kernels), every attention block's V rows of the qkv convolution (weights and bias) x 2^-14 and its proj_out weights x 2^14 - the branch contributes at its
+    usual magnitude, but V and the attention's output are 6e-5 of it.  Unscaled fp16 planes lose the low plane of both there (attention alone: rel-L2 2.8e-4 against float64);
+    with the running V scale inside the attention and the projection convolution's activation scale from the attention's own sum x^2 the usual bound holds."""
+    import bench
+    from humanliff_amd import synthetic as syn
+    from humanliff_amd.improved_diffusion.script_util import create_model_and_diffusion
+    from oracle import unet_oracle as uo
+    cfg = dict(bench.F4, image_size=64, num_res_blocks=1, attention_resolutions="32,8")
+    model, _ = create_model_and_diffusion(**cfg)
+    keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    sd = syn.state_from_shapes(keys, seed=21)
+    heads, n_att, widths = 4, 0, set()
+    for k in list(sd):
+        if k.endswith(".qkv.weight"):
+            p_ = k[:-len(".qkv.weight")]
+            C = sd[k].shape[1]
+            ch = C // heads
+            rows = torch.cat([torch.arange(h * 3 * ch + 2 * ch, h * 3 * ch + 3 * ch) for h in range(heads)])
+            sd[k][rows] *= 2.0 ** -14
+            sd[p_ + ".qkv.bias"][rows] *= 2.0 ** -14
+            sd[p_ + ".proj_out.weight"] *= 2.0 ** 14
+            n_att += 1
+            widths.add(ch)
+    assert n_att >= 4 and widths == {96, 192}, (n_att, widths)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    g = torch.Generator().manual_seed(77)
+    B = 2
+    x = torch.randn((B, 27, 64, 64), generator=g)
+    xc = torch.randn((B, 27, 64, 64), generator=g).clamp(-1, 1) * 0.6
+    t, y = torch.tensor([801, 17]), torch.tensor([1, 3])
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        want = uo.unet_forward(sd, x, t, xc, y, num_heads=heads)
+        got = model(x.to(dev), t.to(dev), xc.to(dev), y=y.to(dev)).cpu()
+        model.set_conv_mode("fp32_mfma")
+        try:
+            alt = model(x.to(dev), t.to(dev), xc.to(dev), y=y.to(dev)).cpu()
+        finally:
+            model.set_conv_mode("fp32")
+    scale = float(want.abs().mean())
+    err, e32 = float((got - want).abs().max()), float((alt - want).abs().max())
+    print(f"tiny attention values: max-abs vs oracle, default {err:.3e}, all-fp32-MFMA {e32:.3e} (output mean-abs {scale:.3f})")
+    assert scale > 0.05 and err < 5e-5 * max(1.0, scale) and e32 < 5e-5 * max(1.0, scale), (err, e32, scale)
+    assert err < 3.0 * e32 + 1e-6, (err, e32)
+
+
 def test_configs1_full_length_loop_is_finite_bounded_and_reproducible(production):
     """BASELINE configs[1] at its real length: 1000-step p_sample_loop of the production net at B = 4 (x_cond = zeros, y = zeros, clip_denoised) - what the bench times for 20
     steps.  No reference trajectory of that length exists (5 - 6 h of CPU), so: every value finite, the final sample inside [-1, 1] (the last step returns the clamped
