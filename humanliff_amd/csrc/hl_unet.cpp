@@ -525,6 +525,11 @@ struct Exec {
         size_t emid = 0;
         if (n.prof) { emid = n.next_event(); a.ev_mid = n.ev_pool[emid]; }
         ok(hl::conv2d(a, st));
+        {   // developer audit (HL_AUDIT_SCALE=1, read once): fp16x2 launches whose raw input came without totals - their activation planes are unscaled (sx = 1)
+            static const int audit_ = [] { const char *e_ = getenv("HL_AUDIT_SCALE"); return e_ ? atoi(e_) : 0; }();
+            if (audit_ && a.path == 6 && af.cA == nullptr && af.gn.gt == nullptr && a.in_stats == nullptr)
+                fprintf(stderr, "[hl audit] fp16x2 convolution with an unscaled raw input: %dx%d px, %d -> %d channels, ks %d, stride %d\n", in.H, in.W, in.C, c.Cout, c.ks, stride);
+        }
         if (n.prof && a.ev_mid_used) span_mid = (long)emid;
         {
             int lvl = 0;
