@@ -731,6 +731,8 @@ struct Exec {
         xin.p = alloc((size_t)xin.pixels() * n.Cpad0);
         View xsum = xin;
         if (c.controlnet) xsum.p = alloc((size_t)xin.pixels() * n.Cpad0);
+        // the inputs' sum x^2 per image (k_prep_inputs): the activation scale of the two 27 -> 192 input convolutions
+        float *xin_tot = alloc_stat(hl::conv_stats_floats(B, (long)H * W)), *xsum_tot = alloc_stat(hl::conv_stats_floats(B, (long)H * W));
         // AdaGN: the condition is projected to one more summand of emb (unet.py:574-578): two stride-2 convs, then a Linear over the
         // 64x64 map (so H = W = 256, as in the reference).  emb = (time_embed + label_emb[y]) + projection.
         View ac, a1, a2;
@@ -763,8 +765,12 @@ struct Exec {
             ok(hl::linear_small(emb, n.E, B, n.E, n.emb_w, n.emb_b, (int)n.emb_total, 1, nullptr, nullptr, emb_all, n.emb_total, st));
             if (c.aware3d) ok(hl::prep_inputs_3d(x, c.controlnet ? x_cond : nullptr, B, c.in_channels, H, W / 3, n.Cpad0, xin.p,
                                                  c.controlnet ? xsum.p : nullptr, st));
-            else ok(hl::prep_inputs(x, c.controlnet ? x_cond : nullptr, B, c.in_channels, H, W, n.Cpad0, xin.p,
-                                    c.controlnet ? xsum.p : nullptr, st));
+            else {
+                ok(hl::prep_inputs(x, c.controlnet ? x_cond : nullptr, B, c.in_channels, H, W, n.Cpad0, xin.p,
+                                   c.controlnet ? xsum.p : nullptr, st, xin_tot, c.controlnet ? xsum_tot : nullptr));
+                stat_reg[xin.p] = {xin_tot, n.Cpad0, 0, n.Cpad0};
+                if (c.controlnet) stat_reg[xsum.p] = {xsum_tot, n.Cpad0, 0, n.Cpad0};
+            }
             span_end(CAT_OTHER, e0, 2.0 * B * ((double)n.E * c.model_channels + (double)n.E * n.E + (double)n.emb_total * n.E));
         }
         // decoder "concat" buffers: [h | skip]; sized from the block structure

@@ -185,8 +185,9 @@ int attention_backward(const float *qkv, const float *out, const float *dout, in
                        size_t scratch_bytes, hipStream_t st);
 
 // (B,C,H,W) x, x_cond -> NHWC padded to Cpad: x_nhwc and (x + x_cond)_nhwc   (unet.py:588,596)
+// x_tot / xsum_tot: optional zeroed conv_stats_floats(B, H * W) floats each - the outputs' sum x^2 per image (the input convolutions' activation scale)
 int prep_inputs(const float *x, const float *x_cond, int B, int C, int H, int W, int Cpad, float *x_nhwc, float *xsum_nhwc,
-                hipStream_t st);
+                hipStream_t st, float *x_tot = nullptr, float *xsum_tot = nullptr);
 
 // cond_type='cross_attention' (spatial_transformer.py): nn.LayerNorm over the channels of every pixel -> y dense (pixels, C); GEGLU on
 // (pixels, 2F) -> (pixels, F); x (N, HW, C) += v (N, C)

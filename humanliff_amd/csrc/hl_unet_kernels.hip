@@ -2619,20 +2619,35 @@ __global__ void k_attention_generic(const float *__restrict__ qkv, int T, int C,
     }
 }
 
-__global__ void k_prep_inputs(const float *__restrict__ x, const float *__restrict__ xc, int B, int C, int HW, int Cpad,
-                              float *__restrict__ xo, float *__restrict__ xs) {
-    const long n = (long)B * HW * Cpad;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % Cpad);
-        const long pix = i / Cpad;
-        const long b = pix / HW, r = pix - b * HW;
+// grid (workgroups per image, B).  xo_tot / xs_tot (optional, zeroed): the sum x^2 of each image of the two outputs as fixed-point totals - the 27 -> 192 input convolutions
+// read their raw input's power-of-two scale from them like every other fp16x2 convolution (hl_stats.h)
+__global__ __launch_bounds__(256) void k_prep_inputs(const float *__restrict__ x, const float *__restrict__ xc, int B, int C, int HW, int Cpad,
+                                                     float *__restrict__ xo, float *__restrict__ xs, float *__restrict__ xo_tot, float *__restrict__ xs_tot) {
+    __shared__ float red[2][4];
+    const long b = blockIdx.y, n_img = (long)HW * Cpad;
+    float q1 = 0.f, q2 = 0.f;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n_img; j += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(j % Cpad);
+        const long r = j / Cpad;
         float v = 0.f, s = 0.f;
         if (c < C) {
             v = x[(b * C + c) * HW + r];
             s = xc ? v + xc[(b * C + c) * HW + r] : v;
         }
-        xo[i] = v;
-        if (xs) xs[i] = s;
+        xo[b * n_img + j] = v;
+        if (xs) xs[b * n_img + j] = s;
+        q1 += v * v;
+        q2 += s * s;
+    }
+    if (xo_tot == nullptr) return;
+    q1 = wave_sum_f32(q1);
+    q2 = wave_sum_f32(q2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = q1; red[1][wave] = q2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        stat_add(xo_tot, B, b, (int)(blockIdx.x & 31), (long)HW, 0.f, ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]);
+        if (xs && xs_tot) stat_add(xs_tot, B, b, (int)(blockIdx.x & 31), (long)HW, 0.f, ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]);
     }
 }
 
@@ -3504,9 +3519,11 @@ int attention(const float *qkv, int N, int T, int C, int heads, float *out, hipS
     return check_launch("k_attention");
 }
 
-int prep_inputs(const float *x, const float *xc, int B, int C, int H, int W, int Cpad, float *xo, float *xs, hipStream_t st) {
-    HL_REQUIRE(x && xo && Cpad >= C, "prep_inputs: bad argument");
-    hipLaunchKernelGGL(k_prep_inputs, dim3(2048), dim3(256), 0, st, x, xc, B, C, H * W, Cpad, xo, xs);
+int prep_inputs(const float *x, const float *xc, int B, int C, int H, int W, int Cpad, float *xo, float *xs, hipStream_t st, float *xo_tot, float *xs_tot) {
+    HL_REQUIRE(x && xo && Cpad >= C && B > 0, "prep_inputs: bad argument");
+    const long per_img = ((long)H * W * Cpad + 255) / 256;
+    const unsigned gx = (unsigned)std::max<long>(1, std::min<long>(per_img, (2048 + B - 1) / B));
+    hipLaunchKernelGGL(k_prep_inputs, dim3(gx, (unsigned)B), dim3(256), 0, st, x, xc, B, C, H * W, Cpad, xo, xs, xo_tot, xs_tot);
     return check_launch("k_prep_inputs");
 }
 
